@@ -1,0 +1,341 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference); the GPU box and the
+test-suite read the committed JSON files, never the reference.
+
+    python tests/golden/gen_golden.py            # rewrites tests/golden/*.json
+
+What is recorded is data only: inputs and the outputs of the reference's
+node2vec/randomwalk.py functions.  The walk
+fixtures (G4/G7) drive the reference's own transformers
+
+    initiate_random_walk -> next_step_random_walk x L -> to_path
+
+with pandas merges standing in for the Fugue joins of node2vec/fugue.py:144-148,
+while `random.random` is patched to replay the build's counter-based uniform
+stream (DESIGN.md "RNG"), so that the reference produces, draw for draw, what the
+exact-mode HIP kernel must produce.
+"""
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import pandas as pd
+
+REF = os.environ.get("N2V_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+import node2vec.randomwalk as ref  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+M64 = (1 << 64) - 1
+
+
+# --- the build's uniform stream, restated in Python ints ----------------------
+def mix64(z):
+    z &= M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return z ^ (z >> 31)
+
+
+def uniform_bits(seed, walk_key, step):
+    h0 = mix64(seed ^ mix64(walk_key + 0x9E3779B97F4A7C15))
+    h = mix64(h0 + (step + 1) * 0xD1B54A32D192ED03)
+    return h >> 32, h & 0xFFFFFFFF
+
+
+class Replay:
+    """Stands in for random.random: pops pre-loaded uniforms."""
+
+    def __init__(self):
+        self.queue = []
+
+    def __call__(self):
+        return self.queue.pop(0)
+
+
+KARATE = {
+    0: [1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 17, 19, 21, 31],
+    1: [2, 3, 7, 13, 17, 19, 21, 30], 2: [3, 7, 8, 9, 13, 27, 28, 32],
+    3: [7, 12, 13], 4: [6, 10], 5: [6, 10, 16], 6: [16], 8: [30, 32, 33],
+    9: [33], 13: [33], 14: [32, 33], 15: [32, 33], 18: [32, 33], 19: [33],
+    20: [32, 33], 22: [32, 33], 23: [25, 27, 29, 32, 33], 24: [25, 27, 31],
+    25: [31], 26: [29, 33], 27: [33], 28: [31, 33], 29: [32, 33],
+    30: [32, 33], 31: [32, 33], 32: [33],
+}
+
+
+def karate_edges():
+    und = [(a, b) for a, bs in KARATE.items() for b in bs]
+    assert len(und) == 78
+    edges = und + [(b, a) for a, b in und]
+    return [(a, b, 1.0) for a, b in sorted(edges)]
+
+
+def f32(x):
+    """weights the product stores as fp32: keep fixtures fp32-representable"""
+    return float(np.float32(x))
+
+
+# --- fugue.py:130-155 emulated with pandas around the reference transformers ---
+def reference_random_walk(edges, num_walks, walk_length, p, q, seed, walk_seed=None):
+    df = pd.DataFrame(edges, columns=["src", "dst", "weight"])
+    # fugue.py:130  partition(by=src, presort=dst).transform(get_vertex_neighbors)
+    adj = {}
+    for src, grp in df.groupby("src", sort=True):
+        grp = grp.sort_values("dst", kind="stable").reset_index(drop=True)
+        row = next(iter(ref.get_vertex_neighbors(grp)))
+        adj[int(row["id"])] = row["neighbors"]
+    # fugue.py:132-134
+    start = sorted(adj)
+    if walk_seed is not None:
+        start = [v for v in start if v in set(walk_seed)]
+    # fugue.py:137-138 (each yielded row is materialised at yield time)
+    walkers = []
+    for row in ref.initiate_random_walk([{"id": v} for v in start], num_walks):
+        walkers.append({"src": row["src"], "dst": row["dst"], "path": list(row["path"]),
+                        "_start": row["dst"], "_ord": -row["src"]})
+    replay = Replay()
+    saved = random.random
+    random.random = replay
+    try:
+        for step in range(walk_length):  # fugue.py:146
+            nxt = []
+            for wk in walkers:
+                # fugue.py:147 left_outer_join(df_src).inner_join(df_dst)
+                if wk["dst"] not in adj:
+                    continue  # inner join drops the walker
+                row = {"src": wk["src"], "path": wk["path"],
+                       "src_neighbors": adj.get(wk["src"]),
+                       "dst_neighbors": adj[wk["dst"]]}
+                key = wk["_start"] * num_walks + (wk["_ord"] - 1)
+                u1, u2 = uniform_bits(seed, key, step)
+                replay.queue = [u1 / 4294967296.0, u2 / 4294967296.0]
+                out = list(ref.next_step_random_walk([row], p, q, None))  # :148
+                assert len(out) == 1 and not replay.queue
+                o = out[0]
+                nxt.append({"src": o["src"], "dst": o["dst"], "path": o["path"],
+                            "_start": wk["_start"], "_ord": wk["_ord"]})
+            walkers = nxt
+    finally:
+        random.random = saved
+    res = []
+    for wk in walkers:  # fugue.py:153 to_path
+        o = next(iter(ref.to_path([{"path": wk["path"]}])))
+        res.append({"start": wk["_start"], "ordinal": wk["_ord"], "src": o["src"],
+                    "walk": [int(x) for x in o["walk"]]})
+    return res
+
+
+def implied_distribution(alias, probs):
+    """probability of each index under sampling_from_alias with exact uniforms"""
+    n = len(alias)
+    out = [0.0] * n
+    for i in range(n):
+        pi = min(max(probs[i], 0.0), 1.0)
+        out[i] += pi / n
+        out[alias[i]] += (1.0 - pi) / n
+    return out
+
+
+def main():
+    rng = np.random.RandomState(12345)
+
+    # ---- G1: generate_alias_tables ------------------------------------------
+    g1 = []
+    cases = [
+        [0.5, 0.8, 1.0], [0.5, 0.2], [0.2], [1.0],      # tests/test_randomwalk.py:135-138
+        [0.1] * 10, [1.0] * 7, [1.0] * 64, [2.0] * 65, [0.25] * 33,
+        [1.0, 0.5, 0.5, 2.0, 1.0, 0.5], [4.0, 0.25, 0.25, 0.25, 1.0],
+        [3.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0],
+    ]
+    for n in (1, 2, 3, 7, 63, 64, 65, 130, 1000, 5000):
+        cases.append([f32(x) for x in rng.uniform(0.01, 3.0, size=n)])
+    for n in (5, 64, 257):  # few distinct values, like p/q-biased unit weights
+        cases.append([float(x) for x in rng.choice([0.5, 1.0, 2.0], size=n)])
+        cases.append([float(x) for x in rng.choice([0.25, 1.0, 4.0], size=n, p=[.7, .2, .1])])
+    cases.append([f32(x) for x in rng.pareto(1.2, size=300) + 0.01])
+    for w in cases:
+        alias, probs = ref.generate_alias_tables(list(w))
+        g1.append({"weights": w, "alias": alias, "probs": probs})
+
+    # ---- G2: generate_edge_alias_tables --------------------------------------
+    g2 = []
+    refcases = [  # tests/test_randomwalk.py:158-160
+        (0, [2], ([0, 2], [0.5, 0.2]), 1.0, 1.0),
+        (1, [], ([1], [0.2]), 0.8, 1.5),
+        (3, [], ([1, 3], [0.5, 1.0]), 2.0, 4.0),
+    ]
+    for s, shared, nbs, p, q in refcases:
+        alias, probs = ref.generate_edge_alias_tables(s, set(shared), nbs, p, q)
+        g2.append({"src_id": s, "src_nbs": shared, "dst_ids": nbs[0], "dst_w": nbs[1],
+                   "p": p, "q": q, "alias": alias, "probs": probs})
+    kedges = karate_edges()
+    kadj = {}
+    for a, b, w in kedges:
+        kadj.setdefault(a, []).append(b)
+    wadj = {v: [f32(x) for x in rng.uniform(0.1, 2.0, size=len(nb))] for v, nb in kadj.items()}
+    pairs = [(a, b) for a, b, _ in kedges]
+    sel = [pairs[i] for i in rng.choice(len(pairs), size=24, replace=False)]
+    for (s, v) in sel:
+        for p, q in ((1.0, 1.0), (0.5, 2.0), (4.0, 0.25), (3.0, 0.7)):
+            for weights in ([1.0] * len(kadj[v]), wadj[v]):
+                nbs = (kadj[v], weights)
+                alias, probs = ref.generate_edge_alias_tables(s, set(kadj[s]), nbs, p, q)
+                g2.append({"src_id": s, "src_nbs": kadj[s], "dst_ids": nbs[0],
+                           "dst_w": nbs[1], "p": p, "q": q, "alias": alias,
+                           "probs": probs, "implied": implied_distribution(alias, probs)})
+    g2_errors = []
+    for s, shared, nbs, p, q in refcases:  # tests/test_randomwalk.py:184-189
+        for args, what in (((s, set(shared), nbs, 0), "p0"),
+                           ((s, set(shared), nbs, 1.0, 0), "q0"),
+                           ((s, set(shared), (nbs[0], nbs[1][:-1])), "ragged")):
+            try:
+                ref.generate_edge_alias_tables(*args)
+                raised = None
+            except Exception as e:  # noqa: BLE001
+                raised = type(e).__name__
+            g2_errors.append({"src_id": s, "src_nbs": shared, "dst_ids": args[2][0],
+                              "dst_w": args[2][1],
+                              "p": args[3] if len(args) > 3 else 1.0,
+                              "q": args[4] if len(args) > 4 else 1.0,
+                              "case": what, "raises": raised})
+
+    # ---- G3: samplers --------------------------------------------------------
+    g3 = []
+    tables = [([1, 0], [0.6666666666666666, 1.0]), ([0, 0], [1.0, 0.5714285714285715])]
+    w = [f32(x) for x in rng.uniform(0.05, 2.0, size=37)]
+    tables.append(ref.generate_alias_tables(w))
+    grid = [0.0, 0.25, 0.5, 0.75, 1 / 3, 0.9999999997671694, 2 ** -32, 1 - 2 ** -32,
+            0.9056396761745207, 0.6862541570267026]
+    grid += [int(x) / 4294967296.0 for x in rng.randint(0, 2 ** 32, size=12, dtype=np.uint64)]
+    for alias, probs in tables:
+        ap = ref.AliasProb((list(alias), list(probs)))
+        rows = []
+        for r1 in grid:
+            rows.append({"r1": r1, "wiki": ap.sampling_from_alias_wiki(r1)})
+            for r2 in grid:
+                rows.append({"r1": r1, "r2": r2, "two": ap.sampling_from_alias(r1, r2)})
+        g3.append({"alias": list(alias), "probs": list(probs), "draws": rows})
+    # seed-20 known answers, tests/test_randomwalk.py:65-72, 83-90
+    random.seed(20)
+    r1, r2 = random.random(), random.random()
+    kat = {"seed": 20, "r1": r1, "r2": r2, "cases": []}
+    for (alias, probs), ids, want in ((tables[0], [11, 22], 22), (tables[1], [122, 221], 122)):
+        ap = ref.AliasProb((alias, probs))
+        a, b = ids[ap.sampling_from_alias_wiki(r1)], ids[ap.sampling_from_alias(r1, r2)]
+        assert a == want and b == want
+        kat["cases"].append({"alias": alias, "probs": probs, "ids": ids, "wiki": a, "two": b})
+
+    # RandomPath.append incl. first-step rule, tests/test_randomwalk.py:94-128
+    g3_path = []
+    for path, dst_nbs, alias, probs in (([-1, 0], [1, 3], [1, 0], [0.6666666666666666, 1.0]),
+                                        ([2, 1], [0, 2], [0, 0], [1.0, 0.5714285714285715]),
+                                        ([0, 3], [0], [0], [1.0]),
+                                        ([-3, 7], [5, 6, 9], [2, 0, 1], [0.6521739130434783, 1.0, 0.9565217391304348])):
+        for r1 in (r1, 0.1, 0.55):
+            for r2 in (None, 0.3, 0.99):
+                out = ref.RandomPath(list(path)).append(dst_nbs, ref.AliasProb((alias, probs)), r1, r2).path
+                g3_path.append({"path": path, "dst_nbs": dst_nbs, "alias": alias,
+                                "probs": probs, "r1": r1, "r2": r2, "result": out})
+
+    # ---- G5: next_step_random_walk under MT seeds, tests/test_randomwalk.py:268-306
+    g5 = []
+    rows = [
+        {"src": 0, "path": [3, 0, 1], "dst_nbs": ([0, 2, 4], [0.5, 0.9, 1.0]), "src_nbs": ([2], [1.0]), "seed": 1000},
+        {"src": 0, "path": [2, 0, 2], "dst_nbs": ([0, 3], [1.2, 0.9]), "src_nbs": None, "seed": 10},
+        {"src": -1, "path": [-1, 2], "dst_nbs": ([0, 3], [1.2, 0.9]), "src_nbs": None, "seed": 20},
+    ]
+    for r in rows:
+        random.seed(r["seed"])
+        u = (random.random(), random.random())
+        row = {"src": r["src"], "path": list(r["path"]),
+               "dst_neighbors": ref.Neighbors(r["dst_nbs"]).serialize(),
+               "src_neighbors": None if r["src_nbs"] is None else ref.Neighbors(r["src_nbs"]).serialize()}
+        out = next(iter(ref.next_step_random_walk([row], 1.0, 1.0, r["seed"])))
+        g5.append({"src": r["src"], "path": r["path"], "dst_ids": r["dst_nbs"][0],
+                   "dst_w": r["dst_nbs"][1],
+                   "src_nbs": [] if r["src_nbs"] is None else r["src_nbs"][0],
+                   "p": 1.0, "q": 1.0, "mt_seed": r["seed"], "r1": u[0], "r2": u[1],
+                   "out_src": out["src"], "out_dst": out["dst"], "out_path": out["path"]})
+    assert [g["out_dst"] for g in g5] == [4, 3, 3]
+
+    # initiate_random_walk / to_path, tests/test_randomwalk.py:245-264, 310-324
+    init_rows = [dict(r, path=list(r["path"])) for r in ref.initiate_random_walk([{"id": 3}, {"id": 2}], 3)]
+    to_path_rows = [dict(r) for r in ref.to_path([{"path": [1, 0, 2]}, {"path": [1, 3]}, {"path": [0, 2, 4]}])]
+
+    # ---- G4 / G7: whole walks through the reference --------------------------
+    g4 = []
+    sink = [(0, 1, 1.0), (1, 2, 1.0), (3, 0, 1.0)]
+    g4.append({"name": "sink3", "edges": sink, "num_walks": 1, "walk_length": 2,
+               "p": 1.0, "q": 1.0, "seed": 42, "walk_seed": None,
+               "walks": reference_random_walk(sink, 1, 2, 1.0, 1.0, 42)})
+    assert sorted(w["walk"] for w in g4[0]["walks"]) == [[0, 1, 2], [3, 0, 1]]
+    sink2 = [(0, 1, 1.0), (1, 2, 0.5), (1, 0, 2.0), (3, 0, 1.0), (2, 4, 1.0), (0, 3, 1.0)]
+    g4.append({"name": "sink_mixed", "edges": sink2, "num_walks": 4, "walk_length": 6,
+               "p": 0.5, "q": 2.0, "seed": 7, "walk_seed": None,
+               "walks": reference_random_walk(sink2, 4, 6, 0.5, 2.0, 7)})
+    for p, q, seed, nw, wl in ((1.0, 1.0, 42, 10, 10), (0.5, 2.0, 42, 3, 20),
+                               (4.0, 0.25, 1, 2, 15), (3.0, 0.7, 99, 2, 12)):
+        g4.append({"name": f"karate_p{p}_q{q}", "edges": kedges, "num_walks": nw,
+                   "walk_length": wl, "p": p, "q": q, "seed": seed, "walk_seed": None,
+                   "walks": reference_random_walk(kedges, nw, wl, p, q, seed)})
+    wk_edges = [(a, b, wadj[a][kadj[a].index(b)]) for a, b, _ in kedges]
+    g4.append({"name": "karate_weighted", "edges": wk_edges, "num_walks": 3, "walk_length": 16,
+               "p": 0.5, "q": 2.0, "seed": 5, "walk_seed": [0, 5, 33, 16],
+               "walks": reference_random_walk(wk_edges, 3, 16, 0.5, 2.0, 5, walk_seed=[0, 5, 33, 16])})
+    # random directed multigraph with sinks, weights, multi-edges and a hub > 64
+    medges = []
+    nv = 120
+    for _ in range(900):
+        a, b = int(rng.randint(0, nv)), int(rng.randint(0, nv))
+        if a % 11 == 0:
+            continue  # sinks
+        medges.append((a, b, f32(rng.uniform(0.2, 3.0))))
+    medges += [(7, int(b), f32(rng.uniform(0.2, 3.0))) for b in rng.randint(0, nv, size=150)]
+    medges += [(int(a), 7, 1.0) for a in range(1, nv, 3) if a % 11]
+    medges = sorted(medges, key=lambda e: (e[0], e[1]))
+    g4.append({"name": "multigraph", "edges": medges, "num_walks": 2, "walk_length": 12,
+               "p": 0.5, "q": 2.0, "seed": 2024, "walk_seed": None,
+               "walks": reference_random_walk(medges, 2, 12, 0.5, 2.0, 2024)})
+    # unit-weight graph with hubs far above one wave: exercises multi-chunk rows
+    hedges = set()
+    for hub in (0, 1, 2):
+        for b in rng.choice(np.arange(3, 600), size=400, replace=False):
+            hedges.add((hub, int(b)))
+            hedges.add((int(b), hub))
+    for _ in range(1500):
+        a, b = int(rng.randint(3, 600)), int(rng.randint(3, 600))
+        if a != b:
+            hedges.add((a, b))
+            hedges.add((b, a))
+    hedges = [(a, b, 1.0) for a, b in sorted(hedges)]
+    for p, q, seed in ((0.5, 2.0, 11), (4.0, 0.25, 12)):
+        g4.append({"name": f"hubs_p{p}_q{q}", "edges": hedges, "num_walks": 1, "walk_length": 10,
+                   "p": p, "q": q, "seed": seed, "walk_seed": list(range(0, 600, 7)),
+                   "walks": reference_random_walk(hedges, 1, 10, p, q, seed,
+                                                  walk_seed=list(range(0, 600, 7)))})
+
+    # uniform stream itself
+    rng_kat = [{"seed": s, "key": k, "step": t, "u": list(uniform_bits(s, k, t))}
+               for s in (0, 42, 2 ** 63 + 5) for k in (0, 1, 339, 10 ** 9 + 7, 2 ** 40) for t in (0, 1, 79)]
+
+    def dump(name, obj):
+        with open(os.path.join(HERE, name), "w") as f:
+            json.dump(obj, f)
+        print(name, os.path.getsize(os.path.join(HERE, name)) // 1024, "KiB")
+
+    dump("g1_alias_tables.json", g1)
+    dump("g2_edge_alias_tables.json", {"cases": g2, "errors": g2_errors})
+    dump("g3_samplers.json", {"tables": g3, "seed20": kat, "path_append": g3_path})
+    dump("g5_next_step.json", {"next_step": g5, "initiate": init_rows, "to_path": to_path_rows})
+    dump("g4_walks.json", g4)
+    dump("rng_kat.json", rng_kat)
+    dump("karate_edges.json", kedges)
+
+
+if __name__ == "__main__":
+    main()
