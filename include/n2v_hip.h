@@ -1,0 +1,136 @@
+/*
+ * n2v_hip.h -- C ABI of libn2v_hip.so, the MI355X (gfx950) node2vec hot path.
+ *
+ * The reference (graph-embedding/node2vec, node2vec-fugue 0.3.5) is pure Python
+ * and has no FFI of its own; the hot path sits behind Python interfaces
+ * (SURVEY.md 8b).  This header is the boundary a maintainer of the reference
+ * binds to replace that path (ctypes stub: INTEGRATION.md).  Each entry point
+ * cites the reference code it replaces, file:line relative to the reference.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (hipMalloc'd / torch CUDA storage) unless
+ *    its name ends in _host; the caller owns all buffers;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls
+ *    only enqueue work, they never synchronise and never allocate;
+ *  - return value: N2V_OK or a negative N2V_E* code for argument / launch
+ *    errors detected on the host; data-dependent errors (the reference's
+ *    ZeroDivisionError) are OR-ed into the device word `status` as N2V_ST_*
+ *    bits, to be read by the caller after it synchronises;
+ *  - no global state: re-entrant, any number of streams / devices.
+ */
+#ifndef N2V_HIP_H
+#define N2V_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define N2V_ABI_VERSION 1
+
+#define N2V_OK 0
+#define N2V_EINVAL (-1)  /* maps to ValueError (randomwalk.py:212-217)      */
+#define N2V_ELAUNCH (-2) /* HIP launch / runtime error -> RuntimeError      */
+#define N2V_ENOGPU (-3)
+
+/* bits of the device status word */
+#define N2V_ST_ZERODIV 1u /* sum(weights) == 0: ZeroDivisionError, randomwalk.py:172-173 */
+#define N2V_ST_RANGE 2u   /* a start id outside [0, n_vertices)                          */
+
+/* walk sampler modes */
+#define N2V_WALK_EXACT 0 /* per-step biased alias rebuild, bit-identical to the reference */
+#define N2V_WALK_FAST 1  /* precomputed first-order tables + rejection (same distribution) */
+
+/* The reference's adjacency DataFrame df_adj (fugue.py:130, randomwalk.py:266-275)
+ * as CSR in HBM: one row per vertex id, neighbours sorted by dst ascending,
+ * multi-edges kept.  `alias` / `prob` are the per-row first-order Walker tables
+ * written by n2v_alias_build (needed by N2V_WALK_FAST only, else may be NULL). */
+typedef struct n2v_graph {
+  int64_t n_vertices;
+  int64_t n_edges;
+  const int64_t *rowptr; /* [n_vertices + 1] */
+  const int32_t *col;    /* [n_edges] */
+  const float *w;        /* [n_edges] fp32 storage, widened to fp64 for arithmetic */
+  const int32_t *alias;  /* [n_edges] index within the row */
+  const double *prob;    /* [n_edges] */
+} n2v_graph;
+
+int n2v_abi_version(void);
+const char *n2v_status_string(int code);
+
+/* Number of GPUs visible to the library (no GPU initialisation side effects
+ * beyond hipGetDeviceCount). */
+int n2v_device_count(void);
+
+/* K1 -- first-order alias tables for every row, exactly
+ * generate_alias_tables(weights of the row) (randomwalk.py:157-190): same LIFO
+ * pairing order, fp64 arithmetic, leftovers keep alias 0.  Rows of degree 0 are
+ * skipped.  alias_out / prob_out are CSR-aligned ([n_edges]). */
+int n2v_alias_build(const int64_t *rowptr, const float *w, int64_t n_rows,
+                    int32_t *alias_out, double *prob_out, uint32_t *status,
+                    void *stream);
+
+/* K2 -- the whole of fugue.random_walk's loop (fugue.py:137-153) on device:
+ * initiate_random_walk (randomwalk.py:279-296), walk_length x
+ * next_step_random_walk (randomwalk.py:300-339) and to_path (:343-349).
+ *
+ *   start_ids   [n_start]   candidate start vertices (walk_start, fugue.py:132-134)
+ *   walks_out   [n_start * num_walks, walk_length + 1] int32, row r = start
+ *               r / num_walks, ordinal r % num_walks + 1 (randomwalk.py:294)
+ *   valid_out   [n_start * num_walks] 1 where the reference emits a row; 0 for
+ *               a start vertex without out-edges (fugue.py:132) and for walkers
+ *               that reach a vertex without out-edges before the last step
+ *               (inner join, fugue.py:147)
+ *   key_base    added to the walker's row index when it is NOT derived from the
+ *               vertex id (unused: keys are start_id * num_walks + ordinal - 1)
+ *
+ * The two uniforms of randomwalk.py:336-337 come from the counter-based stream
+ * of DESIGN.md "RNG", keyed by (seed, start vertex, ordinal, step): results do
+ * not depend on launch geometry or on how start_ids are sharded over GPUs.
+ * mode N2V_WALK_EXACT reproduces generate_edge_alias_tables + sampling_from_alias
+ * bit for bit; N2V_WALK_FAST draws from the same distribution by rejection. */
+int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
+             int32_t num_walks, int32_t walk_length, double return_param,
+             double inout_param, uint64_t seed, int32_t mode,
+             int32_t *walks_out, uint8_t *valid_out, uint32_t *status,
+             void *stream);
+
+/* a9 -- trim_hotspot_vertices (randomwalk.py:238-262): rows with more than
+ * max_out_degree edges keep a uniform sample without replacement of exactly
+ * max_out_degree of them (max_out_degree <= 0 means 100000, constants.py:6).
+ * keep_out[e] = 1 for surviving edges; weights are untouched. */
+int n2v_trim_mark(const int64_t *rowptr, int64_t n_rows, int64_t max_out_degree,
+                  uint64_t seed, uint8_t *keep_out, void *stream);
+
+/* K3 -- one pass of skip-gram negative-sampling SGD over a block of walks; the
+ * arithmetic behind gensim.models.Word2Vec(sg=1, hs=0, negative=k) at the call
+ * site embedding.py:126 (algorithm: DESIGN.md "SGNS").
+ *
+ *   walks      [n_walks, walk_len] int32 vocabulary indices (< 0 = skip token)
+ *   syn0       [n_vocab, dim] fp32 input vectors, updated in place
+ *   syn1neg    [n_vocab, dim] fp32 output vectors, updated in place
+ *   cum_table  [n_vocab] uint32 cumulative count^0.75 table scaled to 2^31 - 1
+ *   alpha      learning rate of this pass (the host applies the linear decay)
+ *   pairs_out  device counter (+= positive pairs trained), may be NULL
+ *   deterministic != 0: one wave, sentences in order (parity mode) */
+typedef struct n2v_sgns_params {
+  int64_t n_vocab;
+  int32_t dim;
+  int32_t window;
+  int32_t negative;
+  float alpha;
+  uint64_t seed;
+  int32_t deterministic;
+  int32_t reserved;
+} n2v_sgns_params;
+
+int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t walk_len,
+                   float *syn0, float *syn1neg, const uint32_t *cum_table,
+                   const n2v_sgns_params *params_host,
+                   unsigned long long *pairs_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,98 @@
+"""ctypes binding of node2vec_amd/libn2v_hip.so (the C ABI of include/n2v_hip.h).
+
+There is deliberately no fallback: a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libn2v_hip.so")
+
+OK, EINVAL, ELAUNCH, ENOGPU = 0, -1, -2, -3
+ST_ZERODIV, ST_RANGE = 1, 2
+WALK_EXACT, WALK_FAST = 0, 1
+
+# every symbol include/n2v_hip.h declares
+SYMBOLS = ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alias_build",
+           "n2v_walk", "n2v_trim_mark", "n2v_sgns_train")
+
+
+class Graph(C.Structure):
+    """struct n2v_graph"""
+    _fields_ = [("n_vertices", C.c_int64), ("n_edges", C.c_int64),
+                ("rowptr", C.c_void_p), ("col", C.c_void_p), ("w", C.c_void_p),
+                ("alias", C.c_void_p), ("prob", C.c_void_p)]
+
+
+class SgnsParams(C.Structure):
+    """struct n2v_sgns_params"""
+    _fields_ = [("n_vocab", C.c_int64), ("dim", C.c_int32), ("window", C.c_int32),
+                ("negative", C.c_int32), ("alpha", C.c_float), ("seed", C.c_uint64),
+                ("deterministic", C.c_int32), ("reserved", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    """Load libn2v_hip.so; raises if it has not been built (python __graft_entry__.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C node2vec_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "node2vec_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.n2v_abi_version.restype = C.c_int
+    L.n2v_status_string.restype = C.c_char_p
+    L.n2v_status_string.argtypes = [C.c_int]
+    L.n2v_device_count.restype = C.c_int
+    L.n2v_alias_build.restype = C.c_int
+    L.n2v_alias_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]
+    L.n2v_walk.restype = C.c_int
+    L.n2v_walk.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                           C.c_double, C.c_double, C.c_uint64, C.c_int32, C.c_void_p,
+                           C.c_void_p, C.c_void_p, C.c_void_p]
+    L.n2v_trim_mark.restype = C.c_int
+    L.n2v_trim_mark.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p,
+                                C.c_void_p]
+    L.n2v_sgns_train.restype = C.c_int
+    L.n2v_sgns_train.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.POINTER(SgnsParams), C.c_void_p, C.c_void_p]
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    """Map C status codes to the exceptions the reference raises."""
+    if rc == OK:
+        return
+    msg = f"{what}: {load().n2v_status_string(rc).decode()}"
+    if rc == EINVAL:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def check_status_word(word, what):
+    if word & ST_ZERODIV:
+        # generate_alias_tables: sum(weights) / n == 0 -> x / 0.0 (randomwalk.py:172-173)
+        raise ZeroDivisionError(f"{what}: float division by zero (all neighbour weights are 0)")
+    if word & ST_RANGE:
+        raise ValueError(f"{what}: vertex id outside [0, n_vertices)")
+
+
+def require_gpu():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("node2vec_amd needs a HIP device (MI355X); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def current_stream_ptr():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,51 @@
+// n2v_capi.hip -- argument checking and dispatch for the C ABI of include/n2v_hip.h.
+#include "n2v_common.h"
+
+extern "C" {
+int n2v_walk_exact_launch(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
+                          int32_t num_walks, int32_t walk_length, double p, double q,
+                          uint64_t seed, int32_t *walks_out, uint8_t *valid_out,
+                          uint32_t *status, void *stream);
+int n2v_walk_fast_launch(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
+                         int32_t num_walks, int32_t walk_length, double p, double q,
+                         uint64_t seed, int32_t *walks_out, uint8_t *valid_out,
+                         uint32_t *status, void *stream);
+
+int n2v_abi_version(void) { return N2V_ABI_VERSION; }
+
+const char *n2v_status_string(int code) {
+  switch (code) {
+    case N2V_OK: return "ok";
+    case N2V_EINVAL: return "invalid argument";
+    case N2V_ELAUNCH: return "HIP launch/runtime error";
+    case N2V_ENOGPU: return "no HIP device";
+    default: return "unknown status";
+  }
+}
+
+int n2v_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start, int32_t num_walks,
+             int32_t walk_length, double return_param, double inout_param, uint64_t seed,
+             int32_t mode, int32_t *walks_out, uint8_t *valid_out, uint32_t *status,
+             void *stream) {
+  if (!g || !g->rowptr || !g->col || !g->w || n_start < 0 || num_walks < 0 || walk_length < 0)
+    return N2V_EINVAL;
+  if (n_start > 0 && (!start_ids || !walks_out || !valid_out || !status)) return N2V_EINVAL;
+  // generate_edge_alias_tables raises ValueError on p == 0 or q == 0 (randomwalk.py:214-217)
+  if (return_param == 0.0 || inout_param == 0.0) return N2V_EINVAL;
+  if (mode == N2V_WALK_EXACT)
+    return n2v_walk_exact_launch(g, start_ids, n_start, num_walks, walk_length, return_param,
+                                 inout_param, seed, walks_out, valid_out, status, stream);
+  if (mode == N2V_WALK_FAST) {
+    if (!g->alias || !g->prob) return N2V_EINVAL;
+    return n2v_walk_fast_launch(g, start_ids, n_start, num_walks, walk_length, return_param,
+                                inout_param, seed, walks_out, valid_out, status, stream);
+  }
+  return N2V_EINVAL;
+}
+}

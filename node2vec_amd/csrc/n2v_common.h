@@ -1,0 +1,69 @@
+// n2v_common.h -- shared device helpers for the gfx950 node2vec kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/n2v_hip.h"
+
+#define N2V_WAVE 64
+
+#define N2V_HIP_CHECK(expr)                         \
+  do {                                              \
+    hipError_t _e = (expr);                         \
+    if (_e != hipSuccess) return N2V_ELAUNCH;       \
+  } while (0)
+
+namespace n2v {
+
+// splitmix64 finaliser; the uniform stream of DESIGN.md "RNG".
+__host__ __device__ inline uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+__host__ __device__ inline uint64_t walker_stream(uint64_t seed, uint64_t walk_key) {
+  return mix64(seed ^ mix64(walk_key + 0x9E3779B97F4A7C15ULL));
+}
+
+// the two 32-bit uniforms of step `step` (randomwalk.py:336-337 replacement)
+__host__ __device__ inline uint64_t step_bits(uint64_t h0, uint32_t step) {
+  return mix64(h0 + ((uint64_t)step + 1ULL) * 0xD1B54A32D192ED03ULL);
+}
+
+// extra uniforms for rejection trials (fast mode only)
+__host__ __device__ inline uint64_t trial_bits(uint64_t hstep, uint32_t trial) {
+  return mix64(hstep ^ (((uint64_t)trial + 1ULL) * 0x8CB92BA72F3D8DD7ULL));
+}
+
+__device__ inline int lane_id() { return __lane_id(); }
+
+__device__ inline double readlane_f64(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ inline double readfirstlane_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readfirstlane(lo);
+  hi = __builtin_amdgcn_readfirstlane(hi);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ inline int64_t readfirstlane_i64(int64_t v) {
+  int lo = (int)(uint32_t)v, hi = (int)(uint32_t)((uint64_t)v >> 32);
+  lo = __builtin_amdgcn_readfirstlane(lo);
+  hi = __builtin_amdgcn_readfirstlane(hi);
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+__device__ inline uint64_t ballot64(bool p) { return __ballot(p); }
+
+__device__ inline int64_t wave_sum_i64(int64_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+}  // namespace n2v

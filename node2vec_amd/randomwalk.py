@@ -1,0 +1,73 @@
+"""Device walk sampler: host-side mirror of the reference's node2vec/randomwalk.py.
+
+The reference's per-partition transformers (initiate_random_walk :279-296,
+next_step_random_walk :300-339, to_path :343-349) and the loop that drives them
+(fugue.py:137-153) run as ONE kernel launch here (n2v_walk, include/n2v_hip.h);
+this module only marshals tensors.  Semantics kept: W walks per start vertex,
+start set = vertices with out-edges, walkers that hit a sink vanish, every
+emitted walk has walk_length + 1 vertices and starts at its source.
+"""
+import os
+from typing import Optional, Tuple
+
+import torch
+
+from node2vec_amd import _lib
+from node2vec_amd.graph import DeviceGraph
+
+MODES = {"exact": _lib.WALK_EXACT, "fast": _lib.WALK_FAST}
+
+
+def fresh_seed() -> int:
+    """random_seed=None in the reference means an unseeded `random` (randomwalk.py:314)."""
+    return int.from_bytes(os.urandom(8), "little")
+
+
+def start_vertices(graph: DeviceGraph, walk_seed_ids=None) -> torch.Tensor:
+    """fugue.py:132-134: ids of df_adj (vertices with >= 1 out-edge), inner-joined
+    with walk_seed.id when given.  Sorted ascending, int32, on the graph's device."""
+    has_out = graph.degrees() > 0
+    if walk_seed_ids is not None:
+        ids = torch.as_tensor(walk_seed_ids).to(device=graph.device, dtype=torch.int64).reshape(-1)
+        ids = torch.unique(ids)
+        ids = ids[(ids >= 0) & (ids < graph.n_vertices)]
+        ids = ids[has_out[ids]]
+    else:
+        ids = torch.nonzero(has_out).reshape(-1)
+    return ids.to(torch.int32)
+
+
+def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_length: int,
+         return_param: float, inout_param: float, seed: int, mode: str = "exact",
+         out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, check: bool = True):
+    """Launch K2.  Returns (walks int32 [n_start*num_walks, walk_length+1], valid bool)."""
+    L = _lib.load()
+    _lib.require_gpu()
+    if mode not in MODES:
+        raise ValueError(f"unknown walk mode {mode!r}")
+    if not graph.rowptr.is_cuda:
+        raise RuntimeError("walk: graph is not on the GPU")
+    if return_param == 0 or inout_param == 0:
+        # generate_edge_alias_tables, randomwalk.py:214-217
+        raise ValueError(f"Zero return ({return_param}) or inout ({inout_param}) parameter!")
+    if mode == "fast" and graph.alias is None:
+        graph.build_alias()
+    start_ids = start_ids.to(device=graph.device, dtype=torch.int32).contiguous()
+    n_start = start_ids.numel()
+    total = n_start * num_walks
+    if out is None:
+        walks = torch.empty((total, walk_length + 1), dtype=torch.int32, device=graph.device)
+        valid = torch.empty(total, dtype=torch.uint8, device=graph.device)
+    else:
+        walks, valid = out
+    status = torch.zeros(1, dtype=torch.int32, device=graph.device)
+    g = graph.c_struct()
+    with torch.cuda.device(graph.device):
+        rc = L.n2v_walk(g, start_ids.data_ptr(), n_start, num_walks, walk_length,
+                        float(return_param), float(inout_param), seed & (2 ** 64 - 1),
+                        MODES[mode], walks.data_ptr(), valid.data_ptr(), status.data_ptr(),
+                        _lib.current_stream_ptr())
+    _lib.check(rc, "n2v_walk")
+    if check:
+        _lib.check_status_word(int(status.item()), "n2v_walk")
+    return walks, valid.bool() if out is None else valid
