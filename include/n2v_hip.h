@@ -82,8 +82,6 @@ int n2v_alias_build(const int64_t *rowptr, const float *w, int64_t n_rows,
  *               a start vertex without out-edges (fugue.py:132) and for walkers
  *               that reach a vertex without out-edges before the last step
  *               (inner join, fugue.py:147)
- *   key_base    added to the walker's row index when it is NOT derived from the
- *               vertex id (unused: keys are start_id * num_walks + ordinal - 1)
  *
  * The two uniforms of randomwalk.py:336-337 come from the counter-based stream
  * of DESIGN.md "RNG", keyed by (seed, start vertex, ordinal, step): results do
@@ -103,30 +101,43 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
 int n2v_trim_mark(const int64_t *rowptr, int64_t n_rows, int64_t max_out_degree,
                   uint64_t seed, uint8_t *keep_out, void *stream);
 
-/* K3 -- one pass of skip-gram negative-sampling SGD over a block of walks; the
- * arithmetic behind gensim.models.Word2Vec(sg=1, hs=0, negative=k) at the call
- * site embedding.py:126 (algorithm: DESIGN.md "SGNS").
+/* K3 -- one pass of skip-gram negative-sampling SGD over a block of walks: the
+ * arithmetic behind gensim.models.Word2Vec(sentences, sg=1, hs=0, negative=k) at
+ * the reference's call site embedding.py:126 (algorithm: DESIGN.md "SGNS"; the
+ * trainer itself is third-party gensim 3.8, absent from the reference tree).
  *
- *   walks      [n_walks, walk_len] int32 vocabulary indices (< 0 = skip token)
- *   syn0       [n_vocab, dim] fp32 input vectors, updated in place
- *   syn1neg    [n_vocab, dim] fp32 output vectors, updated in place
- *   cum_table  [n_vocab] uint32 cumulative count^0.75 table scaled to 2^31 - 1
- *   alpha      learning rate of this pass (the host applies the linear decay)
- *   pairs_out  device counter (+= positive pairs trained), may be NULL
- *   deterministic != 0: one wave, sentences in order (parity mode) */
+ *   walks       [n_walks, walk_len] int32 vocabulary indices, < 0 = token outside
+ *               the vocabulary (dropped before windowing, as gensim does)
+ *   syn0        [n_vocab, dim] fp32 input vectors  (model.wv.vectors), in place
+ *   syn1neg     [n_vocab, dim] fp32 output vectors (model.trainables.syn1neg)
+ *   cum_table   [n_vocab] uint32 cumulative count^0.75, scaled to 2^31 - 1
+ *   sample_int  [n_vocab] uint32 keep-thresholds of frequent-word subsampling,
+ *               or NULL when `sample` == 0
+ *   exp_table   [1000] fp32 sigmoid table over [-6, 6) (word2vec EXP_TABLE)
+ *   pairs_out   device counter, += number of (centre, context) pairs trained
+ *
+ * One wave trains one walk (sentence); walks are spread over the grid hogwild
+ * (unsynchronised updates, as gensim's worker threads).  deterministic != 0 runs
+ * every walk in order on a single wave: bit-identical to oracle/n2v_oracle_sgns.c.
+ * All randomness is counter-based on (seed, sentence_base + row, draw index), so
+ * results do not depend on launch geometry in deterministic mode. */
 typedef struct n2v_sgns_params {
   int64_t n_vocab;
-  int32_t dim;
-  int32_t window;
-  int32_t negative;
-  float alpha;
+  int64_t sentence_base; /* global index of walks[0] (RNG key, multi-GPU shards) */
   uint64_t seed;
+  int32_t dim;      /* 1 .. 1024 */
+  int32_t window;   /* 1 .. 32  (the reference allows 5 .. 30, embedding.py:110) */
+  int32_t negative; /* 1 .. 32 */
+  float alpha;      /* learning rate of this pass (host applies the linear decay) */
   int32_t deterministic;
   int32_t reserved;
 } n2v_sgns_params;
 
+#define N2V_SGNS_MAX_SENTENCE 256 /* longer walks: split rows on the host */
+
 int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t walk_len,
                    float *syn0, float *syn1neg, const uint32_t *cum_table,
+                   const uint32_t *sample_int, const float *exp_table,
                    const n2v_sgns_params *params_host,
                    unsigned long long *pairs_out, void *stream);
 

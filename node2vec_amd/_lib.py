@@ -26,9 +26,9 @@ class Graph(C.Structure):
 
 class SgnsParams(C.Structure):
     """struct n2v_sgns_params"""
-    _fields_ = [("n_vocab", C.c_int64), ("dim", C.c_int32), ("window", C.c_int32),
-                ("negative", C.c_int32), ("alpha", C.c_float), ("seed", C.c_uint64),
-                ("deterministic", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("n_vocab", C.c_int64), ("sentence_base", C.c_int64), ("seed", C.c_uint64),
+                ("dim", C.c_int32), ("window", C.c_int32), ("negative", C.c_int32),
+                ("alpha", C.c_float), ("deterministic", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib = None
@@ -61,7 +61,8 @@ def load():
                                 C.c_void_p]
     L.n2v_sgns_train.restype = C.c_int
     L.n2v_sgns_train.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
-                                 C.c_void_p, C.POINTER(SgnsParams), C.c_void_p, C.c_void_p]
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SgnsParams),
+                                 C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

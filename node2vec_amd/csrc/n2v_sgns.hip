@@ -1,7 +1,261 @@
-// n2v_sgns.hip -- K3 SGNS. Placeholder.
+// n2v_sgns.hip -- K3, skip-gram negative-sampling SGD for gfx950.
+//
+// Replaces the trainer behind the reference's call site embedding.py:126
+// (gensim.models.Word2Vec(sentences=all_walks, sg=1, hs=0, negative=k)); the
+// algorithm is the published word2vec / gensim-3.8 train_batch_sg +
+// fast_sentence_sg_neg, restated in oracle/n2v_oracle_sgns.c (DESIGN.md "SGNS").
+//
+// Design: one wave64 trains one walk.  A vector of `dim` floats lives across the
+// wave (lane l owns elements l*VEC .. l*VEC+VEC-1, 16-B loads where dim = 64*VEC);
+// dot products are per-lane FMA chains closed by an xor-butterfly over DPP/LDS
+// shuffles; the arithmetic intensity is 0.66 flop/B, so the kernel is a stream of
+// row gathers/scatters against HBM -- plain FMA, no MFMA.  Sentence preparation
+// (vocabulary filter, subsampling, reduced windows) and the negative draws
+// (bisect over the cumulative count^0.75 table) are lane-parallel: every random
+// number is a pure function of (seed, sentence id, draw index).  Waves update
+// syn0/syn1neg unsynchronised (hogwild), like gensim's worker threads.
 #include "n2v_common.h"
-extern "C" int n2v_sgns_train(const int32_t *, int64_t, int32_t, float *, float *,
-                              const uint32_t *, const n2v_sgns_params *, unsigned long long *,
-                              void *) {
-  return N2V_EINVAL;
+
+namespace n2v {
+
+constexpr int kSgnsWaves = 4;      // waves per block
+constexpr int kExpTable = 1000;    // EXP_TABLE_SIZE
+constexpr int kMaxSent = N2V_SGNS_MAX_SENTENCE;
+
+__host__ __device__ inline uint64_t sentence_stream(uint64_t seed, uint64_t sentence_id) {
+  return mix64(seed ^ mix64(sentence_id + 0xA0761D6478BD642FULL));
+}
+__host__ __device__ inline uint64_t sgns_draw(uint64_t hs, uint64_t idx) {
+  return mix64(hs + (idx + 1ULL) * 0xE7037ED1A0B428DBULL);
+}
+
+template <int VEC>
+struct Row {
+  float v[VEC];
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_row(const float *base, int dim, int lane, bool full,
+                                         Row<VEC> &r) {
+  if (full) {
+    if constexpr (VEC == 1) {
+      r.v[0] = base[lane];
+    } else if constexpr (VEC == 2) {
+      float2 t = *reinterpret_cast<const float2 *>(base + lane * 2);
+      r.v[0] = t.x;
+      r.v[1] = t.y;
+    } else {
+#pragma unroll
+      for (int q = 0; q < VEC / 4; ++q) {
+        float4 t = *reinterpret_cast<const float4 *>(base + lane * VEC + q * 4);
+        r.v[4 * q + 0] = t.x;
+        r.v[4 * q + 1] = t.y;
+        r.v[4 * q + 2] = t.z;
+        r.v[4 * q + 3] = t.w;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      int e = lane * VEC + v;
+      r.v[v] = e < dim ? base[e] : 0.0f;
+    }
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_row(float *base, int dim, int lane, bool full,
+                                          const Row<VEC> &r) {
+  if (full) {
+    if constexpr (VEC == 1) {
+      base[lane] = r.v[0];
+    } else if constexpr (VEC == 2) {
+      *reinterpret_cast<float2 *>(base + lane * 2) = make_float2(r.v[0], r.v[1]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < VEC / 4; ++q)
+        *reinterpret_cast<float4 *>(base + lane * VEC + q * 4) =
+            make_float4(r.v[4 * q], r.v[4 * q + 1], r.v[4 * q + 2], r.v[4 * q + 3]);
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      int e = lane * VEC + v;
+      if (e < dim) base[e] = r.v[v];
+    }
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ float wave_dot(const Row<VEC> &a, const Row<VEC> &b) {
+  float acc = 0.0f;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc = __fmaf_rn(a.v[v], b.v[v], acc);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc = acc + __shfl_xor(acc, off, 64);
+  return acc;
+}
+
+__device__ __forceinline__ int bisect_left_u32(const uint32_t *a, int64_t n, uint32_t x,
+                                               int iters) {
+  int64_t lo = 0, hi = n;
+  for (int it = 0; it < iters; ++it) {
+    int64_t mid = (lo + hi) >> 1;
+    uint32_t val = a[mid < n ? mid : n - 1];
+    bool act = lo < hi;
+    bool less = val < x;
+    lo = (act && less) ? mid + 1 : lo;
+    hi = (act && !less) ? mid : hi;
+  }
+  return (int)lo;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kSgnsWaves * 64) void sgns_kernel(
+    const int32_t *__restrict__ walks, int64_t n_walks, int32_t walk_len, float *syn0,
+    float *syn1neg, const uint32_t *__restrict__ cum_table,
+    const uint32_t *__restrict__ sample_int, const float *__restrict__ exp_table_g,
+    n2v_sgns_params P, unsigned long long *pairs_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *exp_lds = reinterpret_cast<float *>(smem);
+  const int negcap = (2 * P.window + 1) * P.negative;  // the window incl. the centre slot
+  const int per_wave = 2 * kMaxSent + negcap;  // int32 words
+  const int wave_in_block = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  int32_t *sent = reinterpret_cast<int32_t *>(smem + kExpTable * sizeof(float)) +
+                  wave_in_block * per_wave;
+  int32_t *red = sent + kMaxSent;
+  int32_t *neg = red + kMaxSent;
+  for (int i = threadIdx.x; i < kExpTable; i += blockDim.x) exp_lds[i] = exp_table_g[i];
+  __syncthreads();
+
+  const int dim = P.dim, window = P.window, K = P.negative;
+  const bool full = dim == 64 * VEC;
+  const float alpha = P.alpha;
+  const uint32_t domain = cum_table[P.n_vocab - 1];
+  const int bis_iters = 64 - __clzll((long long)P.n_vocab);
+  const int waves_per_block = blockDim.x >> 6;
+  const int64_t n_waves = (int64_t)gridDim.x * waves_per_block;
+  unsigned long long pairs = 0;
+
+  for (int64_t rr = (int64_t)blockIdx.x * waves_per_block + wave_in_block; rr < n_walks;
+       rr += n_waves) {
+    const int64_t r = readfirstlane_i64(rr);
+    const uint64_t hs = sentence_stream(P.seed, (uint64_t)(P.sentence_base + r));
+    // ---- sentence preparation (lane-parallel, order-preserving compaction) ----
+    int nf = 0;
+    for (int base = 0; base < walk_len; base += 64) {
+      const int t = base + lane;
+      int32_t tok = t < walk_len ? walks[r * walk_len + t] : -1;
+      bool keep = tok >= 0 && (int64_t)tok < P.n_vocab;
+      if (keep && sample_int) {
+        uint32_t rnd = (uint32_t)(sgns_draw(hs, 2ULL * (uint64_t)t) >> 32);
+        keep = !(sample_int[tok] < rnd);
+      }
+      const uint64_t mask = ballot64(keep);
+      const int pos = nf + __popcll(mask & ((1ull << lane) - 1ull));
+      if (keep) {
+        sent[pos] = tok;
+        red[pos] = (int32_t)((uint32_t)(sgns_draw(hs, 2ULL * (uint64_t)t + 1ULL) >> 32) %
+                             (uint32_t)window);
+      }
+      nf += __popcll(mask);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    for (int i = 0; i < nf; ++i) {
+      const int32_t centre = sent[i];
+      const int b = red[i];
+      const int lo = max(0, i - window + b);
+      const int hi = min(nf, i + window + 1 - b);
+      // ---- negative draws for every pair of this position, lane-parallel ----
+      const int nslots = (hi - lo) * K;
+      for (int q = lane; q < nslots; q += 64) {
+        const int jj = q / K, d = q - jj * K;
+        const int j = lo + jj;
+        const int rel = j - i + window - (j > i ? 1 : 0);
+        const uint64_t idx = 2ULL * (uint64_t)walk_len +
+                             ((uint64_t)i * 2ULL * (uint64_t)window + (uint64_t)rel) *
+                                 (uint64_t)K + (uint64_t)d;
+        const uint32_t x = (uint32_t)((sgns_draw(hs, idx) >> 16) % (uint64_t)domain);
+        neg[q] = (j == i) ? centre : bisect_left_u32(cum_table, P.n_vocab, x, bis_iters);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+
+      for (int j = lo; j < hi; ++j) {
+        if (j == i) continue;
+        float *p1 = syn0 + (int64_t)sent[j] * dim;
+        Row<VEC> row1, work;
+        load_row<VEC>(p1, dim, lane, full, row1);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) work.v[v] = 0.0f;
+        for (int d = 0; d <= K; ++d) {
+          const int32_t target = d == 0 ? centre : neg[(j - lo) * K + d - 1];
+          if (d > 0 && target == centre) continue;
+          float *p2 = syn1neg + (int64_t)target * dim;
+          Row<VEC> row2;
+          load_row<VEC>(p2, dim, lane, full, row2);
+          const float f = wave_dot<VEC>(row1, row2);
+          if (f <= -6.0f || f >= 6.0f) continue;
+          const float s = exp_lds[(int)((f + 6.0f) * 83.0f)];
+          const float g = ((d == 0 ? 1.0f : 0.0f) - s) * alpha;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            work.v[v] = __fmaf_rn(g, row2.v[v], work.v[v]);
+            row2.v[v] = __fmaf_rn(g, row1.v[v], row2.v[v]);
+          }
+          store_row<VEC>(p2, dim, lane, full, row2);
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) row1.v[v] = row1.v[v] + work.v[v];
+        store_row<VEC>(p1, dim, lane, full, row1);
+        ++pairs;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (pairs_out && lane == 0 && pairs) atomicAdd(pairs_out, pairs);
+}
+
+}  // namespace n2v
+
+extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t walk_len,
+                              float *syn0, float *syn1neg, const uint32_t *cum_table,
+                              const uint32_t *sample_int, const float *exp_table,
+                              const n2v_sgns_params *P, unsigned long long *pairs_out,
+                              void *stream) {
+  if (!P || !walks || !syn0 || !syn1neg || !cum_table || !exp_table) return N2V_EINVAL;
+  if (n_walks < 0 || walk_len < 1 || walk_len > N2V_SGNS_MAX_SENTENCE) return N2V_EINVAL;
+  if (P->n_vocab < 1 || P->dim < 1 || P->dim > 1024 || P->window < 1 || P->window > 32 ||
+      P->negative < 1 || P->negative > 32)
+    return N2V_EINVAL;
+  if (n_walks == 0) return N2V_OK;
+  using namespace n2v;
+  const size_t lds = kExpTable * sizeof(float) +
+                     (size_t)kSgnsWaves * (2 * kMaxSent + (2 * P->window + 1) * P->negative) * 4;
+  int64_t blocks = (n_walks + kSgnsWaves - 1) / kSgnsWaves;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  dim3 block(kSgnsWaves * 64);
+  if (P->deterministic) {
+    blocks = 1;
+    block = dim3(64);
+  }
+  int V = 1;
+  while (64 * V < P->dim) V *= 2;
+  hipStream_t st = (hipStream_t)stream;
+#define N2V_LAUNCH(VV)                                                                       \
+  hipLaunchKernelGGL(sgns_kernel<VV>, dim3((unsigned)blocks), block, lds, st, walks, n_walks, \
+                     walk_len, syn0, syn1neg, cum_table, sample_int, exp_table, *P, pairs_out)
+  switch (V) {
+    case 1: N2V_LAUNCH(1); break;
+    case 2: N2V_LAUNCH(2); break;
+    case 4: N2V_LAUNCH(4); break;
+    case 8: N2V_LAUNCH(8); break;
+    default: N2V_LAUNCH(16); break;
+  }
+#undef N2V_LAUNCH
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
 }

@@ -38,6 +38,7 @@ def lib():
         L.n2v_oracle_path_append.restype = C.c_int
         L.n2v_oracle_random_walk.restype = C.c_int
         L.n2v_oracle_transition_probs.restype = C.c_int
+        L.n2v_oracle_sgns_train.restype = C.c_int64
         _LIB = L
     return _LIB
 
@@ -156,3 +157,23 @@ def transition_probs(rowptr, col, w, s, v, p, q):
     _raise(lib().n2v_oracle_transition_probs(C.byref(g), C.c_int64(s), C.c_int64(v),
                                              C.c_double(p), C.c_double(q), _p(out)))
     return out[:n]
+
+
+def sgns_train(walks_idx, syn0, syn1neg, cum_table, sample_int, exp_table, n_vocab,
+               sentence_base, seed, dim, window, negative, alpha):
+    """oracle/n2v_oracle_sgns.c: trains in place (syn0, syn1neg float32 C-contiguous),
+    rows in order on one thread.  Returns the number of pairs trained."""
+    walks_idx = np.ascontiguousarray(walks_idx, np.int32)
+    assert syn0.dtype == np.float32 and syn0.flags.c_contiguous
+    assert syn1neg.dtype == np.float32 and syn1neg.flags.c_contiguous
+    cum = np.ascontiguousarray(cum_table).view(np.uint32)
+    si = None if sample_int is None else np.ascontiguousarray(sample_int).view(np.uint32)
+    et = np.ascontiguousarray(exp_table, np.float32)
+    n = lib().n2v_oracle_sgns_train(
+        _p(walks_idx), C.c_int64(walks_idx.shape[0]), C.c_int32(walks_idx.shape[1]),
+        _p(syn0), _p(syn1neg), _p(cum), None if si is None else _p(si), _p(et),
+        C.c_int64(n_vocab), C.c_int64(sentence_base), C.c_uint64(seed), C.c_int32(dim),
+        C.c_int32(window), C.c_int32(negative), C.c_float(alpha))
+    if n < 0:
+        raise ValueError("oracle sgns: invalid argument")
+    return int(n)
