@@ -42,18 +42,26 @@ extern "C" {
 #define N2V_WALK_EXACT 0 /* per-step biased alias rebuild, bit-identical to the reference */
 #define N2V_WALK_FAST 1  /* precomputed first-order tables + rejection (same distribution) */
 
+/* One entry of a first-order Walker alias table, packed so that a draw is ONE
+ * 16-byte access: the neighbour id, the alias index (within the row) and the
+ * pseudo-probability of generate_alias_tables (randomwalk.py:157-190). */
+typedef struct n2v_slot {
+  int32_t col;
+  int32_t alias;
+  double prob;
+} n2v_slot;
+
 /* The reference's adjacency DataFrame df_adj (fugue.py:130, randomwalk.py:266-275)
  * as CSR in HBM: one row per vertex id, neighbours sorted by dst ascending,
- * multi-edges kept.  `alias` / `prob` are the per-row first-order Walker tables
- * written by n2v_alias_build (needed by N2V_WALK_FAST only, else may be NULL). */
+ * multi-edges kept.  `slots` holds the per-row first-order alias tables written by
+ * n2v_alias_build, CSR-aligned (needed by N2V_WALK_FAST only, else may be NULL). */
 typedef struct n2v_graph {
   int64_t n_vertices;
   int64_t n_edges;
   const int64_t *rowptr; /* [n_vertices + 1] */
   const int32_t *col;    /* [n_edges] */
   const float *w;        /* [n_edges] fp32 storage, widened to fp64 for arithmetic */
-  const int32_t *alias;  /* [n_edges] index within the row */
-  const double *prob;    /* [n_edges] */
+  const n2v_slot *slots; /* [n_edges] */
 } n2v_graph;
 
 int n2v_abi_version(void);
@@ -66,9 +74,10 @@ int n2v_device_count(void);
 /* K1 -- first-order alias tables for every row, exactly
  * generate_alias_tables(weights of the row) (randomwalk.py:157-190): same LIFO
  * pairing order, fp64 arithmetic, leftovers keep alias 0.  Rows of degree 0 are
- * skipped.  alias_out / prob_out are CSR-aligned ([n_edges]). */
-int n2v_alias_build(const int64_t *rowptr, const float *w, int64_t n_rows,
-                    int32_t *alias_out, double *prob_out, uint32_t *status,
+ * skipped; a row whose weights sum to 0 sets N2V_ST_ZERODIV.  slots_out is
+ * CSR-aligned ([n_edges]) and also receives a copy of col. */
+int n2v_alias_build(const int64_t *rowptr, const int32_t *col, const float *w,
+                    int64_t n_rows, n2v_slot *slots_out, uint32_t *status,
                     void *stream);
 
 /* K2 -- the whole of fugue.random_walk's loop (fugue.py:137-153) on device:

@@ -21,7 +21,7 @@ class Graph(C.Structure):
     """struct n2v_graph"""
     _fields_ = [("n_vertices", C.c_int64), ("n_edges", C.c_int64),
                 ("rowptr", C.c_void_p), ("col", C.c_void_p), ("w", C.c_void_p),
-                ("alias", C.c_void_p), ("prob", C.c_void_p)]
+                ("slots", C.c_void_p)]
 
 
 class SgnsParams(C.Structure):
@@ -50,7 +50,7 @@ def load():
     L.n2v_status_string.argtypes = [C.c_int]
     L.n2v_device_count.restype = C.c_int
     L.n2v_alias_build.restype = C.c_int
-    L.n2v_alias_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+    L.n2v_alias_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_void_p, C.c_void_p]
     L.n2v_walk.restype = C.c_int
     L.n2v_walk.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_int64, C.c_int32, C.c_int32,

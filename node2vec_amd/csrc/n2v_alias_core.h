@@ -1,0 +1,99 @@
+// n2v_alias_core.h -- device code shared by K1 (n2v_alias.hip) and K2 exact
+// (n2v_walk.hip): the p/q bias of one 64-neighbour chunk (randomwalk.py:219-231)
+// and the exact row sum of generate_alias_tables (randomwalk.py:172).
+#pragma once
+#include "n2v_common.h"
+
+namespace n2v {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kLdsChunks = 256;  // class ballots kept in LDS for rows <= 16384
+
+struct StepCtx {
+  const int32_t *vcol;  // N(v) ids
+  const float *vw;      // N(v) weights
+  const int32_t *scol;  // N(s) ids
+  int n, nch, m, iters;
+  int32_t s;
+  bool need_cls, need_mem;
+  double p, q;
+};
+
+__device__ __forceinline__ bool member_sorted(const int32_t *a, int m, int32_t x, int iters) {
+  int lo = 0, hi = m;
+  for (int it = 0; it < iters; ++it) {
+    int mid = (lo + hi) >> 1;
+    int32_t val = a[mid < m ? mid : m - 1];
+    bool act = lo < hi;
+    bool less = val < x;
+    lo = (act && less) ? mid + 1 : lo;
+    hi = (act && !less) ? mid : hi;
+  }
+  return a[lo < m ? lo : m - 1] == x && lo < m;
+}
+
+// biased weight of element chunk*64+lane (randomwalk.py:219-231); 0 past the row
+template <bool kFromCache>
+__device__ __forceinline__ double chunk_bias(const StepCtx &c, int chunk, int lane,
+                                             uint64_t *cls, bool &valid) {
+  const int i = chunk * 64 + lane;
+  valid = i < c.n;
+  double wt = valid ? (double)c.vw[i] : 0.0;
+  if (!c.need_cls) return wt;
+  bool is_ret, is_mem;
+  if (kFromCache && chunk < kLdsChunks) {
+    is_ret = (cls[2 * chunk] >> lane) & 1ull;
+    is_mem = (cls[2 * chunk + 1] >> lane) & 1ull;
+  } else {
+    int32_t x = valid ? c.vcol[i] : -1;
+    is_ret = valid && x == c.s;
+    is_mem = false;
+    if (c.need_mem) is_mem = member_sorted(c.scol, c.m, x, c.iters) && valid && !is_ret;
+    if (!kFromCache && chunk < kLdsChunks) {
+      uint64_t rm = ballot64(is_ret), mm = ballot64(is_mem);
+      if (lane == 0) {
+        cls[2 * chunk] = rm;
+        cls[2 * chunk + 1] = mm;
+      }
+    }
+  }
+  if (is_ret) return wt / c.p;                  // :223-224
+  if (is_mem || !c.need_mem) return wt;         // :226-227 (and q == 1: w / 1.0 == w)
+  return wt / c.q;                              // :229-230
+}
+
+
+// avg-independent part of generate_alias_tables: sum of the biased weights in the
+// reference's order.  When every b is a multiple of 2^-20 below 2^11 all partial
+// sums are exactly representable, so the wave reduces in int64 (any order gives
+// the same bits); otherwise: serial left-to-right fp64 adds.  Also returns the
+// biased weight of element `pick` (pass pick < 0 to skip).
+__device__ __forceinline__ double row_sum(const StepCtx &c, int lane, uint64_t *cls, int pick,
+                                          double &b_pick) {
+  int64_t isum = 0;
+  bool exact = true;
+  b_pick = 0.0;
+  for (int chunk = 0; chunk < c.nch; ++chunk) {
+    bool valid;
+    double b = chunk_bias<false>(c, chunk, lane, cls, valid);
+    double t = b * 1048576.0;
+    bool ok = (t >= 0.0) && (t < 2147483648.0) && (t == trunc(t));
+    exact = exact && ok;
+    isum += ok ? (int64_t)t : 0;
+    if (chunk == (pick >> 6)) b_pick = readlane_f64(b, pick & 63);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (ballot64(!exact) == 0ull && c.n <= (1 << 21))
+    return (double)wave_sum_i64(isum) * (1.0 / 1048576.0);
+  double total = 0.0;  // reference order: left to right, one rounding per add
+  for (int chunk = 0; chunk < c.nch; ++chunk) {
+    bool valid;
+    double b = chunk_bias<true>(c, chunk, lane, cls, valid);
+    int cnt = min(64, c.n - chunk * 64);
+    for (int j = 0; j < cnt; ++j) total = total + readlane_f64(b, j);
+  }
+  return total;
+}
+
+}  // namespace n2v

@@ -42,7 +42,7 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start, int3
     return n2v_walk_exact_launch(g, start_ids, n_start, num_walks, walk_length, return_param,
                                  inout_param, seed, walks_out, valid_out, status, stream);
   if (mode == N2V_WALK_FAST) {
-    if (!g->alias || !g->prob) return N2V_EINVAL;
+    if (!g->slots) return N2V_EINVAL;
     return n2v_walk_fast_launch(g, start_ids, n_start, num_walks, walk_length, return_param,
                                 inout_param, seed, walks_out, valid_out, status, stream);
   }

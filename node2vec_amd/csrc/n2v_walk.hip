@@ -23,65 +23,9 @@
 //           (underfull / overfull candidates, 64 per refill, consumed through
 //           ballots + v_readlane), with the same fp64 operations in the same
 //           order, and stops as soon as slot `pick` has been paired.
-#include "n2v_common.h"
+#include "n2v_alias_core.h"
 
 namespace n2v {
-
-constexpr int kWavesPerBlock = 4;
-constexpr int kLdsChunks = 256;  // class ballots kept in LDS for rows <= 16384
-
-struct StepCtx {
-  const int32_t *vcol;  // N(v) ids
-  const float *vw;      // N(v) weights
-  const int32_t *scol;  // N(s) ids
-  int n, nch, m, iters;
-  int32_t s;
-  bool need_cls, need_mem;
-  double p, q;
-};
-
-__device__ __forceinline__ bool member_sorted(const int32_t *a, int m, int32_t x, int iters) {
-  int lo = 0, hi = m;
-  for (int it = 0; it < iters; ++it) {
-    int mid = (lo + hi) >> 1;
-    int32_t val = a[mid < m ? mid : m - 1];
-    bool act = lo < hi;
-    bool less = val < x;
-    lo = (act && less) ? mid + 1 : lo;
-    hi = (act && !less) ? mid : hi;
-  }
-  return a[lo < m ? lo : m - 1] == x && lo < m;
-}
-
-// biased weight of element chunk*64+lane (randomwalk.py:219-231); 0 past the row
-template <bool kFromCache>
-__device__ __forceinline__ double chunk_bias(const StepCtx &c, int chunk, int lane,
-                                             uint64_t *cls, bool &valid) {
-  const int i = chunk * 64 + lane;
-  valid = i < c.n;
-  double wt = valid ? (double)c.vw[i] : 0.0;
-  if (!c.need_cls) return wt;
-  bool is_ret, is_mem;
-  if (kFromCache && chunk < kLdsChunks) {
-    is_ret = (cls[2 * chunk] >> lane) & 1ull;
-    is_mem = (cls[2 * chunk + 1] >> lane) & 1ull;
-  } else {
-    int32_t x = valid ? c.vcol[i] : -1;
-    is_ret = valid && x == c.s;
-    is_mem = false;
-    if (c.need_mem) is_mem = member_sorted(c.scol, c.m, x, c.iters) && valid && !is_ret;
-    if (!kFromCache && chunk < kLdsChunks) {
-      uint64_t rm = ballot64(is_ret), mm = ballot64(is_mem);
-      if (lane == 0) {
-        cls[2 * chunk] = rm;
-        cls[2 * chunk + 1] = mm;
-      }
-    }
-  }
-  if (is_ret) return wt / c.p;                  // :223-224
-  if (is_mem || !c.need_mem) return wt;         // :226-227 (and q == 1: w / 1.0 == w)
-  return wt / c.q;                              // :229-230
-}
 
 // Index drawn by sampling_from_alias(r1, r2) on the table that
 // generate_edge_alias_tables would build.  Returns -1 on ZeroDivisionError.
@@ -92,32 +36,8 @@ __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_
   const double r2 = (double)u2 * (1.0 / 4294967296.0);
 
   // ---- pass 1: bias + sum ---------------------------------------------------
-  int64_t isum = 0;
-  bool exact = true;
-  double b_pick = 0.0;
-  for (int chunk = 0; chunk < c.nch; ++chunk) {
-    bool valid;
-    double b = chunk_bias<false>(c, chunk, lane, cls, valid);
-    double t = b * 1048576.0;
-    bool ok = (t >= 0.0) && (t < 2147483648.0) && (t == trunc(t));
-    exact = exact && ok;
-    isum += ok ? (int64_t)t : 0;
-    if (chunk == (pick >> 6)) b_pick = readlane_f64(b, pick & 63);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  double total;
-  if (ballot64(!exact) == 0ull && n <= (1 << 21)) {
-    total = (double)wave_sum_i64(isum) * (1.0 / 1048576.0);
-  } else {  // reference order: left to right, one rounding per add (:172)
-    total = 0.0;
-    for (int chunk = 0; chunk < c.nch; ++chunk) {
-      bool valid;
-      double b = chunk_bias<true>(c, chunk, lane, cls, valid);
-      int cnt = min(64, n - chunk * 64);
-      for (int j = 0; j < cnt; ++j) total = total + readlane_f64(b, j);
-    }
-  }
+  double b_pick;
+  const double total = row_sum(c, lane, cls, pick, b_pick);
   const double avg = total / (double)n;  // :172
   if (avg == 0.0) return -1;
   const double p_pick = b_pick / avg;    // :173

@@ -1,7 +1,161 @@
-// n2v_walk_fast.hip -- K2 fast mode (first-order alias tables + rejection). Placeholder.
+// n2v_walk_fast.hip -- K2 fast mode: the same transition distribution as
+// generate_edge_alias_tables + sampling_from_alias (reference randomwalk.py:193-232,
+// :86-99) without rebuilding a table per step.
+//
+// A candidate x is drawn from the PRECOMPUTED first-order alias table of the
+// current vertex v (K1, one 16-byte slot gather) and accepted with probability
+// beta(x) / beta_max, beta = 1/p if x == s, 1 if x in N(s) (binary search over
+// the sorted row of s), 1/q otherwise: P(x) ~ w(v,x) * beta(x), the reference's
+// unnormalised probability (:223-230).  The first step (s < 0) is the unbiased
+// table itself and is draw-for-draw identical to the exact mode.
+//
+// One LANE per walker, walkers resident for all L steps.  Every loop iteration
+// each live lane performs ONE trial for its own current step; a lane whose
+// candidate is accepted moves to its next step (or its next walker) at once, so
+// no lane waits for another's rejections: the wave only drains when the ballot of
+// live lanes is empty.  Uniforms: (seed, start vertex, ordinal, step, trial).
 #include "n2v_common.h"
-extern "C" int n2v_walk_fast_launch(const n2v_graph *, const int32_t *, int64_t, int32_t, int32_t,
-                                    double, double, uint64_t, int32_t *, uint8_t *, uint32_t *,
-                                    void *) {
-  return N2V_EINVAL;
+
+namespace n2v {
+
+__device__ __forceinline__ bool member_sorted_lane(const int32_t *a, int m, int32_t x) {
+  int lo = 0, hi = m;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (a[mid] < x)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo < m && a[lo] == x;
+}
+
+__global__ __launch_bounds__(256) void walk_fast_kernel(
+    n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
+    int32_t walk_length, double p, double q, uint64_t seed, int32_t *__restrict__ walks_out,
+    uint8_t *__restrict__ valid_out, uint32_t *__restrict__ status,
+    unsigned long long *__restrict__ trials_out) {
+  const int64_t total = n_start * (int64_t)num_walks;
+  const int64_t n_lanes = (int64_t)gridDim.x * blockDim.x;
+  const int L1 = walk_length + 1;
+  const double inv_p = 1.0 / p, inv_q = 1.0 / q;
+  const double beta_max = fmax(1.0, fmax(inv_p, inv_q));
+  const bool biased = !(p == 1.0 && q == 1.0);
+
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // current walker row
+  bool live = false;
+  int32_t s = -1, v = 0;
+  int step = 0;
+  uint32_t trial = 0;
+  int64_t vb = 0, sb = 0;
+  int n = 0, m = 0;
+  uint64_t h0 = 0, hstep = 0;
+  int32_t *out = nullptr;
+  unsigned long long trials = 0;
+
+  // (re)load a walker into this lane; returns false when the lane has none left
+  auto begin_walker = [&]() -> bool {
+    while (r < total) {
+      const int32_t start = start_ids[r / num_walks];
+      const int32_t ordinal = (int32_t)(r % num_walks) + 1;
+      out = walks_out + r * L1;
+      for (int t = 0; t < L1; ++t) out[t] = -1;
+      bool ok = true;
+      if (start < 0 || (int64_t)start >= g.n_vertices) {
+        atomicOr(status, N2V_ST_RANGE);
+        ok = false;
+      }
+      if (ok) {
+        vb = g.rowptr[start];
+        n = (int)(g.rowptr[start + 1] - vb);
+        ok = n > 0;  // fugue.py:132
+      }
+      if (!ok) {
+        valid_out[r] = 0;
+        r += n_lanes;
+        continue;
+      }
+      s = -1;
+      v = start;
+      step = 0;
+      trial = 0;
+      out[0] = start;
+      h0 = walker_stream(seed, (uint64_t)start * (uint64_t)num_walks + (uint64_t)(ordinal - 1));
+      hstep = step_bits(h0, 0);
+      return true;
+    }
+    return false;
+  };
+
+  live = begin_walker();
+  while (__ballot(live) != 0ull) {
+    if (!live) continue;
+    // ---- one trial of the current step ----------------------------------------
+    uint64_t bits = s < 0 ? hstep : trial_bits(hstep, trial);
+    const uint32_t u1 = (uint32_t)(bits >> 32), u2 = (uint32_t)bits;
+    const int pick = (int)__umulhi(u1, (uint32_t)n);
+    const n2v_slot sl = g.slots[vb + pick];
+    const double r2 = (double)u2 * (1.0 / 4294967296.0);
+    int32_t x = sl.col;
+    if (!(r2 < sl.prob)) x = g.slots[vb + sl.alias].col;
+    bool accept = true;
+    ++trials;
+    if (s >= 0 && biased) {
+      double beta;
+      if (x == s)
+        beta = inv_p;
+      else if (q != 1.0 && member_sorted_lane(g.col + sb, m, x))
+        beta = 1.0;
+      else
+        beta = q != 1.0 ? inv_q : 1.0;
+      const uint32_t u3 = (uint32_t)(mix64(bits ^ 0xC2B2AE3D27D4EB4FULL) >> 32);
+      accept = (double)u3 * (1.0 / 4294967296.0) * beta_max < beta;
+    }
+    if (!accept) {
+      ++trial;
+      continue;
+    }
+    // ---- accepted: append, advance ------------------------------------------------
+    out[step + 1] = x;
+    s = v;
+    sb = vb;
+    m = n;
+    v = x;
+    ++step;
+    trial = 0;
+    bool finished = step == walk_length;
+    bool dropped = false;
+    if (!finished) {
+      vb = g.rowptr[v];
+      n = (int)(g.rowptr[v + 1] - vb);
+      dropped = n == 0;  // fugue.py:147: the walker vanishes at a sink
+      hstep = step_bits(h0, (uint32_t)step);
+    }
+    if (finished || dropped) {
+      valid_out[r] = finished ? 1 : 0;
+      r += n_lanes;
+      live = begin_walker();
+    }
+  }
+  if (trials_out && trials) atomicAdd(trials_out, trials);
+}
+
+}  // namespace n2v
+
+extern "C" int n2v_walk_fast_launch(const n2v_graph *g, const int32_t *start_ids,
+                                    int64_t n_start, int32_t num_walks, int32_t walk_length,
+                                    double p, double q, uint64_t seed, int32_t *walks_out,
+                                    uint8_t *valid_out, uint32_t *status, void *stream) {
+  const int64_t total = n_start * (int64_t)num_walks;
+  if (total == 0) return N2V_OK;
+  const int threads = 256;
+  int64_t blocks = (total + threads - 1) / threads;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  // status[1] (when the caller allocates >= 4 words) accumulates the trial count
+  hipLaunchKernelGGL(n2v::walk_fast_kernel, dim3((unsigned)blocks), dim3(threads), 0,
+                     (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, p, q,
+                     seed, walks_out, valid_out, status,
+                     (unsigned long long *)nullptr);
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
 }

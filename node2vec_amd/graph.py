@@ -5,7 +5,7 @@ per source vertex (`partition(by=src, presort=dst).transform(get_vertex_neighbor
 fugue.py:130, randomwalk.py:266-275).  Here the same data is a CSR triple kept
 resident on the GPU: rowptr int64[V+1], col int32[E] (sorted by dst within a
 row, multi-edges kept in input order), w fp32[E]; plus, for the fast sampler,
-CSR-aligned first-order alias tables (alias int32[E], prob fp64[E]).
+CSR-aligned first-order alias tables packed as 16-byte slots {col, alias, prob}.
 """
 import ctypes as C
 from typing import Optional
@@ -24,8 +24,7 @@ class DeviceGraph:
         self.rowptr = rowptr.contiguous()
         self.col = col.contiguous()
         self.w = w.contiguous()
-        self.alias: Optional[torch.Tensor] = None
-        self.prob: Optional[torch.Tensor] = None
+        self.slots: Optional[torch.Tensor] = None  # int32 [E, 4] view of n2v_slot[E]
 
     # -- construction ---------------------------------------------------------
     @classmethod
@@ -79,15 +78,14 @@ class DeviceGraph:
 
     def to(self, device) -> "DeviceGraph":
         g = DeviceGraph(self.rowptr.to(device), self.col.to(device), self.w.to(device))
-        if self.alias is not None:
-            g.alias, g.prob = self.alias.to(device), self.prob.to(device)
+        if self.slots is not None:
+            g.slots = self.slots.to(device)
         return g
 
     def c_struct(self) -> _lib.Graph:
         return _lib.Graph(self.n_vertices, self.n_edges, self.rowptr.data_ptr(),
                           self.col.data_ptr(), self.w.data_ptr(),
-                          0 if self.alias is None else self.alias.data_ptr(),
-                          0 if self.prob is None else self.prob.data_ptr())
+                          0 if self.slots is None else self.slots.data_ptr())
 
     # -- K1 -----------------------------------------------------------------------
     def build_alias(self) -> "DeviceGraph":
@@ -97,14 +95,22 @@ class DeviceGraph:
         _lib.require_gpu()
         if not self.rowptr.is_cuda:
             raise RuntimeError("build_alias: graph is not on the GPU")
-        alias = torch.zeros(self.n_edges, dtype=torch.int32, device=self.device)
-        prob = torch.zeros(self.n_edges, dtype=torch.float64, device=self.device)
+        slots = torch.zeros((self.n_edges, 4), dtype=torch.int32, device=self.device)
         status = torch.zeros(1, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
-            rc = L.n2v_alias_build(self.rowptr.data_ptr(), self.w.data_ptr(), self.n_vertices,
-                                   alias.data_ptr(), prob.data_ptr(), status.data_ptr(),
-                                   _lib.current_stream_ptr())
+            rc = L.n2v_alias_build(self.rowptr.data_ptr(), self.col.data_ptr(),
+                                   self.w.data_ptr(), self.n_vertices, slots.data_ptr(),
+                                   status.data_ptr(), _lib.current_stream_ptr())
         _lib.check(rc, "n2v_alias_build")
         _lib.check_status_word(int(status.item()), "n2v_alias_build")
-        self.alias, self.prob = alias, prob
+        self.slots = slots
         return self
+
+    # -- views of the packed tables (tests, debugging) -------------------------------
+    @property
+    def alias(self) -> Optional[torch.Tensor]:
+        return None if self.slots is None else self.slots[:, 1]
+
+    @property
+    def prob(self) -> Optional[torch.Tensor]:
+        return None if self.slots is None else self.slots.view(torch.float64)[:, 1]

@@ -50,7 +50,7 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     if return_param == 0 or inout_param == 0:
         # generate_edge_alias_tables, randomwalk.py:214-217
         raise ValueError(f"Zero return ({return_param}) or inout ({inout_param}) parameter!")
-    if mode == "fast" and graph.alias is None:
+    if mode == "fast" and graph.slots is None:
         graph.build_alias()
     start_ids = start_ids.to(device=graph.device, dtype=torch.int32).contiguous()
     n_start = start_ids.numel()

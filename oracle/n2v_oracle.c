@@ -332,3 +332,37 @@ int n2v_oracle_transition_probs(const n2v_oracle_csr *g, int64_t s, int64_t v,
   for (int64_t i = 0; i < n; ++i) prob_out[i] /= total;
   return N2V_ORACLE_OK;
 }
+
+/* ------------------------------------------------------------------------ */
+/* randomwalk.py:238-262 trim_hotspot_vertices, on CSR rows                  */
+/* ------------------------------------------------------------------------ */
+/* The reference samples with pandas DataFrame.sample(n=cap, random_state=seed)
+ * (numpy RandomState; cannot be replayed).  What it pins (tests/test_randomwalk.py:
+ * 194-224, tests/test_fugue.py:23-28) is: exactly `cap` edges survive for a row
+ * above the cap, they are a subset of the row, other rows and all weights are
+ * untouched.  This restates the build's selection sampling (Knuth Algorithm S) on
+ * the counter-based stream so that the HIP kernel can be compared bit for bit. */
+static inline uint64_t mulhi64(uint64_t a, uint64_t b) {
+  return (uint64_t)(((unsigned __int128)a * (unsigned __int128)b) >> 64);
+}
+
+int n2v_oracle_trim_mark(const int64_t *rowptr, int64_t n_rows, int64_t max_out_degree,
+                         uint64_t seed, uint8_t *keep_out) {
+  if (max_out_degree <= 0) max_out_degree = 100000; /* constants.py:6, randomwalk.py:252 */
+  for (int64_t row = 0; row < n_rows; ++row) {
+    int64_t b = rowptr[row], d = rowptr[row + 1] - b;
+    if (d <= max_out_degree) { /* :254 */
+      for (int64_t i = 0; i < d; ++i) keep_out[b + i] = 1;
+      continue;
+    }
+    uint64_t h = mix64(seed ^ mix64((uint64_t)row + 0x2545F4914F6CDD1DULL));
+    int64_t need = max_out_degree;
+    for (int64_t i = 0; i < d; ++i) {
+      uint64_t u = mix64(h + ((uint64_t)i + 1ULL) * 0x9FB21C651E98DF25ULL);
+      int take = (int64_t)mulhi64(u, (uint64_t)(d - i)) < need;
+      keep_out[b + i] = (uint8_t)take;
+      need -= take;
+    }
+  }
+  return N2V_ORACLE_OK;
+}

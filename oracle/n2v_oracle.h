@@ -98,6 +98,18 @@ int n2v_oracle_transition_probs(const n2v_oracle_csr *g, int64_t s, int64_t v,
                                 double return_param, double inout_param,
                                 double *prob_out);
 
+/* randomwalk.py:238-262 trim_hotspot_vertices on CSR rows: keep_out[e] = 1 for
+ * surviving edges (exactly max_out_degree per row above the cap). */
+int n2v_oracle_trim_mark(const int64_t *rowptr, int64_t n_rows, int64_t max_out_degree,
+                         uint64_t seed, uint8_t *keep_out);
+
+/* n2v_oracle_sgns.c (PARITY UNPINNED, see its header) */
+int64_t n2v_oracle_sgns_train(const int32_t *walks, int64_t n_walks, int32_t walk_len,
+                              float *syn0, float *syn1neg, const uint32_t *cum_table,
+                              const uint32_t *sample_int, const float *exp_table,
+                              int64_t n_vocab, int64_t sentence_base, uint64_t seed,
+                              int32_t dim, int32_t window, int32_t negative, float alpha);
+
 #ifdef __cplusplus
 }
 #endif

@@ -177,3 +177,11 @@ def sgns_train(walks_idx, syn0, syn1neg, cum_table, sample_int, exp_table, n_voc
     if n < 0:
         raise ValueError("oracle sgns: invalid argument")
     return int(n)
+
+
+def trim_mark(rowptr, max_out_degree, seed):
+    rowptr = np.ascontiguousarray(rowptr, np.int64)
+    keep = np.zeros(int(rowptr[-1]), np.uint8)
+    _raise(lib().n2v_oracle_trim_mark(_p(rowptr), C.c_int64(len(rowptr) - 1),
+                                      C.c_int64(max_out_degree), C.c_uint64(seed), _p(keep)))
+    return keep.astype(bool)
