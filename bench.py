@@ -164,11 +164,83 @@ def main():
                                "algorithmic_bytes_per_walk_step": abytes / max(steps_done, 1)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, g, start_all, W, L)
+    if not args.no_sgns:
+        sg = bench_sgns(args, torch, dist, g, walks, valid, rank, world, barrier)
+        if rank == 0:
+            out["sgns"] = sg
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_sgns(args, torch, dist, g, walks, valid, rank, world, barrier):
+    """Second timed loop: K steps of the SGNS kernel (embedding-updates/s).  One step =
+    one launch over the block of walks of one walk step (batch x W rows of L+1 tokens),
+    vocabulary = every vertex (min_count=0, sample=0: deterministic unit counts), dim
+    args.dim, window 5, k=5.  Unit: one positive (centre, context) pair with its k
+    negative targets.  With N GPUs every rank trains its own walks on a full replica;
+    the delta all-reduce is reported separately (it is per sync, not per step)."""
+    import time as _t
+
+    from node2vec_amd import sgns
+
+    dev = walks.device
+    deg = g.degrees().clamp(min=1)
+    order = torch.sort(deg, descending=True, stable=True).indices
+    index_of = torch.empty(g.n_vertices, dtype=torch.int32, device=dev)
+    index_of[order] = torch.arange(g.n_vertices, dtype=torch.int32, device=dev)
+    vocab = sgns.Vocab(order, deg[order], index_of)
+    model = sgns.SgnsModel(vocab, args.dim, 5, 5, seed=1, sample=0.0, device=dev)
+    idx = index_of[walks[valid.bool()].long()].contiguous()
+    rows = idx.shape[0]
+    for k in range(args.warmup):
+        model.train_block(idx, 0.025, k * rows)
+    model.pairs.zero_()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    barrier()
+    t0 = _t.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        model.train_block(idx, 0.025, (args.warmup + k + rank * 1000) * rows)
+        ev[k][1].record()
+    barrier()
+    elapsed = _t.perf_counter() - t0
+    pairs = float(model.pairs.item())
+    t = torch.tensor([elapsed, pairs], dtype=torch.float64, device=dev)
+    if world > 1:
+        tm = t.clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        ts = t.clone()
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+        elapsed, pairs_total = float(tm[0]), float(ts[1])
+    else:
+        pairs_total = pairs
+    kernel_s = 1e-3 * sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    bytes_per_pair = 8 * args.dim * (2 + 5)            # SURVEY 8(d): 2*4*D*(2+k)
+    flops_per_pair = (1 + 5) * 6 * args.dim + args.dim  # (1+k)*6D + D
+    ach = pairs / args.steps * bytes_per_pair / kernel_s
+    res = {"value": pairs_total / elapsed, "unit": "embedding-updates/s (pairs incl. k=5 negatives)",
+           "row_updates_per_s": pairs_total / elapsed * 6, "ms_per_step": 1e3 * elapsed / args.steps,
+           "dtype": "f32", "config": {"dim": args.dim, "window": 5, "negative": 5,
+                                      "rows_per_step": rows, "n_vocab": g.n_vertices,
+                                      "sample": 0, "min_count": 0},
+           "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
+                        "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": None,
+                        "kernel": "sgns_kernel", "kernel_ms": 1e3 * kernel_s,
+                        "algorithmic_bytes_per_pair": bytes_per_pair,
+                        "fma_utilisation": pairs / args.steps * flops_per_pair / kernel_s / 157.3e12}}
+    if world > 1:  # the exchange step: one delta all-reduce of both matrices
+        sync = sgns.DeltaAllReduce([model.syn0, model.syn1neg], block_rows=1 << 18)
+        barrier()
+        t0 = _t.perf_counter()
+        sync()
+        barrier()
+        res["delta_allreduce_s"] = _t.perf_counter() - t0
+        res["delta_allreduce_bytes"] = 2 * model.syn0.numel() * 4
+    return res
 
 
 def _pmc_traffic():

@@ -235,9 +235,17 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   using namespace n2v;
   const size_t lds = kExpTable * sizeof(float) +
                      (size_t)kSgnsWaves * (2 * kMaxSent + (2 * P->window + 1) * P->negative) * 4;
-  int64_t blocks = (n_walks + kSgnsWaves - 1) / kSgnsWaves;
+  // Hogwild concurrency is scaled to the model: unsynchronised waves are harmless
+  // while collisions on a row are rare (gensim runs <= 16 threads); on a tiny
+  // vocabulary thousands of racing waves would overwrite each other's updates.
+  // One wave per 32 vocabulary rows, up to the whole chip (8192 waves >= 256 K rows).
+  int64_t waves = P->n_vocab / 32;
+  if (waves < 1) waves = 1;
+  if (waves > n_walks) waves = n_walks;
+  int64_t blocks = (waves + kSgnsWaves - 1) / kSgnsWaves;
   if (blocks > 256 * 8) blocks = 256 * 8;
   dim3 block(kSgnsWaves * 64);
+  if (waves < kSgnsWaves) block = dim3((unsigned)waves * 64);
   if (P->deterministic) {
     blocks = 1;
     block = dim3(64);

@@ -1,0 +1,126 @@
+"""End-to-end through the reference-shaped Python API on the GPU: BASELINE cfg 1
+(karate club, p=q=1, walk_len=10, dim=16) and the assertions of the reference's
+tests/test_fugue.py and tests/test_embedding.py."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _karate_df():
+    e = load_golden("karate_edges.json")
+    return pd.DataFrame(e, columns=["src", "dst", "weight"])
+
+
+def test_cfg1_karate_walks_equal_reference_and_embed():
+    from node2vec_amd.embedding import HipW2V, Node2VecHIP
+    from node2vec_amd.fugue import random_walk
+
+    params = {"num_walks": 10, "walk_length": 10, "return_param": 1.0, "inout_param": 1.0}
+    df_walks = random_walk("hip", _karate_df(), params, random_seed=42)
+    assert list(df_walks.columns) == ["src", "walk"] and len(df_walks) == 340
+    assert all(len(w) == 11 and w[0] == s for s, w in zip(df_walks["src"], df_walks["walk"]))
+    # identical to the walks the reference itself produced with this uniform stream (G4)
+    g4 = [c for c in load_golden("g4_walks.json") if c["name"] == "karate_p1.0_q1.0"][0]
+    want = sorted(w["walk"] for w in g4["walks"])
+    assert sorted(df_walks["walk"].tolist()) == want
+
+    w2v = {"min_count": 0, "iter": 40, "size": 16, "negative": 5}
+    n2v = Node2VecHIP(df_walks, w2v, random_seed=1000)
+    with pytest.raises(ValueError):
+        n2v.embedding()
+    model = n2v.fit()
+    assert isinstance(model, HipW2V) and model.pairs_trained > 0
+    emb = n2v.embedding()
+    assert list(emb.columns) == ["id", "vector"] and len(emb) == 34
+    assert all(len(v) == 16 for v in emb["vector"])
+    assert len(n2v.get_vector(vertex_id="0")) == 16 and len(n2v.get_vector(vertex_id=1)) == 16
+    # structure is learnt: adjacent vertices are closer than non-adjacent ones
+    ids = emb["id"].to_numpy()
+    V = np.array(emb["vector"].tolist())
+    V = V - V.mean(axis=0, keepdims=True)  # remove the common direction SGNS gives tiny graphs
+    V = V / np.linalg.norm(V, axis=1, keepdims=True)
+    S = V @ V.T
+    adj = np.zeros((34, 34), bool)
+    for a_, b_, _ in load_golden("karate_edges.json"):
+        adj[a_, b_] = True
+    A = adj[np.ix_(ids, ids)]
+    off = ~np.eye(34, dtype=bool)
+    assert S[A].mean() > S[~A & off].mean() + 0.1
+
+
+def test_save_load_round_trip(tmp_path):
+    """tests/test_embedding.py:64-72"""
+    from node2vec_amd.embedding import HipW2V, KeyedVectors, Node2VecHIP
+
+    df = pd.DataFrame.from_dict({"walk": [[0, 1, 1, 0, 3, 4], [1, 2, 3, 2, 0, 4], [2, 3, 1, 0, 4, 4]]})
+    params = {"min_count": 0, "iter": 1, "seed": 1000, "batch_words": 1, "size": 4, "workers": 4}
+    n2v = Node2VecHIP(df, w2v_params=params)
+    assert isinstance(n2v.fit(), HipW2V)
+    df_res = n2v.embedding()
+    assert isinstance(df_res, pd.DataFrame) and len(df_res) > 0 and list(df_res.columns) == ["id", "vector"]
+    n2v.save_model(str(tmp_path), "tmp")
+    assert os.path.exists(tmp_path / "tmp.model")
+    assert isinstance(n2v.load_model(str(tmp_path), "tmp"), HipW2V)
+    n2v.save_vectors(str(tmp_path), "tmp_vec")
+    assert isinstance(n2v.load_vectors(str(tmp_path), "tmp_vec"), KeyedVectors)
+    name_id = pd.DataFrame.from_dict({"name": ["a", "b", "c", "d", "e"], "id": [0, 1, 2, 3, 4]})
+    n2v = Node2VecHIP(df, params, name_id=name_id)
+    with pytest.raises(ValueError):
+        n2v.embedding()
+    n2v.fit()
+    res = n2v.embedding()
+    assert list(res.columns) == ["name", "vector"] and set(res["name"]) <= set("abcde")
+
+
+def test_trim_index_counts():
+    """tests/test_fugue.py:23-28, 38-41: cap 1 keeps one edge per source"""
+    from node2vec_amd.fugue import trim_index
+
+    df = pd.DataFrame({"src": ["a1", "a1", "a1", "a2", "a5", "b2"],
+                       "dst": ["a5", "b2", "b6", "b2", "b2", "b6"]})
+    e, name_id = trim_index(None, df, indexed=False, directed=True, max_out_deg=1, random_seed=1)
+    assert len(e) == 4 and len(name_id) <= 5 and list(e.columns) == ["src", "dst", "weight"]
+    e, name_id = trim_index(None, df, indexed=False, directed=False, max_out_deg=0)
+    assert len(e) == 12 and len(name_id) == 5
+    dfi = pd.DataFrame({"src": [0, 0, 0, 1], "dst": [1, 2, 3, 0], "weight": [1.0, 2.0, 3.0, 1.0]})
+    e, none = trim_index(None, dfi, indexed=True, max_out_deg=2, random_seed=3)
+    assert none is None and len(e) == 3 and set(map(tuple, e.values.tolist())) <= set(map(tuple, dfi.values.tolist()))
+
+
+def test_random_walk_walk_seed_and_sinks():
+    """fugue.py:132-134, 147: walk_seed filter and the sink drop (G7)"""
+    from node2vec_amd.fugue import random_walk
+
+    df = pd.DataFrame({"src": [0, 1, 3], "dst": [1, 2, 0], "weight": [1.0, 1.0, 1.0]})
+    out = random_walk(None, df, {"num_walks": 1, "walk_length": 2}, random_seed=42)
+    assert sorted(out["walk"].tolist()) == [[0, 1, 2], [3, 0, 1]]
+    out = random_walk(None, df, {"num_walks": 2, "walk_length": 1}, random_seed=1,
+                      walk_seed=pd.DataFrame({"id": [3, 2]}))
+    assert out["src"].tolist() == [3, 3]
+    with pytest.raises(ValueError):
+        random_walk(None, df, {}, walk_seed=pd.DataFrame({"x": [1]}))
+    with pytest.raises(ValueError):
+        random_walk(None, df, {"return_param": 0.0, "walk_length": 3})
+
+
+def test_on_device_corpus_feeds_sgns_without_dataframe():
+    """walks stay in HBM from K2 to K3"""
+    from node2vec_amd import synthetic
+    from node2vec_amd.embedding import Node2VecHIP
+    from node2vec_amd.fugue import random_walk_tensors
+
+    g = synthetic.rmat(11, 20000, device="cuda")
+    walks, valid = random_walk_tensors(g, {"num_walks": 4, "walk_length": 20, "return_param": 0.5,
+                                           "inout_param": 2.0}, random_seed=3, mode="fast")
+    assert walks.is_cuda and bool(valid.all())
+    n2v = Node2VecHIP(walks, {"min_count": 1, "iter": 1, "size": 64, "sample": 1e-3}, random_seed=9)
+    m = n2v.fit()
+    assert m.wv.vectors.shape[1] == 64 and np.isfinite(m.wv.vectors).all()
+    assert len(m.wv.vocab) == int(torch.unique(walks).numel())

@@ -1,0 +1,59 @@
+"""The C-ABI library loads on a GPU-less host and exports every symbol that
+include/n2v_hip.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "n2v_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(n2v_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    names = _declared()
+    for want in ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alias_build",
+                 "n2v_walk", "n2v_trim_mark", "n2v_sgns_train"):
+        assert want in names
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+
+    ge.build()
+    from node2vec_amd import _lib
+
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), name
+    assert sorted(_lib.SYMBOLS) == _declared()
+    lib.n2v_abi_version.restype = ctypes.c_int
+    assert lib.n2v_abi_version() == 1
+    lib.n2v_status_string.restype = ctypes.c_char_p
+    assert lib.n2v_status_string(-1) == b"invalid argument"
+
+
+def test_ctypes_structs_match_header_layout():
+    """sizeof / field order of the two structs passed by pointer"""
+    from node2vec_amd import _lib
+
+    assert ctypes.sizeof(_lib.Graph) == 6 * 8
+    assert [f[0] for f in _lib.Graph._fields_] == ["n_vertices", "n_edges", "rowptr", "col", "w", "slots"]
+    assert ctypes.sizeof(_lib.SgnsParams) == 3 * 8 + 6 * 4
+    assert [f[0] for f in _lib.SgnsParams._fields_] == [
+        "n_vocab", "sentence_base", "seed", "dim", "window", "negative", "alpha",
+        "deterministic", "reserved"]
+
+
+def test_product_package_never_touches_the_oracle():
+    """no file of node2vec_amd/ imports, loads or mentions oracle/ code paths"""
+    pkg = os.path.join(ROOT, "node2vec_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "n2v_oracle" not in text.replace("oracle/n2v_oracle", ""), f
+                assert "import n2v_oracle" not in text, f

@@ -1,0 +1,198 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU): the same
+things the reference's tests pin for these layers (tests/test_constants.py,
+tests/test_indexer.py, tests/test_fugue.py error paths, tests/test_embedding.py
+constructor / base-class behaviour)."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+
+def test_constants_match_reference_defaults():
+    """tests/test_constants.py + constants.py:6-68"""
+    from node2vec_amd import constants as c
+
+    assert c.MAX_OUT_DEGREES == 100000 and c.NUM_PARTITIONS == 3000
+    assert c.NODE2VEC_PARAMS == {"num_walks": 10, "walk_length": 20, "return_param": 1.0,
+                                 "inout_param": 1.0}
+    assert c.GENSIM_PARAMS == {"min_count": 10, "alpha": 0.025, "iter": 10, "seed": None,
+                               "batch_words": 1000, "window": 5, "size": 128, "negative": 0,
+                               "workers": 16}
+    assert c.WORD2VEC_PARAMS["windowSize"] == 5 and c.WORD2VEC_PARAMS["vectorSize"] == 128
+    assert set(c.WORD2VEC_PARAMS) == {"minCount", "numPartitions", "stepSize", "maxIter", "seed",
+                                      "maxSentenceLength", "windowSize", "vectorSize"}
+
+
+def _graph_df():
+    # the 6-edge graph of tests/test_indexer.py / tests/test_fugue.py
+    return pd.DataFrame({"src": ["a1", "a1", "a1", "a2", "a5", "b2"],
+                         "dst": ["a5", "b2", "b6", "b2", "b2", "b6"]})
+
+
+def test_index_graph_pandas_counts_and_errors():
+    """tests/test_indexer.py:17-20, 39-42: 5 names -> 5 ids, edges x2 when undirected"""
+    from node2vec_amd.indexer import index_graph_pandas
+
+    df = _graph_df()
+    e, name_id = index_graph_pandas(df.copy(), True)
+    assert len(name_id) == 5 and len(e) == 6
+    assert list(name_id.columns) == ["name", "id"] and list(e.columns) == ["src", "dst", "weight"]
+    assert sorted(name_id["id"]) == list(range(5)) and (e["weight"] == 1.0).all()
+    back = dict(zip(name_id["id"], name_id["name"]))
+    assert [(back[s], back[d]) for s, d in zip(e["src"], e["dst"])] == list(zip(df["src"], df["dst"]))
+    e2, _ = index_graph_pandas(df.copy(), False)
+    assert len(e2) == 12
+    with pytest.raises(ValueError):
+        index_graph_pandas(df.rename(columns={"src": "source"}), True)
+
+
+def test_trim_index_and_random_walk_validate_before_touching_the_gpu():
+    """fugue.py:53-54 and :123-124"""
+    from node2vec_amd.fugue import random_walk, trim_index
+
+    with pytest.raises(ValueError):
+        trim_index(None, pd.DataFrame({"src1": [0], "dst": [1]}))
+    params = {"num_walks": 2}
+    with pytest.raises(ValueError):
+        random_walk(None, pd.DataFrame({"src": [0], "dst": [1], "weight": [1.0]}), params,
+                    walk_seed=pd.DataFrame({"vid": [0]}))
+    # defaults are filled into the CALLER's dict (fugue.py:120-122)
+    assert params == {"num_walks": 2, "walk_length": 20, "return_param": 1.0, "inout_param": 1.0}
+
+
+def test_kernels_fail_loudly_without_a_gpu():
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    g = DeviceGraph.from_edges([0, 1], [1, 0], [1.0, 1.0])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        rw.walk(g, torch.tensor([0], dtype=torch.int32), 1, 2, 1.0, 1.0, 1)
+    with pytest.raises(RuntimeError):
+        g.build_alias()
+
+
+def test_missing_library_raises_import_error(monkeypatch):
+    from node2vec_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libn2v_hip.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_device_graph_csr_matches_presorted_adjacency():
+    """fugue.py:130 partition(by=src, presort=dst): rows sorted by dst, multi-edges in
+    input order, vertices without out-edges have empty rows"""
+    from node2vec_amd.graph import DeviceGraph
+
+    g = DeviceGraph.from_edges([3, 3, 0, 3, 0], [2, 0, 1, 0, 1], [1.0, 0.2, 5.0, 1.4, 6.0])
+    assert g.rowptr.tolist() == [0, 2, 2, 2, 5]
+    assert g.col.tolist() == [1, 1, 0, 0, 2]
+    np.testing.assert_allclose(g.w.numpy(), [5.0, 6.0, 0.2, 1.4, 1.0], rtol=1e-7)
+    assert g.degrees().tolist() == [2, 0, 0, 3]
+    with pytest.raises(ValueError):
+        DeviceGraph.from_edges([-1], [0], [1.0])
+    with pytest.raises(KeyError):
+        DeviceGraph.from_pandas(pd.DataFrame({"src": [0], "dst": [1]}))
+
+
+def test_start_vertices_is_adjacency_ids_joined_with_walk_seed():
+    """fugue.py:132-134"""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+
+    g = DeviceGraph.from_edges([0, 1, 3], [1, 2, 0], [1.0, 1.0, 1.0])
+    assert rw.start_vertices(g).tolist() == [0, 1, 3]
+    assert rw.start_vertices(g, [3, 2, 3, 9, -1]).tolist() == [3]
+
+
+def test_node2vec_base_is_abstract():
+    """tests/test_embedding.py:17-31"""
+    from node2vec_amd.embedding import Node2VecBase
+
+    n2v = Node2VecBase()
+    for call in (n2v.fit, n2v.embedding, lambda: n2v.get_vector(0),
+                 lambda: n2v.save_model("file:///a", "b"), lambda: n2v.load_model("file:///a", "b")):
+        with pytest.raises(NotImplementedError):
+            call()
+
+
+def test_node2vec_hip_constructor_contract():
+    """tests/test_embedding.py:38-48, embedding.py:105-116, 133-134"""
+    from node2vec_amd.embedding import Node2VecGensim, Node2VecHIP
+
+    assert Node2VecGensim is Node2VecHIP
+    df = pd.DataFrame.from_dict({"walk": [[0, 1, 1, 0, 3, 4], [1, 2, 3, 2, 0, 4], [2, 3, 1, 0, 4, 4]]})
+    params = {}
+    n2v = Node2VecHIP(df, params)
+    assert set(params) >= {"min_count", "alpha", "iter", "seed", "batch_words", "window", "size",
+                           "negative", "workers"}
+    assert params["seed"] > 0 and n2v.w2v_params is params
+    p2 = {"iter": 3}
+    Node2VecHIP(df, w2v_params=p2, window_size=6, vector_size=64, random_seed=1000)
+    assert (p2["window"], p2["size"], p2["seed"], p2["iter"]) == (6, 64, 1000, 3)
+    for kw in ({"window_size": 3}, {"window_size": 31}, {"vector_size": 16}, {"vector_size": 2048}):
+        with pytest.raises(ValueError):
+            Node2VecHIP(df, {}, **kw)
+    with pytest.raises(ValueError):
+        Node2VecHIP(df, {"hs": 1})
+    with pytest.raises(ValueError, match="Model is not available"):
+        n2v.embedding()
+
+
+def test_keyed_vectors_word2vec_text_round_trip(tmp_path):
+    from node2vec_amd.embedding import HipW2V, KeyedVectors
+
+    vec = np.random.default_rng(0).normal(size=(5, 8)).astype(np.float32)
+    kv = KeyedVectors(["3", "0", "7", "1", "4"], vec)
+    assert "7" in kv and np.array_equal(kv["7"], vec[2]) and list(kv.vocab) == ["3", "0", "7", "1", "4"]
+    kv.save_word2vec_format(str(tmp_path / "v.txt"))
+    assert open(tmp_path / "v.txt").readline() == "5 8\n"
+    kv2 = KeyedVectors.load_word2vec_format(str(tmp_path / "v.txt"))
+    assert kv2.index2word == kv.index2word and np.array_equal(kv2.vectors, vec)
+    m = HipW2V(kv, vec * 2, {"size": 8}, 11)
+    m.save(str(tmp_path / "m.model"))
+    m2 = HipW2V.load(str(tmp_path / "m.model"))
+    assert np.array_equal(m2.wv.vectors, vec) and m2.pairs_trained == 11 and os.path.exists(tmp_path / "m.model")
+
+
+def test_sgns_host_tables():
+    from node2vec_amd import sgns
+
+    t = sgns.exp_table()
+    assert t.dtype == np.float32 and len(t) == 1000
+    assert abs(t[0] - 1 / (1 + np.exp(6.0))) < 1e-6 and abs(t[500] - 0.5) < 1e-6 and t[999] > 0.997
+    walks = torch.tensor([[5, 5, 5, 2], [2, 9, 5, -1], [9, 2, 7, 7]], dtype=torch.int32)
+    v = sgns.build_vocab(walks, min_count=2)
+    assert v.ids.tolist() == [5, 2, 7, 9] and v.counts.tolist() == [4, 3, 2, 2]  # ties: id asc
+    assert v.index_of.tolist() == [-1, -1, 1, -1, -1, 0, -1, 2, -1, 3]
+    cum = sgns.make_cum_table(v.counts).numpy().astype(np.int64)
+    p = np.array([4, 3, 2, 2], float) ** 0.75
+    want = np.round(np.cumsum(p) / p.sum() * (2 ** 31 - 1)).astype(np.int64)
+    assert cum.tolist() == want.tolist() and cum[-1] == 2 ** 31 - 1
+    assert sgns.make_sample_int(v.counts, 0) is None
+    si = sgns.make_sample_int(torch.tensor([1000, 10, 1]), 0.01).numpy().view(np.uint32).astype(np.int64)
+    thr = 0.01 * 1011
+    want0 = round((np.sqrt(1000 / thr) + 1) * (thr / 1000) * 2 ** 32)
+    assert si[0] == want0 and si[1] == 2 ** 32 - 1 and si[2] == 2 ** 32 - 1  # prob clipped to 1
+    assert sgns.split_rows(torch.arange(12, dtype=torch.int32).reshape(2, 6), 4).tolist() == [
+        [0, 1, 2, 3], [4, 5, -1, -1], [6, 7, 8, 9], [10, 11, -1, -1]]
+
+
+def test_shard_range_is_a_disjoint_cover():
+    from node2vec_amd.shard import sentence_base, shard_range
+
+    for n in (0, 1, 7, 8, 471785):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+    with pytest.raises(ValueError):
+        shard_range(5, 2, 2)
+    bases = {sentence_base(r, 4, 100, e) for r in range(4) for e in range(3)}
+    assert len(bases) == 12
