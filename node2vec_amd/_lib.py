@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libn2v_hip.so")
+# N2V_HIP_LIB: developer override used by scripts/ablate_walk.sh (timing-only builds)
+LIB_PATH = os.environ.get("N2V_HIP_LIB") or os.path.join(_HERE, "libn2v_hip.so")
 
 OK, EINVAL, ELAUNCH, ENOGPU = 0, -1, -2, -3
 ST_ZERODIV, ST_RANGE = 1, 2

@@ -7,7 +7,7 @@
 namespace n2v {
 
 constexpr int kWavesPerBlock = 4;
-constexpr int kLdsChunks = 256;  // class ballots kept in LDS for rows <= 16384
+constexpr int kLdsChunks = 128;  // class ballots kept in LDS for rows <= 8192
 
 struct StepCtx {
   const int32_t *vcol;  // N(v) ids
@@ -32,6 +32,38 @@ __device__ __forceinline__ bool member_sorted(const int32_t *a, int m, int32_t x
   return a[lo < m ? lo : m - 1] == x && lo < m;
 }
 
+// four independent searches advanced in lockstep: 4 gathers in flight per round
+__device__ __forceinline__ void member_sorted_x4(const int32_t *a, int m, const int32_t (&x)[4],
+                                                 int iters, bool (&found)[4]) {
+  int lo[4], hi[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    lo[u] = 0;
+    hi[u] = m;
+  }
+  for (int it = 0; it < iters; ++it) {
+    int32_t val[4];
+    int mid[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      mid[u] = (lo[u] + hi[u]) >> 1;
+      val[u] = a[mid[u] < m ? mid[u] : m - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool act = lo[u] < hi[u];
+      const bool less = val[u] < x[u];
+      lo[u] = (act && less) ? mid[u] + 1 : lo[u];
+      hi[u] = (act && !less) ? mid[u] : hi[u];
+    }
+  }
+  int32_t fin[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) fin[u] = a[lo[u] < m ? lo[u] : m - 1];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) found[u] = fin[u] == x[u] && lo[u] < m;
+}
+
 // biased weight of element chunk*64+lane (randomwalk.py:219-231); 0 past the row
 template <bool kFromCache>
 __device__ __forceinline__ double chunk_bias(const StepCtx &c, int chunk, int lane,
@@ -48,7 +80,11 @@ __device__ __forceinline__ double chunk_bias(const StepCtx &c, int chunk, int la
     int32_t x = valid ? c.vcol[i] : -1;
     is_ret = valid && x == c.s;
     is_mem = false;
+#if defined(N2V_ABLATE) && (N2V_ABLATE & 2)  // timing-only build: no membership search
+    if (c.need_mem) is_mem = false;
+#else
     if (c.need_mem) is_mem = member_sorted(c.scol, c.m, x, c.iters) && valid && !is_ret;
+#endif
     if (!kFromCache && chunk < kLdsChunks) {
       uint64_t rm = ballot64(is_ret), mm = ballot64(is_mem);
       if (lane == 0) {

@@ -27,97 +27,414 @@
 
 namespace n2v {
 
+#ifdef N2V_STATS
+__device__ unsigned long long n2v_stats[32];
+struct WaveStats { unsigned long long v[32]; };
+#define N2V_STATS_ARG , WaveStats &WS
+#define N2V_STATS_PASS , WS
+#define N2V_STAT(i, v_) do { WS.v[i] += (unsigned long long)(v_); } while (0)
+#define N2V_T0 unsigned long long n2v_tprev = __builtin_readcyclecounter();
+#define N2V_T(i) do { unsigned long long tn_ = __builtin_readcyclecounter(); WS.v[i] += tn_ - n2v_tprev; n2v_tprev = tn_; } while (0)
+#else
+#define N2V_T0
+#define N2V_T(i) do { } while (0)
+#define N2V_STATS_ARG
+#define N2V_STATS_PASS
+#define N2V_STAT(i, v) do { } while (0)
+#endif
+
+constexpr int kBqCap = 1024;      // scaled biased weights of the LAST kBqCap neighbours
+constexpr int kBitWordsMax = 512;  // membership filter: up to 16384 bits
+constexpr int kMaybeCap = 256;     // filter hits waiting for exact verification
+
+struct WaveLds {
+  uint64_t cls[2 * kLdsChunks];  // per 64-neighbour chunk: ballot(return), ballot(shared)
+  int32_t bq[kBqCap];            // b * 2^20 at position n-1-i (valid in exact-sum mode)
+  uint32_t bits[kBitWordsMax];   // hashed id filter of N(s)
+  int32_t mlist[kMaybeCap];      // indices into N(v) that hit the filter
+};
+
+__device__ __forceinline__ uint32_t hash_id(int32_t y, int shift) {
+  return ((uint32_t)y * 2654435761u) >> shift;
+}
+
+struct SumState {
+  int64_t isum;
+  bool exact;
+  double b_pick, bmin, bmax;
+};
+
+__device__ __forceinline__ void account(SumState &st, WaveLds &L, const StepCtx &c, int i,
+                                        bool act, double b, int lane, int pick) {
+  const double t = b * 1048576.0;
+  const bool ok = (t >= 0.0) && (t < 2147483648.0) && (t == trunc(t));
+  st.exact = st.exact && (ok || !act);
+  st.isum += (ok && act) ? (int64_t)t : 0;
+  if (act) {
+    const int pos = c.n - 1 - i;
+    if (pos < kBqCap) L.bq[pos] = ok ? (int32_t)t : 0;
+    st.bmin = fmin(st.bmin, b);
+    st.bmax = fmax(st.bmax, b);
+  }
+  const uint64_t pm = ballot64(act && i == pick);
+  if (pm) st.b_pick = readlane_f64(b, __ffsll((long long)pm) - 1);
+}
+
+// exact membership for the filter hits collected in L.mlist[0, count)
+__device__ __forceinline__ void verify_maybes(const StepCtx &c, WaveLds &L, int count, int lane,
+                                              int pick, SumState &st) {
+  for (int k = 0; k < count; k += 64) {
+    const bool act = k + lane < count;
+    const int i = act ? L.mlist[k + lane] : 0;
+    const int32_t x = act ? c.vcol[i] : -1;
+    const double wt = act ? (double)c.vw[i] : 0.0;
+    const bool mem = member_sorted(c.scol, c.m, x, c.iters) && act;
+    const double b = mem ? wt : wt / c.q;  // :226-230
+    if (mem && (i >> 6) < kLdsChunks)
+      atomicOr(reinterpret_cast<unsigned long long *>(&L.cls[2 * (i >> 6) + 1]),
+               1ull << (i & 63));
+    account(st, L, c, i, act, b, lane, pick);
+  }
+}
+
+// probs0 of chunk `chunk` (w_biased / avg); from the LDS cache when it covers the chunk
+__device__ __forceinline__ double load_vals(const StepCtx &c, WaveLds &L, int chunk, int lane,
+                                            bool bq_valid, double avg, bool &valid) {
+  const int i = chunk * 64 + lane;
+  if (bq_valid && c.n - 1 - chunk * 64 < kBqCap) {  // wave-uniform: whole chunk cached
+    valid = i < c.n;
+    const int pos = c.n - 1 - i;
+    const double b = valid ? (double)L.bq[pos] * (1.0 / 1048576.0) : 0.0;
+    return b / avg;
+  }
+  return chunk_bias<true>(c, chunk, lane, L.cls, valid) / avg;
+}
+
+// The while-loop of generate_alias_tables (:182-189), replayed until alias[pick] and
+// probs[pick] are final.  Equivalent formulation of the two Python stacks: the top
+// of `overfull` is always the current `over` (it is re-pushed while >= 1.0), and an
+// `over` that drops below 1.0 is pushed on `underfull` and is therefore the very
+// next `under`.  So: outer loop = one overfull slot per iteration (descending
+// index), inner loop = that slot absorbing underfull slots (descending index) with
+// the reference's two fp64 operations, until it is demoted (carry).  Candidates
+// come 64 at a time from ballots over a chunk of probs0 = b / avg.
+template <bool kCached>
+__device__ __forceinline__ int pairing(const StepCtx &c, WaveLds &L, int lane, int pick,
+                                       double avg, double p_pick, double r2, bool bq_valid N2V_STATS_ARG) {
+  const int n = c.n;
+  // Rows longer than the LDS cache re-read their weights from HBM/L2.  The loop
+  // below is serial, so that latency would be fully exposed at every refill: each
+  // stream therefore keeps the NEXT chunk's weights in flight (wnext) while the
+  // current 64 candidates are consumed.
+  auto fetch_w = [&](int chunk) -> float {
+    const int i = chunk * 64 + lane;
+    return (chunk >= 0 && i < n) ? c.vw[i] : 0.0f;
+  };
+  auto load_s = [&](int chunk, float &wnext, int &wnext_chunk, bool &valid) -> double {
+    const int i = chunk * 64 + lane;
+    if (kCached || (bq_valid && n - 1 - chunk * 64 < kBqCap)) {  // wave-uniform
+      valid = i < n;
+      const double b = valid ? (double)L.bq[n - 1 - i] * (1.0 / 1048576.0) : 0.0;
+      return b / avg;
+    }
+    if (c.need_cls && chunk >= kLdsChunks)  // classes not cached: search again
+      return chunk_bias<true>(c, chunk, lane, L.cls, valid) / avg;
+    valid = i < n;
+    const float wf = (wnext_chunk == chunk) ? wnext : fetch_w(chunk);
+    wnext = fetch_w(chunk - 1);
+    wnext_chunk = chunk - 1;
+    const double wt = valid ? (double)wf : 0.0;
+    double b = wt;
+    if (c.need_cls) {
+      const bool is_ret = (L.cls[2 * chunk] >> lane) & 1ull;
+      const bool is_mem = (L.cls[2 * chunk + 1] >> lane) & 1ull;
+      if (is_ret)
+        b = wt / c.p;
+      else if (!(is_mem || !c.need_mem))
+        b = wt / c.q;
+    }
+    return b / avg;
+  };
+  float wu_next = 0.0f, wo_next = 0.0f;
+  int wu_chunk = -2, wo_chunk = -2;
+  int cu = c.nch, co = c.nch;
+  uint64_t um = 0, om = 0;
+  double uval = 0.0, oval = 0.0;
+  bool carry = false;
+  double carry_r = 0.0;
+  int carry_idx = 0;
+  double fin_prob = p_pick;
+  int fin_alias = 0;
+  for (;;) {
+    N2V_STAT(9, 1);
+    while (om == 0ull && co > 0) {  // next overfull candidates
+      --co;
+      bool valid;
+      oval = load_s(co, wo_next, wo_chunk, valid);
+      om = ballot64(valid && !(oval < 1.0));
+    }
+    if (om == 0ull) {  // `overfull` empty: a demoted slot keeps alias 0
+      if (carry && carry_idx == pick) fin_prob = carry_r;
+      break;
+    }
+    const int lo = 63 - __clzll((long long)om);
+    om ^= 1ull << lo;
+    double r = readlane_f64(oval, lo);
+    const int o_idx = co * 64 + lo;
+    if (carry) {  // under = the slot demoted last iteration
+      if (carry_idx == pick) {
+        fin_prob = carry_r;
+        fin_alias = o_idx;
+        break;
+      }
+      r = readfirstlane_f64(r + carry_r - 1.0);
+      carry = false;
+      if (r < 1.0) {
+        carry = true;
+        carry_r = r;
+        carry_idx = o_idx;
+        continue;
+      }
+    }
+    bool finished = false;
+    for (;;) {  // `over` absorbs underfull slots
+      N2V_STAT(8, 1);
+      while (um == 0ull && cu > 0) {
+        --cu;
+        bool valid;
+        uval = load_s(cu, wu_next, wu_chunk, valid);
+        um = ballot64(valid && uval < 1.0);
+      }
+      if (um == 0ull) {  // `underfull` empty
+        if (o_idx == pick) fin_prob = r;
+        finished = true;
+        break;
+      }
+      const int l = 63 - __clzll((long long)um);
+      um ^= 1ull << l;
+      const double pu = readlane_f64(uval, l);
+      if (cu * 64 + l == pick) {  // alias[under] = over; probs[under] is final
+        fin_prob = pu;
+        fin_alias = o_idx;
+        finished = true;
+        break;
+      }
+      r = readfirstlane_f64(r + pu - 1.0);  // probs[over] = probs[over] + probs[under] - 1.0
+      if (r < 1.0) {  // demoted: it is the next `under`
+        carry = true;
+        carry_r = r;
+        carry_idx = o_idx;
+        break;
+      }
+    }
+    if (finished) break;
+  }
+  return (r2 < fin_prob) ? pick : fin_alias;  // :95-99
+}
+
 // Index drawn by sampling_from_alias(r1, r2) on the table that
 // generate_edge_alias_tables would build.  Returns -1 on ZeroDivisionError.
 __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_t u2,
-                                          int lane, uint64_t *cls) {
+                                          int lane, WaveLds &L N2V_STATS_ARG) {
   const int n = c.n;
   const int pick = (int)__umulhi(u1, (uint32_t)n);  // int(r1 * n), r1 = u1 / 2^32
   const double r2 = (double)u2 * (1.0 / 4294967296.0);
 
-  // ---- pass 1: bias + sum ---------------------------------------------------
-  double b_pick;
-  const double total = row_sum(c, lane, cls, pick, b_pick);
+  N2V_T0
+  // ---- pass 0: hashed-id filter of N(s) in LDS ---------------------------------
+  // Membership "x in N(s)" (:226) costs a dependent chain of ~log2(m) gathers per
+  // 64 neighbours when searched directly.  Instead every y of N(s) sets one bit;
+  // pass 1 tests one bit per x; only the hits (true members + a few false
+  // positives) are verified by binary search, batched once per step.
+#if defined(N2V_ABLATE) && (N2V_ABLATE & 8)  // timing-only: no filter, no search at all
+  const bool use_filter = false;
+#else
+  const bool use_filter = c.need_mem && c.m <= 8192 && c.m <= 8 * n + 64;
+#endif
+  int shift = 32;
+  if (use_filter) {
+    int words = 64;
+    while (words < kBitWordsMax && words * 32 < 16 * c.m) words <<= 1;
+    shift = 32 - (5 + (31 - __clz(words)));
+    for (int wv = lane; wv < words; wv += 64) L.bits[wv] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int yb = 0; yb < c.m; yb += 256) {  // 4 loads in flight per lane
+      int32_t y[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = yb + u * 64 + lane;
+        y[u] = j < c.m ? c.scol[j] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (yb + u * 64 + lane < c.m) {
+          const uint32_t h = hash_id(y[u], shift);
+          atomicOr(&L.bits[h >> 5], 1u << (h & 31));
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  N2V_T(16);
+  N2V_STAT(0, 1); N2V_STAT(1, use_filter ? 1 : 0); N2V_STAT(2, (c.need_mem && !use_filter) ? 1 : 0);
+  // ---- pass 1: stream N(v): classify, bias, sum ----------------------------------
+  SumState st;
+  st.isum = 0;
+  st.exact = true;
+  st.b_pick = 0.0;
+  st.bmin = __builtin_huge_val();
+  st.bmax = -__builtin_huge_val();
+  int mcount = 0;
+  constexpr int kU = 4;  // chunks per iteration: 2 * kU global loads in flight per lane
+  for (int chunk0 = 0; chunk0 < c.nch; chunk0 += kU) {
+    float wf[kU];
+    int32_t xs[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int i = (chunk0 + u) * 64 + lane;
+      const bool valid = i < n;
+      wf[u] = valid ? c.vw[i] : 0.0f;
+      xs[u] = (valid && c.need_cls) ? c.vcol[i] : -1;
+    }
+    bool memv[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) memv[u] = false;
+    if (c.need_mem && !use_filter) {
+#if !(defined(N2V_ABLATE) && (N2V_ABLATE & 2))
+      member_sorted_x4(c.scol, c.m, xs, c.iters, memv);  // 4 interleaved searches
+#endif
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int chunk = chunk0 + u;
+      if (chunk >= c.nch) break;  // wave-uniform
+      const int i = chunk * 64 + lane;
+      const bool valid = i < n;
+      const double wt = (double)wf[u];
+      bool is_ret = false, is_mem = false, maybe = false;
+      if (c.need_cls) {
+        const int32_t x = xs[u];
+        is_ret = valid && x == c.s;
+        if (use_filter) {
+          const uint32_t h = hash_id(x, shift);
+          maybe = valid && !is_ret && ((L.bits[h >> 5] >> (h & 31)) & 1u);
+        } else if (c.need_mem) {
+          is_mem = memv[u] && valid && !is_ret;
+        }
+        if (chunk < kLdsChunks) {
+          const uint64_t rm = ballot64(is_ret), mm = ballot64(is_mem);
+          if (lane == 0) {
+            L.cls[2 * chunk] = rm;
+            L.cls[2 * chunk + 1] = mm;
+          }
+        }
+      }
+      double b;
+      if (is_ret)
+        b = wt / c.p;  // :223-224
+      else if (is_mem || !c.need_mem)
+        b = wt;        // :226-227 (and q == 1)
+      else
+        b = wt / c.q;  // :229-230
+      account(st, L, c, i, valid && !maybe, b, lane, pick);
+      const uint64_t mm = ballot64(maybe);
+      if (mm) {
+        const int cnt = __popcll(mm);
+        if (mcount + cnt > kMaybeCap) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          verify_maybes(c, L, mcount, lane, pick, st);
+          mcount = 0;
+        }
+        if (maybe) L.mlist[mcount + __popcll(mm & ((1ull << lane) - 1ull))] = i;
+        mcount += cnt;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  N2V_T(17);
+#if !(defined(N2V_ABLATE) && (N2V_ABLATE & 4))  // timing-only: no verification of filter hits
+  if (mcount) verify_maybes(c, L, mcount, lane, pick, st);
+#endif
+  N2V_STAT(3, mcount); N2V_STAT(4, (mcount + 63) / 64);
+  N2V_T(18);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- sum in the reference's order (:172) ---------------------------------------
+  const bool bq_valid = ballot64(!st.exact) == 0ull && n <= (1 << 21);
+  double total, b_pick = st.b_pick;
+  if (bq_valid) {
+    // every b is a multiple of 2^-20 below 2^11: all partial sums are exactly
+    // representable, any order gives the reference's bits
+    total = (double)wave_sum_i64(st.isum) * (1.0 / 1048576.0);
+  } else {
+    total = 0.0;  // left to right, one rounding per add
+    for (int chunk = 0; chunk < c.nch; ++chunk) {
+      bool valid;
+      const double b = chunk_bias<true>(c, chunk, lane, L.cls, valid);
+      const int cnt = min(64, n - chunk * 64);
+      for (int j = 0; j < cnt; ++j) total = total + readlane_f64(b, j);
+    }
+  }
   const double avg = total / (double)n;  // :172
   if (avg == 0.0) return -1;
   const double p_pick = b_pick / avg;    // :173
 
+  N2V_T(19);
   // untouched underfull slot: probs[pick] never changes, alias irrelevant
   if (p_pick < 1.0 && r2 < p_pick) return pick;
-
-  // ---- pass 2: LIFO pairing (:182-189) until slot `pick` is final ------------
-  int cu = c.nch, co = c.nch;
-  uint64_t um = 0, om = 0;
-  double uval = 0.0, oval = 0.0;
-  bool have_dem = false, have_o = false;
-  double dem_r = 0.0, r = 0.0;
-  int dem_idx = 0, o_idx = 0;
-  double fin_prob = p_pick;
-  int fin_alias = 0;
-  for (;;) {
-    double pu;
-    int ui;
-    if (have_dem) {  // the just-demoted overfull is the top of `underfull`
-      pu = dem_r;
-      ui = dem_idx;
-      have_dem = false;
-    } else {
-      while (um == 0ull && cu > 0) {
-        --cu;
-        bool valid;
-        uval = chunk_bias<true>(c, cu, lane, cls, valid) / avg;
-        um = ballot64(valid && uval < 1.0);
-      }
-      if (um == 0ull) {  // underfull empty
-        if (have_o && o_idx == pick) fin_prob = r;
-        break;
-      }
-      int l = 63 - __clzll((long long)um);
-      um &= ~(1ull << l);
-      pu = readlane_f64(uval, l);
-      ui = cu * 64 + l;
-    }
-    if (!have_o) {
-      while (om == 0ull && co > 0) {
-        --co;
-        bool valid;
-        oval = chunk_bias<true>(c, co, lane, cls, valid) / avg;
-        om = ballot64(valid && !(oval < 1.0));
-      }
-      if (om == 0ull) {  // overfull empty: `under` stays where it was
-        if (ui == pick) fin_prob = pu;
-        break;
-      }
-      int l = 63 - __clzll((long long)om);
-      om &= ~(1ull << l);
-      r = readlane_f64(oval, l);
-      o_idx = co * 64 + l;
-      have_o = true;
-    }
-    if (ui == pick) {  // alias[under] = over; probs[under] is final
-      fin_prob = pu;
-      fin_alias = o_idx;
-      break;
-    }
-    r = r + pu - 1.0;  // probs[over] = probs[over] + probs[under] - 1.0
-    if (r < 1.0) {
-      have_dem = true;
-      dem_r = r;
-      dem_idx = o_idx;
-      have_o = false;
-    }
+  N2V_STAT(5, 1);
+#if defined(N2V_ABLATE) && (N2V_ABLATE & 1)  // timing-only build: no pairing pass
+  return pick;
+#endif
+  // x -> x / avg is monotone, so the extreme weights decide whether either stack
+  // is empty; then the pairing loop (:182) never runs: alias stays 0, probs stay.
+#if defined(N2V_ABLATE) && (N2V_ABLATE & 64)  // timing-only: stop before the min/max shortcut
+  return pick;
+#endif
+  double bmin = st.bmin, bmax = st.bmax;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    bmin = fmin(bmin, __shfl_xor(bmin, off, 64));
+    bmax = fmax(bmax, __shfl_xor(bmax, off, 64));
   }
-  return (r2 < fin_prob) ? pick : fin_alias;  // :95-99
+  N2V_T(20);
+  if (!(bmin / avg < 1.0) || (bmax / avg < 1.0)) return (r2 < p_pick) ? pick : 0;
+
+  N2V_STAT(6, 1); N2V_STAT(7, n <= 64 ? 1 : 0); N2V_STAT(10, (bq_valid && n <= kBqCap) ? 0 : 1);
+  // ---- pass 2: LIFO pairing (:182-189) until slot `pick` is final ------------
+#if defined(N2V_ABLATE) && (N2V_ABLATE & 16)  // timing-only: run the pairing twice
+  if (bq_valid && n <= kBqCap) {
+    int tmp = pairing<true>(c, L, lane, pick, avg, p_pick, r2, bq_valid N2V_STATS_PASS);
+    asm volatile("" ::"v"(tmp));
+  }
+#endif
+  if (bq_valid && n <= kBqCap) {
+    const int res = pairing<true>(c, L, lane, pick, avg, p_pick, r2, bq_valid N2V_STATS_PASS);
+    N2V_T(21);
+    return res;
+  }
+#if defined(N2V_ABLATE) && (N2V_ABLATE & 32)  // timing-only: no pairing on uncached rows
+  return pick;
+#endif
+  const int res2 = pairing<false>(c, L, lane, pick, avg, p_pick, r2, bq_valid N2V_STATS_PASS);
+  N2V_T(22);
+  return res2;
 }
 
 __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double p, double q, uint64_t seed, int32_t *__restrict__ walks_out,
     uint8_t *__restrict__ valid_out, uint32_t *__restrict__ status) {
-  __shared__ uint64_t cls_all[kWavesPerBlock][2 * kLdsChunks];
+  __shared__ WaveLds lds_all[kWavesPerBlock];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
-  uint64_t *cls = cls_all[wave_in_block];
+  WaveLds &L = lds_all[wave_in_block];
   const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
   const int64_t total = n_start * (int64_t)num_walks;
   const int L1 = walk_length + 1;
@@ -125,6 +442,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
   StepCtx c;
   c.p = p;
   c.q = q;
+#ifdef N2V_STATS
+  WaveStats WS;
+  for (int i = 0; i < 32; ++i) WS.v[i] = 0;
+  const unsigned long long t_kernel0 = __builtin_readcyclecounter();
+#endif
 
   for (int64_t rr = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block; rr < total;
        rr += n_waves) {
@@ -177,7 +499,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
           c.iters = 32 - __clz(c.m);
         }
         const uint64_t bits = step_bits(h0, (uint32_t)step);
-        const int idx = exact_draw(c, (uint32_t)(bits >> 32), (uint32_t)bits, lane, cls);
+        const int idx = exact_draw(c, (uint32_t)(bits >> 32), (uint32_t)bits, lane, L N2V_STATS_PASS);
         if (idx < 0) {
           if (lane == 0) atomicOr(status, N2V_ST_ZERODIV);
           alive = false;
@@ -191,6 +513,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
     }
     if (lane == 0) valid_out[r] = alive ? 1 : 0;
   }
+#ifdef N2V_STATS
+  WS.v[23] = __builtin_readcyclecounter() - t_kernel0;
+  if (lane == 0)
+    for (int i = 0; i < 32; ++i) atomicAdd(&n2v_stats[i], WS.v[i]);
+#endif
 }
 
 }  // namespace n2v
@@ -210,3 +537,14 @@ extern "C" int n2v_walk_exact_launch(const n2v_graph *g, const int32_t *start_id
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
 }
+
+#ifdef N2V_STATS
+extern "C" int n2v_debug_stats(unsigned long long *out_host, int reset) {
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(n2v::n2v_stats), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(n2v::n2v_stats), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
