@@ -60,7 +60,9 @@ typedef struct n2v_graph {
   int64_t n_edges;
   const int64_t *rowptr; /* [n_vertices + 1] */
   const int32_t *col;    /* [n_edges] */
-  const float *w;        /* [n_edges] fp32 storage, widened to fp64 for arithmetic */
+  const float *w;        /* [n_edges] fp32 storage, widened to fp64 for arithmetic;
+                            NULL = every weight is 1.0 (unweighted graph): the walk
+                            kernels then never read weights */
   const n2v_slot *slots; /* [n_edges] */
 } n2v_graph;
 

@@ -9,6 +9,14 @@ namespace n2v {
 constexpr int kWavesPerBlock = 4;
 constexpr int kLdsChunks = 128;  // class ballots kept in LDS for rows <= 8192
 
+constexpr int kBitWordsMax = 512;  // membership filter: up to 16384 bits
+constexpr int kMaybeCap = 256;     // filter hits waiting for exact verification
+
+// multiplicative hash of a vertex id onto the filter's bit range
+__device__ __forceinline__ uint32_t hash_id(int32_t y, int shift) {
+  return ((uint32_t)y * 2654435761u) >> shift;
+}
+
 struct StepCtx {
   const int32_t *vcol;  // N(v) ids
   const float *vw;      // N(v) weights
@@ -70,7 +78,7 @@ __device__ __forceinline__ double chunk_bias(const StepCtx &c, int chunk, int la
                                              uint64_t *cls, bool &valid) {
   const int i = chunk * 64 + lane;
   valid = i < c.n;
-  double wt = valid ? (double)c.vw[i] : 0.0;
+  double wt = valid ? (c.vw ? (double)c.vw[i] : 1.0) : 0.0;
   if (!c.need_cls) return wt;
   bool is_ret, is_mem;
   if (kFromCache && chunk < kLdsChunks) {

@@ -6,6 +6,10 @@ int n2v_walk_exact_launch(const n2v_graph *g, const int32_t *start_ids, int64_t 
                           int32_t num_walks, int32_t walk_length, double p, double q,
                           uint64_t seed, int32_t *walks_out, uint8_t *valid_out,
                           uint32_t *status, void *stream);
+int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
+                            int32_t num_walks, int32_t walk_length, double p, double q,
+                            uint64_t seed, int32_t *walks_out, uint8_t *valid_out,
+                            uint32_t *status, void *stream);
 int n2v_walk_fast_launch(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
                          int32_t num_walks, int32_t walk_length, double p, double q,
                          uint64_t seed, int32_t *walks_out, uint8_t *valid_out,
@@ -33,14 +37,20 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start, int3
              int32_t walk_length, double return_param, double inout_param, uint64_t seed,
              int32_t mode, int32_t *walks_out, uint8_t *valid_out, uint32_t *status,
              void *stream) {
-  if (!g || !g->rowptr || !g->col || !g->w || n_start < 0 || num_walks < 0 || walk_length < 0)
+  if (!g || !g->rowptr || !g->col || n_start < 0 || num_walks < 0 || walk_length < 0)
     return N2V_EINVAL;
   if (n_start > 0 && (!start_ids || !walks_out || !valid_out || !status)) return N2V_EINVAL;
   // generate_edge_alias_tables raises ValueError on p == 0 or q == 0 (randomwalk.py:214-217)
   if (return_param == 0.0 || inout_param == 0.0) return N2V_EINVAL;
-  if (mode == N2V_WALK_EXACT)
+  if (mode == N2V_WALK_EXACT) {
+    // w == NULL: every weight is 1.0; the specialised kernel applies when 1/p, 1/q scale exactly
+    const int rc = n2v_walk_exact_unit_try(g, start_ids, n_start, num_walks, walk_length,
+                                           return_param, inout_param, seed, walks_out,
+                                           valid_out, status, stream);
+    if (rc != 0) return rc < 0 ? rc : N2V_OK;
     return n2v_walk_exact_launch(g, start_ids, n_start, num_walks, walk_length, return_param,
                                  inout_param, seed, walks_out, valid_out, status, stream);
+  }
   if (mode == N2V_WALK_FAST) {
     if (!g->slots) return N2V_EINVAL;
     return n2v_walk_fast_launch(g, start_ids, n_start, num_walks, walk_length, return_param,

@@ -44,8 +44,6 @@ struct WaveStats { unsigned long long v[32]; };
 #endif
 
 constexpr int kBqCap = 1024;      // scaled biased weights of the LAST kBqCap neighbours
-constexpr int kBitWordsMax = 512;  // membership filter: up to 16384 bits
-constexpr int kMaybeCap = 256;     // filter hits waiting for exact verification
 
 struct WaveLds {
   uint64_t cls[2 * kLdsChunks];  // per 64-neighbour chunk: ballot(return), ballot(shared)
@@ -53,10 +51,6 @@ struct WaveLds {
   uint32_t bits[kBitWordsMax];   // hashed id filter of N(s)
   int32_t mlist[kMaybeCap];      // indices into N(v) that hit the filter
 };
-
-__device__ __forceinline__ uint32_t hash_id(int32_t y, int shift) {
-  return ((uint32_t)y * 2654435761u) >> shift;
-}
 
 struct SumState {
   int64_t isum;
@@ -87,7 +81,7 @@ __device__ __forceinline__ void verify_maybes(const StepCtx &c, WaveLds &L, int 
     const bool act = k + lane < count;
     const int i = act ? L.mlist[k + lane] : 0;
     const int32_t x = act ? c.vcol[i] : -1;
-    const double wt = act ? (double)c.vw[i] : 0.0;
+    const double wt = act ? (c.vw ? (double)c.vw[i] : 1.0) : 0.0;
     const bool mem = member_sorted(c.scol, c.m, x, c.iters) && act;
     const double b = mem ? wt : wt / c.q;  // :226-230
     if (mem && (i >> 6) < kLdsChunks)
@@ -128,7 +122,7 @@ __device__ __forceinline__ int pairing(const StepCtx &c, WaveLds &L, int lane, i
   // current 64 candidates are consumed.
   auto fetch_w = [&](int chunk) -> float {
     const int i = chunk * 64 + lane;
-    return (chunk >= 0 && i < n) ? c.vw[i] : 0.0f;
+    return (chunk >= 0 && i < n) ? (c.vw ? c.vw[i] : 1.0f) : 0.0f;
   };
   auto load_s = [&](int chunk, float &wnext, int &wnext_chunk, bool &valid) -> double {
     const int i = chunk * 64 + lane;
@@ -296,7 +290,7 @@ __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_
     for (int u = 0; u < kU; ++u) {
       const int i = (chunk0 + u) * 64 + lane;
       const bool valid = i < n;
-      wf[u] = valid ? c.vw[i] : 0.0f;
+      wf[u] = valid ? (c.vw ? c.vw[i] : 1.0f) : 0.0f;
       xs[u] = (valid && c.need_cls) ? c.vcol[i] : -1;
     }
     bool memv[kU];
@@ -481,7 +475,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
           break;
         }
         c.vcol = g.col + vb;
-        c.vw = g.w + vb;
+        c.vw = g.w ? g.w + vb : nullptr;
         c.n = n;
         c.nch = (n + 63) >> 6;
         c.s = s;

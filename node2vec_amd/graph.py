@@ -25,6 +25,9 @@ class DeviceGraph:
         self.col = col.contiguous()
         self.w = w.contiguous()
         self.slots: Optional[torch.Tensor] = None  # int32 [E, 4] view of n2v_slot[E]
+        # unweighted graph (index_graph_* gives weight 1.0, indexer.py:20-21): the walk
+        # kernels are told through w == NULL and never read the weights
+        self.unit_weights = bool((self.w == 1.0).all()) if self.w.numel() else True
 
     # -- construction ---------------------------------------------------------
     @classmethod
@@ -84,7 +87,7 @@ class DeviceGraph:
 
     def c_struct(self) -> _lib.Graph:
         return _lib.Graph(self.n_vertices, self.n_edges, self.rowptr.data_ptr(),
-                          self.col.data_ptr(), self.w.data_ptr(),
+                          self.col.data_ptr(), 0 if self.unit_weights else self.w.data_ptr(),
                           0 if self.slots is None else self.slots.data_ptr())
 
     # -- K1 -----------------------------------------------------------------------
