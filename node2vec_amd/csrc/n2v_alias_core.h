@@ -9,6 +9,23 @@ namespace n2v {
 constexpr int kWavesPerBlock = 4;
 constexpr int kLdsChunks = 128;  // class ballots kept in LDS for rows <= 8192
 
+// diagnostic build only (-DN2V_STATS): per-wave counters / cycle stamps, flushed once
+#ifdef N2V_STATS
+static __device__ unsigned long long n2v_stats[32];  // one copy per translation unit
+struct WaveStats { unsigned long long v[32]; };
+#define N2V_STATS_ARG , WaveStats &WS
+#define N2V_STATS_PASS , WS
+#define N2V_STAT(i, v_) do { WS.v[i] += (unsigned long long)(v_); } while (0)
+#define N2V_T0 unsigned long long n2v_tprev = __builtin_readcyclecounter();
+#define N2V_T(i) do { unsigned long long tn_ = __builtin_readcyclecounter(); WS.v[i] += tn_ - n2v_tprev; n2v_tprev = tn_; } while (0)
+#else
+#define N2V_T0
+#define N2V_T(i) do { } while (0)
+#define N2V_STATS_ARG
+#define N2V_STATS_PASS
+#define N2V_STAT(i, v) do { } while (0)
+#endif
+
 constexpr int kBitWordsMax = 512;  // membership filter: up to 16384 bits
 constexpr int kMaybeCap = 256;     // filter hits waiting for exact verification
 

@@ -27,22 +27,6 @@
 
 namespace n2v {
 
-#ifdef N2V_STATS
-__device__ unsigned long long n2v_stats[32];
-struct WaveStats { unsigned long long v[32]; };
-#define N2V_STATS_ARG , WaveStats &WS
-#define N2V_STATS_PASS , WS
-#define N2V_STAT(i, v_) do { WS.v[i] += (unsigned long long)(v_); } while (0)
-#define N2V_T0 unsigned long long n2v_tprev = __builtin_readcyclecounter();
-#define N2V_T(i) do { unsigned long long tn_ = __builtin_readcyclecounter(); WS.v[i] += tn_ - n2v_tprev; n2v_tprev = tn_; } while (0)
-#else
-#define N2V_T0
-#define N2V_T(i) do { } while (0)
-#define N2V_STATS_ARG
-#define N2V_STATS_PASS
-#define N2V_STAT(i, v) do { } while (0)
-#endif
-
 constexpr int kBqCap = 1024;      // scaled biased weights of the LAST kBqCap neighbours
 
 struct WaveLds {

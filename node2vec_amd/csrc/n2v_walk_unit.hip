@@ -21,13 +21,33 @@
 
 namespace n2v {
 
-constexpr int kUC = 256;  // class ballots cached for the TOP 256 chunks (16384 neighbours)
+constexpr int kUC = 128;     // class ballots cached for the TOP 128 chunks (8192 neighbours)
+constexpr int kYsCap = 1024;  // N(s) staged in LDS when it has at most this many ids
+constexpr int kBitsA = 256;   // filter words beside a staged N(s)        (8192 bits)
+constexpr int kBitsB = 1024;  // filter words when N(s) is not staged     (32768 bits)
 
+// 8 KB per wave.  `pool` is either {staged ids of N(s)} (m <= kYsCap, filter in
+// `bits`) or one large filter (kYsCap < m <= 8192).
 struct UnitLds {
-  uint64_t cls[2 * kUC];        // slot nch-1-chunk: ballot(return), ballot(shared)
-  uint32_t bits[kBitWordsMax];  // hashed-id filter of N(s)
-  int32_t mlist[kMaybeCap];     // filter hits waiting for verification
+  uint64_t cls[2 * kUC];     // slot nch-1-chunk: ballot(return), ballot(shared)
+  uint32_t bits[kBitsA];     // small filter
+  int32_t mlist[kMaybeCap];  // filter hits waiting for verification
+  uint32_t pool[kYsCap];     // staged N(s)  |  large filter
 };
+
+// binary search over ids staged in LDS (no global gathers on the dependent chain)
+__device__ __forceinline__ bool member_lds(const uint32_t *ys, int m, int32_t x, int iters) {
+  int lo = 0, hi = m;
+  for (int it = 0; it < iters; ++it) {
+    const int mid = (lo + hi) >> 1;
+    const int32_t val = (int32_t)ys[mid < m ? mid : m - 1];
+    const bool act = lo < hi;
+    const bool less = val < x;
+    lo = (act && less) ? mid + 1 : lo;
+    hi = (act && !less) ? mid : hi;
+  }
+  return (int32_t)ys[lo < m ? lo : m - 1] == x && lo < m;
+}
 
 struct UnitConsts {
   double bR, bM, bO;     // 1/p, 1, 1/q
@@ -66,12 +86,13 @@ __device__ __forceinline__ void chunk_classes(const UnitStep &c, UnitLds &L, int
 }
 
 __device__ __forceinline__ void verify_unit(const UnitStep &c, UnitLds &L, int count, int lane,
-                                            int &nM) {
+                                            bool staged, int &nM) {
   for (int k = 0; k < count; k += 64) {
     const bool act = k + lane < count;
     const int i = act ? L.mlist[k + lane] : 0;
     const int32_t x = act ? c.vcol[i] : -1;
-    const bool mem = member_sorted(c.scol, c.m, x, c.iters) && act;
+    const bool mem = (staged ? member_lds(L.pool, c.m, x, c.iters)
+                             : member_sorted(c.scol, c.m, x, c.iters)) && act;
     const int ci = c.nch - 1 - (i >> 6);
     if (mem && ci < kUC)
       atomicOr(reinterpret_cast<unsigned long long *>(&L.cls[2 * ci + 1]), 1ull << (i & 63));
@@ -80,22 +101,35 @@ __device__ __forceinline__ void verify_unit(const UnitStep &c, UnitLds &L, int c
 }
 
 __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K, uint32_t u1,
-                                         uint32_t u2, int lane, UnitLds &L) {
+                                         uint32_t u2, int lane, UnitLds &L N2V_STATS_ARG) {
   const int n = c.n;
   const int pick = (int)__umulhi(u1, (uint32_t)n);  // int(r1 * n)
   const double r2 = (double)u2 * (1.0 / 4294967296.0);
 
-  // ---- pass 0: hashed-id filter of N(s) ----------------------------------------
-  const bool use_filter = c.need_mem && c.m <= 8192 && c.m <= 8 * n + 64;
+  N2V_T0
+  // ---- pass 0: membership strategy for "x in N(s)" (:226) ---------------------------
+  //  staged  m <= 1024: N(s) is copied into LDS; rows of v up to 2 chunks search it
+  //          directly, longer rows test a hashed-id filter first and verify only the
+  //          hits, by LDS binary search (no global gather on any dependent chain)
+  //  filter  m <= 8192 and not much longer than N(v): large filter, hits verified by
+  //          binary search over global memory, batched once per step
+  //  direct  otherwise (N(s) a hub, N(v) short): per-lane global binary search
+  const bool staged = c.need_mem && c.m <= kYsCap;
+  const bool big_filter = c.need_mem && !staged && c.m <= 8192 && c.m <= 8 * n + 64;
+  const bool use_filter = big_filter || (staged && c.nch > 2);
+  uint32_t *fbits = staged ? L.bits : L.pool;
   int shift = 32;
-  if (use_filter) {
-    int words = 64;
-    while (words < kBitWordsMax && words * 32 < 16 * c.m) words <<= 1;
-    shift = 32 - (5 + (31 - __clz(words)));
-    for (int wv = lane; wv < words; wv += 64) L.bits[wv] = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int yb = 0; yb < c.m; yb += 256) {
+  if (staged || big_filter) {
+    if (use_filter) {
+      const int cap = staged ? kBitsA : kBitsB;
+      int words = 64;
+      while (words < cap && words * 32 < 16 * c.m) words <<= 1;
+      shift = 32 - (5 + (31 - __clz(words)));
+      for (int wv = lane; wv < words; wv += 64) fbits[wv] = 0u;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    for (int yb = 0; yb < c.m; yb += 256) {  // 4 loads in flight per lane
       int32_t y[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -104,9 +138,13 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (yb + u * 64 + lane < c.m) {
-          const uint32_t h = hash_id(y[u], shift);
-          atomicOr(&L.bits[h >> 5], 1u << (h & 31));
+        const int j = yb + u * 64 + lane;
+        if (j < c.m) {
+          if (staged) L.pool[j] = (uint32_t)y[u];
+          if (use_filter) {
+            const uint32_t h = hash_id(y[u], shift);
+            atomicOr(&fbits[h >> 5], 1u << (h & 31));
+          }
         }
       }
     }
@@ -114,6 +152,9 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
     __builtin_amdgcn_wave_barrier();
   }
 
+  N2V_T(16);
+  N2V_STAT(0, 1); N2V_STAT(1, (staged && use_filter) ? 1 : 0); N2V_STAT(2, (c.need_mem && !staged && !big_filter) ? 1 : 0);
+  N2V_STAT(11, (staged && !use_filter) ? 1 : 0); N2V_STAT(12, big_filter ? 1 : 0);
   // ---- pass 1: stream N(v) ids, classify, count ---------------------------------
   int nR = 0, nM = 0, mcount = 0;
   for (int chunk0 = 0; chunk0 < c.nch; chunk0 += 4) {
@@ -124,7 +165,15 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
       xs[u] = i < n ? c.vcol[i] : -1;
     }
     bool memv[4] = {false, false, false, false};
-    if (c.need_mem && !use_filter) member_sorted_x4(c.scol, c.m, xs, c.iters, memv);
+    if (c.need_mem && !use_filter) {
+      if (staged) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (chunk0 + u < c.nch) memv[u] = member_lds(L.pool, c.m, xs[u], c.iters);
+      } else {
+        member_sorted_x4(c.scol, c.m, xs, c.iters, memv);  // 4 interleaved searches
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int chunk = chunk0 + u;
@@ -135,7 +184,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
       bool is_mem = false, maybe = false;
       if (use_filter) {
         const uint32_t h = hash_id(xs[u], shift);
-        maybe = valid && !is_ret && ((L.bits[h >> 5] >> (h & 31)) & 1u);
+        maybe = valid && !is_ret && ((fbits[h >> 5] >> (h & 31)) & 1u);
       } else {
         is_mem = memv[u] && valid && !is_ret;
       }
@@ -153,7 +202,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
         if (mcount + cnt > kMaybeCap) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          verify_unit(c, L, mcount, lane, nM);
+          verify_unit(c, L, mcount, lane, staged, nM);
           mcount = 0;
         }
         if (maybe) L.mlist[mcount + __popcll(ym & ((1ull << lane) - 1ull))] = i;
@@ -163,10 +212,13 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  if (mcount) verify_unit(c, L, mcount, lane, nM);
+  N2V_T(17);
+  N2V_STAT(3, mcount);
+  if (mcount) verify_unit(c, L, mcount, lane, staged, nM);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
+  N2V_T(18);
   // ---- :172-173 on three values -----------------------------------------------------
   const int nO = n - nR - nM;
   const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
@@ -176,13 +228,110 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   chunk_classes(c, L, pick >> 6, lane, prm, pmm);
   const bool pR = (prm >> (pick & 63)) & 1ull, pM = (pmm >> (pick & 63)) & 1ull;
   const double p_pick = pR ? vR : (pM ? vM : vO);
+  N2V_T(19);
   if (p_pick < 1.0 && r2 < p_pick) return pick;  // untouched underfull slot
   const bool uR = vR < 1.0, uM = vM < 1.0, uO = vO < 1.0;
   const bool any_under = (nR && uR) || (nM && uM) || (nO && uO);
   const bool any_over = (nR && !uR) || (nM && !uM) || (nO && !uO);
   if (!any_under || !any_over) return (r2 < p_pick) ? pick : 0;  // the loop of :182 never runs
 
-  // ---- pairing (:182-189), candidate masks are scalar --------------------------------
+  N2V_STAT(6, 1);
+  // ---- pairing, count-based fast path ----------------------------------------------
+  // When "other" is the ONLY underfull class every absorbed slot has the same value
+  // vO, so the fp64 sequence of :186 depends on how MANY slots an overfull absorbs,
+  // not on which ones; the identity of a slot matters only to know when `pick` is
+  // next, i.e. its rank among the underfull slots above it -- a popcount over the
+  // class ballots.  The stack discipline is unchanged: overfull slots are taken in
+  // descending index order, a demoted one is absorbed first by its successor.
+  const int top_cached_chunk = c.nch - kUC;  // chunks below this are not in LDS
+  if (uO && !(nR && uR) && !(nM && uM) && (pick >> 6) >= top_cached_chunk) {
+    const int total_u = nO;
+    int above = total_u + 1;  // underfull slots consumed before `pick` is next (never, if overfull)
+    if (!pR && !pM) {
+      int nrm = 0;  // return/shared slots with index > pick
+      const int pc = pick >> 6;
+      for (int base = pc; base < c.nch; base += 64) {
+        const int ch = base + lane;
+        uint64_t w = 0;
+        if (ch < c.nch) {
+          const int ci = c.nch - 1 - ch;
+          w = L.cls[2 * ci] | L.cls[2 * ci + 1];
+          if (ch == pc) w &= ~((2ull << (pick & 63)) - 1ull);
+        }
+        nrm += __popcll(w);
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) nrm += __shfl_xor(nrm, off, 64);
+      above = (n - 1 - pick) - nrm;
+    }
+    int co2 = c.nch, consumed = 0;
+    uint64_t om2 = 0, orm2 = 0, omm2 = 0;
+    bool carry2 = false;
+    double carry2_r = 0.0;
+    int carry2_idx = 0;
+    double fprob = p_pick;
+    int falias = 0;
+    for (;;) {
+      while (om2 == 0ull && co2 > 0) {  // next overfull candidates: return | shared
+        --co2;
+        chunk_classes(c, L, co2, lane, orm2, omm2);
+        om2 = orm2 | omm2;
+      }
+      if (om2 == 0ull) {  // `overfull` empty
+        if (carry2 && carry2_idx == pick) fprob = carry2_r;
+        break;
+      }
+      const int lo = 63 - __clzll((long long)om2);
+      om2 ^= 1ull << lo;
+      double r = ((orm2 >> lo) & 1ull) ? vR : vM;
+      const int o_idx = co2 * 64 + lo;
+      if (carry2) {
+        if (carry2_idx == pick) {
+          fprob = carry2_r;
+          falias = o_idx;
+          break;
+        }
+        r = readfirstlane_f64(r + carry2_r - 1.0);
+        carry2 = false;
+        if (r < 1.0) {
+          carry2 = true;
+          carry2_r = r;
+          carry2_idx = o_idx;
+          continue;
+        }
+      }
+      const int limit = min(total_u, above) - consumed;
+      int j = 0;
+      bool demoted = false;
+      while (j < limit) {  // probs[over] = probs[over] + probs[under] - 1.0
+        N2V_STAT(8, 1);
+        r = r + vO - 1.0;
+        ++j;
+        if (r < 1.0) {
+          demoted = true;
+          break;
+        }
+      }
+      r = readfirstlane_f64(r);
+      consumed += j;
+      if (demoted) {
+        carry2 = true;
+        carry2_r = r;
+        carry2_idx = o_idx;
+        continue;
+      }
+      if (consumed == above) {  // the next `under` is pick: alias[pick] = over
+        fprob = vO;
+        falias = o_idx;
+      } else if (o_idx == pick) {  // `underfull` empty
+        fprob = r;
+      }
+      break;
+    }
+    N2V_T(21);
+    return (r2 < fprob) ? pick : falias;
+  }
+  // ---- pairing (:182-189), general path: candidate masks are scalar -------------------
   int cu = c.nch, co = c.nch;
   uint64_t um = 0, om = 0, urm = 0, umm = 0, orm = 0, omm = 0;
   bool carry = false;
@@ -235,6 +384,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
         finished = true;
         break;
       }
+      N2V_STAT(8, 1);
       const int l = 63 - __clzll((long long)um);
       um ^= 1ull << l;
       const double pu = ((urm >> l) & 1ull) ? vR : (((umm >> l) & 1ull) ? vM : vO);
@@ -254,6 +404,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
     }
     if (finished) break;
   }
+  N2V_T(21);
   return (r2 < fin_prob) ? pick : fin_alias;
 }
 
@@ -272,6 +423,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_unit_kernel(
   const bool biased = !(p == 1.0 && q == 1.0);
   UnitStep c;
   c.need_mem = q != 1.0;
+#ifdef N2V_STATS
+  WaveStats WS;
+  for (int i = 0; i < 32; ++i) WS.v[i] = 0;
+  const unsigned long long t_kernel0 = __builtin_readcyclecounter();
+#endif
 
   for (int64_t rr = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block; rr < total;
        rr += n_waves) {
@@ -319,7 +475,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_unit_kernel(
           c.scol = g.col + sb;
           c.m = m;
           c.iters = 32 - __clz(m);
-          idx = unit_draw(c, K, (uint32_t)(bits >> 32), (uint32_t)bits, lane, L);
+          idx = unit_draw(c, K, (uint32_t)(bits >> 32), (uint32_t)bits, lane, L N2V_STATS_PASS);
         }
         const int32_t next = __builtin_amdgcn_readfirstlane(g.col[vb + idx]);
         if (lane == 0) out[step + 1] = next;
@@ -331,6 +487,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_unit_kernel(
     }
     if (lane == 0) valid_out[r] = alive ? 1 : 0;
   }
+#ifdef N2V_STATS
+  WS.v[23] = __builtin_readcyclecounter() - t_kernel0;
+  if (lane == 0)
+    for (int i = 0; i < 32; ++i) atomicAdd(&n2v_stats[i], WS.v[i]);
+#endif
 }
 
 }  // namespace n2v
@@ -369,3 +530,14 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
   if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
   return 1;
 }
+
+#ifdef N2V_STATS
+extern "C" int n2v_debug_stats_unit(unsigned long long *out_host, int reset) {
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(n2v::n2v_stats), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(n2v::n2v_stats), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
