@@ -158,7 +158,8 @@ def main():
             ach = per_launch_bytes / avg_kernel_s
             out["roofline"] = {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
                                "unit": "GB/s", "frac": ach / HBM_PEAK,
-                               "traffic": _pmc_traffic(), "kernel": "walk_exact_kernel",
+                               "traffic": _pmc_traffic(),
+                               "kernel": "walk_exact_unit_kernel" if g.unit_weights else "walk_exact_kernel",
                                "kernel_ms": 1e3 * avg_kernel_s,
                                "algorithmic_bytes_per_launch": per_launch_bytes,
                                "algorithmic_bytes_per_walk_step": abytes / max(steps_done, 1)}

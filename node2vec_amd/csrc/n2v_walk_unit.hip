@@ -107,6 +107,64 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   const double r2 = (double)u2 * (1.0 / 4294967296.0);
 
   N2V_T0
+  int nR = 0, nM = 0;
+  // ---- reverse classification: search from the SHORTER list --------------------------
+  // The classes of N(v) are needed as ballots and counts, not as a stream.  When N(s)
+  // is much shorter than N(v) (or only the return slot matters, q == 1) it is cheaper
+  // to locate s and every distinct id of N(s) inside the sorted row of v by binary
+  // search and scatter the class bits: O(m log n) instead of O(n), and N(v) is never
+  // read.  Multi-edges: every occurrence of an id in N(v) is marked; a repeated id of
+  // N(s) is searched once.
+  const bool reverse = n > 256 && (!c.need_mem || 2 * c.m < n);
+  if (reverse) {
+    const int ncached = c.nch < kUC ? c.nch : kUC;
+    for (int wv = lane; wv < 2 * ncached; wv += 64) L.cls[wv] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int items = 1 + (c.need_mem ? c.m : 0);  // item 0 = s, item k = N(s)[k-1]
+    const int iters_n = 32 - __clz(n);
+    for (int base = 0; base < items; base += 256) {
+      int32_t x[4];
+      bool isret[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = base + u * 64 + lane;
+        isret[u] = k == 0;
+        x[u] = -1;
+        if (k == 0) {
+          x[u] = c.s;
+        } else if (k < items) {
+          const int32_t y = c.scol[k - 1];
+          const int32_t prev = k >= 2 ? c.scol[k - 2] : -1;
+          x[u] = (y == c.s || y == prev) ? -1 : y;  // return slot / repeated id
+        }
+      }
+      int lo[4];
+      bool found[4];
+      lower_bound_x4(c.vcol, n, x, iters_n, lo, found);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        bool f = found[u] && x[u] >= 0;
+        int j = lo[u];
+        while (ballot64(f) != 0ull) {
+          if (f) {
+            const int ci = c.nch - 1 - (j >> 6);
+            if (ci < kUC)
+              atomicOr(reinterpret_cast<unsigned long long *>(&L.cls[2 * ci + (isret[u] ? 0 : 1)]),
+                       1ull << (j & 63));
+          }
+          nR += __popcll(ballot64(f && isret[u]));
+          nM += __popcll(ballot64(f && !isret[u]));
+          ++j;
+          f = f && j < n && c.vcol[j < n ? j : n - 1] == x[u];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    N2V_T(17);
+    N2V_STAT(13, 1);
+  } else {
   // ---- pass 0: membership strategy for "x in N(s)" (:226) ---------------------------
   //  staged  m <= 1024: N(s) is copied into LDS; rows of v up to 2 chunks search it
   //          directly, longer rows test a hashed-id filter first and verify only the
@@ -156,7 +214,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   N2V_STAT(0, 1); N2V_STAT(1, (staged && use_filter) ? 1 : 0); N2V_STAT(2, (c.need_mem && !staged && !big_filter) ? 1 : 0);
   N2V_STAT(11, (staged && !use_filter) ? 1 : 0); N2V_STAT(12, big_filter ? 1 : 0);
   // ---- pass 1: stream N(v) ids, classify, count ---------------------------------
-  int nR = 0, nM = 0, mcount = 0;
+  int mcount = 0;
   for (int chunk0 = 0; chunk0 < c.nch; chunk0 += 4) {
     int32_t xs[4];
 #pragma unroll
@@ -218,6 +276,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
+  }
   N2V_T(18);
   // ---- :172-173 on three values -----------------------------------------------------
   const int nO = n - nR - nM;
