@@ -184,6 +184,14 @@ __global__ __launch_bounds__(kSgnsWaves * 64) void sgns_kernel(
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
 
+      // The centre row syn1neg[centre] is the label-1 target of EVERY pair of this
+      // position and no negative may equal it (such a draw is skipped), so it lives in
+      // registers for the whole position and is stored once: same values as updating
+      // it in memory pair by pair.
+      float *pc = syn1neg + (int64_t)centre * dim;
+      Row<VEC> crow;
+      load_row<VEC>(pc, dim, lane, full, crow);
+      constexpr int KP = VEC <= 4 ? 5 : (VEC == 8 ? 3 : 1);  // negative rows in flight
       for (int j = lo; j < hi; ++j) {
         if (j == i) continue;
         float *p1 = syn0 + (int64_t)sent[j] * dim;
@@ -191,28 +199,51 @@ __global__ __launch_bounds__(kSgnsWaves * 64) void sgns_kernel(
         load_row<VEC>(p1, dim, lane, full, row1);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) work.v[v] = 0.0f;
-        for (int d = 0; d <= K; ++d) {
-          const int32_t target = d == 0 ? centre : neg[(j - lo) * K + d - 1];
-          if (d > 0 && target == centre) continue;
-          float *p2 = syn1neg + (int64_t)target * dim;
-          Row<VEC> row2;
-          load_row<VEC>(p2, dim, lane, full, row2);
-          const float f = wave_dot<VEC>(row1, row2);
-          if (f <= -6.0f || f >= 6.0f) continue;
-          const float s = exp_lds[(int)((f + 6.0f) * 83.0f)];
-          const float g = ((d == 0 ? 1.0f : 0.0f) - s) * alpha;
+        {  // d == 0: the centre word, label 1
+          const float f = wave_dot<VEC>(row1, crow);
+          if (!(f <= -6.0f || f >= 6.0f)) {
+            const float g = (1.0f - exp_lds[(int)((f + 6.0f) * 83.0f)]) * alpha;
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            work.v[v] = __fmaf_rn(g, row2.v[v], work.v[v]);
-            row2.v[v] = __fmaf_rn(g, row1.v[v], row2.v[v]);
+            for (int v = 0; v < VEC; ++v) {
+              work.v[v] = __fmaf_rn(g, crow.v[v], work.v[v]);
+              crow.v[v] = __fmaf_rn(g, row1.v[v], crow.v[v]);
+            }
           }
-          store_row<VEC>(p2, dim, lane, full, row2);
+        }
+        const int32_t *ng = neg + (j - lo) * K;
+        for (int d0 = 0; d0 < K; d0 += KP) {  // negatives, KP rows prefetched together
+          int32_t tg[KP];
+          Row<VEC> rows[KP];
+#pragma unroll
+          for (int e = 0; e < KP; ++e) {
+            tg[e] = (d0 + e < K) ? ng[d0 + e] : centre;  // centre = "skip"
+            if (tg[e] != centre) load_row<VEC>(syn1neg + (int64_t)tg[e] * dim, dim, lane, full, rows[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < KP; ++e) {
+            if (tg[e] == centre) continue;  // drawn the centre word, or past K
+            float *p2 = syn1neg + (int64_t)tg[e] * dim;
+            bool dup = false;  // same row earlier in this group: read its update back
+#pragma unroll
+            for (int e2 = 0; e2 < e; ++e2) dup = dup || tg[e2] == tg[e];
+            if (dup) load_row<VEC>(p2, dim, lane, full, rows[e]);
+            const float f = wave_dot<VEC>(row1, rows[e]);
+            if (f <= -6.0f || f >= 6.0f) continue;
+            const float g = (0.0f - exp_lds[(int)((f + 6.0f) * 83.0f)]) * alpha;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+              work.v[v] = __fmaf_rn(g, rows[e].v[v], work.v[v]);
+              rows[e].v[v] = __fmaf_rn(g, row1.v[v], rows[e].v[v]);
+            }
+            store_row<VEC>(p2, dim, lane, full, rows[e]);
+          }
         }
 #pragma unroll
         for (int v = 0; v < VEC; ++v) row1.v[v] = row1.v[v] + work.v[v];
         store_row<VEC>(p1, dim, lane, full, row1);
         ++pairs;
       }
+      store_row<VEC>(pc, dim, lane, full, crow);
       __builtin_amdgcn_wave_barrier();
     }
   }
