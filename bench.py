@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sgns", action="store_true")
+    ap.add_argument("--no-fast", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -165,6 +166,10 @@ def main():
                                "algorithmic_bytes_per_walk_step": abytes / max(steps_done, 1)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, g, start_all, W, L)
+    if args.mode == "exact" and not args.no_fast:
+        fm = bench_fast(args, torch, dist, g, rw, batch, walks, valid, rank, world, barrier)
+        if rank == 0:
+            out["fast_mode"] = fm
     if not args.no_sgns:
         sg = bench_sgns(args, torch, dist, g, walks, valid, rank, world, barrier)
         if rank == 0:
@@ -174,6 +179,68 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_fast(args, torch, dist, g, rw, batch, walks, valid, rank, world, barrier):
+    """Secondary figure: the same K steps with the rejection sampler (N2V_WALK_FAST,
+    same transition distribution, not the same draws).  Algorithmic bytes per accepted
+    step: 16 + T*(16 + [s>=0: 16 + 4*ceil(log2(deg(s)+1))]) + 4."""
+    import math
+    import time as _t
+
+    W, L = args.num_walks, args.walk_length
+    if g.slots is None:
+        g.build_alias()
+    stats = {}
+
+    def step(k):
+        rw.walk(g, batch(k * world + rank), W, L, args.p, args.q, 42, mode="fast",
+                out=(walks, valid), check=False, stats=stats)
+
+    for k in range(args.warmup):
+        step(k)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    trials = 0
+    barrier()
+    t0 = _t.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        step(args.warmup + k)
+        ev[k][1].record()
+    barrier()
+    elapsed = _t.perf_counter() - t0
+    steps_done, abytes = 0, 0.0
+    deg = g.degrees()
+    for k in range(args.steps):  # recount outside the timed region
+        step(args.warmup + k)
+        torch.cuda.synchronize()
+        v = valid.bool()
+        n_steps = int(v.sum()) * L
+        steps_done += n_steps
+        tr = int(stats["trials"].item())
+        trials += tr
+        ds = deg[walks[v][:, :-2].long()].double()
+        per_trial = 16.0 + (16.0 + 4.0 * torch.ceil(torch.log2(ds + 1.0))).mean().item() * (L - 1) / L
+        abytes += 20.0 * n_steps + tr * per_trial
+    t = torch.tensor([elapsed, float(steps_done)], dtype=torch.float64, device=walks.device)
+    if world > 1:
+        tm, ts = t.clone(), t.clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+        elapsed, total = float(tm[0]), float(ts[1])
+    else:
+        total = float(steps_done)
+    kernel_s = 1e-3 * sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    ach = abytes / args.steps / kernel_s
+    del math
+    return {"value": total / elapsed, "unit": "walk-steps/s", "walk_mode": "fast",
+            "parity": "same transition distribution (chi-square tested), not the same draws",
+            "trials_per_step": trials / max(steps_done, 1),
+            "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK, "traffic": None, "kernel": "walk_fast_kernel",
+                         "kernel_ms": 1e3 * kernel_s,
+                         "algorithmic_bytes_per_walk_step": abytes / max(steps_done, 1)}}
 
 
 def bench_sgns(args, torch, dist, g, walks, valid, rank, world, barrier):

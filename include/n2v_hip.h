@@ -14,8 +14,11 @@
  *    only enqueue work, they never synchronise and never allocate;
  *  - return value: N2V_OK or a negative N2V_E* code for argument / launch
  *    errors detected on the host; data-dependent errors (the reference's
- *    ZeroDivisionError) are OR-ed into the device word `status` as N2V_ST_*
- *    bits, to be read by the caller after it synchronises;
+ *    ZeroDivisionError) are OR-ed into the device word status[0] as N2V_ST_*
+ *    bits, to be read by the caller after it synchronises.  `status` points to
+ *    FOUR uint32 words, zeroed by the caller: [0] status bits, [1] reserved,
+ *    [2..3] a 64-bit counter that N2V_WALK_FAST increments by its number of
+ *    rejection trials (for the algorithmic-bytes accounting of DESIGN.md);
  *  - no global state: re-entrant, any number of streams / devices.
  */
 #ifndef N2V_HIP_H

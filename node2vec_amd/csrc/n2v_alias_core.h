@@ -122,6 +122,44 @@ __device__ __forceinline__ void lower_bound_x4(const int32_t *a, int m, const in
   for (int u = 0; u < 4; ++u) found[u] = fin[u] == x[u] && lo[u] < m;
 }
 
+// lower_bound of x[u] in a[0, m), each search confined to its slice
+// [slice*stride, min(m, (slice+1)*stride)) (the caller guarantees the answer lies in
+// the slice or at its end); found[u] = a[lo[u]] == x[u]
+__device__ __forceinline__ void lower_bound_slices_x4(const int32_t *a, int m, int stride,
+                                                      const int (&slice)[4],
+                                                      const int32_t (&x)[4], int iters,
+                                                      int (&lo)[4], bool (&found)[4]) {
+  int hi[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    lo[u] = slice[u] * stride;
+    hi[u] = lo[u] + stride;
+    lo[u] = lo[u] < m ? lo[u] : m;
+    hi[u] = hi[u] < m ? hi[u] : m;
+  }
+  for (int it = 0; it < iters; ++it) {
+    int32_t val[4];
+    int mid[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      mid[u] = (lo[u] + hi[u]) >> 1;
+      val[u] = a[mid[u] < m ? mid[u] : m - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool act = lo[u] < hi[u];
+      const bool less = val[u] < x[u];
+      lo[u] = (act && less) ? mid[u] + 1 : lo[u];
+      hi[u] = (act && !less) ? mid[u] : hi[u];
+    }
+  }
+  int32_t fin[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) fin[u] = a[lo[u] < m ? lo[u] : m - 1];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) found[u] = fin[u] == x[u] && lo[u] < m;
+}
+
 // biased weight of element chunk*64+lane (randomwalk.py:219-231); 0 past the row
 template <bool kFromCache>
 __device__ __forceinline__ double chunk_bias(const StepCtx &c, int chunk, int lane,

@@ -15,6 +15,22 @@
 
 namespace n2v {
 
+// Grid size of a persistent (grid-stride) kernel: CUs x resident blocks per CU of the
+// current device (occupancy query is advisory; a larger grid would only queue blocks).
+inline int64_t resident_blocks(const void *kernel, int block_threads, size_t dyn_lds) {
+  int dev = 0, cus = 256, per_cu = 4;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+  }
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, block_threads, dyn_lds) == hipSuccess &&
+      occ > 0)
+    per_cu = occ;
+  return (int64_t)cus * per_cu;
+}
+
 // splitmix64 finaliser; the uniform stream of DESIGN.md "RNG".
 __host__ __device__ inline uint64_t mix64(uint64_t z) {
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;

@@ -507,7 +507,8 @@ extern "C" int n2v_walk_exact_launch(const n2v_graph *g, const int32_t *start_id
   const int64_t total = n_start * (int64_t)num_walks;
   if (total == 0) return N2V_OK;
   int64_t blocks = (total + n2v::kWavesPerBlock - 1) / n2v::kWavesPerBlock;
-  const int64_t cap = 256 * 8;  // 256 CUs x 8 resident 4-wave blocks
+  const int64_t cap = n2v::resident_blocks((const void *)n2v::walk_exact_kernel,
+                                           n2v::kWavesPerBlock * 64, 0);
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(n2v::walk_exact_kernel, dim3((unsigned)blocks),
                      dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, *g, start_ids,

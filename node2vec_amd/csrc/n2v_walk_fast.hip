@@ -151,11 +151,11 @@ extern "C" int n2v_walk_fast_launch(const n2v_graph *g, const int32_t *start_ids
   const int threads = 256;
   int64_t blocks = (total + threads - 1) / threads;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  // status[1] (when the caller allocates >= 4 words) accumulates the trial count
+  // status[2..3]: 64-bit trial counter (include/n2v_hip.h)
   hipLaunchKernelGGL(n2v::walk_fast_kernel, dim3((unsigned)blocks), dim3(threads), 0,
                      (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, p, q,
                      seed, walks_out, valid_out, status,
-                     (unsigned long long *)nullptr);
+                     reinterpret_cast<unsigned long long *>(status + 2));
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
 }

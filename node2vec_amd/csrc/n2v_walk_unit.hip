@@ -22,16 +22,17 @@
 namespace n2v {
 
 constexpr int kUC = 128;     // class ballots cached for the TOP 128 chunks (8192 neighbours)
-constexpr int kYsCap = 1024;  // N(s) staged in LDS when it has at most this many ids
+constexpr int kYsCap = 640;   // N(s) staged in LDS when it has at most this many ids
 constexpr int kBitsA = 256;   // filter words beside a staged N(s)        (8192 bits)
-constexpr int kBitsB = 1024;  // filter words when N(s) is not staged     (32768 bits)
+constexpr int kBitsB = 512;   // filter words when N(s) is not staged     (16384 bits)
+constexpr int kMaybeU = 128;  // filter hits waiting for verification
 
-// 8 KB per wave.  `pool` is either {staged ids of N(s)} (m <= kYsCap, filter in
+// 6 KB per wave (6 blocks of 4 waves per CU).  `pool` is either {staged ids of N(s)} (m <= kYsCap, filter in
 // `bits`) or one large filter (kYsCap < m <= 8192).
 struct UnitLds {
   uint64_t cls[2 * kUC];     // slot nch-1-chunk: ballot(return), ballot(shared)
   uint32_t bits[kBitsA];     // small filter
-  int32_t mlist[kMaybeCap];  // filter hits waiting for verification
+  int32_t mlist[kMaybeU];    // filter hits waiting for verification
   uint32_t pool[kYsCap];     // staged N(s)  |  large filter
 };
 
@@ -107,6 +108,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   const double r2 = (double)u2 * (1.0 / 4294967296.0);
 
   N2V_T0
+  N2V_STAT(0, 1);
   int nR = 0, nM = 0;
   // ---- reverse classification: search from the SHORTER list --------------------------
   // The classes of N(v) are needed as ballots and counts, not as a stream.  When N(s)
@@ -122,7 +124,17 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int items = 1 + (c.need_mem ? c.m : 0);  // item 0 = s, item k = N(s)[k-1]
-    const int iters_n = 32 - __clz(n);
+    // first level shared by every search: 64 pivots N(v)[(l+1) * stride - 1], one
+    // gather, parked in LDS (mlist is idle here); each lane then finds its 1/64
+    // slice by LDS binary search, leaving log2(n/64) global rounds instead of log2(n)
+    const int stride = (n + 63) >> 6;
+    {
+      const int pi = (lane + 1) * stride - 1;
+      L.mlist[lane] = c.vcol[pi < n ? pi : n - 1];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int iters_n = 32 - __clz(stride);
     for (int base = 0; base < items; base += 256) {
       int32_t x[4];
       bool isret[4];
@@ -141,7 +153,21 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
       }
       int lo[4];
       bool found[4];
-      lower_bound_x4(c.vcol, n, x, iters_n, lo, found);
+      int slice[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // slice = number of pivots < x  (0..64)
+        int a = 0, b = 64;
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+          const int mid = (a + b) >> 1;
+          const bool less = a < b && L.mlist[mid < 64 ? mid : 63] < x[u];
+          const bool act = a < b;
+          a = (act && less) ? mid + 1 : a;
+          b = (act && !less) ? mid : b;
+        }
+        slice[u] = a < 63 ? a : 63;  // x above the last pivot: search the last slice
+      }
+      lower_bound_slices_x4(c.vcol, n, stride, slice, x, iters_n, lo, found);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         bool f = found[u] && x[u] >= 0;
@@ -162,7 +188,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    N2V_T(17);
+    N2V_T(24);
     N2V_STAT(13, 1);
   } else {
   // ---- pass 0: membership strategy for "x in N(s)" (:226) ---------------------------
@@ -173,7 +199,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   //          binary search over global memory, batched once per step
   //  direct  otherwise (N(s) a hub, N(v) short): per-lane global binary search
   const bool staged = c.need_mem && c.m <= kYsCap;
-  const bool big_filter = c.need_mem && !staged && c.m <= 8192 && c.m <= 8 * n + 64;
+  const bool big_filter = c.need_mem && !staged && c.m <= 4096 && c.m <= 8 * n + 64;
   const bool use_filter = big_filter || (staged && c.nch > 2);
   uint32_t *fbits = staged ? L.bits : L.pool;
   int shift = 32;
@@ -211,7 +237,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   }
 
   N2V_T(16);
-  N2V_STAT(0, 1); N2V_STAT(1, (staged && use_filter) ? 1 : 0); N2V_STAT(2, (c.need_mem && !staged && !big_filter) ? 1 : 0);
+  N2V_STAT(1, (staged && use_filter) ? 1 : 0); N2V_STAT(2, (c.need_mem && !staged && !big_filter) ? 1 : 0);
   N2V_STAT(11, (staged && !use_filter) ? 1 : 0); N2V_STAT(12, big_filter ? 1 : 0);
   // ---- pass 1: stream N(v) ids, classify, count ---------------------------------
   int mcount = 0;
@@ -257,7 +283,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
       const uint64_t ym = ballot64(maybe);
       if (ym) {
         const int cnt = __popcll(ym);
-        if (mcount + cnt > kMaybeCap) {
+        if (mcount + cnt > kMaybeU) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           verify_unit(c, L, mcount, lane, staged, nM);
@@ -580,8 +606,11 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
   if (K.TR == 0 || K.TO == 0) return 0;  // a zero class could make the row sum 0
   const int64_t total = n_start * (int64_t)num_walks;
   if (total == 0) return 1;
+  // persistent grid: exactly the resident capacity, walkers are grid-strided
   int64_t blocks = (total + n2v::kWavesPerBlock - 1) / n2v::kWavesPerBlock;
-  if (blocks > 256 * 8) blocks = 256 * 8;
+  const int64_t cap = n2v::resident_blocks((const void *)n2v::walk_exact_unit_kernel,
+                                           n2v::kWavesPerBlock * 64, 0);
+  if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(n2v::walk_exact_unit_kernel, dim3((unsigned)blocks),
                      dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, *g, start_ids,
                      n_start, num_walks, walk_length, p, q, K, seed, walks_out, valid_out,

@@ -99,13 +99,13 @@ class DeviceGraph:
         if not self.rowptr.is_cuda:
             raise RuntimeError("build_alias: graph is not on the GPU")
         slots = torch.zeros((self.n_edges, 4), dtype=torch.int32, device=self.device)
-        status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        status = torch.zeros(4, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             rc = L.n2v_alias_build(self.rowptr.data_ptr(), self.col.data_ptr(),
                                    self.w.data_ptr(), self.n_vertices, slots.data_ptr(),
                                    status.data_ptr(), _lib.current_stream_ptr())
         _lib.check(rc, "n2v_alias_build")
-        _lib.check_status_word(int(status.item()), "n2v_alias_build")
+        _lib.check_status_word(int(status[0].item()), "n2v_alias_build")
         self.slots = slots
         return self
 

@@ -39,7 +39,8 @@ def start_vertices(graph: DeviceGraph, walk_seed_ids=None) -> torch.Tensor:
 
 def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_length: int,
          return_param: float, inout_param: float, seed: int, mode: str = "exact",
-         out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, check: bool = True):
+         out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, check: bool = True,
+         stats: Optional[dict] = None):
     """Launch K2.  Returns (walks int32 [n_start*num_walks, walk_length+1], valid bool)."""
     L = _lib.load()
     _lib.require_gpu()
@@ -60,7 +61,7 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
         valid = torch.empty(total, dtype=torch.uint8, device=graph.device)
     else:
         walks, valid = out
-    status = torch.zeros(1, dtype=torch.int32, device=graph.device)
+    status = torch.zeros(4, dtype=torch.int32, device=graph.device)  # include/n2v_hip.h
     g = graph.c_struct()
     with torch.cuda.device(graph.device):
         rc = L.n2v_walk(g, start_ids.data_ptr(), n_start, num_walks, walk_length,
@@ -69,5 +70,7 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
                         _lib.current_stream_ptr())
     _lib.check(rc, "n2v_walk")
     if check:
-        _lib.check_status_word(int(status.item()), "n2v_walk")
+        _lib.check_status_word(int(status[0].item()), "n2v_walk")
+    if stats is not None:  # device tensor; read after synchronising
+        stats["trials"] = status[2:4].view(torch.int64)
     return walks, valid.bool() if out is None else valid

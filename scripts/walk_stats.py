@@ -6,14 +6,14 @@ g = synthetic.rmat(20, 5_000_000, device="cuda")
 start = rw.start_vertices(g)[:47104].contiguous()
 L = _lib.load()
 names = ["draw_steps", "staged+filter", "direct_search", "maybes", "verify_rounds", "past_quick_exit",
-         "pair_invocations", "pair_inv_n<=64", "pair_iterations", "refills", "pair_not_cached", "staged_nofilter", "big_filter"]
-for p, q in ((0.5, 2.0), (1.0, 1.0)):
+         "pair_invocations", "pair_inv_n<=64", "pair_iterations", "refills", "pair_not_cached", "staged_nofilter", "big_filter", "reverse"]
+for p, q in ((0.5, 2.0),):
     buf = (C.c_ulonglong * 32)()
     L.n2v_debug_stats_unit(buf, 1)
     walks, valid = rw.walk(g, start, 10, 80, p, q, 42); torch.cuda.synchronize()
     L.n2v_debug_stats_unit(buf, 1)
     st = dict(zip(names, list(buf)))
     print(p, q, {k: (v, round(v / max(st["draw_steps"], 1), 4)) for k, v in st.items()})
-    ph = ["P0 stage/filter", "P1 stream", "P2 verify", "sum+avg", "minmax", "pairing", "pair uncached"]
-    cyc = list(buf)[16:23]; tot = list(buf)[23]
+    ph = ["P0 stage/filter", "P1 stream", "P2 verify", "sum+avg", "minmax", "pairing", "pair uncached", "reverse classify"]
+    cyc = list(buf)[16:23] + [list(buf)[24]]; tot = list(buf)[23]
     print("  wave-cycles total", tot, "per step", round(tot/st["draw_steps"]));    print("  cycles/step by phase:", {n: (round(c / st["draw_steps"]), f"{100*c/tot:.1f}%") for n, c in zip(ph, cyc)})
