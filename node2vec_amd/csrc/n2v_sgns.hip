@@ -21,6 +21,7 @@ namespace n2v {
 constexpr int kSgnsWaves = 4;      // waves per block
 constexpr int kExpTable = 1000;    // EXP_TABLE_SIZE
 constexpr int kMaxSent = N2V_SGNS_MAX_SENTENCE;
+constexpr int kBuckets = 1024;     // coarse index of cum_table: bucket b covers values [b<<21, (b+1)<<21)
 
 __host__ __device__ inline uint64_t sentence_stream(uint64_t seed, uint64_t sentence_id) {
   return mix64(seed ^ mix64(sentence_id + 0xA0761D6478BD642FULL));
@@ -118,22 +119,27 @@ __global__ __launch_bounds__(kSgnsWaves * 64) void sgns_kernel(
     n2v_sgns_params P, unsigned long long *pairs_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *exp_lds = reinterpret_cast<float *>(smem);
+  int32_t *bucket = reinterpret_cast<int32_t *>(smem + kExpTable * sizeof(float));
   const int negcap = (2 * P.window + 1) * P.negative;  // the window incl. the centre slot
   const int per_wave = 2 * kMaxSent + negcap;  // int32 words
   const int wave_in_block = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   int32_t *sent = reinterpret_cast<int32_t *>(smem + kExpTable * sizeof(float)) +
-                  wave_in_block * per_wave;
+                  (kBuckets + 1) + wave_in_block * per_wave;
   int32_t *red = sent + kMaxSent;
   int32_t *neg = red + kMaxSent;
   for (int i = threadIdx.x; i < kExpTable; i += blockDim.x) exp_lds[i] = exp_table_g[i];
+  const int bis_iters = 64 - __clzll((long long)P.n_vocab);
+  // bucket[b] = bisect_left(cum_table, b << 21): a draw r lies in bucket r >> 21 and its
+  // bisect_left is confined to [bucket[b], bucket[b+1]] -- same index, half the probes
+  for (int b = threadIdx.x; b <= kBuckets; b += blockDim.x)
+    bucket[b] = bisect_left_u32(cum_table, P.n_vocab, (uint32_t)b << 21, bis_iters);
   __syncthreads();
 
   const int dim = P.dim, window = P.window, K = P.negative;
   const bool full = dim == 64 * VEC;
   const float alpha = P.alpha;
   const uint32_t domain = cum_table[P.n_vocab - 1];
-  const int bis_iters = 64 - __clzll((long long)P.n_vocab);
   const int waves_per_block = blockDim.x >> 6;
   const int64_t n_waves = (int64_t)gridDim.x * waves_per_block;
   unsigned long long pairs = 0;
@@ -179,7 +185,15 @@ __global__ __launch_bounds__(kSgnsWaves * 64) void sgns_kernel(
                              ((uint64_t)i * 2ULL * (uint64_t)window + (uint64_t)rel) *
                                  (uint64_t)K + (uint64_t)d;
         const uint32_t x = (uint32_t)((sgns_draw(hs, idx) >> 16) % (uint64_t)domain);
-        neg[q] = (j == i) ? centre : bisect_left_u32(cum_table, P.n_vocab, x, bis_iters);
+        int blo = bucket[x >> 21], bhi = bucket[(x >> 21) + 1];
+        while (blo < bhi) {  // bisect_left inside the bucket
+          const int mid = (blo + bhi) >> 1;
+          if (cum_table[mid] < x)
+            blo = mid + 1;
+          else
+            bhi = mid;
+        }
+        neg[q] = (j == i) ? centre : blo;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -264,7 +278,7 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
     return N2V_EINVAL;
   if (n_walks == 0) return N2V_OK;
   using namespace n2v;
-  const size_t lds = kExpTable * sizeof(float) +
+  const size_t lds = kExpTable * sizeof(float) + (kBuckets + 1) * sizeof(int32_t) +
                      (size_t)kSgnsWaves * (2 * kMaxSent + (2 * P->window + 1) * P->negative) * 4;
   // Hogwild concurrency is scaled to the model: unsynchronised waves are harmless
   // while collisions on a row are rare (gensim runs <= 16 threads); on a tiny
