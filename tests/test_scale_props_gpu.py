@@ -1,0 +1,104 @@
+"""Size-independent properties at larger scale (where the CPU oracle would take too
+long to check every walk): every hop is an edge, rows are complete, runs are
+reproducible, exact and fast modes agree in distribution, and a sampled subset of
+walks still equals the oracle bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _edge_keys(g):
+    src = torch.repeat_interleave(torch.arange(g.n_vertices, device=g.device), g.degrees())
+    return torch.sort(src * g.n_vertices + g.col.long()).values
+
+
+def _all_hops_are_edges(g, walks, valid):
+    w = walks[valid].long()
+    hop = (w[:, :-1] * g.n_vertices + w[:, 1:]).reshape(-1)
+    keys = _edge_keys(g)
+    pos = torch.searchsorted(keys, hop).clamp_(max=keys.numel() - 1)
+    return bool((keys[pos] == hop).all())
+
+
+@pytest.mark.parametrize("pq", [(0.5, 2.0), (4.0, 0.25)])
+def test_rmat18_exact_properties_and_oracle_sample(oracle, pq):
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd import synthetic
+
+    p, q = pq
+    g = synthetic.rmat(18, 1_200_000, device="cuda")
+    start = rw.start_vertices(g)
+    walks, valid = rw.walk(g, start, 4, 40, p, q, 2024)
+    assert bool(valid.all())  # symmetrised graph: no sinks
+    assert walks.shape == (start.numel() * 4, 41)
+    assert torch.equal(walks[:, 0], start.repeat_interleave(4))  # to_path: src = path[0]
+    assert _all_hops_are_edges(g, walks, valid)
+    again, _ = rw.walk(g, start, 4, 40, p, q, 2024)
+    assert torch.equal(walks, again)  # reproducible, independent of scheduling
+    other, _ = rw.walk(g, start, 4, 40, p, q, 2025)
+    assert not torch.equal(walks, other)
+    # a sample of start vertices (incl. the biggest hubs) against the oracle
+    deg = g.degrees()
+    hubs = torch.topk(deg, 40).indices.to(torch.int32)
+    sample = torch.unique(torch.cat([hubs, start[:: max(1, start.numel() // 400)]]))
+    got, gv = rw.walk(g, sample, 4, 40, p, q, 2024)
+    want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.w.cpu().numpy(),
+                                  sample.cpu().numpy(), 4, 40, p, q, 2024, n_threads=8)
+    assert np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy(), want)
+
+
+def test_cfg5_shape_bipartite_hubs(oracle):
+    """BASELINE cfg 5 in miniature: hubs of ~10 k leaves + one hub per leaf, p=4 q=0.25.
+    Bipartite => the 'shared neighbour' branch never fires; hub rows exceed the LDS
+    class cache; the return slot is the only underfull one."""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd import synthetic
+
+    g = synthetic.hub_bipartite(300_000, 30, 10_000, device="cuda")
+    deg = g.degrees()
+    assert int(deg.max()) > 8192 * 2
+    start = rw.start_vertices(g)
+    sample = torch.cat([torch.arange(30, dtype=torch.int32, device="cuda"), start[30::997]])
+    got, gv = rw.walk(g, sample, 3, 30, 4.0, 0.25, 7)
+    want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.w.cpu().numpy(),
+                                  sample.cpu().numpy(), 3, 30, 4.0, 0.25, 7, n_threads=8)
+    assert np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy(), want)
+    assert _all_hops_are_edges(g, got, gv)
+    # walks alternate between the hub side (ids < 30) and the leaf side
+    w = got[gv].long()
+    side = w < 30
+    assert bool((side[:, :-1] != side[:, 1:]).all())
+
+
+def test_exact_and_fast_visit_the_same_distribution():
+    """degree-bucketed visit frequencies of the two samplers agree (same Markov chain)"""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd import synthetic
+
+    g = synthetic.rmat(16, 400_000, device="cuda", weights="uniform")
+    start = rw.start_vertices(g)
+    a, _ = rw.walk(g, start, 6, 30, 0.5, 2.0, 1, mode="exact")
+    b, _ = rw.walk(g, start, 6, 30, 0.5, 2.0, 2, mode="fast")
+    deg = g.degrees()
+    bucket = torch.log2(deg.clamp(min=1).double()).long()
+    ha = torch.bincount(bucket[a[:, 1:].long()].reshape(-1), minlength=20).double()
+    hb = torch.bincount(bucket[b[:, 1:].long()].reshape(-1), minlength=20).double()
+    ha, hb = ha / ha.sum(), hb / hb.sum()
+    assert float((ha - hb).abs().max()) < 5e-3
+
+
+def test_weighted_generic_kernel_large_rows(oracle):
+    """weighted graph (generic kernel): hubs beyond the 1024-entry weight cache"""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd import synthetic
+
+    g = synthetic.rmat(15, 300_000, device="cuda", weights="uniform")
+    assert not g.unit_weights and int(g.degrees().max()) > 2048
+    hubs = torch.topk(g.degrees(), 30).indices.to(torch.int32)
+    sample = torch.unique(torch.cat([hubs, rw.start_vertices(g)[::97]]))
+    got, gv = rw.walk(g, sample, 3, 25, 0.5, 2.0, 11)
+    want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.w.cpu().numpy(),
+                                  sample.cpu().numpy(), 3, 25, 0.5, 2.0, 11, n_threads=8)
+    assert np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy(), want)
