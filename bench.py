@@ -164,7 +164,7 @@ def main():
                                "kernel_ms": 1e3 * avg_kernel_s,
                                "algorithmic_bytes_per_launch": per_launch_bytes,
                                "algorithmic_bytes_per_walk_step": abytes / max(steps_done, 1)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, g, start_all, W, L)
     if args.mode == "exact" and not args.no_fast:
         fm = bench_fast(args, torch, dist, g, rw, batch, walks, valid, rank, world, barrier)

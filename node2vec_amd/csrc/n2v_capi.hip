@@ -39,9 +39,12 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start, int3
              void *stream) {
   if (!g || !g->rowptr || !g->col || n_start < 0 || num_walks < 0 || walk_length < 0)
     return N2V_EINVAL;
-  if (n_start > 0 && (!start_ids || !walks_out || !valid_out || !status)) return N2V_EINVAL;
+  // buffers are only required when there is at least one walker
+  const bool any = n_start > 0 && num_walks > 0;
+  if (any && (!start_ids || !walks_out || !valid_out || !status)) return N2V_EINVAL;
   // generate_edge_alias_tables raises ValueError on p == 0 or q == 0 (randomwalk.py:214-217)
   if (return_param == 0.0 || inout_param == 0.0) return N2V_EINVAL;
+  if (!any) return (mode == N2V_WALK_EXACT || mode == N2V_WALK_FAST) ? N2V_OK : N2V_EINVAL;
   if (mode == N2V_WALK_EXACT) {
     // w == NULL: every weight is 1.0; the specialised kernel applies when 1/p, 1/q scale exactly
     const int rc = n2v_walk_exact_unit_try(g, start_ids, n_start, num_walks, walk_length,

@@ -430,7 +430,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
        rr += n_waves) {
     const int64_t r = readfirstlane_i64(rr);
     int32_t *out = walks_out + r * L1;
-    for (int t = lane; t < L1; t += 64) out[t] = -1;
+    // the path lives in registers (lane t holds vertices t and 64 + t) and is stored as
+    // whole rows at the end; walks longer than 128 vertices fall back to direct stores
+    const bool buffered = L1 <= 128;
+    int32_t path0 = -1, path1 = -1;
+    if (!buffered)
+      for (int t = lane; t < L1; t += 64) out[t] = -1;
     const int32_t start = __builtin_amdgcn_readfirstlane(start_ids[r / num_walks]);
     const int32_t ordinal = (int32_t)(r % num_walks) + 1;  // randomwalk.py:294
     bool alive = true;
@@ -449,7 +454,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
       const uint64_t key = (uint64_t)start * (uint64_t)num_walks + (uint64_t)(ordinal - 1);
       const uint64_t h0 = walker_stream(seed, key);
       __builtin_amdgcn_wave_barrier();
-      if (lane == 0) out[0] = start;  // path[0] after the first-step rule (:146-147)
+      if (buffered) {
+        if (lane == 0) path0 = start;
+      } else if (lane == 0) {
+        out[0] = start;
+      }  // path[0] after the first-step rule (:146-147)
       for (int step = 0; step < walk_length; ++step) {
         const int64_t vb = readfirstlane_i64(g.rowptr[v]);
         const int64_t ve = readfirstlane_i64(g.rowptr[v + 1]);
@@ -484,10 +493,24 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
           break;
         }
         const int32_t next = __builtin_amdgcn_readfirstlane(c.vcol[idx]);
-        if (lane == 0) out[step + 1] = next;
+        if (buffered) {
+          const int t = step + 1;
+          if (lane == (t & 63)) {
+            if (t < 64)
+              path0 = next;
+            else
+              path1 = next;
+          }
+        } else if (lane == 0) {
+          out[step + 1] = next;
+        }
         s = v;  // :339 src = path[-2], dst = path[-1]
         v = next;
       }
+    }
+    if (buffered) {
+      if (lane < L1) out[lane] = path0;
+      if (64 + lane < L1) out[64 + lane] = path1;
     }
     if (lane == 0) valid_out[r] = alive ? 1 : 0;
   }

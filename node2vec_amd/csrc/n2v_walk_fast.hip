@@ -70,8 +70,10 @@ __global__ __launch_bounds__(256) void walk_fast_kernel(
         n = (int)(g.rowptr[start + 1] - vb);
         ok = n > 0;  // fugue.py:132
       }
-      if (!ok) {
-        valid_out[r] = 0;
+      if (!ok || walk_length == 0) {
+        // no out-edges (fugue.py:132), or nothing to walk: the row is just [start]
+        if (ok) out[0] = start;
+        valid_out[r] = ok ? 1 : 0;
         r += n_lanes;
         continue;
       }

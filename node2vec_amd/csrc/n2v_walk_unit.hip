@@ -493,7 +493,8 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   return (r2 < fin_prob) ? pick : fin_alias;
 }
 
-__global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_unit_kernel(
+// 6 waves per SIMD (<= 80 VGPRs) matches the 6 resident blocks the 24 KB of LDS allow
+__global__ __launch_bounds__(kWavesPerBlock * 64, 6) void walk_exact_unit_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double p, double q, UnitConsts K, uint64_t seed,
     int32_t *__restrict__ walks_out, uint8_t *__restrict__ valid_out,
@@ -518,7 +519,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_unit_kernel(
        rr += n_waves) {
     const int64_t r = readfirstlane_i64(rr);
     int32_t *out = walks_out + r * L1;
-    for (int t = lane; t < L1; t += 64) out[t] = -1;
+    // the path lives in registers (lane t holds vertices t and 64 + t) and is stored as
+    // whole rows at the end; walks longer than 128 vertices fall back to direct stores
+    const bool buffered = L1 <= 128;
+    int32_t path0 = -1, path1 = -1;
+    if (!buffered)
+      for (int t = lane; t < L1; t += 64) out[t] = -1;
     const int32_t start = __builtin_amdgcn_readfirstlane(start_ids[r / num_walks]);
     const int32_t ordinal = (int32_t)(r % num_walks) + 1;
     bool alive = true;
@@ -536,7 +542,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_unit_kernel(
       const uint64_t key = (uint64_t)start * (uint64_t)num_walks + (uint64_t)(ordinal - 1);
       const uint64_t h0 = walker_stream(seed, key);
       __builtin_amdgcn_wave_barrier();
-      if (lane == 0) out[0] = start;
+      if (buffered) {
+        if (lane == 0) path0 = start;
+      } else if (lane == 0) {
+        out[0] = start;
+      }
       int64_t sb = 0;
       int m = 0;
       for (int step = 0; step < walk_length; ++step) {
@@ -563,12 +573,26 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_unit_kernel(
           idx = unit_draw(c, K, (uint32_t)(bits >> 32), (uint32_t)bits, lane, L N2V_STATS_PASS);
         }
         const int32_t next = __builtin_amdgcn_readfirstlane(g.col[vb + idx]);
-        if (lane == 0) out[step + 1] = next;
+        if (buffered) {
+          const int t = step + 1;
+          if (lane == (t & 63)) {
+            if (t < 64)
+              path0 = next;
+            else
+              path1 = next;
+          }
+        } else if (lane == 0) {
+          out[step + 1] = next;
+        }
         s = v;  // the row of the new previous vertex is the row just walked
         sb = vb;
         m = n;
         v = next;
       }
+    }
+    if (buffered) {
+      if (lane < L1) out[lane] = path0;
+      if (64 + lane < L1) out[64 + lane] = path1;
     }
     if (lane == 0) valid_out[r] = alive ? 1 : 0;
   }

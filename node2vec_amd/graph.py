@@ -99,6 +99,9 @@ class DeviceGraph:
         if not self.rowptr.is_cuda:
             raise RuntimeError("build_alias: graph is not on the GPU")
         slots = torch.zeros((self.n_edges, 4), dtype=torch.int32, device=self.device)
+        if self.n_edges == 0:  # nothing to build (and no buffer to hand over)
+            self.slots = slots
+            return self
         status = torch.zeros(4, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             rc = L.n2v_alias_build(self.rowptr.data_ptr(), self.col.data_ptr(),
