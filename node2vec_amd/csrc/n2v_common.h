@@ -75,6 +75,8 @@ __device__ inline int64_t readfirstlane_i64(int64_t v) {
   return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
+__device__ inline uint64_t readfirstlane_u64(uint64_t v) { return (uint64_t)readfirstlane_i64((int64_t)v); }
+
 __device__ inline uint64_t ballot64(bool p) { return __ballot(p); }
 
 __device__ inline int64_t wave_sum_i64(int64_t v) {

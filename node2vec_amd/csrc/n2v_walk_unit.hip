@@ -22,13 +22,14 @@
 namespace n2v {
 
 constexpr int kUC = 128;     // class ballots cached for the TOP 128 chunks (8192 neighbours)
-constexpr int kYsCap = 640;   // N(s) staged in LDS when it has at most this many ids
+constexpr int kYsCap = 384;   // N(s) staged in LDS when it has at most this many ids
 constexpr int kBitsA = 256;   // filter words beside a staged N(s)        (8192 bits)
-constexpr int kBitsB = 512;   // filter words when N(s) is not staged     (16384 bits)
+constexpr int kBitsB = 256;   // filter words when N(s) is not staged (a power of two <= kYsCap)
 constexpr int kMaybeU = 128;  // filter hits waiting for verification
 
-// 6 KB per wave (6 blocks of 4 waves per CU).  `pool` is either {staged ids of N(s)} (m <= kYsCap, filter in
+// 5 KB per wave: 8 blocks of 4 waves per CU, the hardware maximum of 8 waves per SIMD.  `pool` is either {staged ids of N(s)} (m <= kYsCap, filter in
 // `bits`) or one large filter (kYsCap < m <= 8192).
+static_assert(kBitsB <= kYsCap && (kBitsB & (kBitsB - 1)) == 0, "large filter must fit the pool");
 struct UnitLds {
   uint64_t cls[2 * kUC];     // slot nch-1-chunk: ballot(return), ballot(shared)
   uint32_t bits[kBitsA];     // small filter
@@ -72,8 +73,10 @@ __device__ __forceinline__ void chunk_classes(const UnitStep &c, UnitLds &L, int
                                               uint64_t &rm, uint64_t &mm) {
   const int ci = c.nch - 1 - chunk;
   if (ci < kUC) {
-    rm = L.cls[2 * ci];
-    mm = L.cls[2 * ci + 1];
+    // uniform address, but an LDS load is lane-varying to the compiler: say it is scalar,
+    // so that everything derived from the class masks stays on the scalar unit
+    rm = readfirstlane_u64(L.cls[2 * ci]);
+    mm = readfirstlane_u64(L.cls[2 * ci + 1]);
     return;
   }
   const int i = chunk * 64 + lane;
@@ -347,7 +350,9 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
       }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) nrm += __shfl_xor(nrm, off, 64);
-      above = (n - 1 - pick) - nrm;
+      // a shuffle result is lane-varying to the compiler: make the count a scalar, or
+      // the absorb loop below is compiled as a divergent (exec-masked) loop
+      above = (n - 1 - pick) - __builtin_amdgcn_readfirstlane(nrm);
     }
     int co2 = c.nch, consumed = 0;
     uint64_t om2 = 0, orm2 = 0, omm2 = 0;
@@ -385,7 +390,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
           continue;
         }
       }
-      const int limit = min(total_u, above) - consumed;
+      const int limit = __builtin_amdgcn_readfirstlane(min(total_u, above) - consumed);
       int j = 0;
       bool demoted = false;
       while (j < limit) {  // probs[over] = probs[over] + probs[under] - 1.0
@@ -493,8 +498,8 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   return (r2 < fin_prob) ? pick : fin_alias;
 }
 
-// 6 waves per SIMD (<= 80 VGPRs) matches the 6 resident blocks the 24 KB of LDS allow
-__global__ __launch_bounds__(kWavesPerBlock * 64, 6) void walk_exact_unit_kernel(
+// 8 waves per SIMD (<= 64 VGPRs) matches the 8 resident blocks the 20 KB of LDS allow
+__global__ __launch_bounds__(kWavesPerBlock * 64, 8) void walk_exact_unit_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double p, double q, UnitConsts K, uint64_t seed,
     int32_t *__restrict__ walks_out, uint8_t *__restrict__ valid_out,
