@@ -217,7 +217,7 @@ __device__ __forceinline__ double row_sum(const StepCtx &c, int lane, uint64_t *
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   if (ballot64(!exact) == 0ull && c.n <= (1 << 21))
-    return (double)wave_sum_i64(isum) * (1.0 / 1048576.0);
+    return (double)readfirstlane_i64(wave_sum_i64(isum)) * (1.0 / 1048576.0);
   double total = 0.0;  // reference order: left to right, one rounding per add
   for (int chunk = 0; chunk < c.nch; ++chunk) {
     bool valid;

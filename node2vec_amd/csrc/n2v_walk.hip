@@ -349,7 +349,9 @@ __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_
   if (bq_valid) {
     // every b is a multiple of 2^-20 below 2^11: all partial sums are exactly
     // representable, any order gives the reference's bits
-    total = (double)wave_sum_i64(st.isum) * (1.0 / 1048576.0);
+    // (a shuffle reduction is lane-varying to the compiler: make the sum a scalar so that
+    // avg, the shortcuts and the pairing loops below stay wave-uniform)
+    total = (double)readfirstlane_i64(wave_sum_i64(st.isum)) * (1.0 / 1048576.0);
   } else {
     total = 0.0;  // left to right, one rounding per add
     for (int chunk = 0; chunk < c.nch; ++chunk) {
@@ -359,9 +361,9 @@ __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_
       for (int j = 0; j < cnt; ++j) total = total + readlane_f64(b, j);
     }
   }
-  const double avg = total / (double)n;  // :172
+  const double avg = readfirstlane_f64(total / (double)n);  // :172
   if (avg == 0.0) return -1;
-  const double p_pick = b_pick / avg;    // :173
+  const double p_pick = readfirstlane_f64(b_pick / avg);    // :173
 
   N2V_T(19);
   // untouched underfull slot: probs[pick] never changes, alias irrelevant
@@ -382,6 +384,8 @@ __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_
     bmax = fmax(bmax, __shfl_xor(bmax, off, 64));
   }
   N2V_T(20);
+  bmin = readfirstlane_f64(bmin);
+  bmax = readfirstlane_f64(bmax);
   if (!(bmin / avg < 1.0) || (bmax / avg < 1.0)) return (r2 < p_pick) ? pick : 0;
 
   N2V_STAT(6, 1); N2V_STAT(7, n <= 64 ? 1 : 0); N2V_STAT(10, (bq_valid && n <= kBqCap) ? 0 : 1);
