@@ -103,15 +103,25 @@ __global__ __launch_bounds__(256) void walk_fast_kernel(
     bool accept = true;
     ++trials;
     if (s >= 0 && biased) {
-      double beta;
-      if (x == s)
-        beta = inv_p;
-      else if (q != 1.0 && member_sorted_lane(g.col + sb, m, x))
-        beta = 1.0;
-      else
-        beta = q != 1.0 ? inv_q : 1.0;
+      // accept iff u < beta(x), u uniform on [0, beta_max).  beta is 1/p for the return
+      // edge; otherwise it is 1 (x in N(s)) or 1/q, so the binary search over N(s) is
+      // only needed when u falls BETWEEN those two values: same decisions, far fewer
+      // dependent gathers (p=0.5, q=2: one trial in four).
       const uint32_t u3 = (uint32_t)(mix64(bits ^ 0xC2B2AE3D27D4EB4FULL) >> 32);
-      accept = (double)u3 * (1.0 / 4294967296.0) * beta_max < beta;
+      const double u = (double)u3 * (1.0 / 4294967296.0) * beta_max;
+      if (x == s) {
+        accept = u < inv_p;
+      } else if (q == 1.0) {
+        accept = u < 1.0;
+      } else {
+        const double b_lo = fmin(1.0, inv_q), b_hi = fmax(1.0, inv_q);
+        if (u < b_lo)
+          accept = true;
+        else if (!(u < b_hi))
+          accept = false;
+        else
+          accept = u < (member_sorted_lane(g.col + sb, m, x) ? 1.0 : inv_q);
+      }
     }
     if (!accept) {
       ++trial;
