@@ -124,3 +124,25 @@ def test_on_device_corpus_feeds_sgns_without_dataframe():
     m = n2v.fit()
     assert m.wv.vectors.shape[1] == 64 and np.isfinite(m.wv.vectors).all()
     assert len(m.wv.vocab) == int(torch.unique(walks).numel())
+
+
+def test_three_stage_example_pipeline(tmp_path):
+    """examples/hip_pipeline.py: index | walk | embed through parquet stage files"""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    names = [f"v{i}" for i in range(40)]
+    rng = np.random.default_rng(0)
+    df = pd.DataFrame({"src": rng.choice(names, 300), "dst": rng.choice(names, 300)})
+    df = df[df["src"] != df["dst"]]
+    csv = tmp_path / "edges.csv"
+    df.to_csv(csv, index=False)
+    work = str(tmp_path / "work")
+    for stage, extra in (("index", [str(csv)]), ("walk", []), ("embed", [])):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "examples", "hip_pipeline.py"), stage, work] + extra)
+    vec = pd.read_parquet(os.path.join(work, "graph_vectors.parquet"))
+    assert list(vec.columns) == ["name", "vector"] and set(vec["name"]) <= set(names)
+    assert len(vec) > 30 and all(len(v) == 128 for v in vec["vector"])
+    assert open(os.path.join(work, "vectors.w2v")).readline().split()[1] == "128"

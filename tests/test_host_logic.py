@@ -196,3 +196,22 @@ def test_shard_range_is_a_disjoint_cover():
         shard_range(5, 2, 2)
     bases = {sentence_base(r, 4, 100, e) for r in range(4) for e in range(3)}
     assert len(bases) == 12
+
+
+def test_walk_stage_files_round_trip(tmp_path):
+    """parquet stage files with the reference's [src, walk] schema (examples/fugue_spark.py:60)"""
+    from node2vec_amd import io as n2v_io
+
+    walks = torch.tensor([[3, 1, 2], [0, 2, 2], [5, 5, 1]], dtype=torch.int32)
+    valid = torch.tensor([1, 0, 1], dtype=torch.uint8)
+    path = str(tmp_path / "stage" / "walks.parquet")
+    assert n2v_io.write_walks(path, walks, valid) == 2
+    df = n2v_io.read_table(path)
+    assert list(df.columns) == ["src", "walk"] and df["src"].tolist() == [3, 5]
+    assert [list(w) for w in df["walk"]] == [[3, 1, 2], [5, 5, 1]]
+    back = n2v_io.read_walks(path)
+    assert back.dtype == torch.int32 and back.tolist() == [[3, 1, 2], [5, 5, 1]]
+    assert n2v_io.write_walks(str(tmp_path / "empty.parquet"), walks[:0]) == 0
+    vec = pd.DataFrame({"id": [1, 2], "vector": [[0.5, 1.0], [2.0, 3.0]]})
+    n2v_io.write_vectors(str(tmp_path / "v.parquet"), vec)
+    assert n2v_io.read_table(str(tmp_path / "v.parquet"))["id"].tolist() == [1, 2]
