@@ -393,14 +393,41 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
       const int limit = __builtin_amdgcn_readfirstlane(min(total_u, above) - consumed);
       int j = 0;
       bool demoted = false;
-      while (j < limit) {  // probs[over] = probs[over] + probs[under] - 1.0
+      // probs[over] = probs[over] + probs[under] - 1.0, one absorbed slot per step.  With
+      // vO < 1 the residual never increases, so four steps can be taken at once and only
+      // the last one tested; the exact exit step is resolved when it dropped below 1.0.
+      while (j + 4 <= limit) {
+        N2V_STAT(8, 4);
+        const double a1 = r + vO - 1.0;
+        const double a2 = a1 + vO - 1.0;
+        const double a3 = a2 + vO - 1.0;
+        const double a4 = a3 + vO - 1.0;
+        if (!(a4 < 1.0)) {
+          r = a4;
+          j += 4;
+          continue;
+        }
+        demoted = true;
+        if (a1 < 1.0) {
+          r = a1;
+          j += 1;
+        } else if (a2 < 1.0) {
+          r = a2;
+          j += 2;
+        } else if (a3 < 1.0) {
+          r = a3;
+          j += 3;
+        } else {
+          r = a4;
+          j += 4;
+        }
+        break;
+      }
+      while (!demoted && j < limit) {
         N2V_STAT(8, 1);
         r = r + vO - 1.0;
         ++j;
-        if (r < 1.0) {
-          demoted = true;
-          break;
-        }
+        if (r < 1.0) demoted = true;
       }
       r = readfirstlane_f64(r);
       consumed += j;
