@@ -68,6 +68,30 @@ __device__ __forceinline__ uint64_t valid_mask(const UnitStep &c, int chunk) {
   return rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
 }
 
+// number of pivots < x among the 64 pivots parked in LDS (0..63): the 1/64 slice of the
+// sorted row that can contain x
+__device__ __forceinline__ int pivot_slice(const int32_t *piv, int32_t x) {
+  int a = 0, b = 64;
+#pragma unroll
+  for (int it = 0; it < 7; ++it) {
+    const int mid = (a + b) >> 1;
+    const bool act = a < b;
+    const bool less = act && piv[mid < 64 ? mid : 63] < x;
+    a = (act && less) ? mid + 1 : a;
+    b = (act && !less) ? mid : b;
+  }
+  return a < 63 ? a : 63;
+}
+
+// park 64 pivots row[(l+1)*stride - 1] of a sorted row in LDS
+__device__ __forceinline__ void park_pivots(int32_t *piv, const int32_t *row, int len, int stride,
+                                            int lane) {
+  const int pi = (lane + 1) * stride - 1;
+  piv[lane] = row[pi < len ? pi : len - 1];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // class ballots of one chunk: from LDS when cached, else by searching again
 __device__ __forceinline__ void chunk_classes(const UnitStep &c, UnitLds &L, int chunk, int lane,
                                               uint64_t &rm, uint64_t &mm) {
@@ -89,14 +113,37 @@ __device__ __forceinline__ void chunk_classes(const UnitStep &c, UnitLds &L, int
   mm = ballot64(is_mem);
 }
 
+// member test through the 64 pivots of N(s) parked in `piv`: LDS search for the slice,
+// then a binary search confined to it (log2(m/64) global rounds instead of log2(m))
+__device__ __forceinline__ bool member_pivoted(const UnitStep &c, const int32_t *piv, int stride,
+                                               int iters, int32_t x) {
+  int lo = pivot_slice(piv, x) * stride;
+  int hi = lo + stride;
+  lo = lo < c.m ? lo : c.m;
+  hi = hi < c.m ? hi : c.m;
+  for (int it = 0; it < iters; ++it) {
+    const int mid = (lo + hi) >> 1;
+    const int32_t val = c.scol[mid < c.m ? mid : c.m - 1];
+    const bool act = lo < hi;
+    const bool less = val < x;
+    lo = (act && less) ? mid + 1 : lo;
+    hi = (act && !less) ? mid : hi;
+  }
+  return c.scol[lo < c.m ? lo : c.m - 1] == x && lo < c.m;
+}
+
 __device__ __forceinline__ void verify_unit(const UnitStep &c, UnitLds &L, int count, int lane,
                                             bool staged, int &nM) {
+  const int stride_s = (c.m + 63) >> 6;
+  const int iters_s = 32 - __clz(stride_s);
   for (int k = 0; k < count; k += 64) {
     const bool act = k + lane < count;
     const int i = act ? L.mlist[k + lane] : 0;
     const int32_t x = act ? c.vcol[i] : -1;
+    // not staged = large-filter mode: the small filter `bits` is idle and holds the pivots
     const bool mem = (staged ? member_lds(L.pool, c.m, x, c.iters)
-                             : member_sorted(c.scol, c.m, x, c.iters)) && act;
+                             : member_pivoted(c, reinterpret_cast<const int32_t *>(L.bits),
+                                              stride_s, iters_s, x)) && act;
     const int ci = c.nch - 1 - (i >> 6);
     if (mem && ci < kUC)
       atomicOr(reinterpret_cast<unsigned long long *>(&L.cls[2 * ci + 1]), 1ull << (i & 63));
@@ -131,12 +178,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
     // gather, parked in LDS (mlist is idle here); each lane then finds its 1/64
     // slice by LDS binary search, leaving log2(n/64) global rounds instead of log2(n)
     const int stride = (n + 63) >> 6;
-    {
-      const int pi = (lane + 1) * stride - 1;
-      L.mlist[lane] = c.vcol[pi < n ? pi : n - 1];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    park_pivots(L.mlist, c.vcol, n, stride, lane);
     const int iters_n = 32 - __clz(stride);
     for (int base = 0; base < items; base += 256) {
       int32_t x[4];
@@ -158,18 +200,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
       bool found[4];
       int slice[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {  // slice = number of pivots < x  (0..64)
-        int a = 0, b = 64;
-#pragma unroll
-        for (int it = 0; it < 7; ++it) {
-          const int mid = (a + b) >> 1;
-          const bool less = a < b && L.mlist[mid < 64 ? mid : 63] < x[u];
-          const bool act = a < b;
-          a = (act && less) ? mid + 1 : a;
-          b = (act && !less) ? mid : b;
-        }
-        slice[u] = a < 63 ? a : 63;  // x above the last pivot: search the last slice
-      }
+      for (int u = 0; u < 4; ++u) slice[u] = pivot_slice(L.mlist, x[u]);
       lower_bound_slices_x4(c.vcol, n, stride, slice, x, iters_n, lo, found);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -206,6 +237,11 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   const bool use_filter = big_filter || (staged && c.nch > 2);
   uint32_t *fbits = staged ? L.bits : L.pool;
   int shift = 32;
+  const bool direct = c.need_mem && !staged && !big_filter;
+  const int stride_s = (c.m + 63) >> 6;
+  const int iters_s = 32 - __clz(stride_s);
+  if (big_filter) park_pivots(reinterpret_cast<int32_t *>(L.bits), c.scol, c.m, stride_s, lane);
+  if (direct) park_pivots(L.mlist, c.scol, c.m, stride_s, lane);  // no filter hits in this mode
   if (staged || big_filter) {
     if (use_filter) {
       const int cap = staged ? kBitsA : kBitsB;
@@ -257,8 +293,11 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
 #pragma unroll
         for (int u = 0; u < 4; ++u)
           if (chunk0 + u < c.nch) memv[u] = member_lds(L.pool, c.m, xs[u], c.iters);
-      } else {
-        member_sorted_x4(c.scol, c.m, xs, c.iters, memv);  // 4 interleaved searches
+      } else {  // direct: shared pivot level, then 4 interleaved confined searches
+        int slice[4], lo4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) slice[u] = pivot_slice(L.mlist, xs[u]);
+        lower_bound_slices_x4(c.scol, c.m, stride_s, slice, xs, iters_s, lo4, memv);
       }
     }
 #pragma unroll
