@@ -113,6 +113,24 @@ __device__ __forceinline__ void chunk_classes(const UnitStep &c, UnitLds &L, int
   mm = ballot64(is_mem);
 }
 
+// one lower_bound confined to a slice of a sorted row (see lower_bound_slices_x4)
+__device__ __forceinline__ int lower_bound_slice(const int32_t *a, int m, int stride, int slice,
+                                                 int32_t x, int iters, bool &found) {
+  int lo = slice * stride, hi = lo + stride;
+  lo = lo < m ? lo : m;
+  hi = hi < m ? hi : m;
+  for (int it = 0; it < iters; ++it) {
+    const int mid = (lo + hi) >> 1;
+    const int32_t val = a[mid < m ? mid : m - 1];
+    const bool act = lo < hi;
+    const bool less = val < x;
+    lo = (act && less) ? mid + 1 : lo;
+    hi = (act && !less) ? mid : hi;
+  }
+  found = a[lo < m ? lo : m - 1] == x && lo < m;
+  return lo;
+}
+
 // member test through the 64 pivots of N(s) parked in `piv`: LDS search for the slice,
 // then a binary search confined to it (log2(m/64) global rounds instead of log2(m))
 __device__ __forceinline__ bool member_pivoted(const UnitStep &c, const int32_t *piv, int stride,
@@ -180,44 +198,47 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
     const int stride = (n + 63) >> 6;
     park_pivots(L.mlist, c.vcol, n, stride, lane);
     const int iters_n = 32 - __clz(stride);
-    for (int base = 0; base < items; base += 256) {
-      int32_t x[4];
-      bool isret[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = base + u * 64 + lane;
-        isret[u] = k == 0;
-        x[u] = -1;
-        if (k == 0) {
-          x[u] = c.s;
-        } else if (k < items) {
-          const int32_t y = c.scol[k - 1];
-          const int32_t prev = k >= 2 ? c.scol[k - 2] : -1;
-          x[u] = (y == c.s || y == prev) ? -1 : y;  // return slot / repeated id
+    auto mark = [&](bool f, int j, int32_t xv, bool isr) {  // every occurrence of xv in N(v)
+      while (ballot64(f) != 0ull) {
+        if (f) {
+          const int ci = c.nch - 1 - (j >> 6);
+          if (ci < kUC)
+            atomicOr(reinterpret_cast<unsigned long long *>(&L.cls[2 * ci + (isr ? 0 : 1)]),
+                     1ull << (j & 63));
         }
+        nR += __popcll(ballot64(f && isr));
+        nM += __popcll(ballot64(f && !isr));
+        ++j;
+        f = f && j < n && c.vcol[j < n ? j : n - 1] == xv;
       }
-      int lo[4];
-      bool found[4];
-      int slice[4];
+    };
+    auto item = [&](int k, bool &isr) -> int32_t {  // item 0 = s, item k = N(s)[k-1]
+      isr = k == 0;
+      if (k == 0) return c.s;
+      if (k >= items) return -1;
+      const int32_t y = c.scol[k - 1];
+      const int32_t prev = k >= 2 ? c.scol[k - 2] : -1;
+      return (y == c.s || y == prev) ? -1 : y;  // return slot / repeated id: skip
+    };
+    if (items <= 64) {  // one search per lane is enough
+      bool isr, found;
+      const int32_t xv = item(lane, isr);
+      const int lo1 = lower_bound_slice(c.vcol, n, stride, pivot_slice(L.mlist, xv), xv, iters_n,
+                                        found);
+      mark(found && xv >= 0, lo1, xv, isr);
+    } else {
+      for (int base = 0; base < items; base += 256) {
+        int32_t x[4];
+        bool isret[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) slice[u] = pivot_slice(L.mlist, x[u]);
-      lower_bound_slices_x4(c.vcol, n, stride, slice, x, iters_n, lo, found);
+        for (int u = 0; u < 4; ++u) x[u] = item(base + u * 64 + lane, isret[u]);
+        int lo[4], slice[4];
+        bool found[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        bool f = found[u] && x[u] >= 0;
-        int j = lo[u];
-        while (ballot64(f) != 0ull) {
-          if (f) {
-            const int ci = c.nch - 1 - (j >> 6);
-            if (ci < kUC)
-              atomicOr(reinterpret_cast<unsigned long long *>(&L.cls[2 * ci + (isret[u] ? 0 : 1)]),
-                       1ull << (j & 63));
-          }
-          nR += __popcll(ballot64(f && isret[u]));
-          nM += __popcll(ballot64(f && !isret[u]));
-          ++j;
-          f = f && j < n && c.vcol[j < n ? j : n - 1] == x[u];
-        }
+        for (int u = 0; u < 4; ++u) slice[u] = pivot_slice(L.mlist, x[u]);
+        lower_bound_slices_x4(c.vcol, n, stride, slice, x, iters_n, lo, found);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mark(found[u] && x[u] >= 0, lo[u], x[u], isret[u]);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -293,6 +314,9 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
 #pragma unroll
         for (int u = 0; u < 4; ++u)
           if (chunk0 + u < c.nch) memv[u] = member_lds(L.pool, c.m, xs[u], c.iters);
+      } else if (c.nch - chunk0 == 1) {  // direct, a single chunk left: one search, not four
+        lower_bound_slice(c.scol, c.m, stride_s, pivot_slice(L.mlist, xs[0]), xs[0], iters_s,
+                          memv[0]);
       } else {  // direct: shared pivot level, then 4 interleaved confined searches
         int slice[4], lo4[4];
 #pragma unroll
