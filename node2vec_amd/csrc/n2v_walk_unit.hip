@@ -301,7 +301,42 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   N2V_STAT(11, (staged && !use_filter) ? 1 : 0); N2V_STAT(12, big_filter ? 1 : 0);
   // ---- pass 1: stream N(v) ids, classify, count ---------------------------------
   int mcount = 0;
-  for (int chunk0 = 0; chunk0 < c.nch; chunk0 += 4) {
+  // classify one chunk given its ids and (outside filter mode) the membership flags
+  auto finish_chunk = [&](int chunk, int32_t x, bool memflag) {
+    const int i = chunk * 64 + lane;
+    const bool valid = i < n;
+    const bool is_ret = valid && x == c.s;
+    bool is_mem = false, maybe = false;
+    if (use_filter) {
+      const uint32_t h = hash_id(x, shift);
+      maybe = valid && !is_ret && ((fbits[h >> 5] >> (h & 31)) & 1u);
+    } else {
+      is_mem = memflag && valid && !is_ret;
+    }
+    const uint64_t rm = ballot64(is_ret), mm = ballot64(is_mem);
+    nR += __popcll(rm);
+    nM += __popcll(mm);
+    const int ci = c.nch - 1 - chunk;
+    if (ci < kUC && lane == 0) {
+      L.cls[2 * ci] = rm;
+      L.cls[2 * ci + 1] = mm;
+    }
+    const uint64_t ym = ballot64(maybe);
+    if (ym) {
+      const int cnt = __popcll(ym);
+      if (mcount + cnt > kMaybeU) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        verify_unit(c, L, mcount, lane, staged, nM);
+        mcount = 0;
+      }
+      if (maybe) L.mlist[mcount + __popcll(ym & ((1ull << lane) - 1ull))] = i;
+      mcount += cnt;
+    }
+  };
+  const bool search_here = c.need_mem && !use_filter;  // staged (short rows) or direct
+  int chunk0 = 0;
+  for (; chunk0 + 4 <= c.nch; chunk0 += 4) {  // full groups: 4 loads / 4 searches in flight
     int32_t xs[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -309,14 +344,10 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
       xs[u] = i < n ? c.vcol[i] : -1;
     }
     bool memv[4] = {false, false, false, false};
-    if (c.need_mem && !use_filter) {
+    if (search_here) {
       if (staged) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (chunk0 + u < c.nch) memv[u] = member_lds(L.pool, c.m, xs[u], c.iters);
-      } else if (c.nch - chunk0 == 1) {  // direct, a single chunk left: one search, not four
-        lower_bound_slice(c.scol, c.m, stride_s, pivot_slice(L.mlist, xs[0]), xs[0], iters_s,
-                          memv[0]);
+        for (int u = 0; u < 4; ++u) memv[u] = member_lds(L.pool, c.m, xs[u], c.iters);
       } else {  // direct: shared pivot level, then 4 interleaved confined searches
         int slice[4], lo4[4];
 #pragma unroll
@@ -325,40 +356,19 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int chunk = chunk0 + u;
-      if (chunk >= c.nch) break;  // wave-uniform
-      const int i = chunk * 64 + lane;
-      const bool valid = i < n;
-      const bool is_ret = valid && xs[u] == c.s;
-      bool is_mem = false, maybe = false;
-      if (use_filter) {
-        const uint32_t h = hash_id(xs[u], shift);
-        maybe = valid && !is_ret && ((fbits[h >> 5] >> (h & 31)) & 1u);
-      } else {
-        is_mem = memv[u] && valid && !is_ret;
-      }
-      const uint64_t rm = ballot64(is_ret), mm = ballot64(is_mem);
-      nR += __popcll(rm);
-      nM += __popcll(mm);
-      const int ci = c.nch - 1 - chunk;
-      if (ci < kUC && lane == 0) {
-        L.cls[2 * ci] = rm;
-        L.cls[2 * ci + 1] = mm;
-      }
-      const uint64_t ym = ballot64(maybe);
-      if (ym) {
-        const int cnt = __popcll(ym);
-        if (mcount + cnt > kMaybeU) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          verify_unit(c, L, mcount, lane, staged, nM);
-          mcount = 0;
-        }
-        if (maybe) L.mlist[mcount + __popcll(ym & ((1ull << lane) - 1ull))] = i;
-        mcount += cnt;
-      }
+    for (int u = 0; u < 4; ++u) finish_chunk(chunk0 + u, xs[u], memv[u]);
+  }
+  for (; chunk0 < c.nch; ++chunk0) {  // remainder (and every row of <= 3 chunks): one at a time
+    const int i = chunk0 * 64 + lane;
+    const int32_t x = i < n ? c.vcol[i] : -1;
+    bool memflag = false;
+    if (search_here) {
+      if (staged)
+        memflag = member_lds(L.pool, c.m, x, c.iters);
+      else
+        lower_bound_slice(c.scol, c.m, stride_s, pivot_slice(L.mlist, x), x, iters_s, memflag);
     }
+    finish_chunk(chunk0, x, memflag);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
