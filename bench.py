@@ -72,12 +72,16 @@ def main():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # under torch.distributed.run (RANK set) always go through RCCL, also at N=1: the same
+    # code path at every N
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -130,7 +134,7 @@ def main():
             abytes += algorithmic_bytes_exact(torch, g, walks, v)
     t = torch.tensor([elapsed, float(steps_done), float(abytes), sum(kernel_ms)],
                      dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -167,21 +171,21 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, g, start_all, W, L)
     if args.mode == "exact" and not args.no_fast:
-        fm = bench_fast(args, torch, dist, g, rw, batch, walks, valid, rank, world, barrier)
+        fm = bench_fast(args, torch, dist, g, rw, batch, walks, valid, rank, world, barrier, use_dist)
         if rank == 0:
             out["fast_mode"] = fm
     if not args.no_sgns:
-        sg = bench_sgns(args, torch, dist, g, walks, valid, rank, world, barrier)
+        sg = bench_sgns(args, torch, dist, g, walks, valid, rank, world, barrier, use_dist)
         if rank == 0:
             out["sgns"] = sg
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def bench_fast(args, torch, dist, g, rw, batch, walks, valid, rank, world, barrier):
+def bench_fast(args, torch, dist, g, rw, batch, walks, valid, rank, world, barrier, use_dist=False):
     """Secondary figure: the same K steps with the rejection sampler (N2V_WALK_FAST,
     same transition distribution, not the same draws).  Algorithmic bytes per accepted
     step: 16 + T*(16 + [s>=0: 16 + 4*ceil(log2(deg(s)+1))]) + 4."""
@@ -224,7 +228,7 @@ def bench_fast(args, torch, dist, g, rw, batch, walks, valid, rank, world, barri
         per_trial = 16.0 + (16.0 + 4.0 * torch.ceil(torch.log2(ds + 1.0))).mean().item() * (L - 1) / L
         abytes += 20.0 * n_steps + tr * per_trial
     t = torch.tensor([elapsed, float(steps_done)], dtype=torch.float64, device=walks.device)
-    if world > 1:
+    if use_dist:
         tm, ts = t.clone(), t.clone()
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         dist.all_reduce(ts, op=dist.ReduceOp.SUM)
@@ -243,7 +247,7 @@ def bench_fast(args, torch, dist, g, rw, batch, walks, valid, rank, world, barri
                          "algorithmic_bytes_per_walk_step": abytes / max(steps_done, 1)}}
 
 
-def bench_sgns(args, torch, dist, g, walks, valid, rank, world, barrier):
+def bench_sgns(args, torch, dist, g, walks, valid, rank, world, barrier, use_dist=False):
     """Second timed loop: K steps of the SGNS kernel (embedding-updates/s).  One step =
     one launch over the block of walks of one walk step (batch x W rows of L+1 tokens),
     vocabulary = every vertex (min_count=0, sample=0: deterministic unit counts), dim
@@ -278,7 +282,7 @@ def bench_sgns(args, torch, dist, g, walks, valid, rank, world, barrier):
     elapsed = _t.perf_counter() - t0
     pairs = float(model.pairs.item())
     t = torch.tensor([elapsed, pairs], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         tm = t.clone()
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         ts = t.clone()
@@ -300,7 +304,7 @@ def bench_sgns(args, torch, dist, g, walks, valid, rank, world, barrier):
                         "kernel": "sgns_kernel", "kernel_ms": 1e3 * kernel_s,
                         "algorithmic_bytes_per_pair": bytes_per_pair,
                         "fma_utilisation": pairs / args.steps * flops_per_pair / kernel_s / 157.3e12}}
-    if world > 1:  # the exchange step: one delta all-reduce of both matrices
+    if use_dist:  # the exchange step: one delta all-reduce of both matrices
         sync = sgns.DeltaAllReduce([model.syn0, model.syn1neg], block_rows=1 << 18)
         barrier()
         t0 = _t.perf_counter()

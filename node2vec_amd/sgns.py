@@ -183,9 +183,10 @@ class DeltaAllReduce:
         self.tensors = list(model_tensors)
         self.synced = [t.clone() for t in self.tensors]
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized()
 
     def __call__(self, _model=None):
-        if self.world == 1:
+        if not self.active:
             return
         for t, s in zip(self.tensors, self.synced):
             for lo in range(0, t.shape[0], self.block_rows):
