@@ -111,7 +111,7 @@ __device__ __forceinline__ int bisect_left_u32(const uint32_t *a, int64_t n, uin
   return (int)lo;
 }
 
-template <int VEC>
+template <int VEC, bool kAhead>
 __global__ __launch_bounds__(kSgnsWaves * 64) void sgns_kernel(
     const int32_t *__restrict__ walks, int64_t n_walks, int32_t walk_len, float *syn0,
     float *syn1neg, const uint32_t *__restrict__ cum_table,
@@ -206,56 +206,138 @@ __global__ __launch_bounds__(kSgnsWaves * 64) void sgns_kernel(
       Row<VEC> crow;
       load_row<VEC>(pc, dim, lane, full, crow);
       constexpr int KP = VEC <= 4 ? 5 : (VEC == 8 ? 3 : 1);  // negative rows in flight
-      for (int j = lo; j < hi; ++j) {
-        if (j == i) continue;
+      struct PairBuf {
+        Row<VEC> row1;
+        Row<VEC> rows[KP];
+        int32_t tg[KP];
+        int j;
+        bool late_row1;    // the pair trained just before writes this row: load it afterwards
+        bool late[KP];
+      };
+      // start every row load of pair (i, j): the context row and the first KP negatives
+      // Start the row loads of pair (i, j): the context row and the first KP negatives.
+      // `jprev` >= 0 names the pair that will be trained between this request and the use
+      // of the rows (lookahead): a row that pair writes -- its context row, or any of its
+      // K negatives -- must not be read early, so it is marked `late` and loaded when the
+      // pair is processed.  With that, lookahead order == sequential order, bit for bit.
+      auto issue_negs = [&](int j, int jprev, PairBuf &B) {
+        const int32_t *ng = neg + (j - lo) * K;
+#pragma unroll
+        for (int e = 0; e < KP; ++e) {
+          // targets are wave-uniform; an LDS load is lane-varying to the compiler
+          B.tg[e] = (e < K) ? __builtin_amdgcn_readfirstlane(ng[e]) : centre;  // centre = "skip"
+          B.late[e] = false;
+        }
+        if (jprev >= 0) {
+          const int32_t *ngp = neg + (jprev - lo) * K;
+          for (int d = 0; d < K; ++d) {
+            const int32_t tp = __builtin_amdgcn_readfirstlane(ngp[d]);
+#pragma unroll
+            for (int e = 0; e < KP; ++e) B.late[e] = B.late[e] || B.tg[e] == tp;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < KP; ++e)
+          if (B.tg[e] != centre && !B.late[e])
+            load_row<VEC>(syn1neg + (int64_t)B.tg[e] * dim, dim, lane, full, B.rows[e]);
+      };
+      auto issue = [&](int j, int jprev, PairBuf &B) {
+        B.j = j;
+        B.late_row1 = jprev >= 0 && sent[j] == sent[jprev];
+        if (!B.late_row1) load_row<VEC>(syn0 + (int64_t)sent[j] * dim, dim, lane, full, B.row1);
+        if (kAhead) issue_negs(j, jprev, B);  // strict order requests them after the centre word
+      };
+      // one negative target: f, sigma, the two FMAs, store (word2vec's inner body, label 0)
+      auto train_negative = [&](Row<VEC> &row1, Row<VEC> &work, Row<VEC> &row2, float *p2) {
+        const float f = wave_dot<VEC>(row1, row2);
+        if (f <= -6.0f || f >= 6.0f) return;
+        const float g = (0.0f - exp_lds[(int)((f + 6.0f) * 83.0f)]) * alpha;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          work.v[v] = __fmaf_rn(g, row2.v[v], work.v[v]);
+          row2.v[v] = __fmaf_rn(g, row1.v[v], row2.v[v]);
+        }
+        store_row<VEC>(p2, dim, lane, full, row2);
+      };
+      auto process = [&](PairBuf &A) {
+        const int j = A.j;
         float *p1 = syn0 + (int64_t)sent[j] * dim;
-        Row<VEC> row1, work;
-        load_row<VEC>(p1, dim, lane, full, row1);
+        if (A.late_row1) load_row<VEC>(p1, dim, lane, full, A.row1);
+        Row<VEC> work;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) work.v[v] = 0.0f;
         {  // d == 0: the centre word, label 1
-          const float f = wave_dot<VEC>(row1, crow);
+          const float f = wave_dot<VEC>(A.row1, crow);
           if (!(f <= -6.0f || f >= 6.0f)) {
             const float g = (1.0f - exp_lds[(int)((f + 6.0f) * 83.0f)]) * alpha;
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
               work.v[v] = __fmaf_rn(g, crow.v[v], work.v[v]);
-              crow.v[v] = __fmaf_rn(g, row1.v[v], crow.v[v]);
+              crow.v[v] = __fmaf_rn(g, A.row1.v[v], crow.v[v]);
             }
           }
         }
+        if (!kAhead) issue_negs(j, -1, A);
+#pragma unroll
+        for (int e = 0; e < KP; ++e) {  // first group: rows already in flight
+          if (A.tg[e] == centre) continue;  // drawn the centre word, or past K
+          float *p2 = syn1neg + (int64_t)A.tg[e] * dim;
+          bool dup = A.late[e];  // written by the previous pair, or earlier in this group:
+#pragma unroll                   // read the update back
+          for (int e2 = 0; e2 < e; ++e2) dup = dup || A.tg[e2] == A.tg[e];
+          if (dup) load_row<VEC>(p2, dim, lane, full, A.rows[e]);
+          train_negative(A.row1, work, A.rows[e], p2);
+        }
         const int32_t *ng = neg + (j - lo) * K;
-        for (int d0 = 0; d0 < K; d0 += KP) {  // negatives, KP rows prefetched together
+        for (int d0 = KP; d0 < K; d0 += KP) {  // further groups (negative > KP)
           int32_t tg[KP];
           Row<VEC> rows[KP];
 #pragma unroll
           for (int e = 0; e < KP; ++e) {
-            tg[e] = (d0 + e < K) ? ng[d0 + e] : centre;  // centre = "skip"
+            tg[e] = (d0 + e < K) ? __builtin_amdgcn_readfirstlane(ng[d0 + e]) : centre;
             if (tg[e] != centre) load_row<VEC>(syn1neg + (int64_t)tg[e] * dim, dim, lane, full, rows[e]);
           }
 #pragma unroll
           for (int e = 0; e < KP; ++e) {
-            if (tg[e] == centre) continue;  // drawn the centre word, or past K
+            if (tg[e] == centre) continue;
             float *p2 = syn1neg + (int64_t)tg[e] * dim;
-            bool dup = false;  // same row earlier in this group: read its update back
+            bool dup = false;
 #pragma unroll
             for (int e2 = 0; e2 < e; ++e2) dup = dup || tg[e2] == tg[e];
             if (dup) load_row<VEC>(p2, dim, lane, full, rows[e]);
-            const float f = wave_dot<VEC>(row1, rows[e]);
-            if (f <= -6.0f || f >= 6.0f) continue;
-            const float g = (0.0f - exp_lds[(int)((f + 6.0f) * 83.0f)]) * alpha;
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-              work.v[v] = __fmaf_rn(g, rows[e].v[v], work.v[v]);
-              rows[e].v[v] = __fmaf_rn(g, row1.v[v], rows[e].v[v]);
-            }
-            store_row<VEC>(p2, dim, lane, full, rows[e]);
+            train_negative(A.row1, work, rows[e], p2);
           }
         }
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) row1.v[v] = row1.v[v] + work.v[v];
-        store_row<VEC>(p1, dim, lane, full, row1);
+        for (int v = 0; v < VEC; ++v) A.row1.v[v] = A.row1.v[v] + work.v[v];
+        store_row<VEC>(p1, dim, lane, full, A.row1);
         ++pairs;
+      };
+      int j = lo + (lo == i ? 1 : 0);
+      if (kAhead) {
+        // The kernel is latency-bound (waves spend ~87 % of their cycles waiting on
+        // memory), so the next pair's rows are requested before this pair is trained:
+        // two pairs' worth of loads in flight per wave.  Rows the pair in between writes
+        // are excluded from the early request (see issue), so the result is identical to
+        // training strictly in order -- deterministic mode uses the same path.
+        PairBuf bufA, bufB;
+        if (j < hi) issue(j, -1, bufA);
+        while (j < hi) {
+          int jn = j + 1;
+          if (jn == i) ++jn;
+          if (jn < hi) issue(jn, j, bufB);
+          process(bufA);
+          bufA = bufB;
+          j = jn;
+        }
+      } else {
+        PairBuf buf;
+        while (j < hi) {
+          issue(j, -1, buf);
+          process(buf);
+          ++j;
+          if (j == i) ++j;
+        }
       }
       store_row<VEC>(pc, dim, lane, full, crow);
       __builtin_amdgcn_wave_barrier();
@@ -298,9 +380,18 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   int V = 1;
   while (64 * V < P->dim) V *= 2;
   hipStream_t st = (hipStream_t)stream;
+  const bool ahead = true;  // one-pair lookahead for dim <= 128 (hazard-free, see the kernel)
 #define N2V_LAUNCH(VV)                                                                       \
-  hipLaunchKernelGGL(sgns_kernel<VV>, dim3((unsigned)blocks), block, lds, st, walks, n_walks, \
-                     walk_len, syn0, syn1neg, cum_table, sample_int, exp_table, *P, pairs_out)
+  do {                                                                                       \
+    if (ahead && (VV) <= 2)                                                                    \
+      hipLaunchKernelGGL((sgns_kernel<VV, (VV) <= 2>), dim3((unsigned)blocks), block, lds, st, \
+                         walks, n_walks, walk_len, syn0, syn1neg, cum_table, sample_int,       \
+                         exp_table, *P, pairs_out);                                            \
+    else                                                                                       \
+      hipLaunchKernelGGL((sgns_kernel<VV, false>), dim3((unsigned)blocks), block, lds, st,     \
+                         walks, n_walks, walk_len, syn0, syn1neg, cum_table, sample_int,       \
+                         exp_table, *P, pairs_out);                                            \
+  } while (0)
   switch (V) {
     case 1: N2V_LAUNCH(1); break;
     case 2: N2V_LAUNCH(2); break;
