@@ -383,8 +383,8 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   const bool ahead = true;  // one-pair lookahead for dim <= 128 (hazard-free, see the kernel)
 #define N2V_LAUNCH(VV)                                                                       \
   do {                                                                                       \
-    if (ahead && (VV) <= 2)                                                                    \
-      hipLaunchKernelGGL((sgns_kernel<VV, (VV) <= 2>), dim3((unsigned)blocks), block, lds, st, \
+    if (ahead && (VV) <= 4)                                                                    \
+      hipLaunchKernelGGL((sgns_kernel<VV, (VV) <= 4>), dim3((unsigned)blocks), block, lds, st, \
                          walks, n_walks, walk_len, syn0, syn1neg, cum_table, sample_int,       \
                          exp_table, *P, pairs_out);                                            \
     else                                                                                       \
