@@ -111,7 +111,7 @@ __device__ __forceinline__ int bisect_left_u32(const uint32_t *a, int64_t n, uin
   return (int)lo;
 }
 
-template <int VEC, bool kAhead>
+template <int VEC, int kDepth>  // kDepth: pairs requested ahead of the one being trained
 __global__ __launch_bounds__(kSgnsWaves * 64) void sgns_kernel(
     const int32_t *__restrict__ walks, int64_t n_walks, int32_t walk_len, float *syn0,
     float *syn1neg, const uint32_t *__restrict__ cum_table,
@@ -220,7 +220,8 @@ __global__ __launch_bounds__(kSgnsWaves * 64) void sgns_kernel(
       // of the rows (lookahead): a row that pair writes -- its context row, or any of its
       // K negatives -- must not be read early, so it is marked `late` and loaded when the
       // pair is processed.  With that, lookahead order == sequential order, bit for bit.
-      auto issue_negs = [&](int j, int jprev, PairBuf &B) {
+      constexpr bool kAhead = kDepth > 0;
+      auto issue_negs = [&](int j, int jprev, int jprev2, PairBuf &B) {
         const int32_t *ng = neg + (j - lo) * K;
 #pragma unroll
         for (int e = 0; e < KP; ++e) {
@@ -228,8 +229,10 @@ __global__ __launch_bounds__(kSgnsWaves * 64) void sgns_kernel(
           B.tg[e] = (e < K) ? __builtin_amdgcn_readfirstlane(ng[e]) : centre;  // centre = "skip"
           B.late[e] = false;
         }
-        if (jprev >= 0) {
-          const int32_t *ngp = neg + (jprev - lo) * K;
+        for (int which = 0; which < 2; ++which) {
+          const int jp = which == 0 ? jprev : jprev2;
+          if (jp < 0) continue;
+          const int32_t *ngp = neg + (jp - lo) * K;
           for (int d = 0; d < K; ++d) {
             const int32_t tp = __builtin_amdgcn_readfirstlane(ngp[d]);
 #pragma unroll
@@ -241,11 +244,11 @@ __global__ __launch_bounds__(kSgnsWaves * 64) void sgns_kernel(
           if (B.tg[e] != centre && !B.late[e])
             load_row<VEC>(syn1neg + (int64_t)B.tg[e] * dim, dim, lane, full, B.rows[e]);
       };
-      auto issue = [&](int j, int jprev, PairBuf &B) {
+      auto issue = [&](int j, int jprev, int jprev2, PairBuf &B) {
         B.j = j;
-        B.late_row1 = jprev >= 0 && sent[j] == sent[jprev];
+        B.late_row1 = (jprev >= 0 && sent[j] == sent[jprev]) || (jprev2 >= 0 && sent[j] == sent[jprev2]);
         if (!B.late_row1) load_row<VEC>(syn0 + (int64_t)sent[j] * dim, dim, lane, full, B.row1);
-        if (kAhead) issue_negs(j, jprev, B);  // strict order requests them after the centre word
+        if (kAhead) issue_negs(j, jprev, jprev2, B);  // strict order: after the centre word
       };
       // one negative target: f, sigma, the two FMAs, store (word2vec's inner body, label 0)
       auto train_negative = [&](Row<VEC> &row1, Row<VEC> &work, Row<VEC> &row2, float *p2) {
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(kSgnsWaves * 64) void sgns_kernel(
             }
           }
         }
-        if (!kAhead) issue_negs(j, -1, A);
+        if (!kAhead) issue_negs(j, -1, -1, A);
 #pragma unroll
         for (int e = 0; e < KP; ++e) {  // first group: rows already in flight
           if (A.tg[e] == centre) continue;  // drawn the centre word, or past K
@@ -320,20 +323,36 @@ __global__ __launch_bounds__(kSgnsWaves * 64) void sgns_kernel(
         // two pairs' worth of loads in flight per wave.  Rows the pair in between writes
         // are excluded from the early request (see issue), so the result is identical to
         // training strictly in order -- deterministic mode uses the same path.
-        PairBuf bufA, bufB;
-        if (j < hi) issue(j, -1, bufA);
-        while (j < hi) {
-          int jn = j + 1;
-          if (jn == i) ++jn;
-          if (jn < hi) issue(jn, j, bufB);
-          process(bufA);
-          bufA = bufB;
-          j = jn;
+        auto next_pair = [&](int jj) { return jj + 1 == i ? jj + 2 : jj + 1; };
+        if constexpr (kDepth == 1) {
+          PairBuf bufA, bufB;
+          if (j < hi) issue(j, -1, -1, bufA);
+          while (j < hi) {
+            const int jn = next_pair(j);
+            if (jn < hi) issue(jn, j, -1, bufB);
+            process(bufA);
+            bufA = bufB;
+            j = jn;
+          }
+        } else {
+          PairBuf b0, b1, b2;
+          int j0 = j, j1 = next_pair(j0), j2 = next_pair(j1);
+          if (j0 < hi) issue(j0, -1, -1, b0);
+          if (j1 < hi) issue(j1, j0, -1, b1);
+          while (j0 < hi) {
+            if (j2 < hi) issue(j2, j1, j0, b2);  // pairs j0 and j1 are trained before j2
+            process(b0);
+            b0 = b1;
+            b1 = b2;
+            j0 = j1;
+            j1 = j2;
+            j2 = next_pair(j2);
+          }
         }
       } else {
         PairBuf buf;
         while (j < hi) {
-          issue(j, -1, buf);
+          issue(j, -1, -1, buf);
           process(buf);
           ++j;
           if (j == i) ++j;
@@ -380,17 +399,14 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   int V = 1;
   while (64 * V < P->dim) V *= 2;
   hipStream_t st = (hipStream_t)stream;
-  const bool ahead = true;  // one-pair lookahead for dim <= 128 (hazard-free, see the kernel)
+  // lookahead depth: 1 pair for dim <= 256, none above (registers).  Depth 2 was measured
+  // at dim 128: 533 vs 567 M pairs/s -- the third buffer costs a wave of occupancy.
 #define N2V_LAUNCH(VV)                                                                       \
   do {                                                                                       \
-    if (ahead && (VV) <= 4)                                                                    \
-      hipLaunchKernelGGL((sgns_kernel<VV, (VV) <= 4>), dim3((unsigned)blocks), block, lds, st, \
-                         walks, n_walks, walk_len, syn0, syn1neg, cum_table, sample_int,       \
-                         exp_table, *P, pairs_out);                                            \
-    else                                                                                       \
-      hipLaunchKernelGGL((sgns_kernel<VV, false>), dim3((unsigned)blocks), block, lds, st,     \
-                         walks, n_walks, walk_len, syn0, syn1neg, cum_table, sample_int,       \
-                         exp_table, *P, pairs_out);                                            \
+    constexpr int kD = (VV) <= 4 ? 1 : 0;                                                     \
+    hipLaunchKernelGGL((sgns_kernel<VV, kD>), dim3((unsigned)blocks), block, lds, st, walks,  \
+                       n_walks, walk_len, syn0, syn1neg, cum_table, sample_int, exp_table,    \
+                       *P, pairs_out);                                                        \
   } while (0)
   switch (V) {
     case 1: N2V_LAUNCH(1); break;
