@@ -1,0 +1,81 @@
+"""Randomised differential test of the exact walk kernels against the CPU oracle
+(test infrastructure; run on the GPU box):  python scripts/fuzz_walk.py [seconds] [seed]"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import n2v_oracle
+from node2vec_amd import randomwalk as rw
+from node2vec_amd.graph import DeviceGraph
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+THREADS = min(64, os.cpu_count() or 8)
+
+def graph(kind):
+    nv = int(rng.choice([50, 400, 3000, 20000]))
+    if kind == "er":
+        ne = int(nv * rng.choice([2, 8, 30]))
+        src, dst = rng.integers(0, nv, ne), rng.integers(0, nv, ne)
+    elif kind == "powerlaw":
+        ne = int(nv * rng.choice([4, 16]))
+        a = 1.0 + rng.uniform(0.3, 1.5)
+        src = np.minimum((rng.pareto(a, ne)).astype(np.int64), nv - 1)
+        dst = rng.integers(0, nv, ne)
+        if rng.random() < 0.7:
+            src, dst = np.concatenate([src, dst]), np.concatenate([dst, src])
+    elif kind == "hubs":
+        nv = max(nv, 3000)
+        src, dst = list(rng.integers(0, nv, nv * 3)), list(rng.integers(0, nv, nv * 3))
+        for h in rng.integers(0, nv, int(rng.integers(1, 5))):
+            k = int(rng.choice([70, 200, 700, 2500, 9000, 20000]))
+            nb = rng.integers(0, nv, k)
+            src += [h] * k + list(nb); dst += list(nb) + [h] * k
+        src, dst = np.array(src), np.array(dst)
+    else:  # bipartite
+        nh = int(rng.integers(2, 12)); nv = max(nv, 2000)
+        leaves = rng.integers(nh, nv, nh * int(rng.choice([100, 3000, 12000])))
+        hubs = rng.integers(0, nh, len(leaves))
+        src, dst = np.concatenate([hubs, leaves]), np.concatenate([leaves, hubs])
+    if rng.random() < 0.3:  # sinks
+        keep = src % 7 != 3; src, dst = src[keep], dst[keep]
+    if rng.random() < 0.3:  # de-duplicate (otherwise multi-edges stay)
+        key = np.unique(src.astype(np.int64) * nv + dst); src, dst = key // nv, key % nv
+    wk = rng.choice(["unit", "unit", "dyadic", "arbitrary"])
+    if wk == "unit":
+        w = np.ones(len(src), np.float32)
+    elif wk == "dyadic":
+        w = rng.choice([0.25, 0.5, 1.0, 2.0, 1.5], len(src)).astype(np.float32)
+    else:
+        w = rng.uniform(0.01, 5.0, len(src)).astype(np.float32)
+    return nv, src, dst, w, wk
+
+t0 = time.time(); n_cases = 0; n_walks = 0
+while time.time() - t0 < budget:
+    kind = rng.choice(["er", "powerlaw", "hubs", "bipartite"])
+    nv, src, dst, w, wk = graph(kind)
+    if len(src) == 0:
+        continue
+    g = DeviceGraph.from_edges(src, dst, w, n_vertices=nv, device="cuda")
+    p = float(rng.choice([0.25, 0.5, 1.0, 2.0, 4.0, 3.0, 0.7]))
+    q = float(rng.choice([0.25, 0.5, 1.0, 2.0, 4.0, 1.3, 0.1]))
+    nw, wl = int(rng.integers(1, 5)), int(rng.choice([1, 5, 20, 60, 130]))
+    seed = int(rng.integers(0, 2 ** 62))
+    deg = g.degrees()
+    starts = torch.unique(torch.cat([torch.topk(deg, min(20, nv)).indices,
+                                     torch.from_numpy(rng.integers(0, nv, 300)).cuda()])).to(torch.int32)
+    if wk == "arbitrary" and int(deg.max()) > 3000:
+        starts = starts[:60]; wl = min(wl, 20)  # the oracle is O(degree) per step
+    got, gv = rw.walk(g, starts, nw, wl, p, q, seed)
+    want, wv = n2v_oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.w.cpu().numpy(),
+                                      starts.cpu().numpy(), nw, wl, p, q, seed, n_threads=THREADS)
+    ok = np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy(), want)
+    n_cases += 1; n_walks += int(wv.sum())
+    if not ok:
+        bad = np.nonzero((got.cpu().numpy() != want).any(1) | (gv.cpu().numpy() != wv))[0][:5]
+        print("MISMATCH", dict(kind=kind, nv=nv, ne=len(src), weights=wk, p=p, q=q, nw=nw, wl=wl, seed=seed,
+                               maxdeg=int(deg.max()), unit=g.unit_weights), "rows", bad.tolist(), flush=True)
+        for r in bad[:2]:
+            print(" got ", got[r].tolist()[:12], "\n want", want[r].tolist()[:12])
+        sys.exit(1)
+print(f"fuzz ok: {n_cases} cases, {n_walks} walks bit-identical to the oracle in {time.time()-t0:.0f} s")
