@@ -7,8 +7,7 @@
 //
 // Design: one wave64 trains one walk.  A vector of `dim` floats lives across the
 // wave (lane l owns elements l*VEC .. l*VEC+VEC-1, 16-B loads where dim = 64*VEC);
-// dot products are per-lane FMA chains closed by an xor-butterfly over DPP/LDS
-// shuffles; the arithmetic intensity is 0.66 flop/B, so the kernel is a stream of
+// dot products are per-lane FMA chains closed by a DPP + readlane tree reduction; the arithmetic intensity is 0.66 flop/B, so the kernel is a stream of
 // row gathers/scatters against HBM -- plain FMA, no MFMA.  Sentence preparation
 // (vocabulary filter, subsampling, reduced windows) and the negative draws
 // (bisect over the cumulative count^0.75 table) are lane-parallel: every random
@@ -87,14 +86,33 @@ __device__ __forceinline__ void store_row(float *base, int dim, int lane, bool f
   }
 }
 
+// one DPP step: value of the lane selected by `kCtrl` (no LDS round trip)
+template <int kCtrl>
+__device__ __forceinline__ float dpp_move(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), kCtrl, 0xF, 0xF, true));
+}
+
+// Dot product across the wave.  Per-lane FMA chain over its VEC elements, then a balanced
+// tree over adjacent lanes (butterfly distances 1, 2, 4, 8, 16, 32 -- the order the oracle
+// restates).  Distances 1..8 are DPP modifiers on the adds (quad_perm, row_half_mirror,
+// row_mirror: values are already uniform inside the mirrored groups, so mirror == xor);
+// the four row sums are read with v_readlane and combined as (R0 + R1) + (R2 + R3).
+// No LDS crossbar (ds_bpermute cost six dependent LDS round trips per dot), and the
+// result is a scalar to the compiler, so the branches on it are scalar branches.
 template <int VEC>
 __device__ __forceinline__ float wave_dot(const Row<VEC> &a, const Row<VEC> &b) {
   float acc = 0.0f;
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc = __fmaf_rn(a.v[v], b.v[v], acc);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc = acc + __shfl_xor(acc, off, 64);
-  return acc;
+  acc = acc + dpp_move<0xB1>(acc);   // quad_perm [1,0,3,2]  : lane ^ 1
+  acc = acc + dpp_move<0x4E>(acc);   // quad_perm [2,3,0,1]  : lane ^ 2
+  acc = acc + dpp_move<0x141>(acc);  // row_half_mirror      : the other quad  (== lane ^ 4)
+  acc = acc + dpp_move<0x140>(acc);  // row_mirror           : the other half-row (== lane ^ 8)
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 48));
+  return (r0 + r1) + (r2 + r3);      // lane ^ 16, then lane ^ 32
 }
 
 __device__ __forceinline__ int bisect_left_u32(const uint32_t *a, int64_t n, uint32_t x,
@@ -171,8 +189,9 @@ __global__ __launch_bounds__(kSgnsWaves * 64) void sgns_kernel(
     __builtin_amdgcn_wave_barrier();
 
     for (int i = 0; i < nf; ++i) {
-      const int32_t centre = sent[i];
-      const int b = red[i];
+      // LDS loads at a uniform address are lane-varying to the compiler: mark them scalar
+      const int32_t centre = __builtin_amdgcn_readfirstlane(sent[i]);
+      const int b = __builtin_amdgcn_readfirstlane(red[i]);
       const int lo = max(0, i - window + b);
       const int hi = min(nf, i + window + 1 - b);
       // ---- negative draws for every pair of this position, lane-parallel ----
@@ -246,8 +265,10 @@ __global__ __launch_bounds__(kSgnsWaves * 64) void sgns_kernel(
       };
       auto issue = [&](int j, int jprev, int jprev2, PairBuf &B) {
         B.j = j;
-        B.late_row1 = (jprev >= 0 && sent[j] == sent[jprev]) || (jprev2 >= 0 && sent[j] == sent[jprev2]);
-        if (!B.late_row1) load_row<VEC>(syn0 + (int64_t)sent[j] * dim, dim, lane, full, B.row1);
+        const int32_t cj = __builtin_amdgcn_readfirstlane(sent[j]);
+        B.late_row1 = (jprev >= 0 && cj == __builtin_amdgcn_readfirstlane(sent[jprev])) ||
+                      (jprev2 >= 0 && cj == __builtin_amdgcn_readfirstlane(sent[jprev2]));
+        if (!B.late_row1) load_row<VEC>(syn0 + (int64_t)cj * dim, dim, lane, full, B.row1);
         if (kAhead) issue_negs(j, jprev, jprev2, B);  // strict order: after the centre word
       };
       // one negative target: f, sigma, the two FMAs, store (word2vec's inner body, label 0)
@@ -264,7 +285,7 @@ __global__ __launch_bounds__(kSgnsWaves * 64) void sgns_kernel(
       };
       auto process = [&](PairBuf &A) {
         const int j = A.j;
-        float *p1 = syn0 + (int64_t)sent[j] * dim;
+        float *p1 = syn0 + (int64_t)__builtin_amdgcn_readfirstlane(sent[j]) * dim;
         if (A.late_row1) load_row<VEC>(p1, dim, lane, full, A.row1);
         Row<VEC> work;
 #pragma unroll

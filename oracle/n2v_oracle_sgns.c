@@ -55,7 +55,8 @@ static int vec_width(int dim) {
 }
 
 /* dot product in wave64 order: lane l owns elements l*V .. l*V+V-1 (fma chain),
- * then an xor-butterfly over lane distances 32,16,8,4,2,1 */
+ * then an xor-butterfly over lane distances 1,2,4,8,16,32 (a balanced tree over
+ * adjacent lanes: what the kernel's DPP quad/row steps + row-sum combine compute) */
 static float wave_dot(const float *a, const float *b, int dim, int V) {
   float p[64], t[64];
   for (int l = 0; l < 64; ++l) {
@@ -66,7 +67,7 @@ static float wave_dot(const float *a, const float *b, int dim, int V) {
     }
     p[l] = acc;
   }
-  for (int off = 32; off > 0; off >>= 1) {
+  for (int off = 1; off < 64; off <<= 1) {
     for (int l = 0; l < 64; ++l) t[l] = p[l] + p[l ^ off];
     memcpy(p, t, sizeof(p));
   }
