@@ -420,11 +420,11 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   int V = 1;
   while (64 * V < P->dim) V *= 2;
   hipStream_t st = (hipStream_t)stream;
-  // lookahead depth: 1 pair for dim <= 256, none above (registers).  Depth 2 was measured
-  // at dim 128: 533 vs 567 M pairs/s -- the third buffer costs a wave of occupancy.
+  // lookahead depth: 1 pair for dim <= 512, none above (registers).  Depth 2 was measured
+  // twice at dim 128 and lost both times (628 vs 674 M pairs/s at equal occupancy).
 #define N2V_LAUNCH(VV)                                                                       \
   do {                                                                                       \
-    constexpr int kD = (VV) <= 4 ? 1 : 0;                                                     \
+    constexpr int kD = (VV) <= 8 ? 1 : 0;                                                     \
     hipLaunchKernelGGL((sgns_kernel<VV, kD>), dim3((unsigned)blocks), block, lds, st, walks,  \
                        n_walks, walk_len, syn0, syn1neg, cum_table, sample_int, exp_table,    \
                        *P, pairs_out);                                                        \

@@ -16,7 +16,7 @@ deg = g.degrees().clamp(min=1)
 order = torch.sort(deg, descending=True, stable=True).indices
 index_of = torch.empty(g.n_vertices, dtype=torch.int32, device="cuda"); index_of[order] = torch.arange(g.n_vertices, dtype=torch.int32, device="cuda")
 vocab = sgns.Vocab(order, deg[order], index_of)
-for dim in (128, 256):
+for dim in (128, 256, 512):
     m = sgns.SgnsModel(vocab, dim, 5, 5, seed=1, sample=0.0)
     idx = index_of[walks.long()]
     for it in range(3):
