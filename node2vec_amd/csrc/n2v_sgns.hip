@@ -130,7 +130,7 @@ __device__ __forceinline__ int bisect_left_u32(const uint32_t *a, int64_t n, uin
 }
 
 template <int VEC, int kDepth>  // kDepth: pairs requested ahead of the one being trained
-__global__ __launch_bounds__(kSgnsWaves * 64) void sgns_kernel(
+__global__ __launch_bounds__(kSgnsWaves * 64, (VEC <= 2 ? 8 : 1)) void sgns_kernel(
     const int32_t *__restrict__ walks, int64_t n_walks, int32_t walk_len, float *syn0,
     float *syn1neg, const uint32_t *__restrict__ cum_table,
     const uint32_t *__restrict__ sample_int, const float *__restrict__ exp_table_g,
