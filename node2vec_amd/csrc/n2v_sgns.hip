@@ -130,6 +130,8 @@ __device__ __forceinline__ int bisect_left_u32(const uint32_t *a, int64_t n, uin
 }
 
 template <int VEC, int kDepth>  // kDepth: pairs requested ahead of the one being trained
+// dim <= 128 needs 56 VGPRs: hold the full 8 waves per SIMD (the kernel is latency-bound).
+// Forcing 6 waves at dim 256 was measured: it spills and is slower.
 __global__ __launch_bounds__(kSgnsWaves * 64, (VEC <= 2 ? 8 : 1)) void sgns_kernel(
     const int32_t *__restrict__ walks, int64_t n_walks, int32_t walk_len, float *syn0,
     float *syn1neg, const uint32_t *__restrict__ cum_table,
