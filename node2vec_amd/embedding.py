@@ -148,7 +148,15 @@ class Node2VecHIP(Node2VecBase):
         return torch.from_numpy(arr.astype(np.int32)).to(device)
 
     def fit(self, device=None, sync=None, sentence_base: int = 0) -> HipW2V:
-        """Trains and returns the model (embedding.py:120-127)."""
+        """Trains and returns the model (embedding.py:120-127).
+
+        Under an initialised torch.distributed process group (one process per GPU) the
+        walks held by this object are this rank's shard: the vocabulary is built from
+        globally summed counts, every rank starts from the same seeded model, trains on its
+        own walks with disjoint sentence ids, and the model deltas are all-reduced (RCCL)
+        after every block (sgns.DeltaAllReduce), so all ranks return the same vectors."""
+        import torch.distributed as dist
+
         from node2vec_amd import _lib
 
         dev = device or _lib.require_gpu()
@@ -163,6 +171,14 @@ class Node2VecHIP(Node2VecBase):
                            sample=float(p["sample"] or 0.0), ns_exponent=float(p["ns_exponent"]),
                            device=dev)
         idx = sgns.split_rows(vocab.index_of[walks.long()])
+        if sync is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from node2vec_amd.shard import sentence_base as rank_base
+
+            rows = torch.tensor([idx.shape[0]], device=dev)
+            dist.all_reduce(rows, op=dist.ReduceOp.MAX)
+            sentence_base = rank_base(dist.get_rank(), dist.get_world_size(),
+                                      int(rows.item()) * max(int(p["iter"]), 1))
+            sync = sgns.DeltaAllReduce([m.syn0, m.syn1neg])
         m.train(idx, int(p["iter"]), float(p["alpha"]), float(p["min_alpha"]),
                 sentence_base=sentence_base, sync=sync)
         torch.cuda.synchronize(dev)

@@ -41,16 +41,32 @@ class Vocab:
         return self.ids.numel()
 
 
-def build_vocab(walks: torch.Tensor, min_count: int) -> Vocab:
+def build_vocab(walks: torch.Tensor, min_count: int, group=None) -> Vocab:
+    """Vocabulary of the walk corpus.  Under torch.distributed every rank holds only its
+    shard of the walks, so token counts are summed over the ranks first (one all-reduce of
+    a dense count vector): all ranks then build the SAME index, which the replicated model
+    and its delta all-reduce rely on."""
     flat = walks.reshape(-1)
     flat = flat[flat >= 0].long()
-    ids, counts = torch.unique(flat, return_counts=True)  # ids ascending
+    import torch.distributed as dist
+
+    n_ids = int(flat.max()) + 1 if flat.numel() else 0  # size of the id -> index lookup
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        size = torch.tensor([int(flat.max()) + 1 if flat.numel() else 0], device=walks.device)
+        dist.all_reduce(size, op=dist.ReduceOp.MAX, group=group)
+        n_ids = int(size.item())  # the same on every rank
+        dense = torch.bincount(flat, minlength=n_ids)
+        dist.all_reduce(dense, op=dist.ReduceOp.SUM, group=group)
+        ids = torch.nonzero(dense).reshape(-1)
+        counts = dense[ids]
+    else:
+        ids, counts = torch.unique(flat, return_counts=True)  # ids ascending
     keep = counts >= max(int(min_count), 0)
     ids, counts = ids[keep], counts[keep]
     order = torch.sort(counts, descending=True, stable=True).indices
     ids, counts = ids[order], counts[order]
-    size = int(flat.max()) + 1 if flat.numel() else 0
-    index_of = torch.full((size,), -1, dtype=torch.int32, device=walks.device)
+    index_of = torch.full((n_ids,), -1, dtype=torch.int32, device=walks.device)
     index_of[ids] = torch.arange(ids.numel(), dtype=torch.int32, device=walks.device)
     return Vocab(ids, counts, index_of)
 

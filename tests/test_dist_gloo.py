@@ -49,6 +49,14 @@ def _worker(rank, world, port, ret):
         cover[lo:hi] = 1
         dist.all_reduce(cover)
         ok = ok and bool((cover == 1).all())
+        # vocabulary from globally summed counts: identical on every rank
+        from node2vec_amd.sgns import build_vocab
+
+        shards = [torch.tensor([[5, 5, 2, -1], [9, 2, 5, 5]], dtype=torch.int32),
+                  torch.tensor([[9, 9, 9, 7], [11, 2, 2, 2]], dtype=torch.int32)]
+        v = build_vocab(shards[rank], min_count=2)
+        ok = ok and v.ids.tolist() == [2, 5, 9] and v.counts.tolist() == [5, 4, 4]  # ties: id asc
+        ok = ok and v.index_of.tolist() == [-1, -1, 0, -1, -1, 1, -1, -1, -1, 2, -1, -1]
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
