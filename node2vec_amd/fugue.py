@@ -94,14 +94,29 @@ def trim_index(
 
 
 def random_walk_tensors(graph: DeviceGraph, n2v_params: Dict[str, Any], walk_seed_ids=None,
-                        random_seed: Optional[int] = None, mode: str = "exact"):
+                        random_seed: Optional[int] = None, mode: str = "exact", shard: bool = True):
     """The on-device corpus: (walks int32 [n, L+1], valid bool [n])
-    stay in HBM, ready for the SGNS kernel; no DataFrame is materialised."""
+    stay in HBM, ready for the SGNS kernel; no DataFrame is materialised.
+
+    Under an initialised torch.distributed process group (one process per GPU, graph
+    replicated) each rank walks its contiguous range of the start vertices
+    (shard.shard_range).  The walker RNG is keyed by (seed, start vertex, ordinal), so the
+    union of the ranks' walks equals the single-GPU result and no collective is needed;
+    pass the SAME random_seed on every rank.  shard=False walks everything on this rank."""
     for param in NODE2VEC_PARAMS:  # fugue.py:120-122: fills the caller's dict
         if param not in n2v_params:
             n2v_params[param] = NODE2VEC_PARAMS[param]
     seed = rw.fresh_seed() if random_seed is None else int(random_seed)
     start = rw.start_vertices(graph, walk_seed_ids)
+    import torch.distributed as dist
+
+    if shard and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if random_seed is None:
+            raise ValueError("random_seed must be given (the same on every rank) when walks are sharded")
+        from node2vec_amd.shard import shard_range
+
+        lo, hi = shard_range(start.numel(), dist.get_rank(), dist.get_world_size())
+        start = start[lo:hi].contiguous()
     return rw.walk(graph, start, int(n2v_params["num_walks"]), int(n2v_params["walk_length"]),
                    float(n2v_params["return_param"]), float(n2v_params["inout_param"]), seed, mode)
 
