@@ -46,11 +46,12 @@ extern "C" {
 #define N2V_WALK_FAST 1  /* precomputed first-order tables + rejection (same distribution) */
 
 /* One entry of a first-order Walker alias table, packed so that a draw is ONE
- * 16-byte access: the neighbour id, the alias index (within the row) and the
- * pseudo-probability of generate_alias_tables (randomwalk.py:157-190). */
+ * 16-byte access: the neighbour id, the neighbour id BEHIND the alias index of
+ * generate_alias_tables (row[alias[i]], randomwalk.py:140-141 looks it up the same
+ * way) and the pseudo-probability (randomwalk.py:157-190). */
 typedef struct n2v_slot {
   int32_t col;
-  int32_t alias;
+  int32_t alias; /* vertex id, not an index */
   double prob;
 } n2v_slot;
 
@@ -78,9 +79,10 @@ int n2v_device_count(void);
 
 /* K1 -- first-order alias tables for every row, exactly
  * generate_alias_tables(weights of the row) (randomwalk.py:157-190): same LIFO
- * pairing order, fp64 arithmetic, leftovers keep alias 0.  Rows of degree 0 are
- * skipped; a row whose weights sum to 0 sets N2V_ST_ZERODIV.  slots_out is
- * CSR-aligned ([n_edges]) and also receives a copy of col. */
+ * pairing order, fp64 arithmetic, leftovers keep alias 0 (= the row's first
+ * neighbour).  Rows of degree 0 are skipped; a row whose weights sum to 0 sets
+ * N2V_ST_ZERODIV.  slots_out is CSR-aligned ([n_edges]); slot.alias holds the
+ * neighbour id the alias index points to, slot.col a copy of col. */
 int n2v_alias_build(const int64_t *rowptr, const int32_t *col, const float *w,
                     int64_t n_rows, n2v_slot *slots_out, uint32_t *status,
                     void *stream);

@@ -6,8 +6,9 @@
 // One wave64 per row: the split and the normalisation are lane-parallel, the
 // pairing is replayed as two descending candidate streams exactly as in K2
 // (n2v_walk.hip), here writing every slot instead of stopping at one.
-// Output: packed 16-byte slots {col, alias, prob}, CSR-aligned, so that one draw
-// of the fast sampler is one 16-byte gather.  Algorithmic bytes: 16 V + 24 E
+// Output: packed 16-byte slots {col, alias vertex, prob}, CSR-aligned, so that one
+// draw of the fast sampler is one 16-byte gather (the alias INDEX of the reference's
+// table is resolved to the neighbour id it points to, row by row, at the end).  Algorithmic bytes: 16 V + 24 E
 // (rowptr + col + w read, 16-byte slot written).
 #include "n2v_alias_core.h"
 
@@ -117,6 +118,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void alias_build_kernel(
       }
     }
     if (have_o && lane == 0) out[o_idx].prob = r;  // overfull left on its stack
+    // The table is complete with alias = index into the row (what the reference stores).
+    // The walk sampler only ever needs the vertex behind that index, so resolve it here:
+    // a draw is then ONE 16-byte gather {col, alias vertex, prob}.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int chunk = 0; chunk < c.nch; ++chunk) {
+      const int i = chunk * 64 + lane;
+      if (i < n) out[i].alias = c.vcol[out[i].alias];
+    }
   }
 }
 

@@ -3,7 +3,8 @@
 // :86-99) without rebuilding a table per step.
 //
 // A candidate x is drawn from the PRECOMPUTED first-order alias table of the
-// current vertex v (K1, one 16-byte slot gather) and accepted with probability
+// current vertex v (K1; exactly one 16-byte slot gather, the slot holds both the
+// neighbour and its alias's vertex id) and accepted with probability
 // beta(x) / beta_max, beta = 1/p if x == s, 1 if x in N(s) (binary search over
 // the sorted row of s), 1/q otherwise: P(x) ~ w(v,x) * beta(x), the reference's
 // unnormalised probability (:223-230).  The first step (s < 0) is the unbiased
@@ -98,8 +99,7 @@ __global__ __launch_bounds__(256) void walk_fast_kernel(
     const int pick = (int)__umulhi(u1, (uint32_t)n);
     const n2v_slot sl = g.slots[vb + pick];
     const double r2 = (double)u2 * (1.0 / 4294967296.0);
-    int32_t x = sl.col;
-    if (!(r2 < sl.prob)) x = g.slots[vb + sl.alias].col;
+    const int32_t x = (r2 < sl.prob) ? sl.col : sl.alias;  // slot.alias is already a vertex id
     bool accept = true;
     ++trials;
     if (s >= 0 && biased) {

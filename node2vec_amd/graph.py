@@ -5,7 +5,7 @@ per source vertex (`partition(by=src, presort=dst).transform(get_vertex_neighbor
 fugue.py:130, randomwalk.py:266-275).  Here the same data is a CSR triple kept
 resident on the GPU: rowptr int64[V+1], col int32[E] (sorted by dst within a
 row, multi-edges kept in input order), w fp32[E]; plus, for the fast sampler,
-CSR-aligned first-order alias tables packed as 16-byte slots {col, alias, prob}.
+CSR-aligned first-order alias tables packed as 16-byte slots {col, alias vertex, prob}.
 """
 import ctypes as C
 from typing import Optional
@@ -115,6 +115,7 @@ class DeviceGraph:
     # -- views of the packed tables (tests, debugging) -------------------------------
     @property
     def alias(self) -> Optional[torch.Tensor]:
+        """neighbour id behind each slot's alias index (row[alias[i]])"""
         return None if self.slots is None else self.slots[:, 1]
 
     @property

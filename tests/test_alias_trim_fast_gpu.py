@@ -28,8 +28,8 @@ def test_alias_build_equals_generate_alias_tables(oracle, weighted):
     probs identical to the oracle (itself pinned to the reference, G1)."""
     g = _rand_graph(11, 2000, 30000, weighted).build_alias()
     torch.cuda.synchronize()
-    rowptr, w = g.rowptr.cpu().numpy(), g.w.cpu().numpy()
-    alias, prob = g.alias.cpu().numpy(), g.prob.cpu().numpy()
+    rowptr, w, col = g.rowptr.cpu().numpy(), g.w.cpu().numpy(), g.col.cpu().numpy()
+    alias, prob = g.alias.cpu().numpy(), g.prob.cpu().numpy()  # alias: vertex behind the index
     assert np.array_equal(g.slots[:, 0].cpu().numpy(), g.col.cpu().numpy())
     checked = 0
     for v in range(g.n_vertices):
@@ -37,7 +37,7 @@ def test_alias_build_equals_generate_alias_tables(oracle, weighted):
         if e == b:
             continue
         a, p = oracle.alias_tables(w[b:e].astype(np.float64))
-        assert alias[b:e].tolist() == a, v
+        assert alias[b:e].tolist() == col[b:e][np.array(a)].tolist(), v
         assert prob[b:e].tolist() == p, v
         checked += 1
     assert checked > 1500
@@ -55,10 +55,12 @@ def test_alias_build_golden_rows(oracle):
     w = np.concatenate([np.array(c["weights"], np.float32) for c in cases])
     g = DeviceGraph.from_edges(src, dst, w, n_vertices=max(len(cases), int(dst.max()) + 1),
                                device="cuda").build_alias()
-    rowptr = g.rowptr.cpu().numpy()
+    rowptr, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
     alias, prob = g.alias.cpu().numpy(), g.prob.cpu().numpy()
     for i, c in enumerate(cases):
         b, e = rowptr[i], rowptr[i + 1]
+        # the row's ids are 0..n-1 here, so the vertex behind an alias index IS the index
+        assert col[b:e].tolist() == list(range(e - b))
         assert alias[b:e].tolist() == c["alias"] and prob[b:e].tolist() == c["probs"], i
 
 

@@ -91,7 +91,7 @@ def test_alias_build_on_empty_and_single_rows(oracle):
     from node2vec_amd.graph import DeviceGraph
 
     g = DeviceGraph.from_edges([2], [0], [0.3], n_vertices=5, device="cuda").build_alias()
-    assert g.alias.tolist() == [0] and g.prob.tolist() == [1.0]
+    assert g.alias.tolist() == [0] and g.prob.tolist() == [1.0]  # alias index 0 -> neighbour id 0
     a, p = oracle.alias_tables([float(np.float32(0.3))])
     assert (a, p) == ([0], [1.0])
     empty = DeviceGraph.from_edges([], [], [], n_vertices=3, device="cuda").build_alias()
