@@ -675,7 +675,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 8) void walk_exact_unit_kernel
           c.scol = g.col + sb;
           c.m = m;
           c.iters = 32 - __clz(m);
+#ifdef N2V_STATS
+          const unsigned long long t_s0 = __builtin_readcyclecounter();
+#endif
           idx = unit_draw(c, K, (uint32_t)(bits >> 32), (uint32_t)bits, lane, L N2V_STATS_PASS);
+#ifdef N2V_STATS
+          {
+            const unsigned long long dt = __builtin_readcyclecounter() - t_s0;
+            const int bk = n <= 16 ? 0 : (n <= 64 ? 1 : (n <= 256 ? 2 : (n <= 1024 ? 3 : 4)));
+            WS.v[25 + bk] += dt;
+            WS.v[14 + (bk > 1 ? 1 : 0)] += 1;  // 14: n <= 64, 15: larger
+          }
+#endif
         }
         const int32_t next = __builtin_amdgcn_readfirstlane(g.col[vb + idx]);
         if (buffered) {

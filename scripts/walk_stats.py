@@ -17,3 +17,7 @@ for p, q in ((0.5, 2.0),):
     ph = ["P0 stage/filter", "P1 stream", "P2 verify", "sum+avg", "minmax", "pairing", "pair uncached", "reverse classify"]
     cyc = list(buf)[16:23] + [list(buf)[24]]; tot = list(buf)[23]
     print("  wave-cycles total", tot, "per step", round(tot/st["draw_steps"]));    print("  cycles/step by phase:", {n: (round(c / st["draw_steps"]), f"{100*c/tot:.1f}%") for n, c in zip(ph, cyc)})
+    b = list(buf)
+    tot_draw = sum(b[25:30])
+    print("  draw cycles by deg(v) bucket [<=16, <=64, <=256, <=1024, >1024]:", [f"{100*x/tot_draw:.1f}%" for x in b[25:30]],
+          " steps n<=64:", b[14], " larger:", b[15])
