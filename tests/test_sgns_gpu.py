@@ -119,3 +119,57 @@ def test_hogwild_learns_community_structure(oracle):
     g_cpu = gap(s0, ids)
     assert g_gpu > 0.2 and g_cpu > 0.2
     assert abs(g_gpu - g_cpu) < 0.15
+
+
+def test_hogwild_vs_deterministic_statistical_parity():
+    """Full-speed (hogwild) mode cannot be bit-compared; the claim is statistical
+    (SURVEY.md 8c): on a planted-partition graph (50 communities x 40 vertices) the
+    community-separation AUC of the hogwild embedding equals the deterministic one within
+    0.01 and both exceed 0.99; after Procrustes alignment the mean per-vertex cosine is
+    >= 0.9 between two hogwild runs and >= 0.6 between hogwild and deterministic
+    (measured: 0.99 and 0.78)."""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd import sgns
+    from node2vec_amd.graph import DeviceGraph
+
+    rng = np.random.default_rng(0)
+    nc, sz = 50, 40
+    nv = nc * sz
+    comm = np.repeat(np.arange(nc), sz)
+    src, dst = [], []
+    for v in range(nv):
+        for u in list(rng.choice(np.nonzero(comm == comm[v])[0], 8)) + list(rng.integers(0, nv, 2)):
+            if u != v:
+                src += [v, u]
+                dst += [u, v]
+    g = DeviceGraph.from_edges(src, dst, np.ones(len(src), np.float32), n_vertices=nv, device="cuda")
+    walks, _ = rw.walk(g, rw.start_vertices(g), 10, 40, 1.0, 1.0, 1)
+    vocab = sgns.build_vocab(walks, 1)
+    idx = vocab.index_of[walks.long()]
+    ids = vocab.ids.cpu().numpy()
+
+    def train(det):
+        m = sgns.SgnsModel(vocab, 64, 5, 5, seed=7, sample=0.0)
+        m.train(idx, epochs=3, alpha=0.025, deterministic=det)
+        torch.cuda.synchronize()
+        return m.syn0.cpu().numpy()
+
+    def auc(v):
+        v = v - v.mean(0)
+        v = v / np.linalg.norm(v, axis=1, keepdims=True)
+        a, b = rng.integers(0, len(v), 100000), rng.integers(0, len(v), 100000)
+        s = (v[a] * v[b]).sum(1)
+        same = comm[ids[a]] == comm[ids[b]]
+        return float((s[same][:, None] > s[~same][None, :2000]).mean())
+
+    def procrustes_cos(x, y):
+        x, y = x - x.mean(0), y - y.mean(0)
+        u, _, vt = np.linalg.svd(x.T @ y)
+        xr = x @ (u @ vt)
+        return float(np.mean((xr * y).sum(1) / (np.linalg.norm(xr, axis=1) * np.linalg.norm(y, axis=1))))
+
+    det, h1, h2 = train(True), train(False), train(False)
+    a_det, a_h1 = auc(det), auc(h1)
+    assert a_det > 0.99 and a_h1 > 0.99 and abs(a_det - a_h1) < 0.01
+    assert procrustes_cos(h1, h2) > 0.9
+    assert procrustes_cos(det, h1) > 0.6
