@@ -176,7 +176,6 @@ __device__ __forceinline__ int pairing(const StepCtx &c, WaveLds &L, int lane, i
     }
     bool finished = false;
     for (;;) {  // `over` absorbs underfull slots
-      N2V_STAT(8, 1);
       while (um == 0ull && cu > 0) {
         --cu;
         bool valid;
@@ -188,20 +187,36 @@ __device__ __forceinline__ int pairing(const StepCtx &c, WaveLds &L, int lane, i
         finished = true;
         break;
       }
-      const int l = 63 - __clzll((long long)um);
-      um ^= 1ull << l;
-      const double pu = readlane_f64(uval, l);
-      if (cu * 64 + l == pick) {  // alias[under] = over; probs[under] is final
-        fin_prob = pu;
-        fin_alias = o_idx;
-        finished = true;
-        break;
+      // Candidates of this chunk that come BEFORE slot `pick` (higher index) are absorbed in
+      // a minimal loop: find bit, v_readlane, the reference's two fp64 operations, compare.
+      // Whether `pick` is the next candidate is decided once per chunk, not per slot.
+      const int pl = pick & 63;
+      const bool stop_here = (pick >> 6) == cu && ((um >> pl) & 1ull);
+      uint64_t run = stop_here ? (um & ~((2ull << pl) - 1ull)) : um;
+      um &= ~run;
+      bool demoted = false;
+      while (run != 0ull) {
+        N2V_STAT(8, 1);
+        const int l = 63 - __clzll((long long)run);
+        run ^= 1ull << l;
+        r = r + readlane_f64(uval, l) - 1.0;  // probs[over] = probs[over] + probs[under] - 1.0
+        if (r < 1.0) {
+          demoted = true;
+          break;
+        }
       }
-      r = readfirstlane_f64(r + pu - 1.0);  // probs[over] = probs[over] + probs[under] - 1.0
-      if (r < 1.0) {  // demoted: it is the next `under`
+      um |= run;  // candidates not consumed yet
+      r = readfirstlane_f64(r);
+      if (demoted) {  // it is the next `under`
         carry = true;
         carry_r = r;
         carry_idx = o_idx;
+        break;
+      }
+      if (stop_here) {  // alias[under] = over; probs[under] is final
+        fin_prob = readlane_f64(uval, pl);
+        fin_alias = o_idx;
+        finished = true;
         break;
       }
     }
