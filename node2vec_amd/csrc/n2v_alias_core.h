@@ -26,8 +26,8 @@ struct WaveStats { unsigned long long v[32]; };
 #define N2V_STAT(i, v) do { } while (0)
 #endif
 
-constexpr int kBitWordsMax = 512;  // membership filter: up to 16384 bits
-constexpr int kMaybeCap = 256;     // filter hits waiting for exact verification
+constexpr int kBitWordsMax = 256;  // membership filter: up to 8192 bits
+constexpr int kMaybeCap = 128;     // filter hits waiting for exact verification
 
 // multiplicative hash of a vertex id onto the filter's bit range
 __device__ __forceinline__ uint32_t hash_id(int32_t y, int shift) {

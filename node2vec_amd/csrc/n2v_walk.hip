@@ -27,7 +27,7 @@
 
 namespace n2v {
 
-constexpr int kBqCap = 1024;      // scaled biased weights of the LAST kBqCap neighbours
+constexpr int kBqCap = 512;       // scaled biased weights of the LAST kBqCap neighbours
 
 struct WaveLds {
   uint64_t cls[2 * kLdsChunks];  // per 64-neighbour chunk: ballot(return), ballot(shared)
@@ -242,7 +242,7 @@ __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_
 #if defined(N2V_ABLATE) && (N2V_ABLATE & 8)  // timing-only: no filter, no search at all
   const bool use_filter = false;
 #else
-  const bool use_filter = c.need_mem && c.m <= 8192 && c.m <= 8 * n + 64;
+  const bool use_filter = c.need_mem && c.m <= 4096 && c.m <= 8 * n + 64;
 #endif
   int shift = 32;
   if (use_filter) {
