@@ -521,6 +521,165 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
     N2V_T(21);
     return (r2 < fprob) ? pick : falias;
   }
+  // ---- pairing, count-based path for an OVERFULL bulk class -----------------------------
+  // With q < 1 the roles flip: "other" (the bulk of the row) is overfull with a tiny excess
+  // vO - 1, and the few return/shared slots are the underfull ones.  An absorbed under
+  // value then demotes its `over`, which is pushed on `underfull` and absorbed by the next
+  // `over`, and so on: the residual CASCADES down the row through runs of identical
+  // "other" slots until one of them stays >= 1.0.  Inside a run the slots are
+  // interchangeable, so the cascade is two fp64 adds per slot (four slots per iteration:
+  // the residual never decreases), no bit scanning; return/shared slots and slot `pick`
+  // are run boundaries and are handled one by one.
+  if (!uO && nO > 0) {
+    auto kth_highest = [](uint64_t mask, int k) {  // index of the k-th highest set bit, k >= 1
+      for (int t = 1; t < k; ++t) mask ^= 1ull << (63 - __clzll((long long)mask));
+      return 63 - __clzll((long long)mask);
+    };
+    int cu = c.nch, co = c.nch;
+    uint64_t um = 0, urm = 0, umm = 0, om = 0, orm = 0, omm = 0;
+    bool have_cur = false, cur_is_pick = false, carry = false, carry_is_pick = false;
+    double r = 0.0, carry_r = 0.0;
+    int cur_idx = 0;
+    double fprob = p_pick;
+    int falias = 0;
+    const int pc = pick >> 6;
+    const uint64_t pbit = 1ull << (pick & 63);
+    for (;;) {
+      // ---- under: the demoted slot if there is one, else the next return/shared slot
+      double pu;
+      bool u_is_pick;
+      if (carry) {
+        pu = carry_r;
+        u_is_pick = carry_is_pick;
+        carry = false;
+      } else {
+        while (um == 0ull && cu > 0) {
+          --cu;
+          chunk_classes(c, L, cu, lane, urm, umm);
+          um = (uR ? urm : 0ull) | (uM ? umm : 0ull);
+        }
+        if (um == 0ull) {  // `underfull` empty
+          if (have_cur && cur_is_pick) fprob = r;
+          break;
+        }
+        const int l = 63 - __clzll((long long)um);
+        um ^= 1ull << l;
+        pu = ((urm >> l) & 1ull) ? vR : vM;
+        u_is_pick = cu * 64 + l == pick;
+      }
+      // ---- over: the current one, else the next slot of the overfull stack
+      if (have_cur) {
+        if (u_is_pick) {
+          fprob = pu;
+          falias = cur_idx;
+          break;
+        }
+        r = readfirstlane_f64(r + pu - 1.0);
+        if (r < 1.0) {
+          carry = true;
+          carry_r = r;
+          carry_is_pick = cur_is_pick;
+          have_cur = false;
+        }
+        continue;
+      }
+      while (om == 0ull && co > 0) {
+        --co;
+        chunk_classes(c, L, co, lane, orm, omm);
+        om = valid_mask(c, co) & ~((uR ? orm : 0ull) | (uM ? omm : 0ull));
+      }
+      if (om == 0ull) {  // `overfull` empty: the under stays where it was
+        if (u_is_pick) fprob = pu;
+        break;
+      }
+      const int l = 63 - __clzll((long long)om);
+      const uint64_t lbit = 1ull << l;
+      const uint64_t singles = om & (orm | omm | (co == pc ? pbit : 0ull));
+      if (u_is_pick) {  // alias[pick] = the top of `overfull`, whatever it is
+        fprob = pu;
+        falias = co * 64 + l;
+        break;
+      }
+      if (singles & lbit) {  // an overfull return/shared slot, or slot `pick`
+        om ^= lbit;
+        const int idx = co * 64 + l;
+        const double v0 = (orm & lbit) ? vR : ((omm & lbit) ? vM : vO);
+        r = readfirstlane_f64(v0 + pu - 1.0);
+        if (r < 1.0) {
+          carry = true;
+          carry_r = r;
+          carry_is_pick = idx == pick;
+        } else {
+          have_cur = true;
+          cur_idx = idx;
+          cur_is_pick = idx == pick;
+        }
+        continue;
+      }
+      // a run of "other" slots: from l down to the next single (exclusive)
+      uint64_t run = om & (lbit | (lbit - 1ull));
+      const uint64_t below = singles & (lbit - 1ull);
+      if (below) run &= ~((2ull << (63 - __clzll((long long)below))) - 1ull);
+      const int count = __popcll(run);
+      double cval = pu;  // value absorbed by the next slot of the run
+      int k = 0;
+      bool settled = false;
+      while (k + 4 <= count) {
+        const double a1 = vO + cval - 1.0;
+        const double a2 = vO + a1 - 1.0;
+        const double a3 = vO + a2 - 1.0;
+        const double a4 = vO + a3 - 1.0;
+        if (a4 < 1.0) {  // all four slots demoted in turn
+          cval = a4;
+          k += 4;
+          continue;
+        }
+        settled = true;
+        if (!(a1 < 1.0)) {
+          r = a1;
+          k += 1;
+        } else if (!(a2 < 1.0)) {
+          r = a2;
+          k += 2;
+        } else if (!(a3 < 1.0)) {
+          r = a3;
+          k += 3;
+        } else {
+          r = a4;
+          k += 4;
+        }
+        break;
+      }
+      while (!settled && k < count) {
+        const double a = vO + cval - 1.0;
+        ++k;
+        if (a < 1.0) {
+          cval = a;
+        } else {
+          r = a;
+          settled = true;
+        }
+      }
+      // k slots of the run were consumed; when settled the k-th one is the current `over`
+      if (settled) {
+        cur_idx = co * 64 + kth_highest(run, k);
+        have_cur = true;
+        cur_is_pick = false;
+        r = readfirstlane_f64(r);
+      } else {
+        carry = true;
+        carry_r = readfirstlane_f64(cval);
+        carry_is_pick = false;
+      }
+      if (k == count) {
+        om &= ~run;
+      } else {
+        for (int t = 0; t < k; ++t) om ^= 1ull << (63 - __clzll((long long)(om & run)));
+      }
+    }
+    N2V_T(21);
+    return (r2 < fprob) ? pick : falias;
+  }
   // ---- pairing (:182-189), general path: candidate masks are scalar -------------------
   int cu = c.nch, co = c.nch;
   uint64_t um = 0, om = 0, urm = 0, umm = 0, orm = 0, omm = 0;
