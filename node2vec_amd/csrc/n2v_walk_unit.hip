@@ -38,6 +38,11 @@ struct UnitLds {
 };
 
 // binary search over ids staged in LDS (no global gathers on the dependent chain)
+template <typename T>
+__device__ __forceinline__ T pick3(bool first, bool second, T a, T b, T c) {
+  return first ? a : (second ? b : c);
+}
+
 __device__ __forceinline__ bool member_lds(const uint32_t *ys, int m, int32_t x, int iters) {
   int lo = 0, hi = m;
   for (int it = 0; it < iters; ++it) {
@@ -384,7 +389,9 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   const int nO = n - nR - nM;
   const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
   const double avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;
-  const double vR = K.bR / avg, vM = K.bM / avg, vO = K.bO / avg;
+  // uniform values: scalar registers, so they cost no VGPRs across the pairing code
+  const double vR = readfirstlane_f64(K.bR / avg), vM = readfirstlane_f64(K.bM / avg),
+               vO = readfirstlane_f64(K.bO / avg);
   uint64_t prm, pmm;
   chunk_classes(c, L, pick >> 6, lane, prm, pmm);
   const bool pR = (prm >> (pick & 63)) & 1ull, pM = (pmm >> (pick & 63)) & 1ull;
@@ -521,61 +528,139 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
     N2V_T(21);
     return (r2 < fprob) ? pick : falias;
   }
-  // ---- pairing, count-based path for an OVERFULL bulk class -----------------------------
-  // With q < 1 the roles flip: "other" (the bulk of the row) is overfull with a tiny excess
-  // vO - 1, and the few return/shared slots are the underfull ones.  An absorbed under
-  // value then demotes its `over`, which is pushed on `underfull` and absorbed by the next
-  // `over`, and so on: the residual CASCADES down the row through runs of identical
-  // "other" slots until one of them stays >= 1.0.  Inside a run the slots are
-  // interchangeable, so the cascade is two fp64 adds per slot (four slots per iteration:
-  // the residual never decreases), no bit scanning; return/shared slots and slot `pick`
-  // are run boundaries and are handled one by one.
-  if (!uO && nO > 0) {
-    auto kth_highest = [](uint64_t mask, int k) {  // index of the k-th highest set bit, k >= 1
-      for (int t = 1; t < k; ++t) mask ^= 1ull << (63 - __clzll((long long)mask));
-      return 63 - __clzll((long long)mask);
-    };
-    int cu = c.nch, co = c.nch;
-    uint64_t um = 0, urm = 0, umm = 0, om = 0, orm = 0, omm = 0;
-    bool have_cur = false, cur_is_pick = false, carry = false, carry_is_pick = false;
-    double r = 0.0, carry_r = 0.0;
-    int cur_idx = 0;
-    double fprob = p_pick;
-    int falias = 0;
+  // ---- pairing, run engine (every other class arrangement) -----------------------------
+  // Both Python stacks are consumed in descending index order and their interleaving does
+  // not matter, only each stack's own order.  With three class values a stack is a
+  // sequence of RUNS of same-class slots; slot `pick` is always a run of its own.  Two
+  // things happen, over and over (:182-189):
+  //   absorb   the current `over` (r >= 1) takes a run of equal under values v < 1:
+  //            r = r + v - 1 per slot, non-increasing, four slots per loop iteration;
+  //   cascade  a demoted residual (the next `under`) meets a run of equal over values
+  //            V in [1, 2): each slot becomes fl(V + a) - 1 and is demoted in turn until
+  //            one settles at >= 1.  a, V - 1 and V are multiples of 2^-52 below 2, so
+  //            V + a is exactly representable while it stays below 2, i.e. while the slot
+  //            is demoted: slot i holds a1 + (i-1)*(V-1) EXACTLY.  The number of demoted
+  //            slots follows from integer-valued arithmetic (all products stay below 2^53
+  //            ulps), and the slot that settles is computed with the real operations again
+  //            because its sum reaches [2, 3) where it may round.  A run costs O(1).
+  {
     const int pc = pick >> 6;
     const uint64_t pbit = 1ull << (pick & 63);
-    for (;;) {
-      // ---- under: the demoted slot if there is one, else the next return/shared slot
-      double pu;
-      bool u_is_pick;
-      if (carry) {
-        pu = carry_r;
-        u_is_pick = carry_is_pick;
-        carry = false;
-      } else {
-        while (um == 0ull && cu > 0) {
-          --cu;
-          chunk_classes(c, L, cu, lane, urm, umm);
-          um = (uR ? urm : 0ull) | (uM ? umm : 0ull);
-        }
-        if (um == 0ull) {  // `underfull` empty
-          if (have_cur && cur_is_pick) fprob = r;
-          break;
-        }
-        const int l = 63 - __clzll((long long)um);
-        um ^= 1ull << l;
-        pu = ((urm >> l) & 1ull) ? vR : vM;
-        u_is_pick = cu * 64 + l == pick;
+    // A stream holds the chunk being scanned (cm = candidates not yet handed out) and the
+    // run handed out last, consumed by count: `used` of its `cnt` slots, highest first.
+    struct RunStream {
+      int c;
+      uint64_t cm, rm, mm;
+      uint64_t run;
+      int rc, cnt, used;
+      double val, inv;
+      bool is_pick;
+    };
+    RunStream U{c.nch, 0ull, 0ull, 0ull, 0ull, 0, 0, 0, 0.0, 0.0, false};
+    RunStream O{c.nch, 0ull, 0ull, 0ull, 0ull, 0, 0, 0, 0.0, 0.0, false};
+    // 1 / (V - 1) per overfull class, only to seed the exact search for the demoted count
+    const double invR = readfirstlane_f64(uR ? 0.0 : 1.0 / (vR - 1.0));
+    const double invM = readfirstlane_f64(uM ? 0.0 : 1.0 / (vM - 1.0));
+    const double invO = readfirstlane_f64(uO ? 0.0 : 1.0 / (vO - 1.0));
+    // next run of a stream: same class as the top candidate, down to (excluding) the next
+    // candidate of another class or slot `pick`; `pick` itself is a run of one
+    auto fetch = [&](RunStream &S, bool under) __attribute__((always_inline)) -> bool {
+      if (S.used < S.cnt) return true;
+      while (S.cm == 0ull && S.c > 0) {
+        --S.c;
+        chunk_classes(c, L, S.c, lane, S.rm, S.mm);
+        const uint64_t vm = valid_mask(c, S.c);
+        const uint64_t um = (uR ? S.rm : 0ull) | (uM ? S.mm : 0ull) | (uO ? (vm & ~(S.rm | S.mm)) : 0ull);
+        S.cm = under ? um : (vm & ~um);
       }
-      // ---- over: the current one, else the next slot of the overfull stack
+      if (S.cm == 0ull) return false;
+      const int l = 63 - __clzll((long long)S.cm);
+      const uint64_t lbit = 1ull << l;
+      const uint64_t pk = S.c == pc ? pbit : 0ull;
+      const bool isR = S.rm & lbit, isM = S.mm & lbit;
+      // (a conditional on captured lvalues is an lvalue: clang then selects ADDRESSES and the
+      // values are forced into scratch memory; pick3 takes them by value)
+      S.val = pick3(isR, isM, vR, vM, vO);
+      S.inv = pick3(isR, isM, invR, invM, invO);
+      S.is_pick = (pk & lbit) != 0ull;
+      uint64_t run = lbit;
+      if (!S.is_pick) {
+        const uint64_t cmask = pick3(isR, isM, S.rm, S.mm, ~(S.rm | S.mm));
+        run = S.cm & cmask & (lbit | (lbit - 1ull));
+        const uint64_t stop = ((S.cm & ~cmask) | (S.cm & pk)) & (lbit - 1ull);
+        if (stop) run &= ~((2ull << (63 - __clzll((long long)stop))) - 1ull);
+      }
+      S.run = run;
+      S.cm &= ~run;
+      S.rc = S.c;
+      S.cnt = __popcll(run);
+      S.used = 0;
+      return true;
+    };
+    // neighbour index of the k-th highest slot of a run (k >= 1)
+    auto kth_index = [&](uint64_t run, int rc, int k) __attribute__((always_inline)) -> int {
+      const uint64_t sh = run >> lane;
+      const uint64_t hit = ballot64((sh & 1ull) && __popcll(sh) == k);
+      return rc * 64 + (int)__builtin_ctzll(hit);
+    };
+    bool have_cur = false, cur_is_pick = false, carry = false, carry_is_pick = false;
+    double r = 0.0, carry_r = 0.0;
+    uint64_t cur_run = 0ull;  // the current `over` is slot cur_k of this run
+    int cur_rc = 0, cur_k = 0;
+    double fprob = p_pick;
+    int falias = 0;
+    for (;;) {
       if (have_cur) {
-        if (u_is_pick) {
-          fprob = pu;
-          falias = cur_idx;
+        // ---- absorb: the current `over` takes slots of the run at the top of `underfull`
+        if (!fetch(U, true)) {  // `underfull` empty
+          if (cur_is_pick) fprob = r;
           break;
         }
-        r = readfirstlane_f64(r + pu - 1.0);
-        if (r < 1.0) {
+        if (U.is_pick) {  // alias[pick] = over; probs[pick] is final
+          fprob = U.val;
+          falias = kth_index(cur_run, cur_rc, cur_k);
+          break;
+        }
+        const double val = U.val;
+        int j = U.used;
+        const int count = U.cnt;
+        bool demoted = false;
+        while (j + 4 <= count) {
+          N2V_STAT(8, 4);
+          const double a1 = r + val - 1.0;
+          const double a2 = a1 + val - 1.0;
+          const double a3 = a2 + val - 1.0;
+          const double a4 = a3 + val - 1.0;
+          if (!(a4 < 1.0)) {
+            r = a4;
+            j += 4;
+            continue;
+          }
+          demoted = true;
+          if (a1 < 1.0) {
+            r = a1;
+            j += 1;
+          } else if (a2 < 1.0) {
+            r = a2;
+            j += 2;
+          } else if (a3 < 1.0) {
+            r = a3;
+            j += 3;
+          } else {
+            r = a4;
+            j += 4;
+          }
+          break;
+        }
+        while (!demoted && j < count) {
+          N2V_STAT(8, 1);
+          r = r + val - 1.0;
+          ++j;
+          if (r < 1.0) demoted = true;
+        }
+        U.used = j;
+        r = readfirstlane_f64(r);
+        if (demoted) {  // it is the next `under`
           carry = true;
           carry_r = r;
           carry_is_pick = cur_is_pick;
@@ -583,182 +668,83 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
         }
         continue;
       }
-      while (om == 0ull && co > 0) {
-        --co;
-        chunk_classes(c, L, co, lane, orm, omm);
-        om = valid_mask(c, co) & ~((uR ? orm : 0ull) | (uM ? omm : 0ull));
+      // ---- no current `over`: one under value meets the run at the top of `overfull`
+      double pu;
+      bool u_is_pick;
+      if (carry) {
+        pu = carry_r;
+        u_is_pick = carry_is_pick;
+        carry = false;
+      } else {
+        if (!fetch(U, true)) break;  // `underfull` empty
+        pu = U.val;
+        u_is_pick = U.is_pick;
+        ++U.used;  // exactly one slot
       }
-      if (om == 0ull) {  // `overfull` empty: the under stays where it was
+      if (!fetch(O, false)) {  // `overfull` empty: the under stays where it was
         if (u_is_pick) fprob = pu;
         break;
       }
-      const int l = 63 - __clzll((long long)om);
-      const uint64_t lbit = 1ull << l;
-      const uint64_t singles = om & (orm | omm | (co == pc ? pbit : 0ull));
-      if (u_is_pick) {  // alias[pick] = the top of `overfull`, whatever it is
+      if (u_is_pick) {  // alias[pick] = the top of `overfull`
         fprob = pu;
-        falias = co * 64 + l;
+        falias = kth_index(O.run, O.rc, O.used + 1);
         break;
       }
-      if (singles & lbit) {  // an overfull return/shared slot, or slot `pick`
-        om ^= lbit;
-        const int idx = co * 64 + l;
-        const double v0 = (orm & lbit) ? vR : ((omm & lbit) ? vM : vO);
-        r = readfirstlane_f64(v0 + pu - 1.0);
-        if (r < 1.0) {
-          carry = true;
-          carry_r = r;
-          carry_is_pick = idx == pick;
-        } else {
-          have_cur = true;
-          cur_idx = idx;
-          cur_is_pick = idx == pick;
-        }
-        continue;
-      }
-      // a run of "other" slots: from l down to the next single (exclusive)
-      uint64_t run = om & (lbit | (lbit - 1ull));
-      const uint64_t below = singles & (lbit - 1ull);
-      if (below) run &= ~((2ull << (63 - __clzll((long long)below))) - 1ull);
-      const int count = __popcll(run);
-      double cval = pu;  // value absorbed by the next slot of the run
-      int k = 0;
-      bool settled = false;
-      while (k + 4 <= count) {
-        const double a1 = vO + cval - 1.0;
-        const double a2 = vO + a1 - 1.0;
-        const double a3 = vO + a2 - 1.0;
-        const double a4 = vO + a3 - 1.0;
-        if (a4 < 1.0) {  // all four slots demoted in turn
-          cval = a4;
-          k += 4;
-          continue;
-        }
+      N2V_STAT(9, 1);
+      const double val = O.val;
+      const int avail = O.cnt - O.used;
+      int k;
+      bool settled;
+      const double a1 = val + pu - 1.0;  // slot 1, the reference's two operations
+      if (!(a1 < 1.0)) {
+        r = a1;
+        k = 1;
         settled = true;
-        if (!(a1 < 1.0)) {
-          r = a1;
-          k += 1;
-        } else if (!(a2 < 1.0)) {
-          r = a2;
-          k += 2;
-        } else if (!(a3 < 1.0)) {
-          r = a3;
-          k += 3;
+      } else {
+        const double d = val - 1.0;    // a1 < 1 implies val < 2: exact by Sterbenz
+        const double need = 1.0 - a1;  // exact, > 0
+        const double m1 = (double)(avail - 1);
+        if (m1 * d < need) {  // even the last slot of the run is demoted
+          k = avail;
+          carry_r = a1 + m1 * d;  // exact, < 1
+          settled = false;
         } else {
-          r = a4;
-          k += 4;
-        }
-        break;
-      }
-      while (!settled && k < count) {
-        const double a = vO + cval - 1.0;
-        ++k;
-        if (a < 1.0) {
-          cval = a;
-        } else {
-          r = a;
+          // j = the first i >= 1 with a1 + i*d >= 1.0: seeded by a multiplication, then
+          // fixed up with exact products (j*d stays below 2)
+          double j = fmin(fmax(ceil(need * O.inv), 1.0), m1);
+          while (j * d < need) j += 1.0;
+          while (j >= 2.0 && (j - 1.0) * d >= need) j -= 1.0;
+          k = (int)j + 1;  // slot j+1 settles
+          const double a_prev = a1 + (j - 1.0) * d;  // slot j: exact, < 1
+          r = val + a_prev - 1.0;
           settled = true;
         }
       }
-      // k slots of the run were consumed; when settled the k-th one is the current `over`
-      if (settled) {
-        cur_idx = co * 64 + kth_highest(run, k);
+      k = __builtin_amdgcn_readfirstlane(k);
+      O.used += k;
+      if (settled) {  // the slot consumed last is the current `over`
+        cur_run = O.run;
+        cur_rc = O.rc;
+        cur_k = O.used;
         have_cur = true;
-        cur_is_pick = false;
+        cur_is_pick = O.is_pick;
         r = readfirstlane_f64(r);
       } else {
         carry = true;
-        carry_r = readfirstlane_f64(cval);
-        carry_is_pick = false;
-      }
-      if (k == count) {
-        om &= ~run;
-      } else {
-        for (int t = 0; t < k; ++t) om ^= 1ull << (63 - __clzll((long long)(om & run)));
+        carry_r = readfirstlane_f64(carry_r);
+        carry_is_pick = O.is_pick;
       }
     }
     N2V_T(21);
     return (r2 < fprob) ? pick : falias;
   }
-  // ---- pairing (:182-189), general path: candidate masks are scalar -------------------
-  int cu = c.nch, co = c.nch;
-  uint64_t um = 0, om = 0, urm = 0, umm = 0, orm = 0, omm = 0;
-  bool carry = false;
-  double carry_r = 0.0;
-  int carry_idx = 0;
-  double fin_prob = p_pick;
-  int fin_alias = 0;
-  auto under_mask = [&](uint64_t rm, uint64_t mm, uint64_t vm) -> uint64_t {
-    return (uR ? rm : 0ull) | (uM ? mm : 0ull) | (uO ? (vm & ~(rm | mm)) : 0ull);
-  };
-  for (;;) {
-    while (om == 0ull && co > 0) {  // next overfull candidates
-      --co;
-      chunk_classes(c, L, co, lane, orm, omm);
-      const uint64_t vm = valid_mask(c, co);
-      om = vm & ~under_mask(orm, omm, vm);
-    }
-    if (om == 0ull) {
-      if (carry && carry_idx == pick) fin_prob = carry_r;
-      break;
-    }
-    const int lo = 63 - __clzll((long long)om);
-    om ^= 1ull << lo;
-    double r = ((orm >> lo) & 1ull) ? vR : (((omm >> lo) & 1ull) ? vM : vO);
-    const int o_idx = co * 64 + lo;
-    if (carry) {
-      if (carry_idx == pick) {
-        fin_prob = carry_r;
-        fin_alias = o_idx;
-        break;
-      }
-      r = readfirstlane_f64(r + carry_r - 1.0);
-      carry = false;
-      if (r < 1.0) {
-        carry = true;
-        carry_r = r;
-        carry_idx = o_idx;
-        continue;
-      }
-    }
-    bool finished = false;
-    for (;;) {
-      while (um == 0ull && cu > 0) {
-        --cu;
-        chunk_classes(c, L, cu, lane, urm, umm);
-        um = under_mask(urm, umm, valid_mask(c, cu));
-      }
-      if (um == 0ull) {
-        if (o_idx == pick) fin_prob = r;
-        finished = true;
-        break;
-      }
-      N2V_STAT(8, 1);
-      const int l = 63 - __clzll((long long)um);
-      um ^= 1ull << l;
-      const double pu = ((urm >> l) & 1ull) ? vR : (((umm >> l) & 1ull) ? vM : vO);
-      if (cu * 64 + l == pick) {
-        fin_prob = pu;
-        fin_alias = o_idx;
-        finished = true;
-        break;
-      }
-      r = readfirstlane_f64(r + pu - 1.0);  // probs[over] = probs[over] + probs[under] - 1.0
-      if (r < 1.0) {
-        carry = true;
-        carry_r = r;
-        carry_idx = o_idx;
-        break;
-      }
-    }
-    if (finished) break;
-  }
-  N2V_T(21);
-  return (r2 < fin_prob) ? pick : fin_alias;
 }
 
 // 8 waves per SIMD (<= 64 VGPRs) matches the 8 resident blocks the 20 KB of LDS allow
-__global__ __launch_bounds__(kWavesPerBlock * 64, 8) void walk_exact_unit_kernel(
+#ifndef N2V_UNIT_WAVES
+#define N2V_UNIT_WAVES 8
+#endif
+__global__ __launch_bounds__(kWavesPerBlock * 64, N2V_UNIT_WAVES) void walk_exact_unit_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double p, double q, UnitConsts K, uint64_t seed,
     int32_t *__restrict__ walks_out, uint8_t *__restrict__ valid_out,

@@ -7,7 +7,8 @@ start = rw.start_vertices(g)[:47104].contiguous()
 L = _lib.load()
 names = ["draw_steps", "staged+filter", "direct_search", "maybes", "verify_rounds", "past_quick_exit",
          "pair_invocations", "pair_inv_n<=64", "pair_iterations", "refills", "pair_not_cached", "staged_nofilter", "big_filter", "reverse"]
-for p, q in ((0.5, 2.0),):
+PQ = tuple(float(x) for x in os.environ.get("PQ", "0.5,2.0").split(","))
+for p, q in (PQ,):
     buf = (C.c_ulonglong * 32)()
     L.n2v_debug_stats_unit(buf, 1)
     walks, valid = rw.walk(g, start, 10, 80, p, q, 42); torch.cuda.synchronize()
