@@ -412,6 +412,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   // class ballots.  The stack discipline is unchanged: overfull slots are taken in
   // descending index order, a demoted one is absorbed first by its successor.
   const int top_cached_chunk = c.nch - kUC;  // chunks below this are not in LDS
+#ifndef N2V_NO_CASE_A
   if (uO && !(nR && uR) && !(nM && uM) && (pick >> 6) >= top_cached_chunk) {
     const int total_u = nO;
     int above = total_u + 1;  // underfull slots consumed before `pick` is next (never, if overfull)
@@ -528,6 +529,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
     N2V_T(21);
     return (r2 < fprob) ? pick : falias;
   }
+#endif
   // ---- pairing, run engine (every other class arrangement) -----------------------------
   // Both Python stacks are consumed in descending index order and their interleaving does
   // not matter, only each stack's own order.  With three class values a stack is a
@@ -546,8 +548,14 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   {
     const int pc = pick >> 6;
     const uint64_t pbit = 1ull << (pick & 63);
-    // A stream holds the chunk being scanned (cm = candidates not yet handed out) and the
-    // run handed out last, consumed by count: `used` of its `cnt` slots, highest first.
+    // A stream holds the run handed out last, consumed by count: `used` of its `cnt`
+    // slots, highest index first.  Two ways to produce runs:
+    //   by chunk  cm = candidates of the chunk being scanned that were not handed out yet;
+    //             a run is a bit mask inside one chunk;
+    //   by rank   when the stack holds ONE class (and every class ballot of the row is in
+    //             LDS) all its slots have the same value, so the stack is one run from the
+    //             top down to `pick`, `pick`, and one run below it: nothing but counts, and
+    //             a rank -> neighbour index conversion once, for the alias that is returned.
     struct RunStream {
       int c;
       uint64_t cm, rm, mm;
@@ -555,19 +563,75 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
       int rc, cnt, used;
       double val, inv;
       bool is_pick;
+      bool homog;
+      int total, handed, rho, base;  // by rank: size, slots handed out, rank of pick (-1: none)
     };
-    RunStream U{c.nch, 0ull, 0ull, 0ull, 0ull, 0, 0, 0, 0.0, 0.0, false};
-    RunStream O{c.nch, 0ull, 0ull, 0ull, 0ull, 0, 0, 0, 0.0, 0.0, false};
+    RunStream U{c.nch, 0ull, 0ull, 0ull, 0ull, 0, 0, 0, 0.0, 0.0, false, false, 0, 0, -1, 0};
+    RunStream O{c.nch, 0ull, 0ull, 0ull, 0ull, 0, 0, 0, 0.0, 0.0, false, false, 0, 0, -1, 0};
     // 1 / (V - 1) per overfull class, only to seed the exact search for the demoted count
     const double invR = readfirstlane_f64(uR ? 0.0 : 1.0 / (vR - 1.0));
     const double invM = readfirstlane_f64(uM ? 0.0 : 1.0 / (vM - 1.0));
     const double invO = readfirstlane_f64(uO ? 0.0 : 1.0 / (vO - 1.0));
+    {
+      const bool cR = nR > 0, cM = nM > 0, cO = nO > 0;
+      const int n_under = (int)(cR && uR) + (int)(cM && uM) + (int)(cO && uO);
+      const int n_over = (int)(cR && !uR) + (int)(cM && !uM) + (int)(cO && !uO);
+      const bool cached = c.nch <= kUC;
+      U.homog = cached && n_under == 1;
+      O.homog = cached && n_over == 1;
+      U.total = (uR ? nR : 0) + (uM ? nM : 0) + (uO ? nO : 0);
+      O.total = n - U.total;
+      if (U.homog || O.homog) {
+        // return / shared slots with a higher index than pick: one popcount pass
+        int packed = 0;
+        for (int base = pc; base < c.nch; base += 64) {
+          const int ch = base + lane;
+          if (ch < c.nch) {
+            const int ci = c.nch - 1 - ch;
+            uint64_t wr = L.cls[2 * ci], wm = L.cls[2 * ci + 1];
+            if (ch == pc) {
+              const uint64_t keep = ~((2ull << (pick & 63)) - 1ull);
+              wr &= keep;
+              wm &= keep;
+            }
+            packed += __popcll(wr) + (__popcll(wm) << 16);
+          }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) packed += __shfl_xor(packed, off, 64);
+        packed = __builtin_amdgcn_readfirstlane(packed);
+        const int aR = packed & 0xffff, aM = packed >> 16, aO = (n - 1 - pick) - aR - aM;
+        const int above_u = (uR ? aR : 0) + (uM ? aM : 0) + (uO ? aO : 0);
+        const bool pick_under = p_pick < 1.0;
+        if (U.homog) {
+          U.rho = pick_under ? above_u : -1;
+          U.val = pick3(cR && uR, cM && uM, vR, vM, vO);
+        }
+        if (O.homog) {
+          O.rho = pick_under ? -1 : (n - 1 - pick) - above_u;
+          O.val = pick3(cR && !uR, cM && !uM, vR, vM, vO);
+          O.inv = pick3(cR && !uR, cM && !uM, invR, invM, invO);
+        }
+      }
+    }
     // next run of a stream: same class as the top candidate, down to (excluding) the next
     // candidate of another class or slot `pick`; `pick` itself is a run of one
     auto fetch = [&](RunStream &S, bool under) __attribute__((always_inline)) -> bool {
       if (S.used < S.cnt) return true;
+      if (S.homog) {
+        const int remaining = S.total - S.handed;
+        if (remaining <= 0) return false;
+        S.base = S.handed;
+        S.is_pick = S.handed == S.rho;
+        S.cnt = S.is_pick ? 1 : (S.handed < S.rho ? S.rho - S.handed : remaining);
+        S.handed += S.cnt;
+        S.used = 0;
+        return true;
+      }
       while (S.cm == 0ull && S.c > 0) {
         --S.c;
+        N2V_STAT(10, 1);
+        if (c.nch - 1 - S.c >= kUC) N2V_STAT(7, 1);
         chunk_classes(c, L, S.c, lane, S.rm, S.mm);
         const uint64_t vm = valid_mask(c, S.c);
         const uint64_t um = (uR ? S.rm : 0ull) | (uM ? S.mm : 0ull) | (uO ? (vm & ~(S.rm | S.mm)) : 0ull);
@@ -597,144 +661,167 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
       S.used = 0;
       return true;
     };
-    // neighbour index of the k-th highest slot of a run (k >= 1)
+    // neighbour index of the k-th highest slot of a run of `overfull` (k >= 1)
     auto kth_index = [&](uint64_t run, int rc, int k) __attribute__((always_inline)) -> int {
+      if (O.homog) {
+        // by rank: `run` is unused, rc is the rank of the run's first slot.  Find the
+        // chunk that holds rank K (popcounts of 64 chunks at a time + a wave scan).
+        const int K = rc + k - 1;
+        int running = 0;
+        for (int base = 0; base < c.nch; base += 64) {
+          const int ci = base + lane;
+          uint64_t mem = 0ull;
+          if (ci < c.nch) {
+            const int ch = c.nch - 1 - ci;
+            const uint64_t wr = L.cls[2 * ci], wm = L.cls[2 * ci + 1];
+            const uint64_t vm = valid_mask(c, ch);
+            const uint64_t um = (uR ? wr : 0ull) | (uM ? wm : 0ull) | (uO ? (vm & ~(wr | wm)) : 0ull);
+            mem = vm & ~um;
+          }
+          const int mine = __popcll(mem);
+          int incl = mine;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+          }
+          const int block = __builtin_amdgcn_readlane(incl, 63);
+          if (K < running + block) {
+            const int sel = (int)__builtin_ctzll(ballot64(running + incl > K));
+            const int excl = __builtin_amdgcn_readlane(incl - mine, sel);
+            const uint64_t m = readfirstlane_u64(__shfl(mem, sel, 64));
+            const int kk = K - running - excl + 1;
+            const uint64_t sh = m >> lane;
+            const uint64_t hit = ballot64((sh & 1ull) && __popcll(sh) == kk);
+            return (c.nch - 1 - (base + sel)) * 64 + (int)__builtin_ctzll(hit);
+          }
+          running += block;
+        }
+        return 0;  // not reached: K < O.total
+      }
       const uint64_t sh = run >> lane;
       const uint64_t hit = ballot64((sh & 1ull) && __popcll(sh) == k);
       return rc * 64 + (int)__builtin_ctzll(hit);
     };
-    bool have_cur = false, cur_is_pick = false, carry = false, carry_is_pick = false;
-    double r = 0.0, carry_r = 0.0;
-    uint64_t cur_run = 0ull;  // the current `over` is slot cur_k of this run
-    int cur_rc = 0, cur_k = 0;
+    // The loop of :182-189 as two alternating phases.  An under value pu < 1 (the first
+    // slot of `underfull`, later always the residual of the `over` demoted last) cascades
+    // through `overfull` until a slot survives it; that slot, r >= 1, then absorbs slots of
+    // `underfull` until it drops below 1 and becomes the next under value.
     double fprob = p_pick;
     int falias = 0;
-    for (;;) {
-      if (have_cur) {
-        // ---- absorb: the current `over` takes slots of the run at the top of `underfull`
-        if (!fetch(U, true)) {  // `underfull` empty
-          if (cur_is_pick) fprob = r;
-          break;
-        }
-        if (U.is_pick) {  // alias[pick] = over; probs[pick] is final
-          fprob = U.val;
-          falias = kth_index(cur_run, cur_rc, cur_k);
-          break;
-        }
-        const double val = U.val;
-        int j = U.used;
-        const int count = U.cnt;
-        bool demoted = false;
-        while (j + 4 <= count) {
-          N2V_STAT(8, 4);
-          const double a1 = r + val - 1.0;
-          const double a2 = a1 + val - 1.0;
-          const double a3 = a2 + val - 1.0;
-          const double a4 = a3 + val - 1.0;
-          if (!(a4 < 1.0)) {
-            r = a4;
-            j += 4;
-            continue;
+    [&]() __attribute__((always_inline)) {
+      if (!fetch(U, true)) return;  // not reached: both stacks are non-empty here
+      double pu = U.val, r = 0.0;
+      bool u_is_pick = U.is_pick, cur_is_pick = false;
+      ++U.used;
+      for (;;) {
+        // ---- cascade
+        int cur_rc, cur_k;
+        uint64_t cur_run;
+        for (;;) {
+          if (!fetch(O, false)) {  // `overfull` empty: the under keeps its value
+            if (u_is_pick) fprob = pu;
+            return;
           }
-          demoted = true;
-          if (a1 < 1.0) {
+          if (u_is_pick) {  // alias[pick] = the top of `overfull`
+            fprob = pu;
+            falias = kth_index(O.run, O.homog ? O.base : O.rc, O.used + 1);
+            return;
+          }
+          N2V_STAT(9, 1);
+          const double val = O.val;
+          const int avail = O.cnt - O.used;
+          int k;
+          bool settled = true;
+          const double a1 = val + pu - 1.0;  // slot 1, the reference's two operations
+          if (!(a1 < 1.0)) {
             r = a1;
-            j += 1;
-          } else if (a2 < 1.0) {
-            r = a2;
-            j += 2;
-          } else if (a3 < 1.0) {
-            r = a3;
-            j += 3;
+            k = 1;
           } else {
-            r = a4;
-            j += 4;
+            const double d = val - 1.0;    // a1 < 1 implies val < 2: exact by Sterbenz
+            const double need = 1.0 - a1;  // exact, > 0
+            const double m1 = (double)(avail - 1);
+            if (m1 * d < need) {  // even the last slot of the run is demoted
+              k = avail;
+              pu = a1 + m1 * d;  // exact, < 1
+              settled = false;
+            } else {
+              // j = the first i >= 1 with a1 + i*d >= 1.0: seeded by a multiplication, then
+              // fixed up with exact products (j*d stays below 2)
+              double j = fmin(fmax(ceil(need * O.inv), 1.0), m1);
+              while (j * d < need) j += 1.0;
+              while (j >= 2.0 && (j - 1.0) * d >= need) j -= 1.0;
+              k = (int)j + 1;                            // slot j+1 settles
+              const double a_prev = a1 + (j - 1.0) * d;  // slot j: exact, < 1
+              r = val + a_prev - 1.0;
+            }
           }
-          break;
+          O.used += __builtin_amdgcn_readfirstlane(k);
+          if (settled) break;
+          pu = readfirstlane_f64(pu);
+          u_is_pick = O.is_pick;
         }
-        while (!demoted && j < count) {
-          N2V_STAT(8, 1);
-          r = r + val - 1.0;
-          ++j;
-          if (r < 1.0) demoted = true;
-        }
-        U.used = j;
         r = readfirstlane_f64(r);
-        if (demoted) {  // it is the next `under`
-          carry = true;
-          carry_r = r;
-          carry_is_pick = cur_is_pick;
-          have_cur = false;
-        }
-        continue;
-      }
-      // ---- no current `over`: one under value meets the run at the top of `overfull`
-      double pu;
-      bool u_is_pick;
-      if (carry) {
-        pu = carry_r;
-        u_is_pick = carry_is_pick;
-        carry = false;
-      } else {
-        if (!fetch(U, true)) break;  // `underfull` empty
-        pu = U.val;
-        u_is_pick = U.is_pick;
-        ++U.used;  // exactly one slot
-      }
-      if (!fetch(O, false)) {  // `overfull` empty: the under stays where it was
-        if (u_is_pick) fprob = pu;
-        break;
-      }
-      if (u_is_pick) {  // alias[pick] = the top of `overfull`
-        fprob = pu;
-        falias = kth_index(O.run, O.rc, O.used + 1);
-        break;
-      }
-      N2V_STAT(9, 1);
-      const double val = O.val;
-      const int avail = O.cnt - O.used;
-      int k;
-      bool settled;
-      const double a1 = val + pu - 1.0;  // slot 1, the reference's two operations
-      if (!(a1 < 1.0)) {
-        r = a1;
-        k = 1;
-        settled = true;
-      } else {
-        const double d = val - 1.0;    // a1 < 1 implies val < 2: exact by Sterbenz
-        const double need = 1.0 - a1;  // exact, > 0
-        const double m1 = (double)(avail - 1);
-        if (m1 * d < need) {  // even the last slot of the run is demoted
-          k = avail;
-          carry_r = a1 + m1 * d;  // exact, < 1
-          settled = false;
-        } else {
-          // j = the first i >= 1 with a1 + i*d >= 1.0: seeded by a multiplication, then
-          // fixed up with exact products (j*d stays below 2)
-          double j = fmin(fmax(ceil(need * O.inv), 1.0), m1);
-          while (j * d < need) j += 1.0;
-          while (j >= 2.0 && (j - 1.0) * d >= need) j -= 1.0;
-          k = (int)j + 1;  // slot j+1 settles
-          const double a_prev = a1 + (j - 1.0) * d;  // slot j: exact, < 1
-          r = val + a_prev - 1.0;
-          settled = true;
-        }
-      }
-      k = __builtin_amdgcn_readfirstlane(k);
-      O.used += k;
-      if (settled) {  // the slot consumed last is the current `over`
+        cur_is_pick = O.is_pick;  // the slot consumed last is the current `over`
         cur_run = O.run;
-        cur_rc = O.rc;
+        cur_rc = O.homog ? O.base : O.rc;
         cur_k = O.used;
-        have_cur = true;
-        cur_is_pick = O.is_pick;
-        r = readfirstlane_f64(r);
-      } else {
-        carry = true;
-        carry_r = readfirstlane_f64(carry_r);
-        carry_is_pick = O.is_pick;
+        // ---- absorb
+        for (;;) {
+          if (!fetch(U, true)) {  // `underfull` empty
+            if (cur_is_pick) fprob = r;
+            return;
+          }
+          if (U.is_pick) {  // alias[pick] = over; probs[pick] is final
+            fprob = U.val;
+            falias = kth_index(cur_run, cur_rc, cur_k);
+            return;
+          }
+          const double val = U.val;
+          int j = U.used;
+          const int count = U.cnt;
+          bool demoted = false;
+          while (j + 4 <= count) {
+            N2V_STAT(8, 4);
+            const double a1 = r + val - 1.0;
+            const double a2 = a1 + val - 1.0;
+            const double a3 = a2 + val - 1.0;
+            const double a4 = a3 + val - 1.0;
+            if (!(a4 < 1.0)) {
+              r = a4;
+              j += 4;
+              continue;
+            }
+            demoted = true;
+            if (a1 < 1.0) {
+              r = a1;
+              j += 1;
+            } else if (a2 < 1.0) {
+              r = a2;
+              j += 2;
+            } else if (a3 < 1.0) {
+              r = a3;
+              j += 3;
+            } else {
+              r = a4;
+              j += 4;
+            }
+            break;
+          }
+          while (!demoted && j < count) {
+            N2V_STAT(8, 1);
+            r = r + val - 1.0;
+            ++j;
+            if (r < 1.0) demoted = true;
+          }
+          U.used = __builtin_amdgcn_readfirstlane(j);
+          r = readfirstlane_f64(r);
+          if (demoted) break;
+        }
+        pu = r;  // the demoted `over` is the next under
+        u_is_pick = cur_is_pick;
       }
-    }
+    }();
     N2V_T(21);
     return (r2 < fprob) ? pick : falias;
   }
