@@ -26,9 +26,11 @@ constexpr int kYsCap = 384;   // N(s) staged in LDS when it has at most this man
 constexpr int kBitsA = 256;   // filter words beside a staged N(s)        (8192 bits)
 constexpr int kBitsB = 256;   // filter words when N(s) is not staged (a power of two <= kYsCap)
 constexpr int kMaybeU = 128;  // filter hits waiting for verification
+constexpr int kSparseCap = 64;  // reverse mode: return/shared slots below the cached chunks, by position
 
 // 5 KB per wave: 8 blocks of 4 waves per CU, the hardware maximum of 8 waves per SIMD.  `pool` is either {staged ids of N(s)} (m <= kYsCap, filter in
-// `bits`) or one large filter (kYsCap < m <= 8192).
+// `bits`) or one large filter (kYsCap < m <= 8192); reverse classification uses it for the positions of
+// the return/shared slots that lie below the cached chunks (kSparseCap entries: index | class << 31).
 static_assert(kBitsB <= kYsCap && (kBitsB & (kBitsB - 1)) == 0, "large filter must fit the pool");
 struct UnitLds {
   uint64_t cls[2 * kUC];     // slot nch-1-chunk: ballot(return), ballot(shared)
@@ -37,12 +39,12 @@ struct UnitLds {
   uint32_t pool[kYsCap];     // staged N(s)  |  large filter
 };
 
-// binary search over ids staged in LDS (no global gathers on the dependent chain)
 template <typename T>
 __device__ __forceinline__ T pick3(bool first, bool second, T a, T b, T c) {
   return first ? a : (second ? b : c);
 }
 
+// binary search over ids staged in LDS (no global gathers on the dependent chain)
 __device__ __forceinline__ bool member_lds(const uint32_t *ys, int m, int32_t x, int iters) {
   int lo = 0, hi = m;
   for (int it = 0; it < iters; ++it) {
@@ -99,13 +101,28 @@ __device__ __forceinline__ void park_pivots(int32_t *piv, const int32_t *row, in
 
 // class ballots of one chunk: from LDS when cached, else by searching again
 __device__ __forceinline__ void chunk_classes(const UnitStep &c, UnitLds &L, int chunk, int lane,
-                                              uint64_t &rm, uint64_t &mm) {
+                                              int sp_n, uint64_t &rm, uint64_t &mm) {
   const int ci = c.nch - 1 - chunk;
   if (ci < kUC) {
     // uniform address, but an LDS load is lane-varying to the compiler: say it is scalar,
     // so that everything derived from the class masks stays on the scalar unit
     rm = readfirstlane_u64(L.cls[2 * ci]);
     mm = readfirstlane_u64(L.cls[2 * ci + 1]);
+    return;
+  }
+  if (sp_n >= 0) {  // reverse mode kept every return/shared slot of the uncached part by position
+    const int32_t e = lane < sp_n ? (int32_t)L.pool[lane] : 0;
+    uint64_t b = ballot64(lane < sp_n && ((e & 0x7fffffff) >> 6) == chunk);
+    rm = 0ull;
+    mm = 0ull;
+    while (b) {
+      const int32_t el = __builtin_amdgcn_readlane(e, (int)__builtin_ctzll(b));
+      b &= b - 1ull;
+      if (el < 0)
+        rm |= 1ull << (el & 63);
+      else
+        mm |= 1ull << (el & 63);
+    }
     return;
   }
   const int i = chunk * 64 + lane;
@@ -183,6 +200,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   N2V_T0
   N2V_STAT(0, 1);
   int nR = 0, nM = 0;
+  int sp_n = -1;  // >= 0: L.pool holds the position of every return/shared slot below the cached chunks
   // ---- reverse classification: search from the SHORTER list --------------------------
   // The classes of N(v) are needed as ballots and counts, not as a stream.  When N(s)
   // is much shorter than N(v) (or only the return slot matters, q == 1) it is cheaper
@@ -201,15 +219,21 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
     // gather, parked in LDS (mlist is idle here); each lane then finds its 1/64
     // slice by LDS binary search, leaving log2(n/64) global rounds instead of log2(n)
     const int stride = (n + 63) >> 6;
+    sp_n = 0;
     park_pivots(L.mlist, c.vcol, n, stride, lane);
     const int iters_n = 32 - __clz(stride);
     auto mark = [&](bool f, int j, int32_t xv, bool isr) {  // every occurrence of xv in N(v)
       while (ballot64(f) != 0ull) {
-        if (f) {
-          const int ci = c.nch - 1 - (j >> 6);
-          if (ci < kUC)
-            atomicOr(reinterpret_cast<unsigned long long *>(&L.cls[2 * ci + (isr ? 0 : 1)]),
-                     1ull << (j & 63));
+        const int ci = c.nch - 1 - (j >> 6);
+        if (f && ci < kUC)
+          atomicOr(reinterpret_cast<unsigned long long *>(&L.cls[2 * ci + (isr ? 0 : 1)]),
+                   1ull << (j & 63));
+        const bool far = f && ci >= kUC;
+        const uint64_t fb = ballot64(far);
+        if (fb != 0ull) {
+          const int slot = sp_n + __popcll(fb & ((1ull << lane) - 1ull));
+          if (far && slot < kSparseCap) L.pool[slot] = (uint32_t)j | (isr ? 0x80000000u : 0u);
+          sp_n += __popcll(fb);
         }
         nR += __popcll(ballot64(f && isr));
         nM += __popcll(ballot64(f && !isr));
@@ -246,6 +270,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
         for (int u = 0; u < 4; ++u) mark(found[u] && x[u] >= 0, lo[u], x[u], isret[u]);
       }
     }
+    if (sp_n > kSparseCap) sp_n = -1;  // too many: the uncached chunks are searched again on demand
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     N2V_T(24);
@@ -393,7 +418,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   const double vR = readfirstlane_f64(K.bR / avg), vM = readfirstlane_f64(K.bM / avg),
                vO = readfirstlane_f64(K.bO / avg);
   uint64_t prm, pmm;
-  chunk_classes(c, L, pick >> 6, lane, prm, pmm);
+  chunk_classes(c, L, pick >> 6, lane, sp_n, prm, pmm);
   const bool pR = (prm >> (pick & 63)) & 1ull, pM = (pmm >> (pick & 63)) & 1ull;
   const double p_pick = pR ? vR : (pM ? vM : vO);
   N2V_T(19);
@@ -445,7 +470,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
     for (;;) {
       while (om2 == 0ull && co2 > 0) {  // next overfull candidates: return | shared
         --co2;
-        chunk_classes(c, L, co2, lane, orm2, omm2);
+        chunk_classes(c, L, co2, lane, sp_n, orm2, omm2);
         om2 = orm2 | omm2;
       }
       if (om2 == 0ull) {  // `overfull` empty
@@ -576,15 +601,16 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
       const bool cR = nR > 0, cM = nM > 0, cO = nO > 0;
       const int n_under = (int)(cR && uR) + (int)(cM && uM) + (int)(cO && uO);
       const int n_over = (int)(cR && !uR) + (int)(cM && !uM) + (int)(cO && !uO);
-      const bool cached = c.nch <= kUC;
-      U.homog = cached && n_under == 1;
-      O.homog = cached && n_over == 1;
+      // every class ballot of the row is at hand: in LDS, or (reverse mode) by position
+      const bool known = c.nch <= kUC || sp_n >= 0;
+      U.homog = known && n_under == 1;
+      O.homog = known && n_over == 1;
       U.total = (uR ? nR : 0) + (uM ? nM : 0) + (uO ? nO : 0);
       O.total = n - U.total;
       if (U.homog || O.homog) {
         // return / shared slots with a higher index than pick: one popcount pass
         int packed = 0;
-        for (int base = pc; base < c.nch; base += 64) {
+        for (int base = max(pc, c.nch - kUC); base < c.nch; base += 64) {
           const int ch = base + lane;
           if (ch < c.nch) {
             const int ci = c.nch - 1 - ch;
@@ -600,7 +626,14 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) packed += __shfl_xor(packed, off, 64);
         packed = __builtin_amdgcn_readfirstlane(packed);
-        const int aR = packed & 0xffff, aM = packed >> 16, aO = (n - 1 - pick) - aR - aM;
+        int aR = packed & 0xffff, aM = packed >> 16;
+        if (sp_n > 0) {  // the slots kept by position (all below the cached chunks)
+          const int32_t e = lane < sp_n ? (int32_t)L.pool[lane] : 0;
+          const bool hi = lane < sp_n && (e & 0x7fffffff) > pick;
+          aR += __popcll(ballot64(hi && e < 0));
+          aM += __popcll(ballot64(hi && e >= 0));
+        }
+        const int aO = (n - 1 - pick) - aR - aM;
         const int above_u = (uR ? aR : 0) + (uM ? aM : 0) + (uO ? aO : 0);
         const bool pick_under = p_pick < 1.0;
         if (U.homog) {
@@ -632,7 +665,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
         --S.c;
         N2V_STAT(10, 1);
         if (c.nch - 1 - S.c >= kUC) N2V_STAT(7, 1);
-        chunk_classes(c, L, S.c, lane, S.rm, S.mm);
+        chunk_classes(c, L, S.c, lane, sp_n, S.rm, S.mm);
         const uint64_t vm = valid_mask(c, S.c);
         const uint64_t um = (uR ? S.rm : 0ull) | (uM ? S.mm : 0ull) | (uO ? (vm & ~(S.rm | S.mm)) : 0ull);
         S.cm = under ? um : (vm & ~um);
@@ -668,10 +701,11 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
         // chunk that holds rank K (popcounts of 64 chunks at a time + a wave scan).
         const int K = rc + k - 1;
         int running = 0;
-        for (int base = 0; base < c.nch; base += 64) {
+        const int ncached = c.nch < kUC ? c.nch : kUC;
+        for (int base = 0; base < ncached; base += 64) {
           const int ci = base + lane;
           uint64_t mem = 0ull;
-          if (ci < c.nch) {
+          if (ci < ncached) {
             const int ch = c.nch - 1 - ci;
             const uint64_t wr = L.cls[2 * ci], wm = L.cls[2 * ci + 1];
             const uint64_t vm = valid_mask(c, ch);
@@ -697,7 +731,30 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
           }
           running += block;
         }
-        return 0;  // not reached: K < O.total
+        // below the cached chunks (reverse mode): indices [0, lim) with the return/shared
+        // slots known by position
+        const int lim = (c.nch - kUC) * 64, kk = K - running;
+        const int32_t e = lane < sp_n ? (int32_t)L.pool[lane] : 0;
+        const int pos = e & 0x7fffffff;
+        if (nO > 0 && !uO) {
+          // the stack is the "other" class: the (kk+1)-th highest index that is not in the
+          // list.  idx = lim-1-kk-#(listed >= idx), iterated downwards to its largest fixed point
+          int idx = lim - 1 - kk;
+          for (;;) {
+            const int nidx = lim - 1 - kk - __popcll(ballot64(lane < sp_n && pos >= idx));
+            if (nidx == idx) break;
+            idx = nidx;
+          }
+          return idx;
+        }
+        // the stack is the return or the shared class: the (kk+1)-th highest listed position
+        const bool want_r = nR > 0 && !uR;
+        const bool match = lane < sp_n && ((e < 0) == want_r);
+        int greater = 0;
+        for (uint64_t b = ballot64(match); b != 0ull; b &= b - 1ull)
+          greater += (int)(__builtin_amdgcn_readlane(pos, (int)__builtin_ctzll(b)) > pos);
+        const uint64_t hit = ballot64(match && greater == kk);
+        return __builtin_amdgcn_readlane(pos, (int)__builtin_ctzll(hit));
       }
       const uint64_t sh = run >> lane;
       const uint64_t hit = ballot64((sh & 1ull) && __popcll(sh) == k);
@@ -914,9 +971,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_UNIT_WAVES) void walk_exac
 #ifdef N2V_STATS
           {
             const unsigned long long dt = __builtin_readcyclecounter() - t_s0;
-            const int bk = n <= 16 ? 0 : (n <= 64 ? 1 : (n <= 256 ? 2 : (n <= 1024 ? 3 : 4)));
+            const int bk = n <= 64 ? 0 : (n <= 1024 ? 1 : (n <= 4096 ? 2 : (n <= 8192 ? 3 : 4)));
             WS.v[25 + bk] += dt;
-            WS.v[14 + (bk > 1 ? 1 : 0)] += 1;  // 14: n <= 64, 15: larger
+            if (bk >= 3) WS.v[14 + bk - 3] += 1;  // 14: 4096 < n <= 8192, 15: larger
           }
 #endif
         }

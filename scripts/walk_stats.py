@@ -20,5 +20,5 @@ for p, q in (PQ,):
     print("  wave-cycles total", tot, "per step", round(tot/st["draw_steps"]));    print("  cycles/step by phase:", {n: (round(c / st["draw_steps"]), f"{100*c/tot:.1f}%") for n, c in zip(ph, cyc)})
     b = list(buf)
     tot_draw = sum(b[25:30])
-    print("  draw cycles by deg(v) bucket [<=16, <=64, <=256, <=1024, >1024]:", [f"{100*x/tot_draw:.1f}%" for x in b[25:30]],
-          " steps n<=64:", b[14], " larger:", b[15])
+    print("  draw cycles by deg(v) bucket [<=64, <=1024, <=4096, <=8192, >8192]:", [f"{100*x/tot_draw:.1f}%" for x in b[25:30]],
+          " steps 4096<n<=8192:", b[14], " n>8192:", b[15])
