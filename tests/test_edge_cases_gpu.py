@@ -87,6 +87,36 @@ def test_star_graph_hub_return_probabilities(oracle):
     assert 0.0 < ret.mean() < 1.0
 
 
+@pytest.mark.parametrize("pq", [(0.5, 2.0), (4.0, 0.25), (0.25, 0.25), (4.0, 4.0), (1.0, 0.5)])
+def test_rows_longer_than_the_ballot_cache(oracle, pq):
+    """rows of 20 000 neighbours (the unit kernel caches class ballots for 8192): reverse
+    classification keeps return/shared slots below the cache by position (hub A seen from a
+    leaf: 1-3 slots; from B: 300 slots, more than the list holds, so it falls back to
+    searching), with multi-edges, for every arrangement of under/overfull classes"""
+    rng = np.random.default_rng(5)
+    A, B, C = 0, 1, 2
+    leaves = np.arange(100, 20100)
+    src = [np.full(leaves.size, A), leaves]          # A <-> every leaf
+    dst = [leaves, np.full(leaves.size, A)]
+    lb = leaves[:300]                                  # B <-> A and the 300 lowest leaves
+    src += [np.full(lb.size, B), lb, [A, B]]
+    dst += [lb, np.full(lb.size, B), [B, A]]
+    lc = rng.choice(leaves, 9000, replace=True)        # C <-> 9000 random leaves (with repeats) and A
+    src += [np.full(lc.size, C), lc, [A, C]]
+    dst += [lc, np.full(lc.size, C), [C, A]]
+    dup = leaves[::997]                                # multi-edges A <-> leaf
+    src += [np.full(dup.size, A), dup]
+    dst += [dup, np.full(dup.size, A)]
+    src, dst = np.concatenate(src), np.concatenate(dst)
+    from node2vec_amd.graph import DeviceGraph
+
+    g = DeviceGraph.from_edges(src, dst, np.ones(src.size, np.float32), n_vertices=20100, device="cuda")
+    assert g.unit_weights and int(g.degrees().max()) > 8192
+    start = [A, B, C] + list(leaves[::400]) + list(lb[::60])
+    got, gv, want, wv = _both(oracle, g, start, 3, 12, pq[0], pq[1], 77)
+    assert np.array_equal(gv, wv) and np.array_equal(got, want)
+
+
 def test_alias_build_on_empty_and_single_rows(oracle):
     from node2vec_amd.graph import DeviceGraph
 
