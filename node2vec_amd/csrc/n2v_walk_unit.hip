@@ -60,8 +60,59 @@ __device__ __forceinline__ bool member_lds(const uint32_t *ys, int m, int32_t x,
 
 struct UnitConsts {
   double bR, bM, bO;     // 1/p, 1, 1/q
-  int64_t TR, TM, TO;    // the same times 2^20 (exact integers)
+  int64_t TR, TM, TO;    // the same times 2^20 (exact integers; dyadic kernel only)
 };
+
+// ---- the reference's row sum when 1/p or 1/q is not dyadic ------------------------------
+// sum(node_weights) (:172) adds left to right in fp64, so with values that are not
+// multiples of 2^-20 the result depends on the order of the classes.  A row is a few
+// return/shared slots separated by long runs of "other" slots, and a run of k equal
+// addends needs no loop: while s stays inside one binade [2^e, 2^(e+1)) it is a multiple
+// of ulp = 2^(e-52), c = m*ulp + f, and fl(s + c) = s + (m or m+1)*ulp according to f
+// alone -- the same step for every addition.  (If f is exactly ulp/2 the tie goes to the
+// even neighbour: after one addition s is an even multiple of ulp and from then on the
+// step is constant again.)  So: per binade, one real addition to measure the step, an
+// exact multiply for all additions that stay below 2^(e+1), one real addition to cross.
+__device__ __forceinline__ int biased_exp(double x) {
+  return (int)((__double_as_longlong(x) >> 52) & 0x7ff);
+}
+
+__device__ __forceinline__ double rep_add(double s, double c, int k) {
+  const uint64_t c_man =
+      ((uint64_t)__double_as_longlong(c) & 0x000fffffffffffffull) | 0x0010000000000000ull;
+  const int c_exp = biased_exp(c);
+  while (k > 0) {
+    const int es = biased_exp(s);
+    if (es == 0) {  // s == 0.0: the first addend, exact
+      s = s + c;
+      --k;
+      continue;
+    }
+    const int shift = es - c_exp;  // low bits of c below ulp(s)
+    if (shift >= 1 && shift <= 53 && (c_man & ((1ull << shift) - 1ull)) == (1ull << (shift - 1))) {
+      s = readfirstlane_f64(s + c);  // a tie: one real addition makes s an even multiple of ulp
+      --k;
+      if (k == 0 || biased_exp(s) != es) continue;
+    }
+    const double t = readfirstlane_f64(s + c);
+    if (biased_exp(t) != es) {  // this addition leaves the binade: the real operation
+      s = t;
+      --k;
+      continue;
+    }
+    const double step = t - s;  // exact
+    if (step == 0.0) return s;  // c vanishes against s
+    // the largest j with s + j*step < 2^(e+1), at least 1 here
+    const double need = __longlong_as_double((long long)(es + 1) << 52) - s;  // exact
+    double j = ceil(need / step) - 1.0;
+    while ((j + 1.0) * step < need) j += 1.0;
+    while (j * step >= need) j -= 1.0;
+    j = fmin(j, (double)k);
+    s = readfirstlane_f64(s + j * step);  // exact: a multiple of ulp below 2^(e+1)
+    k -= __builtin_amdgcn_readfirstlane((int)j);
+  }
+  return s;
+}
 
 struct UnitStep {
   const int32_t *vcol, *scol;
@@ -191,6 +242,7 @@ __device__ __forceinline__ void verify_unit(const UnitStep &c, UnitLds &L, int c
   }
 }
 
+template <bool kDyadic>
 __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K, uint32_t u1,
                                          uint32_t u2, int lane, UnitLds &L N2V_STATS_ARG) {
   const int n = c.n;
@@ -412,8 +464,33 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   N2V_T(18);
   // ---- :172-173 on three values -----------------------------------------------------
   const int nO = n - nR - nM;
-  const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
-  const double avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;
+  double avg;
+  if (kDyadic) {
+    const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
+    avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;
+  } else {
+    // left to right over the classes of N(v); runs of "other" slots by rep_add
+    double sum = 0.0;
+    int pending = 0;
+    for (int chunk = 0; chunk < c.nch; ++chunk) {
+      uint64_t rm, mm;
+      chunk_classes(c, L, chunk, lane, sp_n, rm, mm);
+      const uint64_t vm = valid_mask(c, chunk);
+      uint64_t spec = (rm | mm) & vm;
+      int pos = 0;
+      while (spec != 0ull) {
+        const int l = (int)__builtin_ctzll(spec);
+        spec &= spec - 1ull;
+        sum = rep_add(sum, K.bO, pending + l - pos);
+        sum = readfirstlane_f64(sum + (((rm >> l) & 1ull) ? K.bR : K.bM));
+        pending = 0;
+        pos = l + 1;
+      }
+      pending += __popcll(vm) - pos;
+    }
+    sum = rep_add(sum, K.bO, pending);
+    avg = sum / (double)n;
+  }
   // uniform values: scalar registers, so they cost no VGPRs across the pairing code
   const double vR = readfirstlane_f64(K.bR / avg), vM = readfirstlane_f64(K.bM / avg),
                vO = readfirstlane_f64(K.bO / avg);
@@ -888,6 +965,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
 #ifndef N2V_UNIT_WAVES
 #define N2V_UNIT_WAVES 8
 #endif
+template <bool kDyadic>
 __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_UNIT_WAVES) void walk_exact_unit_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double p, double q, UnitConsts K, uint64_t seed,
@@ -967,7 +1045,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_UNIT_WAVES) void walk_exac
 #ifdef N2V_STATS
           const unsigned long long t_s0 = __builtin_readcyclecounter();
 #endif
-          idx = unit_draw(c, K, (uint32_t)(bits >> 32), (uint32_t)bits, lane, L N2V_STATS_PASS);
+          idx = unit_draw<kDyadic>(c, K, (uint32_t)(bits >> 32), (uint32_t)bits, lane, L N2V_STATS_PASS);
 #ifdef N2V_STATS
           {
             const unsigned long long dt = __builtin_readcyclecounter() - t_s0;
@@ -1030,20 +1108,31 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
   K.bR = 1.0 / p;  // the reference's weight / return_param with weight == 1.0
   K.bM = 1.0;
   K.bO = 1.0 / q;
-  if (!scales_exactly(K.bR, &K.TR) || !scales_exactly(K.bM, &K.TM) || !scales_exactly(K.bO, &K.TO))
-    return 0;
-  if (K.TR == 0 || K.TO == 0) return 0;  // a zero class could make the row sum 0
+  K.TR = K.TM = K.TO = 0;
+  // dyadic 1/p, 1/q: the row sum is an integer combination of three counts; otherwise it is
+  // added up in the reference's order, run by run (needs ordinary magnitudes)
+  const bool dyadic = scales_exactly(K.bR, &K.TR) && scales_exactly(K.bM, &K.TM) &&
+                      scales_exactly(K.bO, &K.TO) && K.TR != 0 && K.TO != 0;
+  const bool ordinary = K.bR >= 0x1p-20 && K.bR <= 0x1p20 && K.bO >= 0x1p-20 && K.bO <= 0x1p20;
+  if (!dyadic && !ordinary) return 0;
   const int64_t total = n_start * (int64_t)num_walks;
   if (total == 0) return 1;
   // persistent grid: exactly the resident capacity, walkers are grid-strided
   int64_t blocks = (total + n2v::kWavesPerBlock - 1) / n2v::kWavesPerBlock;
-  const int64_t cap = n2v::resident_blocks((const void *)n2v::walk_exact_unit_kernel,
-                                           n2v::kWavesPerBlock * 64, 0);
+  const void *fn = dyadic ? (const void *)n2v::walk_exact_unit_kernel<true>
+                          : (const void *)n2v::walk_exact_unit_kernel<false>;
+  const int64_t cap = n2v::resident_blocks(fn, n2v::kWavesPerBlock * 64, 0);
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(n2v::walk_exact_unit_kernel, dim3((unsigned)blocks),
-                     dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, *g, start_ids,
-                     n_start, num_walks, walk_length, p, q, K, seed, walks_out, valid_out,
-                     status);
+  if (dyadic)
+    hipLaunchKernelGGL(n2v::walk_exact_unit_kernel<true>, dim3((unsigned)blocks),
+                       dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, *g, start_ids,
+                       n_start, num_walks, walk_length, p, q, K, seed, walks_out, valid_out,
+                       status);
+  else
+    hipLaunchKernelGGL(n2v::walk_exact_unit_kernel<false>, dim3((unsigned)blocks),
+                       dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, *g, start_ids,
+                       n_start, num_walks, walk_length, p, q, K, seed, walks_out, valid_out,
+                       status);
   if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
   return 1;
 }
