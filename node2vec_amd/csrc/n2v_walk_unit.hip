@@ -5,10 +5,12 @@
 // builds (reference randomwalk.py:86-99, :157-232).  With every weight 1.0 the
 // biased weight of a neighbour takes one of three values (:223-230):
 //     return  1.0 / p     shared  1.0     other  1.0 / q
-// and when those scale to exact integers (x * 2^20, true for the dyadic p, q of
-// every BASELINE config) the whole step is integer / scalar work:
-//   * the row sum of :172 is three popcounts times three constants (every partial
-//     sum is exactly representable, so order does not matter);
+// and the whole step is integer / scalar work:
+//   * when those scale to exact integers (x * 2^20, true for the dyadic p, q of every
+//     BASELINE config) the row sum of :172 is three popcounts times three constants
+//     (every partial sum is exactly representable, so order does not matter); for other
+//     p, q it is added in the reference's order, one closed-form step per run of equal
+//     addends (rep_add below, kernel instance <false>);
 //   * the LDS cache is the two class ballots per 64-neighbour chunk, w is never read;
 //   * probs0 has three values (3 fp64 divisions per step), so the underfull /
 //     overfull candidate masks of the pairing (:175-189) are scalar AND/OR of the
@@ -104,6 +106,10 @@ __device__ __forceinline__ double rep_add(double s, double c, int k) {
     if (step == 0.0) return s;  // c vanishes against s
     // the largest j with s + j*step < 2^(e+1), at least 1 here
     const double need = __longlong_as_double((long long)(es + 1) << 52) - s;  // exact
+    if ((double)k * step < need) {  // the usual case: the whole run stays in the binade
+      // (a product that compares below need is below 2^(e+1) and a multiple of ulp: exact)
+      return readfirstlane_f64(s + (double)k * step);
+    }
     double j = ceil(need / step) - 1.0;
     while ((j + 1.0) * step < need) j += 1.0;
     while (j * step >= need) j -= 1.0;
@@ -667,13 +673,10 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
       bool is_pick;
       bool homog;
       int total, handed, rho, base;  // by rank: size, slots handed out, rank of pick (-1: none)
+      int cid;                       // by chunk: class of the run `inv` was computed for
     };
-    RunStream U{c.nch, 0ull, 0ull, 0ull, 0ull, 0, 0, 0, 0.0, 0.0, false, false, 0, 0, -1, 0};
-    RunStream O{c.nch, 0ull, 0ull, 0ull, 0ull, 0, 0, 0, 0.0, 0.0, false, false, 0, 0, -1, 0};
-    // 1 / (V - 1) per overfull class, only to seed the exact search for the demoted count
-    const double invR = readfirstlane_f64(uR ? 0.0 : 1.0 / (vR - 1.0));
-    const double invM = readfirstlane_f64(uM ? 0.0 : 1.0 / (vM - 1.0));
-    const double invO = readfirstlane_f64(uO ? 0.0 : 1.0 / (vO - 1.0));
+    RunStream U{c.nch, 0ull, 0ull, 0ull, 0ull, 0, 0, 0, 0.0, 0.0, false, false, 0, 0, -1, 0, -1};
+    RunStream O{c.nch, 0ull, 0ull, 0ull, 0ull, 0, 0, 0, 0.0, 0.0, false, false, 0, 0, -1, 0, -1};
     {
       const bool cR = nR > 0, cM = nM > 0, cO = nO > 0;
       const int n_under = (int)(cR && uR) + (int)(cM && uM) + (int)(cO && uO);
@@ -720,7 +723,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
         if (O.homog) {
           O.rho = pick_under ? -1 : (n - 1 - pick) - above_u;
           O.val = pick3(cR && !uR, cM && !uM, vR, vM, vO);
-          O.inv = pick3(cR && !uR, cM && !uM, invR, invM, invO);
+          O.inv = readfirstlane_f64(1.0 / (O.val - 1.0));  // seeds the search for the demoted count
         }
       }
     }
@@ -738,7 +741,27 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
         S.used = 0;
         return true;
       }
+      // a stack without the "other" class has candidates in few chunks: after one empty
+      // chunk, look at the ballots of the next 64 cached chunks at once and jump
+      const bool sparse = under ? !(uO && nO > 0) : (uO || nO == 0);
+      bool looked = false;
       while (S.cm == 0ull && S.c > 0) {
+        const int low_cached = max(c.nch - kUC, 0);
+        if (looked && sparse && S.c > low_cached) {
+          const int ch = S.c - 1 - lane;
+          bool has = false;
+          if (ch >= low_cached) {
+            const int ci = c.nch - 1 - ch;
+            const uint64_t wr = L.cls[2 * ci], wm = L.cls[2 * ci + 1];
+            const uint64_t um = (uR ? wr : 0ull) | (uM ? wm : 0ull);
+            has = (under ? um : ((wr | wm) & ~um)) != 0ull;
+          }
+          const uint64_t hit = ballot64(has);
+          const int span = min(64, S.c - low_cached);
+          S.c -= hit ? (int)__builtin_ctzll(hit) : span;
+          if (!hit) continue;
+        }
+        looked = true;
         --S.c;
         N2V_STAT(10, 1);
         if (c.nch - 1 - S.c >= kUC) N2V_STAT(7, 1);
@@ -755,7 +778,13 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
       // (a conditional on captured lvalues is an lvalue: clang then selects ADDRESSES and the
       // values are forced into scratch memory; pick3 takes them by value)
       S.val = pick3(isR, isM, vR, vM, vO);
-      S.inv = pick3(isR, isM, invR, invM, invO);
+      if (!under) {  // 1 / (V - 1) seeds the search for the demoted count: once per class
+        const int cid = isR ? 0 : (isM ? 1 : 2);
+        if (cid != S.cid) {
+          S.cid = cid;
+          S.inv = readfirstlane_f64(1.0 / (S.val - 1.0));
+        }
+      }
       S.is_pick = (pk & lbit) != 0ull;
       uint64_t run = lbit;
       if (!S.is_pick) {
