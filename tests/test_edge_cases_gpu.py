@@ -87,12 +87,14 @@ def test_star_graph_hub_return_probabilities(oracle):
     assert 0.0 < ret.mean() < 1.0
 
 
-@pytest.mark.parametrize("pq", [(0.5, 2.0), (4.0, 0.25), (0.25, 0.25), (4.0, 4.0), (1.0, 0.5)])
+@pytest.mark.parametrize("pq", [(0.5, 2.0), (4.0, 0.25), (0.25, 0.25), (4.0, 4.0), (1.0, 0.5),
+                                (3.0, 0.7), (0.7, 1.3), (1.5, 1.0 / 3.0)])
 def test_rows_longer_than_the_ballot_cache(oracle, pq):
     """rows of 20 000 neighbours (the unit kernel caches class ballots for 8192): reverse
     classification keeps return/shared slots below the cache by position (hub A seen from a
     leaf: 1-3 slots; from B: 300 slots, more than the list holds, so it falls back to
-    searching), with multi-edges, for every arrangement of under/overfull classes"""
+    searching), with multi-edges, for every arrangement of under/overfull classes; the
+    non-dyadic p, q also exercise the run-by-run row sum across many binades"""
     rng = np.random.default_rng(5)
     A, B, C = 0, 1, 2
     leaves = np.arange(100, 20100)
