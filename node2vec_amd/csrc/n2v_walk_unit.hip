@@ -266,6 +266,7 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   // search and scatter the class bits: O(m log n) instead of O(n), and N(v) is never
   // read.  Multi-edges: every occurrence of an id in N(v) is marked; a repeated id of
   // N(s) is searched once.
+  // (thresholds 128..512 and ratios 1..4 were timed on cfg 2: flat within 2 %)
   const bool reverse = n > 256 && (!c.need_mem || 2 * c.m < n);
   if (reverse) {
     const int ncached = c.nch < kUC ? c.nch : kUC;
