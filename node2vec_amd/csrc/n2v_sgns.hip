@@ -13,6 +13,8 @@
 // (bisect over the cumulative count^0.75 table) are lane-parallel: every random
 // number is a pure function of (seed, sentence id, draw index).  Waves update
 // syn0/syn1neg unsynchronised (hogwild), like gensim's worker threads.
+#include <cstdlib>
+
 #include "n2v_common.h"
 
 namespace n2v {
@@ -413,6 +415,9 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   if (waves > n_walks) waves = n_walks;
   int64_t blocks = (waves + kSgnsWaves - 1) / kSgnsWaves;
   if (blocks > 256 * 8) blocks = 256 * 8;
+#ifdef N2V_SGNS_TUNE
+  if (const char *e = getenv("N2V_SGNS_BLOCKS_PER_CU")) { int64_t cap = 256 * (int64_t)atoi(e); if (blocks > cap) blocks = cap; }
+#endif
   dim3 block(kSgnsWaves * 64);
   if (waves < kSgnsWaves) block = dim3((unsigned)waves * 64);
   if (P->deterministic) {
