@@ -18,7 +18,7 @@ for mode in ("exact", "fast"):
 clampdeg = deg.clamp(min=1)
 order = torch.sort(clampdeg, descending=True, stable=True).indices
 index_of = torch.empty(g.n_vertices, dtype=torch.int32, device="cuda"); index_of[order] = torch.arange(g.n_vertices, dtype=torch.int32, device="cuda")
-m = sgns.SgnsModel(sgns.Vocab(order, clampdeg[order], index_of), 256, 5, 5, seed=1)
+m = sgns.SgnsModel(sgns.Vocab(order, clampdeg[order], index_of), 256, 5, 5, seed=1, sample=0.0)
 idx = index_of[walks[valid].long()]
 for it in range(2):
     m.pairs.zero_(); torch.cuda.synchronize(); t0 = time.time(); m.train_block(idx, 0.025, 0); torch.cuda.synchronize(); dt = time.time() - t0
