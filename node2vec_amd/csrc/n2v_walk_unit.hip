@@ -60,6 +60,26 @@ __device__ __forceinline__ bool member_lds(const uint32_t *ys, int m, int32_t x,
   return (int32_t)ys[lo < m ? lo : m - 1] == x && lo < m;
 }
 
+// four LDS searches in lock-step (independent chains, so their LDS round trips overlap)
+__device__ __forceinline__ void member_lds_x4(const uint32_t *ys, int m, const int32_t (&x)[4],
+                                              int iters, bool (&found)[4]) {
+  int lo[4] = {0, 0, 0, 0}, hi[4] = {m, m, m, m};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int mid = (lo[u] + hi[u]) >> 1;
+      const int32_t val = (int32_t)ys[mid < m ? mid : m - 1];
+      const bool act = lo[u] < hi[u];
+      const bool less = val < x[u];
+      lo[u] = (act && less) ? mid + 1 : lo[u];
+      hi[u] = (act && !less) ? mid : hi[u];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    found[u] = found[u] | ((int32_t)ys[lo[u] < m ? lo[u] : m - 1] == x[u] && lo[u] < m);
+}
+
 struct UnitConsts {
   double bR, bM, bO;     // 1/p, 1, 1/q
   int64_t TR, TM, TO;    // the same times 2^20 (exact integers; dyadic kernel only)
@@ -341,13 +361,18 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   //          hits, by LDS binary search (no global gather on any dependent chain)
   //  filter  m <= 8192 and not much longer than N(v): large filter, hits verified by
   //          binary search over global memory, batched once per step
+  //  merge   N(s) too long for a filter and N(v) of comparable length (hub to hub): both rows
+  //          are sorted, so the ids N(s) can share with a group of 256 neighbours form one
+  //          window that only moves forward; it is staged in LDS 384 ids at a time and
+  //          searched there (one coalesced load per window instead of 8 dependent gathers)
   //  direct  otherwise (N(s) a hub, N(v) short): per-lane global binary search
   const bool staged = c.need_mem && c.m <= kYsCap;
   const bool big_filter = c.need_mem && !staged && c.m <= 4096 && c.m <= 8 * n + 64;
   const bool use_filter = big_filter || (staged && c.nch > 2);
   uint32_t *fbits = staged ? L.bits : L.pool;
   int shift = 32;
-  const bool direct = c.need_mem && !staged && !big_filter;
+  const bool merge = c.need_mem && !staged && !big_filter && c.m <= 4 * n;
+  const bool direct = c.need_mem && !staged && !big_filter && !merge;
   const int stride_s = (c.m + 63) >> 6;
   const int iters_s = 32 - __clz(stride_s);
   if (big_filter) park_pivots(reinterpret_cast<int32_t *>(L.bits), c.scol, c.m, stride_s, lane);
@@ -423,8 +448,50 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
       mcount += cnt;
     }
   };
-  const bool search_here = c.need_mem && !use_filter;  // staged (short rows) or direct
+  const bool search_here = c.need_mem && !use_filter;  // staged (short rows), merge or direct
   int chunk0 = 0;
+  if (merge) {
+    int sp = 0;  // every id of N(s)[0, sp) is below the ids of N(v) still to come
+    for (; chunk0 < c.nch; chunk0 += 4) {
+      int32_t xs[4];
+      bool memv[4] = {false, false, false, false};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = (chunk0 + u) * 64 + lane;
+        xs[u] = i < n ? c.vcol[i] : -1;
+      }
+      const int32_t x_hi = __builtin_amdgcn_readfirstlane(c.vcol[min(n, (chunk0 + 4) * 64) - 1]);
+      for (;;) {
+        const int wn = min(kYsCap, c.m - sp);
+        if (wn <= 0) break;
+        int32_t y[kYsCap / 64];
+#pragma unroll
+        for (int k = 0; k < kYsCap / 64; ++k) {
+          const int j = lane + 64 * k;
+          y[k] = j < wn ? c.scol[sp + j] : 0x7fffffff;
+        }
+        int below = 0;  // window ids smaller than the last id of the group
+#pragma unroll
+        for (int k = 0; k < kYsCap / 64; ++k) {
+          const int j = lane + 64 * k;
+          if (j < wn) L.pool[j] = (uint32_t)y[k];
+          below += (int)(y[k] < x_hi);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        member_lds_x4(L.pool, wn, xs, 9, memv);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) below += __shfl_xor(below, off, 64);
+        below = __builtin_amdgcn_readfirstlane(below);
+        __builtin_amdgcn_wave_barrier();
+        sp += below;
+        if (below < wn) break;  // the window reaches the last id of the group: nothing further can match
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (chunk0 + u < c.nch) finish_chunk(chunk0 + u, xs[u], memv[u]);
+    }
+  }
   for (; chunk0 + 4 <= c.nch; chunk0 += 4) {  // full groups: 4 loads / 4 searches in flight
     int32_t xs[4];
 #pragma unroll
@@ -461,7 +528,9 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  N2V_T(17);
+#ifdef N2V_STATS
+  if (merge) { N2V_T(22); N2V_STAT(5, 1); } else if (direct) { N2V_T(20); } else { N2V_T(17); }
+#endif
   N2V_STAT(3, mcount);
   if (mcount) verify_unit(c, L, mcount, lane, staged, nM);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -2,10 +2,20 @@ import ctypes as C, os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 os.environ["N2V_HIP_LIB"] = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "build_variants/libn2v_stats.so")
 from node2vec_amd import synthetic, randomwalk as rw, _lib
-g = synthetic.rmat(20, 5_000_000, device="cuda")
-start = rw.start_vertices(g)[:47104].contiguous()
+if os.environ.get("GRAPH") == "cfg3":  # Chung-Lu 10 M, trimmed at 10 000 (scripts/scale_check.py)
+    from node2vec_amd.fugue import trim_hotspot_edges
+    from node2vec_amd.graph import DeviceGraph
+    g = synthetic.chung_lu(10_000_000, 100_000_000, device="cuda")
+    src = torch.repeat_interleave(torch.arange(g.n_vertices, device="cuda"), g.degrees())
+    keep = trim_hotspot_edges(src, 10_000, 42)
+    g = DeviceGraph.from_edges(src[keep], g.col[keep].long(), g.w[keep], n_vertices=g.n_vertices, device="cuda")
+    sv = rw.start_vertices(g)
+    start = sv[torch.randperm(sv.numel(), device="cuda")[:47104]].contiguous()
+else:
+    g = synthetic.rmat(20, 5_000_000, device="cuda")
+    start = rw.start_vertices(g)[:47104].contiguous()
 L = _lib.load()
-names = ["draw_steps", "staged+filter", "direct_search", "maybes", "verify_rounds", "past_quick_exit",
+names = ["draw_steps", "staged+filter", "direct_search", "maybes", "verify_rounds", "merge_steps",
          "pair_invocations", "pair_inv_n<=64", "pair_iterations", "refills", "pair_not_cached", "staged_nofilter", "big_filter", "reverse"]
 PQ = tuple(float(x) for x in os.environ.get("PQ", "0.5,2.0").split(","))
 for p, q in (PQ,):
@@ -15,7 +25,7 @@ for p, q in (PQ,):
     L.n2v_debug_stats_unit(buf, 1)
     st = dict(zip(names, list(buf)))
     print(p, q, {k: (v, round(v / max(st["draw_steps"], 1), 4)) for k, v in st.items()})
-    ph = ["P0 stage/filter", "P1 stream", "P2 verify", "sum+avg", "minmax", "pairing", "pair uncached", "reverse classify"]
+    ph = ["P0 stage/filter", "P1 staged/filter", "P2 verify", "sum+avg", "P1 direct", "pairing", "P1 merge", "reverse classify"]
     cyc = list(buf)[16:23] + [list(buf)[24]]; tot = list(buf)[23]
     print("  wave-cycles total", tot, "per step", round(tot/st["draw_steps"]));    print("  cycles/step by phase:", {n: (round(c / st["draw_steps"]), f"{100*c/tot:.1f}%") for n, c in zip(ph, cyc)})
     b = list(buf)
