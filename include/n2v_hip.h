@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define N2V_ABI_VERSION 1
+#define N2V_ABI_VERSION 2
 
 #define N2V_OK 0
 #define N2V_EINVAL (-1)  /* maps to ValueError (randomwalk.py:212-217)      */
@@ -58,7 +58,10 @@ typedef struct n2v_slot {
 /* The reference's adjacency DataFrame df_adj (fugue.py:130, randomwalk.py:266-275)
  * as CSR in HBM: one row per vertex id, neighbours sorted by dst ascending,
  * multi-edges kept.  `slots` holds the per-row first-order alias tables written by
- * n2v_alias_build, CSR-aligned (needed by N2V_WALK_FAST only, else may be NULL). */
+ * n2v_alias_build, CSR-aligned (needed by N2V_WALK_FAST only, else may be NULL).
+ * `pivots` is an optional search index over `col` written by n2v_pivots_build
+ * (NULL = plain binary search): the test "x in N_out(src)" of randomwalk.py:226 then
+ * touches 2-3 cache lines instead of log2(degree). */
 typedef struct n2v_graph {
   int64_t n_vertices;
   int64_t n_edges;
@@ -68,6 +71,7 @@ typedef struct n2v_graph {
                             NULL = every weight is 1.0 (unweighted graph): the walk
                             kernels then never read weights */
   const n2v_slot *slots; /* [n_edges] */
+  const int32_t *pivots; /* [(n_edges + 31) / 32]: col[min(32 j + 31, n_edges - 1)] */
 } n2v_graph;
 
 int n2v_abi_version(void);
@@ -86,6 +90,12 @@ int n2v_device_count(void);
 int n2v_alias_build(const int64_t *rowptr, const int32_t *col, const float *w,
                     int64_t n_rows, n2v_slot *slots_out, uint32_t *status,
                     void *stream);
+
+/* Search index for N2V_WALK_FAST: the last id of every aligned block of 32 entries of
+ * `col` (one 128-byte line).  Inside a sorted row the block ends ascend, so a
+ * membership query is a binary search over (degree / 32) pivots followed by one over a
+ * single line.  pivots_out: [(n_edges + 31) / 32] int32. */
+int n2v_pivots_build(const int32_t *col, int64_t n_edges, int32_t *pivots_out, void *stream);
 
 /* K2 -- the whole of fugue.random_walk's loop (fugue.py:137-153) on device:
  * initiate_random_walk (randomwalk.py:279-296), walk_length x

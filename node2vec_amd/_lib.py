@@ -15,14 +15,14 @@ WALK_EXACT, WALK_FAST = 0, 1
 
 # every symbol include/n2v_hip.h declares
 SYMBOLS = ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alias_build",
-           "n2v_walk", "n2v_trim_mark", "n2v_sgns_train")
+           "n2v_pivots_build", "n2v_walk", "n2v_trim_mark", "n2v_sgns_train")
 
 
 class Graph(C.Structure):
     """struct n2v_graph"""
     _fields_ = [("n_vertices", C.c_int64), ("n_edges", C.c_int64),
                 ("rowptr", C.c_void_p), ("col", C.c_void_p), ("w", C.c_void_p),
-                ("slots", C.c_void_p)]
+                ("slots", C.c_void_p), ("pivots", C.c_void_p)]
 
 
 class SgnsParams(C.Structure):
@@ -53,6 +53,8 @@ def load():
     L.n2v_alias_build.restype = C.c_int
     L.n2v_alias_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_void_p, C.c_void_p]
+    L.n2v_pivots_build.restype = C.c_int
+    L.n2v_pivots_build.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.n2v_walk.restype = C.c_int
     L.n2v_walk.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                            C.c_double, C.c_double, C.c_uint64, C.c_int32, C.c_void_p,

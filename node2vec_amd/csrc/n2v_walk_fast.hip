@@ -31,6 +31,43 @@ __device__ __forceinline__ bool member_sorted_lane(const int32_t *a, int m, int3
   return lo < m && a[lo] == x;
 }
 
+// The same test through the block-end index (include/n2v_hip.h, n2v_pivots_build).  The
+// kernel is bound by the number of cache lines its random probes pull in (every probe of a
+// plain binary search is another 128-byte line until the last few), so the search runs
+// over pivots[j] = col[32 j + 31] of the aligned 32-entry blocks that END inside the row
+// -- (degree / 32) ids, contiguous -- and then inside the one block that can hold x.
+__device__ __forceinline__ bool member_pivoted_lane(const int32_t *col, const int32_t *pivots,
+                                                    int64_t first, int m, int32_t x) {
+  const int64_t last = first + m;  // row = col[first, last)
+  int64_t lo = first >> 5, hi = (last - 1) >> 5;  // blocks lo .. hi-1 end inside the row
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (pivots[mid] < x)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  int64_t a = max(first, lo << 5);
+  const int64_t end = min(last, (lo << 5) + 32);
+  int64_t b = end;
+  while (a < b) {
+    const int64_t mid = (a + b) >> 1;
+    if (col[mid] < x)
+      a = mid + 1;
+    else
+      b = mid;
+  }
+  return a < end && col[a] == x;
+}
+
+__global__ void pivots_build_kernel(const int32_t *__restrict__ col, int64_t n_edges,
+                                    int32_t *__restrict__ pivots) {
+  const int64_t n_blocks = (n_edges + 31) >> 5;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_blocks;
+       j += (int64_t)gridDim.x * blockDim.x)
+    pivots[j] = col[min(32 * j + 31, n_edges - 1)];
+}
+
 __global__ __launch_bounds__(256) void walk_fast_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double p, double q, uint64_t seed, int32_t *__restrict__ walks_out,
@@ -120,7 +157,10 @@ __global__ __launch_bounds__(256) void walk_fast_kernel(
         else if (!(u < b_hi))
           accept = false;
         else
-          accept = u < (member_sorted_lane(g.col + sb, m, x) ? 1.0 : inv_q);
+          accept = u < ((g.pivots ? member_pivoted_lane(g.col, g.pivots, sb, m, x)
+                                 : member_sorted_lane(g.col + sb, m, x))
+                            ? 1.0
+                            : inv_q);
       }
     }
     if (!accept) {
@@ -168,6 +208,19 @@ extern "C" int n2v_walk_fast_launch(const n2v_graph *g, const int32_t *start_ids
                      (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, p, q,
                      seed, walks_out, valid_out, status,
                      reinterpret_cast<unsigned long long *>(status + 2));
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}
+
+extern "C" int n2v_pivots_build(const int32_t *col, int64_t n_edges, int32_t *pivots_out,
+                                void *stream) {
+  if (n_edges < 0 || (n_edges > 0 && (!col || !pivots_out))) return N2V_EINVAL;
+  if (n_edges == 0) return N2V_OK;
+  const int64_t n_blocks = (n_edges + 31) >> 5;
+  int64_t blocks = (n_blocks + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(n2v::pivots_build_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, col, n_edges, pivots_out);
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
 }

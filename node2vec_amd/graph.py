@@ -25,6 +25,7 @@ class DeviceGraph:
         self.col = col.contiguous()
         self.w = w.contiguous()
         self.slots: Optional[torch.Tensor] = None  # int32 [E, 4] view of n2v_slot[E]
+        self.pivots: Optional[torch.Tensor] = None  # int32 [(E + 31) / 32] search index (fast mode)
         # unweighted graph (index_graph_* gives weight 1.0, indexer.py:20-21): the walk
         # kernels are told through w == NULL and never read the weights
         self.unit_weights = bool((self.w == 1.0).all()) if self.w.numel() else True
@@ -83,12 +84,15 @@ class DeviceGraph:
         g = DeviceGraph(self.rowptr.to(device), self.col.to(device), self.w.to(device))
         if self.slots is not None:
             g.slots = self.slots.to(device)
+        if self.pivots is not None:
+            g.pivots = self.pivots.to(device)
         return g
 
     def c_struct(self) -> _lib.Graph:
         return _lib.Graph(self.n_vertices, self.n_edges, self.rowptr.data_ptr(),
                           self.col.data_ptr(), 0 if self.unit_weights else self.w.data_ptr(),
-                          0 if self.slots is None else self.slots.data_ptr())
+                          0 if self.slots is None else self.slots.data_ptr(),
+                          0 if self.pivots is None else self.pivots.data_ptr())
 
     # -- K1 -----------------------------------------------------------------------
     def build_alias(self) -> "DeviceGraph":
@@ -110,6 +114,20 @@ class DeviceGraph:
         _lib.check(rc, "n2v_alias_build")
         _lib.check_status_word(int(status[0].item()), "n2v_alias_build")
         self.slots = slots
+        return self.build_pivots()
+
+    def build_pivots(self) -> "DeviceGraph":
+        """Block-end search index over `col` (n2v_pivots_build): fast-mode membership tests
+        then touch 2-3 cache lines instead of log2(degree)."""
+        L = _lib.load()
+        _lib.require_gpu()
+        pivots = torch.zeros(((self.n_edges + 31) // 32,), dtype=torch.int32, device=self.device)
+        if self.n_edges:
+            with torch.cuda.device(self.device):
+                rc = L.n2v_pivots_build(self.col.data_ptr(), self.n_edges, pivots.data_ptr(),
+                                        _lib.current_stream_ptr())
+            _lib.check(rc, "n2v_pivots_build")
+        self.pivots = pivots
         return self
 
     # -- views of the packed tables (tests, debugging) -------------------------------

@@ -11,4 +11,5 @@ for weights in (None, "uniform"):
             walks, valid = rw.walk(g, start, 10, 80, p, q, 42, mode="fast", stats=st)
             torch.cuda.synchronize(); best = min(best, time.time() - t)
         n = int(valid.sum()) * 80
-        print(f"fast weights={weights} p={p} q={q}: {best*1e3:7.1f} ms {n/best/1e6:8.1f} Msteps/s trials/step {int(st['trials'].item())/n:.2f}", flush=True)
+        chk = int((walks.long() * torch.arange(1, walks.shape[1] + 1, device='cuda')).sum().item()) & 0xffffffffffff
+        print(f"fast weights={weights} p={p} q={q}: {best*1e3:7.1f} ms {n/best/1e6:8.1f} Msteps/s trials/step {int(st['trials'].item())/n:.2f} checksum {chk:x}", flush=True)

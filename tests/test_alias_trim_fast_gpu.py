@@ -177,3 +177,31 @@ def test_fast_mode_sinks_and_independence_of_sharding():
     assert all(int(h) in key for h in hop[:5000])
     parts = [rw.walk(g, c, 2, 15, 0.5, 2.0, 5, mode="fast") for c in torch.chunk(start, 4)]
     assert torch.equal(torch.cat([x[0] for x in parts]), walks)
+
+
+@pytest.mark.parametrize("pq", [(0.5, 2.0), (4.0, 0.25), (2.0, 0.5)])
+def test_fast_mode_pivot_index_changes_no_decision(pq):
+    """the block-end search index (n2v_pivots_build) answers "x in N(s)" exactly like the
+    plain binary search: fast walks with and without it are identical, on rows that start
+    and end anywhere inside the 32-entry blocks, with multi-edges and hubs"""
+    import torch
+
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+
+    rng = np.random.default_rng(11)
+    nv = 5000
+    src = np.concatenate([rng.integers(0, nv, 60000), np.full(4000, 7), rng.integers(0, nv, 4000),
+                          np.full(900, 123), rng.integers(0, 50, 900)])
+    dst = np.concatenate([rng.integers(0, nv, 60000), rng.integers(0, nv, 4000), np.full(4000, 7),
+                          rng.integers(0, 50, 900), np.full(900, 123)])
+    g = DeviceGraph.from_edges(src, dst, np.ones(src.size, np.float32), n_vertices=nv, device="cuda")
+    g.build_alias()
+    piv = g.pivots.cpu().numpy()
+    col = g.col.cpu().numpy()
+    assert np.array_equal(piv, col[np.minimum(np.arange(piv.size) * 32 + 31, col.size - 1)])
+    start = rw.start_vertices(g)
+    with_index = rw.walk(g, start, 4, 40, pq[0], pq[1], 5, mode="fast")
+    g.pivots = None
+    without = rw.walk(g, start, 4, 40, pq[0], pq[1], 5, mode="fast")
+    assert torch.equal(with_index[0], without[0]) and torch.equal(with_index[1], without[1])
