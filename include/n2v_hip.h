@@ -113,7 +113,10 @@ int n2v_pivots_build(const int32_t *col, int64_t n_edges, int32_t *pivots_out, v
  * of DESIGN.md "RNG", keyed by (seed, start vertex, ordinal, step): results do
  * not depend on launch geometry or on how start_ids are sharded over GPUs.
  * mode N2V_WALK_EXACT reproduces generate_edge_alias_tables + sampling_from_alias
- * bit for bit; N2V_WALK_FAST draws from the same distribution by rejection. */
+ * bit for bit; N2V_WALK_FAST draws from the same distribution by rejection.
+ * With return_param == inout_param == 1 (the reference's defaults) and g->slots set,
+ * exact mode reads the K1 tables instead of rebuilding them: same bits, one gather per
+ * step. */
 int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
              int32_t num_walks, int32_t walk_length, double return_param,
              double inout_param, uint64_t seed, int32_t mode,

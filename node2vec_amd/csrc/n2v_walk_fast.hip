@@ -7,8 +7,9 @@
 // neighbour and its alias's vertex id) and accepted with probability
 // beta(x) / beta_max, beta = 1/p if x == s, 1 if x in N(s) (binary search over
 // the sorted row of s), 1/q otherwise: P(x) ~ w(v,x) * beta(x), the reference's
-// unnormalised probability (:223-230).  The first step (s < 0) is the unbiased
-// table itself and is draw-for-draw identical to the exact mode.
+// unnormalised probability (:223-230).  The first step (s < 0), and every step when
+// p == q == 1, is the unbiased table itself and is draw-for-draw identical to the exact
+// mode (n2v_walk dispatches exact walks with p == q == 1 here when the slots exist).
 //
 // One LANE per walker, walkers resident for all L steps.  Every loop iteration
 // each live lane performs ONE trial for its own current step; a lane whose
@@ -131,7 +132,9 @@ __global__ __launch_bounds__(256) void walk_fast_kernel(
   while (__ballot(live) != 0ull) {
     if (!live) continue;
     // ---- one trial of the current step ----------------------------------------
-    uint64_t bits = s < 0 ? hstep : trial_bits(hstep, trial);
+    // unbiased steps (the first one; every one when p == q == 1) never reject and use the exact
+    // mode's two uniforms: those draws are bit-identical to exact mode
+    uint64_t bits = (s < 0 || !biased) ? hstep : trial_bits(hstep, trial);
     const uint32_t u1 = (uint32_t)(bits >> 32), u2 = (uint32_t)bits;
     const int pick = (int)__umulhi(u1, (uint32_t)n);
     const n2v_slot sl = g.slots[vb + pick];

@@ -53,6 +53,13 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
         raise ValueError(f"Zero return ({return_param}) or inout ({inout_param}) parameter!")
     if mode == "fast" and graph.slots is None:
         graph.build_alias()
+    if mode == "exact" and return_param == 1.0 and inout_param == 1.0 and graph.slots is None:
+        # the reference's default p = q = 1: every per-step table is the first-order table of
+        # the current vertex, i.e. the K1 slots (bit-identical); build them once (milliseconds)
+        try:
+            graph.build_alias()
+        except ZeroDivisionError:
+            pass  # some row sums to 0: keep the per-step path, which raises only if it is visited
     start_ids = start_ids.to(device=graph.device, dtype=torch.int32).contiguous()
     n_start = start_ids.numel()
     total = n_start * num_walks

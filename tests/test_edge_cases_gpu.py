@@ -119,6 +119,36 @@ def test_rows_longer_than_the_ballot_cache(oracle, pq):
     assert np.array_equal(gv, wv) and np.array_equal(got, want)
 
 
+def test_default_p_q_uses_the_first_order_tables_and_the_same_bits(oracle, monkeypatch):
+    """p = q = 1 (the reference's defaults): exact mode reads the K1 tables when they exist and
+    rebuilds per step when they do not; both equal the oracle on a weighted graph with sinks"""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+
+    rng = np.random.default_rng(21)
+    src, dst = rng.integers(0, 800, 9000), rng.integers(0, 800, 9000)
+    keep = src % 11 != 3
+    src, dst = src[keep], dst[keep]
+    w = rng.uniform(0.1, 3.0, src.size).astype(np.float32)
+    g = DeviceGraph.from_edges(src, dst, w, n_vertices=800, device="cuda")
+    start = np.arange(0, 800, dtype=np.int32)
+    want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.w.cpu().numpy(),
+                                  start, 3, 30, 1.0, 1.0, 9)
+    assert g.slots is None
+    got, gv = rw.walk(g, torch.as_tensor(start), 3, 30, 1.0, 1.0, 9)  # builds and uses the slots
+    assert g.slots is not None
+    assert np.array_equal(gv.cpu().numpy().astype(bool), wv) and np.array_equal(got.cpu().numpy(), want)
+    g.slots = g.pivots = None
+
+    def refuse(self):
+        raise ZeroDivisionError("pretend a row sums to zero")
+
+    monkeypatch.setattr(DeviceGraph, "build_alias", refuse)
+    got2, gv2 = rw.walk(g, torch.as_tensor(start), 3, 30, 1.0, 1.0, 9)  # per-step rebuild
+    assert g.slots is None
+    assert torch.equal(got, got2) and torch.equal(gv, gv2)
+
+
 def test_alias_build_on_empty_and_single_rows(oracle):
     from node2vec_amd.graph import DeviceGraph
 
