@@ -57,8 +57,13 @@ while time.time() - t0 < budget:
     if len(src) == 0:
         continue
     g = DeviceGraph.from_edges(src, dst, w, n_vertices=nv, device="cuda")
-    p = float(rng.choice([0.25, 0.5, 1.0, 2.0, 4.0, 3.0, 0.7]))
-    q = float(rng.choice([0.25, 0.5, 1.0, 2.0, 4.0, 1.3, 0.1]))
+    # FUZZ_PQ=extreme: very small / very large and non-dyadic parameters
+    if os.environ.get("FUZZ_PQ") == "extreme":
+        vals = [0.001, 0.01, 0.03125, 0.03, 1.0 / 3.0, 0.999, 1.001, 16.0, 37.5, 100.0, 1000.0, 1024.0]
+        p, q = float(rng.choice(vals)), float(rng.choice(vals))
+    else:
+        p = float(rng.choice([0.25, 0.5, 1.0, 2.0, 4.0, 3.0, 0.7]))
+        q = float(rng.choice([0.25, 0.5, 1.0, 2.0, 4.0, 1.3, 0.1]))
     nw, wl = int(rng.integers(1, 5)), int(rng.choice([1, 5, 20, 60, 130]))
     seed = int(rng.integers(0, 2 ** 62))
     deg = g.degrees()
