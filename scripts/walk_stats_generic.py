@@ -9,7 +9,7 @@ g = DeviceGraph(base.rowptr, base.col, torch.randint(1, 6, (base.n_edges,), gene
 start = rw.start_vertices(g)[:47104].contiguous()
 L = _lib.load()
 names = {0: "steps", 1: "filter_steps", 2: "direct_steps", 3: "maybes", 5: "past_quick_exit", 6: "pair_invocations", 7: "pair_inv_n<=64", 8: "pair_iterations", 9: "overfull_consumed", 10: "pair_uncached_inv"}
-for p, q in ((1.0, 1.0), (0.5, 2.0)):
+for p, q in ((0.5, 2.0), (4.0, 0.25)):
     buf = (C.c_ulonglong * 32)()
     L.n2v_debug_stats(buf, 1)
     walks, valid = rw.walk(g, start, 10, 80, p, q, 42); torch.cuda.synchronize()
