@@ -41,7 +41,11 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
          return_param: float, inout_param: float, seed: int, mode: str = "exact",
          out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, check: bool = True,
          stats: Optional[dict] = None):
-    """Launch K2.  Returns (walks int32 [n_start*num_walks, walk_length+1], valid bool)."""
+    """Launch K2.  Returns (walks int32 [n_start*num_walks, walk_length+1], valid bool).
+
+    mode "fast", and mode "exact" with return_param == inout_param == 1 (the reference's
+    defaults), read the first-order alias tables of the graph: they are built on first use
+    (graph.build_alias(): 16 bytes per edge plus the search index, kept on the graph)."""
     L = _lib.load()
     _lib.require_gpu()
     if mode not in MODES:
