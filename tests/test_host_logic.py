@@ -215,3 +215,27 @@ def test_walk_stage_files_round_trip(tmp_path):
     vec = pd.DataFrame({"id": [1, 2], "vector": [[0.5, 1.0], [2.0, 3.0]]})
     n2v_io.write_vectors(str(tmp_path / "v.parquet"), vec)
     assert n2v_io.read_table(str(tmp_path / "v.parquet"))["id"].tolist() == [1, 2]
+
+
+def test_index_graph_tensors_matches_the_pandas_indexer():
+    """integer-named edge list: the torch (device) indexer gives the ids and the edge set
+    of index_graph_pandas, directed and undirected, with duplicate and reversed edges"""
+    import torch
+
+    from node2vec_amd.indexer import index_graph_pandas, index_graph_tensors
+
+    rng = np.random.default_rng(3)
+    src = rng.choice([5, 17, 900, 42, 7, 123456789], 60)
+    dst = rng.choice([5, 17, 900, 42, 8, 11], 60)
+    w = rng.choice([0.5, 1.0, 2.0], 60)
+    df = pd.DataFrame({"src": src, "dst": dst, "weight": w})
+    for directed in (True, False):
+        e, name_id = index_graph_pandas(df.copy(), directed)
+        s_id, d_id, ww, names = index_graph_tensors(torch.from_numpy(src), torch.from_numpy(dst),
+                                                     torch.from_numpy(w), directed)
+        assert names.tolist() == name_id["name"].tolist()
+        want = sorted(zip(e["src"], e["dst"], e["weight"].astype(np.float32)))
+        got = sorted(zip(s_id.tolist(), d_id.tolist(), ww.numpy()))
+        assert got == want
+    s_id, d_id, ww, names = index_graph_tensors(torch.tensor([3, 3]), torch.tensor([9, 3]))
+    assert ww.tolist() == [1.0, 1.0] and names.tolist() == [3, 9]
