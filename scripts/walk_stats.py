@@ -16,7 +16,7 @@ else:
     start = rw.start_vertices(g)[:47104].contiguous()
 L = _lib.load()
 names = ["draw_steps", "staged+filter", "direct_search", "maybes", "verify_rounds", "merge_steps",
-         "pair_invocations", "pair_inv_n<=64", "pair_iterations", "refills", "pair_not_cached", "staged_nofilter", "big_filter", "reverse"]
+         "pair_invocations", "engine_chunk_loads_uncached", "absorbed_slots", "cascades", "engine_chunk_loads", "staged_nofilter", "big_filter", "reverse"]
 PQ = tuple(float(x) for x in os.environ.get("PQ", "0.5,2.0").split(","))
 for p, q in (PQ,):
     buf = (C.c_ulonglong * 32)()
