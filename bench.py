@@ -300,7 +300,8 @@ def bench_sgns(args, torch, dist, g, walks, valid, rank, world, barrier, use_dis
                                       "rows_per_step": rows, "n_vocab": g.n_vertices,
                                       "sample": 0, "min_count": 0},
            "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
-                        "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": None,
+                        "unit": "GB/s", "frac": ach / HBM_PEAK,
+                        "traffic": _pmc_traffic("sgns_pmc_traffic.json") if args.dim == 128 else None,
                         "kernel": "sgns_kernel", "kernel_ms": 1e3 * kernel_s,
                         "algorithmic_bytes_per_pair": bytes_per_pair,
                         "fma_utilisation": pairs / args.steps * flops_per_pair / kernel_s / 157.3e12}}
@@ -315,10 +316,10 @@ def bench_sgns(args, torch, dist, g, walks, valid, rank, world, barrier, use_dis
     return res
 
 
-def _pmc_traffic():
+def _pmc_traffic(name="walk_pmc_traffic.json"):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/),
     corrected as MI355X_MICROARCH.md prescribes; None until such a profile exists."""
-    path = os.path.join(ROOT, "profiles", "walk_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):
         with open(path) as f:
             return json.load(f).get("hbm_bytes_per_launch")
