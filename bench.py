@@ -242,7 +242,8 @@ def bench_fast(args, torch, dist, g, rw, batch, walks, valid, rank, world, barri
             "parity": "same transition distribution (chi-square tested), not the same draws",
             "trials_per_step": trials / max(steps_done, 1),
             "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK, "traffic": None, "kernel": "walk_fast_kernel",
+                         "frac": ach / HBM_PEAK, "traffic": _pmc_traffic("fast_pmc_traffic.json"),
+                         "kernel": "walk_fast_kernel",
                          "kernel_ms": 1e3 * kernel_s,
                          "algorithmic_bytes_per_walk_step": abytes / max(steps_done, 1)}}
 
