@@ -49,6 +49,36 @@ def test_rmat18_exact_properties_and_oracle_sample(oracle, pq):
     assert np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("pq", [(0.5, 2.0), (4.0, 0.25), (3.0, 0.7), (1.0, 1.0)])
+def test_cfg2_full_size_properties_and_oracle_sample(oracle, pq):
+    """BASELINE cfg 2 at its full size (R-MAT scale 20, ~9.7 M directed edges, W = 10, L = 80):
+    the bench batch is walked once whole and once in 7 uneven shards -- same walks (a checksum of
+    row checksums and the rows themselves), every hop is an edge, and a sample of start vertices
+    (the biggest hubs included) equals the oracle bit for bit"""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd import synthetic
+
+    p, q = pq
+    g = synthetic.rmat(20, 5_000_000, device="cuda")
+    start = rw.start_vertices(g)[:47104].contiguous()
+    walks, valid = rw.walk(g, start, 10, 80, p, q, 42)
+    assert bool(valid.all()) and walks.shape == (471040, 81)
+    assert _all_hops_are_edges(g, walks, valid)
+    cuts = [0, 1, 777, 5000, 5001, 20000, 40001, 47104]
+    parts = [rw.walk(g, start[a:b].contiguous(), 10, 80, p, q, 42)[0] for a, b in zip(cuts, cuts[1:])]
+    sharded = torch.cat(parts)
+    weights = torch.arange(1, 82, device="cuda", dtype=torch.int64)
+    rows = (walks.long() * weights).sum(1)
+    assert int(rows.sum()) == int((sharded.long() * weights).sum())
+    assert torch.equal(walks, sharded)
+    deg = g.degrees()
+    sample = torch.unique(torch.cat([torch.topk(deg, 25).indices.to(torch.int32), start[::1500]]))
+    got, gv = rw.walk(g, sample, 2, 30, p, q, 42)
+    want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.w.cpu().numpy(),
+                                  sample.cpu().numpy(), 2, 30, p, q, 42, n_threads=8)
+    assert np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy(), want)
+
+
 def test_cfg5_shape_bipartite_hubs(oracle):
     """BASELINE cfg 5 in miniature: hubs of ~10 k leaves + one hub per leaf, p=4 q=0.25.
     Bipartite => the 'shared neighbour' branch never fires; hub rows exceed the LDS
