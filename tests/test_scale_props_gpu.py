@@ -132,3 +132,51 @@ def test_weighted_generic_kernel_large_rows(oracle):
     want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.w.cpu().numpy(),
                                   sample.cpu().numpy(), 3, 25, 0.5, 2.0, 11, n_threads=8)
     assert np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy(), want)
+
+
+def test_cfg2_full_size_sgns_properties(oracle):
+    """K3 on the bench corpus at full size (471 040 rows of 81 tokens, 1 M-row model, dim 128):
+    the number of trained pairs depends only on (seed, sentence ids) -- equal across launches,
+    equal to the sum over row blocks launched separately, and equal to the oracle on a block
+    of rows; with alpha = 0 the model comes back bit-identical; with alpha > 0 every row that
+    occurs in the corpus moves and everything stays finite"""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd import sgns, synthetic
+
+    g = synthetic.rmat(20, 5_000_000, device="cuda")
+    start = rw.start_vertices(g)[:47104].contiguous()
+    walks, valid = rw.walk(g, start, 10, 80, 0.5, 2.0, 42)
+    deg = g.degrees().clamp(min=1)
+    order = torch.sort(deg, descending=True, stable=True).indices
+    index_of = torch.empty(g.n_vertices, dtype=torch.int32, device="cuda")
+    index_of[order] = torch.arange(g.n_vertices, dtype=torch.int32, device="cuda")
+    m = sgns.SgnsModel(sgns.Vocab(order, deg[order], index_of), 128, 5, 5, seed=3, sample=0.0)
+    idx = index_of[walks[valid].long()].contiguous()
+    s0, s1 = m.syn0.clone(), m.syn1neg.clone()
+    m.train_block(idx, 0.0, 0)  # alpha = 0: g = 0 for every target
+    torch.cuda.synchronize()
+    whole = int(m.pairs.item())
+    assert torch.equal(m.syn0, s0) and torch.equal(m.syn1neg, s1)
+    m.pairs.zero_()
+    cuts = [0, 1000, 250000, 471040]
+    for a, b in zip(cuts, cuts[1:]):
+        m.train_block(idx[a:b].contiguous(), 0.0, a)  # sentence ids continue at a
+    torch.cuda.synchronize()
+    assert int(m.pairs.item()) == whole
+    blk = idx[250000:251500].contiguous()
+    m.pairs.zero_()
+    m.train_block(blk, 0.0, 250000)
+    torch.cuda.synchronize()
+    o0, o1 = s0.cpu().numpy().copy(), s1.cpu().numpy().copy()
+    n = oracle.sgns_train(blk.cpu().numpy(), o0, o1, m.cum_table.cpu().numpy(), None,
+                          sgns.exp_table(), len(m.vocab), 250000, m.seed, 128, 5, 5, 0.0)
+    assert int(m.pairs.item()) == n
+    m.pairs.zero_()
+    m.train_block(idx, 0.025, 0)
+    torch.cuda.synchronize()
+    assert int(m.pairs.item()) == whole
+    assert bool(torch.isfinite(m.syn0).all()) and bool(torch.isfinite(m.syn1neg).all())
+    seen = torch.zeros(g.n_vertices, dtype=torch.bool, device="cuda")
+    seen[idx.long().reshape(-1)] = True
+    moved = (m.syn0 != s0).any(1)
+    assert bool(moved[seen].all()) and not bool(moved[~seen].any())
