@@ -180,3 +180,28 @@ def test_cfg2_full_size_sgns_properties(oracle):
     seen[idx.long().reshape(-1)] = True
     moved = (m.syn0 != s0).any(1)
     assert bool(moved[seen].all()) and not bool(moved[~seen].any())
+
+
+def test_trim_at_scale_properties():
+    """trim_hotspot_vertices on a power-law graph of 2 M vertices (cfg 3's generator): every row
+    above the cap keeps exactly `cap` edges, rows at or below it keep all, the mask depends only
+    on the seed, and two seeds keep different samples of the same size"""
+    from node2vec_amd import synthetic
+    from node2vec_amd.fugue import trim_hotspot_edges
+
+    g = synthetic.chung_lu(2_000_000, 20_000_000, device="cuda")
+    deg = g.degrees()
+    cap = 1000
+    assert int(deg.max()) > 20 * cap
+    src = torch.repeat_interleave(torch.arange(g.n_vertices, device="cuda"), deg)
+    keep = trim_hotspot_edges(src, cap, 42)
+    kept = torch.bincount(src[keep], minlength=g.n_vertices)
+    assert torch.equal(kept, deg.clamp(max=cap))
+    assert torch.equal(keep, trim_hotspot_edges(src, cap, 42))
+    other = trim_hotspot_edges(src, cap, 43)
+    assert int(other.sum()) == int(keep.sum()) and not torch.equal(other, keep)
+    # the kept sample of the biggest row is spread over the whole row, not a prefix
+    hub = int(torch.argmax(deg))
+    lo, hi = int(g.rowptr[hub]), int(g.rowptr[hub + 1])
+    pos = torch.nonzero(keep[lo:hi]).flatten().double() / (hi - lo)
+    assert 0.4 < float(pos.mean()) < 0.6 and float(pos.max()) > 0.95 and float(pos.min()) < 0.05
