@@ -205,3 +205,26 @@ def test_trim_at_scale_properties():
     lo, hi = int(g.rowptr[hub]), int(g.rowptr[hub + 1])
     pos = torch.nonzero(keep[lo:hi]).flatten().double() / (hi - lo)
     assert 0.4 < float(pos.mean()) < 0.6 and float(pos.max()) > 0.95 and float(pos.min()) < 0.05
+
+
+def test_alias_tables_at_scale_encode_the_row_distribution():
+    """K1 on a weighted R-MAT graph (262 k vertices, ~2.3 M edges): the table of every row,
+    read back as a distribution -- slot i gives its own neighbour with prob_i / n and the
+    neighbour behind its alias with (1 - prob_i) / n -- is w / sum(w) of that row to 1e-12"""
+    from node2vec_amd import synthetic
+
+    g = synthetic.rmat(18, 1_200_000, device="cuda", weights="uniform").build_alias()
+    deg = g.degrees()
+    row = torch.repeat_interleave(torch.arange(g.n_vertices, device="cuda"), deg)
+    n = deg[row].double()
+    prob = g.prob.double()
+    keys = row * g.n_vertices + g.col.long()  # unique: the generator de-duplicates edges
+    assert bool((keys[1:] > keys[:-1]).all())
+    mass = prob / n
+    alias_key = row * g.n_vertices + g.alias.long()
+    pos = torch.searchsorted(keys, alias_key)
+    assert bool((keys[pos.clamp(max=keys.numel() - 1)] == alias_key).all())  # alias is a neighbour
+    mass = mass.index_add(0, pos, (1.0 - prob) / n)
+    w = g.w.double()
+    total = torch.zeros(g.n_vertices, dtype=torch.float64, device="cuda").index_add(0, row, w)
+    assert float((mass - w / total[row]).abs().max()) < 1e-12
