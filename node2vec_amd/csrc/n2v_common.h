@@ -52,6 +52,15 @@ __host__ __device__ inline uint64_t trial_bits(uint64_t hstep, uint32_t trial) {
   return mix64(hstep ^ (((uint64_t)trial + 1ULL) * 0x8CB92BA72F3D8DD7ULL));
 }
 
+// pick = int(r1 * n), r1 = u1 / 2^32 (sampling_from_alias, randomwalk.py:95).  Below 2^21
+// neighbours u1 * n < 2^53, the fp64 product is exact and the integer high word is the same
+// number; for longer rows Python's product rounds once before int() truncates, so the same
+// two fp64 operations are used.
+__device__ inline int pick_index(uint32_t u1, int n) {
+  if (n < (1 << 21)) return (int)__umulhi(u1, (uint32_t)n);
+  return (int)(((double)u1 * (1.0 / 4294967296.0)) * (double)n);
+}
+
 __device__ inline int lane_id() { return __lane_id(); }
 
 __device__ inline double readlane_f64(double v, int lane) {

@@ -230,7 +230,7 @@ __device__ __forceinline__ int pairing(const StepCtx &c, WaveLds &L, int lane, i
 __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_t u2,
                                           int lane, WaveLds &L N2V_STATS_ARG) {
   const int n = c.n;
-  const int pick = (int)__umulhi(u1, (uint32_t)n);  // int(r1 * n), r1 = u1 / 2^32
+  const int pick = pick_index(u1, n);  // int(r1 * n), r1 = u1 / 2^32
   const double r2 = (double)u2 * (1.0 / 4294967296.0);
 
   N2V_T0

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void walk_fast_kernel(
     // mode's two uniforms: those draws are bit-identical to exact mode
     uint64_t bits = (s < 0 || !biased) ? hstep : trial_bits(hstep, trial);
     const uint32_t u1 = (uint32_t)(bits >> 32), u2 = (uint32_t)bits;
-    const int pick = (int)__umulhi(u1, (uint32_t)n);
+    const int pick = pick_index(u1, n);
     const n2v_slot sl = g.slots[vb + pick];
     const double r2 = (double)u2 * (1.0 / 4294967296.0);
     const int32_t x = (r2 < sl.prob) ? sl.col : sl.alias;  // slot.alias is already a vertex id

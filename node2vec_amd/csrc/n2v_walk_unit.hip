@@ -272,7 +272,7 @@ template <bool kDyadic>
 __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K, uint32_t u1,
                                          uint32_t u2, int lane, UnitLds &L N2V_STATS_ARG) {
   const int n = c.n;
-  const int pick = (int)__umulhi(u1, (uint32_t)n);  // int(r1 * n)
+  const int pick = pick_index(u1, n);  // int(r1 * n)
   const double r2 = (double)u2 * (1.0 / 4294967296.0);
 
   N2V_T0
@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_UNIT_WAVES) void walk_exac
         int idx;
         if (s < 0 || !biased) {
           // uniform row: probs0 == 1.0 everywhere, no underfull slot, alias unused
-          idx = (int)__umulhi((uint32_t)(bits >> 32), (uint32_t)n);
+          idx = pick_index((uint32_t)(bits >> 32), n);
         } else {
           c.vcol = g.col + vb;
           c.n = n;

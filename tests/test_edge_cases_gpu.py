@@ -149,6 +149,29 @@ def test_default_p_q_uses_the_first_order_tables_and_the_same_bits(oracle, monke
     assert torch.equal(got, got2) and torch.equal(gv, gv2)
 
 
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_row_of_more_than_two_million_neighbours(oracle, mode):
+    """a star with 2.2 M leaves: above 2^21 neighbours int(r1 * n) is no longer an exact
+    integer product in the reference (fp64 rounds before int() truncates); the kernels switch
+    to the same two fp64 operations.  Exact mode equals the oracle; fast mode at p = q = 1
+    is the same draw"""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+
+    n = 2_200_000
+    leaves = torch.arange(1, n + 1, device="cuda")
+    hub = torch.zeros(n, dtype=torch.int64, device="cuda")
+    g = DeviceGraph.from_edges(torch.cat([hub, leaves]), torch.cat([leaves, hub]),
+                               torch.ones(2 * n, device="cuda"), n_vertices=n + 1, device="cuda")
+    assert int(g.degrees().max()) > (1 << 21)
+    start = np.array([0, 1, 5, 70001, 1048577, 2097153, n], np.int32)
+    p, q = (1.0, 1.0) if mode == "fast" else (0.5, 2.0)
+    got, gv = rw.walk(g, torch.as_tensor(start), 3, 4, p, q, 11, mode=mode)
+    want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.w.cpu().numpy(),
+                                  start, 3, 4, p, q, 11, n_threads=8)
+    assert np.array_equal(gv.cpu().numpy().astype(bool), wv) and np.array_equal(got.cpu().numpy(), want)
+
+
 def test_alias_build_on_empty_and_single_rows(oracle):
     from node2vec_amd.graph import DeviceGraph
 
