@@ -16,7 +16,8 @@
  *    errors detected on the host; data-dependent errors (the reference's
  *    ZeroDivisionError) are OR-ed into the device word status[0] as N2V_ST_*
  *    bits, to be read by the caller after it synchronises.  `status` points to
- *    FOUR uint32 words, zeroed by the caller: [0] status bits, [1] reserved,
+ *    FOUR uint32 words, zeroed by the caller: [0] status bits, [1] scratch (the exact walk
+ *    kernels hand out walkers through it; the library resets it on the stream before a launch),
  *    [2..3] a 64-bit counter that N2V_WALK_FAST increments by its number of
  *    rejection trials (for the algorithmic-bytes accounting of DESIGN.md);
  *  - no global state: re-entrant, any number of streams / devices.

@@ -445,9 +445,20 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
   const unsigned long long t_kernel0 = __builtin_readcyclecounter();
 #endif
 
-  for (int64_t rr = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block; rr < total;
-       rr += n_waves) {
+  // walkers are taken from a shared counter (status[1], zero at launch), not by a fixed
+  // stride: their costs differ widely and no wave should sit on a long queue while others idle
+  // (n2v_walk_unit.hip); results are addressed by walker row
+  const bool dynamic = total < 0xffffffffll;
+  int64_t rr = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block;
+  for (;;) {
+    if (dynamic) {
+      uint32_t t = 0;
+      if (lane == 0) t = atomicAdd(&status[1], 1u);
+      rr = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    }
+    if (rr >= total) break;
     const int64_t r = readfirstlane_i64(rr);
+    if (!dynamic) rr += n_waves;
     int32_t *out = walks_out + r * L1;
     // the path lives in registers (lane t holds vertices t and 64 + t) and is stored as
     // whole rows at the end; walks longer than 128 vertices fall back to direct stores
@@ -552,6 +563,9 @@ extern "C" int n2v_walk_exact_launch(const n2v_graph *g, const int32_t *start_id
   const int64_t cap = n2v::resident_blocks((const void *)n2v::walk_exact_kernel,
                                            n2v::kWavesPerBlock * 64, 0);
   if (blocks > cap) blocks = cap;
+  // status[1] is the kernel's walker counter: start it at zero on the same stream
+  if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
+    return N2V_ELAUNCH;
   hipLaunchKernelGGL(n2v::walk_exact_kernel, dim3((unsigned)blocks),
                      dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, *g, start_ids,
                      n_start, num_walks, walk_length, p, q, seed, walks_out, valid_out, status);

@@ -1086,9 +1086,21 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_UNIT_WAVES) void walk_exac
   const unsigned long long t_kernel0 = __builtin_readcyclecounter();
 #endif
 
-  for (int64_t rr = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block; rr < total;
-       rr += n_waves) {
+  // Walkers differ a lot in cost (a walk that lingers among hubs is many times dearer than one
+  // in the periphery), so waves take them from a shared counter (status[1], zero at launch)
+  // instead of a fixed stride: no wave is left with a long queue while others idle.  Results
+  // are addressed by walker row, so they do not depend on who walks what.
+  const bool dynamic = total < 0xffffffffll;
+  int64_t rr = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block;
+  for (;;) {
+    if (dynamic) {
+      uint32_t t = 0;
+      if (lane == 0) t = atomicAdd(&status[1], 1u);
+      rr = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    }
+    if (rr >= total) break;
     const int64_t r = readfirstlane_i64(rr);
+    if (!dynamic) rr += n_waves;
     int32_t *out = walks_out + r * L1;
     // the path lives in registers (lane t holds vertices t and 64 + t) and is stored as
     // whole rows at the end; walks longer than 128 vertices fall back to direct stores
@@ -1222,6 +1234,9 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
                           : (const void *)n2v::walk_exact_unit_kernel<false>;
   const int64_t cap = n2v::resident_blocks(fn, n2v::kWavesPerBlock * 64, 0);
   if (blocks > cap) blocks = cap;
+  // status[1] is the kernel's walker counter: start it at zero on the same stream
+  if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
+    return N2V_ELAUNCH;
   if (dyadic)
     hipLaunchKernelGGL(n2v::walk_exact_unit_kernel<true>, dim3((unsigned)blocks),
                        dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, *g, start_ids,
