@@ -448,13 +448,22 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
   // walkers are taken from a shared counter (status[1], zero at launch), not by a fixed
   // stride: their costs differ widely and no wave should sit on a long queue while others idle
   // (n2v_walk_unit.hip); results are addressed by walker row
-  const bool dynamic = total < 0xffffffffll;
+  // (short walks are fetched eight at a time: fewer atomics on the one counter)
+  const bool dynamic = total < 0xfffffff0ll;
+  const uint32_t grab = walk_length >= 16 ? 1u : 8u;
   int64_t rr = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block;
+  uint32_t left = 0;
   for (;;) {
     if (dynamic) {
-      uint32_t t = 0;
-      if (lane == 0) t = atomicAdd(&status[1], 1u);
-      rr = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+      if (left == 0) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&status[1], grab);
+        rr = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        left = grab;
+      } else {
+        ++rr;
+      }
+      --left;
     }
     if (rr >= total) break;
     const int64_t r = readfirstlane_i64(rr);
