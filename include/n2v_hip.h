@@ -144,7 +144,9 @@ int n2v_trim_mark(const int64_t *rowptr, int64_t n_rows, int64_t max_out_degree,
  *   sample_int  [n_vocab] uint32 keep-thresholds of frequent-word subsampling,
  *               or NULL when `sample` == 0
  *   exp_table   [1000] fp32 sigmoid table over [-6, 6) (word2vec EXP_TABLE)
- *   pairs_out   device counter, += number of (centre, context) pairs trained
+ *   pairs_out   TWO device uint64 (or NULL): [0] += number of (centre, context) pairs
+ *               trained; [1] scratch, the kernel hands out rows through it (reset by the
+ *               library on the stream before the launch)
  *
  * One wave trains one walk (sentence); walks are spread over the grid hogwild
  * (unsynchronised updates, as gensim's worker threads).  deterministic != 0 runs

@@ -166,9 +166,21 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (VEC <= 2 ? 8 : 1)) void sgns_kern
   const int64_t n_waves = (int64_t)gridDim.x * waves_per_block;
   unsigned long long pairs = 0;
 
-  for (int64_t rr = (int64_t)blockIdx.x * waves_per_block + wave_in_block; rr < n_walks;
-       rr += n_waves) {
+  // rows are taken from a shared counter (pairs_out[1], reset by the launcher) rather than by a
+  // fixed stride: a few per cent of tail at dim 128-256; a single wave (deterministic mode)
+  // still sees them in order
+  const bool dynamic = pairs_out != nullptr && n_walks < 0xfffffff0ll;
+  unsigned int *row_counter = reinterpret_cast<unsigned int *>(pairs_out + 1);
+  int64_t rr = (int64_t)blockIdx.x * waves_per_block + wave_in_block;
+  for (;;) {
+    if (dynamic) {
+      unsigned int t = 0;
+      if (lane == 0) t = atomicAdd(row_counter, 1u);
+      rr = (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+    }
+    if (rr >= n_walks) break;
     const int64_t r = readfirstlane_i64(rr);
+    if (!dynamic) rr += n_waves;
     const uint64_t hs = sentence_stream(P.seed, (uint64_t)(P.sentence_base + r));
     // ---- sentence preparation (lane-parallel, order-preserving compaction) ----
     int nf = 0;
@@ -427,6 +439,9 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   int V = 1;
   while (64 * V < P->dim) V *= 2;
   hipStream_t st = (hipStream_t)stream;
+  // pairs_out[1] is the kernel's row counter: start it at zero on the same stream
+  if (pairs_out && hipMemsetAsync(pairs_out + 1, 0, sizeof(unsigned long long), st) != hipSuccess)
+    return N2V_ELAUNCH;
   // lookahead depth: 1 pair for dim <= 512, none above (registers).  Depth 2 was measured
   // twice at dim 128 and lost both times (628 vs 674 M pairs/s at equal occupancy).
 #define N2V_LAUNCH(VV)                                                                       \

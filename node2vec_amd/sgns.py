@@ -124,7 +124,9 @@ class SgnsModel:
         if self.sample_int is not None:
             self.sample_int = self.sample_int.to(device)
         self.exp_table = torch.from_numpy(exp_table()).to(device)
-        self.pairs = torch.zeros(1, dtype=torch.int64, device=device)
+        # include/n2v_hip.h: pairs_out is two uint64, [0] the pair counter, [1] kernel scratch
+        self._counters = torch.zeros(2, dtype=torch.int64, device=device)
+        self.pairs = self._counters[:1]
         self.sentences_seen = 0
 
     # -- one kernel launch ----------------------------------------------------
