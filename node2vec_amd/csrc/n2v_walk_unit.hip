@@ -1110,6 +1110,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_UNIT_WAVES) void walk_exac
     if (rr >= total) break;
     const int64_t r = readfirstlane_i64(rr);
     if (!dynamic) rr += n_waves;
+#ifdef N2V_STATS
+    const unsigned long long t_walker0 = __builtin_readcyclecounter();
+#endif
     int32_t *out = walks_out + r * L1;
     // the path lives in registers (lane t holds vertices t and 64 + t) and is stored as
     // whole rows at the end; walks longer than 128 vertices fall back to direct stores
@@ -1198,6 +1201,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_UNIT_WAVES) void walk_exac
       if (64 + lane < L1) out[64 + lane] = path1;
     }
     if (lane == 0) valid_out[r] = alive ? 1 : 0;
+#ifdef N2V_STATS
+    {  // slowest walker and when the wave took it (tail diagnostics)
+      const unsigned long long tw = __builtin_readcyclecounter() - t_walker0;
+      if (lane == 0) atomicMax(&n2v_stats[30], tw);
+      WS.v[31] += tw;
+    }
+#endif
   }
 #ifdef N2V_STATS
   WS.v[23] = __builtin_readcyclecounter() - t_kernel0;

@@ -32,3 +32,4 @@ for p, q in (PQ,):
     tot_draw = sum(b[25:30])
     print("  draw cycles by deg(v) bucket [<=64, <=1024, <=4096, <=8192, >8192]:", [f"{100*x/tot_draw:.1f}%" for x in b[25:30]],
           " steps 4096<n<=8192:", b[14], " n>8192:", b[15])
+    print("  walkers: mean wave-cycles", round(b[31] / (walks.shape[0])), " slowest", b[30], " kernel wave-cycles per wave", round(tot / 8192))
