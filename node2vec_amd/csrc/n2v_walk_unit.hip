@@ -567,15 +567,18 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
     sum = rep_add(sum, K.bO, pending);
     avg = sum / (double)n;
   }
-  // uniform values: scalar registers, so they cost no VGPRs across the pairing code
-  const double vR = readfirstlane_f64(K.bR / avg), vM = readfirstlane_f64(K.bM / avg),
-               vO = readfirstlane_f64(K.bO / avg);
+  // probs0 of slot `pick` first: one fp64 division decides most steps (an underfull slot that is
+  // accepted never changes); the other two class values are only needed past this exit
   uint64_t prm, pmm;
   chunk_classes(c, L, pick >> 6, lane, sp_n, prm, pmm);
   const bool pR = (prm >> (pick & 63)) & 1ull, pM = (pmm >> (pick & 63)) & 1ull;
-  const double p_pick = pR ? vR : (pM ? vM : vO);
+  const double p_pick = readfirstlane_f64(pick3(pR, pM, K.bR, K.bM, K.bO) / avg);
   N2V_T(19);
   if (p_pick < 1.0 && r2 < p_pick) return pick;  // untouched underfull slot
+  // uniform values: scalar registers, so they cost no VGPRs across the pairing code
+  const double vR = pR ? p_pick : readfirstlane_f64(K.bR / avg);
+  const double vM = (pM && !pR) ? p_pick : readfirstlane_f64(K.bM / avg);
+  const double vO = (!pR && !pM) ? p_pick : readfirstlane_f64(K.bO / avg);
   const bool uR = vR < 1.0, uM = vM < 1.0, uO = vO < 1.0;
   const bool any_under = (nR && uR) || (nM && uM) || (nO && uO);
   const bool any_over = (nR && !uR) || (nM && !uM) || (nO && !uO);
