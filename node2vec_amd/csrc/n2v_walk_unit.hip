@@ -12,13 +12,16 @@
 //     p, q it is added in the reference's order, one closed-form step per run of equal
 //     addends (rep_add below, kernel instance <false>);
 //   * the LDS cache is the two class ballots per 64-neighbour chunk, w is never read;
-//   * probs0 has three values (3 fp64 divisions per step), so the underfull /
-//     overfull candidate masks of the pairing (:175-189) are scalar AND/OR of the
-//     ballots, and a candidate's value is two bit tests;
+//   * probs0 has three values (one fp64 division decides most steps, three at most), so
+//     the underfull / overfull stacks of the pairing (:175-189) are sequences of RUNS of
+//     equal values: an over absorbs a run in a tight loop, a demoted residual cascades
+//     through a run in closed form, a single-class stack is consumed by rank alone
+//     (see "pairing, run engine" in unit_draw);
 //   * a uniform row (first step, or p == q == 1) has probs0 == 1.0 everywhere, no
 //     underfull slot, and the draw is `pick` itself: O(1).
-// Membership "x in N(s)" (:226) uses the LDS hashed-id filter + batched exact
-// verification of the hits, as in the generic kernel.
+// Membership "x in N(s)" (:226) picks one of five strategies by the two row lengths
+// (reverse / staged / filter / merge / direct, see unit_draw).  One wave64 per walker;
+// waves take walkers from a shared counter (status[1]), because walks differ widely in cost.
 #include "n2v_alias_core.h"
 
 namespace n2v {
