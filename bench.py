@@ -1,20 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- node2vec hot path on MI355X: walk-steps/s (+ embedding-updates/s).
+"""bench.py -- node2vec hot path on MI355X: walk-steps/s + embedding-updates/s.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg4|cfg3|cfg2]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1], "cfg 2"): R-MAT scale 20, 5 M draws symmetrised
-(~9.7 M directed edges, ~472 k non-isolated vertices), p=0.5 q=2, 10 walks per
-vertex, walk_length 80.  One "step" = one launch of the walk kernel over one batch
-of start vertices (inputs resident in HBM).  With N GPUs the graph is replicated and
-start vertices are sharded by range: rank r walks batch (k*N + r); no collective is
-on the data path ("weak" scaling: per-GPU work per step is fixed).
+Default workload = the configuration BASELINE.json's metric is quoted on ("100M-node
+synthetic", BASELINE.md section 4 row 4, "cfg 4"): Chung-Lu power-law graph, gamma = 2.1,
+10^8 vertices, 5 x 10^8 undirected draws symmetrised and de-duplicated (~0.9 x 10^9
+directed edges), out-degree trimmed at 10 000 (trim_hotspot_vertices), 10 walks per
+vertex, walk_length 80, p = q = 1, seed 42.  It fits one GPU (graph 4 GB + model 102 GB).
 
-Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline      algorithmic HBM bytes of the walk kernel / its HIP-event duration
-  cpu_baseline  the CPU oracle (OpenMP, all host cores) on a bounded sample
-  sgns          the same measurement for the SGNS kernel (embedding-updates/s)
+One "step" = one launch of the walk kernel over one batch of start vertices, inputs
+resident in HBM.  With N GPUs the graph is replicated and start vertices are sharded by
+range: rank r walks batch k * N + r; no collective is on the walk path ("weak" scaling:
+per-GPU work per step is fixed).
+
+ONE JSON line on rank 0.  Beside the contract's keys:
+  roofline      the headline walk kernel: bytes / HIP-event duration against 8 TB/s
+  biased        the same graph walked exactly at p = 0.5, q = 2 (at p = q = 1 a step is two
+                gathers; the second-order bias is where the sampler works)
+  fast_mode     rejection sampler at p = 0.5, q = 2 (same distribution, not the same draws)
+  sgns          K launches of the SGNS kernel on a 10^8 x 128 model (embedding-updates/s)
+  cpu_baseline  the CPU oracle (a port of the reference's algorithm) on this box's cores:
+                walks single-thread and all-core, SGNS single-thread and all-core
+  setup         one-off costs (graph build, trim, tables)
 """
 import argparse
 import json
@@ -26,6 +35,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+FP32_PEAK = 157.3e12
+
+CONFIGS = {
+    "cfg4": dict(gen="chung_lu", n=100_000_000, draws=500_000_000, trim=10_000, p=1.0, q=1.0,
+                 batch=1 << 20, biased_batch=1 << 17, sgns_vertices=1 << 16, dim=128,
+                 label="cfg4 Chung-Lu power-law gamma=2.1, 100M vertices / 5e8 undirected draws "
+                       "symmetrised, out-degree trimmed at 10000"),
+    "cfg3": dict(gen="chung_lu", n=10_000_000, draws=100_000_000, trim=10_000, p=1.0, q=1.0,
+                 batch=1 << 20, biased_batch=1 << 17, sgns_vertices=1 << 16, dim=128,
+                 label="cfg3 Chung-Lu power-law gamma=2.1, 10M vertices / 1e8 undirected draws "
+                       "symmetrised, out-degree trimmed at 10000"),
+    "cfg2": dict(gen="rmat", scale=20, draws=5_000_000, trim=0, p=0.5, q=2.0,
+                 batch=47_104, biased_batch=47_104, sgns_vertices=47_104, dim=128,
+                 label="cfg2 R-MAT scale 20, 5e6 draws symmetrised"),
+}
+BIASED_PQ = (0.5, 2.0)
 
 
 def parse():
@@ -33,31 +58,111 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
-    ap.add_argument("--scale", type=int, default=20)
-    ap.add_argument("--draws", type=int, default=5_000_000)
-    ap.add_argument("--batch", type=int, default=47_104, help="start vertices per step per GPU")
+    ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
     ap.add_argument("--num-walks", type=int, default=10)
     ap.add_argument("--walk-length", type=int, default=80)
-    ap.add_argument("--p", type=float, default=0.5)
-    ap.add_argument("--q", type=float, default=2.0)
-    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=0, help="start vertices per step per GPU (0 = config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sgns", action="store_true")
     ap.add_argument("--no-fast", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-biased", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU time budget per baseline leg")
     return ap.parse_args()
 
 
-def algorithmic_bytes_exact(torch, g, walks, valid):
-    """SURVEY.md 8(d), exact mode, summed over the emitted walks:
-    B = 16 (rowptr v) + 8*deg(v) (col+w) + [s>=0: 16 (rowptr s) + 4*deg(s)] + 4 (path write)."""
+def build_graph(cfg, torch, dev, setup):
+    from node2vec_amd import synthetic
+
+    t0 = time.perf_counter()
+    if cfg["gen"] == "rmat":
+        g = synthetic.rmat(cfg["scale"], cfg["draws"], seed=42, device=dev)
+    else:
+        g = synthetic.chung_lu(cfg["n"], cfg["draws"], seed=42, device=dev)
+    torch.cuda.synchronize()
+    setup["graph_generate_s"] = time.perf_counter() - t0
+    setup["edges_before_trim"] = g.n_edges
+    if cfg["trim"]:
+        t0 = time.perf_counter()
+        g = g.trimmed(cfg["trim"], 42)  # trim_hotspot_vertices, randomwalk.py:238-262
+        torch.cuda.synchronize()
+        setup["trim_s"] = time.perf_counter() - t0
+    torch.cuda.empty_cache()
+    return g
+
+
+def reference_algorithmic_bytes(torch, g, walks, valid, rows=65536):
+    """SURVEY.md 8(d), exact mode, per walk-step (estimated on the first `rows` walks of the
+    launch): B = 16 (rowptr v) + 8*deg(v) (col + w) + [s >= 0: 16 (rowptr s) + 4*deg(s)] + 4
+    (path write) -- the bytes the REFERENCE's algorithm touches (it rebuilds the table of the
+    whole row at every step); the kernels here move far fewer, see roofline.traffic."""
     deg = g.degrees()
-    w = walks[valid].long()
-    d = deg[w[:, :-1]]                      # degree of the current vertex at every step
-    total = (16 + 8 * d + 4).sum()
-    total = total + (16 + 4 * d[:, :-1]).sum()  # previous vertex, steps >= 1
-    return int(total)
+    w = walks[:rows][valid[:rows].bool()].long()
+    if w.numel() == 0:
+        return None
+    d = deg[w[:, :-1]]
+    total = (16 + 8 * d + 4).sum() + (16 + 4 * d[:, :-1]).sum()
+    return float(total) / float(d.numel())
+
+
+class WalkLeg:
+    """K timed launches of n2v_walk over batches of start vertices."""
+
+    def __init__(self, torch, rw, g, start_all, W, L, p, q, mode, batch, rank, world):
+        self.torch, self.rw, self.g, self.start_all = torch, rw, g, start_all
+        self.W, self.L, self.p, self.q, self.mode = W, L, p, q, mode
+        self.batch = int(min(batch, start_all.numel()))
+        self.rank, self.world = rank, world
+        self.n_batches = max(1, start_all.numel() // self.batch)
+        dev = g.device
+        self.walks = torch.empty((self.batch * W, L + 1), dtype=torch.int32, device=dev)
+        self.valid = torch.empty(self.batch * W, dtype=torch.uint8, device=dev)
+        self.stats = {}
+
+    def starts(self, k):
+        i = (k * self.world + self.rank) % self.n_batches
+        return self.start_all[i * self.batch:(i + 1) * self.batch]
+
+    def step(self, k):
+        self.rw.walk(self.g, self.starts(k), self.W, self.L, self.p, self.q, 42, mode=self.mode,
+                     out=(self.walks, self.valid), check=False, stats=self.stats)
+
+    def run(self, steps, warmup, barrier):
+        torch = self.torch
+        for k in range(warmup):
+            self.step(k)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(steps)]
+        # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides ----
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record()  # torch's current stream IS the launch stream (randomwalk.walk)
+            self.step(warmup + k)
+            ev[k][1].record()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = [a.elapsed_time(b) for a, b in ev]
+        # unit counts, outside the timed region: the same K batches walked again
+        steps_done, trials = 0, 0
+        for k in range(steps):
+            self.step(warmup + k)
+            torch.cuda.synchronize()
+            steps_done += int(self.valid.sum()) * self.L
+            if self.mode == "fast":
+                trials += int(self.stats["trials"].item())
+        return {"elapsed": elapsed, "steps_done": steps_done, "trials": trials,
+                "kernel_s": 1e-3 * sum(kernel_ms) / steps}
+
+
+def reduce_job(torch, dist, use_dist, dev, elapsed, units):
+    """max-over-ranks time, sum-over-ranks units"""
+    if not use_dist:
+        return elapsed, float(units)
+    t = torch.tensor([elapsed, float(units)], dtype=torch.float64, device=dev)
+    tm, ts = t.clone(), t.clone()
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+    return float(tm[0]), float(ts[1])
 
 
 def main():
@@ -86,187 +191,193 @@ def main():
         torch.cuda.synchronize()
 
     from node2vec_amd import randomwalk as rw
-    from node2vec_amd import synthetic
 
-    g = synthetic.rmat(args.scale, args.draws, seed=42, device=dev)
-    if args.mode == "fast":
-        g.build_alias()
-    start_all = rw.start_vertices(g)
-    n_batches = max(1, start_all.numel() // args.batch)
+    cfg = CONFIGS[args.config]
     W, L = args.num_walks, args.walk_length
+    setup = {}
+    g = build_graph(cfg, torch, dev, setup)
+    start_all = rw.start_vertices(g)
+    batch = args.batch or cfg["batch"]
 
-    def batch(i):
-        i = i % n_batches
-        return start_all[i * args.batch:(i + 1) * args.batch].contiguous()
-
-    walks = torch.empty((args.batch * W, L + 1), dtype=torch.int32, device=dev)
-    valid = torch.empty(args.batch * W, dtype=torch.uint8, device=dev)
-
-    def step(k):
-        rw.walk(g, batch(k * world + rank), W, L, args.p, args.q, 42, mode=args.mode,
-                out=(walks, valid), check=False)
-
-    for k in range(args.warmup):
-        step(k)
-    # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides ----
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
-    steps_done = 0
-    abytes = 0
-    barrier()
+    # ---- headline: exact walks at the config's p, q --------------------------------------
+    p, q = cfg["p"], cfg["q"]
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        step(args.warmup + k)
-        ev[k][1].record()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]  # events on the launch stream
-    # unit counts (outside the timed region): re-derive from the last launch and
-    # from a recount of every timed batch's valid walks
-    for k in range(args.steps):
-        step(args.warmup + k)
-        torch.cuda.synchronize()
-        v = valid.bool()
-        steps_done += int(v.sum()) * L
-        if args.mode == "exact":
-            abytes += algorithmic_bytes_exact(torch, g, walks, v)
-    t = torch.tensor([elapsed, float(steps_done), float(abytes), sum(kernel_ms)],
-                     dtype=torch.float64, device=dev)
-    if use_dist:
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed, steps_total = float(tmax[0]), float(tsum[1])
-    else:
-        steps_total = float(steps_done)
+    rw.walk(g, start_all[:64], W, 4, p, q, 42, mode="exact")  # tables built on first use
+    torch.cuda.synchronize()
+    setup["exact_tables_first_use_s"] = time.perf_counter() - t0
+    leg = WalkLeg(torch, rw, g, start_all, W, L, p, q, "exact", batch, rank, world)
+    res = leg.run(args.steps, args.warmup, barrier)
+    elapsed, steps_total = reduce_job(torch, dist, use_dist, dev, res["elapsed"], res["steps_done"])
     value = steps_total / elapsed
-
+    head_kernel = kernel_name(g, p, q)
+    ref_bytes = reference_algorithmic_bytes(torch, g, leg.walks, leg.valid)
+    workload = (f"{cfg['label']}: {g.n_vertices} vertices, {g.n_edges} directed edges, "
+                f"{int(start_all.numel())} start vertices; p={p} q={q}, {W} walks x length {L}, "
+                f"{leg.batch} start vertices per step per GPU, seed 42")
     out = {
         "metric": "walk-steps/sec + embedding-updates/sec on 100M-node synthetic; 1/2/4/8 GPU",
         "value": value, "unit": "walk-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"cfg2 RMAT scale {args.scale} / {g.n_edges} directed edges, "
-                               f"p={args.p} q={args.q}, {W} walks x length {L}, "
-                               f"{args.batch} start vertices per step per GPU",
-                   "walk_mode": args.mode, "n_vertices": g.n_vertices, "n_edges": g.n_edges,
-                   "start_vertices": int(start_all.numel()), "parallelism": f"range-shard x{world}"},
+        "config": {"workload": workload, "walk_mode": "exact", "n_vertices": g.n_vertices,
+                   "n_edges": g.n_edges, "start_vertices": int(start_all.numel()),
+                   "parallelism": f"graph replicated, start vertices range-sharded x{world}"},
     }
     if rank == 0:
-        avg_kernel_s = 1e-3 * sum(kernel_ms) / args.steps
-        per_launch_bytes = abytes / args.steps if abytes else None
-        if per_launch_bytes:
-            ach = per_launch_bytes / avg_kernel_s
-            out["roofline"] = {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
-                               "unit": "GB/s", "frac": ach / HBM_PEAK,
-                               "traffic": _pmc_traffic(),
-                               "kernel": "walk_exact_unit_kernel" if g.unit_weights else "walk_exact_kernel",
-                               "kernel_ms": 1e3 * avg_kernel_s,
-                               "algorithmic_bytes_per_launch": per_launch_bytes,
-                               "algorithmic_bytes_per_walk_step": abytes / max(steps_done, 1)}
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args, g, start_all, W, L)
-    if args.mode == "exact" and not args.no_fast:
-        fm = bench_fast(args, torch, dist, g, rw, batch, walks, valid, rank, world, barrier, use_dist)
+        out["roofline"] = roofline(head_kernel, res, leg, args.config, p, q, "exact", ref_bytes)
+    del leg
+    torch.cuda.empty_cache()
+
+    # ---- the second-order bias on the same graph: exact and rejection sampling -------------
+    bp, bq = BIASED_PQ
+    if not args.no_biased and (bp, bq) != (p, q):
+        t0 = time.perf_counter()
+        rw.walk(g, start_all[:64], W, 4, bp, bq, 42, mode="exact")  # edge classes, first use
+        torch.cuda.synchronize()
+        setup["edge_classes_build_s"] = time.perf_counter() - t0
+        leg = WalkLeg(torch, rw, g, start_all, W, L, bp, bq, "exact", cfg["biased_batch"], rank, world)
+        r2 = leg.run(args.steps, args.warmup, barrier)
+        e2, s2 = reduce_job(torch, dist, use_dist, dev, r2["elapsed"], r2["steps_done"])
         if rank == 0:
-            out["fast_mode"] = fm
+            rb = reference_algorithmic_bytes(torch, g, leg.walks, leg.valid)
+            out["biased"] = {"value": s2 / e2, "unit": "walk-steps/s", "walk_mode": "exact",
+                             "p": bp, "q": bq, "ms_per_step": 1e3 * e2 / args.steps,
+                             "start_vertices_per_step": leg.batch,
+                             "parity": "bit-identical to the per-step alias rebuild of the reference",
+                             "roofline": roofline(kernel_name(g, bp, bq), r2, leg, args.config, bp,
+                                                  bq, "exact", rb)}
+        del leg
+        torch.cuda.empty_cache()
+    if not args.no_fast:
+        t0 = time.perf_counter()
+        rw.walk(g, start_all[:64], W, 4, bp, bq, 42, mode="fast")  # K1 tables, first use
+        torch.cuda.synchronize()
+        setup["alias_tables_build_s"] = time.perf_counter() - t0
+        leg = WalkLeg(torch, rw, g, start_all, W, L, bp, bq, "fast", batch, rank, world)
+        r3 = leg.run(args.steps, args.warmup, barrier)
+        e3, s3 = reduce_job(torch, dist, use_dist, dev, r3["elapsed"], r3["steps_done"])
+        if rank == 0:
+            out["fast_mode"] = {"value": s3 / e3, "unit": "walk-steps/s", "walk_mode": "fast",
+                                "p": bp, "q": bq, "ms_per_step": 1e3 * e3 / args.steps,
+                                "start_vertices_per_step": leg.batch,
+                                "parity": "same transition distribution (chi-square tested), "
+                                          "not the same draws",
+                                "trials_per_step": r3["trials"] / max(r3["steps_done"], 1),
+                                "roofline": roofline("walk_fast_kernel", r3, leg, args.config, bp,
+                                                     bq, "fast", None)}
+        del leg
+        g.slots = None
+        g.pivots = None
+        torch.cuda.empty_cache()
+
+    # ---- SGNS on the config's model ------------------------------------------------------------
+    sg_walks = None
+    if not args.no_sgns or (not args.no_cpu_baseline and world == 1):
+        nv = min(cfg["sgns_vertices"], int(start_all.numel()))
+        lo = (rank * nv) % max(1, int(start_all.numel()) - nv + 1)
+        sw, sv = rw.walk(g, start_all[lo:lo + nv], W, L, p, q, 42, mode="exact")
+        sg_walks = sw[sv]
+        del sw, sv
+    model = None
     if not args.no_sgns:
-        sg = bench_sgns(args, torch, dist, g, walks, valid, rank, world, barrier, use_dist)
+        sg, model = bench_sgns(args, cfg, torch, dist, g, sg_walks, rank, world, barrier, use_dist)
         if rank == 0:
             out["sgns"] = sg
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args, cfg, torch, g, start_all, W, L, p, q, sg_walks,
+                                           model)
     if rank == 0:
+        setup["hbm_peak_allocated_GB"] = torch.cuda.max_memory_allocated() / 1e9
+        out["setup"] = setup
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def bench_fast(args, torch, dist, g, rw, batch, walks, valid, rank, world, barrier, use_dist=False):
-    """Secondary figure: the same K steps with the rejection sampler (N2V_WALK_FAST,
-    same transition distribution, not the same draws).  Algorithmic bytes per accepted
-    step: 16 + T*(16 + [s>=0: 16 + 4*ceil(log2(deg(s)+1))]) + 4."""
-    import math
-    import time as _t
+def kernel_name(g, p, q):
+    """the kernel n2v_walk dispatches exact mode to (node2vec_amd/csrc/n2v_capi.hip)"""
+    from node2vec_amd.randomwalk import _dyadic
 
-    W, L = args.num_walks, args.walk_length
-    if g.slots is None:
-        g.build_alias()
-    stats = {}
+    if g.unit_weights:
+        if (p == 1.0 and q == 1.0) or (_dyadic(p) and _dyadic(q) and g.edge_classes is not None):
+            return "walk_exact_unit_lanes_kernel"
+        return "walk_exact_unit_kernel"
+    return "walk_fast_kernel" if (p == 1.0 and q == 1.0) else "walk_exact_kernel"
 
-    def step(k):
-        rw.walk(g, batch(k * world + rank), W, L, args.p, args.q, 42, mode="fast",
-                out=(walks, valid), check=False, stats=stats)
 
-    for k in range(args.warmup):
-        step(k)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
-    trials = 0
-    barrier()
-    t0 = _t.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        step(args.warmup + k)
-        ev[k][1].record()
-    barrier()
-    elapsed = _t.perf_counter() - t0
-    steps_done, abytes = 0, 0.0
-    deg = g.degrees()
-    for k in range(args.steps):  # recount outside the timed region
-        step(args.warmup + k)
-        torch.cuda.synchronize()
-        v = valid.bool()
-        n_steps = int(v.sum()) * L
-        steps_done += n_steps
-        tr = int(stats["trials"].item())
-        trials += tr
-        ds = deg[walks[v][:, :-2].long()].double()
-        per_trial = 16.0 + (16.0 + 4.0 * torch.ceil(torch.log2(ds + 1.0))).mean().item() * (L - 1) / L
-        abytes += 20.0 * n_steps + tr * per_trial
-    t = torch.tensor([elapsed, float(steps_done)], dtype=torch.float64, device=walks.device)
-    if use_dist:
-        tm, ts = t.clone(), t.clone()
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
-        elapsed, total = float(tm[0]), float(ts[1])
+def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
+    """HBM roofline of one walk kernel.
+
+    `traffic` = bytes per launch past L2 from the committed rocprofv3 --pmc passes of THIS
+    workload (profiles/pmc_traffic.json, FETCH_SIZE + WRITE_SIZE corrected as
+    MI355X_MICROARCH.md "HBM" prescribes), or null.  `achieved` = those bytes / the kernel's
+    HIP-event duration when they exist -- the bytes the kernel really moves, so frac <= 1 by
+    construction; without a profile, the kernel's own algorithmic bytes (what its algorithm
+    must touch at byte granularity, formula in `algorithmic_formula`).  The reference
+    algorithm's bytes are reported beside it, never as the roofline."""
+    per_launch_steps = leg.batch * leg.W * leg.L
+    if mode == "fast":
+        t = res["trials"] / max(res["steps_done"], 1)
+        alg = 16 + t * 16 + 4  # rowptr pair, one 16-B slot per trial, path write (+ searches)
+        formula = "16 (rowptr pair) + trials * 16 (slot) + 4 (path); membership searches extra"
+    elif p == 1.0 and q == 1.0:
+        alg = 16 + 4 + 4
+        formula = "16 (rowptr pair of v) + 4 (col[pick]) + 4 (path write) per step"
     else:
-        total = float(steps_done)
-    kernel_s = 1e-3 * sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    ach = abytes / args.steps / kernel_s
-    del math
-    return {"value": total / elapsed, "unit": "walk-steps/s", "walk_mode": "fast",
-            "parity": "same transition distribution (chi-square tested), not the same draws",
-            "trials_per_step": trials / max(steps_done, 1),
-            "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK, "traffic": _pmc_traffic("fast_pmc_traffic.json"),
-                         "kernel": "walk_fast_kernel",
-                         "kernel_ms": 1e3 * kernel_s,
-                         "algorithmic_bytes_per_walk_step": abytes / max(steps_done, 1)}}
+        alg = 16 + 4 + 4 + 4
+        formula = ("16 (rowptr pair) + 4 (edge class word) + 4 (col[pick]) + 4 (path write) per "
+                   "step, + 4 per probe of the membership search; steps that run the pairing "
+                   "read both rows")
+    traffic = pmc_traffic(config, kernel, p, q, leg.batch)
+    alg_launch = alg * per_launch_steps
+    used = traffic if traffic else alg_launch
+    ach = used / res["kernel_s"]
+    r = {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+         "frac": ach / HBM_PEAK, "traffic": traffic, "kernel": kernel,
+         "kernel_ms": 1e3 * res["kernel_s"],
+         "achieved_from": "pmc traffic" if traffic else "kernel algorithmic bytes (no pmc profile of this workload)",
+         "algorithmic_bytes_per_launch": alg_launch, "algorithmic_bytes_per_walk_step": alg,
+         "algorithmic_formula": formula,
+         "binding_resource": "dependent random gathers (latency / sectors per step), not streamed bytes"}
+    if ref_bytes:
+        r["reference_algorithmic_bytes_per_walk_step"] = ref_bytes
+        r["reference_algorithmic_GBps_equivalent"] = ref_bytes * per_launch_steps / res["kernel_s"] / 1e9
+    return r
 
 
-def bench_sgns(args, torch, dist, g, walks, valid, rank, world, barrier, use_dist=False):
-    """Second timed loop: K steps of the SGNS kernel (embedding-updates/s).  One step =
-    one launch over the block of walks of one walk step (batch x W rows of L+1 tokens),
-    vocabulary = every vertex (min_count=0, sample=0: deterministic unit counts), dim
-    args.dim, window 5, k=5.  Unit: one positive (centre, context) pair with its k
-    negative targets.  With N GPUs every rank trains its own walks on a full replica;
-    the delta all-reduce is reported separately (it is per sync, not per step)."""
-    import time as _t
+def pmc_traffic(config, kernel, p, q, batch):
+    """bytes per launch from profiles/pmc_traffic.json for exactly this workload, else None"""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    key = f"{config}:{kernel}:p{p}:q{q}:batch{batch}"
+    ent = table.get(key)
+    return float(ent["hbm_bytes_per_launch"]) if ent else None
 
+
+def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist):
+    """K launches of the SGNS kernel (embedding-updates/s).  One step = one launch over the
+    walks of `sgns_vertices` start vertices (x W rows of L+1 tokens), vocabulary = every
+    vertex (min_count=0, sample=0: deterministic unit counts; index order = descending
+    degree), dim from the config, window 5, k=5.  Unit: one positive (centre, context) pair
+    with its k negative targets.  With N GPUs every rank trains its own walks on a full
+    replica; the exchange step (bf16 delta all-reduce, sgns.DeltaSync) is timed beside it."""
     from node2vec_amd import sgns
 
     dev = walks.device
+    dim = cfg["dim"]
     deg = g.degrees().clamp(min=1)
     order = torch.sort(deg, descending=True, stable=True).indices
     index_of = torch.empty(g.n_vertices, dtype=torch.int32, device=dev)
     index_of[order] = torch.arange(g.n_vertices, dtype=torch.int32, device=dev)
     vocab = sgns.Vocab(order, deg[order], index_of)
-    model = sgns.SgnsModel(vocab, args.dim, 5, 5, seed=1, sample=0.0, device=dev)
-    idx = index_of[walks[valid.bool()].long()].contiguous()
+    del deg
+    model = sgns.SgnsModel(vocab, dim, 5, 5, seed=1, sample=0.0, device=dev)
+    idx = index_of[walks.long()].contiguous()
     rows = idx.shape[0]
     for k in range(args.warmup):
         model.train_block(idx, 0.025, k * rows)
@@ -274,84 +385,172 @@ def bench_sgns(args, torch, dist, g, walks, valid, rank, world, barrier, use_dis
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
     barrier()
-    t0 = _t.perf_counter()
+    t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
         model.train_block(idx, 0.025, (args.warmup + k + rank * 1000) * rows)
         ev[k][1].record()
     barrier()
-    elapsed = _t.perf_counter() - t0
+    elapsed = time.perf_counter() - t0
     pairs = float(model.pairs.item())
-    t = torch.tensor([elapsed, pairs], dtype=torch.float64, device=dev)
-    if use_dist:
-        tm = t.clone()
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        ts = t.clone()
-        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
-        elapsed, pairs_total = float(tm[0]), float(ts[1])
-    else:
-        pairs_total = pairs
+    elapsed, pairs_total = reduce_job(torch, dist, use_dist, dev, elapsed, pairs)
     kernel_s = 1e-3 * sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    bytes_per_pair = 8 * args.dim * (2 + 5)            # 2*4*D*(2+k)
-    flops_per_pair = (1 + 5) * 6 * args.dim + args.dim  # (1+k)*6D + D
+    bytes_per_pair = 8 * dim * (2 + 5)            # 2*4*D*(2+k)
+    flops_per_pair = (1 + 5) * 6 * dim + dim      # (1+k)*6D + D
     ach = pairs / args.steps * bytes_per_pair / kernel_s
+    traffic = pmc_traffic(args.config, "sgns_kernel", 0, 0, rows)
     res = {"value": pairs_total / elapsed, "unit": "embedding-updates/s (pairs incl. k=5 negatives)",
            "row_updates_per_s": pairs_total / elapsed * 6, "ms_per_step": 1e3 * elapsed / args.steps,
-           "dtype": "f32", "config": {"dim": args.dim, "window": 5, "negative": 5,
-                                      "rows_per_step": rows, "n_vocab": g.n_vertices,
-                                      "sample": 0, "min_count": 0},
+           "dtype": "f32", "config": {"dim": dim, "window": 5, "negative": 5, "rows_per_step": rows,
+                                      "n_vocab": g.n_vertices, "sample": 0, "min_count": 0,
+                                      "model_bytes": 2 * g.n_vertices * dim * 4},
            "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
-                        "unit": "GB/s", "frac": ach / HBM_PEAK,
-                        "traffic": _pmc_traffic("sgns_pmc_traffic.json") if args.dim == 128 else None,
+                        "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic,
                         "kernel": "sgns_kernel", "kernel_ms": 1e3 * kernel_s,
                         "algorithmic_bytes_per_pair": bytes_per_pair,
-                        "fma_utilisation": pairs / args.steps * flops_per_pair / kernel_s / 157.3e12}}
-    if use_dist:  # the exchange step: one delta all-reduce of both matrices
-        sync = sgns.DeltaAllReduce([model.syn0, model.syn1neg], block_rows=1 << 18)
+                        "fma_utilisation": pairs / args.steps * flops_per_pair / kernel_s / FP32_PEAK}}
+    if use_dist:  # the exchange step of the multi-GPU path, timed once (blocking, bf16 deltas)
+        sync = sgns.DeltaSync(model, wire="bf16")
         barrier()
-        t0 = _t.perf_counter()
-        sync()
+        t0 = time.perf_counter()
+        sync.sync(blocking=True)
         barrier()
-        res["delta_allreduce_s"] = _t.perf_counter() - t0
-        res["delta_allreduce_bytes"] = 2 * model.syn0.numel() * 4
-    return res
+        dt = time.perf_counter() - t0
+        step_s = 1e-3 * res["ms_per_step"]
+        every = max(1, -(-int(1e6 * dt * 0.9) // max(1, int(1e6 * 0.1 * step_s))))
+        res["exchange"] = {"world": dist.get_world_size(), "backend": "nccl (RCCL)",
+                           "delta_allreduce_s": dt, "wire_dtype": sync.wire_dtype_name,
+                           "wire_bytes_per_rank": sync.wire_bytes,
+                           "share_of_step_time_if_every_launch": dt / (dt + step_s),
+                           "sync_every_for_10pct": every,
+                           "share_at_that_period": dt / (dt + every * step_s)}
+        del sync
+    return res, model
 
 
-def _pmc_traffic(name="walk_pmc_traffic.json"):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/),
-    corrected as MI355X_MICROARCH.md prescribes; None until such a profile exists."""
-    path = os.path.join(ROOT, "profiles", name)
-    if os.path.exists(path):
-        with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
-    return None
+def host_cores():
+    """threads this process may really use: affinity mask, capped by a cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
 
 
-def cpu_baseline(args, g, start_all, W, L):
-    """The CPU oracle (a port of the reference's algorithm: per-step biased alias
-    rebuild + two-uniform draw) on the host cores, bounded sample of the same workload."""
+def cpu_baseline(args, cfg, torch, g, start_all, W, L, p, q, sg_walks, model):
+    """The CPU oracle -- a C port of the reference's algorithm (per-step biased alias rebuild
+    + two-uniform draw; per-pair SGNS) -- timed on this box's host cores on a bounded sample
+    of the same workload: single-thread and all cores (OpenMP over walkers; hogwild threads
+    over sentences, as gensim's workers)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+
     import n2v_oracle
 
-    cores = os.cpu_count() or 1
-    rowptr, col, w = g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.w.cpu().numpy()
+    cores = host_cores()
+    budget = args.cpu_seconds
+    rowptr, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
+    w = None if g.unit_weights else g.w.cpu().numpy()
     starts = start_all.cpu().numpy()
-    # calibrate on a small slice, then size the sample for ~cpu_seconds of work
-    n0 = 64
+    rng = np.random.default_rng(42)
+
+    def sample(n):
+        n = int(max(1, min(len(starts), n)))
+        return np.sort(rng.choice(starts, n, replace=False)).astype(np.int32)
+
+    def run(s, threads):
+        t0 = time.perf_counter()
+        _, valid = n2v_oracle.random_walk(rowptr, col, w, s, W, L, p, q, 42, n_threads=threads)
+        dt = time.perf_counter() - t0
+        return float(valid.sum()) * L / dt, dt
+
+    rate0, _ = run(sample(16), 1)                       # calibration
+    per_vertex = W * L / rate0
+    s1 = sample(0.4 * budget / per_vertex)
+    r1, dt1 = run(s1, 1)
+    per_vertex = W * L / r1
+    # all cores: at least 16 dynamic chunks (4 walkers each) per thread
+    sN = sample(max(cores * 8, 0.6 * budget * cores / per_vertex))
+    rN, dtN = run(sN, cores)
+    out = {"value": rN, "unit": "walk-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{len(sN)} start vertices (uniform sample, seed 42) x {W} walks x {L} steps "
+                     f"at p={p} q={q} on the bench graph, {dtN:.1f} s, oracle/n2v_oracle.c, "
+                     f"OpenMP {cores} threads (affinity mask / cgroup quota; os.cpu_count()="
+                     f"{os.cpu_count()})",
+           "single_thread": {"value": r1, "unit": "walk-steps/s", "cores": 1,
+                             "sample": f"{len(s1)} start vertices x {W} x {L}, {dt1:.1f} s"},
+           "reference_python": {"value": 2.8e4, "unit": "walk-steps/s", "cores": 1,
+                                "note": "the reference's own next_step_random_walk, CPython, measured "
+                                        "in the survey container (BASELINE.md section 2); cannot run here"}}
+    if sg_walks is not None:
+        out["sgns"] = cpu_baseline_sgns(args, cfg, torch, g, sg_walks, cores, np, n2v_oracle)
+    return out
+
+
+def cpu_baseline_sgns(args, cfg, torch, g, walks, cores, np, n2v_oracle):
+    """oracle/n2v_oracle_sgns.c (restated gensim-3.8 SGNS, parity unpinned) on host cores.
+    The CPU model is capped at 16 M rows x dim (2 x 8 GB at dim 128: far beyond every CPU
+    cache, so row gathers are DRAM-bound like the full 100 M-row model) and tokens are
+    folded into it; initialising two 51 GB host matrices would dominate the bench."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from node2vec_amd import sgns
+
+    dim = cfg["dim"]
+    n_cpu = int(min(g.n_vertices, 16_000_000))
+    deg = g.degrees().clamp(min=1)
+    order = torch.sort(deg, descending=True, stable=True).indices[:n_cpu]
+    cum = sgns.make_cum_table(deg[order]).cpu().numpy()
+    index_of = torch.empty(g.n_vertices, dtype=torch.int32, device=walks.device)
+    full = torch.sort(deg, descending=True, stable=True).indices
+    index_of[full] = (torch.arange(g.n_vertices, device=walks.device) % n_cpu).to(torch.int32)
+    idx = index_of[walks.long()].cpu().numpy()
+    del index_of, full
+    rng = np.random.default_rng(1)
+    block = ((rng.random((1 << 20, dim), dtype=np.float32) - 0.5) / dim).astype(np.float32)
+    syn0 = np.empty((n_cpu, dim), np.float32)
+    for lo in range(0, n_cpu, 1 << 20):
+        syn0[lo:lo + (1 << 20)] = block[:min(1 << 20, n_cpu - lo)]
+    syn1 = np.zeros((n_cpu, dim), np.float32)
+    syn1[:] = 0.0  # touch the pages: no first-touch faults inside the timed region
+    et = sgns.exp_table()
+
+    def train(rows, base):
+        return n2v_oracle.sgns_train(rows, syn0, syn1, cum, None, et, n_cpu, base, 1, dim, 5, 5, 0.025)
+
     t0 = time.perf_counter()
-    n2v_oracle.random_walk(rowptr, col, w, starts[:n0], W, L, args.p, args.q, 42, n_threads=cores)
-    dt0 = max(time.perf_counter() - t0, 1e-3)
-    n = int(min(len(starts), max(n0, n0 * args.cpu_seconds / dt0)))
-    stride = max(1, len(starts) // n)
-    sample = starts[::stride][:n]
+    pairs0 = train(idx[:8], 0)
+    rate0 = pairs0 / max(time.perf_counter() - t0, 1e-6)
+    pairs_per_row = pairs0 / 8
+    budget = args.cpu_seconds
+    n1 = int(max(8, min(len(idx), 0.4 * budget * rate0 / pairs_per_row)))
     t0 = time.perf_counter()
-    _, valid = n2v_oracle.random_walk(rowptr, col, w, sample, W, L, args.p, args.q, 42,
-                                      n_threads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": float(valid.sum()) * L / dt, "unit": "walk-steps/s", "cores": cores,
-            "kind": "port",
-            "sample": f"{len(sample)} start vertices (every {stride}th) x {W} walks x {L} steps, "
-                      f"{dt:.1f} s, oracle/n2v_oracle.c with OpenMP"}
+    p1 = train(idx[:n1], 1 << 20)
+    dt1 = time.perf_counter() - t0
+    r1 = p1 / dt1
+    nN = int(max(cores * 4, min(len(idx), 0.6 * budget * r1 * cores / pairs_per_row)))
+    per = max(1, nN // (cores * 4))
+    jobs = [(idx[lo:lo + per], (2 << 20) + lo) for lo in range(0, nN, per)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL: real threads, hogwild
+        pN = sum(ex.map(lambda a: train(*a), jobs))
+    dtN = time.perf_counter() - t0
+    return {"value": pN / dtN, "unit": "embedding-updates/s (pairs incl. k=5 negatives)",
+            "cores": cores, "kind": "port",
+            "sample": f"{nN} walks of {idx.shape[1]} tokens in {len(jobs)} hogwild jobs on {cores} "
+                      f"threads, {dtN:.1f} s; model {n_cpu} x {dim} fp32 (tokens folded modulo "
+                      f"{n_cpu}), oracle/n2v_oracle_sgns.c",
+            "single_thread": {"value": r1, "cores": 1, "sample": f"{n1} walks, {dt1:.1f} s"}}
 
 
 if __name__ == "__main__":

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define N2V_ABI_VERSION 3
+#define N2V_ABI_VERSION 4
 
 #define N2V_OK 0
 #define N2V_EINVAL (-1)  /* maps to ValueError (randomwalk.py:212-217)      */
@@ -58,22 +58,37 @@ typedef struct n2v_slot {
 
 /* The reference's adjacency DataFrame df_adj (fugue.py:130, randomwalk.py:266-275)
  * as CSR in HBM: one row per vertex id, neighbours sorted by dst ascending,
- * multi-edges kept.  `slots` holds the per-row first-order alias tables written by
- * n2v_alias_build, CSR-aligned (needed by N2V_WALK_FAST only, else may be NULL).
- * `pivots` is an optional search index over `col` written by n2v_pivots_build
+ * multi-edges kept.  Weights: the reference carries Python floats (randomwalk.py:20,
+ * indexer.py:24), so `w64` holds them as fp64; `w` is the 4-byte form for weights that are
+ * exactly representable in fp32 (same bits after widening); at most one of the two is set,
+ * both NULL = every weight is 1.0 (what index_graph_* produces, indexer.py:20-21) and the
+ * walk kernels never read weights.
+ * `slots` holds the per-row first-order alias tables written by n2v_alias_build,
+ * CSR-aligned (N2V_WALK_FAST on weighted graphs; exact walks with p == q == 1 on weighted
+ * graphs).  `pivots` is an optional search index over `col` written by n2v_pivots_build
  * (NULL = plain binary search): the test "x in N_out(src)" of randomwalk.py:226 then
- * touches 2-3 cache lines instead of log2(degree). */
+ * touches 2-3 cache lines instead of log2(degree).  `edge_classes` (unit-weight graphs,
+ * optional) is written by n2v_edge_classes_build: per edge e = (s -> v) the class counts
+ * of the table generate_edge_alias_tables builds at (s, v) -- see there. */
 typedef struct n2v_graph {
   int64_t n_vertices;
   int64_t n_edges;
   const int64_t *rowptr; /* [n_vertices + 1] */
   const int32_t *col;    /* [n_edges] */
-  const float *w;        /* [n_edges] fp32 storage, widened to fp64 for arithmetic;
-                            NULL = every weight is 1.0 (unweighted graph): the walk
-                            kernels then never read weights */
-  const n2v_slot *slots; /* [n_edges] */
-  const int32_t *pivots; /* [(n_edges + 31) / 32]: col[min(32 j + 31, n_edges - 1)] */
+  const float *w;        /* [n_edges] fp32 storage, or NULL */
+  const double *w64;     /* [n_edges] fp64 storage, or NULL */
+  const n2v_slot *slots; /* [n_edges] or NULL */
+  const int32_t *pivots; /* [(n_edges + 31) / 32]: col[min(32 j + 31, n_edges - 1)], or NULL */
+  const uint32_t *edge_classes; /* [n_edges] or NULL */
 } n2v_graph;
+
+/* edge_classes[e] for e = (s -> v): bits 0..23 = number of entries x of N(v) with
+ * x in N_out(s) and x != s ("shared", randomwalk.py:226-227), bits 24..31 = number of
+ * entries of N(v) equal to s ("return", :223-224); a field that does not fit is stored
+ * saturated (all ones) and the kernels then classify the row themselves. */
+#define N2V_EC_SHARED_MASK 0x00ffffffu
+#define N2V_EC_RETURN_SHIFT 24
+#define N2V_EC_RETURN_SAT 0xffu
 
 int n2v_abi_version(void);
 const char *n2v_status_string(int code);
@@ -88,9 +103,23 @@ int n2v_device_count(void);
  * neighbour).  Rows of degree 0 are skipped; a row whose weights sum to 0 sets
  * N2V_ST_ZERODIV.  slots_out is CSR-aligned ([n_edges]); slot.alias holds the
  * neighbour id the alias index points to, slot.col a copy of col. */
-int n2v_alias_build(const int64_t *rowptr, const int32_t *col, const float *w,
-                    int64_t n_rows, n2v_slot *slots_out, uint32_t *status,
+int n2v_alias_build(const n2v_graph *g, n2v_slot *slots_out, uint32_t *status,
                     void *stream);
+
+/* Per-edge class counts for exact walks on a unit-weight graph (g->w == g->w64 == NULL).
+ * The table generate_edge_alias_tables builds for a step (s -> v) (randomwalk.py:219-231)
+ * is a function of the EDGE (s, v) only, and with unit weights its row sum (:172) and the
+ * value probs[i] of every slot before the pairing (:173) follow from two counts: how many
+ * neighbours of v are s itself and how many are out-neighbours of s.  The reference
+ * recomputes them (a set intersection) at every step; this pass computes them once per
+ * edge -- one wave per source row, the shorter list searched in the longer -- and
+ * N2V_WALK_EXACT then decides most steps from {rowptr[v], classes[e], col[pick], one
+ * membership test}, bit-identical to the per-step rebuild, and only rebuilds the class
+ * layout of a row when the pairing loop (:182-189) actually has to run for slot `pick`.
+ * classes_out: [n_edges] uint32, layout above.  status: the four words described at the
+ * top (word [1] is the kernel's batch counter). */
+int n2v_edge_classes_build(const n2v_graph *g, uint32_t *classes_out, uint32_t *status,
+                           void *stream);
 
 /* Search index for N2V_WALK_FAST: the last id of every aligned block of 32 entries of
  * `col` (one 128-byte line).  Inside a sorted row the block ends ascend, so a
@@ -172,6 +201,32 @@ int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t walk_len,
                    const uint32_t *sample_int, const float *exp_table,
                    const n2v_sgns_params *params_host,
                    unsigned long long *pairs_out, void *stream);
+
+/* The exchange step of the multi-GPU SGNS path.  The reference trains on
+ * one machine: gensim's worker threads share syn0 / syn1neg (embedding.py:126).  Sharded
+ * over GPUs, every rank trains its own walks on a full replica and the replicas are
+ * averaged every few launches by an all-reduce (RCCL) between these two elementwise passes:
+ *
+ *   n2v_delta_pack   before_out[i] = cur[i] (snapshot), and the rank's contribution
+ *                    wire_out[i] = cur[i]                        N2V_WIRE_F32 (fp32 [n])
+ *                                = bf16(cur[i] - ref_bf16[i])    N2V_WIRE_BF16 (bf16 [n])
+ *   (caller: all-reduce SUM of wire over the ranks)
+ *   n2v_delta_apply  mean = wire_sum[i] / world                       (F32)
+ *                         = ref_bf16[i] + wire_sum[i] / world         (BF16; ref := bf16(mean))
+ *                    cur[i] += mean - before[i]
+ *
+ * so that updates made to cur while the collective was in flight survive.  With
+ * before_out / before == NULL no snapshot is taken and apply stores cur[i] = mean exactly
+ * (a blocking exchange: every rank ends with the same bits).  ref_bf16 is a
+ * bf16 reference copy shared by all ranks (n2v_delta_ref_init writes bf16(cur) once, on
+ * identical replicas); the F32 form needs no reference at all. */
+#define N2V_WIRE_F32 0
+#define N2V_WIRE_BF16 1
+int n2v_delta_ref_init(const float *cur, int64_t n, uint16_t *ref_bf16_out, void *stream);
+int n2v_delta_pack(const float *cur, const uint16_t *ref_bf16, int64_t n, float *before_out,
+                   void *wire_out, int32_t wire_dtype, void *stream);
+int n2v_delta_apply(float *cur, uint16_t *ref_bf16, const float *before, const void *wire_sum,
+                    int32_t wire_dtype, int32_t world, int64_t n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -6,23 +6,26 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# N2V_HIP_LIB: developer override used by scripts/ablate_walk.sh (timing-only builds)
-LIB_PATH = os.environ.get("N2V_HIP_LIB") or os.path.join(_HERE, "libn2v_hip.so")
+LIB_PATH = os.path.join(_HERE, "libn2v_hip.so")
+ABI_VERSION = 4
 
 OK, EINVAL, ELAUNCH, ENOGPU = 0, -1, -2, -3
 ST_ZERODIV, ST_RANGE = 1, 2
 WALK_EXACT, WALK_FAST = 0, 1
+WIRE_F32, WIRE_BF16 = 0, 1
 
 # every symbol include/n2v_hip.h declares
 SYMBOLS = ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alias_build",
-           "n2v_pivots_build", "n2v_walk", "n2v_trim_mark", "n2v_sgns_train")
+           "n2v_pivots_build", "n2v_edge_classes_build", "n2v_walk", "n2v_trim_mark",
+           "n2v_sgns_train", "n2v_delta_ref_init", "n2v_delta_pack", "n2v_delta_apply")
 
 
 class Graph(C.Structure):
     """struct n2v_graph"""
     _fields_ = [("n_vertices", C.c_int64), ("n_edges", C.c_int64),
                 ("rowptr", C.c_void_p), ("col", C.c_void_p), ("w", C.c_void_p),
-                ("slots", C.c_void_p), ("pivots", C.c_void_p)]
+                ("w64", C.c_void_p), ("slots", C.c_void_p), ("pivots", C.c_void_p),
+                ("edge_classes", C.c_void_p)]
 
 
 class SgnsParams(C.Structure):
@@ -51,8 +54,12 @@ def load():
     L.n2v_status_string.argtypes = [C.c_int]
     L.n2v_device_count.restype = C.c_int
     L.n2v_alias_build.restype = C.c_int
-    L.n2v_alias_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
-                                  C.c_void_p, C.c_void_p]
+    if L.n2v_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {L.n2v_abi_version()}, this package needs "
+                          f"{ABI_VERSION}: rebuild it (make -C node2vec_amd/csrc)")
+    L.n2v_alias_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.n2v_edge_classes_build.restype = C.c_int
+    L.n2v_edge_classes_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p]
     L.n2v_pivots_build.restype = C.c_int
     L.n2v_pivots_build.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.n2v_walk.restype = C.c_int
@@ -66,6 +73,14 @@ def load():
     L.n2v_sgns_train.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SgnsParams),
                                  C.c_void_p, C.c_void_p]
+    L.n2v_delta_ref_init.restype = C.c_int
+    L.n2v_delta_ref_init.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.n2v_delta_pack.restype = C.c_int
+    L.n2v_delta_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                 C.c_int32, C.c_void_p]
+    L.n2v_delta_apply.restype = C.c_int
+    L.n2v_delta_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                  C.c_int32, C.c_int64, C.c_void_p]
     _lib = L
     return L
 

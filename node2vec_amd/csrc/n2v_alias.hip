@@ -16,8 +16,8 @@ namespace n2v {
 
 __global__ __launch_bounds__(kWavesPerBlock * 64) void alias_build_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-    const float *__restrict__ w, int64_t n_rows, n2v_slot *__restrict__ slots,
-    uint32_t *__restrict__ status) {
+    const float *__restrict__ w, const double *__restrict__ w64, int64_t n_rows,
+    n2v_slot *__restrict__ slots, uint32_t *__restrict__ status) {
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
@@ -37,7 +37,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void alias_build_kernel(
     if (n == 0) continue;
     c.vcol = col + vb;
     c.scol = col;
-    c.vw = w + vb;
+    c.vw = w ? w + vb : nullptr;
+    c.vw64 = w64 ? w64 + vb : nullptr;
     c.n = n;
     c.nch = (n + 63) >> 6;
     n2v_slot *out = slots + vb;
@@ -132,16 +133,20 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void alias_build_kernel(
 
 }  // namespace n2v
 
-extern "C" int n2v_alias_build(const int64_t *rowptr, const int32_t *col, const float *w,
-                               int64_t n_rows, n2v_slot *slots_out, uint32_t *status,
+extern "C" int n2v_alias_build(const n2v_graph *g, n2v_slot *slots_out, uint32_t *status,
                                void *stream) {
-  if (!rowptr || !col || !w || !slots_out || !status || n_rows < 0) return N2V_EINVAL;
-  if (n_rows == 0) return N2V_OK;
+  if (!g || !g->rowptr || !slots_out || !status || g->n_vertices < 0) return N2V_EINVAL;
+  if (g->w && g->w64) return N2V_EINVAL;  // one storage form at most
+  const int64_t n_rows = g->n_vertices;
+  if (n_rows == 0 || g->n_edges == 0) return N2V_OK;
+  if (!g->col) return N2V_EINVAL;
   int64_t blocks = (n_rows + n2v::kWavesPerBlock - 1) / n2v::kWavesPerBlock;
-  if (blocks > 256 * 8) blocks = 256 * 8;
+  const int64_t cap = n2v::resident_blocks((const void *)n2v::alias_build_kernel,
+                                           n2v::kWavesPerBlock * 64, 0);
+  if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(n2v::alias_build_kernel, dim3((unsigned)blocks),
-                     dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, rowptr, col, w,
-                     n_rows, slots_out, status);
+                     dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, g->rowptr, g->col,
+                     g->w, g->w64, n_rows, slots_out, status);
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
 }

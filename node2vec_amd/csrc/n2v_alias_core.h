@@ -36,13 +36,21 @@ __device__ __forceinline__ uint32_t hash_id(int32_t y, int shift) {
 
 struct StepCtx {
   const int32_t *vcol;  // N(v) ids
-  const float *vw;      // N(v) weights
+  const float *vw;      // N(v) weights, fp32 storage ...
+  const double *vw64;   // ... or fp64 storage (at most one is set; both NULL = unit weights)
   const int32_t *scol;  // N(s) ids
   int n, nch, m, iters;
   int32_t s;
   bool need_cls, need_mem;
   double p, q;
 };
+
+// weight of neighbour i of the current row, widened to the fp64 the reference computes in
+// (wave-uniform pointers: the selection is a scalar branch)
+__device__ __forceinline__ double weight_at(const StepCtx &c, int i) {
+  if (c.vw64) return c.vw64[i];
+  return c.vw ? (double)c.vw[i] : 1.0;
+}
 
 __device__ __forceinline__ bool member_sorted(const int32_t *a, int m, int32_t x, int iters) {
   int lo = 0, hi = m;
@@ -166,7 +174,7 @@ __device__ __forceinline__ double chunk_bias(const StepCtx &c, int chunk, int la
                                              uint64_t *cls, bool &valid) {
   const int i = chunk * 64 + lane;
   valid = i < c.n;
-  double wt = valid ? (c.vw ? (double)c.vw[i] : 1.0) : 0.0;
+  double wt = valid ? weight_at(c, i) : 0.0;
   if (!c.need_cls) return wt;
   bool is_ret, is_mem;
   if (kFromCache && chunk < kLdsChunks) {

@@ -45,7 +45,13 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start, int3
   // generate_edge_alias_tables raises ValueError on p == 0 or q == 0 (randomwalk.py:214-217)
   if (return_param == 0.0 || inout_param == 0.0) return N2V_EINVAL;
   if (!any) return (mode == N2V_WALK_EXACT || mode == N2V_WALK_FAST) ? N2V_OK : N2V_EINVAL;
+  if (g->w && g->w64) return N2V_EINVAL;  // one storage form at most
   if (mode == N2V_WALK_EXACT) {
+    // every weight 1.0 (w == w64 == NULL): the specialised kernels (n2v_walk_unit.hip)
+    const int rc = n2v_walk_exact_unit_try(g, start_ids, n_start, num_walks, walk_length,
+                                           return_param, inout_param, seed, walks_out,
+                                           valid_out, status, stream);
+    if (rc != 0) return rc < 0 ? rc : N2V_OK;
     // p == q == 1 (the reference's defaults, constants.py:22,26): w/p == w/q == w exactly, so
     // the table generate_edge_alias_tables builds at (s, v) IS generate_alias_tables(row v) --
     // the K1 slots when the caller has them.  One 16-byte gather per step instead of a
@@ -53,11 +59,6 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start, int3
     if (return_param == 1.0 && inout_param == 1.0 && g->slots)
       return n2v_walk_fast_launch(g, start_ids, n_start, num_walks, walk_length, return_param,
                                   inout_param, seed, walks_out, valid_out, status, stream);
-    // w == NULL: every weight is 1.0 -- the specialised kernel
-    const int rc = n2v_walk_exact_unit_try(g, start_ids, n_start, num_walks, walk_length,
-                                           return_param, inout_param, seed, walks_out,
-                                           valid_out, status, stream);
-    if (rc != 0) return rc < 0 ? rc : N2V_OK;
     return n2v_walk_exact_launch(g, start_ids, n_start, num_walks, walk_length, return_param,
                                  inout_param, seed, walks_out, valid_out, status, stream);
   }

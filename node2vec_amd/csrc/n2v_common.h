@@ -88,6 +88,19 @@ __device__ inline uint64_t readfirstlane_u64(uint64_t v) { return (uint64_t)read
 
 __device__ inline uint64_t ballot64(bool p) { return __ballot(p); }
 
+// "x in a[0, m)" for a sorted row, by ONE lane (data-dependent trip count: lanes diverge)
+__device__ __forceinline__ bool member_sorted_lane(const int32_t *a, int m, int32_t x) {
+  int lo = 0, hi = m;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < x)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo < m && a[lo] == x;
+}
+
 __device__ inline int64_t wave_sum_i64(int64_t v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -65,7 +65,7 @@ __device__ __forceinline__ void verify_maybes(const StepCtx &c, WaveLds &L, int 
     const bool act = k + lane < count;
     const int i = act ? L.mlist[k + lane] : 0;
     const int32_t x = act ? c.vcol[i] : -1;
-    const double wt = act ? (c.vw ? (double)c.vw[i] : 1.0) : 0.0;
+    const double wt = act ? weight_at(c, i) : 0.0;
     const bool mem = member_sorted(c.scol, c.m, x, c.iters) && act;
     const double b = mem ? wt : wt / c.q;  // :226-230
     if (mem && (i >> 6) < kLdsChunks)
@@ -104,11 +104,11 @@ __device__ __forceinline__ int pairing(const StepCtx &c, WaveLds &L, int lane, i
   // below is serial, so that latency would be fully exposed at every refill: each
   // stream therefore keeps the NEXT chunk's weights in flight (wnext) while the
   // current 64 candidates are consumed.
-  auto fetch_w = [&](int chunk) -> float {
+  auto fetch_w = [&](int chunk) -> double {
     const int i = chunk * 64 + lane;
-    return (chunk >= 0 && i < n) ? (c.vw ? c.vw[i] : 1.0f) : 0.0f;
+    return (chunk >= 0 && i < n) ? weight_at(c, i) : 0.0;
   };
-  auto load_s = [&](int chunk, float &wnext, int &wnext_chunk, bool &valid) -> double {
+  auto load_s = [&](int chunk, double &wnext, int &wnext_chunk, bool &valid) -> double {
     const int i = chunk * 64 + lane;
     if (kCached || (bq_valid && n - 1 - chunk * 64 < kBqCap)) {  // wave-uniform
       valid = i < n;
@@ -118,10 +118,10 @@ __device__ __forceinline__ int pairing(const StepCtx &c, WaveLds &L, int lane, i
     if (c.need_cls && chunk >= kLdsChunks)  // classes not cached: search again
       return chunk_bias<true>(c, chunk, lane, L.cls, valid) / avg;
     valid = i < n;
-    const float wf = (wnext_chunk == chunk) ? wnext : fetch_w(chunk);
+    const double wf = (wnext_chunk == chunk) ? wnext : fetch_w(chunk);
     wnext = fetch_w(chunk - 1);
     wnext_chunk = chunk - 1;
-    const double wt = valid ? (double)wf : 0.0;
+    const double wt = valid ? wf : 0.0;
     double b = wt;
     if (c.need_cls) {
       const bool is_ret = (L.cls[2 * chunk] >> lane) & 1ull;
@@ -133,7 +133,7 @@ __device__ __forceinline__ int pairing(const StepCtx &c, WaveLds &L, int lane, i
     }
     return b / avg;
   };
-  float wu_next = 0.0f, wo_next = 0.0f;
+  double wu_next = 0.0, wo_next = 0.0;
   int wu_chunk = -2, wo_chunk = -2;
   int cu = c.nch, co = c.nch;
   uint64_t um = 0, om = 0;
@@ -283,13 +283,13 @@ __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_
   int mcount = 0;
   constexpr int kU = 4;  // chunks per iteration: 2 * kU global loads in flight per lane
   for (int chunk0 = 0; chunk0 < c.nch; chunk0 += kU) {
-    float wf[kU];
+    double wf[kU];
     int32_t xs[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const int i = (chunk0 + u) * 64 + lane;
       const bool valid = i < n;
-      wf[u] = valid ? (c.vw ? c.vw[i] : 1.0f) : 0.0f;
+      wf[u] = valid ? weight_at(c, i) : 0.0;
       xs[u] = (valid && c.need_cls) ? c.vcol[i] : -1;
     }
     bool memv[kU];
@@ -306,7 +306,7 @@ __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_
       if (chunk >= c.nch) break;  // wave-uniform
       const int i = chunk * 64 + lane;
       const bool valid = i < n;
-      const double wt = (double)wf[u];
+      const double wt = wf[u];
       bool is_ret = false, is_mem = false, maybe = false;
       if (c.need_cls) {
         const int32_t x = xs[u];
@@ -508,6 +508,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
         }
         c.vcol = g.col + vb;
         c.vw = g.w ? g.w + vb : nullptr;
+        c.vw64 = g.w64 ? g.w64 + vb : nullptr;
         c.n = n;
         c.nch = (n + 63) >> 6;
         c.s = s;

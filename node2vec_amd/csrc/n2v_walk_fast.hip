@@ -20,18 +20,6 @@
 
 namespace n2v {
 
-__device__ __forceinline__ bool member_sorted_lane(const int32_t *a, int m, int32_t x) {
-  int lo = 0, hi = m;
-  while (lo < hi) {
-    int mid = (lo + hi) >> 1;
-    if (a[mid] < x)
-      lo = mid + 1;
-    else
-      hi = mid;
-  }
-  return lo < m && a[lo] == x;
-}
-
 // The same test through the block-end index (include/n2v_hip.h, n2v_pivots_build).  The
 // kernel is bound by the number of cache lines its random probes pull in (every probe of a
 // plain binary search is another 128-byte line until the last few), so the search runs

@@ -1222,6 +1222,158 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_UNIT_WAVES) void walk_exac
 #endif
 }
 
+// ---- lanes kernel: one LANE per walker, the wave only for the pairing -------------------
+// With the class counts of every edge at hand (n2v_edge_classes_build) a step (s -> v) needs
+// no classification of N(v) unless the pairing loop (:182-189) has to run for slot `pick`:
+//   avg     = (nR / p + nM + nO / q) / n              from edge_classes[e], e = the edge walked last
+//   probs0  = the class value of slot `pick` / avg     one membership test "N(v)[pick] in N(s)"
+//   exit 1  probs0 < 1 and r2 < probs0 -> pick         (an underfull slot that is accepted never
+//                                                       changes, same exit as unit_draw)
+//   exit 2  one of the two stacks is empty -> pick or 0 (the loop of :182 never runs)
+// Those exits decide ~80 % of the steps of the BASELINE graphs, and they are per-lane work:
+// four to six dependent gathers, no LDS, no wave-wide scan.  So 64 walkers share a wave and
+// advance in lock-step; the lanes whose step is not decided are served one after the other by
+// the whole wave running unit_draw (the routine of the wave-per-walker kernel, unchanged: same
+// bits).  Dyadic p, q only (the row sum is then an integer combination of the counts); p == q
+// == 1 needs no counts at all (every step is `pick`).
+#ifndef N2V_LANES_WAVES
+#define N2V_LANES_WAVES 5
+#endif
+__global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exact_unit_lanes_kernel(
+    n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
+    int32_t walk_length, double p, double q, UnitConsts K, uint64_t seed,
+    int32_t *__restrict__ walks_out, uint8_t *__restrict__ valid_out,
+    uint32_t *__restrict__ status) {
+  __shared__ UnitLds lds_all[kWavesPerBlock];
+  const int lane = threadIdx.x & 63;
+  UnitLds &L = lds_all[threadIdx.x >> 6];
+  const int64_t total = n_start * (int64_t)num_walks;
+  const int L1 = walk_length + 1;
+  const bool biased = !(p == 1.0 && q == 1.0);
+  const bool need_mem = q != 1.0;
+  UnitStep c;
+  c.need_mem = need_mem;
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&status[1], 64u);
+    const int64_t base = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (base >= total) break;
+    const int64_t r = base + lane;
+    const bool have = r < total;
+    int32_t start = -1;
+    uint64_t h0 = 0;
+    bool alive = have;
+    if (have) {
+      start = start_ids[r / num_walks];
+      const int32_t ordinal = (int32_t)(r % num_walks) + 1;
+      h0 = walker_stream(seed, (uint64_t)start * (uint64_t)num_walks + (uint64_t)(ordinal - 1));
+      if (start < 0 || (int64_t)start >= g.n_vertices) {
+        atomicOr(status, N2V_ST_RANGE);
+        alive = false;
+      }
+    }
+    int64_t vb = 0, sb = 0, e_prev = 0;
+    int n = 0, m = 0;
+    if (alive) {
+      vb = g.rowptr[start];
+      n = (int)(g.rowptr[start + 1] - vb);
+      alive = n > 0;  // fugue.py:132
+    }
+    int32_t *out = walks_out + r * L1;
+    if (have) out[0] = alive ? start : -1;
+    const bool started = alive;
+    int32_t s = -1, v = start;
+    bool walking = alive;
+    for (int step = 0; step < walk_length; ++step) {
+      if (ballot64(walking) == 0ull) break;
+      int idx = 0;
+      int32_t x = -1;
+      bool unresolved = false;
+      uint32_t u1 = 0, u2 = 0;
+      if (walking) {
+        const uint64_t bits = step_bits(h0, (uint32_t)step);
+        u1 = (uint32_t)(bits >> 32);
+        u2 = (uint32_t)bits;
+        const int pick = pick_index(u1, n);
+        idx = pick;
+        x = g.col[vb + pick];
+        if (s >= 0 && biased) {
+          const uint32_t ec = g.edge_classes[e_prev];
+          const uint32_t fR = ec >> N2V_EC_RETURN_SHIFT, fM = ec & N2V_EC_SHARED_MASK;
+          if (fR == N2V_EC_RETURN_SAT || fM == N2V_EC_SHARED_MASK) {
+            unresolved = true;  // a count that did not fit: classify the row
+          } else {
+            const int nR = (int)fR, nM = need_mem ? (int)fM : 0, nO = n - nR - nM;
+            const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
+            const double avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;  // :172
+            const bool isR = x == s;
+            bool isM = false;
+            if (need_mem && !isR) isM = member_sorted_lane(g.col + sb, m, x);  // :226
+            const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) / avg;      // :173
+            const double r2 = (double)u2 * (1.0 / 4294967296.0);
+            if (!(p_pick < 1.0 && r2 < p_pick)) {
+              const bool uR = K.bR / avg < 1.0, uM = K.bM / avg < 1.0, uO = K.bO / avg < 1.0;
+              const bool any_under = (nR && uR) || (nM && uM) || (nO && uO);
+              const bool any_over = (nR && !uR) || (nM && !uM) || (nO && !uO);
+              if (!any_under || !any_over) {  // the loop of :182 never runs
+                if (!(r2 < p_pick)) {
+                  idx = 0;
+                  x = g.col[vb];
+                }
+              } else {
+                unresolved = true;
+              }
+            }
+          }
+        }
+      }
+      // the steps that need the pairing: the whole wave, one walker at a time
+      uint64_t fb = ballot64(unresolved);
+      while (fb != 0ull) {
+        const int l = (int)__builtin_ctzll(fb);
+        fb &= fb - 1ull;
+        const int64_t vb_l = readfirstlane_i64(__shfl(vb, l, 64));
+        const int64_t sb_l = readfirstlane_i64(__shfl(sb, l, 64));
+        c.vcol = g.col + vb_l;
+        c.scol = g.col + sb_l;
+        c.n = __builtin_amdgcn_readlane(n, l);
+        c.nch = (c.n + 63) >> 6;
+        c.m = __builtin_amdgcn_readlane(m, l);
+        c.iters = 32 - __clz(c.m);
+        c.s = __builtin_amdgcn_readlane(s, l);
+        const uint32_t u1_l = (uint32_t)__builtin_amdgcn_readlane((int)u1, l);
+        const uint32_t u2_l = (uint32_t)__builtin_amdgcn_readlane((int)u2, l);
+        const int res = __builtin_amdgcn_readfirstlane(unit_draw<true>(c, K, u1_l, u2_l, lane, L));
+        __builtin_amdgcn_wave_barrier();
+        if (lane == l) idx = res;
+      }
+      if (unresolved) x = g.col[vb + idx];
+      if (walking) {
+        out[step + 1] = x;
+        e_prev = vb + idx;
+        s = v;  // the row of the new previous vertex is the row just walked
+        sb = vb;
+        m = n;
+        v = x;
+        if (step + 1 < walk_length) {
+          vb = g.rowptr[v];
+          n = (int)(g.rowptr[v + 1] - vb);
+          if (n == 0) {  // fugue.py:147: the walker vanishes at a sink
+            walking = false;
+            alive = false;
+            for (int tt = step + 2; tt < L1; ++tt) out[tt] = -1;
+          }
+        }
+      }
+    }
+    if (have) {
+      if (!started)  // no such vertex / no out-edges: the row is all -1, like the other kernels
+        for (int tt = 1; tt < L1; ++tt) out[tt] = -1;
+      valid_out[r] = alive ? 1 : 0;
+    }
+  }
+}
+
 }  // namespace n2v
 
 // true when x * 2^20 is an exact integer in [0, 2^31): the integer-sum argument holds
@@ -1239,7 +1391,7 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
                                        int32_t walk_length, double p, double q, uint64_t seed,
                                        int32_t *walks_out, uint8_t *valid_out, uint32_t *status,
                                        void *stream) {
-  if (g->w != nullptr) return 0;
+  if (g->w != nullptr || g->w64 != nullptr) return 0;
   n2v::UnitConsts K;
   K.bR = 1.0 / p;  // the reference's weight / return_param with weight == 1.0
   K.bM = 1.0;
@@ -1253,15 +1405,28 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
   if (!dyadic && !ordinary) return 0;
   const int64_t total = n_start * (int64_t)num_walks;
   if (total == 0) return 1;
+  // status[1] is the kernels' walker counter: start it at zero on the same stream
+  if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
+    return N2V_ELAUNCH;
+  // lanes kernel: dyadic p, q with the per-edge class counts at hand (p == q == 1 needs none)
+  if (dyadic && total < 0xffffff00ll && (g->edge_classes || (p == 1.0 && q == 1.0))) {
+    int64_t blocks = (total + 255) / 256;
+    const int64_t cap = n2v::resident_blocks((const void *)n2v::walk_exact_unit_lanes_kernel,
+                                             n2v::kWavesPerBlock * 64, 0);
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(n2v::walk_exact_unit_lanes_kernel, dim3((unsigned)blocks),
+                       dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, *g, start_ids,
+                       n_start, num_walks, walk_length, p, q, K, seed, walks_out, valid_out,
+                       status);
+    if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
+    return 1;
+  }
   // persistent grid: exactly the resident capacity, walkers are grid-strided
   int64_t blocks = (total + n2v::kWavesPerBlock - 1) / n2v::kWavesPerBlock;
   const void *fn = dyadic ? (const void *)n2v::walk_exact_unit_kernel<true>
                           : (const void *)n2v::walk_exact_unit_kernel<false>;
   const int64_t cap = n2v::resident_blocks(fn, n2v::kWavesPerBlock * 64, 0);
   if (blocks > cap) blocks = cap;
-  // status[1] is the kernel's walker counter: start it at zero on the same stream
-  if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
-    return N2V_ELAUNCH;
   if (dyadic)
     hipLaunchKernelGGL(n2v::walk_exact_unit_kernel<true>, dim3((unsigned)blocks),
                        dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, *g, start_ids,

@@ -153,8 +153,11 @@ class Node2VecHIP(Node2VecBase):
         Under an initialised torch.distributed process group (one process per GPU) the
         walks held by this object are this rank's shard: the vocabulary is built from
         globally summed counts, every rank starts from the same seeded model, trains on its
-        own walks with disjoint sentence ids, and the model deltas are all-reduced (RCCL)
-        after every block (sgns.DeltaAllReduce), so all ranks return the same vectors."""
+        own walks with disjoint sentence ids, and the replicas are averaged (RCCL) every
+        `sync_every` launches (sgns.DeltaSync; w2v_params["sync_every"], default: chosen so that
+        the exchange takes <= 10 % of the time; w2v_params["sync_wire"] "fp32" | "bf16"), with a
+        final blocking exchange, so all ranks return the same vectors.  Ranks may hold
+        different numbers of walks (or none): the block grid is laid over the largest shard."""
         import torch.distributed as dist
 
         from node2vec_amd import _lib
@@ -170,17 +173,23 @@ class Node2VecHIP(Node2VecBase):
         m = sgns.SgnsModel(vocab, int(p["size"]), int(p["window"]), negative, int(p["seed"]),
                            sample=float(p["sample"] or 0.0), ns_exponent=float(p["ns_exponent"]),
                            device=dev)
-        idx = sgns.split_rows(vocab.index_of[walks.long()])
+        # tokens < 0 (rows of dropped walkers in an on-device corpus, fugue.random_walk_tensors)
+        # stay outside the vocabulary; a negative index must not wrap around
+        idx = torch.where(walks >= 0, vocab.index_of[walks.clamp(min=0).long()],
+                          torch.full_like(walks, -1))
+        idx = sgns.split_rows(idx)
+        rows_max = None
         if sync is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             from node2vec_amd.shard import sentence_base as rank_base
 
             rows = torch.tensor([idx.shape[0]], device=dev)
             dist.all_reduce(rows, op=dist.ReduceOp.MAX)
+            rows_max = int(rows.item())  # every rank lays the same block grid over this
             sentence_base = rank_base(dist.get_rank(), dist.get_world_size(),
-                                      int(rows.item()) * max(int(p["iter"]), 1))
-            sync = sgns.DeltaAllReduce([m.syn0, m.syn1neg])
+                                      rows_max * max(int(p["iter"]), 1))
+            sync = sgns.DeltaSync(m, sync_every=p.get("sync_every"), wire=p.get("sync_wire", "fp32"))
         m.train(idx, int(p["iter"]), float(p["alpha"]), float(p["min_alpha"]),
-                sentence_base=sentence_base, sync=sync)
+                sentence_base=sentence_base, sync=sync, rows_global_max=rows_max)
         torch.cuda.synchronize(dev)
         tokens = [str(int(i)) for i in vocab.ids.cpu().numpy()]
         p["negative"] = negative

@@ -16,28 +16,55 @@ from node2vec_amd import _lib
 
 
 class DeviceGraph:
-    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, w: torch.Tensor):
-        if rowptr.dtype != torch.int64 or col.dtype != torch.int32 or w.dtype != torch.float32:
-            raise TypeError("DeviceGraph wants rowptr int64, col int32, w float32")
-        if col.numel() != w.numel() or rowptr.numel() < 1:
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, w: Optional[torch.Tensor]):
+        """`w` None = every weight is 1.0 (what index_graph_* produces, indexer.py:20-21):
+        nothing is stored for the weights and the walk kernels never read them."""
+        if rowptr.dtype != torch.int64 or col.dtype != torch.int32:
+            raise TypeError("DeviceGraph wants rowptr int64, col int32")
+        if w is not None and w.dtype not in (torch.float32, torch.float64):
+            raise TypeError("DeviceGraph wants w float32 / float64 (or None for unit weights)")
+        if (w is not None and col.numel() != w.numel()) or rowptr.numel() < 1:
             raise ValueError("DeviceGraph: ragged CSR arrays")
         self.rowptr = rowptr.contiguous()
         self.col = col.contiguous()
-        self.w = w.contiguous()
+        # unweighted graph: the kernels are told through w == NULL
+        if w is not None and (w.numel() == 0 or bool((w == 1.0).all())):
+            w = None
+        self._w = None if w is None else w.contiguous()
+        self.unit_weights = self._w is None
         self.slots: Optional[torch.Tensor] = None  # int32 [E, 4] view of n2v_slot[E]
         self.pivots: Optional[torch.Tensor] = None  # int32 [(E + 31) / 32] search index (fast mode)
-        # unweighted graph (index_graph_* gives weight 1.0, indexer.py:20-21): the walk
-        # kernels are told through w == NULL and never read the weights
-        self.unit_weights = bool((self.w == 1.0).all()) if self.w.numel() else True
+        self.edge_classes: Optional[torch.Tensor] = None  # uint32-in-int32 [E] (exact mode, unit weights)
+
+    @property
+    def w(self) -> torch.Tensor:
+        """Edge weights as a tensor (ones are materialised on demand for a unit-weight graph)."""
+        if self._w is None:
+            return torch.ones(self.n_edges, dtype=torch.float32, device=self.device)
+        return self._w
 
     # -- construction ---------------------------------------------------------
     @classmethod
-    def from_edges(cls, src, dst, weight, n_vertices: Optional[int] = None, device=None):
-        """Stable sort by (src, dst) == partition(by=src, presort=dst) (fugue.py:130)."""
+    def from_edges(cls, src, dst, weight=None, n_vertices: Optional[int] = None, device=None):
+        """Stable sort by (src, dst) == partition(by=src, presort=dst) (fugue.py:130).
+
+        `weight` None = unit weights.  The reference carries weights as Python floats
+        (randomwalk.py:20, indexer.py:24): float64 input stays float64 in HBM unless every
+        value is exactly representable in float32, in which case the 4-byte form is stored
+        (both are widened to fp64 before any arithmetic, so the results are the same bits)."""
         src = torch.as_tensor(src).to(device=device, dtype=torch.int64).reshape(-1)
         dst = torch.as_tensor(dst).to(device=device, dtype=torch.int64).reshape(-1)
-        w = torch.as_tensor(weight).to(device=device, dtype=torch.float32).reshape(-1)
-        if not (src.numel() == dst.numel() == w.numel()):
+        w = None
+        if weight is not None:
+            w = torch.as_tensor(weight).to(device=device).reshape(-1)
+            if w.dtype in (torch.float16, torch.bfloat16, torch.float32):
+                w = w.to(torch.float32)
+            else:
+                w = w.to(torch.float64)
+                w32 = w.to(torch.float32)
+                if bool((w32.to(torch.float64) == w).all()):
+                    w = w32
+        if src.numel() != dst.numel() or (w is not None and w.numel() != src.numel()):
             raise ValueError("src, dst and weight differ in length")
         if src.numel() and (int(src.min()) < 0 or int(dst.min()) < 0):
             raise ValueError("vertex ids must be non-negative (negative ids mark first steps, "
@@ -48,12 +75,25 @@ class DeviceGraph:
         if hi > n_vertices or n_vertices >= 2 ** 31:
             raise ValueError("vertex id out of range for int32 CSR")
         key = src * max(n_vertices, 1) + dst
-        order = torch.sort(key, stable=True).indices
-        src, dst, w = src[order], dst[order], w[order]
+        del dst
+        key, order = torch.sort(key, stable=True)
         counts = torch.bincount(src, minlength=n_vertices)
-        rowptr = torch.zeros(n_vertices + 1, dtype=torch.int64, device=src.device)
+        del src
+        rowptr = torch.zeros(n_vertices + 1, dtype=torch.int64, device=key.device)
         torch.cumsum(counts, 0, out=rowptr[1:])
-        return cls(rowptr, dst.to(torch.int32), w)
+        col = (key % max(n_vertices, 1)).to(torch.int32)
+        return cls(rowptr, col, None if w is None else w[order])
+
+    @classmethod
+    def from_sorted_keys(cls, key: torch.Tensor, n_vertices: int) -> "DeviceGraph":
+        """Unit-weight CSR from edge keys src * n_vertices + dst that are already sorted
+        ascending (torch.unique output): no second sort, no weight array."""
+        src = key // max(n_vertices, 1)
+        counts = torch.bincount(src, minlength=n_vertices)
+        del src
+        rowptr = torch.zeros(n_vertices + 1, dtype=torch.int64, device=key.device)
+        torch.cumsum(counts, 0, out=rowptr[1:])
+        return cls(rowptr, (key % max(n_vertices, 1)).to(torch.int32), None)
 
     @classmethod
     def from_pandas(cls, df, n_vertices: Optional[int] = None, device=None):
@@ -81,18 +121,48 @@ class DeviceGraph:
         return self.rowptr[1:] - self.rowptr[:-1]
 
     def to(self, device) -> "DeviceGraph":
-        g = DeviceGraph(self.rowptr.to(device), self.col.to(device), self.w.to(device))
-        if self.slots is not None:
-            g.slots = self.slots.to(device)
-        if self.pivots is not None:
-            g.pivots = self.pivots.to(device)
+        g = DeviceGraph(self.rowptr.to(device), self.col.to(device),
+                        None if self._w is None else self._w.to(device))
+        for name in ("slots", "pivots", "edge_classes"):
+            t = getattr(self, name)
+            if t is not None:
+                setattr(g, name, t.to(device))
         return g
 
     def c_struct(self) -> _lib.Graph:
+        w32 = self._w is not None and self._w.dtype == torch.float32
+        w64 = self._w is not None and self._w.dtype == torch.float64
         return _lib.Graph(self.n_vertices, self.n_edges, self.rowptr.data_ptr(),
-                          self.col.data_ptr(), 0 if self.unit_weights else self.w.data_ptr(),
+                          self.col.data_ptr(), self._w.data_ptr() if w32 else 0,
+                          self._w.data_ptr() if w64 else 0,
                           0 if self.slots is None else self.slots.data_ptr(),
-                          0 if self.pivots is None else self.pivots.data_ptr())
+                          0 if self.pivots is None else self.pivots.data_ptr(),
+                          0 if self.edge_classes is None else self.edge_classes.data_ptr())
+
+    # -- a9 -----------------------------------------------------------------------
+    def trimmed(self, max_out_degree: int, seed: int) -> "DeviceGraph":
+        """trim_hotspot_vertices (randomwalk.py:238-262) on the CSR itself: rows above the cap
+        keep a uniform sample without replacement of exactly `cap` edges (n2v_trim_mark), in
+        their original order; other rows and all weights are untouched.  Returns a new graph
+        (or self when no row exceeds the cap)."""
+        from node2vec_amd.constants import MAX_OUT_DEGREES
+
+        cap = int(max_out_degree) if max_out_degree > 0 else MAX_OUT_DEGREES  # randomwalk.py:252-253
+        deg = self.degrees()
+        if self.n_edges == 0 or int(deg.max()) <= cap:
+            return self
+        L = _lib.load()
+        _lib.require_gpu()
+        keep = torch.ones(self.n_edges, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = L.n2v_trim_mark(self.rowptr.data_ptr(), self.n_vertices, cap,
+                                 int(seed) & (2 ** 64 - 1), keep.data_ptr(),
+                                 _lib.current_stream_ptr())
+        _lib.check(rc, "n2v_trim_mark")
+        keep = keep.bool()
+        rowptr = torch.zeros_like(self.rowptr)
+        torch.cumsum(deg.clamp(max=cap), 0, out=rowptr[1:])
+        return DeviceGraph(rowptr, self.col[keep], None if self._w is None else self._w[keep])
 
     # -- K1 -----------------------------------------------------------------------
     def build_alias(self) -> "DeviceGraph":
@@ -108,13 +178,31 @@ class DeviceGraph:
             return self
         status = torch.zeros(4, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
-            rc = L.n2v_alias_build(self.rowptr.data_ptr(), self.col.data_ptr(),
-                                   self.w.data_ptr(), self.n_vertices, slots.data_ptr(),
-                                   status.data_ptr(), _lib.current_stream_ptr())
+            rc = L.n2v_alias_build(self.c_struct(), slots.data_ptr(), status.data_ptr(),
+                                   _lib.current_stream_ptr())
         _lib.check(rc, "n2v_alias_build")
         _lib.check_status_word(int(status[0].item()), "n2v_alias_build")
         self.slots = slots
         return self.build_pivots()
+
+    def build_edge_classes(self) -> "DeviceGraph":
+        """Per-edge class counts (n2v_edge_classes_build) for exact walks on a unit-weight
+        graph: 4 bytes per edge, computed once, kept on the graph."""
+        L = _lib.load()
+        _lib.require_gpu()
+        if not self.unit_weights:
+            raise ValueError("edge classes exist for unit-weight graphs only")
+        if not self.rowptr.is_cuda:
+            raise RuntimeError("build_edge_classes: graph is not on the GPU")
+        ec = torch.zeros(self.n_edges, dtype=torch.int32, device=self.device)
+        if self.n_edges:
+            status = torch.zeros(4, dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                rc = L.n2v_edge_classes_build(self.c_struct(), ec.data_ptr(), status.data_ptr(),
+                                              _lib.current_stream_ptr())
+            _lib.check(rc, "n2v_edge_classes_build")
+        self.edge_classes = ec
+        return self
 
     def build_pivots(self) -> "DeviceGraph":
         """Block-end search index over `col` (n2v_pivots_build): fast-mode membership tests

@@ -81,6 +81,7 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
     epochs = max(int(p["iter"]), 1)
     alpha, min_alpha = float(p["alpha"]), float(p["min_alpha"])
     total, done = rows_total * epochs, 0
+    submitted = 0  # SGNS sentence ids: rows handed to the kernel so far (after split_rows)
     for ep in range(epochs):
         for lo, b in batches():
             walks, valid = walk(b)
@@ -88,7 +89,8 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
             idx = torch.where(valid.bool().unsqueeze(1) & (walks >= 0), idx, torch.full_like(idx, -1))
             a = max(min_alpha, alpha - (alpha - min_alpha) * (done / max(total, 1)))
             for part in torch.split(sgns.split_rows(idx), 1 << 22):
-                model.train_block(part, a, ep * rows_total + lo * W)
+                model.train_block(part, a, submitted)
+                submitted += part.shape[0]
             done += idx.shape[0]
     torch.cuda.synchronize(dev)
     tokens = [str(int(i)) for i in vocab.ids.cpu().numpy()]

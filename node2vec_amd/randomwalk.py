@@ -18,6 +18,12 @@ from node2vec_amd.graph import DeviceGraph
 MODES = {"exact": _lib.WALK_EXACT, "fast": _lib.WALK_FAST}
 
 
+def _dyadic(x: float) -> bool:
+    """1/x * 2^20 is an exact integer below 2^31 (the lanes kernel's integer row sum)"""
+    t = (1.0 / x) * 1048576.0
+    return 0.0 < t < 2147483648.0 and t == float(int(t))
+
+
 def fresh_seed() -> int:
     """random_seed=None in the reference means an unseeded `random` (randomwalk.py:314)."""
     return int.from_bytes(os.urandom(8), "little")
@@ -40,12 +46,15 @@ def start_vertices(graph: DeviceGraph, walk_seed_ids=None) -> torch.Tensor:
 def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_length: int,
          return_param: float, inout_param: float, seed: int, mode: str = "exact",
          out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, check: bool = True,
-         stats: Optional[dict] = None):
+         stats: Optional[dict] = None, use_edge_classes: bool = True):
     """Launch K2.  Returns (walks int32 [n_start*num_walks, walk_length+1], valid bool).
 
-    mode "fast", and mode "exact" with return_param == inout_param == 1 (the reference's
-    defaults), read the first-order alias tables of the graph: they are built on first use
-    (graph.build_alias(): 16 bytes per edge plus the search index, kept on the graph)."""
+    mode "fast", and on weighted graphs mode "exact" with return_param == inout_param == 1
+    (the reference's defaults), read the first-order alias tables of the graph: they are
+    built on first use (graph.build_alias(): 16 bytes per edge plus the search index, kept
+    on the graph).  Exact walks on a unit-weight graph with other p, q use the per-edge
+    class counts (graph.build_edge_classes(): 4 bytes per edge, built on first use;
+    use_edge_classes=False walks without them, one wave per walker: same bits, slower)."""
     L = _lib.load()
     _lib.require_gpu()
     if mode not in MODES:
@@ -55,9 +64,16 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     if return_param == 0 or inout_param == 0:
         # generate_edge_alias_tables, randomwalk.py:214-217
         raise ValueError(f"Zero return ({return_param}) or inout ({inout_param}) parameter!")
+    biased = not (return_param == 1.0 and inout_param == 1.0)
     if mode == "fast" and graph.slots is None:
         graph.build_alias()
-    if mode == "exact" and return_param == 1.0 and inout_param == 1.0 and graph.slots is None:
+    if mode == "exact" and graph.unit_weights:
+        # unit weights: the per-step table follows from two counts per edge, computed once
+        # (n2v_edge_classes_build, 4 bytes per edge); p == q == 1 needs nothing at all
+        if (use_edge_classes and biased and graph.edge_classes is None and _dyadic(return_param)
+                and _dyadic(inout_param)):
+            graph.build_edge_classes()
+    elif mode == "exact" and not biased and graph.slots is None:
         # the reference's default p = q = 1: every per-step table is the first-order table of
         # the current vertex, i.e. the K1 slots (bit-identical); build them once (milliseconds)
         try:
@@ -74,6 +90,8 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
         walks, valid = out
     status = torch.zeros(4, dtype=torch.int32, device=graph.device)  # include/n2v_hip.h
     g = graph.c_struct()
+    if not use_edge_classes:  # the wave-per-walker kernel (what a C caller without the counts gets)
+        g.edge_classes = 0
     with torch.cuda.device(graph.device):
         rc = L.n2v_walk(g, start_ids.data_ptr(), n_start, num_walks, walk_length,
                         float(return_param), float(inout_param), seed & (2 ** 64 - 1),

@@ -154,23 +154,34 @@ class SgnsModel:
     # -- epochs with linear decay ----------------------------------------------
     def train(self, walks_idx: torch.Tensor, epochs: int, alpha: float = 0.025,
               min_alpha: float = 1e-4, block_rows: Optional[int] = None,
-              sentence_base: int = 0, deterministic: bool = False, sync=None):
+              sentence_base: int = 0, deterministic: bool = False, sync=None,
+              rows_global_max: Optional[int] = None):
         """`epochs` passes over walks_idx; the learning rate falls linearly from alpha
         to min_alpha with the fraction of rows trained (gensim: by words, per job).
-        `sync`: optional callable run after every block (multi-GPU delta all-reduce)."""
+
+        `sync`: the multi-GPU exchange (DeltaSync, or any object with step()/finish()).
+        Every rank must then make the SAME number of calls to it, whatever its own row
+        count, so the block grid is laid over `rows_global_max` (the largest row count of
+        any rank, all-reduced by the caller): a rank whose shard is shorter -- or empty --
+        trains nothing in its last blocks but still takes part in every collective."""
         rows = walks_idx.shape[0]
+        grid_rows = max(rows, int(rows_global_max or 0))
         if block_rows is None:
-            block_rows = max(1, min(rows, max(65536, math.ceil(rows / 64))))
-        total = max(1, rows * max(epochs, 1))
+            block_rows = max(1, min(max(grid_rows, 1), max(65536, math.ceil(grid_rows / 64))))
+        total = max(1, grid_rows * max(epochs, 1))
         done = 0
         for ep in range(epochs):
-            for lo in range(0, rows, block_rows):
-                hi = min(rows, lo + block_rows)
+            for lo in range(0, max(grid_rows, 1), block_rows):
+                hi = min(grid_rows, lo + block_rows)
                 a = max(min_alpha, alpha - (alpha - min_alpha) * (done / total))
-                self.train_block(walks_idx[lo:hi], a, sentence_base + ep * rows + lo, deterministic)
+                if lo < rows:
+                    self.train_block(walks_idx[lo:min(hi, rows)], a,
+                                     sentence_base + ep * grid_rows + lo, deterministic)
                 done += hi - lo
                 if sync is not None:
-                    sync(self)
+                    sync.step()
+        if sync is not None:
+            sync.finish()
         self.sentences_seen += rows * epochs
         return self
 
@@ -187,31 +198,198 @@ def split_rows(walks_idx: torch.Tensor, max_len: int = MAX_SENTENCE) -> torch.Te
     return w.reshape(n * parts, max_len).contiguous()
 
 
-class DeltaAllReduce:
-    """Multi-GPU exchange step of the SGNS path: every rank trains
-    its own walks on a full replica; `sync` all-reduces the model deltas accumulated
-    since the last sync (RCCL over xGMI with backend "nccl"; gloo on CPU in tests)
-    and applies their mean (or sum) to the synchronised copy.  Row blocks bound the
-    temporary to `block_rows * dim` floats."""
+class DeltaSync:
+    """Multi-GPU exchange step of the SGNS path.  Every rank trains its
+    own walks on a full replica of syn0 / syn1neg; every `sync_every` launches the replicas
+    are averaged: new = mean over ranks (= the synchronised state + the mean of the deltas
+    trained since).  RCCL over xGMI with backend "nccl"; gloo on CPU tensors in the tests.
 
-    def __init__(self, model_tensors, group=None, mean: bool = True, block_rows: int = 1 << 20):
+    * `sync_every` None = chosen after the first exchange so that the collective takes at
+      most `comm_share` (10 %) of the time: ceil(t_sync * (1 - share) / (share * t_launch)),
+      agreed by a MAX all-reduce.  At cfg 4 (2 x 51 GB replicas) one exchange moves
+      2 x 51 GB (fp32) or 2 x 26 GB (bf16) per rank.
+    * wire "fp32": the rows themselves are summed -- no reference copy of the model exists
+      at all; wire "bf16": bf16(row - ref) against a bf16 reference shared by all ranks
+      (half the bytes on the links; + 2 bytes per element of HBM for the reference).
+    * No full clone: rows go through two reusable buffers of `block_rows` rows.
+    * overlap: on the GPU the whole exchange runs on a side stream, block by block (pack,
+      all-reduce, apply), while the main stream keeps training; `apply` adds mean - snapshot,
+      so what was trained meanwhile is kept.  finish() drains it and ends with one blocking
+      exchange that leaves all replicas bit-identical.
+    Every rank must call step() the same number of times (SgnsModel.train sees to that)."""
+
+    def __init__(self, model_or_tensors, group=None, sync_every: Optional[int] = None,
+                 wire: str = "fp32", block_rows: int = 1 << 20, overlap: bool = True,
+                 comm_share: float = 0.10):
         import torch.distributed as dist
 
-        self.dist, self.group, self.mean, self.block_rows = dist, group, mean, block_rows
-        self.tensors = list(model_tensors)
-        self.synced = [t.clone() for t in self.tensors]
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.active = dist.is_initialized()
+        if wire not in ("fp32", "bf16"):
+            raise ValueError(f"unknown wire format {wire!r}")
+        tensors = ([model_or_tensors.syn0, model_or_tensors.syn1neg]
+                   if hasattr(model_or_tensors, "syn0") else list(model_or_tensors))
+        self.dist, self.group = dist, group
+        self.tensors = [t for t in tensors]
+        for t in self.tensors:
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise TypeError("DeltaSync wants contiguous float32 matrices")
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.wire, self.block_rows, self.comm_share = wire, int(block_rows), float(comm_share)
+        self.sync_every = None if sync_every is None else max(1, int(sync_every))
+        self.calls = 0
+        self.syncs = 0
+        self.on_gpu = all(t.is_cuda for t in self.tensors)
+        self.side = torch.cuda.Stream(self.tensors[0].device) if (overlap and self.on_gpu) else None
+        self._pending = None
+        self._t_sync = None
+        self._t_mark = None
+        self._before = self._wire = None
+        self.refs = None
+        if wire == "bf16" and self.world > 1:
+            self.refs = [self._ref_init(t) for t in self.tensors]
 
-    def __call__(self, _model=None):
-        if not self.active:
-            return
-        for t, s in zip(self.tensors, self.synced):
+    # -- sizes reported by bench.py ------------------------------------------------------
+    @property
+    def wire_dtype_name(self) -> str:
+        return self.wire
+
+    @property
+    def wire_bytes(self) -> int:
+        return sum(t.numel() for t in self.tensors) * (4 if self.wire == "fp32" else 2)
+
+    # -- elementwise passes: HIP kernels on the GPU, torch on CPU tensors (gloo tests) ------
+    def _ref_init(self, t):
+        ref = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+        if t.is_cuda:
+            L = _lib.load()
+            with torch.cuda.device(t.device):
+                _lib.check(L.n2v_delta_ref_init(t.data_ptr(), t.numel(), ref.data_ptr(),
+                                                _lib.current_stream_ptr()), "n2v_delta_ref_init")
+        else:
+            ref.copy_(t)
+        return ref
+
+    def _buffers(self, like):
+        n = min(self.block_rows, max(t.shape[0] for t in self.tensors)) * max(
+            t.shape[1] if t.dim() > 1 else 1 for t in self.tensors)
+        if self._before is None or self._before.numel() < n or self._before.device != like.device:
+            self._before = torch.empty(n, dtype=torch.float32, device=like.device)
+            self._wire = torch.empty(n, dtype=torch.float32 if self.wire == "fp32" else torch.bfloat16,
+                                     device=like.device)
+        return self._before, self._wire
+
+    def _pack(self, cur, ref, before, wire):
+        if cur.is_cuda:
+            L = _lib.load()
+            _lib.check(L.n2v_delta_pack(cur.data_ptr(), 0 if ref is None else ref.data_ptr(),
+                                        cur.numel(), 0 if before is None else before.data_ptr(),
+                                        wire.data_ptr(),
+                                        _lib.WIRE_F32 if self.wire == "fp32" else _lib.WIRE_BF16,
+                                        _lib.current_stream_ptr()), "n2v_delta_pack")
+        else:
+            if before is not None:
+                before.copy_(cur.reshape(-1))
+            wire.copy_(cur.reshape(-1) if ref is None else cur.reshape(-1) - ref.reshape(-1).float())
+
+    def _apply(self, cur, ref, before, wire):
+        if cur.is_cuda:
+            L = _lib.load()
+            _lib.check(L.n2v_delta_apply(cur.data_ptr(), 0 if ref is None else ref.data_ptr(),
+                                         0 if before is None else before.data_ptr(), wire.data_ptr(),
+                                         _lib.WIRE_F32 if self.wire == "fp32" else _lib.WIRE_BF16,
+                                         self.world, cur.numel(), _lib.current_stream_ptr()),
+                       "n2v_delta_apply")
+        else:
+            flat = cur.reshape(-1)
+            if ref is None:
+                mean = wire / self.world
+            else:
+                mean = ref.reshape(-1).float() + wire.float() / self.world
+                ref.reshape(-1).copy_(mean)
+            if before is None:
+                flat.copy_(mean)
+            else:
+                flat.add_(mean - before)
+
+    def _exchange(self, exact: bool = False):
+        """pack / all-reduce / apply over all matrices, block by block, on the current stream;
+        `exact` (nothing trains meanwhile): rows are SET to the mean, no snapshot"""
+        for k, t in enumerate(self.tensors):
+            ref = None if self.refs is None else self.refs[k]
+            before, wire = self._buffers(t)
             for lo in range(0, t.shape[0], self.block_rows):
                 hi = min(t.shape[0], lo + self.block_rows)
-                d = t[lo:hi] - s[lo:hi]
-                self.dist.all_reduce(d, op=self.dist.ReduceOp.SUM, group=self.group)
-                if self.mean:
-                    d.div_(self.world)
-                s[lo:hi].add_(d)
-                t[lo:hi].copy_(s[lo:hi])
+                cur = t[lo:hi]
+                n = cur.numel()
+                snap = None if exact else before[:n]
+                self._pack(cur, None if ref is None else ref[lo:hi], snap, wire[:n])
+                self.dist.all_reduce(wire[:n], op=self.dist.ReduceOp.SUM, group=self.group)
+                self._apply(cur, None if ref is None else ref[lo:hi], snap, wire[:n])
+
+    # -- the protocol -------------------------------------------------------------------------
+    def sync(self, blocking: bool = False):
+        if not self.active or self.world == 1:
+            return
+        self.syncs += 1
+        if self.side is None or blocking:
+            self._drain()
+            self._exchange(exact=True)
+            return
+        main = torch.cuda.current_stream(self.tensors[0].device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.side.wait_event(ev)  # everything trained so far is visible to the exchange
+        with torch.cuda.stream(self.side):
+            self._exchange()
+            self._pending = torch.cuda.Event()
+            self._pending.record(self.side)
+
+    def _drain(self):
+        if self._pending is not None:
+            torch.cuda.current_stream(self.tensors[0].device).wait_event(self._pending)
+            self._pending = None
+
+    def step(self):
+        """call after every training launch, on every rank"""
+        self.calls += 1
+        if not self.active or self.world == 1:
+            return
+        if self.sync_every is None:
+            self._autotune()
+        elif self.calls % self.sync_every == 0:
+            self.sync()
+
+    def _autotune(self):
+        import time
+
+        def now():
+            if self.on_gpu:
+                torch.cuda.synchronize(self.tensors[0].device)
+            return time.perf_counter()
+
+        if self._t_sync is None:  # first call: one timed blocking exchange
+            t0 = now()
+            self.sync(blocking=True)
+            self._t_mark = now()
+            self._t_sync = self._t_mark - t0
+            return
+        t_launch = max(now() - self._t_mark, 1e-6)  # one training launch since then
+        share = min(max(self.comm_share, 1e-3), 0.999)
+        every = max(1, math.ceil(self._t_sync * (1.0 - share) / (share * t_launch)))
+        dev = self.tensors[0].device
+        v = torch.tensor([every], dtype=torch.int64, device=dev)
+        self.dist.all_reduce(v, op=self.dist.ReduceOp.MAX, group=self.group)
+        self.sync_every = int(v.item())
+        self.calls = 0  # periods count from here
+
+    def finish(self):
+        """drain the side stream and average once more, blocking: all replicas identical"""
+        if not self.active or self.world == 1:
+            return
+        self._drain()
+        self.sync(blocking=True)
+
+    __call__ = sync  # the old DeltaAllReduce was called like a function
+
+
+DeltaAllReduce = DeltaSync

@@ -8,11 +8,17 @@ import torch
 from node2vec_amd.graph import DeviceGraph
 
 
-def _symmetrize_dedupe(src, dst, n):
+def _symmetrize_dedupe_keys(src, dst, n):
+    """sorted unique keys src * n + dst of the symmetrised graph without self-loops"""
     keep = src != dst
     src, dst = src[keep], dst[keep]
     key = torch.cat([src * n + dst, dst * n + src])
-    key = torch.unique(key)
+    del src, dst
+    return torch.unique(key)
+
+
+def _symmetrize_dedupe(src, dst, n):
+    key = _symmetrize_dedupe_keys(src, dst, n)
     return key // n, key % n
 
 
@@ -29,11 +35,10 @@ def rmat(scale: int, n_draws: int, a=0.57, b=0.19, c=0.19, seed=42, device=None,
         r = torch.rand(n_draws, generator=gen, device=device)
         src = src * 2 + (r >= ab).long()
         dst = dst * 2 + (((r >= a) & (r < ab)) | (r >= abc)).long()
+    if weights != "uniform":
+        return DeviceGraph.from_sorted_keys(_symmetrize_dedupe_keys(src, dst, n), n)
     s, d = _symmetrize_dedupe(src, dst, n)
-    if weights == "uniform":
-        w = torch.rand(s.numel(), generator=gen, device=device) * 1.9 + 0.1
-    else:
-        w = torch.ones(s.numel(), device=device)
+    w = torch.rand(s.numel(), generator=gen, device=device) * 1.9 + 0.1
     return DeviceGraph.from_edges(s, d, w, n_vertices=n, device=device)
 
 
@@ -50,9 +55,7 @@ def chung_lu(n: int, n_draws: int, gamma=2.1, seed=42, device=None) -> DeviceGra
         x = ((n + 1.0) ** e - 1.0) * u + 1.0
         return (x ** (1.0 / e)).long().clamp_(1, n) - 1
 
-    s, d = _symmetrize_dedupe(draw(n_draws), draw(n_draws), n)
-    w = torch.ones(s.numel(), device=device)
-    return DeviceGraph.from_edges(s, d, w, n_vertices=n, device=device)
+    return DeviceGraph.from_sorted_keys(_symmetrize_dedupe_keys(draw(n_draws), draw(n_draws), n), n)
 
 
 def hub_bipartite(n: int, n_hubs: int, hub_degree: int, seed=42, device=None) -> DeviceGraph:
@@ -64,6 +67,4 @@ def hub_bipartite(n: int, n_hubs: int, hub_degree: int, seed=42, device=None) ->
     ls = torch.randint(0, n_leaf, (n_hubs * hub_degree,), generator=gen, device=device) + n_hubs
     l2 = torch.arange(n_leaf, device=device) + n_hubs
     h2 = torch.randint(0, n_hubs, (n_leaf,), generator=gen, device=device)
-    s, d = _symmetrize_dedupe(torch.cat([hs, h2]), torch.cat([ls, l2]), n)
-    w = torch.ones(s.numel(), device=device)
-    return DeviceGraph.from_edges(s, d, w, n_vertices=n, device=device)
+    return DeviceGraph.from_sorted_keys(_symmetrize_dedupe_keys(torch.cat([hs, h2]), torch.cat([ls, l2]), n), n)

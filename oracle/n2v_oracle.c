@@ -62,6 +62,13 @@ int n2v_oracle_alias_tables(const double *node_weights, int64_t n,
   return rc;
 }
 
+/* weight of edge e as the fp64 the reference computes with (randomwalk.py:20 keeps Python
+ * floats): fp64 storage, else fp32 storage widened, else 1.0 (indexer.py:20-21) */
+static inline double csr_weight(const n2v_oracle_csr *g, int64_t e) {
+  if (g->w64) return g->w64[e];
+  return g->w ? (double)g->w[e] : 1.0;
+}
+
 /* `x in src_nbs_id` (randomwalk.py:226) on the sorted neighbour list */
 static int contains_sorted(const int32_t *a, int64_t n, int32_t x) {
   int64_t lo = 0, hi = n;
@@ -239,7 +246,7 @@ static int walk_one(const n2v_oracle_csr *g, int32_t start, int32_t ordinal,
     if (n == 0) return N2V_ORACLE_OK;
     if (ws_reserve(ws, n)) return N2V_ORACLE_ENOMEM;
     const int32_t *dst_ids = g->col + vb;
-    for (int64_t i = 0; i < n; ++i) ws->wd[i] = (double)g->w[vb + i];
+    for (int64_t i = 0; i < n; ++i) ws->wd[i] = csr_weight(g, vb + i);
     int rc;
     if (src < 0) { /* randomwalk.py:320-321 */
       rc = alias_tables_ws(ws->wd, n, ws->alias, ws->probs, ws->stk, ws->stk + n);
@@ -291,7 +298,7 @@ int n2v_oracle_random_walk(const n2v_oracle_csr *g, const int32_t *start_ids,
   {
     walk_ws ws;
     memset(&ws, 0, sizeof(ws));
-#pragma omp for schedule(dynamic, 64)
+#pragma omp for schedule(dynamic, 4)
     for (int64_t r = 0; r < total; ++r) {
       int32_t start = start_ids[r / num_walks];
       int32_t ordinal = (int32_t)(r % num_walks) + 1; /* randomwalk.py:294 */
@@ -317,7 +324,7 @@ int n2v_oracle_transition_probs(const n2v_oracle_csr *g, int64_t s, int64_t v,
   if (n <= 0) return N2V_ORACLE_EZERODIV;
   double *wd = (double *)malloc(sizeof(double) * (size_t)n);
   if (!wd) return N2V_ORACLE_ENOMEM;
-  for (int64_t i = 0; i < n; ++i) wd[i] = (double)g->w[vb + i];
+  for (int64_t i = 0; i < n; ++i) wd[i] = csr_weight(g, vb + i);
   if (s >= 0) {
     int64_t sb = g->rowptr[s], m = g->rowptr[s + 1] - sb;
     edge_bias(s, g->col + sb, m, g->col + vb, wd, n, return_param, inout_param,
@@ -362,6 +369,35 @@ int n2v_oracle_trim_mark(const int64_t *rowptr, int64_t n_rows, int64_t max_out_
       int take = (int64_t)mulhi64(u, (uint64_t)(d - i)) < need;
       keep_out[b + i] = (uint8_t)take;
       need -= take;
+    }
+  }
+  return N2V_ORACLE_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Class counts of the table of randomwalk.py:219-231 on a unit-weight graph */
+/* ------------------------------------------------------------------------ */
+/* For every edge e = (s -> v): how many neighbours x of v take the branch x == s (:223)
+ * and how many the branch x in src_nbs_id (:226), evaluated exactly as the reference does
+ * (walk N(v), test each id).  Checker for n2v_edge_classes_build; same packing
+ * (bits 0..23 shared, 24..31 return, saturating). */
+int n2v_oracle_edge_classes(const n2v_oracle_csr *g, uint32_t *classes_out) {
+  for (int64_t s = 0; s < g->n_vertices; ++s) {
+    const int64_t sb = g->rowptr[s], ds = g->rowptr[s + 1] - sb;
+    for (int64_t e = sb; e < sb + ds; ++e) {
+      const int64_t v = g->col[e];
+      const int64_t vb = g->rowptr[v], dv = g->rowptr[v + 1] - vb;
+      uint32_t n_ret = 0, n_sh = 0;
+      for (int64_t j = 0; j < dv; ++j) {
+        const int32_t x = g->col[vb + j];
+        if ((int64_t)x == s)
+          ++n_ret;
+        else if (contains_sorted(g->col + sb, ds, x))
+          ++n_sh;
+      }
+      if (n_ret > 0xffu) n_ret = 0xffu;
+      if (n_sh > 0xffffffu) n_sh = 0xffffffu;
+      classes_out[e] = (n_ret << 24) | n_sh;
     }
   }
   return N2V_ORACLE_OK;

@@ -32,12 +32,14 @@ extern "C" {
 
 /* CSR view of the reference's df_adj (fugue.py:130): one row per source vertex,
  * neighbours sorted by dst id ascending (presort="dst"), multi-edges kept.
- * Weights are fp32 in storage and widened to fp64 before any arithmetic. */
+ * Weights: fp64 (`w64`, what the reference's Python floats are) or fp32 storage (`w`,
+ * widened to fp64 before any arithmetic); both NULL = every weight 1.0. */
 typedef struct {
   int64_t n_vertices;
   const int64_t *rowptr; /* [n_vertices + 1] */
   const int32_t *col;    /* [n_edges] */
-  const float *w;        /* [n_edges] */
+  const float *w;        /* [n_edges] or NULL */
+  const double *w64;     /* [n_edges] or NULL */
 } n2v_oracle_csr;
 
 /* randomwalk.py:157-190 generate_alias_tables */
@@ -102,6 +104,10 @@ int n2v_oracle_transition_probs(const n2v_oracle_csr *g, int64_t s, int64_t v,
  * surviving edges (exactly max_out_degree per row above the cap). */
 int n2v_oracle_trim_mark(const int64_t *rowptr, int64_t n_rows, int64_t max_out_degree,
                          uint64_t seed, uint8_t *keep_out);
+
+/* Per-edge class counts of the table of randomwalk.py:219-231 on a unit-weight graph
+ * (checker for n2v_edge_classes_build of include/n2v_hip.h, same packing). */
+int n2v_oracle_edge_classes(const n2v_oracle_csr *g, uint32_t *classes_out);
 
 /* n2v_oracle_sgns.c (PARITY UNPINNED, see its header) */
 int64_t n2v_oracle_sgns_train(const int32_t *walks, int64_t n_walks, int32_t walk_len,

@@ -17,7 +17,23 @@ OK, EINVAL, EZERODIV, ENOMEM = 0, -1, -2, -3
 
 class CSR(C.Structure):
     _fields_ = [("n_vertices", C.c_int64), ("rowptr", C.c_void_p),
-                ("col", C.c_void_p), ("w", C.c_void_p)]
+                ("col", C.c_void_p), ("w", C.c_void_p), ("w64", C.c_void_p)]
+
+
+def _csr(rowptr, col, w):
+    """(struct, keep-alive tuple): w None = unit weights, float64 = fp64 storage, else fp32"""
+    rowptr = np.ascontiguousarray(rowptr, np.int64)
+    col = np.ascontiguousarray(col, np.int32)
+    w32 = w64 = None
+    if w is not None:
+        w = np.asarray(w)
+        if w.dtype == np.float64:
+            w64 = np.ascontiguousarray(w)
+        else:
+            w32 = np.ascontiguousarray(w, np.float32)
+    g = CSR(len(rowptr) - 1, _p(rowptr).value, _p(col).value,
+            None if w32 is None else _p(w32).value, None if w64 is None else _p(w64).value)
+    return g, (rowptr, col, w32, w64)
 
 
 def build():
@@ -38,6 +54,7 @@ def lib():
         L.n2v_oracle_path_append.restype = C.c_int
         L.n2v_oracle_random_walk.restype = C.c_int
         L.n2v_oracle_transition_probs.restype = C.c_int
+        L.n2v_oracle_edge_classes.restype = C.c_int
         L.n2v_oracle_sgns_train.restype = C.c_int64
         _LIB = L
     return _LIB
@@ -132,11 +149,8 @@ def csr_from_edges(edges, n_vertices=None):
 
 
 def random_walk(rowptr, col, w, start_ids, num_walks, walk_length, p, q, seed, n_threads=1):
-    rowptr = np.ascontiguousarray(rowptr, np.int64)
-    col = np.ascontiguousarray(col, np.int32)
-    w = np.ascontiguousarray(w, np.float32)
+    g, _keep = _csr(rowptr, col, w)
     start = np.ascontiguousarray(start_ids, np.int32)
-    g = CSR(len(rowptr) - 1, _p(rowptr).value, _p(col).value, _p(w).value)
     total = len(start) * num_walks
     walks = np.full((total, walk_length + 1), -1, np.int32)
     valid = np.zeros(total, np.uint8)
@@ -148,15 +162,19 @@ def random_walk(rowptr, col, w, start_ids, num_walks, walk_length, p, q, seed, n
 
 
 def transition_probs(rowptr, col, w, s, v, p, q):
-    rowptr = np.ascontiguousarray(rowptr, np.int64)
-    col = np.ascontiguousarray(col, np.int32)
-    w = np.ascontiguousarray(w, np.float32)
-    g = CSR(len(rowptr) - 1, _p(rowptr).value, _p(col).value, _p(w).value)
+    g, _keep = _csr(rowptr, col, w)
     n = int(rowptr[v + 1] - rowptr[v])
     out = np.zeros(max(n, 1), np.float64)
     _raise(lib().n2v_oracle_transition_probs(C.byref(g), C.c_int64(s), C.c_int64(v),
                                              C.c_double(p), C.c_double(q), _p(out)))
     return out[:n]
+
+
+def edge_classes(rowptr, col):
+    g, _keep = _csr(rowptr, col, None)
+    out = np.zeros(max(len(col), 1), np.uint32)
+    _raise(lib().n2v_oracle_edge_classes(C.byref(g), _p(out)))
+    return out[:len(col)]
 
 
 def sgns_train(walks_idx, syn0, syn1neg, cum_table, sample_int, exp_table, n_vocab,

@@ -16,7 +16,8 @@ def _declared():
 def test_header_declares_the_expected_entry_points():
     names = _declared()
     for want in ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alias_build", "n2v_pivots_build",
-                 "n2v_walk", "n2v_trim_mark", "n2v_sgns_train"):
+                 "n2v_edge_classes_build", "n2v_walk", "n2v_trim_mark", "n2v_sgns_train",
+                 "n2v_delta_ref_init", "n2v_delta_pack", "n2v_delta_apply"):
         assert want in names
 
 
@@ -31,7 +32,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert sorted(_lib.SYMBOLS) == _declared()
     lib.n2v_abi_version.restype = ctypes.c_int
-    assert lib.n2v_abi_version() == 3
+    assert lib.n2v_abi_version() == _lib.ABI_VERSION == 4
     lib.n2v_status_string.restype = ctypes.c_char_p
     assert lib.n2v_status_string(-1) == b"invalid argument"
 
@@ -40,9 +41,14 @@ def test_ctypes_structs_match_header_layout():
     """sizeof / field order of the two structs passed by pointer"""
     from node2vec_amd import _lib
 
-    assert ctypes.sizeof(_lib.Graph) == 7 * 8
-    assert [f[0] for f in _lib.Graph._fields_] == ["n_vertices", "n_edges", "rowptr", "col", "w", "slots",
-                                                    "pivots"]
+    assert ctypes.sizeof(_lib.Graph) == 9 * 8
+    assert [f[0] for f in _lib.Graph._fields_] == ["n_vertices", "n_edges", "rowptr", "col", "w", "w64",
+                                                    "slots", "pivots", "edge_classes"]
+    # the header's field order, read from the header itself
+    text = open(os.path.join(ROOT, "include", "n2v_hip.h")).read()
+    body = text[text.index("typedef struct n2v_graph {"):text.index("} n2v_graph;")]
+    fields = re.findall(r"\*?\s*\b(\w+);", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    assert fields == [f[0] for f in _lib.Graph._fields_]
     assert ctypes.sizeof(_lib.SgnsParams) == 3 * 8 + 6 * 4
     assert [f[0] for f in _lib.SgnsParams._fields_] == [
         "n_vocab", "sentence_base", "seed", "dim", "window", "negative", "alpha",

@@ -20,29 +20,79 @@ def _worker(rank, world, port, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from node2vec_amd.sgns import DeltaAllReduce
+        from node2vec_amd.sgns import DeltaSync
         from node2vec_amd.shard import shard_range
 
         torch.manual_seed(0)
         base0, base1 = torch.randn(37, 8), torch.randn(37, 8)  # same on every rank
-        syn0, syn1 = base0.clone(), base1.clone()
-        sync = DeltaAllReduce([syn0, syn1], mean=True, block_rows=16)
-        g = torch.Generator().manual_seed(100 + rank)
-        d0, d1 = torch.randn(37, 8, generator=g), torch.randn(37, 8, generator=g)
-        syn0 += d0  # "local training" since the last sync
-        syn1 += d1
-        sync()
-        # every rank must hold base + mean of all ranks' deltas
-        all_d0 = [torch.randn(37, 8, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
-        want0 = base0 + sum(all_d0) / world
-        ok = torch.allclose(syn0, want0, atol=1e-6)
-        gathered = [torch.zeros_like(syn1) for _ in range(world)]
-        dist.all_gather(gathered, syn1)
-        ok = ok and all(torch.equal(gathered[0], x) for x in gathered)
-        # a second round starts from the synchronised copy
-        syn0 += 1.0 if rank == 0 else 3.0
-        sync()
-        ok = ok and torch.allclose(syn0, want0 + 2.0, atol=1e-6)
+        ok = True
+        for wire, tol in (("fp32", 1e-6), ("bf16", 2e-2)):
+            syn0, syn1 = base0.clone(), base1.clone()
+            sync = DeltaSync([syn0, syn1], block_rows=16, sync_every=1, wire=wire)
+            g = torch.Generator().manual_seed(100 + rank)
+            d0, d1 = torch.randn(37, 8, generator=g), torch.randn(37, 8, generator=g)
+            syn0 += d0  # "local training" since the last exchange
+            syn1 += d1
+            sync.step()
+            # every rank must hold base + mean of all ranks' deltas
+            all_d0 = [torch.randn(37, 8, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+            want0 = base0 + sum(all_d0) / world
+            ok = ok and torch.allclose(syn0, want0, atol=tol)
+            gathered = [torch.zeros_like(syn1) for _ in range(world)]
+            dist.all_gather(gathered, syn1)
+            ok = ok and all(torch.equal(gathered[0], x) for x in gathered)  # identical replicas
+            # a second round starts from the synchronised state
+            syn0 += 1.0 if rank == 0 else 3.0
+            sync.step()
+            ok = ok and torch.allclose(syn0, want0 + 2.0, atol=2 * tol)
+            sync.finish()
+            ok = ok and sync.syncs == 3
+        # period logic: 7 launches at sync_every=3 -> exchanges after launches 3 and 6 + finish()
+        t = torch.zeros(4, 2) + rank
+        sync = DeltaSync([t], sync_every=3)
+        seen = []
+        for k in range(7):
+            t += 1.0
+            sync.step()
+            seen.append(sync.syncs)
+        sync.finish()
+        ok = ok and seen == [0, 0, 1, 1, 1, 2, 2] and sync.syncs == 3
+        ok = ok and torch.allclose(t, torch.full((4, 2), 7.5))  # mean of (0 + 7, 1 + 7)
+        # SgnsModel.train with UNEVEN shards: rank 0 holds 5 rows, rank 1 holds 9; with blocks of
+        # 4 rows rank 0 has 2 blocks of its own, rank 1 has 3 -- both must run the grid of the
+        # largest shard (3 blocks x 2 epochs) or the collectives dead-lock
+        from node2vec_amd import sgns
+
+        class _Model(sgns.SgnsModel):
+            def __init__(self):  # no vocabulary, no kernel: the loop structure only
+                self.sentences_seen = 0
+                self.launched = []
+
+            def train_block(self, walks_idx, alpha, sentence_base, deterministic=False):
+                self.launched.append((walks_idx.shape[0], sentence_base))
+
+        class _Sync:
+            def __init__(self):
+                self.steps = 0
+
+            def step(self):
+                self.steps += 1
+                x = torch.ones(1)
+                dist.all_reduce(x)  # a real collective: uneven call counts would hang here
+
+            def finish(self):
+                self.steps += 100
+
+        rows = 5 if rank == 0 else 9
+        rmax = torch.tensor([rows])
+        dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
+        m, sy = _Model(), _Sync()
+        m.train(torch.zeros((rows, 3), dtype=torch.int32), epochs=2, block_rows=4, sync=sy,
+                rows_global_max=int(rmax))
+        ok = ok and sy.steps == 106
+        want_rows = [4, 1, 4, 1] if rank == 0 else [4, 4, 1, 4, 4, 1]
+        ok = ok and [r for r, _ in m.launched] == want_rows
+        ok = ok and len({b for _, b in m.launched}) == len(m.launched)  # sentence ids never repeat
         # walk sharding: ranges are disjoint and cover all start vertices
         lo, hi = shard_range(1001, rank, world)
         cover = torch.zeros(1001)
@@ -71,12 +121,13 @@ def test_delta_all_reduce_and_sharding_world2():
     assert dict(ret) == {0: True, 1: True}
 
 
-def test_delta_all_reduce_is_identity_on_one_rank():
-    from node2vec_amd.sgns import DeltaAllReduce
+def test_delta_sync_is_identity_on_one_rank():
+    from node2vec_amd.sgns import DeltaSync
 
     t = torch.randn(5, 4)
     want = t.clone() + 1
-    sync = DeltaAllReduce([t])
+    sync = DeltaSync([t])
     t += 1
-    sync()
+    sync.step()
+    sync.finish()
     assert torch.equal(t, want) and np.isfinite(t.numpy()).all()
