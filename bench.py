@@ -298,10 +298,12 @@ def main():
 
 def kernel_name(g, p, q):
     """the kernel n2v_walk dispatches exact mode to (node2vec_amd/csrc/n2v_capi.hip)"""
-    from node2vec_amd.randomwalk import _dyadic
+    from node2vec_amd.randomwalk import lanes_regime
 
     if g.unit_weights:
-        if (p == 1.0 and q == 1.0) or (_dyadic(p) and _dyadic(q) and g.edge_classes is not None):
+        if p == 1.0 and q == 1.0:
+            return "walk_uniform_kernel"
+        if lanes_regime(p, q) and g.edge_classes is not None:
             return "walk_exact_unit_lanes_kernel"
         return "walk_exact_unit_kernel"
     return "walk_fast_kernel" if (p == 1.0 and q == 1.0) else "walk_exact_kernel"

@@ -11,8 +11,8 @@ constexpr int kLdsChunks = 128;  // class ballots kept in LDS for rows <= 8192
 
 // diagnostic build only (-DN2V_STATS): per-wave counters / cycle stamps, flushed once
 #ifdef N2V_STATS
-static __device__ unsigned long long n2v_stats[32];  // one copy per translation unit
-struct WaveStats { unsigned long long v[32]; };
+static __device__ unsigned long long n2v_stats[40];  // one copy per translation unit
+struct WaveStats { unsigned long long v[40]; };
 #define N2V_STATS_ARG , WaveStats &WS
 #define N2V_STATS_PASS , WS
 #define N2V_STAT(i, v_) do { WS.v[i] += (unsigned long long)(v_); } while (0)

@@ -10,6 +10,10 @@ int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_ids, int64_
                             int32_t num_walks, int32_t walk_length, double p, double q,
                             uint64_t seed, int32_t *walks_out, uint8_t *valid_out,
                             uint32_t *status, void *stream);
+int n2v_walk_uniform_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
+                         int32_t num_walks, int32_t walk_length, double p, double q,
+                         uint64_t seed, int32_t *walks_out, uint8_t *valid_out,
+                         uint32_t *status, void *stream);
 int n2v_walk_fast_launch(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
                          int32_t num_walks, int32_t walk_length, double p, double q,
                          uint64_t seed, int32_t *walks_out, uint8_t *valid_out,
@@ -47,7 +51,12 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start, int3
   if (!any) return (mode == N2V_WALK_EXACT || mode == N2V_WALK_FAST) ? N2V_OK : N2V_EINVAL;
   if (g->w && g->w64) return N2V_EINVAL;  // one storage form at most
   if (mode == N2V_WALK_EXACT) {
-    // every weight 1.0 (w == w64 == NULL): the specialised kernels (n2v_walk_unit.hip)
+    // every weight 1.0 (w == w64 == NULL): the specialised kernels -- p == q == 1 is two
+    // gathers per step (n2v_walk_uniform.hip), other p, q n2v_walk_unit.hip
+    const int ru = n2v_walk_uniform_try(g, start_ids, n_start, num_walks, walk_length,
+                                        return_param, inout_param, seed, walks_out, valid_out,
+                                        status, stream);
+    if (ru != 0) return ru < 0 ? ru : N2V_OK;
     const int rc = n2v_walk_exact_unit_try(g, start_ids, n_start, num_walks, walk_length,
                                            return_param, inout_param, seed, walks_out,
                                            valid_out, status, stream);

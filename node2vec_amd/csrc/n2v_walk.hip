@@ -441,7 +441,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
   c.q = q;
 #ifdef N2V_STATS
   WaveStats WS;
-  for (int i = 0; i < 32; ++i) WS.v[i] = 0;
+  for (int i = 0; i < 40; ++i) WS.v[i] = 0;
   const unsigned long long t_kernel0 = __builtin_readcyclecounter();
 #endif
 
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
 #ifdef N2V_STATS
   WS.v[23] = __builtin_readcyclecounter() - t_kernel0;
   if (lane == 0)
-    for (int i = 0; i < 32; ++i) atomicAdd(&n2v_stats[i], WS.v[i]);
+    for (int i = 0; i < 40; ++i) atomicAdd(&n2v_stats[i], WS.v[i]);
 #endif
 }
 
@@ -585,9 +585,9 @@ extern "C" int n2v_walk_exact_launch(const n2v_graph *g, const int32_t *start_id
 
 #ifdef N2V_STATS
 extern "C" int n2v_debug_stats(unsigned long long *out_host, int reset) {
-  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(n2v::n2v_stats), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(n2v::n2v_stats), sizeof(unsigned long long) * 40) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[32] = {0};
+    unsigned long long z[40] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(n2v::n2v_stats), z, sizeof(z)) != hipSuccess) return -1;
   }
   return 0;

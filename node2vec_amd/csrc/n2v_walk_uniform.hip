@@ -1,0 +1,137 @@
+// n2v_walk_uniform.hip -- K2 exact mode on a unit-weight graph with p == q == 1 (the
+// reference's defaults, constants.py:22,26; BASELINE cfg 4).
+//
+// With every weight 1.0 and p == q == 1 the table generate_edge_alias_tables builds at a
+// step (reference randomwalk.py:193-232) has probs == [1.0] * n exactly (the row sum of
+// :172 is the integer n, n / n == 1.0, every x / 1.0 == 1.0), no slot is underfull, the loop
+// of :182 never runs, and sampling_from_alias(r1, r2) (:86-99) returns pick = int(r1 * n)
+// whatever r2 is.  A step is therefore two dependent gathers -- the row pointer pair of the
+// current vertex and col[row + pick] -- and the kernel is bound by the chip's rate of random
+// 64-byte sector reads (scripts/micro/gather_ceiling.hip: ~25-27 G such steps/s), so what it
+// can save is requests:
+//   * one LANE per walker, 8 waves per SIMD, nothing else in flight;
+//   * the path is NOT stored word by word (a 4-byte store into a 324-byte-pitch row costs a
+//     32-byte write request each, as many requests as the reads): every lane keeps the 16
+//     words of the 64-byte sector of walks_out it is currently filling in registers
+//     (selected by a v_cndmask chain, no scratch) and stores the sector whole when it is
+//     complete -- four aligned 16-byte stores per 16 steps.
+// Same uniform stream as every other kernel (step_bits, n2v_common.h): bit-identical walks.
+#include "n2v_common.h"
+
+namespace n2v {
+
+__global__ __launch_bounds__(256, 8) void walk_uniform_kernel(
+    n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
+    int32_t walk_length, uint64_t seed, int32_t *__restrict__ walks_out,
+    uint8_t *__restrict__ valid_out, uint32_t *__restrict__ status) {
+  const int lane = threadIdx.x & 63;
+  const int64_t total = n_start * (int64_t)num_walks;
+  const int L1 = walk_length + 1;
+  // whole sectors need a 64-byte aligned output base (torch / hipMalloc give >= 256)
+  const bool base_aligned = (reinterpret_cast<uintptr_t>(walks_out) & 63u) == 0;
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&status[1], 64u);
+    const int64_t base = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (base >= total) break;
+    const int64_t r = base + lane;
+    const bool have = r < total;
+    int32_t v = -1;
+    uint64_t h0 = 0;
+    bool alive = have;
+    if (have) {
+      v = start_ids[r / num_walks];
+      const int32_t ordinal = (int32_t)(r % num_walks) + 1;
+      h0 = walker_stream(seed, (uint64_t)v * (uint64_t)num_walks + (uint64_t)(ordinal - 1));
+      if (v < 0 || (int64_t)v >= g.n_vertices) {
+        atomicOr(status, N2V_ST_RANGE);
+        alive = false;
+      }
+    }
+    int64_t vb = 0;
+    int n = 0;
+    if (alive) {
+      vb = g.rowptr[v];
+      n = (int)(g.rowptr[v + 1] - vb);
+      alive = n > 0;  // fugue.py:132
+    }
+    bool walking = alive;
+    // absolute word index of path position 0; word a lives in buf[a & 15]
+    const int64_t w0 = r * (int64_t)L1;
+    int32_t buf[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) buf[k] = -1;
+    int lo = (int)(w0 & 15);  // first word of the current sector that belongs to this row
+    auto put = [&](int64_t a, int32_t x) {
+      const int k = (int)(a & 15);
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) buf[kk] = (k == kk) ? x : buf[kk];
+    };
+    auto flush = [&](int64_t a) {  // words [sector(a) + lo, a] are complete: store them
+      const int k = (int)(a & 15);
+      int32_t *sec = walks_out + (a & ~(int64_t)15);
+      if (lo == 0 && k == 15 && base_aligned) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          reinterpret_cast<int4 *>(sec)[u] =
+              make_int4(buf[4 * u], buf[4 * u + 1], buf[4 * u + 2], buf[4 * u + 3]);
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+          if (kk >= lo && kk <= k) sec[kk] = buf[kk];
+      }
+      lo = 0;
+    };
+    if (have) {
+      put(w0, alive ? v : -1);
+      if ((w0 & 15) == 15 || walk_length == 0) flush(w0);
+    }
+    for (int step = 0; step < walk_length; ++step) {
+      if (ballot64(have) == 0ull) break;
+      int32_t x = -1;
+      if (walking) {
+        const uint64_t bits = step_bits(h0, (uint32_t)step);
+        const int pick = pick_index((uint32_t)(bits >> 32), n);  // int(r1 * n); r2 is irrelevant
+        x = g.col[vb + pick];
+        if (step + 1 < walk_length) {
+          vb = g.rowptr[x];
+          n = (int)(g.rowptr[x + 1] - vb);
+          if (n == 0) {  // fugue.py:147: the walker vanishes at a sink, the rest of its row is -1
+            walking = false;
+            alive = false;
+          }
+        }
+      }
+      if (have) {
+        const int64_t a = w0 + step + 1;
+        put(a, x);
+        if ((a & 15) == 15 || step + 1 == walk_length) flush(a);
+      }
+    }
+    if (have) valid_out[r] = alive ? 1 : 0;
+  }
+}
+
+}  // namespace n2v
+
+// returns 1 when the kernel applies (and was launched), 0 when it does not, < 0 on error
+extern "C" int n2v_walk_uniform_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
+                                    int32_t num_walks, int32_t walk_length, double p, double q,
+                                    uint64_t seed, int32_t *walks_out, uint8_t *valid_out,
+                                    uint32_t *status, void *stream) {
+  if (g->w != nullptr || g->w64 != nullptr || p != 1.0 || q != 1.0) return 0;
+  const int64_t total = n_start * (int64_t)num_walks;
+  if (total >= 0xffffff00ll) return 0;
+  if (total == 0) return 1;
+  // status[1] is the kernel's walker counter: start it at zero on the same stream
+  if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
+    return N2V_ELAUNCH;
+  int64_t blocks = (total + 255) / 256;
+  const int64_t cap = n2v::resident_blocks((const void *)n2v::walk_uniform_kernel, 256, 0);
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(n2v::walk_uniform_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, seed,
+                     walks_out, valid_out, status);
+  if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
+  return 1;
+}

@@ -143,6 +143,50 @@ __device__ __forceinline__ double rep_add(double s, double c, int k) {
   return s;
 }
 
+// ---- absorbing a long run of equal under values in O(1) per binade ----------------------
+// The inner statement of the pairing, probs[over] = probs[over] + probs[under] - 1.0 (:186),
+// applied to a run of slots with the same value v < 1: r' = fl(r + v) - 1.0.  The subtraction
+// is always exact (t = fl(r + v) >= 2 while the over is not demoted, and t - 1 is a multiple of
+// ulp(t) below 2 t), so the only rounding is that of r + v, and while t stays inside one
+// binade [2^e, 2^(e+1)) it is the same at every step: r is a multiple of u = ulp(t) (it is a
+// previous t minus 1), v = k u + f, and fl rounds f the same way each time -- a tie f == u/2
+// goes to the even neighbour, after which t and r are even multiples of u and the choice is
+// constant as well.  So after three real steps inside one binade (the first brings r onto the
+// grid, the second may be the tie, the third measures the decrement d = r2 - r3, exact) the
+// next n steps are r - n d exactly, for every n that keeps t strictly above 2^e (below the
+// edge the grid is finer and the argument ends).  Demotion (r < 1) is t < 2, the lower edge of
+// binade 1, so it is never skipped: the caller's step-by-step loop finds it.
+// Advances (r, j) by real steps and exact jumps, never past `limit` slots and never past a
+// demotion; what is left is finished by the caller's loop.
+__device__ __forceinline__ void absorb_skip(double &r, double val, int &j, int limit) {
+  while (j + 3 < limit) {
+    const double t1 = r + val, r1 = t1 - 1.0;
+    const double t2 = r1 + val, r2 = t2 - 1.0;
+    const double t3 = r2 + val, r3 = t3 - 1.0;
+    if (r3 < 1.0) return;  // demoted within three steps: the exact loop takes over
+    const int e1 = biased_exp(t1), e3 = biased_exp(t3);
+    j += 3;
+    r = r3;
+    if (e1 != e3) continue;  // crossed into a lower binade: measure again there
+    const double edge = __longlong_as_double((long long)e3 << 52);  // 2^e
+    const double d = r2 - r3;  // exact
+    const int room = limit - j;
+    if (d == 0.0) {  // val vanishes against r: every remaining slot is absorbed unchanged
+      j += room;
+      return;
+    }
+    if (!(t3 > edge)) continue;
+    double nn = floor((t3 - edge) / d) - 1.0;
+    nn = fmin(nn, (double)room);
+    while (nn >= 1.0 && !(t3 - nn * d > edge)) nn -= 1.0;  // exact products: stay above the edge
+    if (nn >= 1.0) {
+      r = r3 - nn * d;  // exact: a multiple of ulp(t) inside the binade
+      j += (int)nn;
+    }
+    if (nn < 4.0) return;  // at the edge of the binade: let the exact loop cross it
+  }
+}
+
 struct UnitStep {
   const int32_t *vcol, *scol;
   int n, nch, m, iters;
@@ -658,9 +702,15 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
       const int limit = __builtin_amdgcn_readfirstlane(min(total_u, above) - consumed);
       int j = 0;
       bool demoted = false;
-      // probs[over] = probs[over] + probs[under] - 1.0, one absorbed slot per step.  With
-      // vO < 1 the residual never increases, so four steps can be taken at once and only
-      // the last one tested; the exact exit step is resolved when it dropped below 1.0.
+      // probs[over] = probs[over] + probs[under] - 1.0, one absorbed slot per step.  Long runs
+      // are skipped in closed form (absorb_skip); then, with vO < 1 the residual never
+      // increases, so four steps can be taken at once and only the last one tested; the exact
+      // exit step is resolved when it dropped below 1.0.
+      if (limit >= 16) {
+        absorb_skip(r, vO, j, limit);
+        r = readfirstlane_f64(r);
+        j = __builtin_amdgcn_readfirstlane(j);
+      }
       while (j + 4 <= limit) {
         N2V_STAT(8, 4);
         const double a1 = r + vO - 1.0;
@@ -1020,6 +1070,11 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
           int j = U.used;
           const int count = U.cnt;
           bool demoted = false;
+          if (count - j >= 16) {
+            absorb_skip(r, val, j, count);
+            r = readfirstlane_f64(r);
+            j = __builtin_amdgcn_readfirstlane(j);
+          }
           while (j + 4 <= count) {
             N2V_STAT(8, 4);
             const double a1 = r + val - 1.0;
@@ -1088,7 +1143,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_UNIT_WAVES) void walk_exac
   c.need_mem = q != 1.0;
 #ifdef N2V_STATS
   WaveStats WS;
-  for (int i = 0; i < 32; ++i) WS.v[i] = 0;
+  for (int i = 0; i < 40; ++i) WS.v[i] = 0;
   const unsigned long long t_kernel0 = __builtin_readcyclecounter();
 #endif
 
@@ -1218,7 +1273,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_UNIT_WAVES) void walk_exac
 #ifdef N2V_STATS
   WS.v[23] = __builtin_readcyclecounter() - t_kernel0;
   if (lane == 0)
-    for (int i = 0; i < 32; ++i) atomicAdd(&n2v_stats[i], WS.v[i]);
+    for (int i = 0; i < 40; ++i) atomicAdd(&n2v_stats[i], WS.v[i]);
 #endif
 }
 
@@ -1253,6 +1308,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
   const bool need_mem = q != 1.0;
   UnitStep c;
   c.need_mem = need_mem;
+#ifdef N2V_STATS
+  WaveStats WS;
+  for (int i = 0; i < 40; ++i) WS.v[i] = 0;
+  const unsigned long long t_kernel0 = __builtin_readcyclecounter();
+#endif
   for (;;) {
     uint32_t t = 0;
     if (lane == 0) t = atomicAdd(&status[1], 64u);
@@ -1290,6 +1350,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
       int32_t x = -1;
       bool unresolved = false;
       uint32_t u1 = 0, u2 = 0;
+#ifdef N2V_STATS
+      const unsigned long long t_q0 = __builtin_readcyclecounter();
+#endif
       if (walking) {
         const uint64_t bits = step_bits(h0, (uint32_t)step);
         u1 = (uint32_t)(bits >> 32);
@@ -1329,6 +1392,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
       }
       // the steps that need the pairing: the whole wave, one walker at a time
       uint64_t fb = ballot64(unresolved);
+#ifdef N2V_STATS
+      const unsigned long long t_f0 = __builtin_readcyclecounter();
+      WS.v[26] += t_f0 - t_q0;
+      WS.v[28] += __popcll(ballot64(walking));
+      WS.v[29] += __popcll(fb);
+#endif
       while (fb != 0ull) {
         const int l = (int)__builtin_ctzll(fb);
         fb &= fb - 1ull;
@@ -1343,10 +1412,23 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
         c.s = __builtin_amdgcn_readlane(s, l);
         const uint32_t u1_l = (uint32_t)__builtin_amdgcn_readlane((int)u1, l);
         const uint32_t u2_l = (uint32_t)__builtin_amdgcn_readlane((int)u2, l);
-        const int res = __builtin_amdgcn_readfirstlane(unit_draw<true>(c, K, u1_l, u2_l, lane, L));
+#ifdef N2V_STATS
+        const unsigned long long t_d0 = __builtin_readcyclecounter();
+#endif
+        const int res = __builtin_amdgcn_readfirstlane(unit_draw<true>(c, K, u1_l, u2_l, lane, L N2V_STATS_PASS));
         __builtin_amdgcn_wave_barrier();
         if (lane == l) idx = res;
+#ifdef N2V_STATS
+        {  // fallback draws and their cycles by deg(v) bucket
+          const int bk = c.n <= 64 ? 0 : (c.n <= 1024 ? 1 : (c.n <= 4096 ? 2 : 3));
+          WS.v[32 + bk] += 1;
+          WS.v[36 + bk] += __builtin_readcyclecounter() - t_d0;
+        }
+#endif
       }
+#ifdef N2V_STATS
+      WS.v[27] += __builtin_readcyclecounter() - t_f0;
+#endif
       if (unresolved) x = g.col[vb + idx];
       if (walking) {
         out[step + 1] = x;
@@ -1372,6 +1454,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
       valid_out[r] = alive ? 1 : 0;
     }
   }
+#ifdef N2V_STATS
+  WS.v[23] = __builtin_readcyclecounter() - t_kernel0;
+  if (lane == 0)
+    for (int i = 0; i < 40; ++i) atomicAdd(&n2v_stats[i], WS.v[i]);
+#endif
 }
 
 }  // namespace n2v
@@ -1408,8 +1495,14 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
   // status[1] is the kernels' walker counter: start it at zero on the same stream
   if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
     return N2V_ELAUNCH;
-  // lanes kernel: dyadic p, q with the per-edge class counts at hand (p == q == 1 needs none)
-  if (dyadic && total < 0xffffff00ll && (g->edge_classes || (p == 1.0 && q == 1.0))) {
+  // lanes kernel: dyadic p, q with the per-edge class counts at hand (p == q == 1 needs none),
+  // when the "other" class -- nearly every slot of a row -- is the underfull one: 1/q <= 1 and
+  // 1/p >= 1/q.  Then ~80 % of the steps leave through the per-lane exits.  For the other
+  // arrangements (q < 1, or p > q) the usual `pick` is an overfull slot, every step needs the
+  // pairing, and one wave per walker (below) is the better shape (measured: cfg 2, p = 4,
+  // q = 0.25: 344 against 241 M steps/s; p = 2, q = 1: 938 against 711).
+  const bool lanes_regime = (p == 1.0 && q == 1.0) || (K.bO <= 1.0 && K.bR >= K.bO);
+  if (dyadic && lanes_regime && total < 0xffffff00ll && (g->edge_classes || (p == 1.0 && q == 1.0))) {
     int64_t blocks = (total + 255) / 256;
     const int64_t cap = n2v::resident_blocks((const void *)n2v::walk_exact_unit_lanes_kernel,
                                              n2v::kWavesPerBlock * 64, 0);
@@ -1443,9 +1536,9 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
 
 #ifdef N2V_STATS
 extern "C" int n2v_debug_stats_unit(unsigned long long *out_host, int reset) {
-  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(n2v::n2v_stats), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(n2v::n2v_stats), sizeof(unsigned long long) * 40) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[32] = {0};
+    unsigned long long z[40] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(n2v::n2v_stats), z, sizeof(z)) != hipSuccess) return -1;
   }
   return 0;

@@ -24,6 +24,13 @@ def _dyadic(x: float) -> bool:
     return 0.0 < t < 2147483648.0 and t == float(int(t))
 
 
+def lanes_regime(p: float, q: float) -> bool:
+    """The (p, q) for which exact walks on a unit-weight graph use the per-edge class counts
+    (same predicate as n2v_walk_exact_unit_try, csrc/n2v_walk_unit.hip): dyadic values with
+    1/q <= 1 and 1/p >= 1/q, i.e. the bulk of every row ("other" neighbours) is underfull."""
+    return _dyadic(p) and _dyadic(q) and 1.0 / q <= 1.0 and 1.0 / p >= 1.0 / q
+
+
 def fresh_seed() -> int:
     """random_seed=None in the reference means an unseeded `random` (randomwalk.py:314)."""
     return int.from_bytes(os.urandom(8), "little")
@@ -70,8 +77,8 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     if mode == "exact" and graph.unit_weights:
         # unit weights: the per-step table follows from two counts per edge, computed once
         # (n2v_edge_classes_build, 4 bytes per edge); p == q == 1 needs nothing at all
-        if (use_edge_classes and biased and graph.edge_classes is None and _dyadic(return_param)
-                and _dyadic(inout_param)):
+        if (use_edge_classes and biased and graph.edge_classes is None
+                and lanes_regime(return_param, inout_param)):
             graph.build_edge_classes()
     elif mode == "exact" and not biased and graph.slots is None:
         # the reference's default p = q = 1: every per-step table is the first-order table of

@@ -10,7 +10,7 @@ from node2vec_amd.graph import DeviceGraph
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-THREADS = min(64, os.cpu_count() or 8)
+THREADS = min(64, len(os.sched_getaffinity(0)))
 
 def graph(kind):
     nv = int(rng.choice([50, 400, 3000, 20000]))
@@ -41,11 +41,13 @@ def graph(kind):
         keep = src % 7 != 3; src, dst = src[keep], dst[keep]
     if rng.random() < 0.3:  # de-duplicate (otherwise multi-edges stay)
         key = np.unique(src.astype(np.int64) * nv + dst); src, dst = key // nv, key % nv
-    wk = rng.choice(["unit", "unit", "dyadic", "arbitrary"])
+    wk = rng.choice(["unit", "unit", "unit", "dyadic", "arbitrary", "arbitrary64"])
     if wk == "unit":
         w = np.ones(len(src), np.float32)
     elif wk == "dyadic":
         w = rng.choice([0.25, 0.5, 1.0, 2.0, 1.5], len(src)).astype(np.float32)
+    elif wk == "arbitrary64":  # Python-float weights (the reference's own type): fp64 storage
+        w = rng.uniform(0.01, 5.0, len(src))
     else:
         w = rng.uniform(0.01, 5.0, len(src)).astype(np.float32)
     return nv, src, dst, w, wk
@@ -69,9 +71,12 @@ while time.time() - t0 < budget:
     deg = g.degrees()
     starts = torch.unique(torch.cat([torch.topk(deg, min(20, nv)).indices,
                                      torch.from_numpy(rng.integers(0, nv, 300)).cuda()])).to(torch.int32)
-    if wk == "arbitrary" and int(deg.max()) > 3000:
+    if wk.startswith("arbitrary") and int(deg.max()) > 3000:
         starts = starts[:60]; wl = min(wl, 20)  # the oracle is O(degree) per step
-    got, gv = rw.walk(g, starts, nw, wl, p, q, seed)
+    # unit weights, dyadic p, q: the lanes kernel (per-edge class counts) by default, the
+    # wave-per-walker kernel without them -- both must match
+    uec = bool(rng.random() < 0.7)
+    got, gv = rw.walk(g, starts, nw, wl, p, q, seed, use_edge_classes=uec)
     want, wv = n2v_oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.w.cpu().numpy(),
                                       starts.cpu().numpy(), nw, wl, p, q, seed, n_threads=THREADS)
     ok = np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy(), want)
@@ -79,7 +84,7 @@ while time.time() - t0 < budget:
     if not ok:
         bad = np.nonzero((got.cpu().numpy() != want).any(1) | (gv.cpu().numpy() != wv))[0][:5]
         print("MISMATCH", dict(kind=kind, nv=nv, ne=len(src), weights=wk, p=p, q=q, nw=nw, wl=wl, seed=seed,
-                               maxdeg=int(deg.max()), unit=g.unit_weights), "rows", bad.tolist(), flush=True)
+                               maxdeg=int(deg.max()), unit=g.unit_weights, edge_classes=uec), "rows", bad.tolist(), flush=True)
         for r in bad[:2]:
             print(" got ", got[r].tolist()[:12], "\n want", want[r].tolist()[:12])
         sys.exit(1)

@@ -1,35 +1,43 @@
+"""Where the exact unit-weight walk kernels spend their cycles (diagnostic build, -DN2V_STATS):
+GRAPH=cfg2|cfg3 PQ=0.5,2.0 KERNEL=lanes|wave python scripts/walk_stats.py   (bash scripts/build_stats.sh first)"""
 import ctypes as C, os, sys, torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
-os.environ["N2V_HIP_LIB"] = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "build_variants/libn2v_stats.so")
-from node2vec_amd import synthetic, randomwalk as rw, _lib
-if os.environ.get("GRAPH") == "cfg3":  # Chung-Lu 10 M, trimmed at 10 000 (scripts/scale_check.py)
-    from node2vec_amd.fugue import trim_hotspot_edges
-    from node2vec_amd.graph import DeviceGraph
-    g = synthetic.chung_lu(10_000_000, 100_000_000, device="cuda")
-    src = torch.repeat_interleave(torch.arange(g.n_vertices, device="cuda"), g.degrees())
-    keep = trim_hotspot_edges(src, 10_000, 42)
-    g = DeviceGraph.from_edges(src[keep], g.col[keep].long(), g.w[keep], n_vertices=g.n_vertices, device="cuda")
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from node2vec_amd import _lib
+_lib.LIB_PATH = os.path.join(ROOT, "build_stats", "libn2v_stats.so")  # developer build, loaded by path
+from node2vec_amd import synthetic, randomwalk as rw
+if os.environ.get("GRAPH") == "cfg3":
+    g = synthetic.chung_lu(10_000_000, 100_000_000, device="cuda").trimmed(10_000, 42)
     sv = rw.start_vertices(g)
-    start = sv[torch.randperm(sv.numel(), device="cuda")[:47104]].contiguous()
+    start = sv[torch.randperm(sv.numel(), device="cuda")[:131072]].contiguous()
 else:
     g = synthetic.rmat(20, 5_000_000, device="cuda")
-    start = rw.start_vertices(g)[:47104].contiguous()
+    start = rw.start_vertices(g)[:131072].contiguous()
 L = _lib.load()
+L.n2v_debug_stats_unit.argtypes = [C.c_void_p, C.c_int]
 names = ["draw_steps", "staged+filter", "direct_search", "maybes", "verify_rounds", "merge_steps",
-         "pair_invocations", "engine_chunk_loads_uncached", "absorbed_slots", "cascades", "engine_chunk_loads", "staged_nofilter", "big_filter", "reverse"]
-PQ = tuple(float(x) for x in os.environ.get("PQ", "0.5,2.0").split(","))
-for p, q in (PQ,):
-    buf = (C.c_ulonglong * 32)()
-    L.n2v_debug_stats_unit(buf, 1)
-    walks, valid = rw.walk(g, start, 10, 80, p, q, 42); torch.cuda.synchronize()
-    L.n2v_debug_stats_unit(buf, 1)
-    st = dict(zip(names, list(buf)))
-    print(p, q, {k: (v, round(v / max(st["draw_steps"], 1), 4)) for k, v in st.items()})
-    ph = ["P0 stage/filter", "P1 staged/filter", "P2 verify", "sum+avg", "P1 direct", "pairing", "P1 merge", "reverse classify"]
-    cyc = list(buf)[16:23] + [list(buf)[24]]; tot = list(buf)[23]
-    print("  wave-cycles total", tot, "per step", round(tot/st["draw_steps"]));    print("  cycles/step by phase:", {n: (round(c / st["draw_steps"]), f"{100*c/tot:.1f}%") for n, c in zip(ph, cyc)})
-    b = list(buf)
-    tot_draw = sum(b[25:30])
-    print("  draw cycles by deg(v) bucket [<=64, <=1024, <=4096, <=8192, >8192]:", [f"{100*x/tot_draw:.1f}%" for x in b[25:30]],
-          " steps 4096<n<=8192:", b[14], " n>8192:", b[15])
-    print("  walkers: mean wave-cycles", round(b[31] / (walks.shape[0])), " slowest", b[30], " kernel wave-cycles per wave", round(tot / 8192))
+         "pair_invocations", "engine_chunk_loads_uncached", "absorbed_slots", "cascades", "engine_chunk_loads",
+         "staged_nofilter", "big_filter", "reverse"]
+p, q = (float(x) for x in os.environ.get("PQ", "0.5,2.0").split(","))
+lanes = os.environ.get("KERNEL", "lanes") == "lanes"
+buf = (C.c_ulonglong * 40)()
+rw.walk(g, start[:1024], 10, 80, p, q, 42, use_edge_classes=lanes); torch.cuda.synchronize()
+L.n2v_debug_stats_unit(buf, 1)
+walks, valid = rw.walk(g, start, 10, 80, p, q, 42, use_edge_classes=lanes); torch.cuda.synchronize()
+L.n2v_debug_stats_unit(buf, 1)
+b = list(buf)
+st = dict(zip(names, b))
+draws = max(st["draw_steps"], 1)
+print("p,q", p, q, "kernel", "lanes" if lanes else "wave", {k: (v, round(v / draws, 3)) for k, v in st.items()})
+ph = ["P0 stage/filter", "P1 staged/filter", "P2 verify", "sum+avg", "P1 direct", "pairing", "P1 merge", "reverse classify"]
+cyc = b[16:23] + [b[24]]
+tot = b[23]
+print("  unit_draw cycles per draw by phase:", {n: round(c / draws) for n, c in zip(ph, cyc)}, " sum", round(sum(cyc) / draws))
+if lanes:
+    steps = max(b[28], 1)
+    print(f"  lanes kernel: walker-steps {b[28]}, fallback draws {b[29]} ({100*b[29]/steps:.1f} %), wave-cycles total {tot}")
+    print(f"  wave-cycles: quick phase {100*b[26]/tot:.1f} %, fallback phase {100*b[27]/tot:.1f} %; per fallback draw {round(b[27]/max(b[29],1))} cycles")
+    bk = ["n<=64", "n<=1024", "n<=4096", "n>4096"]
+    print("  fallback draws by deg(v):", {k: (b[32 + i], f"{100*b[36+i]/max(b[27],1):.1f}% of fallback cycles", round(b[36 + i] / max(b[32 + i], 1))) for i, k in enumerate(bk)})
+else:
+    print("  wave kernel: wave-cycles total", tot, "per step", round(tot / draws))
