@@ -72,7 +72,8 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start, int3
                                  inout_param, seed, walks_out, valid_out, status, stream);
   }
   if (mode == N2V_WALK_FAST) {
-    if (!g->slots) return N2V_EINVAL;
+    // weighted graphs draw candidates from the K1 tables; unit-weight graphs from col itself
+    if (!g->slots && (g->w || g->w64)) return N2V_EINVAL;
     return n2v_walk_fast_launch(g, start_ids, n_start, num_walks, walk_length, return_param,
                                 inout_param, seed, walks_out, valid_out, status, stream);
   }

@@ -57,7 +57,31 @@ __global__ void pivots_build_kernel(const int32_t *__restrict__ col, int64_t n_e
     pivots[j] = col[min(32 * j + 31, n_edges - 1)];
 }
 
-__global__ __launch_bounds__(256) void walk_fast_kernel(
+// position of the first entry >= x in the sorted row a[0, m) (one lane)
+__device__ __forceinline__ int lower_bound_lane(const int32_t *a, int m, int32_t x) {
+  int lo = 0, hi = m;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < x)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// kUnit: every weight is 1.0 -- the first-order table of a row is uniform, so a candidate is
+// col[row + int(r1 * n)] (4-byte gather, no slots needed, and the index of the edge walked is
+// known).  With the per-edge class counts (g.edge_classes, n2v_edge_classes_build) two more
+// things follow for the step (s -> v): the multiplicity nR of the return edge, which takes the
+// return edge OUT of the rejection envelope (choose "return" with its exact share
+// (nR/p) / (nR/p + (n - nR) b'), otherwise draw among the other entries and accept with
+// beta(x) / b', b' = max(1, 1/q): P(x) ~ beta(x) as before, but p no longer inflates the
+// envelope -- 3.5 -> 2.1 trials per step at p = 0.5, q = 2); and the number nM of neighbours of
+// v that are neighbours of s: when it is 0 the test "x in N(s)" (:226) is known to fail and
+// its binary search is skipped.
+template <bool kUnit>
+__global__ __launch_bounds__(256, 6) void walk_fast_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double p, double q, uint64_t seed, int32_t *__restrict__ walks_out,
     uint8_t *__restrict__ valid_out, uint32_t *__restrict__ status,
@@ -66,27 +90,60 @@ __global__ __launch_bounds__(256) void walk_fast_kernel(
   const int64_t n_lanes = (int64_t)gridDim.x * blockDim.x;
   const int L1 = walk_length + 1;
   const double inv_p = 1.0 / p, inv_q = 1.0 / q;
-  const double beta_max = fmax(1.0, fmax(inv_p, inv_q));
+  const double b_lo = fmin(1.0, inv_q), b_hi = fmax(1.0, inv_q);  // biases of the non-return entries
+  const double beta_max = fmax(b_hi, inv_p);
   const bool biased = !(p == 1.0 && q == 1.0);
+  const bool have_ec = kUnit && g.edge_classes != nullptr;
+  const bool fold_return = have_ec && inv_p > b_hi;
+  const bool base_aligned = (reinterpret_cast<uintptr_t>(walks_out) & 63u) == 0;
 
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // current walker row
   bool live = false;
   int32_t s = -1, v = 0;
   int step = 0;
   uint32_t trial = 0;
-  int64_t vb = 0, sb = 0;
+  int64_t vb = 0, sb = 0, w0 = 0;
   int n = 0, m = 0;
   uint64_t h0 = 0, hstep = 0;
-  int32_t *out = nullptr;
   unsigned long long trials = 0;
+  double rho = -1.0;   // share of the return branch at this step (< 0: not folded)
+  int shared = -1;     // neighbours of v inside N(s) at this step, -1 = unknown
+
+  // The path is not stored word by word: a 4-byte store into a 324-byte-pitch row costs a
+  // 32-byte write request.  Each lane keeps the 16 words of the 64-byte sector of walks_out
+  // it is filling in LDS (word k of lane t at [k][t]: conflict-free) and stores the sector
+  // whole: four aligned 16-byte stores per 16 steps.
+  __shared__ int32_t path_tile[16][256];
+  const int tid = threadIdx.x;
+  int lo = 0;  // first word of the current sector that belongs to this row
+  auto put = [&](int64_t a, int32_t x) { path_tile[(int)(a & 15)][tid] = x; };
+  auto flush = [&](int64_t a) {  // words [sector(a) + lo, a] are complete
+    const int k = (int)(a & 15);
+    int32_t *sec = walks_out + (a & ~(int64_t)15);
+    if (lo == 0 && k == 15 && base_aligned) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        reinterpret_cast<int4 *>(sec)[u] =
+            make_int4(path_tile[4 * u][tid], path_tile[4 * u + 1][tid], path_tile[4 * u + 2][tid],
+                      path_tile[4 * u + 3][tid]);
+    } else {
+      for (int kk = lo; kk <= k; ++kk) sec[kk] = path_tile[kk][tid];
+    }
+    lo = 0;
+  };
+  auto emit = [&](int pos, int32_t x) {  // path position pos of the current walker
+    const int64_t a = w0 + pos;
+    put(a, x);
+    if ((a & 15) == 15 || pos == walk_length) flush(a);
+  };
 
   // (re)load a walker into this lane; returns false when the lane has none left
   auto begin_walker = [&]() -> bool {
     while (r < total) {
       const int32_t start = start_ids[r / num_walks];
       const int32_t ordinal = (int32_t)(r % num_walks) + 1;
-      out = walks_out + r * L1;
-      for (int t = 0; t < L1; ++t) out[t] = -1;
+      w0 = r * (int64_t)L1;
+      lo = (int)(w0 & 15);
       bool ok = true;
       if (start < 0 || (int64_t)start >= g.n_vertices) {
         atomicOr(status, N2V_ST_RANGE);
@@ -98,8 +155,9 @@ __global__ __launch_bounds__(256) void walk_fast_kernel(
         ok = n > 0;  // fugue.py:132
       }
       if (!ok || walk_length == 0) {
-        // no out-edges (fugue.py:132), or nothing to walk: the row is just [start]
-        if (ok) out[0] = start;
+        // no out-edges (fugue.py:132): the row is all -1; nothing to walk: the row is [start]
+        emit(0, ok ? start : -1);
+        for (int t = 1; t < L1; ++t) emit(t, -1);
         valid_out[r] = ok ? 1 : 0;
         r += n_lanes;
         continue;
@@ -108,7 +166,9 @@ __global__ __launch_bounds__(256) void walk_fast_kernel(
       v = start;
       step = 0;
       trial = 0;
-      out[0] = start;
+      rho = -1.0;
+      shared = -1;
+      emit(0, start);
       h0 = walker_stream(seed, (uint64_t)start * (uint64_t)num_walks + (uint64_t)(ordinal - 1));
       hstep = step_bits(h0, 0);
       return true;
@@ -122,36 +182,48 @@ __global__ __launch_bounds__(256) void walk_fast_kernel(
     // ---- one trial of the current step ----------------------------------------
     // unbiased steps (the first one; every one when p == q == 1) never reject and use the exact
     // mode's two uniforms: those draws are bit-identical to exact mode
-    uint64_t bits = (s < 0 || !biased) ? hstep : trial_bits(hstep, trial);
+    const bool plain = s < 0 || !biased;
+    const uint64_t bits = plain ? hstep : trial_bits(hstep, trial);
     const uint32_t u1 = (uint32_t)(bits >> 32), u2 = (uint32_t)bits;
     const int pick = pick_index(u1, n);
-    const n2v_slot sl = g.slots[vb + pick];
-    const double r2 = (double)u2 * (1.0 / 4294967296.0);
-    const int32_t x = (r2 < sl.prob) ? sl.col : sl.alias;  // slot.alias is already a vertex id
+    int32_t x;
+    int64_t e = vb + pick;  // kUnit: the edge (v -> x) itself
+    if (kUnit) {
+      x = g.col[e];
+    } else {
+      const n2v_slot sl = g.slots[e];
+      const double r2 = (double)u2 * (1.0 / 4294967296.0);
+      x = (r2 < sl.prob) ? sl.col : sl.alias;  // slot.alias is already a vertex id
+    }
     bool accept = true;
     ++trials;
-    if (s >= 0 && biased) {
-      // accept iff u < beta(x), u uniform on [0, beta_max).  beta is 1/p for the return
-      // edge; otherwise it is 1 (x in N(s)) or 1/q, so the binary search over N(s) is
-      // only needed when u falls BETWEEN those two values: same decisions, far fewer
-      // dependent gathers (p=0.5, q=2: one trial in four).
-      const uint32_t u3 = (uint32_t)(mix64(bits ^ 0xC2B2AE3D27D4EB4FULL) >> 32);
-      const double u = (double)u3 * (1.0 / 4294967296.0) * beta_max;
-      if (x == s) {
-        accept = u < inv_p;
-      } else if (q == 1.0) {
-        accept = u < 1.0;
+    if (!plain) {
+      const uint64_t b2 = mix64(bits ^ 0xC2B2AE3D27D4EB4FULL);
+      const double ua = (double)(uint32_t)(b2 >> 32) * (1.0 / 4294967296.0);
+      // accept a non-return candidate x iff u < beta(x), beta = 1 (x in N(s)) or 1/q: the
+      // binary search over N(s) is only needed when u falls BETWEEN those two values
+      auto accept_other = [&](double u) -> bool {
+        if (u < b_lo) return true;
+        if (!(u < b_hi)) return false;
+        bool member = false;
+        if (q != 1.0 && shared != 0)
+          member = g.pivots ? member_pivoted_lane(g.col, g.pivots, sb, m, x)
+                            : member_sorted_lane(g.col + sb, m, x);
+        return u < (member ? 1.0 : inv_q);
+      };
+      if (rho >= 0.0) {  // return edge outside the envelope
+        const double ub = (double)(uint32_t)b2 * (1.0 / 4294967296.0);
+        if (ub < rho) {
+          x = s;
+          e = vb + lower_bound_lane(g.col + vb, n, s);  // the edge (v -> s): its counts are needed next
+        } else if (x == s) {
+          accept = false;  // drawn among the OTHER entries: try again
+        } else {
+          accept = accept_other(ua * b_hi);
+        }
       } else {
-        const double b_lo = fmin(1.0, inv_q), b_hi = fmax(1.0, inv_q);
-        if (u < b_lo)
-          accept = true;
-        else if (!(u < b_hi))
-          accept = false;
-        else
-          accept = u < ((g.pivots ? member_pivoted_lane(g.col, g.pivots, sb, m, x)
-                                 : member_sorted_lane(g.col + sb, m, x))
-                            ? 1.0
-                            : inv_q);
+        const double u = ua * beta_max;
+        accept = (x == s) ? (u < inv_p) : accept_other(u);
       }
     }
     if (!accept) {
@@ -159,22 +231,35 @@ __global__ __launch_bounds__(256) void walk_fast_kernel(
       continue;
     }
     // ---- accepted: append, advance ------------------------------------------------
-    out[step + 1] = x;
+    emit(step + 1, x);
     s = v;
     sb = vb;
     m = n;
     v = x;
     ++step;
     trial = 0;
-    bool finished = step == walk_length;
+    const bool finished = step == walk_length;
     bool dropped = false;
     if (!finished) {
       vb = g.rowptr[v];
       n = (int)(g.rowptr[v + 1] - vb);
       dropped = n == 0;  // fugue.py:147: the walker vanishes at a sink
       hstep = step_bits(h0, (uint32_t)step);
+      rho = -1.0;
+      shared = -1;
+      if (have_ec && biased && !dropped) {
+        const uint32_t ec = g.edge_classes[e];
+        const uint32_t fR = ec >> N2V_EC_RETURN_SHIFT, fM = ec & N2V_EC_SHARED_MASK;
+        if (fM != N2V_EC_SHARED_MASK) shared = (int)fM;
+        if (fold_return && fR != N2V_EC_RETURN_SAT) {
+          const double wr = (double)fR * inv_p;
+          rho = wr / (wr + (double)(n - (int)fR) * b_hi);
+        }
+      }
     }
     if (finished || dropped) {
+      if (dropped)
+        for (int t = step + 1; t < L1; ++t) emit(t, -1);
       valid_out[r] = finished ? 1 : 0;
       r += n_lanes;
       live = begin_walker();
@@ -191,14 +276,24 @@ extern "C" int n2v_walk_fast_launch(const n2v_graph *g, const int32_t *start_ids
                                     uint8_t *valid_out, uint32_t *status, void *stream) {
   const int64_t total = n_start * (int64_t)num_walks;
   if (total == 0) return N2V_OK;
+  const bool unit = g->w == nullptr && g->w64 == nullptr;
+  if (!unit && !g->slots) return N2V_EINVAL;
   const int threads = 256;
   int64_t blocks = (total + threads - 1) / threads;
-  if (blocks > 256 * 8) blocks = 256 * 8;
+  const void *fn = unit ? (const void *)n2v::walk_fast_kernel<true>
+                        : (const void *)n2v::walk_fast_kernel<false>;
+  const int64_t cap = n2v::resident_blocks(fn, threads, 0);
+  if (blocks > cap) blocks = cap;
   // status[2..3]: 64-bit trial counter (include/n2v_hip.h)
-  hipLaunchKernelGGL(n2v::walk_fast_kernel, dim3((unsigned)blocks), dim3(threads), 0,
-                     (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, p, q,
-                     seed, walks_out, valid_out, status,
-                     reinterpret_cast<unsigned long long *>(status + 2));
+  unsigned long long *trials = reinterpret_cast<unsigned long long *>(status + 2);
+  if (unit)
+    hipLaunchKernelGGL(n2v::walk_fast_kernel<true>, dim3((unsigned)blocks), dim3(threads), 0,
+                       (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, p, q,
+                       seed, walks_out, valid_out, status, trials);
+  else
+    hipLaunchKernelGGL(n2v::walk_fast_kernel<false>, dim3((unsigned)blocks), dim3(threads), 0,
+                       (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, p, q,
+                       seed, walks_out, valid_out, status, trials);
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
 }
@@ -209,7 +304,8 @@ extern "C" int n2v_pivots_build(const int32_t *col, int64_t n_edges, int32_t *pi
   if (n_edges == 0) return N2V_OK;
   const int64_t n_blocks = (n_edges + 31) >> 5;
   int64_t blocks = (n_blocks + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  const int64_t cap = n2v::resident_blocks((const void *)n2v::pivots_build_kernel, 256, 0) * 2;
+  if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(n2v::pivots_build_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      (hipStream_t)stream, col, n_edges, pivots_out);
   N2V_HIP_CHECK(hipGetLastError());

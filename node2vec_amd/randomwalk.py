@@ -72,8 +72,17 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
         # generate_edge_alias_tables, randomwalk.py:214-217
         raise ValueError(f"Zero return ({return_param}) or inout ({inout_param}) parameter!")
     biased = not (return_param == 1.0 and inout_param == 1.0)
-    if mode == "fast" and graph.slots is None:
-        graph.build_alias()
+    if mode == "fast":
+        if not graph.unit_weights:
+            if graph.slots is None:
+                graph.build_alias()  # candidates come from the first-order tables
+        else:
+            # unit weights: candidates are col[row + int(r1 * n)]; the per-edge class counts take
+            # the return edge out of the rejection envelope and skip hopeless membership searches
+            if graph.pivots is None:
+                graph.build_pivots()
+            if use_edge_classes and biased and graph.edge_classes is None:
+                graph.build_edge_classes()
     if mode == "exact" and graph.unit_weights:
         # unit weights: the per-step table follows from two counts per edge, computed once
         # (n2v_edge_classes_build, 4 bytes per edge); p == q == 1 needs nothing at all
