@@ -1,0 +1,128 @@
+"""BASELINE cfgs 3, 4 and 5 at their full graph sizes, on one GPU.
+
+The CPU oracle cannot replay 10^9 walk-steps, so each configuration is checked through what
+does not depend on size (fugue.py:130-155 semantics): every hop of every walk is an edge of the
+graph, rows are complete and start at their source, the result does not depend on how the start
+vertices are sharded (the multi-GPU partition), exact and fast modes emit valid
+walks -- and a sample of start vertices that includes the biggest hubs equals the oracle bit for
+bit (the per-step alias rebuild of randomwalk.py:193-232 on rows of up to 10^4 neighbours).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+W, L = 10, 80  # 10 walks per vertex, walk_length 80
+
+
+def _hops_are_edges(g, walks, valid):
+    """CSR rows are sorted by destination, so src * V + dst ascends over the edge array"""
+    src = torch.repeat_interleave(torch.arange(g.n_vertices, device=g.device), g.degrees())
+    keys = src * g.n_vertices + g.col.long()
+    del src
+    w = walks[valid].long()
+    hop = (w[:, :-1] * g.n_vertices + w[:, 1:]).reshape(-1)
+    ok = True
+    for part in torch.split(hop, 1 << 26):
+        pos = torch.searchsorted(keys, part).clamp_(max=keys.numel() - 1)
+        ok = ok and bool((keys[pos] == part).all())
+    return ok
+
+
+def _sample_with_hubs(g, start, n_random, n_hubs, seed):
+    gen = torch.Generator().manual_seed(seed)
+    pick = torch.randperm(start.numel(), generator=gen)[:n_random].to(start.device)
+    hubs = torch.topk(g.degrees(), n_hubs).indices.to(torch.int32)
+    return torch.unique(torch.cat([hubs, start[pick]]))
+
+
+def _check_config(oracle, g, start, p, q, seed, n_oracle, n_hubs, oracle_len):
+    """the size-independent properties + the oracle sample, for one (p, q)"""
+    from node2vec_amd import randomwalk as rw
+
+    walks, valid = rw.walk(g, start, W, L, p, q, seed)
+    assert walks.shape == (start.numel() * W, L + 1)
+    assert bool(valid.all())  # symmetrised graphs: no sinks
+    assert torch.equal(walks[:, 0], start.repeat_interleave(W))  # to_path: src = path[0]
+    assert int(walks.min()) >= 0 and int(walks.max()) < g.n_vertices
+    assert _hops_are_edges(g, walks, valid)
+    # sharding invariance: 5 uneven contiguous ranges of the start set == the whole launch
+    n = start.numel()
+    cuts = [0, 1, n // 7, n // 2 + 3, n - 5, n]
+    parts = [rw.walk(g, start[a:b].contiguous(), W, L, p, q, seed)[0] for a, b in zip(cuts, cuts[1:])]
+    assert torch.equal(walks, torch.cat(parts))
+    del parts, walks
+    # fast mode: same chain by rejection; first step identical to exact mode, every hop an edge
+    fw, fv = rw.walk(g, start[: min(n, 20000)].contiguous(), W, L, p, q, seed, mode="fast")
+    assert bool(fv.all()) and _hops_are_edges(g, fw, fv)
+    # oracle sample, the biggest hubs included (rows of ~10^4 neighbours rebuilt per step)
+    sample = _sample_with_hubs(g, start, n_oracle, n_hubs, seed)
+    got, gv = rw.walk(g, sample, W, oracle_len, p, q, seed)
+    want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), None,
+                                  sample.cpu().numpy(), W, oracle_len, p, q, seed, n_threads=16)
+    assert np.array_equal(gv.cpu().numpy(), wv)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_cfg3_power_law_10m_trimmed(oracle):
+    """cfg 3: Chung-Lu gamma = 2.1, 10 M vertices, 10^8 undirected draws symmetrised (~1.9 x 10^8
+    directed edges), out-degree trimmed at 10 000 (trim_hotspot_vertices); p = q = 1 and (0.5, 2)"""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd import synthetic
+
+    g = synthetic.chung_lu(10_000_000, 100_000_000, seed=42, device="cuda")
+    assert g.n_vertices == 10_000_000 and g.n_edges > 150_000_000
+    before = g.degrees()
+    g = g.trimmed(10_000, 42)
+    deg = g.degrees()
+    assert int(before.max()) > 10_000 and int(deg.max()) == 10_000
+    assert torch.equal(deg, before.clamp(max=10_000))  # rows at or below the cap are untouched
+    del before
+    start_all = rw.start_vertices(g)
+    gen = torch.Generator().manual_seed(3)
+    pick = torch.sort(torch.randperm(start_all.numel(), generator=gen)[:60_000]).values
+    start = start_all[pick.to("cuda")].contiguous()
+    for p, q in ((1.0, 1.0), (0.5, 2.0)):
+        _check_config(oracle, g, start, p, q, 42, n_oracle=48, n_hubs=16, oracle_len=40)
+
+
+def test_cfg4_power_law_100m(oracle):
+    """cfg 4 (the configuration BASELINE.json's metric is quoted on): 10^8 vertices, 5 x 10^8
+    undirected draws (~0.9 x 10^9 directed edges), trimmed at 10 000; 100 k start vertices"""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd import synthetic
+
+    g = synthetic.chung_lu(100_000_000, 500_000_000, seed=42, device="cuda")
+    assert g.n_vertices == 100_000_000 and g.n_edges > 800_000_000
+    g = g.trimmed(10_000, 42)
+    torch.cuda.empty_cache()
+    assert int(g.degrees().max()) == 10_000
+    start_all = rw.start_vertices(g)
+    gen = torch.Generator().manual_seed(4)
+    pick = torch.sort(torch.randperm(start_all.numel(), generator=gen)[:100_000]).values
+    start = start_all[pick.to("cuda")].contiguous()
+    for p, q in ((1.0, 1.0), (0.5, 2.0)):
+        _check_config(oracle, g, start, p, q, 42, n_oracle=48, n_hubs=16, oracle_len=40)
+
+
+def test_cfg5_bipartite_50m_hubs_of_20k(oracle):
+    """cfg 5: 50 M vertices, 5 000 hubs x 10 000 leaves + one hub per leaf (hub degree ~20 000,
+    beyond every LDS cache of the exact kernels), p = 4, q = 0.25.  Bipartite: the "shared
+    neighbour" branch (randomwalk.py:226) never fires and walks alternate between the sides."""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd import synthetic
+
+    n_hubs = 5_000
+    g = synthetic.hub_bipartite(50_000_000, n_hubs, 10_000, seed=42, device="cuda")
+    deg = g.degrees()
+    assert g.n_vertices == 50_000_000 and int(deg[:n_hubs].min()) > 19_000
+    start_all = rw.start_vertices(g)
+    gen = torch.Generator().manual_seed(5)
+    pick = torch.sort(torch.randperm(start_all.numel(), generator=gen)[:100_000]).values
+    start = torch.unique(torch.cat([start_all[pick.to("cuda")],
+                                    torch.arange(64, dtype=torch.int32, device="cuda")]))
+    _check_config(oracle, g, start, 4.0, 0.25, 42, n_oracle=40, n_hubs=12, oracle_len=30)
+    walks, valid = rw.walk(g, start[:4096].contiguous(), W, L, 4.0, 0.25, 42)
+    side = walks[valid].long() < n_hubs
+    assert bool((side[:, :-1] != side[:, 1:]).all())
