@@ -201,15 +201,18 @@ def main():
 
     # ---- headline: exact walks at the config's p, q --------------------------------------
     p, q = cfg["p"], cfg["q"]
-    t0 = time.perf_counter()
-    rw.walk(g, start_all[:64], W, 4, p, q, 42, mode="exact")  # tables built on first use
-    torch.cuda.synchronize()
-    setup["exact_tables_first_use_s"] = time.perf_counter() - t0
+    # one-off tables, built explicitly (randomwalk.walk would build them on first use) so that
+    # every launch of a walk kernel in this process has the bench's size: the rocprofv3
+    # --kernel-trace average of the kernel is then the HIP-event average reported below
+    prepare_tables(torch, g, p, q, "exact", setup, "headline")
     leg = WalkLeg(torch, rw, g, start_all, W, L, p, q, "exact", batch, rank, world)
     res = leg.run(args.steps, args.warmup, barrier)
     elapsed, steps_total = reduce_job(torch, dist, use_dist, dev, res["elapsed"], res["steps_done"])
     value = steps_total / elapsed
     head_kernel = kernel_name(g, p, q)
+    # the SGNS legs train on walks of this leg (rows of the last batch walked)
+    nv = min(cfg["sgns_vertices"], leg.batch)
+    sg_walks = leg.walks[: nv * W][leg.valid[: nv * W].bool()].clone()
     ref_bytes = reference_algorithmic_bytes(torch, g, leg.walks, leg.valid)
     workload = (f"{cfg['label']}: {g.n_vertices} vertices, {g.n_edges} directed edges, "
                 f"{int(start_all.numel())} start vertices; p={p} q={q}, {W} walks x length {L}, "
@@ -232,10 +235,7 @@ def main():
     # ---- the second-order bias on the same graph: exact and rejection sampling -------------
     bp, bq = BIASED_PQ
     if not args.no_biased and (bp, bq) != (p, q):
-        t0 = time.perf_counter()
-        rw.walk(g, start_all[:64], W, 4, bp, bq, 42, mode="exact")  # edge classes, first use
-        torch.cuda.synchronize()
-        setup["edge_classes_build_s"] = time.perf_counter() - t0
+        prepare_tables(torch, g, bp, bq, "exact", setup, "biased")
         leg = WalkLeg(torch, rw, g, start_all, W, L, bp, bq, "exact", cfg["biased_batch"], rank, world)
         r2 = leg.run(args.steps, args.warmup, barrier)
         e2, s2 = reduce_job(torch, dist, use_dist, dev, r2["elapsed"], r2["steps_done"])
@@ -250,10 +250,7 @@ def main():
         del leg
         torch.cuda.empty_cache()
     if not args.no_fast:
-        t0 = time.perf_counter()
-        rw.walk(g, start_all[:64], W, 4, bp, bq, 42, mode="fast")  # K1 tables, first use
-        torch.cuda.synchronize()
-        setup["alias_tables_build_s"] = time.perf_counter() - t0
+        prepare_tables(torch, g, bp, bq, "fast", setup, "fast")
         leg = WalkLeg(torch, rw, g, start_all, W, L, bp, bq, "fast", batch, rank, world)
         r3 = leg.run(args.steps, args.warmup, barrier)
         e3, s3 = reduce_job(torch, dist, use_dist, dev, r3["elapsed"], r3["steps_done"])
@@ -267,18 +264,12 @@ def main():
                                 "roofline": roofline("walk_fast_kernel", r3, leg, args.config, bp,
                                                      bq, "fast", None)}
         del leg
-        g.slots = None
-        g.pivots = None
         torch.cuda.empty_cache()
+    # the walk tables are not needed any more (the CPU baseline reads rowptr / col only)
+    g.slots = g.pivots = g.hops = g.edge_classes = None
+    torch.cuda.empty_cache()
 
     # ---- SGNS on the config's model ------------------------------------------------------------
-    sg_walks = None
-    if not args.no_sgns or (not args.no_cpu_baseline and world == 1):
-        nv = min(cfg["sgns_vertices"], int(start_all.numel()))
-        lo = (rank * nv) % max(1, int(start_all.numel()) - nv + 1)
-        sw, sv = rw.walk(g, start_all[lo:lo + nv], W, L, p, q, 42, mode="exact")
-        sg_walks = sw[sv]
-        del sw, sv
     model = None
     if not args.no_sgns:
         sg, model = bench_sgns(args, cfg, torch, dist, g, sg_walks, rank, world, barrier, use_dist)
@@ -294,6 +285,30 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def prepare_tables(torch, g, p, q, mode, setup, tag):
+    """the one-off tables randomwalk.walk builds on first use for (p, q, mode), timed"""
+    from node2vec_amd.randomwalk import lanes_regime
+
+    biased = not (p == 1.0 and q == 1.0)
+
+    def timed(key, fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        setup[f"{tag}_{key}_s"] = time.perf_counter() - t0
+
+    if g.unit_weights:
+        if mode == "fast" and g.pivots is None:
+            timed("pivots_build", g.build_pivots)
+        if biased and g.edge_classes is None and (mode == "fast" or lanes_regime(p, q)):
+            timed("edge_classes_build", g.build_edge_classes)
+        if g.hops is None or (g.edge_classes is not None and not g.hops_have_classes):
+            timed("hop_table_build", g.build_hops)
+    elif g.slots is None and (mode == "fast" or not biased):
+        timed("alias_tables_build", g.build_alias)
 
 
 def kernel_name(g, p, q):
@@ -320,29 +335,38 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
     must touch at byte granularity, formula in `algorithmic_formula`).  The reference
     algorithm's bytes are reported beside it, never as the roofline."""
     per_launch_steps = leg.batch * leg.W * leg.L
+    hops = leg.g.hops is not None
     if mode == "fast":
         t = res["trials"] / max(res["steps_done"], 1)
-        alg = 16 + t * 16 + 4  # rowptr pair, one 16-B slot per trial, path write (+ searches)
-        formula = "16 (rowptr pair) + trials * 16 (slot) + 4 (path); membership searches extra"
+        alg = (t * 16 + 4) if hops else (16 + t * 16 + 4)
+        formula = ("trials * 16 (hop entry: neighbour, its row and degree, edge classes) + 4 (path)"
+                   if hops else "16 (rowptr pair) + trials * 16 (slot) + 4 (path)") + \
+            "; membership searches extra"
     elif p == 1.0 and q == 1.0:
-        alg = 16 + 4 + 4
-        formula = "16 (rowptr pair of v) + 4 (col[pick]) + 4 (path write) per step"
+        alg = (16 + 4) if hops else (16 + 4 + 4)
+        formula = ("16 (hop entry: col[pick] with the row pointer and degree of that neighbour) + "
+                   "4 (path write) per step" if hops else
+                   "16 (rowptr pair of v) + 4 (col[pick]) + 4 (path write) per step")
     else:
-        alg = 16 + 4 + 4 + 4
-        formula = ("16 (rowptr pair) + 4 (edge class word) + 4 (col[pick]) + 4 (path write) per "
-                   "step, + 4 per probe of the membership search; steps that run the pairing "
+        alg = (16 + 4) if hops else (16 + 4 + 4 + 4)
+        formula = (("16 (hop entry) + 4 (path write)" if hops else
+                    "16 (rowptr pair) + 4 (edge class word) + 4 (col[pick]) + 4 (path write)") +
+                   " per step, + 4 per probe of the membership search; steps that run the pairing "
                    "read both rows")
-    traffic = pmc_traffic(config, kernel, p, q, leg.batch)
+    kernel_key = kernel + (":hops" if hops else "")
+    traffic = pmc_traffic(config, kernel_key, p, q, leg.batch)
     alg_launch = alg * per_launch_steps
     used = traffic if traffic else alg_launch
     ach = used / res["kernel_s"]
     r = {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-         "frac": ach / HBM_PEAK, "traffic": traffic, "kernel": kernel,
+         "frac": ach / HBM_PEAK, "traffic": traffic, "kernel": kernel, "hop_table": hops,
          "kernel_ms": 1e3 * res["kernel_s"],
          "achieved_from": "pmc traffic" if traffic else "kernel algorithmic bytes (no pmc profile of this workload)",
          "algorithmic_bytes_per_launch": alg_launch, "algorithmic_bytes_per_walk_step": alg,
          "algorithmic_formula": formula,
-         "binding_resource": "dependent random gathers (latency / sectors per step), not streamed bytes"}
+         "binding_resource": "random 64-byte sector reads: the chip sustains ~50 G/s = 3.2 TB/s of them "
+                             "(profiles/r02_gather_ceiling.log), i.e. frac <= ~0.4 for a gather-bound "
+                             "kernel; what a kernel can lower is its sectors per step"}
     if ref_bytes:
         r["reference_algorithmic_bytes_per_walk_step"] = ref_bytes
         r["reference_algorithmic_GBps_equivalent"] = ref_bytes * per_launch_steps / res["kernel_s"] / 1e9

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define N2V_ABI_VERSION 4
+#define N2V_ABI_VERSION 5
 
 #define N2V_OK 0
 #define N2V_EINVAL (-1)  /* maps to ValueError (randomwalk.py:212-217)      */
@@ -56,6 +56,21 @@ typedef struct n2v_slot {
   double prob;
 } n2v_slot;
 
+/* One entry of the hop table (optional, unit-weight graphs; n2v_hops_build): everything a
+ * walker needs once it has chosen edge e = (v -> x), in ONE 16-byte access -- the neighbour
+ * id, the class counts of that edge (edge_classes[e], needed at the walker's next step) and
+ * the row of x: rowptr[x] in the low 40 bits, the out-degree of x in the high 24.  The
+ * reference fetches the same facts by two joins per step (fugue.py:146-148); on the GPU each
+ * would be a dependent random gather, and random 64-byte sectors per step are what bounds the
+ * walk kernels (DESIGN.md "K2").  Costs 16 bytes per edge of HBM. */
+typedef struct n2v_hop {
+  int32_t col;
+  uint32_t classes; /* layout of edge_classes[]; all ones = unknown (the kernels classify) */
+  uint64_t row;     /* rowptr[col] | (uint64_t)degree(col) << 40 */
+} n2v_hop;
+#define N2V_HOP_DEG_SHIFT 40
+#define N2V_HOP_ROW_MASK 0xffffffffffull
+
 /* The reference's adjacency DataFrame df_adj (fugue.py:130, randomwalk.py:266-275)
  * as CSR in HBM: one row per vertex id, neighbours sorted by dst ascending,
  * multi-edges kept.  Weights: the reference carries Python floats (randomwalk.py:20,
@@ -69,7 +84,9 @@ typedef struct n2v_slot {
  * (NULL = plain binary search): the test "x in N_out(src)" of randomwalk.py:226 then
  * touches 2-3 cache lines instead of log2(degree).  `edge_classes` (unit-weight graphs,
  * optional) is written by n2v_edge_classes_build: per edge e = (s -> v) the class counts
- * of the table generate_edge_alias_tables builds at (s, v) -- see there. */
+ * of the table generate_edge_alias_tables builds at (s, v) -- see there.  `hops` (unit-weight
+ * graphs, optional) is written by n2v_hops_build; with it a step of the p == q == 1, the
+ * class-count and the rejection kernels is one gather instead of two or three. */
 typedef struct n2v_graph {
   int64_t n_vertices;
   int64_t n_edges;
@@ -80,6 +97,7 @@ typedef struct n2v_graph {
   const n2v_slot *slots; /* [n_edges] or NULL */
   const int32_t *pivots; /* [(n_edges + 31) / 32]: col[min(32 j + 31, n_edges - 1)], or NULL */
   const uint32_t *edge_classes; /* [n_edges] or NULL */
+  const struct n2v_hop *hops;   /* [n_edges] or NULL (unit-weight graphs) */
 } n2v_graph;
 
 /* edge_classes[e] for e = (s -> v): bits 0..23 = number of entries x of N(v) with
@@ -121,6 +139,13 @@ int n2v_alias_build(const n2v_graph *g, n2v_slot *slots_out, uint32_t *status,
 int n2v_edge_classes_build(const n2v_graph *g, uint32_t *classes_out, uint32_t *status,
                            void *stream);
 
+/* Hop table of a unit-weight graph (struct n2v_hop above): hops_out[e] = {col[e],
+ * g->edge_classes ? g->edge_classes[e] : all ones, rowptr[col[e]] | degree(col[e]) << 40}.
+ * N2V_EINVAL when the graph has weights or 2^40 edges or more; a row of 2^24 entries or more
+ * sets N2V_ST_RANGE in status[0] (read after synchronising): the table must then be discarded
+ * (walk without it). */
+int n2v_hops_build(const n2v_graph *g, struct n2v_hop *hops_out, uint32_t *status, void *stream);
+
 /* Search index for N2V_WALK_FAST: the last id of every aligned block of 32 entries of
  * `col` (one 128-byte line).  Inside a sorted row the block ends ascend, so a
  * membership query is a binary search over (degree / 32) pivots followed by one over a
@@ -152,6 +177,35 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
              double inout_param, uint64_t seed, int32_t mode,
              int32_t *walks_out, uint8_t *valid_out, uint32_t *status,
              void *stream);
+
+/* The reference's transformer-level protocol on MATERIALISED tables, one partition (a batch of
+ * walker rows) per call.  n2v_walk never builds the table of a step; next_step_random_walk
+ * (randomwalk.py:300-339) and the reference's known-answer tests (tests/test_randomwalk.py:
+ * 131-189, 268-306) are stated on it, with the two uniforms supplied by the caller
+ * (random.random(), :336-337).  Rows are CSR-packed: row r holds the neighbour list of the
+ * walker's current vertex, ids[rowptr[r] .. rowptr[r+1]) sorted by id (fugue.py:130).
+ *
+ *   n2v_edge_bias    w_out[e] = the unnormalised probability generate_edge_alias_tables gives
+ *                    entry e (randomwalk.py:219-231): weight / return_param if ids[e] ==
+ *                    src_id[r], weight if ids[e] is in the row's src_nbs list (sorted; the
+ *                    caller's set src_nbs_id, :318), weight / inout_param otherwise; rows with
+ *                    src_id[r] < 0 (first step, :319-320) and src_id == NULL keep the weight.
+ *                    w / w64: fp32 or fp64 weights (both NULL = 1.0).  N2V_EINVAL when
+ *                    return_param or inout_param is 0 (ValueError, :214-217).
+ *   n2v_alias_build  on {rowptr, ids, w64 = w_out} then IS generate_alias_tables(biased row)
+ *                    (:232, :157-190).
+ *   n2v_alias_draw   sampling_from_alias(r1, r2) (:86-99) followed by the neighbour lookup of
+ *                    RandomPath.append (:140-144): vertex_out[r] = the id behind the drawn
+ *                    index.  r2 == NULL selects sampling_from_alias_wiki(r1) (:70-84).  A row
+ *                    without neighbours yields -1; r1 outside [0, 1) sets N2V_ST_RANGE (the
+ *                    reference raises IndexError). */
+int n2v_edge_bias(const int64_t *rowptr, const int32_t *ids, const float *w, const double *w64,
+                  const int32_t *src_id, const int64_t *src_rowptr, const int32_t *src_nbs,
+                  int64_t n_rows, int64_t nnz, double return_param, double inout_param,
+                  double *w_out, void *stream);
+int n2v_alias_draw(const int64_t *rowptr, const n2v_slot *slots, int64_t n_rows,
+                   const double *r1, const double *r2, int32_t *vertex_out, uint32_t *status,
+                   void *stream);
 
 /* a9 -- trim_hotspot_vertices (randomwalk.py:238-262): rows with more than
  * max_out_degree edges keep a uniform sample without replacement of exactly

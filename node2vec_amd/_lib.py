@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libn2v_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK, EINVAL, ELAUNCH, ENOGPU = 0, -1, -2, -3
 ST_ZERODIV, ST_RANGE = 1, 2
@@ -17,7 +17,8 @@ WIRE_F32, WIRE_BF16 = 0, 1
 # every symbol include/n2v_hip.h declares
 SYMBOLS = ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alias_build",
            "n2v_pivots_build", "n2v_edge_classes_build", "n2v_walk", "n2v_trim_mark",
-           "n2v_sgns_train", "n2v_delta_ref_init", "n2v_delta_pack", "n2v_delta_apply")
+           "n2v_sgns_train", "n2v_delta_ref_init", "n2v_delta_pack", "n2v_delta_apply",
+           "n2v_edge_bias", "n2v_alias_draw", "n2v_hops_build")
 
 
 class Graph(C.Structure):
@@ -25,7 +26,7 @@ class Graph(C.Structure):
     _fields_ = [("n_vertices", C.c_int64), ("n_edges", C.c_int64),
                 ("rowptr", C.c_void_p), ("col", C.c_void_p), ("w", C.c_void_p),
                 ("w64", C.c_void_p), ("slots", C.c_void_p), ("pivots", C.c_void_p),
-                ("edge_classes", C.c_void_p)]
+                ("edge_classes", C.c_void_p), ("hops", C.c_void_p)]
 
 
 class SgnsParams(C.Structure):
@@ -60,6 +61,8 @@ def load():
     L.n2v_alias_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p]
     L.n2v_edge_classes_build.restype = C.c_int
     L.n2v_edge_classes_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.n2v_hops_build.restype = C.c_int
+    L.n2v_hops_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p]
     L.n2v_pivots_build.restype = C.c_int
     L.n2v_pivots_build.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.n2v_walk.restype = C.c_int
@@ -81,6 +84,13 @@ def load():
     L.n2v_delta_apply.restype = C.c_int
     L.n2v_delta_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                   C.c_int32, C.c_int64, C.c_void_p]
+    L.n2v_edge_bias.restype = C.c_int
+    L.n2v_edge_bias.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_double,
+                                C.c_double, C.c_void_p, C.c_void_p]
+    L.n2v_alias_draw.restype = C.c_int
+    L.n2v_alias_draw.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

@@ -61,6 +61,18 @@ __device__ inline int pick_index(uint32_t u1, int n) {
   return (int)(((double)u1 * (1.0 / 4294967296.0)) * (double)n);
 }
 
+// hop table entry (include/n2v_hip.h): one 16-byte load
+__device__ __forceinline__ n2v_hop load_hop(const n2v_hop *p) {
+  const int4 v = *reinterpret_cast<const int4 *>(p);
+  n2v_hop h;
+  h.col = v.x;
+  h.classes = (uint32_t)v.y;
+  h.row = (uint64_t)(uint32_t)v.z | ((uint64_t)(uint32_t)v.w << 32);
+  return h;
+}
+__device__ __forceinline__ int64_t hop_row(const n2v_hop &h) { return (int64_t)(h.row & N2V_HOP_ROW_MASK); }
+__device__ __forceinline__ int hop_deg(const n2v_hop &h) { return (int)(h.row >> N2V_HOP_DEG_SHIFT); }
+
 __device__ inline int lane_id() { return __lane_id(); }
 
 __device__ inline double readlane_f64(double v, int lane) {

@@ -1,0 +1,56 @@
+// n2v_hops.hip -- the hop table of a unit-weight graph (struct n2v_hop, include/n2v_hip.h).
+//
+// The reference advances a walker by two joins per step (fugue.py:146-148): the walker row is
+// joined with the adjacency row of its current vertex and with that of its previous vertex.
+// On the GPU each of these is a dependent random gather, and the walk kernels are bound by
+// the chip's rate of random 64-byte sector reads (~50 G/s, profiles/r02_gather_ceiling.log),
+// not by bytes: a step of the p == q == 1 kernel was {col[row + pick]} then {rowptr[x],
+// rowptr[x + 1]} -- two sectors.  The hop table stores, beside every neighbour id, the row
+// pointer and degree of that neighbour and the class counts of the edge (edge_classes[e]), so
+// the entry that names the next vertex already says where its row starts, how long it is and
+// what the per-step table of the NEXT step looks like: one sector per step.  16 bytes per
+// edge; built in one streaming pass (one random 16-byte gather of rowptr per edge).
+#include "n2v_common.h"
+
+namespace n2v {
+
+__global__ __launch_bounds__(256) void hops_build_kernel(n2v_graph g, n2v_hop *__restrict__ out,
+                                                         uint32_t *__restrict__ overflow) {
+  bool bad = false;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < g.n_edges;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t x = g.col[e];
+    const int64_t b = g.rowptr[x];
+    const int64_t d = g.rowptr[x + 1] - b;
+    bad = bad || d >= (1ll << (64 - N2V_HOP_DEG_SHIFT));
+    const uint64_t row = (uint64_t)b | ((uint64_t)d << N2V_HOP_DEG_SHIFT);
+    const uint32_t cls = g.edge_classes ? g.edge_classes[e] : 0xffffffffu;
+    int4 v;
+    v.x = x;
+    v.y = (int)cls;
+    v.z = (int)(uint32_t)row;
+    v.w = (int)(uint32_t)(row >> 32);
+    *reinterpret_cast<int4 *>(out + e) = v;
+  }
+  if (bad) atomicOr(overflow, N2V_ST_RANGE);
+}
+
+}  // namespace n2v
+
+extern "C" int n2v_hops_build(const n2v_graph *g, n2v_hop *hops_out, uint32_t *status,
+                              void *stream) {
+  if (!g || !g->rowptr || g->n_vertices < 0 || g->n_edges < 0) return N2V_EINVAL;
+  if (g->w || g->w64) return N2V_EINVAL;  // unit-weight graphs only
+  if (g->n_edges >= (1ll << N2V_HOP_DEG_SHIFT)) return N2V_EINVAL;
+  if (g->n_edges == 0) return N2V_OK;
+  if (!g->col || !hops_out || !status) return N2V_EINVAL;
+  // a degree of 2^24 or more cannot be packed: the kernel then sets N2V_ST_RANGE in status[0]
+  // and the caller must not use the table
+  int64_t blocks = (g->n_edges + 255) / 256;
+  const int64_t cap = n2v::resident_blocks((const void *)n2v::hops_build_kernel, 256, 0) * 2;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(n2v::hops_build_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, *g, hops_out, status);
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}

@@ -80,7 +80,10 @@ __device__ __forceinline__ int lower_bound_lane(const int32_t *a, int m, int32_t
 // envelope -- 3.5 -> 2.1 trials per step at p = 0.5, q = 2); and the number nM of neighbours of
 // v that are neighbours of s: when it is 0 the test "x in N(s)" (:226) is known to fail and
 // its binary search is skipped.
-template <bool kUnit>
+// kHops (unit weights): candidates come from the hop table (n2v_hops_build) -- the accepted
+// entry already holds the row pointer and degree of the next vertex and the class counts of the
+// edge, so an accepted step needs no further gather (one sector per trial + the membership test).
+template <bool kUnit, bool kHops>
 __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double p, double q, uint64_t seed, int32_t *__restrict__ walks_out,
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
   const double b_lo = fmin(1.0, inv_q), b_hi = fmax(1.0, inv_q);  // biases of the non-return entries
   const double beta_max = fmax(b_hi, inv_p);
   const bool biased = !(p == 1.0 && q == 1.0);
-  const bool have_ec = kUnit && g.edge_classes != nullptr;
+  const bool have_ec = kUnit && (kHops || g.edge_classes != nullptr);
   const bool fold_return = have_ec && inv_p > b_hi;
   const bool base_aligned = (reinterpret_cast<uintptr_t>(walks_out) & 63u) == 0;
 
@@ -188,7 +191,14 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
     const int pick = pick_index(u1, n);
     int32_t x;
     int64_t e = vb + pick;  // kUnit: the edge (v -> x) itself
-    if (kUnit) {
+    n2v_hop h;
+    h.col = -1;
+    h.classes = 0xffffffffu;
+    h.row = 0;
+    if (kHops) {
+      h = load_hop(g.hops + e);
+      x = h.col;
+    } else if (kUnit) {
       x = g.col[e];
     } else {
       const n2v_slot sl = g.slots[e];
@@ -216,6 +226,7 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
         if (ub < rho) {
           x = s;
           e = vb + lower_bound_lane(g.col + vb, n, s);  // the edge (v -> s): its counts are needed next
+          if (kHops) h = load_hop(g.hops + e);
         } else if (x == s) {
           accept = false;  // drawn among the OTHER entries: try again
         } else {
@@ -241,14 +252,19 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
     const bool finished = step == walk_length;
     bool dropped = false;
     if (!finished) {
-      vb = g.rowptr[v];
-      n = (int)(g.rowptr[v + 1] - vb);
+      if (kHops) {
+        vb = hop_row(h);
+        n = hop_deg(h);
+      } else {
+        vb = g.rowptr[v];
+        n = (int)(g.rowptr[v + 1] - vb);
+      }
       dropped = n == 0;  // fugue.py:147: the walker vanishes at a sink
       hstep = step_bits(h0, (uint32_t)step);
       rho = -1.0;
       shared = -1;
       if (have_ec && biased && !dropped) {
-        const uint32_t ec = g.edge_classes[e];
+        const uint32_t ec = kHops ? h.classes : g.edge_classes[e];
         const uint32_t fR = ec >> N2V_EC_RETURN_SHIFT, fM = ec & N2V_EC_SHARED_MASK;
         if (fM != N2V_EC_SHARED_MASK) shared = (int)fM;
         if (fold_return && fR != N2V_EC_RETURN_SAT) {
@@ -280,20 +296,25 @@ extern "C" int n2v_walk_fast_launch(const n2v_graph *g, const int32_t *start_ids
   if (!unit && !g->slots) return N2V_EINVAL;
   const int threads = 256;
   int64_t blocks = (total + threads - 1) / threads;
-  const void *fn = unit ? (const void *)n2v::walk_fast_kernel<true>
-                        : (const void *)n2v::walk_fast_kernel<false>;
+  const bool hops = unit && g->hops != nullptr;
+  const void *fn = hops   ? (const void *)n2v::walk_fast_kernel<true, true>
+                   : unit ? (const void *)n2v::walk_fast_kernel<true, false>
+                          : (const void *)n2v::walk_fast_kernel<false, false>;
   const int64_t cap = n2v::resident_blocks(fn, threads, 0);
   if (blocks > cap) blocks = cap;
   // status[2..3]: 64-bit trial counter (include/n2v_hip.h)
   unsigned long long *trials = reinterpret_cast<unsigned long long *>(status + 2);
-  if (unit)
-    hipLaunchKernelGGL(n2v::walk_fast_kernel<true>, dim3((unsigned)blocks), dim3(threads), 0,
-                       (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, p, q,
-                       seed, walks_out, valid_out, status, trials);
+#define N2V_FAST_LAUNCH(U, H)                                                                    \
+  hipLaunchKernelGGL((n2v::walk_fast_kernel<U, H>), dim3((unsigned)blocks), dim3(threads), 0,   \
+                     (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, p, q, \
+                     seed, walks_out, valid_out, status, trials)
+  if (hops)
+    N2V_FAST_LAUNCH(true, true);
+  else if (unit)
+    N2V_FAST_LAUNCH(true, false);
   else
-    hipLaunchKernelGGL(n2v::walk_fast_kernel<false>, dim3((unsigned)blocks), dim3(threads), 0,
-                       (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, p, q,
-                       seed, walks_out, valid_out, status, trials);
+    N2V_FAST_LAUNCH(false, false);
+#undef N2V_FAST_LAUNCH
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
 }

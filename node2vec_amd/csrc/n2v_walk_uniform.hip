@@ -15,11 +15,18 @@
 //     words of the 64-byte sector of walks_out it is currently filling in registers
 //     (selected by a v_cndmask chain, no scratch) and stores the sector whole when it is
 //     complete -- four aligned 16-byte stores per 16 steps.
+//   * with the hop table (n2v_hops_build, 16 bytes per edge: neighbour id + its row pointer
+//     and degree) the two dependent gathers of a step become ONE: the entry that names the next
+//     vertex also says where its row starts and how long it is.  The chip sustains ~50 G random
+//     64-byte sector reads per second whatever the kernel does (profiles/r02_gather_ceiling.log),
+//     so halving the sectors per step is the only lever left; it costs 16 B/edge of HBM
+//     (12 GB at cfg 4 of 288 GB).
 // Same uniform stream as every other kernel (step_bits, n2v_common.h): bit-identical walks.
 #include "n2v_common.h"
 
 namespace n2v {
 
+template <bool kHops>
 __global__ __launch_bounds__(256, 8) void walk_uniform_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, uint64_t seed, int32_t *__restrict__ walks_out,
@@ -92,14 +99,22 @@ __global__ __launch_bounds__(256, 8) void walk_uniform_kernel(
       if (walking) {
         const uint64_t bits = step_bits(h0, (uint32_t)step);
         const int pick = pick_index((uint32_t)(bits >> 32), n);  // int(r1 * n); r2 is irrelevant
-        x = g.col[vb + pick];
-        if (step + 1 < walk_length) {
-          vb = g.rowptr[x];
-          n = (int)(g.rowptr[x + 1] - vb);
-          if (n == 0) {  // fugue.py:147: the walker vanishes at a sink, the rest of its row is -1
-            walking = false;
-            alive = false;
+        if (kHops) {
+          const n2v_hop h = load_hop(g.hops + vb + pick);
+          x = h.col;
+          vb = hop_row(h);
+          n = hop_deg(h);
+        } else {
+          x = g.col[vb + pick];
+          if (step + 1 < walk_length) {
+            vb = g.rowptr[x];
+            n = (int)(g.rowptr[x + 1] - vb);
           }
+        }
+        // fugue.py:147: the walker vanishes at a sink, the rest of its row is -1
+        if (step + 1 < walk_length && n == 0) {
+          walking = false;
+          alive = false;
         }
       }
       if (have) {
@@ -127,11 +142,18 @@ extern "C" int n2v_walk_uniform_try(const n2v_graph *g, const int32_t *start_ids
   if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
     return N2V_ELAUNCH;
   int64_t blocks = (total + 255) / 256;
-  const int64_t cap = n2v::resident_blocks((const void *)n2v::walk_uniform_kernel, 256, 0);
+  const void *fn = g->hops ? (const void *)n2v::walk_uniform_kernel<true>
+                           : (const void *)n2v::walk_uniform_kernel<false>;
+  const int64_t cap = n2v::resident_blocks(fn, 256, 0);
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(n2v::walk_uniform_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                     (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, seed,
-                     walks_out, valid_out, status);
+  if (g->hops)
+    hipLaunchKernelGGL(n2v::walk_uniform_kernel<true>, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, seed,
+                       walks_out, valid_out, status);
+  else
+    hipLaunchKernelGGL(n2v::walk_uniform_kernel<false>, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, seed,
+                       walks_out, valid_out, status);
   if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
   return 1;
 }

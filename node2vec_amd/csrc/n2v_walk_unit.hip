@@ -1294,6 +1294,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_UNIT_WAVES) void walk_exac
 #ifndef N2V_LANES_WAVES
 #define N2V_LANES_WAVES 5
 #endif
+// kHops: the hop table (n2v_hops_build) is at hand -- the entry that names the next vertex also
+// carries its row pointer, its degree and the class counts of the edge just walked (needed at
+// the next step), so the quick phase of a step is ONE 16-byte gather plus the membership test.
+template <bool kHops>
 __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exact_unit_lanes_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double p, double q, UnitConsts K, uint64_t seed,
@@ -1333,6 +1337,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
       }
     }
     int64_t vb = 0, sb = 0, e_prev = 0;
+    uint32_t ec_prev = 0;  // kHops: class counts of the edge (s -> v), from the hop that walked it
     int n = 0, m = 0;
     if (alive) {
       vb = g.rowptr[start];
@@ -1350,6 +1355,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
       int32_t x = -1;
       bool unresolved = false;
       uint32_t u1 = 0, u2 = 0;
+      n2v_hop h;
+      h.col = -1;
+      h.classes = 0;
+      h.row = 0;
 #ifdef N2V_STATS
       const unsigned long long t_q0 = __builtin_readcyclecounter();
 #endif
@@ -1359,9 +1368,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
         u2 = (uint32_t)bits;
         const int pick = pick_index(u1, n);
         idx = pick;
-        x = g.col[vb + pick];
+        if (kHops) {
+          h = load_hop(g.hops + vb + pick);
+          x = h.col;
+        } else {
+          x = g.col[vb + pick];
+        }
         if (s >= 0 && biased) {
-          const uint32_t ec = g.edge_classes[e_prev];
+          const uint32_t ec = kHops ? ec_prev : g.edge_classes[e_prev];
           const uint32_t fR = ec >> N2V_EC_RETURN_SHIFT, fM = ec & N2V_EC_SHARED_MASK;
           if (fR == N2V_EC_RETURN_SAT || fM == N2V_EC_SHARED_MASK) {
             unresolved = true;  // a count that did not fit: classify the row
@@ -1381,7 +1395,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
               if (!any_under || !any_over) {  // the loop of :182 never runs
                 if (!(r2 < p_pick)) {
                   idx = 0;
-                  x = g.col[vb];
+                  if (kHops) {
+                    h = load_hop(g.hops + vb);
+                    x = h.col;
+                  } else {
+                    x = g.col[vb];
+                  }
                 }
               } else {
                 unresolved = true;
@@ -1429,17 +1448,30 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
 #ifdef N2V_STATS
       WS.v[27] += __builtin_readcyclecounter() - t_f0;
 #endif
-      if (unresolved) x = g.col[vb + idx];
+      if (unresolved) {
+        if (kHops) {
+          h = load_hop(g.hops + vb + idx);
+          x = h.col;
+        } else {
+          x = g.col[vb + idx];
+        }
+      }
       if (walking) {
         out[step + 1] = x;
         e_prev = vb + idx;
+        ec_prev = h.classes;
         s = v;  // the row of the new previous vertex is the row just walked
         sb = vb;
         m = n;
         v = x;
         if (step + 1 < walk_length) {
-          vb = g.rowptr[v];
-          n = (int)(g.rowptr[v + 1] - vb);
+          if (kHops) {
+            vb = hop_row(h);
+            n = hop_deg(h);
+          } else {
+            vb = g.rowptr[v];
+            n = (int)(g.rowptr[v + 1] - vb);
+          }
           if (n == 0) {  // fugue.py:147: the walker vanishes at a sink
             walking = false;
             alive = false;
@@ -1502,15 +1534,23 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
   // pairing, and one wave per walker (below) is the better shape (measured: cfg 2, p = 4,
   // q = 0.25: 344 against 241 M steps/s; p = 2, q = 1: 938 against 711).
   const bool lanes_regime = (p == 1.0 && q == 1.0) || (K.bO <= 1.0 && K.bR >= K.bO);
-  if (dyadic && lanes_regime && total < 0xffffff00ll && (g->edge_classes || (p == 1.0 && q == 1.0))) {
+  if (dyadic && lanes_regime && total < 0xffffff00ll &&
+      (g->edge_classes || g->hops || (p == 1.0 && q == 1.0))) {
     int64_t blocks = (total + 255) / 256;
-    const int64_t cap = n2v::resident_blocks((const void *)n2v::walk_exact_unit_lanes_kernel,
-                                             n2v::kWavesPerBlock * 64, 0);
+    const void *lfn = g->hops ? (const void *)n2v::walk_exact_unit_lanes_kernel<true>
+                              : (const void *)n2v::walk_exact_unit_lanes_kernel<false>;
+    const int64_t cap = n2v::resident_blocks(lfn, n2v::kWavesPerBlock * 64, 0);
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(n2v::walk_exact_unit_lanes_kernel, dim3((unsigned)blocks),
-                       dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, *g, start_ids,
-                       n_start, num_walks, walk_length, p, q, K, seed, walks_out, valid_out,
-                       status);
+    if (g->hops)
+      hipLaunchKernelGGL(n2v::walk_exact_unit_lanes_kernel<true>, dim3((unsigned)blocks),
+                         dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, *g, start_ids,
+                         n_start, num_walks, walk_length, p, q, K, seed, walks_out, valid_out,
+                         status);
+    else
+      hipLaunchKernelGGL(n2v::walk_exact_unit_lanes_kernel<false>, dim3((unsigned)blocks),
+                         dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, *g, start_ids,
+                         n_start, num_walks, walk_length, p, q, K, seed, walks_out, valid_out,
+                         status);
     if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
     return 1;
   }

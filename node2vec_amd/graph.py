@@ -35,6 +35,8 @@ class DeviceGraph:
         self.slots: Optional[torch.Tensor] = None  # int32 [E, 4] view of n2v_slot[E]
         self.pivots: Optional[torch.Tensor] = None  # int32 [(E + 31) / 32] search index (fast mode)
         self.edge_classes: Optional[torch.Tensor] = None  # uint32-in-int32 [E] (exact mode, unit weights)
+        self.hops: Optional[torch.Tensor] = None  # int32 [E, 4] view of n2v_hop[E] (unit weights)
+        self.hops_have_classes = False
 
     @property
     def w(self) -> torch.Tensor:
@@ -123,10 +125,11 @@ class DeviceGraph:
     def to(self, device) -> "DeviceGraph":
         g = DeviceGraph(self.rowptr.to(device), self.col.to(device),
                         None if self._w is None else self._w.to(device))
-        for name in ("slots", "pivots", "edge_classes"):
+        for name in ("slots", "pivots", "edge_classes", "hops"):
             t = getattr(self, name)
             if t is not None:
                 setattr(g, name, t.to(device))
+        g.hops_have_classes = self.hops_have_classes
         return g
 
     def c_struct(self) -> _lib.Graph:
@@ -137,7 +140,8 @@ class DeviceGraph:
                           self._w.data_ptr() if w64 else 0,
                           0 if self.slots is None else self.slots.data_ptr(),
                           0 if self.pivots is None else self.pivots.data_ptr(),
-                          0 if self.edge_classes is None else self.edge_classes.data_ptr())
+                          0 if self.edge_classes is None else self.edge_classes.data_ptr(),
+                          0 if self.hops is None else self.hops.data_ptr())
 
     # -- a9 -----------------------------------------------------------------------
     def trimmed(self, max_out_degree: int, seed: int) -> "DeviceGraph":
@@ -202,6 +206,38 @@ class DeviceGraph:
                                               _lib.current_stream_ptr())
             _lib.check(rc, "n2v_edge_classes_build")
         self.edge_classes = ec
+        return self
+
+    HOP_MAX_DEGREE = 1 << 24  # n2v_hop packs the degree into 24 bits
+
+    def build_hops(self, with_classes: bool = False) -> "DeviceGraph":
+        """Hop table (n2v_hops_build): per edge {neighbour id, class counts of the edge, row
+        pointer and degree of the neighbour} in 16 bytes, so that a walk step is one gather.
+        `with_classes` builds the per-edge class counts first (biased walks need them inside
+        the table).  Unit-weight graphs with rows below 2^24 entries only; otherwise the graph
+        is left without the table and the kernels walk the CSR arrays as before."""
+        L = _lib.load()
+        _lib.require_gpu()
+        if not self.unit_weights:
+            raise ValueError("the hop table exists for unit-weight graphs only")
+        if not self.rowptr.is_cuda:
+            raise RuntimeError("build_hops: graph is not on the GPU")
+        if with_classes and self.edge_classes is None:
+            self.build_edge_classes()
+        if self.n_edges == 0 or self.n_edges >= (1 << 40) or int(self.degrees().max()) >= self.HOP_MAX_DEGREE:
+            self.hops = None
+            return self
+        self.hops = None  # the kernel must not read a half-written table through c_struct()
+        hops = torch.empty((self.n_edges, 4), dtype=torch.int32, device=self.device)
+        status = torch.zeros(4, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = L.n2v_hops_build(self.c_struct(), hops.data_ptr(), status.data_ptr(),
+                                  _lib.current_stream_ptr())
+        _lib.check(rc, "n2v_hops_build")
+        if int(status[0].item()) & _lib.ST_RANGE:
+            return self
+        self.hops = hops
+        self.hops_have_classes = self.edge_classes is not None
         return self
 
     def build_pivots(self) -> "DeviceGraph":

@@ -29,7 +29,7 @@ def test_library_loaded_is_in_tree():
     from node2vec_amd import _lib
 
     L = _lib.load()
-    assert L.n2v_abi_version() == 4
+    assert L.n2v_abi_version() == 5
     assert L.n2v_device_count() >= 1
 
 
@@ -135,3 +135,47 @@ def test_results_independent_of_sharding():
     halves = [rw.walk(g, part, 3, 20, 0.5, 2.0, 42) for part in torch.chunk(start, 3)]
     cat = torch.cat([h[0] for h in halves])
     assert torch.equal(full, cat) and bool(v.all())
+
+
+@pytest.mark.parametrize("pq", [(1.0, 1.0), (0.5, 2.0), (1.0, 2.0), (0.25, 4.0), (4.0, 0.25), (3.0, 0.7)])
+def test_hop_table_and_class_counts_change_no_bit(oracle, pq):
+    """unit-weight graph with sinks, multi-edges and hubs: the walks are the same bits with the
+    hop table (one gather per step), with the CSR arrays + per-edge class counts, and with the
+    wave-per-walker kernel that uses neither -- and equal to the oracle; fast mode draws the same
+    walks with and without the hop table"""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+
+    p, q = pq
+    rng = np.random.default_rng(5)
+    nv = 3000
+    src = np.concatenate([rng.integers(0, nv, 24000), rng.integers(0, 20, 9000), rng.integers(0, nv, 9000)])
+    dst = np.concatenate([rng.integers(0, nv - 50, 24000), rng.integers(0, nv - 50, 9000), rng.integers(0, 20, 9000)])
+    g = DeviceGraph.from_edges(src, dst, None, n_vertices=nv, device="cuda")  # ids >= nv - 50 are sinks
+    assert g.unit_weights
+    start = rw.start_vertices(g)
+    a, av = rw.walk(g, start, 3, 25, p, q, 9)
+    assert g.hops is not None and (p == q == 1.0 or g.hops_have_classes or not rw.lanes_regime(p, q))
+    b, bv = rw.walk(g, start, 3, 25, p, q, 9, use_hops=False)
+    c, cv = rw.walk(g, start, 3, 25, p, q, 9, use_hops=False, use_edge_classes=False)
+    assert torch.equal(a, b) and torch.equal(av, bv) and torch.equal(a, c) and torch.equal(av, cv)
+    want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), None,
+                                  start.cpu().numpy(), 3, 25, p, q, 9, n_threads=8)
+    assert np.array_equal(av.cpu().numpy(), wv)
+    assert np.array_equal(a.cpu().numpy()[wv], want[wv])
+    assert not bool(av.all())  # some walkers did vanish at sinks
+    fa, fav = rw.walk(g, start, 3, 25, p, q, 9, mode="fast")
+    fb, fbv = rw.walk(g, start, 3, 25, p, q, 9, mode="fast", use_hops=False)
+    assert torch.equal(fa, fb) and torch.equal(fav, fbv)
+
+
+def test_hop_table_is_refused_for_rows_it_cannot_pack():
+    """a row of 2^24 neighbours or more does not fit n2v_hop: the graph stays without the table"""
+    from node2vec_amd.graph import DeviceGraph
+
+    n = (1 << 24) + 3
+    rowptr = torch.tensor([0, n, n], dtype=torch.int64, device="cuda")
+    col = torch.ones(n, dtype=torch.int32, device="cuda")
+    g = DeviceGraph(rowptr, col, None)
+    g.build_hops()
+    assert g.hops is None
