@@ -245,10 +245,20 @@ typedef struct n2v_sgns_params {
   int32_t negative; /* 1 .. 32 */
   float alpha;      /* learning rate of this pass (host applies the linear decay) */
   int32_t deterministic;
-  int32_t reserved;
+  int32_t cum_index_bits;   /* log2 of the number of buckets of cum_index (1 .. 30) */
+  const int32_t *cum_index; /* device, [2^bits + 1] from n2v_cum_index_build, or NULL */
 } n2v_sgns_params;
 
 #define N2V_SGNS_MAX_SENTENCE 256 /* longer walks: split rows on the host */
+
+/* Optional index over cum_table for the negative draws of K3: index_out[b] =
+ * bisect_left(cum_table, b << (31 - bits)) for b = 0 .. 2^bits.  A draw r then needs
+ * bisect_left only inside [index[r >> (31 - bits)], index[(r >> (31 - bits)) + 1]]: the same
+ * word as gensim's bisect over the whole table, in one or two memory sectors instead of
+ * log2(n_vocab) dependent probes (at 10^8 words the probes were a fifth of the kernel's read
+ * sectors).  index_out: [2^bits + 1] int32. */
+int n2v_cum_index_build(const uint32_t *cum_table, int64_t n_vocab, int32_t bits,
+                        int32_t *index_out, void *stream);
 
 int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t walk_len,
                    float *syn0, float *syn1neg, const uint32_t *cum_table,

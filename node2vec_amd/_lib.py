@@ -18,7 +18,7 @@ WIRE_F32, WIRE_BF16 = 0, 1
 SYMBOLS = ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alias_build",
            "n2v_pivots_build", "n2v_edge_classes_build", "n2v_walk", "n2v_trim_mark",
            "n2v_sgns_train", "n2v_delta_ref_init", "n2v_delta_pack", "n2v_delta_apply",
-           "n2v_edge_bias", "n2v_alias_draw", "n2v_hops_build")
+           "n2v_edge_bias", "n2v_alias_draw", "n2v_hops_build", "n2v_cum_index_build")
 
 
 class Graph(C.Structure):
@@ -33,7 +33,8 @@ class SgnsParams(C.Structure):
     """struct n2v_sgns_params"""
     _fields_ = [("n_vocab", C.c_int64), ("sentence_base", C.c_int64), ("seed", C.c_uint64),
                 ("dim", C.c_int32), ("window", C.c_int32), ("negative", C.c_int32),
-                ("alpha", C.c_float), ("deterministic", C.c_int32), ("reserved", C.c_int32)]
+                ("alpha", C.c_float), ("deterministic", C.c_int32), ("cum_index_bits", C.c_int32),
+                ("cum_index", C.c_void_p)]
 
 
 _lib = None
@@ -61,6 +62,8 @@ def load():
     L.n2v_alias_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p]
     L.n2v_edge_classes_build.restype = C.c_int
     L.n2v_edge_classes_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.n2v_cum_index_build.restype = C.c_int
+    L.n2v_cum_index_build.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     L.n2v_hops_build.restype = C.c_int
     L.n2v_hops_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p]
     L.n2v_pivots_build.restype = C.c_int

@@ -220,7 +220,19 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (VEC <= 2 ? 8 : 1)) void sgns_kern
                              ((uint64_t)i * 2ULL * (uint64_t)window + (uint64_t)rel) *
                                  (uint64_t)K + (uint64_t)d;
         const uint32_t x = (uint32_t)((sgns_draw(hs, idx) >> 16) % (uint64_t)domain);
-        int blo = bucket[x >> 21], bhi = bucket[(x >> 21) + 1];
+        // bisect_left(cum_table, x) is confined to the bucket of x: [index[b], index[b + 1]] with
+        // b = x >> shift -- through the caller's fine index in HBM (n2v_cum_index_build: with
+        // 10^8 words a draw costs one index sector + one table sector instead of ~17 dependent
+        // probes), else through the 1024-bucket index in LDS.  Same result either way.
+        int blo, bhi;
+        if (P.cum_index) {
+          const uint32_t bk = x >> (31 - P.cum_index_bits);
+          blo = P.cum_index[bk];
+          bhi = P.cum_index[bk + 1];
+        } else {
+          blo = bucket[x >> 21];
+          bhi = bucket[(x >> 21) + 1];
+        }
         while (blo < bhi) {  // bisect_left inside the bucket
           const int mid = (blo + bhi) >> 1;
           if (cum_table[mid] < x)
@@ -404,6 +416,36 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (VEC <= 2 ? 8 : 1)) void sgns_kern
 
 }  // namespace n2v
 
+namespace n2v {
+// index[b] = bisect_left(cum_table, b << (31 - bits)), b = 0 .. 2^bits (2^bits + 1 entries)
+__global__ __launch_bounds__(256) void cum_index_kernel(const uint32_t *__restrict__ cum_table,
+                                                        int64_t n_vocab, int bits,
+                                                        int32_t *__restrict__ index) {
+  const int64_t n = (1ll << bits) + 1;
+  const int iters = 64 - __clzll((long long)n_vocab);
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n;
+       b += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t x = (uint64_t)b << (31 - bits);
+    index[b] = x > 0x7fffffffull ? (int32_t)n_vocab
+                                 : bisect_left_u32(cum_table, n_vocab, (uint32_t)x, iters);
+  }
+}
+}  // namespace n2v
+
+extern "C" int n2v_cum_index_build(const uint32_t *cum_table, int64_t n_vocab, int32_t bits,
+                                   int32_t *index_out, void *stream) {
+  if (!cum_table || !index_out || n_vocab < 1 || n_vocab >= (1ll << 31) || bits < 1 || bits > 30)
+    return N2V_EINVAL;
+  const int64_t n = (1ll << bits) + 1;
+  int64_t blocks = (n + 255) / 256;
+  const int64_t cap = n2v::resident_blocks((const void *)n2v::cum_index_kernel, 256, 0) * 2;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(n2v::cum_index_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, cum_table, n_vocab, bits, index_out);
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}
+
 extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t walk_len,
                               float *syn0, float *syn1neg, const uint32_t *cum_table,
                               const uint32_t *sample_int, const float *exp_table,
@@ -426,7 +468,7 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   if (waves < 1) waves = 1;
   if (waves > n_walks) waves = n_walks;
   int64_t blocks = (waves + kSgnsWaves - 1) / kSgnsWaves;
-  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (P->cum_index && (P->cum_index_bits < 1 || P->cum_index_bits > 30)) return N2V_EINVAL;
 #ifdef N2V_SGNS_TUNE
   if (const char *e = getenv("N2V_SGNS_BLOCKS_PER_CU")) { int64_t cap = 256 * (int64_t)atoi(e); if (blocks > cap) blocks = cap; }
 #endif
@@ -447,6 +489,10 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
 #define N2V_LAUNCH(VV)                                                                       \
   do {                                                                                       \
     constexpr int kD = (VV) <= 8 ? 1 : 0;                                                     \
+    if (!P->deterministic) {                                                                 \
+      const int64_t cap = resident_blocks((const void *)sgns_kernel<VV, kD>, (int)block.x, lds); \
+      if (blocks > cap) blocks = cap;                                                        \
+    }                                                                                        \
     hipLaunchKernelGGL((sgns_kernel<VV, kD>), dim3((unsigned)blocks), block, lds, st, walks,  \
                        n_walks, walk_len, syn0, syn1neg, cum_table, sample_int, exp_table,    \
                        *P, pairs_out);                                                        \

@@ -110,7 +110,8 @@ class SgnsModel:
     """The trained state: what gensim keeps in model.wv.vectors / trainables.syn1neg."""
 
     def __init__(self, vocab: Vocab, dim: int, window: int, negative: int, seed: int,
-                 sample: float = 0.0, ns_exponent: float = 0.75, device=None):
+                 sample: float = 0.0, ns_exponent: float = 0.75, device=None,
+                 use_cum_index: bool = True):
         device = device or vocab.ids.device
         self.vocab, self.dim, self.window, self.negative = vocab, int(dim), int(window), int(negative)
         self.seed = int(seed) & (2 ** 64 - 1)
@@ -124,6 +125,16 @@ class SgnsModel:
         if self.sample_int is not None:
             self.sample_int = self.sample_int.to(device)
         self.exp_table = torch.from_numpy(exp_table()).to(device)
+        # fine index over cum_table (n2v_cum_index_build): ~16 words per bucket, so a negative
+        # draw is one index sector + one table sector; built on the GPU, skipped on CPU tensors
+        self.cum_index, self.cum_index_bits = None, 0
+        if self.cum_table.is_cuda and use_cum_index:
+            self.cum_index_bits = int(min(24, max(10, math.ceil(math.log2(max(n, 2))) - 4)))
+            self.cum_index = torch.empty((1 << self.cum_index_bits) + 1, dtype=torch.int32, device=device)
+            with torch.cuda.device(device):
+                _lib.check(_lib.load().n2v_cum_index_build(
+                    self.cum_table.data_ptr(), n, self.cum_index_bits, self.cum_index.data_ptr(),
+                    _lib.current_stream_ptr()), "n2v_cum_index_build")
         # include/n2v_hip.h: pairs_out is two uint64, [0] the pair counter, [1] kernel scratch
         self._counters = torch.zeros(2, dtype=torch.int64, device=device)
         self.pairs = self._counters[:1]
@@ -141,7 +152,8 @@ class SgnsModel:
             raise ValueError(f"walks longer than {MAX_SENTENCE}: split rows first (split_rows)")
         walks_idx = walks_idx.contiguous()
         P = _lib.SgnsParams(len(self.vocab), int(sentence_base), self.seed, self.dim, self.window,
-                            self.negative, float(alpha), int(bool(deterministic)), 0)
+                            self.negative, float(alpha), int(bool(deterministic)),
+                            self.cum_index_bits, 0 if self.cum_index is None else self.cum_index.data_ptr())
         with torch.cuda.device(walks_idx.device):
             rc = L.n2v_sgns_train(walks_idx.data_ptr(), walks_idx.shape[0], walks_idx.shape[1],
                                   self.syn0.data_ptr(), self.syn1neg.data_ptr(),

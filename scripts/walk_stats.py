@@ -6,7 +6,11 @@ sys.path.insert(0, ROOT)
 from node2vec_amd import _lib
 _lib.LIB_PATH = os.path.join(ROOT, "build_stats", "libn2v_stats.so")  # developer build, loaded by path
 from node2vec_amd import synthetic, randomwalk as rw
-if os.environ.get("GRAPH") == "cfg3":
+if os.environ.get("GRAPH") == "cfg4":
+    g = synthetic.chung_lu(100_000_000, 500_000_000, device="cuda").trimmed(10_000, 42)
+    sv = rw.start_vertices(g)
+    start = sv[torch.randperm(sv.numel(), device="cuda")[:131072]].contiguous()
+elif os.environ.get("GRAPH") == "cfg3":
     g = synthetic.chung_lu(10_000_000, 100_000_000, device="cuda").trimmed(10_000, 42)
     sv = rw.start_vertices(g)
     start = sv[torch.randperm(sv.numel(), device="cuda")[:131072]].contiguous()

@@ -18,7 +18,7 @@ def test_header_declares_the_expected_entry_points():
     for want in ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alias_build", "n2v_pivots_build",
                  "n2v_edge_classes_build", "n2v_walk", "n2v_trim_mark", "n2v_sgns_train",
                  "n2v_delta_ref_init", "n2v_delta_pack", "n2v_delta_apply", "n2v_edge_bias", "n2v_alias_draw",
-                 "n2v_hops_build"):
+                 "n2v_hops_build", "n2v_cum_index_build"):
         assert want in names
 
 
@@ -50,10 +50,10 @@ def test_ctypes_structs_match_header_layout():
     body = text[text.index("typedef struct n2v_graph {"):text.index("} n2v_graph;")]
     fields = re.findall(r"\*?\s*\b(\w+);", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
     assert fields == [f[0] for f in _lib.Graph._fields_]
-    assert ctypes.sizeof(_lib.SgnsParams) == 3 * 8 + 6 * 4
+    assert ctypes.sizeof(_lib.SgnsParams) == 3 * 8 + 6 * 4 + 8
     assert [f[0] for f in _lib.SgnsParams._fields_] == [
         "n_vocab", "sentence_base", "seed", "dim", "window", "negative", "alpha",
-        "deterministic", "reserved"]
+        "deterministic", "cum_index_bits", "cum_index"]
 
 
 def test_product_package_never_touches_the_oracle():

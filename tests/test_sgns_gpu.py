@@ -173,3 +173,36 @@ def test_hogwild_vs_deterministic_statistical_parity():
     assert a_det > 0.99 and a_h1 > 0.99 and abs(a_det - a_h1) < 0.01
     assert procrustes_cos(h1, h2) > 0.9
     assert procrustes_cos(det, h1) > 0.6
+
+
+def test_cum_index_is_bisect_left_and_changes_no_draw(oracle):
+    """n2v_cum_index_build: index[b] == bisect_left(cum_table, b << (31 - bits)) for every bucket
+    (numpy searchsorted on the same table), and training through it is bit-identical to training
+    through the LDS buckets (and to the oracle, which bisects the whole table) on a vocabulary
+    large enough for buckets to hold many words"""
+    from node2vec_amd import sgns
+
+    gen = torch.Generator().manual_seed(8)
+    n_tok = 200_000
+    p = 1.0 / torch.arange(1, n_tok + 1, dtype=torch.float64) ** 0.9
+    walks = torch.multinomial(p, 3000 * 41, replacement=True, generator=gen).reshape(3000, 41).to(torch.int32).cuda()
+    vocab = sgns.build_vocab(walks, 1)
+    a = sgns.SgnsModel(vocab, 64, 5, 5, seed=3)
+    b = sgns.SgnsModel(vocab, 64, 5, 5, seed=3, use_cum_index=False)
+    assert a.cum_index is not None and b.cum_index is None
+    cum = a.cum_table.cpu().numpy().astype(np.uint32)
+    bits = a.cum_index_bits
+    edges = (np.arange((1 << bits) + 1, dtype=np.uint64) << np.uint64(31 - bits))
+    want = np.searchsorted(cum, np.minimum(edges, 2 ** 32 - 1).astype(np.uint32), side="left")
+    want[edges > 0x7fffffff] = len(cum)
+    assert np.array_equal(a.cum_index.cpu().numpy(), want.astype(np.int32))
+    idx = vocab.index_of[walks.long()]
+    s0, s1 = a.syn0.cpu().numpy().copy(), a.syn1neg.cpu().numpy().copy()
+    a.train_block(idx[:64], 0.025, 5, deterministic=True)
+    b.train_block(idx[:64], 0.025, 5, deterministic=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a.syn0, b.syn0) and torch.equal(a.syn1neg, b.syn1neg)
+    n = oracle.sgns_train(idx[:64].cpu().numpy(), s0, s1, cum, None, sgns.exp_table(), len(vocab), 5, 3,
+                          64, 5, 5, 0.025)
+    assert n == int(a.pairs.item()) == int(b.pairs.item())
+    assert np.array_equal(a.syn0.cpu().numpy(), s0) and np.array_equal(a.syn1neg.cpu().numpy(), s1)
