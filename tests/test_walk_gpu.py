@@ -149,8 +149,8 @@ def test_hop_table_and_class_counts_change_no_bit(oracle, pq):
     p, q = pq
     rng = np.random.default_rng(5)
     nv = 3000
-    src = np.concatenate([rng.integers(0, nv, 24000), rng.integers(0, 20, 9000), rng.integers(0, nv, 9000)])
-    dst = np.concatenate([rng.integers(0, nv - 50, 24000), rng.integers(0, nv - 50, 9000), rng.integers(0, 20, 9000)])
+    src = np.concatenate([rng.integers(0, nv - 50, 24000), rng.integers(0, 20, 9000), rng.integers(0, nv - 50, 9000)])
+    dst = np.concatenate([rng.integers(0, nv, 24000), rng.integers(0, nv, 9000), rng.integers(0, 20, 9000)])
     g = DeviceGraph.from_edges(src, dst, None, n_vertices=nv, device="cuda")  # ids >= nv - 50 are sinks
     assert g.unit_weights
     start = rw.start_vertices(g)
