@@ -73,10 +73,13 @@ def trim_index(
     directed: bool = True,
     max_out_deg: int = 0,
     random_seed: Optional[int] = None,
+    id_rule: str = "sorted",
 ) -> Tuple[pd.DataFrame, Optional[pd.DataFrame]]:
     """fugue.py:24-77: validate, trim hotspot vertices, index.  Returns
     (edges[src:int, dst:int, weight:float], name_id[name, id]) or (trimmed df, None)
-    when the graph is already indexed."""
+    when the graph is already indexed.  `id_rule` (not in the reference's signature) selects
+    the numbering of indexer.index_graph_pandas: "sorted" (Spark twin) or "first_appearance"
+    (pandas twin)."""
     logging.info("trim_index(): start validating, trimming, and indexing ...")
     df = _as_pandas(df_graph)
     if "src" not in df.columns or "dst" not in df.columns:
@@ -90,7 +93,7 @@ def trim_index(
     df = df[keep].reset_index(drop=True)
     if indexed is True:
         return df, None  # fugue.py:70-71
-    return index_graph_pandas(df, directed)
+    return index_graph_pandas(df, directed, id_rule=id_rule)
 
 
 def random_walk_tensors(graph: DeviceGraph, n2v_params: Dict[str, Any], walk_seed_ids=None,
@@ -148,8 +151,14 @@ def random_walk(
     graph = df_graph if isinstance(df_graph, DeviceGraph) else DeviceGraph.from_pandas(
         _as_pandas(df_graph), device=dev)
     walks, valid = random_walk_tensors(graph, n2v_params, seed_ids, random_seed, mode)
-    w = walks[valid].cpu().numpy()
+    kept = walks[valid]
+    w = kept.cpu().numpy()
     logging.info("random_walk(): random walking done ...")
-    # to_path, randomwalk.py:343-349: {"src": path[0], "walk": path}
-    return pd.DataFrame({"src": w[:, 0].astype(np.int64) if len(w) else np.zeros(0, np.int64),
-                         "walk": [row.tolist() for row in w]})
+    # to_path, randomwalk.py:343-349: {"src": path[0], "walk": path}.  ndarray.tolist() builds
+    # the list-of-lists column in one C call (a Python loop over rows is 10x slower).
+    df = pd.DataFrame({"src": w[:, 0].astype(np.int64) if len(w) else np.zeros(0, np.int64),
+                       "walk": w.tolist()})
+    # the same walks as an on-device corpus: Node2VecHIP.fit() trains from it when the frame
+    # reaches it unchanged, instead of converting the list column back (embedding.py:125)
+    df.attrs["n2v_device_walks"] = kept
+    return df

@@ -3,11 +3,17 @@
 `index_graph_pandas` keeps the reference's contract (indexer.py:9-49): it needs
 columns src and dst (ValueError otherwise, :18-19), adds weight 1.0 when missing
 (:20-21), casts weight to float, and symmetrises + de-duplicates when the graph is
-undirected (:45-48).  Ids are dense, numbered in sorted-name order like the
-reference's Spark twin (indexer.py:69-70), and name_id has the columns
-["name", "id"] that Node2Vec*.embedding() consumes (embedding.py:138).  (The
-reference's pandas twin numbers by position of first appearance through a
-reset_index quirk and needs pandas < 2; its tests pin only counts.)
+undirected (:45-48).  The reference has two id rules and both are built:
+
+* id_rule="sorted" (default): dense ids in sorted-name order, name_id columns
+  ["name", "id"] -- the Spark twin (indexer.py:69-70), the form
+  Node2Vec*.embedding() consumes (embedding.py:138);
+* id_rule="first_appearance": the pandas twin (indexer.py:26-35).  There
+  `src.append(dst, ignore_index=True).drop_duplicates().reset_index()` makes the id
+  of a name the POSITION of its first appearance in the concatenation
+  [src column, dst column] -- ids are unique but not dense (they range below
+  2 * n_edges) -- and name_id has the columns ["vertex_id", "vertex_name"].
+  (That code needs pandas < 2, DataFrame.append; its tests pin only counts.)
 """
 from typing import Optional, Tuple
 
@@ -16,16 +22,30 @@ import pandas as pd
 import torch
 
 
-def index_graph_pandas(df_graph: pd.DataFrame, directed: bool) -> Tuple[pd.DataFrame, pd.DataFrame]:
+ID_RULES = ("sorted", "first_appearance")
+
+
+def index_graph_pandas(df_graph: pd.DataFrame, directed: bool,
+                       id_rule: str = "sorted") -> Tuple[pd.DataFrame, pd.DataFrame]:
     if "src" not in df_graph.columns or "dst" not in df_graph.columns:
         raise ValueError(f"Input graph NOT in the right format: {df_graph.columns}")
+    if id_rule not in ID_RULES:
+        raise ValueError(f"unknown id_rule {id_rule!r}")
     if "weight" not in df_graph.columns:
         df_graph = df_graph.assign(weight=1.0)
     df_graph = df_graph[["src", "dst", "weight"]].astype({"weight": float})
-    names = np.unique(np.concatenate([df_graph["src"].to_numpy(), df_graph["dst"].to_numpy()]))
-    name_id = pd.DataFrame({"name": names, "id": np.arange(len(names), dtype=np.int64)})
-    src = np.searchsorted(names, df_graph["src"].to_numpy())
-    dst = np.searchsorted(names, df_graph["dst"].to_numpy())
+    both = np.concatenate([df_graph["src"].to_numpy(), df_graph["dst"].to_numpy()])
+    if id_rule == "first_appearance":  # indexer.py:26-35
+        names, first = np.unique(both, return_index=True)
+        ids = first.astype(np.int64)  # position of the first appearance in [src..., dst...]
+        order = np.argsort(ids)
+        name_id = pd.DataFrame({"vertex_id": ids[order], "vertex_name": names[order]})
+    else:  # indexer.py:69-70
+        names = np.unique(both)
+        ids = np.arange(len(names), dtype=np.int64)
+        name_id = pd.DataFrame({"name": names, "id": ids})
+    src = ids[np.searchsorted(names, df_graph["src"].to_numpy())]
+    dst = ids[np.searchsorted(names, df_graph["dst"].to_numpy())]
     df_edge = pd.DataFrame({"src": src.astype(np.int64), "dst": dst.astype(np.int64),
                             "weight": df_graph["weight"].to_numpy()})
     if directed is not True:
@@ -35,14 +55,18 @@ def index_graph_pandas(df_graph: pd.DataFrame, directed: bool) -> Tuple[pd.DataF
 
 
 def index_graph_tensors(src: torch.Tensor, dst: torch.Tensor, weight: Optional[torch.Tensor] = None,
-                        directed: bool = True, device=None):
+                        directed: bool = True, device=None, id_rule: str = "sorted"):
     """The same indexing for integer-named edge lists that already live in (or fit) device
     memory: sort/unique on the GPU instead of pandas merges, for graphs of 10^8-10^9 edges.
 
     Returns (src_id int64, dst_id int64, weight float32, names int64) with
-    names[id] = original name, ids numbered in sorted-name order exactly like
-    index_graph_pandas; undirected graphs are symmetrised and de-duplicated on
-    (src, dst, weight) like indexer.py:45-48.  The edge order is by (src, dst, weight)."""
+    names[id] = original name, ids numbered exactly like index_graph_pandas with the same
+    id_rule ("sorted": dense, sorted-name order; "first_appearance": position of the first
+    appearance in [src..., dst...], names[id] = -1 for the unused ids in between); undirected
+    graphs are symmetrised and de-duplicated on (src, dst, weight) like indexer.py:45-48.  The
+    edge order is by (src, dst, weight)."""
+    if id_rule not in ID_RULES:
+        raise ValueError(f"unknown id_rule {id_rule!r}")
     src = torch.as_tensor(src).to(device=device, dtype=torch.int64).reshape(-1)
     dst = torch.as_tensor(dst).to(device=device, dtype=torch.int64).reshape(-1)
     if src.numel() != dst.numel():
@@ -54,6 +78,15 @@ def index_graph_tensors(src: torch.Tensor, dst: torch.Tensor, weight: Optional[t
         if w.numel() != src.numel():
             raise ValueError("weight differs in length from src")
     names, inverse = torch.unique(torch.cat([src, dst]), sorted=True, return_inverse=True)
+    if id_rule == "first_appearance":
+        pos = torch.arange(inverse.numel(), dtype=torch.int64, device=inverse.device)
+        first = torch.full((names.numel(),), inverse.numel(), dtype=torch.int64, device=inverse.device)
+        first.scatter_reduce_(0, inverse, pos, reduce="amin")
+        inverse = first[inverse]
+        table = torch.full((int(first.max()) + 1 if first.numel() else 0,), -1, dtype=torch.int64,
+                           device=inverse.device)
+        table[first] = names
+        names = table
     s_id, d_id = inverse[: src.numel()], inverse[src.numel():]
     if directed is not True:
         s_id, d_id, w = torch.cat([s_id, d_id]), torch.cat([d_id, s_id]), torch.cat([w, w])

@@ -239,3 +239,37 @@ def test_index_graph_tensors_matches_the_pandas_indexer():
         assert got == want
     s_id, d_id, ww, names = index_graph_tensors(torch.tensor([3, 3]), torch.tensor([9, 3]))
     assert ww.tolist() == [1.0, 1.0] and names.tolist() == [3, 9]
+
+
+def test_pandas_twin_id_rule_numbers_by_first_appearance():
+    """indexer.py:26-35: src.append(dst, ignore_index=True).drop_duplicates().reset_index() makes
+    the id of a name the position of its first appearance in [src column, dst column]; on the
+    reference's own test input (tests/test_indexer.py:14-16) that is a1 0, a2 1, a3 2, a4 3, b1 5,
+    b2 6.  The counts the reference pins (6 vertices, 2 x 4 edges) hold for both rules."""
+    import torch
+
+    from node2vec_amd.indexer import index_graph_pandas, index_graph_tensors
+
+    df = pd.DataFrame.from_dict({"src": ["a1", "a2", "a3", "a4"], "dst": ["a2", "b1", "b2", "a1"]})
+    e, vid = index_graph_pandas(df.copy(), False, id_rule="first_appearance")
+    assert list(vid.columns) == ["vertex_id", "vertex_name"]
+    assert dict(zip(vid["vertex_name"], vid["vertex_id"])) == {"a1": 0, "a2": 1, "a3": 2, "a4": 3, "b1": 5, "b2": 6}
+    assert len(vid) == 6 and len(e) == 8
+    assert sorted(zip(e["src"], e["dst"]))[:3] == [(0, 1), (0, 3), (1, 0)]
+    e2, vid2 = index_graph_pandas(df.copy(), False)
+    assert len(vid2) == 6 and len(e2) == 8 and list(vid2.columns) == ["name", "id"]
+    with pytest.raises(ValueError):
+        index_graph_pandas(df.copy(), False, id_rule="alphabetical")
+    # the device indexer follows the same rule
+    rng = np.random.default_rng(4)
+    src, dst = rng.integers(0, 500, 3000) * 7 + 3, rng.integers(0, 500, 3000) * 7 + 3
+    w = rng.choice([0.5, 1.0], 3000)
+    pdf = pd.DataFrame({"src": src, "dst": dst, "weight": w})
+    for directed in (True, False):
+        e, vid = index_graph_pandas(pdf.copy(), directed, id_rule="first_appearance")
+        s_id, d_id, ww, names = index_graph_tensors(torch.from_numpy(src), torch.from_numpy(dst),
+                                                     torch.from_numpy(w), directed, id_rule="first_appearance")
+        assert sorted(zip(s_id.tolist(), d_id.tolist(), ww.numpy())) == \
+            sorted(zip(e["src"], e["dst"], e["weight"].astype(np.float32)))
+        assert names[torch.from_numpy(vid["vertex_id"].to_numpy())].tolist() == vid["vertex_name"].tolist()
+        assert int((names >= 0).sum()) == len(vid)

@@ -1,0 +1,51 @@
+"""f1: the device indexer on the GPU against index_graph_pandas (the reference's
+contract, indexer.py:9-49 / :52-84) for both id rules, and straight into the CSR + a walk."""
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("id_rule", ["sorted", "first_appearance"])
+@pytest.mark.parametrize("directed", [True, False])
+def test_index_graph_tensors_on_the_gpu_equals_the_pandas_indexer(id_rule, directed):
+    from node2vec_amd.indexer import index_graph_pandas, index_graph_tensors
+
+    rng = np.random.default_rng(12)
+    n_e = 400_000
+    names = rng.choice(2 ** 40, 50_000, replace=False)  # sparse 64-bit names
+    src, dst = names[rng.integers(0, len(names), n_e)], names[rng.integers(0, len(names), n_e)]
+    w = rng.choice([0.25, 1.0, 3.0], n_e)
+    e, vid = index_graph_pandas(pd.DataFrame({"src": src, "dst": dst, "weight": w}), directed, id_rule=id_rule)
+    s_id, d_id, ww, nm = index_graph_tensors(torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda(),
+                                             torch.from_numpy(w).cuda(), directed, id_rule=id_rule)
+    assert s_id.is_cuda and nm.is_cuda
+    got = torch.stack([s_id, d_id, (ww * 4).long()], 1).cpu().numpy()
+    want = np.stack([e["src"].to_numpy(), e["dst"].to_numpy(), (e["weight"].to_numpy() * 4).astype(np.int64)], 1)
+    assert np.array_equal(got[np.lexsort(got.T[::-1])], want[np.lexsort(want.T[::-1])])
+    if id_rule == "sorted":
+        assert np.array_equal(nm.cpu().numpy(), vid["name"].to_numpy())
+    else:
+        assert np.array_equal(nm.cpu().numpy()[vid["vertex_id"].to_numpy()], vid["vertex_name"].to_numpy())
+
+
+def test_indexed_tensors_feed_the_csr_and_the_walk(oracle):
+    """raw integer-named undirected edge list -> ids -> CSR -> walks == the oracle on the same CSR"""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+    from node2vec_amd.indexer import index_graph_tensors
+
+    rng = np.random.default_rng(2)
+    src = torch.from_numpy(rng.integers(0, 3000, 20000) * 1000003).cuda()
+    dst = torch.from_numpy(rng.integers(0, 3000, 20000) * 1000003).cuda()
+    s_id, d_id, w, names = index_graph_tensors(src, dst, None, directed=False)
+    g = DeviceGraph.from_edges(s_id, d_id, w, n_vertices=int(names.numel()), device="cuda")
+    assert g.unit_weights
+    start = rw.start_vertices(g)
+    walks, valid = rw.walk(g, start, 2, 20, 0.5, 2.0, 1)
+    want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), None, start.cpu().numpy(),
+                                  2, 20, 0.5, 2.0, 1, n_threads=8)
+    assert np.array_equal(valid.cpu().numpy(), wv) and np.array_equal(walks.cpu().numpy(), want)
+    assert bool((names[walks[valid].long()] % 1000003 == 0).all())  # ids map back to the names
