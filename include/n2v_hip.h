@@ -207,6 +207,15 @@ int n2v_alias_draw(const int64_t *rowptr, const n2v_slot *slots, int64_t n_rows,
                    const double *r1, const double *r2, int32_t *vertex_out, uint32_t *status,
                    void *stream);
 
+/* The two uniforms n2v_walk draws for walker `key[i]` (= start vertex * num_walks + ordinal - 1)
+ * at step `step[i]` (0-based), as the fp64 numbers u / 2^32 the reference's random.random()
+ * stands for (randomwalk.py:336-337).  With them n2v_edge_bias + n2v_alias_build +
+ * n2v_alias_draw reproduce one step of n2v_walk's exact mode bit for bit: the step function of
+ * graph-partitioned walking (node2vec_amd/partitioned.py), where a walker's two rows live on
+ * different GPUs and the step is taken where the current vertex is stored. */
+int n2v_walk_uniforms(uint64_t seed, const int64_t *key, const int32_t *step, int64_t n,
+                      double *r1_out, double *r2_out, void *stream);
+
 /* a9 -- trim_hotspot_vertices (randomwalk.py:238-262): rows with more than
  * max_out_degree edges keep a uniform sample without replacement of exactly
  * max_out_degree of them (max_out_degree <= 0 means 100000, constants.py:6).

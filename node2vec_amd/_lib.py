@@ -18,7 +18,7 @@ WIRE_F32, WIRE_BF16 = 0, 1
 SYMBOLS = ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alias_build",
            "n2v_pivots_build", "n2v_edge_classes_build", "n2v_walk", "n2v_trim_mark",
            "n2v_sgns_train", "n2v_delta_ref_init", "n2v_delta_pack", "n2v_delta_apply",
-           "n2v_edge_bias", "n2v_alias_draw", "n2v_hops_build", "n2v_cum_index_build")
+           "n2v_edge_bias", "n2v_alias_draw", "n2v_hops_build", "n2v_cum_index_build", "n2v_walk_uniforms")
 
 
 class Graph(C.Structure):
@@ -91,6 +91,9 @@ def load():
     L.n2v_edge_bias.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_double,
                                 C.c_double, C.c_void_p, C.c_void_p]
+    L.n2v_walk_uniforms.restype = C.c_int
+    L.n2v_walk_uniforms.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]
     L.n2v_alias_draw.restype = C.c_int
     L.n2v_alias_draw.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]

@@ -78,7 +78,37 @@ __global__ __launch_bounds__(256) void alias_draw_kernel(
   }
 }
 
+// the two uniforms n2v_walk uses at `step` of the walker with stream key `key` (DESIGN.md "RNG"):
+// r = u / 2^32, exact in fp64, so a draw from a materialised table with them is the draw of
+// n2v_walk's exact mode (pick = int(r1 * n) is the same integer, r2 < prob the same comparison)
+__global__ __launch_bounds__(256) void walk_uniforms_kernel(uint64_t seed,
+                                                            const int64_t *__restrict__ key,
+                                                            const int32_t *__restrict__ step,
+                                                            int64_t n, double *__restrict__ r1,
+                                                            double *__restrict__ r2) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t bits = step_bits(walker_stream(seed, (uint64_t)key[i]), (uint32_t)step[i]);
+    r1[i] = (double)(uint32_t)(bits >> 32) * (1.0 / 4294967296.0);
+    r2[i] = (double)(uint32_t)bits * (1.0 / 4294967296.0);
+  }
+}
+
 }  // namespace n2v
+
+extern "C" int n2v_walk_uniforms(uint64_t seed, const int64_t *key, const int32_t *step, int64_t n,
+                                 double *r1_out, double *r2_out, void *stream) {
+  if (n < 0) return N2V_EINVAL;
+  if (n == 0) return N2V_OK;
+  if (!key || !step || !r1_out || !r2_out) return N2V_EINVAL;
+  int64_t blocks = (n + 255) / 256;
+  const int64_t cap = n2v::resident_blocks((const void *)n2v::walk_uniforms_kernel, 256, 0) * 2;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(n2v::walk_uniforms_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, seed, key, step, n, r1_out, r2_out);
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}
 
 extern "C" int n2v_edge_bias(const int64_t *rowptr, const int32_t *ids, const float *w,
                              const double *w64, const int32_t *src_id,

@@ -1,0 +1,341 @@
+"""Graph-partitioned walking: walks over a graph that does not fit one GPU.
+
+The reference never holds the graph in one place: every step of `fugue.random_walk`
+(fugue.py:144-149) joins the walker rows with the adjacency rows of their previous and their
+current vertex -- two shuffles per step, the neighbour list of the previous vertex travelling
+with the walker -- and calls `next_step_random_walk` on the joined rows.  This module is that
+design point on a GPU node:
+
+* the CSR is partitioned by contiguous VERTEX RANGE; rank r stores the rows of its range only
+  (`partition_graph`), so per-GPU memory is E / N instead of E;
+* a walker lives on the rank that stores the row of its CURRENT vertex.  One step there is the
+  reference's transformer on a batch: bias N(v) against the travelling copy of N(s)
+  (n2v_edge_bias), build the tables (K1, n2v_alias_build), draw with the walker's own uniforms
+  (n2v_walk_uniforms + n2v_alias_draw) -- bit-identical to n2v_walk's exact mode, whose RNG is
+  keyed by (seed, start vertex, ordinal, step) and not by where the walker happens to be;
+* then the walker MIGRATES to the owner of the vertex it drew, carrying a 32-byte header
+  (output row, RNG key, previous/current vertex, step) and the row it just left (the
+  `src_neighbors` of its next step): one variable-size all-to-all per step
+  (`torch.distributed.all_to_all_single`, RCCL over xGMI on the GPUs, gloo in the CPU tests);
+* every appended vertex is logged as (row, position, vertex) and sent once, at the end, to the
+  rank that emits the walk (the owner of its start vertex); walkers that reach a vertex without
+  out-edges vanish (inner join, fugue.py:147) and their row is marked invalid.
+
+`walk_partitioned` runs one rank of it; `walk_partitioned_local` runs all ranks of a
+partition in one process (the exchange is a list transpose) and is what the single-GPU tests
+use to prove that partitioned == unpartitioned, bit for bit.  The step function is injectable
+(`step_fn`); the default is the HIP one and raises without a GPU.
+"""
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from node2vec_amd.graph import DeviceGraph
+from node2vec_amd.shard import shard_range
+
+
+@dataclass
+class GraphPart:
+    """rows [lo, hi) of the CSR: rowptr rebased to 0, the rows' neighbour ids (global) and
+    weights (None = unit); `bounds` = the lo of every part + the vertex count (owner lookup)"""
+    rank: int
+    lo: int
+    hi: int
+    rowptr: torch.Tensor
+    col: torch.Tensor
+    w: Optional[torch.Tensor]
+    bounds: torch.Tensor
+
+    @property
+    def device(self):
+        return self.rowptr.device
+
+    def owner(self, v: torch.Tensor) -> torch.Tensor:
+        return torch.searchsorted(self.bounds, v.to(torch.int64), right=True) - 1
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in (self.rowptr, self.col, self.w) if t is not None)
+
+
+def partition_graph(g: DeviceGraph, n_parts: int, balance: str = "edges") -> List[GraphPart]:
+    """Contiguous vertex ranges with about equal numbers of EDGES (default) or of vertices.
+    A rank of a real run would load only its own part; here they are cut from a whole graph."""
+    V = g.n_vertices
+    if balance == "edges" and g.n_edges > 0:
+        targets = torch.arange(1, n_parts, device=g.device, dtype=torch.int64) * g.n_edges // n_parts
+        cuts = torch.searchsorted(g.rowptr, targets, right=False).clamp(0, V).tolist()
+    else:
+        cuts = [shard_range(V, r, n_parts)[0] for r in range(1, n_parts)]
+    los = [0] + [int(c) for c in cuts]
+    his = los[1:] + [V]
+    bounds = torch.tensor(los + [V], dtype=torch.int64, device=g.device)
+    # owner lookup uses searchsorted(right=True) - 1 over the lows; empty ranges own nothing
+    parts = []
+    for r, (lo, hi) in enumerate(zip(los, his)):
+        hi = max(hi, lo)
+        e0, e1 = int(g.rowptr[lo]), int(g.rowptr[hi])
+        parts.append(GraphPart(r, lo, hi, (g.rowptr[lo:hi + 1] - e0).contiguous(),
+                               g.col[e0:e1].contiguous(),
+                               None if g.unit_weights else g.w[e0:e1].contiguous(), bounds[:-1].contiguous()))
+    return parts
+
+
+# ---- messages ---------------------------------------------------------------------------------
+@dataclass
+class Walkers:
+    """a batch of walker states: header int64 [k, 4] = (output row, RNG key, s << 32 | v, step)
+    and the travelling rows N(s) as a packed CSR (ptr int64 [k + 1], ids int32 [nnz])"""
+    head: torch.Tensor
+    ptr: torch.Tensor
+    ids: torch.Tensor
+
+    @classmethod
+    def empty(cls, device):
+        return cls(torch.zeros((0, 4), dtype=torch.int64, device=device),
+                   torch.zeros(1, dtype=torch.int64, device=device),
+                   torch.zeros(0, dtype=torch.int32, device=device))
+
+    def __len__(self):
+        return self.head.shape[0]
+
+    def select(self, idx: torch.Tensor) -> "Walkers":
+        lens = (self.ptr[1:] - self.ptr[:-1])[idx]
+        ptr = torch.zeros(idx.numel() + 1, dtype=torch.int64, device=self.head.device)
+        torch.cumsum(lens, 0, out=ptr[1:])
+        return Walkers(self.head[idx], ptr, _gather_rows(self.ptr, self.ids, idx, ptr))
+
+    @classmethod
+    def cat(cls, parts: Sequence["Walkers"], device) -> "Walkers":
+        parts = [p for p in parts if len(p)]
+        if not parts:
+            return cls.empty(device)
+        lens = torch.cat([p.ptr[1:] - p.ptr[:-1] for p in parts])
+        ptr = torch.zeros(lens.numel() + 1, dtype=torch.int64, device=device)
+        torch.cumsum(lens, 0, out=ptr[1:])
+        return cls(torch.cat([p.head for p in parts]), ptr, torch.cat([p.ids for p in parts]))
+
+
+def _gather_rows(ptr: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor, out_ptr: torch.Tensor):
+    """concatenation of ids[ptr[r] : ptr[r + 1]] for r in rows (out_ptr = the new offsets)"""
+    total = int(out_ptr[-1])
+    if total == 0:
+        return ids[:0]
+    lens = out_ptr[1:] - out_ptr[:-1]
+    which = torch.repeat_interleave(torch.arange(rows.numel(), device=ids.device), lens)
+    within = torch.arange(total, device=ids.device) - out_ptr[:-1][which]
+    return ids[ptr[rows][which] + within]
+
+
+# ---- the step on one rank ---------------------------------------------------------------------
+def hip_step(dst_ptr, dst_ids, dst_w, src_id, src_ptr, src_ids, keys, steps, p, q, seed):
+    """One step of a batch of walkers on the GPU that stores their current rows: the reference's
+    next_step_random_walk (randomwalk.py:300-339) with n2v_walk's uniforms."""
+    from node2vec_amd import _lib
+    from node2vec_amd import transformers as T
+
+    L = _lib.load()
+    _lib.require_gpu()
+    dev = dst_ptr.device
+    n = keys.numel()
+    r1 = torch.empty(n, dtype=torch.float64, device=dev)
+    r2 = torch.empty(n, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.n2v_walk_uniforms(int(seed) & (2 ** 64 - 1), keys.data_ptr(), steps.data_ptr(), n,
+                                       r1.data_ptr(), r2.data_ptr(), _lib.current_stream_ptr()),
+                   "n2v_walk_uniforms")
+    nbs = src_ids if src_ids.numel() else torch.zeros(1, dtype=torch.int32, device=dev)
+    biased = T._bias_rows(dst_ptr, dst_ids, dst_w, src_id, src_ptr, nbs, p, q)
+    slots = T._build_tables(dst_ptr, dst_ids, biased)
+    return T._draw_device(dst_ptr, slots, r1, r2)
+
+
+class RankState:
+    """what one rank holds between steps"""
+
+    def __init__(self, part: GraphPart, num_walks: int, walk_length: int, p: float, q: float, seed: int,
+                 step_fn: Callable = hip_step):
+        if p == 0 or q == 0:
+            raise ValueError(f"Zero return ({p}) or inout ({q}) parameter!")
+        self.part, self.W, self.L, self.p, self.q, self.seed = part, num_walks, walk_length, p, q, seed
+        self.step_fn = step_fn
+        self.walkers = Walkers.empty(part.device)
+        self.log: List[torch.Tensor] = []  # int64 [k, 3]: (output row, position, vertex or -1 = dropped)
+        self.n_rows = 0
+        self.row_base = 0
+
+    # -- initiate_random_walk (randomwalk.py:279-296) for the start vertices this rank owns ----
+    def initiate(self, start_ids_global: torch.Tensor):
+        """start_ids_global: the WHOLE sorted start list (every rank passes the same); this rank
+        creates the walkers of the start vertices in its range.  Output row of (start index i,
+        ordinal o) is i * W + o - 1, as in n2v_walk."""
+        part, dev = self.part, self.part.device
+        s = start_ids_global.to(device=dev, dtype=torch.int64)
+        idx = torch.nonzero((s >= part.lo) & (s < part.hi)).reshape(-1)
+        mine = s[idx]
+        deg = (part.rowptr[1:] - part.rowptr[:-1])[mine - part.lo]
+        ok = deg > 0  # fugue.py:132: vertices without out-edges start no walk
+        self.n_rows = int(s.numel()) * self.W
+        ords = torch.arange(self.W, device=dev, dtype=torch.int64)
+        rows = (idx[:, None] * self.W + ords[None, :]).reshape(-1)
+        keys = (mine[:, None] * self.W + ords[None, :]).reshape(-1)
+        v = mine.repeat_interleave(self.W)
+        live = ok.repeat_interleave(self.W)
+        # position 0 of every row this rank emits (invalid rows are logged as dropped)
+        self.log.append(torch.stack([rows, torch.zeros_like(rows), torch.where(live, v, torch.full_like(v, -1))], 1))
+        rows, keys, v = rows[live], keys[live], v[live]
+        if self.L == 0:
+            return
+        head = torch.stack([rows, keys, (torch.full_like(v, -1) << 32) | (v & 0xffffffff),
+                            torch.zeros_like(rows)], 1)
+        self.walkers = Walkers(head, torch.zeros(rows.numel() + 1, dtype=torch.int64, device=dev),
+                               torch.zeros(0, dtype=torch.int32, device=dev))
+
+    # -- one step of every resident walker; returns the migrating walkers per destination -----
+    def advance(self, n_parts: int) -> List[Walkers]:
+        part, dev, wk = self.part, self.part.device, self.walkers
+        if len(wk) == 0:
+            return [Walkers.empty(dev) for _ in range(n_parts)]
+        rows, keys, sv, step = wk.head[:, 0], wk.head[:, 1], wk.head[:, 2], wk.head[:, 3]
+        s = (sv >> 32).to(torch.int32)
+        v = (sv & 0xffffffff).to(torch.int64)
+        local = v - part.lo
+        # pack the rows of the current vertices (the `dst_neighbors` of the joined row)
+        lens = (part.rowptr[1:] - part.rowptr[:-1])[local]
+        dptr = torch.zeros(len(wk) + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(lens, 0, out=dptr[1:])
+        dids = _gather_rows(part.rowptr, part.col, local, dptr)
+        dw = None if part.w is None else _gather_rows(part.rowptr, part.w, local, dptr)
+        nxt = self.step_fn(dptr, dids, dw, s, wk.ptr, wk.ids, keys.contiguous(),
+                           step.to(torch.int32).contiguous(), self.p, self.q, self.seed)
+        nxt = torch.as_tensor(nxt, device=dev).to(torch.int64)
+        self.log.append(torch.stack([rows, step + 1, nxt], 1))
+        done = step + 1 >= self.L
+        keep = ~done
+        head = torch.stack([rows, keys, (v << 32) | nxt, step + 1], 1)[keep]
+        moving = Walkers(head, *self._subrows(dptr, dids, keep))
+        dest = part.owner(nxt[keep])
+        return [moving.select(torch.nonzero(dest == r).reshape(-1)) for r in range(n_parts)]
+
+    @staticmethod
+    def _subrows(ptr, ids, keep):
+        idx = torch.nonzero(keep).reshape(-1)
+        lens = (ptr[1:] - ptr[:-1])[idx]
+        out = torch.zeros(idx.numel() + 1, dtype=torch.int64, device=ptr.device)
+        torch.cumsum(lens, 0, out=out[1:])
+        return out, _gather_rows(ptr, ids, idx, out)
+
+    # -- arrivals: walkers whose new current vertex has no out-edges vanish (fugue.py:147) -----
+    def receive(self, inbox: Sequence[Walkers]):
+        part, dev = self.part, self.part.device
+        wk = Walkers.cat(inbox, dev)
+        if len(wk):
+            v = (wk.head[:, 2] & 0xffffffff) - part.lo
+            deg = (part.rowptr[1:] - part.rowptr[:-1])[v]
+            dead = deg == 0
+            if bool(dead.any()):
+                self.log.append(torch.stack([wk.head[dead, 0], torch.full_like(wk.head[dead, 0], -1),
+                                             torch.full_like(wk.head[dead, 0], -1)], 1))
+                wk = wk.select(torch.nonzero(~dead).reshape(-1))
+        self.walkers = wk
+
+    def log_by_home(self, start_ids_global: torch.Tensor, n_parts: int) -> List[torch.Tensor]:
+        """the path records, split by the rank that emits each row (owner of its start vertex)"""
+        dev = self.part.device
+        rec = torch.cat(self.log) if self.log else torch.zeros((0, 3), dtype=torch.int64, device=dev)
+        s = start_ids_global.to(device=dev, dtype=torch.int64)
+        home = self.part.owner(s[rec[:, 0] // self.W]) if rec.numel() else rec[:, 0]
+        return [rec[home == r] for r in range(n_parts)]
+
+    def assemble(self, records: Sequence[torch.Tensor], start_ids_global: torch.Tensor):
+        """rows of this rank (start vertices in its range, in start-list order):
+        (walks int32 [k * W, L + 1], valid bool [k * W], global row ids int64)"""
+        part, dev = self.part, self.part.device
+        s = start_ids_global.to(device=dev, dtype=torch.int64)
+        idx = torch.nonzero((s >= part.lo) & (s < part.hi)).reshape(-1)
+        ords = torch.arange(self.W, device=dev, dtype=torch.int64)
+        rows = (idx[:, None] * self.W + ords[None, :]).reshape(-1)
+        pos_of = torch.full((int(s.numel()) * self.W,), -1, dtype=torch.int64, device=dev)
+        pos_of[rows] = torch.arange(rows.numel(), device=dev)
+        walks = torch.full((rows.numel(), self.L + 1), -1, dtype=torch.int32, device=dev)
+        valid = torch.ones(rows.numel(), dtype=torch.bool, device=dev)
+        rec = torch.cat([r.to(dev) for r in records]) if records else torch.zeros((0, 3), dtype=torch.int64, device=dev)
+        if rec.numel():
+            r = pos_of[rec[:, 0]]
+            dropped = rec[:, 1] < 0
+            valid[r[dropped]] = False
+            ok = ~dropped
+            walks[r[ok], rec[ok, 1]] = rec[ok, 2].to(torch.int32)
+            valid[r[ok & (rec[:, 2] < 0)]] = False  # a start vertex without out-edges
+        return walks, valid, rows
+
+
+# ---- drivers ----------------------------------------------------------------------------------
+def walk_partitioned_local(parts: Sequence[GraphPart], start_ids: torch.Tensor, num_walks: int,
+                           walk_length: int, p: float, q: float, seed: int,
+                           step_fn: Callable = hip_step) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Every rank of the partition in ONE process (the all-to-all is a list transpose): returns
+    (walks, valid) in the row order of n2v_walk over the same start list."""
+    n = len(parts)
+    ranks = [RankState(pt, num_walks, walk_length, p, q, seed, step_fn) for pt in parts]
+    for r in ranks:
+        r.initiate(start_ids)
+    for _ in range(walk_length):
+        out = [r.advance(n) for r in ranks]
+        for d, r in enumerate(ranks):
+            r.receive([out[src][d] for src in range(n)])
+    logs = [r.log_by_home(start_ids, n) for r in ranks]
+    dev = parts[0].device
+    total = int(start_ids.numel()) * num_walks
+    walks = torch.full((total, walk_length + 1), -1, dtype=torch.int32, device=dev)
+    valid = torch.zeros(total, dtype=torch.bool, device=dev)
+    for d, r in enumerate(ranks):
+        w, v, rows = r.assemble([logs[src][d] for src in range(n)], start_ids)
+        walks[rows], valid[rows] = w, v
+    return walks, valid
+
+
+def _all_to_all_var(tensors: List[torch.Tensor], group, dist) -> List[torch.Tensor]:
+    """variable-size all-to-all of one tensor per destination rank (first dimension varies)"""
+    world = dist.get_world_size(group)
+    dev = tensors[0].device
+    cpu = dist.get_backend(group) == "gloo"  # gloo moves host tensors
+    send = torch.cat(tensors)
+    if cpu:
+        send = send.cpu()
+    n_send = torch.tensor([t.shape[0] for t in tensors], dtype=torch.int64, device=send.device)
+    n_recv = torch.empty(world, dtype=torch.int64, device=send.device)
+    dist.all_to_all_single(n_recv, n_send, group=group)
+    recv = torch.empty((int(n_recv.sum()),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    dist.all_to_all_single(recv, send.contiguous(), n_recv.tolist(), n_send.tolist(), group=group)
+    return [t.to(dev) for t in torch.split(recv, n_recv.tolist())]
+
+
+def _exchange_walkers(out: List[Walkers], group, dist, dev) -> List[Walkers]:
+    heads = _all_to_all_var([w.head for w in out], group, dist)
+    lens = _all_to_all_var([(w.ptr[1:] - w.ptr[:-1]) for w in out], group, dist)
+    ids = _all_to_all_var([w.ids for w in out], group, dist)
+    res = []
+    for h, ln, i in zip(heads, lens, ids):
+        ptr = torch.zeros(ln.numel() + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(ln, 0, out=ptr[1:])
+        res.append(Walkers(h, ptr, i))
+    return res
+
+
+def walk_partitioned(part: GraphPart, start_ids: torch.Tensor, num_walks: int, walk_length: int,
+                     p: float, q: float, seed: int, group=None, step_fn: Callable = hip_step):
+    """One rank of the partitioned walk under torch.distributed (one process per GPU; backend
+    "nccl" = RCCL over xGMI, or gloo on CPU tensors).  Every rank passes the same sorted
+    `start_ids` and the same seed.  Returns this rank's rows: (walks, valid, global row ids) --
+    the rows of the start vertices in its range, bit-identical to n2v_walk on the whole graph."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    st = RankState(part, num_walks, walk_length, p, q, seed, step_fn)
+    st.initiate(start_ids)
+    for _ in range(walk_length):
+        st.receive(_exchange_walkers(st.advance(world), group, dist, part.device))
+    records = _all_to_all_var(st.log_by_home(start_ids, world), group, dist)
+    return st.assemble(records, start_ids)

@@ -95,13 +95,13 @@ def _build_tables(rowptr: torch.Tensor, ids: torch.Tensor, w64: torch.Tensor) ->
     return slots[:nnz]
 
 
-def _draw(rowptr: torch.Tensor, slots: torch.Tensor, r1, r2) -> np.ndarray:
-    """n2v_alias_draw: one draw per packed row; r2 None = the one-uniform (wiki) variant"""
+def _draw_device(rowptr: torch.Tensor, slots: torch.Tensor, t1: torch.Tensor,
+                 t2: Optional[torch.Tensor]) -> torch.Tensor:
+    """n2v_alias_draw on device tensors: one draw per packed row; t2 None = the one-uniform
+    (wiki) variant.  Returns the drawn vertex ids (int32, on the device)."""
     L = _lib.load()
     dev = rowptr.device
     n_rows = rowptr.numel() - 1
-    t1 = torch.as_tensor(np.asarray(r1, dtype=np.float64), device=dev)
-    t2 = None if r2 is None else torch.as_tensor(np.asarray(r2, dtype=np.float64), device=dev)
     out = torch.empty(max(n_rows, 1), dtype=torch.int32, device=dev)
     status = torch.zeros(4, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
@@ -111,7 +111,14 @@ def _draw(rowptr: torch.Tensor, slots: torch.Tensor, r1, r2) -> np.ndarray:
     _lib.check(rc, "n2v_alias_draw")
     if int(status[0].item()) & _lib.ST_RANGE:
         raise IndexError("list index out of range")  # probs[pick] with r1 outside [0, 1)
-    return out[:n_rows].cpu().numpy()
+    return out[:n_rows]
+
+
+def _draw(rowptr: torch.Tensor, slots: torch.Tensor, r1, r2) -> np.ndarray:
+    dev = rowptr.device
+    t1 = torch.as_tensor(np.asarray(r1, dtype=np.float64), device=dev)
+    t2 = None if r2 is None else torch.as_tensor(np.asarray(r2, dtype=np.float64), device=dev)
+    return _draw_device(rowptr, slots, t1, t2).cpu().numpy()
 
 
 class AliasProb(object):
@@ -213,12 +220,15 @@ def generate_alias_tables(node_weights: List[float]) -> Tuple[List[int], List[fl
     return alias, probs
 
 
-def _bias_rows(rowptr, ids, w64, src_id, src_rowptr, src_nbs, p, q) -> torch.Tensor:
+def _bias_rows(rowptr, ids, w, src_id, src_rowptr, src_nbs, p, q) -> torch.Tensor:
+    """n2v_edge_bias over packed rows; w: None (unit weights), float32 or float64 [nnz]"""
     L = _lib.load()
     dev = rowptr.device
     out = torch.empty(max(int(ids.numel()), 1), dtype=torch.float64, device=dev)
+    w32 = w.data_ptr() if (w is not None and w.dtype == torch.float32) else 0
+    w64 = w.data_ptr() if (w is not None and w.dtype == torch.float64) else 0
     with torch.cuda.device(dev):
-        rc = L.n2v_edge_bias(rowptr.data_ptr(), ids.data_ptr(), 0, w64.data_ptr(),
+        rc = L.n2v_edge_bias(rowptr.data_ptr(), ids.data_ptr(), w32, w64,
                              src_id.data_ptr(), src_rowptr.data_ptr(), src_nbs.data_ptr(),
                              rowptr.numel() - 1, int(ids.numel()), float(p), float(q),
                              out.data_ptr(), _lib.current_stream_ptr())

@@ -18,7 +18,7 @@ def test_header_declares_the_expected_entry_points():
     for want in ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alias_build", "n2v_pivots_build",
                  "n2v_edge_classes_build", "n2v_walk", "n2v_trim_mark", "n2v_sgns_train",
                  "n2v_delta_ref_init", "n2v_delta_pack", "n2v_delta_apply", "n2v_edge_bias", "n2v_alias_draw",
-                 "n2v_hops_build", "n2v_cum_index_build"):
+                 "n2v_hops_build", "n2v_cum_index_build", "n2v_walk_uniforms"):
         assert want in names
 
 
