@@ -36,6 +36,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 FP32_PEAK = 157.3e12
+# random 64-byte sector reads per second the chip sustains over a 16 GB table, measured with
+# scripts/micro/gather_ceiling.hip (profiles/r02_gather_ceiling.log: 48.9 G/s independent,
+# 51.0 G/s as dependent chains, 25.5 G "walk-like" steps/s of two dependent gathers)
+GATHER_CEILING = 51.0e9
 
 CONFIGS = {
     "cfg4": dict(gen="chung_lu", n=100_000_000, draws=500_000_000, trim=10_000, p=1.0, q=1.0,
@@ -367,6 +371,16 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
          "binding_resource": "random 64-byte sector reads: the chip sustains ~50 G/s = 3.2 TB/s of them "
                              "(profiles/r02_gather_ceiling.log), i.e. frac <= ~0.4 for a gather-bound "
                              "kernel; what a kernel can lower is its sectors per step"}
+    if traffic:
+        # the walk kernels' reads are random gathers: each costs one 64-byte sector on the memory
+        # side of L2 (profiles/r02_gather_fetch_calibration.txt), and sectors/s is what the chip
+        # caps (GATHER_CEILING), long before bytes/s
+        sectors = traffic / 64.0
+        r["sectors_per_walk_step"] = sectors / per_launch_steps
+        r["gather_ceiling"] = {"achieved_Gsectors_per_s": sectors / res["kernel_s"] / 1e9,
+                               "ceiling_Gsectors_per_s": GATHER_CEILING / 1e9,
+                               "frac": sectors / res["kernel_s"] / GATHER_CEILING,
+                               "source": "profiles/r02_gather_ceiling.log (scripts/micro/gather_ceiling.hip)"}
     if ref_bytes:
         r["reference_algorithmic_bytes_per_walk_step"] = ref_bytes
         r["reference_algorithmic_GBps_equivalent"] = ref_bytes * per_launch_steps / res["kernel_s"] / 1e9
@@ -433,6 +447,11 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist)
            "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
                         "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic,
                         "kernel": "sgns_kernel", "kernel_ms": 1e3 * kernel_s,
+                        "achieved_from": "algorithmic bytes (SURVEY 8d: 8*D*(2+k) per pair); `traffic` "
+                                         "is the measured memory-side bytes per launch (below the "
+                                         "algorithmic bytes: the centre row stays in registers and hot "
+                                         "rows hit L2)",
+                        "traffic_GBps": None if not traffic else traffic / kernel_s / 1e9,
                         "algorithmic_bytes_per_pair": bytes_per_pair,
                         "fma_utilisation": pairs / args.steps * flops_per_pair / kernel_s / FP32_PEAK}}
     if use_dist:  # the exchange step of the multi-GPU path, timed once (blocking, bf16 deltas)

@@ -76,7 +76,8 @@ def karate_edges():
 
 
 def f32(x):
-    """weights the product stores as fp32: keep fixtures fp32-representable"""
+    """fp32-representable weights (the 4-byte storage form of n2v_graph.w); the *_fp64 cases
+    added at the end of G1 and G4 carry full-precision Python floats (n2v_graph.w64)"""
     return float(np.float32(x))
 
 
@@ -158,6 +159,11 @@ def main():
         cases.append([float(x) for x in rng.choice([0.5, 1.0, 2.0], size=n)])
         cases.append([float(x) for x in rng.choice([0.25, 1.0, 4.0], size=n, p=[.7, .2, .1])])
     cases.append([f32(x) for x in rng.pareto(1.2, size=300) + 0.01])
+    # full-precision weights (not fp32-representable), from a separate stream so that the
+    # cases above keep their values
+    rng64 = np.random.RandomState(6464)
+    for n in (2, 3, 9, 64, 65, 700):
+        cases.append([float(x) for x in rng64.uniform(0.01, 3.0, size=n)])
     for w in cases:
         alias, probs = ref.generate_alias_tables(list(w))
         g1.append({"weights": w, "alias": alias, "probs": probs})
@@ -318,6 +324,16 @@ def main():
                    "p": p, "q": q, "seed": seed, "walk_seed": list(range(0, 600, 7)),
                    "walks": reference_random_walk(hedges, 1, 10, p, q, seed,
                                                   walk_seed=list(range(0, 600, 7)))})
+
+    # the same two weighted graphs with full-precision (fp64, not fp32-representable) weights
+    wk64 = [(a, b, float(rng64.uniform(0.1, 2.0))) for a, b, _ in kedges]
+    g4.append({"name": "karate_weighted_fp64", "edges": wk64, "num_walks": 3, "walk_length": 16,
+               "p": 0.5, "q": 2.0, "seed": 5, "walk_seed": None,
+               "walks": reference_random_walk(wk64, 3, 16, 0.5, 2.0, 5)})
+    m64 = [(a, b, float(rng64.uniform(0.2, 3.0))) for a, b, _ in medges]
+    g4.append({"name": "multigraph_fp64", "edges": m64, "num_walks": 2, "walk_length": 12,
+               "p": 3.0, "q": 0.7, "seed": 2025, "walk_seed": None,
+               "walks": reference_random_walk(m64, 2, 12, 3.0, 0.7, 2025)})
 
     # uniform stream itself
     rng_kat = [{"seed": s, "key": k, "step": t, "u": list(uniform_bits(s, k, t))}

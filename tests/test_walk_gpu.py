@@ -14,7 +14,7 @@ def _graph_from_edges(edges, nv=None):
 
     e = np.array(edges, dtype=np.float64).reshape(-1, 3)
     return DeviceGraph.from_edges(e[:, 0].astype(np.int64), e[:, 1].astype(np.int64),
-                                  e[:, 2].astype(np.float32), n_vertices=nv, device="cuda")
+                                  e[:, 2], n_vertices=nv, device="cuda")  # fp64 kept when not fp32-exact
 
 
 def _hip_walks(g, start, nw, wl, p, q, seed, mode="exact"):
@@ -36,8 +36,12 @@ def test_library_loaded_is_in_tree():
 def test_exact_walks_equal_reference_golden():
     """G4/G7: same walks, same dropped walkers as the reference driven with the
     same uniform stream (tests/golden/gen_golden.py)."""
+    names = set()
     for c in load_golden("g4_walks.json"):
         g = _graph_from_edges(c["edges"])
+        names.add(c["name"])
+        if c["name"].endswith("_fp64"):
+            assert g.w.dtype == torch.float64  # full-precision weights reach the kernel as fp64
         start = list(range(g.n_vertices)) if c["walk_seed"] is None else sorted(set(c["walk_seed"]))
         walks, valid = _hip_walks(g, start, c["num_walks"], c["walk_length"], c["p"], c["q"], c["seed"])
         got = {}
@@ -50,6 +54,7 @@ def test_exact_walks_equal_reference_golden():
         assert got.keys() == want.keys(), c["name"]
         for k in want:
             assert got[k] == want[k], (c["name"], k)
+    assert {"karate_weighted_fp64", "multigraph_fp64"} <= names
 
 
 def _random_graph(rng, nv, ne, weighted, hubs=0, sinks=True):
