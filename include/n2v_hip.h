@@ -98,6 +98,10 @@ typedef struct n2v_graph {
   const int32_t *pivots; /* [(n_edges + 31) / 32]: col[min(32 j + 31, n_edges - 1)], or NULL */
   const uint32_t *edge_classes; /* [n_edges] or NULL */
   const struct n2v_hop *hops;   /* [n_edges] or NULL (unit-weight graphs) */
+  const uint64_t *wedge_off;    /* [n_edges] or NULL: see n2v_wedge_build */
+  const void *wedge_pos;        /* uint16 / uint32 positions, or NULL */
+  int32_t wedge_wide;           /* 0: wedge_pos is uint16 (every degree < 65536), 1: uint32 */
+  int32_t reserved;
 } n2v_graph;
 
 /* edge_classes[e] for e = (s -> v): bits 0..23 = number of entries x of N(v) with
@@ -145,6 +149,28 @@ int n2v_edge_classes_build(const n2v_graph *g, uint32_t *classes_out, uint32_t *
  * sets N2V_ST_RANGE in status[0] (read after synchronising): the table must then be discarded
  * (walk without it). */
 int n2v_hops_build(const n2v_graph *g, struct n2v_hop *hops_out, uint32_t *status, void *stream);
+
+/* Shared-position lists ("wedge table") of a unit-weight graph.  For edge e = (s -> v) the list
+ *   wedge_pos[off .. off + n_shared)   off = wedge_off[e] & (2^40 - 1), n_shared = low 24 bits
+ *                                      of edge_classes[e]
+ * holds, ascending, the positions j with N(v)[j] in N_out(s) and N(v)[j] != s -- WHICH slots of
+ * the table generate_edge_alias_tables builds at (s, v) carry the unchanged weight
+ * (randomwalk.py:226-227) -- and wedge_off[e] >> 40 is the position of the first N(v)[j] == s
+ * (the weight / p slots, :223-224; meaningful when the return count of edge_classes[e] is not
+ * 0).  With them N2V_WALK_EXACT needs neither a search over N(s) nor a pass over N(v) to lay
+ * the table of a step out: the membership test of the drawn slot is a search in its edge's
+ * short list, and the steps that must run the pairing loop (:182-189) read the class of every
+ * slot off the list.  One entry per (edge, common neighbour) pair: six per triangle.
+ *   list_off      [n_edges] exclusive prefix sum of the shared counts (the caller's cumsum over
+ *                 edge_classes & N2V_EC_SHARED_MASK); may be the same buffer as wedge_off_out
+ *   wedge_pos_out [sum of the counts] uint16 when wide == 0 (every out-degree < 65536) else
+ *                 uint32
+ * g->edge_classes must be set.  A list whose length disagrees with its count sets
+ * N2V_ST_RANGE in status[0] (the tables must then be discarded). */
+#define N2V_WEDGE_RPOS_SHIFT 40
+#define N2V_WEDGE_OFF_MASK 0xffffffffffull
+int n2v_wedge_build(const n2v_graph *g, const uint64_t *list_off, uint64_t *wedge_off_out,
+                    void *wedge_pos_out, int32_t wide, uint32_t *status, void *stream);
 
 /* Search index for N2V_WALK_FAST: the last id of every aligned block of 32 entries of
  * `col` (one 128-byte line).  Inside a sorted row the block ends ascend, so a

@@ -1,0 +1,255 @@
+// n2v_wedge.hip -- per-edge shared-position lists ("wedge table") for exact walks on
+// unit-weight graphs.
+//
+// generate_edge_alias_tables(s, N_out(s), N(v), p, q) (reference randomwalk.py:193-232) gives
+// slot j of the table of step (s -> v) one of three values according to N(v)[j]: == s
+// (:223-224), in N_out(s) (:226-227), neither (:229-230).  n2v_edge_classes_build already
+// stores HOW MANY slots of each kind the table of every edge has; that decides ~80 % of the
+// steps (n2v_walk_unit.hip, lanes kernel).  The other steps run the pairing loop (:182-189)
+// and need to know WHICH slots are which -- the reference recomputes the set intersection at
+// every step, and on the GPU that recomputation (searches over N(s), streaming N(v)) was
+// 58 % of those steps' time and 94 % of the kernel's.  This pass stores the answer once per
+// edge:
+//     wedge_pos[off(e) .. off(e) + n_shared(e))  the positions j, ascending, with
+//                                                N(v)[j] in N_out(s) and N(v)[j] != s
+//     wedge_off[e] = off(e) | rpos(e) << 40       rpos = position of the first N(v)[j] == s
+// (n_shared(e) and the return count are edge_classes[e]; off = their exclusive prefix sum,
+// computed by the caller).  The lists hold one entry per (edge, common neighbour) pair -- six
+// per triangle of the graph; 1.2 x 10^10 entries at BASELINE cfg 4 (23 GB as uint16).
+// Same traversal as n2v_edge_classes.hip (the shorter list searched in the longer one, one
+// lane per short edge, the wave for long ones), with ordered emission.
+#include "n2v_alias_core.h"
+
+namespace n2v {
+
+constexpr int kWLaneMax = 24;     // shorter list handled by one lane up to this length
+constexpr int kWEdgeBatch = 256;  // edges per counter grab
+
+template <typename P>
+__device__ __forceinline__ int lower_bound_1(const int32_t *a, int m, int32_t x) {
+  int lo = 0, hi = m;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < x)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// one lane: positions into out[0, cap), returns how many were written (never beyond cap)
+template <typename P>
+__device__ __forceinline__ int wedge_lane(const int32_t *scol, int ds, const int32_t *vcol, int dv,
+                                          int32_t s, P *out, int cap, int &rpos) {
+  int k = 0;
+  rpos = 0;
+  if (dv <= ds) {  // walk N(v), look each id up in N(s)
+    bool seen = false;
+    for (int j = 0; j < dv; ++j) {
+      const int32_t x = vcol[j];
+      if (x == s) {
+        if (!seen) rpos = j;
+        seen = true;
+      } else if (member_sorted_lane(scol, ds, x)) {
+        if (k < cap) out[k] = (P)j;
+        ++k;
+      }
+    }
+  } else {  // walk the distinct ids of N(s), locate their occurrences in N(v)
+    rpos = lower_bound_1<P>(vcol, dv, s);
+    if (rpos >= dv) rpos = 0;
+    int32_t prev = -1;
+    for (int i = 0; i < ds; ++i) {
+      const int32_t y = scol[i];
+      if (y != s && y != prev) {
+        int lo = lower_bound_1<P>(vcol, dv, y);
+        while (lo < dv && vcol[lo] == y) {
+          if (k < cap) out[k] = (P)lo;
+          ++k;
+          ++lo;
+        }
+      }
+      prev = y;
+    }
+  }
+  return k;
+}
+
+// exclusive prefix sum of a small per-lane count over the wave, and the total
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  total = __builtin_amdgcn_readlane(incl, 63);
+  return incl - v;
+}
+
+// the whole wave (all arguments wave-uniform)
+template <typename P>
+__device__ __forceinline__ int wedge_wave(const int32_t *scol, int ds, const int32_t *vcol, int dv,
+                                          int32_t s, int lane, P *out, int cap, int &rpos) {
+  int cnt = 0;
+  int rp = 0x7fffffff;
+  if (dv <= ds) {
+    const int iters = 32 - __clz(ds);
+    for (int base = 0; base < dv; base += 256) {
+      int32_t x[4];
+      bool found[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = base + u * 64 + lane;
+        x[u] = j < dv ? vcol[j] : -1;
+      }
+      member_sorted_x4(scol, ds, x, iters, found);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // sub-chunks in index order: ordered emission
+        const int j = base + u * 64 + lane;
+        const bool act = j < dv;
+        if (act && x[u] == s) rp = min(rp, j);
+        const bool hit = act && x[u] != s && found[u];
+        const uint64_t mask = ballot64(hit);
+        const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+        if (hit && pos < cap) out[pos] = (P)j;
+        cnt += __popcll(mask);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rp = min(rp, __shfl_xor(rp, off, 64));
+  } else {
+    const int iters = 32 - __clz(dv);
+    if (lane == 0) rp = lower_bound_1<P>(vcol, dv, s);
+    rp = __builtin_amdgcn_readfirstlane(rp);
+    for (int base = 0; base < ds; base += 256) {
+      int32_t y[4];
+      int lo[4];
+      bool found[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = base + u * 64 + lane;
+        const int32_t yy = k < ds ? scol[k] : -1;
+        const int32_t prev = (k >= 1 && k < ds) ? scol[k - 1] : -1;
+        y[u] = (yy == s || yy == prev) ? -1 : yy;  // the return slot / a repeated id: skip
+      }
+      lower_bound_x4(vcol, dv, y, iters, lo, found);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int c = 0;
+        if (found[u] && y[u] >= 0) {
+          c = 1;
+          while (lo[u] + c < dv && vcol[lo[u] + c] == y[u]) ++c;  // multi-edges of v
+        }
+        int total;
+        const int at = cnt + wave_excl_scan(c, lane, total);
+        for (int t = 0; t < c; ++t)
+          if (at + t < cap) out[at + t] = (P)(lo[u] + t);
+        cnt += total;
+      }
+    }
+  }
+  rpos = (rp == 0x7fffffff || rp >= dv) ? 0 : __builtin_amdgcn_readfirstlane(rp);
+  return __builtin_amdgcn_readfirstlane(cnt);
+}
+
+template <typename P>
+__global__ __launch_bounds__(256) void wedge_fill_kernel(n2v_graph g,
+                                                        const uint64_t *__restrict__ list_off,
+                                                        uint64_t *__restrict__ wedge_off,
+                                                        P *__restrict__ wedge_pos,
+                                                        uint32_t *__restrict__ status,
+                                                        uint32_t *__restrict__ counter) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n_edges = g.n_edges;
+  const int64_t n_batches = (n_edges + kWEdgeBatch - 1) / kWEdgeBatch;
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(counter, 1u);
+    const int64_t batch = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (batch >= n_batches) break;
+    for (int sub = 0; sub < kWEdgeBatch / 64; ++sub) {
+      const int64_t e = batch * kWEdgeBatch + sub * 64 + lane;
+      const bool act = e < n_edges;
+      int32_t s = 0, v = 0;
+      int64_t sb = 0, vb = 0;
+      int ds = 0, dv = 0, want = 0;
+      uint64_t off = 0;
+      if (act) {
+        int64_t lo = 0, hi = g.n_vertices;  // source row of edge e: last row with rowptr[row] <= e
+        while (hi - lo > 1) {
+          const int64_t mid = (lo + hi) >> 1;
+          if (g.rowptr[mid] <= e)
+            lo = mid;
+          else
+            hi = mid;
+        }
+        s = (int32_t)lo;
+        sb = g.rowptr[s];
+        ds = (int)(g.rowptr[s + 1] - sb);
+        v = g.col[e];
+        vb = g.rowptr[v];
+        dv = (int)(g.rowptr[v + 1] - vb);
+        off = list_off[e];
+        want = (int)(g.edge_classes[e] & N2V_EC_SHARED_MASK);
+      }
+      int got = 0, rpos = 0;
+      const bool small = act && min(ds, dv) <= kWLaneMax;
+      if (small) got = wedge_lane<P>(g.col + sb, ds, g.col + vb, dv, s, wedge_pos + off, want, rpos);
+      uint64_t big = ballot64(act && !small);
+      while (big != 0ull) {
+        const int l = (int)__builtin_ctzll(big);
+        big &= big - 1ull;
+        const int64_t sb_l = readfirstlane_i64(__shfl(sb, l, 64));
+        const int64_t vb_l = readfirstlane_i64(__shfl(vb, l, 64));
+        const int64_t off_l = readfirstlane_i64(__shfl((int64_t)off, l, 64));
+        const int ds_l = __builtin_amdgcn_readlane(ds, l);
+        const int dv_l = __builtin_amdgcn_readlane(dv, l);
+        const int want_l = __builtin_amdgcn_readlane(want, l);
+        const int32_t s_l = __builtin_amdgcn_readlane(s, l);
+        int rp = 0;
+        const int k = wedge_wave<P>(g.col + sb_l, ds_l, g.col + vb_l, dv_l, s_l, lane,
+                                    wedge_pos + off_l, want_l, rp);
+        if (lane == l) {
+          got = k;
+          rpos = rp;
+        }
+      }
+      if (act) {
+        // the list must have exactly the length edge_classes promised (the prefix sum was
+        // taken over those counts); anything else means the two tables disagree
+        if (got != want) atomicOr(status, N2V_ST_RANGE);
+        wedge_off[e] = off | ((uint64_t)(uint32_t)rpos << N2V_WEDGE_RPOS_SHIFT);
+      }
+    }
+  }
+}
+
+}  // namespace n2v
+
+extern "C" int n2v_wedge_build(const n2v_graph *g, const uint64_t *list_off, uint64_t *wedge_off_out,
+                               void *wedge_pos_out, int32_t wide, uint32_t *status, void *stream) {
+  if (!g || !g->rowptr || g->n_vertices < 0 || g->n_edges < 0) return N2V_EINVAL;
+  if (g->w || g->w64) return N2V_EINVAL;  // unit-weight graphs only
+  if (g->n_edges == 0) return N2V_OK;
+  if (!g->col || !g->edge_classes || !list_off || !wedge_off_out || !wedge_pos_out || !status)
+    return N2V_EINVAL;
+  const int64_t n_batches = (g->n_edges + n2v::kWEdgeBatch - 1) / n2v::kWEdgeBatch;
+  if (n_batches >= 0xffff0000ll) return N2V_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), st) != hipSuccess) return N2V_ELAUNCH;
+  int64_t blocks = (n_batches + 3) / 4;
+  const void *fn = wide ? (const void *)n2v::wedge_fill_kernel<uint32_t>
+                        : (const void *)n2v::wedge_fill_kernel<uint16_t>;
+  const int64_t cap = n2v::resident_blocks(fn, 256, 0);
+  if (blocks > cap) blocks = cap;
+  if (wide)
+    hipLaunchKernelGGL(n2v::wedge_fill_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, st, *g,
+                       list_off, wedge_off_out, (uint32_t *)wedge_pos_out, status, status + 1);
+  else
+    hipLaunchKernelGGL(n2v::wedge_fill_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, st, *g,
+                       list_off, wedge_off_out, (uint16_t *)wedge_pos_out, status, status + 1);
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}

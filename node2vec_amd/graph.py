@@ -37,6 +37,8 @@ class DeviceGraph:
         self.edge_classes: Optional[torch.Tensor] = None  # uint32-in-int32 [E] (exact mode, unit weights)
         self.hops: Optional[torch.Tensor] = None  # int32 [E, 4] view of n2v_hop[E] (unit weights)
         self.hops_have_classes = False
+        self.wedge_off: Optional[torch.Tensor] = None  # int64 [E]: list offset | return position << 40
+        self.wedge_pos: Optional[torch.Tensor] = None  # int16 / int32 [sum of shared counts]
 
     @property
     def w(self) -> torch.Tensor:
@@ -125,7 +127,7 @@ class DeviceGraph:
     def to(self, device) -> "DeviceGraph":
         g = DeviceGraph(self.rowptr.to(device), self.col.to(device),
                         None if self._w is None else self._w.to(device))
-        for name in ("slots", "pivots", "edge_classes", "hops"):
+        for name in ("slots", "pivots", "edge_classes", "hops", "wedge_off", "wedge_pos"):
             t = getattr(self, name)
             if t is not None:
                 setattr(g, name, t.to(device))
@@ -141,7 +143,10 @@ class DeviceGraph:
                           0 if self.slots is None else self.slots.data_ptr(),
                           0 if self.pivots is None else self.pivots.data_ptr(),
                           0 if self.edge_classes is None else self.edge_classes.data_ptr(),
-                          0 if self.hops is None else self.hops.data_ptr())
+                          0 if self.hops is None else self.hops.data_ptr(),
+                          0 if self.wedge_off is None else self.wedge_off.data_ptr(),
+                          0 if self.wedge_pos is None else self.wedge_pos.data_ptr(),
+                          0 if self.wedge_pos is None else int(self.wedge_pos.dtype == torch.int32), 0)
 
     # -- a9 -----------------------------------------------------------------------
     def trimmed(self, max_out_degree: int, seed: int) -> "DeviceGraph":
@@ -206,6 +211,45 @@ class DeviceGraph:
                                               _lib.current_stream_ptr())
             _lib.check(rc, "n2v_edge_classes_build")
         self.edge_classes = ec
+        return self
+
+    def build_wedges(self, max_bytes: Optional[int] = None) -> "DeviceGraph":
+        """Shared-position lists (n2v_wedge_build): for every edge (s -> v) the positions in
+        N(v) of the neighbours v shares with s -- what generate_edge_alias_tables recomputes by a
+        set intersection at every step (randomwalk.py:226), stored once.  8 bytes per edge + 2
+        (4 when some degree >= 65536) per (edge, common neighbour) pair; `max_bytes` (default:
+        half of the free device memory) bounds it -- a graph with more triangles than that
+        walks without the lists (same bits, slower on the steps that need the pairing)."""
+        L = _lib.load()
+        _lib.require_gpu()
+        if not self.unit_weights:
+            raise ValueError("the wedge table exists for unit-weight graphs only")
+        if self.edge_classes is None:
+            self.build_edge_classes()
+        self.wedge_off = self.wedge_pos = None
+        if self.n_edges == 0 or int(self.degrees().max()) >= self.HOP_MAX_DEGREE:
+            return self
+        counts = (self.edge_classes & 0xffffff).to(torch.int64)
+        if bool((counts == 0xffffff).any()):
+            return self  # a saturated count: no list for this graph
+        total = int(counts.sum())
+        wide = int(self.degrees().max()) >= 65536
+        need = 8 * self.n_edges + total * (4 if wide else 2)
+        if max_bytes is None:
+            max_bytes = torch.cuda.mem_get_info(self.device)[0] // 2
+        if need > max_bytes or total >= (1 << 40):
+            return self
+        off = torch.cumsum(counts, 0) - counts  # exclusive prefix sum; becomes wedge_off in place
+        del counts
+        pos = torch.empty(max(total, 1), dtype=torch.int32 if wide else torch.int16, device=self.device)
+        status = torch.zeros(4, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = L.n2v_wedge_build(self.c_struct(), off.data_ptr(), off.data_ptr(), pos.data_ptr(),
+                                   int(wide), status.data_ptr(), _lib.current_stream_ptr())
+        _lib.check(rc, "n2v_wedge_build")
+        if int(status[0].item()) & _lib.ST_RANGE:
+            raise RuntimeError("n2v_wedge_build: list lengths disagree with edge_classes")
+        self.wedge_off, self.wedge_pos = off, pos
         return self
 
     HOP_MAX_DEGREE = 1 << 24  # n2v_hop packs the degree into 24 bits
