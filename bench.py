@@ -270,7 +270,7 @@ def main():
         del leg
         torch.cuda.empty_cache()
     # the walk tables are not needed any more (the CPU baseline reads rowptr / col only)
-    g.slots = g.pivots = g.hops = g.edge_classes = None
+    g.slots = g.pivots = g.hops = g.edge_classes = g.wedge_off = g.wedge_pos = None
     torch.cuda.empty_cache()
 
     # ---- SGNS on the config's model ------------------------------------------------------------
@@ -309,6 +309,11 @@ def prepare_tables(torch, g, p, q, mode, setup, tag):
             timed("pivots_build", g.build_pivots)
         if biased and g.edge_classes is None and (mode == "fast" or lanes_regime(p, q)):
             timed("edge_classes_build", g.build_edge_classes)
+        if biased and mode == "exact" and lanes_regime(p, q) and g.wedge_off is None and not g.wedge_tried:
+            g.wedge_tried = True
+            timed("wedge_table_build", g.build_wedges)
+            setup[f"{tag}_wedge_table_GB"] = 0.0 if g.wedge_off is None else (
+                g.wedge_off.numel() * 8 + g.wedge_pos.numel() * g.wedge_pos.element_size()) / 1e9
         if g.hops is None or (g.edge_classes is not None and not g.hops_have_classes):
             timed("hop_table_build", g.build_hops)
     elif g.slots is None and (mode == "fast" or not biased):
@@ -357,13 +362,15 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
                     "16 (rowptr pair) + 4 (edge class word) + 4 (col[pick]) + 4 (path write)") +
                    " per step, + 4 per probe of the membership search; steps that run the pairing "
                    "read both rows")
-    kernel_key = kernel + (":hops" if hops else "")
+    kernel_key = kernel + (":hops" if hops else "") + (
+        ":wedges" if (leg.g.wedge_off is not None and mode == "exact" and not (p == 1.0 and q == 1.0)) else "")
     traffic = pmc_traffic(config, kernel_key, p, q, leg.batch)
     alg_launch = alg * per_launch_steps
     used = traffic if traffic else alg_launch
     ach = used / res["kernel_s"]
     r = {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
          "frac": ach / HBM_PEAK, "traffic": traffic, "kernel": kernel, "hop_table": hops,
+         "wedge_table": ":wedges" in kernel_key,
          "kernel_ms": 1e3 * res["kernel_s"],
          "achieved_from": "pmc traffic" if traffic else "kernel algorithmic bytes (no pmc profile of this workload)",
          "algorithmic_bytes_per_launch": alg_launch, "algorithmic_bytes_per_walk_step": alg,

@@ -192,7 +192,95 @@ struct UnitStep {
   int n, nch, m, iters;
   int32_t s;
   bool need_mem;
+  // the classes of this step's table are already known by position (wedge table of the graph,
+  // n2v_wedge_build): return slots [w_rpos, w_rpos + w_nR), shared slots w_pos[0, w_nM)
+  bool w_have = false, w_wide = false;
+  const void *w_pos = nullptr;
+  int w_nR = 0, w_nM = 0, w_rpos = 0;
 };
+
+// entry k of a wedge list (uint16 or uint32 positions; the width is wave-uniform)
+__device__ __forceinline__ int wedge_at(const void *base, int64_t k, bool wide) {
+  return wide ? (int)reinterpret_cast<const uint32_t *>(base)[k]
+              : (int)reinterpret_cast<const uint16_t *>(base)[k];
+}
+
+// is `pos` one of the (ascending) positions list[0, cnt)?  one lane
+__device__ __forceinline__ bool wedge_has(const void *base, int64_t off, int cnt, int pos, bool wide) {
+  int lo = 0, hi = cnt;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (wedge_at(base, off + mid, wide) < pos)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo < cnt && wedge_at(base, off + lo, wide) == pos;
+}
+
+// ---- the pairing loop of generate_alias_tables (randomwalk.py:175-189) for ONE slot of a row
+// of at most 64 neighbours, by one lane: the two stacks are bit masks (popped from the highest
+// index, as list.pop() does on ascending lists), a demoted overfull slot is the next underfull
+// one, an overfull slot that stays >= 1 is the next overfull one.  Slot values are the three
+// class values; only probs[pick] and alias[pick] are tracked, and the loop stops when `pick`
+// has been paired as an underfull slot (it never changes afterwards).  Returns
+// sampling_from_alias: pick if r2 < probs[pick] else alias[pick].
+__device__ __forceinline__ int lane_pairing(int n, uint64_t Rm, uint64_t Mm, int pick, double r2,
+                                            double vR, double vM, double vO) {
+  const uint64_t valid = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+  Rm &= valid;
+  Mm &= valid & ~Rm;
+  const uint64_t Om = valid & ~(Rm | Mm);
+  uint64_t under = ((vR < 1.0) ? Rm : 0ull) | ((vM < 1.0) ? Mm : 0ull) | ((vO < 1.0) ? Om : 0ull);
+  uint64_t over = valid & ~under;
+  auto val0 = [&](int i) -> double {
+    return pick3(((Rm >> i) & 1ull) != 0, ((Mm >> i) & 1ull) != 0, vR, vM, vO);
+  };
+  double p_pick = val0(pick);
+  int alias_pick = 0;
+  bool have_carry = false, have_cur = false;
+  int carry_i = 0, cur_i = 0;
+  double carry_v = 0.0, cur_v = 0.0;
+  while ((have_carry || under != 0ull) && (have_cur || over != 0ull)) {  // :182
+    int ui, oi;
+    double uv, ov;
+    if (have_carry) {
+      ui = carry_i;
+      uv = carry_v;
+      have_carry = false;
+    } else {
+      ui = 63 - __clzll((long long)under);
+      under &= ~(1ull << ui);
+      uv = val0(ui);
+    }
+    if (have_cur) {
+      oi = cur_i;
+      ov = cur_v;
+      have_cur = false;
+    } else {
+      oi = 63 - __clzll((long long)over);
+      over &= ~(1ull << oi);
+      ov = val0(oi);
+    }
+    if (ui == pick) {  // alias[under] = over (:184); probs[under] is final
+      alias_pick = oi;
+      p_pick = uv;
+      break;
+    }
+    ov = ov + uv - 1.0;  // :185, two roundings
+    if (oi == pick) p_pick = ov;
+    if (ov < 1.0) {  // :186-189
+      have_carry = true;
+      carry_i = oi;
+      carry_v = ov;
+    } else {
+      have_cur = true;
+      cur_i = oi;
+      cur_v = ov;
+    }
+  }
+  return (r2 < p_pick) ? pick : alias_pick;
+}
 
 __device__ __forceinline__ uint64_t valid_mask(const UnitStep &c, int chunk) {
   const int rem = c.n - chunk * 64;
@@ -335,7 +423,41 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
   // N(s) is searched once.
   // (thresholds 128..512 and ratios 1..4 were timed on cfg 2: flat within 2 %)
   const bool reverse = n > 256 && (!c.need_mem || 2 * c.m < n);
-  if (reverse) {
+  if (c.w_have) {
+    // the graph's wedge table names every return / shared slot by position: scatter the class
+    // bits, no search over N(s) and no pass over N(v)
+    const int ncached = c.nch < kUC ? c.nch : kUC;
+    for (int wv = lane; wv < 2 * ncached; wv += 64) L.cls[wv] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    sp_n = 0;
+    nR = c.w_nR;
+    nM = c.need_mem ? c.w_nM : 0;
+    const int items = nR + nM;
+    for (int base = 0; base < items; base += 64) {
+      const int k = base + lane;
+      const bool act = k < items;
+      const bool isr = k < nR;
+      int j = 0;
+      if (act) j = isr ? c.w_rpos + k : wedge_at(c.w_pos, k - nR, c.w_wide);
+      const int ci = c.nch - 1 - (j >> 6);
+      if (act && ci < kUC)
+        atomicOr(reinterpret_cast<unsigned long long *>(&L.cls[2 * ci + (isr ? 0 : 1)]),
+                 1ull << (j & 63));
+      const bool far = act && ci >= kUC;
+      const uint64_t fb = ballot64(far);
+      if (fb != 0ull) {
+        const int slot = sp_n + __popcll(fb & ((1ull << lane) - 1ull));
+        if (far && slot < kSparseCap) L.pool[slot] = (uint32_t)j | (isr ? 0x80000000u : 0u);
+        sp_n += __popcll(fb);
+      }
+    }
+    if (sp_n > kSparseCap) sp_n = -1;  // too many: the uncached chunks are searched on demand
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    N2V_T(24);
+    N2V_STAT(13, 1);
+  } else if (reverse) {
     const int ncached = c.nch < kUC ? c.nch : kUC;
     for (int wv = lane; wv < 2 * ncached; wv += 64) L.cls[wv] = 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1310,6 +1432,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
   const int L1 = walk_length + 1;
   const bool biased = !(p == 1.0 && q == 1.0);
   const bool need_mem = q != 1.0;
+  // wedge table (n2v_wedge_build): the class of every slot of a step's table by position
+  const bool have_w = g.wedge_off != nullptr && g.wedge_pos != nullptr;
+  const bool w_wide = g.wedge_wide != 0;
   UnitStep c;
   c.need_mem = need_mem;
 #ifdef N2V_STATS
@@ -1359,6 +1484,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
       h.col = -1;
       h.classes = 0;
       h.row = 0;
+      int64_t w_off = 0;
+      int w_rpos = 0, w_nR = 0, w_nM = 0;
+      bool w_ok = false;
 #ifdef N2V_STATS
       const unsigned long long t_q0 = __builtin_readcyclecounter();
 #endif
@@ -1385,25 +1513,42 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
             const double avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;  // :172
             const bool isR = x == s;
             bool isM = false;
-            if (need_mem && !isR) isM = member_sorted_lane(g.col + sb, m, x);  // :226
+            if (have_w && (nM > 0 || nR > 0)) {  // this edge's list: offset | return position << 40
+              const uint64_t wraw = g.wedge_off[e_prev];
+              w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
+              w_rpos = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
+            }
+            if (need_mem && !isR && nM > 0)  // :226
+              isM = have_w ? wedge_has(g.wedge_pos, w_off, nM, pick, w_wide)
+                           : member_sorted_lane(g.col + sb, m, x);
             const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) / avg;      // :173
             const double r2 = (double)u2 * (1.0 / 4294967296.0);
             if (!(p_pick < 1.0 && r2 < p_pick)) {
-              const bool uR = K.bR / avg < 1.0, uM = K.bM / avg < 1.0, uO = K.bO / avg < 1.0;
+              const double vR = K.bR / avg, vM = K.bM / avg, vO = K.bO / avg;
+              const bool uR = vR < 1.0, uM = vM < 1.0, uO = vO < 1.0;
               const bool any_under = (nR && uR) || (nM && uM) || (nO && uO);
               const bool any_over = (nR && !uR) || (nM && !uM) || (nO && !uO);
               if (!any_under || !any_over) {  // the loop of :182 never runs
-                if (!(r2 < p_pick)) {
-                  idx = 0;
-                  if (kHops) {
-                    h = load_hop(g.hops + vb);
-                    x = h.col;
-                  } else {
-                    x = g.col[vb];
-                  }
-                }
+                if (!(r2 < p_pick)) idx = 0;
+              } else if (have_w && n <= 64) {
+                // a short row: this lane replays the pairing itself from the two class masks
+                uint64_t Rm = 0ull, Mm = 0ull;
+                if (nR) Rm = ((nR >= 64) ? ~0ull : ((1ull << nR) - 1ull)) << w_rpos;
+                for (int k = 0; k < nM; ++k) Mm |= 1ull << wedge_at(g.wedge_pos, w_off + k, w_wide);
+                idx = lane_pairing(n, Rm, Mm, pick, r2, vR, vM, vO);
               } else {
                 unresolved = true;
+                w_nR = nR;
+                w_nM = nM;
+                w_ok = have_w;
+              }
+              if (!unresolved && idx != pick) {
+                if (kHops) {
+                  h = load_hop(g.hops + vb + idx);
+                  x = h.col;
+                } else {
+                  x = g.col[vb + idx];
+                }
               }
             }
           }
@@ -1429,6 +1574,16 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
         c.m = __builtin_amdgcn_readlane(m, l);
         c.iters = 32 - __clz(c.m);
         c.s = __builtin_amdgcn_readlane(s, l);
+        c.w_have = __builtin_amdgcn_readlane((int)w_ok, l) != 0;
+        c.w_wide = w_wide;
+        c.w_nR = __builtin_amdgcn_readlane(w_nR, l);
+        c.w_nM = __builtin_amdgcn_readlane(w_nM, l);
+        c.w_rpos = __builtin_amdgcn_readlane(w_rpos, l);
+        {
+          const int64_t wo = readfirstlane_i64(__shfl(w_off, l, 64));
+          c.w_pos = w_wide ? (const void *)(reinterpret_cast<const uint32_t *>(g.wedge_pos) + wo)
+                           : (const void *)(reinterpret_cast<const uint16_t *>(g.wedge_pos) + wo);
+        }
         const uint32_t u1_l = (uint32_t)__builtin_amdgcn_readlane((int)u1, l);
         const uint32_t u2_l = (uint32_t)__builtin_amdgcn_readlane((int)u2, l);
 #ifdef N2V_STATS

@@ -39,6 +39,7 @@ class DeviceGraph:
         self.hops_have_classes = False
         self.wedge_off: Optional[torch.Tensor] = None  # int64 [E]: list offset | return position << 40
         self.wedge_pos: Optional[torch.Tensor] = None  # int16 / int32 [sum of shared counts]
+        self.wedge_tried = False  # randomwalk.walk tries to build the table once
 
     @property
     def w(self) -> torch.Tensor:
@@ -213,7 +214,7 @@ class DeviceGraph:
         self.edge_classes = ec
         return self
 
-    def build_wedges(self, max_bytes: Optional[int] = None) -> "DeviceGraph":
+    def build_wedges(self, max_bytes: Optional[int] = None, wide: Optional[bool] = None) -> "DeviceGraph":
         """Shared-position lists (n2v_wedge_build): for every edge (s -> v) the positions in
         N(v) of the neighbours v shares with s -- what generate_edge_alias_tables recomputes by a
         set intersection at every step (randomwalk.py:226), stored once.  8 bytes per edge + 2
@@ -233,7 +234,8 @@ class DeviceGraph:
         if bool((counts == 0xffffff).any()):
             return self  # a saturated count: no list for this graph
         total = int(counts.sum())
-        wide = int(self.degrees().max()) >= 65536
+        if wide is None or int(self.degrees().max()) >= 65536:  # `wide=True` forces 32-bit positions
+            wide = int(self.degrees().max()) >= 65536 or bool(wide)
         need = 8 * self.n_edges + total * (4 if wide else 2)
         if max_bytes is None:
             max_bytes = torch.cuda.mem_get_info(self.device)[0] // 2

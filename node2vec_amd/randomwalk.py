@@ -53,7 +53,8 @@ def start_vertices(graph: DeviceGraph, walk_seed_ids=None) -> torch.Tensor:
 def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_length: int,
          return_param: float, inout_param: float, seed: int, mode: str = "exact",
          out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, check: bool = True,
-         stats: Optional[dict] = None, use_edge_classes: bool = True, use_hops: bool = True):
+         stats: Optional[dict] = None, use_edge_classes: bool = True, use_hops: bool = True,
+         use_wedges: bool = True):
     """Launch K2.  Returns (walks int32 [n_start*num_walks, walk_length+1], valid bool).
 
     mode "fast", and on weighted graphs mode "exact" with return_param == inout_param == 1
@@ -63,7 +64,10 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     class counts (graph.build_edge_classes(): 4 bytes per edge, built on first use;
     use_edge_classes=False walks without them, one wave per walker: same bits, slower).
     Unit-weight graphs also get the hop table (graph.build_hops(): 16 bytes per edge, built on
-    first use; use_hops=False walks the CSR arrays instead: same bits, more gathers per step)."""
+    first use; use_hops=False walks the CSR arrays instead: same bits, more gathers per step)
+    and, for biased exact walks, the wedge table (graph.build_wedges(): the shared neighbours of
+    every edge by position, 8 bytes per edge + 2 per entry, skipped when it would not fit;
+    use_wedges=False walks without it: same bits, searches at the steps that need the pairing)."""
     L = _lib.load()
     _lib.require_gpu()
     if mode not in MODES:
@@ -88,9 +92,14 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     if mode == "exact" and graph.unit_weights:
         # unit weights: the per-step table follows from two counts per edge, computed once
         # (n2v_edge_classes_build, 4 bytes per edge); p == q == 1 needs nothing at all
-        if (use_edge_classes and biased and graph.edge_classes is None
-                and lanes_regime(return_param, inout_param)):
-            graph.build_edge_classes()
+        if use_edge_classes and biased and lanes_regime(return_param, inout_param):
+            if graph.edge_classes is None:
+                graph.build_edge_classes()
+            # which slots are which, per edge (wedge table): built once if it fits in half of the
+            # free device memory; the steps that run the pairing then search and stream nothing
+            if use_wedges and graph.wedge_off is None and not graph.wedge_tried:
+                graph.wedge_tried = True
+                graph.build_wedges()
     elif mode == "exact" and not biased and graph.slots is None:
         # the reference's default p = q = 1: every per-step table is the first-order table of
         # the current vertex, i.e. the K1 slots (bit-identical); build them once (milliseconds)
@@ -118,6 +127,9 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
         g.edge_classes = 0
     if not use_hops or (not use_edge_classes and biased):
         g.hops = 0
+    if not use_wedges or not use_edge_classes:
+        g.wedge_off = 0
+        g.wedge_pos = 0
     with torch.cuda.device(graph.device):
         rc = L.n2v_walk(g, start_ids.data_ptr(), n_start, num_walks, walk_length,
                         float(return_param), float(inout_param), seed & (2 ** 64 - 1),

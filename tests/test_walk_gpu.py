@@ -161,9 +161,13 @@ def test_hop_table_and_class_counts_change_no_bit(oracle, pq):
     start = rw.start_vertices(g)
     a, av = rw.walk(g, start, 3, 25, p, q, 9)
     assert g.hops is not None and (p == q == 1.0 or g.hops_have_classes or not rw.lanes_regime(p, q))
+    assert (g.wedge_off is not None) == (rw.lanes_regime(p, q) and not (p == q == 1.0))
     b, bv = rw.walk(g, start, 3, 25, p, q, 9, use_hops=False)
     c, cv = rw.walk(g, start, 3, 25, p, q, 9, use_hops=False, use_edge_classes=False)
+    d, dv = rw.walk(g, start, 3, 25, p, q, 9, use_wedges=False)
+    e, ev = rw.walk(g, start, 3, 25, p, q, 9, use_hops=False, use_wedges=False)
     assert torch.equal(a, b) and torch.equal(av, bv) and torch.equal(a, c) and torch.equal(av, cv)
+    assert torch.equal(a, d) and torch.equal(av, dv) and torch.equal(a, e) and torch.equal(av, ev)
     want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), None,
                                   start.cpu().numpy(), 3, 25, p, q, 9, n_threads=8)
     assert np.array_equal(av.cpu().numpy(), wv)

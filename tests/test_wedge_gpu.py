@@ -35,18 +35,8 @@ def test_wedge_lists_equal_the_per_step_set_intersection(wide):
     dst = np.concatenate([rng.integers(0, nv, 9000), rng.integers(0, nv, 2500), rng.integers(0, 6, 2500),
                           rng.integers(0, 40, 300)])  # 6 hubs (wave path), multi-edges, self-loops
     g = DeviceGraph.from_edges(src, dst, None, n_vertices=nv, device="cuda")
-    if wide:  # force the 32-bit form
-        g.HOP_MAX_DEGREE = DeviceGraph.HOP_MAX_DEGREE
-        import node2vec_amd.graph as G
-        real = g.degrees
-        g.degrees = lambda: torch.cat([real(), torch.tensor([70000], device="cuda")])  # pretend a long row
-        g.build_edge_classes()
-        g.build_wedges()
-        g.degrees = real
-        assert g.wedge_pos.dtype == torch.int32
-    else:
-        g.build_wedges()
-        assert g.wedge_pos.dtype == torch.int16
+    g.build_wedges(wide=wide)
+    assert g.wedge_pos.dtype == (torch.int32 if wide else torch.int16)
     rowptr, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
     want_pos, want_rpos, want_nr = _expected(rowptr, col)
     ec = g.edge_classes.cpu().numpy().astype(np.uint32)
