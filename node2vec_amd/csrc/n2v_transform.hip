@@ -34,7 +34,11 @@ __global__ __launch_bounds__(256) void edge_bias_kernel(
         hi = mid;
     }
     const int64_t row = lo;
-    const double weight = w64 ? w64[e] : (w ? (double)w[e] : 1.0);
+    double weight = 1.0;  // plain branches: never a select of two loads of different widths
+    if (w64)
+      weight = w64[e];
+    else if (w)
+      weight = (double)w[e];
     const int32_t s = src_id ? src_id[row] : -1;
     double b = weight;  // first step (src < 0): generate_alias_tables(dst weights), :319-320
     if (s >= 0) {

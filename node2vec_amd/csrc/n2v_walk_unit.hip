@@ -26,6 +26,21 @@
 
 namespace n2v {
 
+// diagnostic build only (-DN2V_CHECK): out-of-range values are recorded in status[0] (bits 8..)
+// and clamped instead of being used as addresses
+#ifdef N2V_CHECK
+static __device__ uint32_t *n2v_check_status;
+#define N2V_CHECK_RANGE(code, val, lo_, hi_)                                  \
+  do {                                                                         \
+    if ((val) < (lo_) || (val) >= (hi_)) {                                     \
+      atomicOr(n2v_check_status, 1u << (8 + (code)));                          \
+      (val) = (lo_);                                                           \
+    }                                                                          \
+  } while (0)
+#else
+#define N2V_CHECK_RANGE(code, val, lo_, hi_) do { } while (0)
+#endif
+
 constexpr int kUC = 128;     // class ballots cached for the TOP 128 chunks (8192 neighbours)
 constexpr int kYsCap = 384;   // N(s) staged in LDS when it has at most this many ids
 constexpr int kBitsA = 256;   // filter words beside a staged N(s)        (8192 bits)
@@ -199,23 +214,49 @@ struct UnitStep {
   int w_nR = 0, w_nM = 0, w_rpos = 0;
 };
 
-// entry k of a wedge list (uint16 or uint32 positions; the width is wave-uniform)
-__device__ __forceinline__ int wedge_at(const void *base, int64_t k, bool wide) {
-  return wide ? (int)reinterpret_cast<const uint32_t *>(base)[k]
-              : (int)reinterpret_cast<const uint16_t *>(base)[k];
+// entry k of a wedge list.  The width (uint16 / uint32) is wave-uniform and every caller
+// branches on it OUTSIDE its loops, each side doing plain typed loads: written as one
+// `wide ? load32 : load16` expression the compiler turned the choice into a select of two
+// loads, and the 32-bit one of a 16-bit table reads up to twice as far as the table is long
+// (a memory fault once the table has its own allocation).
+template <typename P>
+__device__ __forceinline__ int wedge_at_t(const void *base, int64_t k) {
+  return (int)reinterpret_cast<const P *>(base)[k];
 }
 
 // is `pos` one of the (ascending) positions list[0, cnt)?  one lane
-__device__ __forceinline__ bool wedge_has(const void *base, int64_t off, int cnt, int pos, bool wide) {
+template <typename P>
+__device__ __forceinline__ bool wedge_has_t(const void *base, int64_t off, int cnt, int pos) {
+  const P *a = reinterpret_cast<const P *>(base) + off;
   int lo = 0, hi = cnt;
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
-    if (wedge_at(base, off + mid, wide) < pos)
+    if ((int)a[mid] < pos)
       lo = mid + 1;
     else
       hi = mid;
   }
-  return lo < cnt && wedge_at(base, off + lo, wide) == pos;
+  if (lo >= cnt) return false;
+  return (int)a[lo] == pos;
+}
+
+__device__ __forceinline__ bool wedge_has(const void *base, int64_t off, int cnt, int pos, bool wide) {
+  if (wide) return wedge_has_t<uint32_t>(base, off, cnt, pos);
+  return wedge_has_t<uint16_t>(base, off, cnt, pos);
+}
+
+// OR of 1 << list[k] for k < cnt (a row of at most 64 neighbours); one lane
+template <typename P>
+__device__ __forceinline__ uint64_t wedge_mask_t(const void *base, int64_t off, int cnt) {
+  const P *a = reinterpret_cast<const P *>(base) + off;
+  uint64_t mk = 0ull;
+  for (int k = 0; k < cnt; ++k) mk |= 1ull << ((int)a[k] & 63);
+  return mk;
+}
+
+__device__ __forceinline__ uint64_t wedge_mask(const void *base, int64_t off, int cnt, bool wide) {
+  if (wide) return wedge_mask_t<uint32_t>(base, off, cnt);
+  return wedge_mask_t<uint16_t>(base, off, cnt);
 }
 
 // ---- the pairing loop of generate_alias_tables (randomwalk.py:175-189) for ONE slot of a row
@@ -439,7 +480,15 @@ __device__ __forceinline__ int unit_draw(const UnitStep &c, const UnitConsts &K,
       const bool act = k < items;
       const bool isr = k < nR;
       int j = 0;
-      if (act) j = isr ? c.w_rpos + k : wedge_at(c.w_pos, k - nR, c.w_wide);
+      if (act) {
+        if (isr)
+          j = c.w_rpos + k;
+        else if (c.w_wide)
+          j = wedge_at_t<uint32_t>(c.w_pos, k - nR);
+        else
+          j = wedge_at_t<uint16_t>(c.w_pos, k - nR);
+      }
+      N2V_CHECK_RANGE(5, j, 0, n);
       const int ci = c.nch - 1 - (j >> 6);
       if (act && ci < kUC)
         atomicOr(reinterpret_cast<unsigned long long *>(&L.cls[2 * ci + (isr ? 0 : 1)]),
@@ -1435,6 +1484,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
   // wedge table (n2v_wedge_build): the class of every slot of a step's table by position
   const bool have_w = g.wedge_off != nullptr && g.wedge_pos != nullptr;
   const bool w_wide = g.wedge_wide != 0;
+#ifdef N2V_CHECK
+  n2v_check_status = status;
+  const int dbg = g.reserved;  // bit 0: no per-lane pairing, 1: no list classification, 2: no list membership
+#else
+  constexpr int dbg = 0;
+#endif
   UnitStep c;
   c.need_mem = need_mem;
 #ifdef N2V_STATS
@@ -1513,14 +1568,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
             const double avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;  // :172
             const bool isR = x == s;
             bool isM = false;
+            N2V_CHECK_RANGE(3, e_prev, (int64_t)0, g.n_edges);
             if (have_w && (nM > 0 || nR > 0)) {  // this edge's list: offset | return position << 40
               const uint64_t wraw = g.wedge_off[e_prev];
               w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
               w_rpos = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
             }
             if (need_mem && !isR && nM > 0)  // :226
-              isM = have_w ? wedge_has(g.wedge_pos, w_off, nM, pick, w_wide)
-                           : member_sorted_lane(g.col + sb, m, x);
+              isM = (have_w && !(dbg & 4)) ? wedge_has(g.wedge_pos, w_off, nM, pick, w_wide)
+                                           : member_sorted_lane(g.col + sb, m, x);
             const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) / avg;      // :173
             const double r2 = (double)u2 * (1.0 / 4294967296.0);
             if (!(p_pick < 1.0 && r2 < p_pick)) {
@@ -1530,17 +1586,19 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
               const bool any_over = (nR && !uR) || (nM && !uM) || (nO && !uO);
               if (!any_under || !any_over) {  // the loop of :182 never runs
                 if (!(r2 < p_pick)) idx = 0;
-              } else if (have_w && n <= 64) {
+              } else if (have_w && n <= 64 && !(dbg & 1)) {
                 // a short row: this lane replays the pairing itself from the two class masks
                 uint64_t Rm = 0ull, Mm = 0ull;
                 if (nR) Rm = ((nR >= 64) ? ~0ull : ((1ull << nR) - 1ull)) << w_rpos;
-                for (int k = 0; k < nM; ++k) Mm |= 1ull << wedge_at(g.wedge_pos, w_off + k, w_wide);
+                const uint64_t Mm_list = wedge_mask(g.wedge_pos, w_off, nM, w_wide);
+                Mm = Mm_list;
                 idx = lane_pairing(n, Rm, Mm, pick, r2, vR, vM, vO);
+                N2V_CHECK_RANGE(2, idx, 0, n);
               } else {
                 unresolved = true;
                 w_nR = nR;
                 w_nM = nM;
-                w_ok = have_w;
+                w_ok = have_w && !(dbg & 2);
               }
               if (!unresolved && idx != pick) {
                 if (kHops) {
@@ -1591,7 +1649,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
 #endif
         const int res = __builtin_amdgcn_readfirstlane(unit_draw<true>(c, K, u1_l, u2_l, lane, L N2V_STATS_PASS));
         __builtin_amdgcn_wave_barrier();
-        if (lane == l) idx = res;
+        if (lane == l) {
+          idx = res;
+          N2V_CHECK_RANGE(1, idx, 0, n);
+        }
 #ifdef N2V_STATS
         {  // fallback draws and their cycles by deg(v) bucket
           const int bk = c.n <= 64 ? 0 : (c.n <= 1024 ? 1 : (c.n <= 4096 ? 2 : 3));

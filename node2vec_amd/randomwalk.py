@@ -138,8 +138,9 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     _lib.check(rc, "n2v_walk")
     if check:
         _lib.check_status_word(int(status[0].item()), "n2v_walk")
-    if stats is not None:  # device tensor; read after synchronising
+    if stats is not None:  # device tensors; read after synchronising
         stats["trials"] = status[2:4].view(torch.int64)
+        stats["status"] = status
     return walks, valid.bool() if out is None else valid
 
 
