@@ -254,6 +254,104 @@ __device__ __forceinline__ uint64_t wedge_mask_t(const void *base, int64_t off, 
   return mk;
 }
 
+// ---- the pairing loop for ONE slot of a row of any length, by one lane, when "other" is the
+// ONLY underfull class (return and shared slots overfull or absent: what p <= q, q > 1 gives on
+// every row that is not nearly a clique).  Every slot the loop absorbs from `underfull` then has
+// the same value vO -- or is the residual of the overfull slot demoted just before, which sits
+// on top of the stack -- so the fp64 sequence of :185 depends on how MANY slots an overfull
+// slot absorbs, not on which; which slot is absorbed k-th is its rank from the top among the
+// "other" slots.  The overfull slots are exactly the listed positions (wedge list + return run),
+// taken in descending order as list.pop() does.  O(return + shared) iterations, each absorbing
+// its run of equal values in closed form (absorb_skip): no pass over the row.
+// `list` = the shared positions, ascending; returns sampling_from_alias.
+template <typename P>
+__device__ __forceinline__ int lane_case_a(int n, int pick, double r2, double vR, double vM,
+                                           double vO, int nR, int rpos, int nM, const P *list,
+                                           bool pickR, bool pickM) {
+  const int nO = n - nR - nM;
+  int km = nM - 1, kr = nR - 1;  // next shared / return slot, descending
+  int rank = -1;                 // pick is the (rank + 1)-th "other" slot from the top
+  if (!pickR && !pickM) {
+    int lo = 0, hi = nM;  // entries of the list above pick
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((int)list[mid] <= pick)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    int above_r = rpos + nR - 1 - pick;
+    above_r = above_r < 0 ? 0 : (above_r > nR ? nR : above_r);
+    rank = (n - 1 - pick) - (nM - lo) - above_r;
+  }
+  int used = 0;  // "other" slots absorbed so far
+  bool have_carry = false;
+  int carry_i = 0, alias_pick = 0;
+  double carry_v = 0.0;
+  double p_pick = pick3(pickR, pickM, vR, vM, vO);
+  for (;;) {
+    if (!have_carry && used >= nO) break;  // underfull is empty (:182)
+    const int pm = km >= 0 ? (int)list[km] : -1;
+    const int pr = kr >= 0 ? rpos + kr : -1;
+    if (pm < 0 && pr < 0) break;  // overfull is empty (:182)
+    int oi;
+    double ov;
+    if (pm > pr) {
+      oi = pm;
+      ov = vM;
+      --km;
+    } else {
+      oi = pr;
+      ov = vR;
+      --kr;
+    }
+    if (have_carry) {  // the slot demoted last is on top of underfull
+      if (carry_i == pick) {  // alias[under] = over: pick is final
+        alias_pick = oi;
+        p_pick = carry_v;
+        break;
+      }
+      ov = ov + carry_v - 1.0;  // :185
+      have_carry = false;
+      if (ov < 1.0) {
+        if (oi == pick) p_pick = ov;
+        have_carry = true;
+        carry_i = oi;
+        carry_v = ov;
+        continue;
+      }
+    }
+    // `oi` absorbs "other" slots until it drops below 1, `pick` is next, or none is left
+    int limit = nO - used;
+    if (rank >= used && rank - used < limit) limit = rank - used;
+    int j = 0;
+    absorb_skip(ov, vO, j, limit);
+    bool demoted = false;
+    while (j < limit) {
+      ov = ov + vO - 1.0;  // :185
+      ++j;
+      if (ov < 1.0) {
+        demoted = true;
+        break;
+      }
+    }
+    used += j;
+    if (oi == pick) p_pick = ov;
+    if (demoted) {
+      have_carry = true;
+      carry_i = oi;
+      carry_v = ov;
+      continue;
+    }
+    if (rank >= 0 && used == rank && used < nO) {  // the next underfull slot is pick itself
+      alias_pick = oi;
+      p_pick = vO;
+    }
+    break;  // pick paired, or underfull exhausted with `oi` still >= 1
+  }
+  return (r2 < p_pick) ? pick : alias_pick;
+}
+
 __device__ __forceinline__ uint64_t wedge_mask(const void *base, int64_t off, int cnt, bool wide) {
   if (wide) return wedge_mask_t<uint32_t>(base, off, cnt);
   return wedge_mask_t<uint16_t>(base, off, cnt);
@@ -1594,6 +1692,17 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
                 Mm = Mm_list;
                 idx = lane_pairing(n, Rm, Mm, pick, r2, vR, vM, vO);
                 N2V_CHECK_RANGE(2, idx, 0, n);
+              } else if (have_w && uO && !(nR && uR) && !(nM && uM) && !(dbg & 8)) {
+                // a longer row whose only underfull class is "other": still this lane's work
+                if (w_wide)
+                  idx = lane_case_a<uint32_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM,
+                                              reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off,
+                                              isR, isM);
+                else
+                  idx = lane_case_a<uint16_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM,
+                                              reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off,
+                                              isR, isM);
+                N2V_CHECK_RANGE(6, idx, 0, n);
               } else {
                 unresolved = true;
                 w_nR = nR;
