@@ -113,6 +113,37 @@ __device__ __forceinline__ bool member_sorted_lane(const int32_t *a, int m, int3
   return lo < m && a[lo] == x;
 }
 
+// entry k of a wedge list.  The width (uint16 / uint32) is wave-uniform and every caller
+// branches on it OUTSIDE its loops, each side doing plain typed loads: written as one
+// `wide ? load32 : load16` expression the compiler turned the choice into a select of two
+// loads, and the 32-bit one of a 16-bit table reads up to twice as far as the table is long
+// (a memory fault once the table has its own allocation).
+template <typename P>
+__device__ __forceinline__ int wedge_at_t(const void *base, int64_t k) {
+  return (int)reinterpret_cast<const P *>(base)[k];
+}
+
+// is `pos` one of the (ascending) positions list[0, cnt)?  one lane
+template <typename P>
+__device__ __forceinline__ bool wedge_has_t(const void *base, int64_t off, int cnt, int pos) {
+  const P *a = reinterpret_cast<const P *>(base) + off;
+  int lo = 0, hi = cnt;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)a[mid] < pos)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  if (lo >= cnt) return false;
+  return (int)a[lo] == pos;
+}
+
+__device__ __forceinline__ bool wedge_has(const void *base, int64_t off, int cnt, int pos, bool wide) {
+  if (wide) return wedge_has_t<uint32_t>(base, off, cnt, pos);
+  return wedge_has_t<uint16_t>(base, off, cnt, pos);
+}
+
 __device__ inline int64_t wave_sum_i64(int64_t v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

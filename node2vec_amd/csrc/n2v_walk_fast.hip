@@ -97,6 +97,11 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
   const double beta_max = fmax(b_hi, inv_p);
   const bool biased = !(p == 1.0 && q == 1.0);
   const bool have_ec = kUnit && (kHops || g.edge_classes != nullptr);
+  // wedge table (n2v_wedge_build): "x in N(s)" for the candidate at position `pick` of N(v) is
+  // "pick is in the list of the edge (s -> v)": one offset gather + a search in a short list
+  const bool have_w = have_ec && g.wedge_off != nullptr && g.wedge_pos != nullptr;
+  const bool w_wide = g.wedge_wide != 0;
+  int64_t e_prev = 0;  // the edge (s -> v) walked last
   const bool fold_return = have_ec && inv_p > b_hi;
   const bool base_aligned = (reinterpret_cast<uintptr_t>(walks_out) & 63u) == 0;
 
@@ -216,9 +221,14 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
         if (u < b_lo) return true;
         if (!(u < b_hi)) return false;
         bool member = false;
-        if (q != 1.0 && shared != 0)
-          member = g.pivots ? member_pivoted_lane(g.col, g.pivots, sb, m, x)
-                            : member_sorted_lane(g.col + sb, m, x);
+        if (q != 1.0 && shared != 0) {
+          if (have_w && shared > 0)
+            member = wedge_has(g.wedge_pos, (int64_t)(g.wedge_off[e_prev] & N2V_WEDGE_OFF_MASK), shared,
+                               pick, w_wide);
+          else
+            member = g.pivots ? member_pivoted_lane(g.col, g.pivots, sb, m, x)
+                              : member_sorted_lane(g.col + sb, m, x);
+        }
         return u < (member ? 1.0 : inv_q);
       };
       if (rho >= 0.0) {  // return edge outside the envelope
@@ -243,6 +253,7 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
     }
     // ---- accepted: append, advance ------------------------------------------------
     emit(step + 1, x);
+    e_prev = e;
     s = v;
     sb = vb;
     m = n;

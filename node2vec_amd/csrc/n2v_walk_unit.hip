@@ -214,43 +214,19 @@ struct UnitStep {
   int w_nR = 0, w_nM = 0, w_rpos = 0;
 };
 
-// entry k of a wedge list.  The width (uint16 / uint32) is wave-uniform and every caller
-// branches on it OUTSIDE its loops, each side doing plain typed loads: written as one
-// `wide ? load32 : load16` expression the compiler turned the choice into a select of two
-// loads, and the 32-bit one of a 16-bit table reads up to twice as far as the table is long
-// (a memory fault once the table has its own allocation).
-template <typename P>
-__device__ __forceinline__ int wedge_at_t(const void *base, int64_t k) {
-  return (int)reinterpret_cast<const P *>(base)[k];
-}
-
-// is `pos` one of the (ascending) positions list[0, cnt)?  one lane
-template <typename P>
-__device__ __forceinline__ bool wedge_has_t(const void *base, int64_t off, int cnt, int pos) {
-  const P *a = reinterpret_cast<const P *>(base) + off;
-  int lo = 0, hi = cnt;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if ((int)a[mid] < pos)
-      lo = mid + 1;
-    else
-      hi = mid;
-  }
-  if (lo >= cnt) return false;
-  return (int)a[lo] == pos;
-}
-
-__device__ __forceinline__ bool wedge_has(const void *base, int64_t off, int cnt, int pos, bool wide) {
-  if (wide) return wedge_has_t<uint32_t>(base, off, cnt, pos);
-  return wedge_has_t<uint16_t>(base, off, cnt, pos);
-}
-
 // OR of 1 << list[k] for k < cnt (a row of at most 64 neighbours); one lane
 template <typename P>
 __device__ __forceinline__ uint64_t wedge_mask_t(const void *base, int64_t off, int cnt) {
   const P *a = reinterpret_cast<const P *>(base) + off;
   uint64_t mk = 0ull;
-  for (int k = 0; k < cnt; ++k) mk |= 1ull << ((int)a[k] & 63);
+  for (int k = 0; k < cnt; k += 8) {  // eight independent loads per round trip
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (k + u < cnt) ? (int)a[k + u] : 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k + u < cnt) mk |= 1ull << (v[u] & 63);
+  }
   return mk;
 }
 
@@ -264,10 +240,27 @@ __device__ __forceinline__ uint64_t wedge_mask_t(const void *base, int64_t off, 
 // taken in descending order as list.pop() does.  O(return + shared) iterations, each absorbing
 // its run of equal values in closed form (absorb_skip): no pass over the row.
 // `list` = the shared positions, ascending; returns sampling_from_alias.
+// The list is consumed from its end, one entry per iteration; read straight from memory that
+// is one dependent round trip per iteration (the kernel was latency-bound on it), so the lane
+// stages kStage entries at a time in its own LDS column (`stage`: [kStage][64] entries of this
+// wave, idle outside the wave fallback): kStage independent loads per round trip.
 template <typename P>
 __device__ __forceinline__ int lane_case_a(int n, int pick, double r2, double vR, double vM,
                                            double vO, int nR, int rpos, int nM, const P *list,
-                                           bool pickR, bool pickM) {
+                                           bool pickR, bool pickM, P *stage, int lane) {
+  constexpr int kStage = sizeof(P) == 2 ? 16 : 8;
+  int st_hi = -1;  // stage slot u holds list[st_hi - u]; nothing staged yet
+  auto list_at = [&](int k) -> int {
+    if (st_hi < 0 || k > st_hi || k < st_hi - (kStage - 1)) {
+      st_hi = k;
+      P v[kStage];
+#pragma unroll
+      for (int u = 0; u < kStage; ++u) v[u] = (k - u >= 0) ? list[k - u] : (P)0;
+#pragma unroll
+      for (int u = 0; u < kStage; ++u) stage[u * 64 + lane] = v[u];
+    }
+    return (int)stage[(st_hi - k) * 64 + lane];
+  };
   const int nO = n - nR - nM;
   int km = nM - 1, kr = nR - 1;  // next shared / return slot, descending
   int rank = -1;                 // pick is the (rank + 1)-th "other" slot from the top
@@ -291,7 +284,7 @@ __device__ __forceinline__ int lane_case_a(int n, int pick, double r2, double vR
   double p_pick = pick3(pickR, pickM, vR, vM, vO);
   for (;;) {
     if (!have_carry && used >= nO) break;  // underfull is empty (:182)
-    const int pm = km >= 0 ? (int)list[km] : -1;
+    const int pm = km >= 0 ? list_at(km) : -1;
     const int pr = kr >= 0 ? rpos + kr : -1;
     if (pm < 0 && pr < 0) break;  // overfull is empty (:182)
     int oi;
@@ -1697,11 +1690,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
                 if (w_wide)
                   idx = lane_case_a<uint32_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM,
                                               reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off,
-                                              isR, isM);
+                                              isR, isM, reinterpret_cast<uint32_t *>(L.cls), lane);
                 else
                   idx = lane_case_a<uint16_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM,
                                               reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off,
-                                              isR, isM);
+                                              isR, isM, reinterpret_cast<uint16_t *>(L.cls), lane);
                 N2V_CHECK_RANGE(6, idx, 0, n);
               } else {
                 unresolved = true;

@@ -175,7 +175,8 @@ def test_hop_table_and_class_counts_change_no_bit(oracle, pq):
     assert not bool(av.all())  # some walkers did vanish at sinks
     fa, fav = rw.walk(g, start, 3, 25, p, q, 9, mode="fast")
     fb, fbv = rw.walk(g, start, 3, 25, p, q, 9, mode="fast", use_hops=False)
-    assert torch.equal(fa, fb) and torch.equal(fav, fbv)
+    fc, fcv = rw.walk(g, start, 3, 25, p, q, 9, mode="fast", use_wedges=False)
+    assert torch.equal(fa, fb) and torch.equal(fav, fbv) and torch.equal(fa, fc) and torch.equal(fav, fcv)
 
 
 def test_hop_table_is_refused_for_rows_it_cannot_pack():
