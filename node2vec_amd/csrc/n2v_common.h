@@ -139,6 +139,30 @@ __device__ __forceinline__ bool wedge_has_t(const void *base, int64_t off, int c
   return (int)a[lo] == pos;
 }
 
+// number of entries of list[0, cnt) below `pos` (its lower bound); found = pos is in the list
+template <typename P>
+__device__ __forceinline__ int wedge_lower_t(const void *base, int64_t off, int cnt, int pos,
+                                             bool &found) {
+  const P *a = reinterpret_cast<const P *>(base) + off;
+  int lo = 0, hi = cnt;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)a[mid] < pos)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  found = false;
+  if (lo < cnt) found = (int)a[lo] == pos;
+  return lo;
+}
+
+__device__ __forceinline__ int wedge_lower(const void *base, int64_t off, int cnt, int pos, bool wide,
+                                           bool &found) {
+  if (wide) return wedge_lower_t<uint32_t>(base, off, cnt, pos, found);
+  return wedge_lower_t<uint16_t>(base, off, cnt, pos, found);
+}
+
 __device__ __forceinline__ bool wedge_has(const void *base, int64_t off, int cnt, int pos, bool wide) {
   if (wide) return wedge_has_t<uint32_t>(base, off, cnt, pos);
   return wedge_has_t<uint16_t>(base, off, cnt, pos);

@@ -101,6 +101,7 @@ __device__ __forceinline__ void member_lds_x4(const uint32_t *ys, int m, const i
 struct UnitConsts {
   double bR, bM, bO;     // 1/p, 1, 1/q
   int64_t TR, TM, TO;    // the same times 2^20 (exact integers; dyadic kernel only)
+  int64_t gR, gM, gO;    // TR, TM, TO divided by their greatest common divisor
 };
 
 // ---- the reference's row sum when 1/p or 1/q is not dyadic ------------------------------
@@ -343,6 +344,92 @@ __device__ __forceinline__ int lane_case_a(int n, int pick, double r2, double vR
     break;  // pick paired, or underfull exhausted with `oi` still >= 1
   }
   return (r2 < p_pick) ? pick : alias_pick;
+}
+
+// ---- the same draw in closed form ---------------------------------------------------------
+// In exact arithmetic the loop of :182-189 under the "other is the only underfull class"
+// arrangement is a bucket process.  Scale every value by isum / n (the dyadic class values are
+// integers gR, gM, gO then, and 1.0 is isum = nR gR + nM gM + nO gO): an overfull slot brings the
+// excess E = g n - isum, an absorbed "other" slot removes D = isum - gO n, a demoted slot carries
+// its (negative) rest to its successor.  So after the first i overfull slots (descending
+// position) X_i = sum of their excesses has been offered and floor(X_i / D) + 1 "other" slots
+// have been absorbed: the slot of rank r (from the top) is absorbed by the first i with
+// X_i >= r D, and overfull slot i is demoted at 1 + (X_i - (floor(X_i / D) + 1) D) / isum and
+// paired with slot i + 1.  X_i is piecewise linear in i (shared slots above the return run,
+// the return run, shared slots below), so i is an integer division -- no loop at all.
+// The reference computes in fp64, one rounding per operation; its decisions can differ from the
+// exact ones only where an exact quantity is 0 (a tie) or within the accumulated rounding
+// (< 4 n 1e-15) of the decision point, and nonzero exact quantities are >= 1 / isum apart.  Ties,
+// rows where that margin does not hold, and a final comparison too close to r2 return -1: the
+// caller then replays the loop step by step (lane_pairing / lane_case_a).  Checked against the
+// reference loop in Python (0 mismatches in 85 k short and 1 k long rows, 5-20 % returned -1).
+template <typename P>
+__device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, const UnitConsts &K,
+                                                int nR, int rpos, int nM, const P *list,
+                                                bool pickR, bool pickM, int lo_pick) {
+  const int nO = n - nR - nM;
+  const int64_t isum = (int64_t)nR * K.gR + (int64_t)nM * K.gM + (int64_t)nO * K.gO;
+  const int64_t EM = K.gM * n - isum, ER = K.gR * n - isum, D = isum - K.gO * n;
+  if (D <= 0 || (nM > 0 && EM <= 0) || (nR > 0 && ER <= 0)) return -1;
+  const double big = (double)(K.gR > K.gM ? K.gR : K.gM);
+  if ((double)n * (double)isum > 2.0e14 || (double)n * (double)n * big > 4.0e18) return -1;
+  int mA = nM;  // shared slots above the return run come first in descending order
+  if (nR > 0 && nM > 0) {
+    int lo = 0, hi = nM;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((int)list[mid] < rpos)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    mA = nM - lo;
+  }
+  const int N = nM + nR;
+  auto X_of = [&](int64_t i) -> int64_t {
+    if (i <= mA) return i * EM;
+    if (i <= mA + nR) return (int64_t)mA * EM + (i - mA) * ER;
+    return (int64_t)mA * EM + (int64_t)nR * ER + (i - mA - nR) * EM;
+  };
+  auto pos_of = [&](int i) -> int {  // position of the i-th overfull slot, i = 1 .. N
+    if (i <= mA) return (int)list[nM - i];
+    if (i <= mA + nR) return rpos + nR - (i - mA);
+    return (int)list[nM - (i - nR)];
+  };
+  if (!pickR && !pickM) {
+    int above_r = rpos + nR - 1 - pick;
+    above_r = above_r < 0 ? 0 : (above_r > nR ? nR : above_r);
+    const int64_t r = (int64_t)(n - 1 - pick) - (nM - lo_pick) - above_r;
+    const int64_t T = r * D;
+    int64_t i;
+    if (T <= 0) {
+      i = 1;
+    } else if (mA > 0 && (int64_t)mA * EM >= T) {
+      i = (T + EM - 1) / EM;
+    } else {
+      const int64_t X1 = (int64_t)mA * EM;
+      if (nR > 0 && X1 + (int64_t)nR * ER >= T)
+        i = mA + (T - X1 + ER - 1) / ER;
+      else
+        i = mA + nR + (T - X1 - (int64_t)nR * ER + EM - 1) / EM;
+    }
+    if (i < 1 || i > N || X_of(i) == T) return -1;  // a tie: fp64 rounding decides
+    return pos_of((int)i);  // r2 >= probs[pick] here: the caller's quick exit took the other case
+  }
+  int64_t i0;
+  if (pickR) {
+    i0 = mA + (nR - (pick - rpos));
+  } else {
+    const int d = nM - lo_pick;  // pick is the d-th shared slot from the top
+    i0 = d <= mA ? d : d + nR;
+  }
+  if (i0 < 1 || i0 >= N) return -1;  // the last overfull slot ends at exactly 1.0: fp64 decides
+  const int64_t X = X_of(i0);
+  if (X % D == 0) return -1;
+  const int64_t rem = X - (X / D + 1) * D;  // in (-D, 0)
+  const double prob = 1.0 + (double)rem / (double)isum;
+  if (fabs(prob - r2) < 1e-9) return -1;
+  return (r2 < prob) ? pick : pos_of((int)i0 + 1);
 }
 
 __device__ __forceinline__ uint64_t wedge_mask(const void *base, int64_t off, int cnt, bool wide) {
@@ -1642,16 +1729,30 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
         u2 = (uint32_t)bits;
         const int pick = pick_index(u1, n);
         idx = pick;
+        // the class counts of this step's table are known before any load (they came with the
+        // hop that walked the edge), so the offset of the edge's wedge list is requested FIRST and
+        // travels together with the hop gather: two independent loads, one latency
+        const bool step_biased = s >= 0 && biased;
+        uint32_t fR = 0, fM = 0;
+        if (step_biased) {
+          const uint32_t ec = kHops ? ec_prev : g.edge_classes[e_prev];
+          fR = ec >> N2V_EC_RETURN_SHIFT;
+          fM = ec & N2V_EC_SHARED_MASK;
+        }
+        const bool counts_ok = step_biased && fR != N2V_EC_RETURN_SAT && fM != N2V_EC_SHARED_MASK;
+        uint64_t wraw = 0;
+        if (have_w && counts_ok && ((need_mem && fM > 0) || fR > 0)) {
+          N2V_CHECK_RANGE(3, e_prev, (int64_t)0, g.n_edges);
+          wraw = g.wedge_off[e_prev];  // list offset | return position << 40
+        }
         if (kHops) {
           h = load_hop(g.hops + vb + pick);
           x = h.col;
         } else {
           x = g.col[vb + pick];
         }
-        if (s >= 0 && biased) {
-          const uint32_t ec = kHops ? ec_prev : g.edge_classes[e_prev];
-          const uint32_t fR = ec >> N2V_EC_RETURN_SHIFT, fM = ec & N2V_EC_SHARED_MASK;
-          if (fR == N2V_EC_RETURN_SAT || fM == N2V_EC_SHARED_MASK) {
+        if (step_biased) {
+          if (!counts_ok) {
             unresolved = true;  // a count that did not fit: classify the row
           } else {
             const int nR = (int)fR, nM = need_mem ? (int)fM : 0, nO = n - nR - nM;
@@ -1659,15 +1760,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
             const double avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;  // :172
             const bool isR = x == s;
             bool isM = false;
-            N2V_CHECK_RANGE(3, e_prev, (int64_t)0, g.n_edges);
-            if (have_w && (nM > 0 || nR > 0)) {  // this edge's list: offset | return position << 40
-              const uint64_t wraw = g.wedge_off[e_prev];
-              w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
-              w_rpos = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
+            w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
+            w_rpos = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
+            int lo_pick = 0;  // entries of the edge's list below `pick`
+            if (need_mem && !isR && nM > 0) {  // :226
+              if (have_w && !(dbg & 4))
+                lo_pick = wedge_lower(g.wedge_pos, w_off, nM, pick, w_wide, isM);
+              else
+                isM = member_sorted_lane(g.col + sb, m, x);
             }
-            if (need_mem && !isR && nM > 0)  // :226
-              isM = (have_w && !(dbg & 4)) ? wedge_has(g.wedge_pos, w_off, nM, pick, w_wide)
-                                           : member_sorted_lane(g.col + sb, m, x);
             const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) / avg;      // :173
             const double r2 = (double)u2 * (1.0 / 4294967296.0);
             if (!(p_pick < 1.0 && r2 < p_pick)) {
@@ -1675,8 +1776,24 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
               const bool uR = vR < 1.0, uM = vM < 1.0, uO = vO < 1.0;
               const bool any_under = (nR && uR) || (nM && uM) || (nO && uO);
               const bool any_over = (nR && !uR) || (nM && !uM) || (nO && !uO);
+              int jres = -1;
+              if (any_under && any_over && have_w && uO && !(nR && uR) && !(nM && uM) &&
+                  !(dbg & (16 | 4))) {
+                // plain branches on the (uniform) list width: never a select between two loads
+                if (w_wide)
+                  jres = lane_case_a_jump<uint32_t>(
+                      n, pick, r2, K, nR, w_rpos, nM,
+                      reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off, isR, isM, lo_pick);
+                else
+                  jres = lane_case_a_jump<uint16_t>(
+                      n, pick, r2, K, nR, w_rpos, nM,
+                      reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off, isR, isM, lo_pick);
+              }
               if (!any_under || !any_over) {  // the loop of :182 never runs
                 if (!(r2 < p_pick)) idx = 0;
+              } else if (jres >= 0) {
+                idx = jres;  // closed form: no loop at all
+                N2V_CHECK_RANGE(7, idx, 0, n);
               } else if (have_w && n <= 64 && !(dbg & 1)) {
                 // a short row: this lane replays the pairing itself from the two class masks
                 uint64_t Rm = 0ull, Mm = 0ull;
@@ -1838,6 +1955,20 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
   // added up in the reference's order, run by run (needs ordinary magnitudes)
   const bool dyadic = scales_exactly(K.bR, &K.TR) && scales_exactly(K.bM, &K.TM) &&
                       scales_exactly(K.bO, &K.TO) && K.TR != 0 && K.TO != 0;
+  K.gR = K.TR;
+  K.gM = K.TM;
+  K.gO = K.TO;
+  if (dyadic) {
+    int64_t a = K.TR, b = K.TM;
+    while (b) { const int64_t t = a % b; a = b; b = t; }
+    b = K.TO;
+    while (b) { const int64_t t = a % b; a = b; b = t; }
+    if (a > 0) {
+      K.gR = K.TR / a;
+      K.gM = K.TM / a;
+      K.gO = K.TO / a;
+    }
+  }
   const bool ordinary = K.bR >= 0x1p-20 && K.bR <= 0x1p20 && K.bO >= 0x1p-20 && K.bO <= 0x1p20;
   if (!dyadic && !ordinary) return 0;
   const int64_t total = n_start * (int64_t)num_walks;
