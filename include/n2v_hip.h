@@ -101,7 +101,7 @@ typedef struct n2v_graph {
   const uint64_t *wedge_off;    /* [n_edges] or NULL: see n2v_wedge_build */
   const void *wedge_pos;        /* uint16 / uint32 positions, or NULL */
   int32_t wedge_wide;           /* 0: wedge_pos is uint16 (every degree < 65536), 1: uint32 */
-  int32_t reserved;
+  int32_t reserved;             /* 0 (bit 0 set: do not use the all-tables kernel; diagnostics) */
 } n2v_graph;
 
 /* edge_classes[e] for e = (s -> v): bits 0..23 = number of entries x of N(v) with

@@ -23,23 +23,9 @@
 // (reverse / staged / filter / merge / direct, see unit_draw).  One wave64 per walker;
 // waves take walkers from a shared counter (status[1]), because walks differ widely in cost.
 #include "n2v_alias_core.h"
+#include "n2v_unit_core.h"
 
 namespace n2v {
-
-// diagnostic build only (-DN2V_CHECK): out-of-range values are recorded in status[0] (bits 8..)
-// and clamped instead of being used as addresses
-#ifdef N2V_CHECK
-static __device__ uint32_t *n2v_check_status;
-#define N2V_CHECK_RANGE(code, val, lo_, hi_)                                  \
-  do {                                                                         \
-    if ((val) < (lo_) || (val) >= (hi_)) {                                     \
-      atomicOr(n2v_check_status, 1u << (8 + (code)));                          \
-      (val) = (lo_);                                                           \
-    }                                                                          \
-  } while (0)
-#else
-#define N2V_CHECK_RANGE(code, val, lo_, hi_) do { } while (0)
-#endif
 
 constexpr int kUC = 128;     // class ballots cached for the TOP 128 chunks (8192 neighbours)
 constexpr int kYsCap = 384;   // N(s) staged in LDS when it has at most this many ids
@@ -58,11 +44,6 @@ struct UnitLds {
   int32_t mlist[kMaybeU];    // filter hits waiting for verification
   uint32_t pool[kYsCap];     // staged N(s)  |  large filter
 };
-
-template <typename T>
-__device__ __forceinline__ T pick3(bool first, bool second, T a, T b, T c) {
-  return first ? a : (second ? b : c);
-}
 
 // binary search over ids staged in LDS (no global gathers on the dependent chain)
 __device__ __forceinline__ bool member_lds(const uint32_t *ys, int m, int32_t x, int iters) {
@@ -98,12 +79,6 @@ __device__ __forceinline__ void member_lds_x4(const uint32_t *ys, int m, const i
     found[u] = found[u] | ((int32_t)ys[lo[u] < m ? lo[u] : m - 1] == x[u] && lo[u] < m);
 }
 
-struct UnitConsts {
-  double bR, bM, bO;     // 1/p, 1, 1/q
-  int64_t TR, TM, TO;    // the same times 2^20 (exact integers; dyadic kernel only)
-  int64_t gR, gM, gO;    // TR, TM, TO divided by their greatest common divisor
-};
-
 // ---- the reference's row sum when 1/p or 1/q is not dyadic ------------------------------
 // sum(node_weights) (:172) adds left to right in fp64, so with values that are not
 // multiples of 2^-20 the result depends on the order of the classes.  A row is a few
@@ -114,10 +89,6 @@ struct UnitConsts {
 // even neighbour: after one addition s is an even multiple of ulp and from then on the
 // step is constant again.)  So: per binade, one real addition to measure the step, an
 // exact multiply for all additions that stay below 2^(e+1), one real addition to cross.
-__device__ __forceinline__ int biased_exp(double x) {
-  return (int)((__double_as_longlong(x) >> 52) & 0x7ff);
-}
-
 __device__ __forceinline__ double rep_add(double s, double c, int k) {
   const uint64_t c_man =
       ((uint64_t)__double_as_longlong(c) & 0x000fffffffffffffull) | 0x0010000000000000ull;
@@ -159,50 +130,6 @@ __device__ __forceinline__ double rep_add(double s, double c, int k) {
   return s;
 }
 
-// ---- absorbing a long run of equal under values in O(1) per binade ----------------------
-// The inner statement of the pairing, probs[over] = probs[over] + probs[under] - 1.0 (:186),
-// applied to a run of slots with the same value v < 1: r' = fl(r + v) - 1.0.  The subtraction
-// is always exact (t = fl(r + v) >= 2 while the over is not demoted, and t - 1 is a multiple of
-// ulp(t) below 2 t), so the only rounding is that of r + v, and while t stays inside one
-// binade [2^e, 2^(e+1)) it is the same at every step: r is a multiple of u = ulp(t) (it is a
-// previous t minus 1), v = k u + f, and fl rounds f the same way each time -- a tie f == u/2
-// goes to the even neighbour, after which t and r are even multiples of u and the choice is
-// constant as well.  So after three real steps inside one binade (the first brings r onto the
-// grid, the second may be the tie, the third measures the decrement d = r2 - r3, exact) the
-// next n steps are r - n d exactly, for every n that keeps t strictly above 2^e (below the
-// edge the grid is finer and the argument ends).  Demotion (r < 1) is t < 2, the lower edge of
-// binade 1, so it is never skipped: the caller's step-by-step loop finds it.
-// Advances (r, j) by real steps and exact jumps, never past `limit` slots and never past a
-// demotion; what is left is finished by the caller's loop.
-__device__ __forceinline__ void absorb_skip(double &r, double val, int &j, int limit) {
-  while (j + 3 < limit) {
-    const double t1 = r + val, r1 = t1 - 1.0;
-    const double t2 = r1 + val, r2 = t2 - 1.0;
-    const double t3 = r2 + val, r3 = t3 - 1.0;
-    if (r3 < 1.0) return;  // demoted within three steps: the exact loop takes over
-    const int e1 = biased_exp(t1), e3 = biased_exp(t3);
-    j += 3;
-    r = r3;
-    if (e1 != e3) continue;  // crossed into a lower binade: measure again there
-    const double edge = __longlong_as_double((long long)e3 << 52);  // 2^e
-    const double d = r2 - r3;  // exact
-    const int room = limit - j;
-    if (d == 0.0) {  // val vanishes against r: every remaining slot is absorbed unchanged
-      j += room;
-      return;
-    }
-    if (!(t3 > edge)) continue;
-    double nn = floor((t3 - edge) / d) - 1.0;
-    nn = fmin(nn, (double)room);
-    while (nn >= 1.0 && !(t3 - nn * d > edge)) nn -= 1.0;  // exact products: stay above the edge
-    if (nn >= 1.0) {
-      r = r3 - nn * d;  // exact: a multiple of ulp(t) inside the binade
-      j += (int)nn;
-    }
-    if (nn < 4.0) return;  // at the edge of the binade: let the exact loop cross it
-  }
-}
-
 struct UnitStep {
   const int32_t *vcol, *scol;
   int n, nch, m, iters;
@@ -214,292 +141,6 @@ struct UnitStep {
   const void *w_pos = nullptr;
   int w_nR = 0, w_nM = 0, w_rpos = 0;
 };
-
-// OR of 1 << list[k] for k < cnt (a row of at most 64 neighbours); one lane
-template <typename P>
-__device__ __forceinline__ uint64_t wedge_mask_t(const void *base, int64_t off, int cnt) {
-  const P *a = reinterpret_cast<const P *>(base) + off;
-  uint64_t mk = 0ull;
-  for (int k = 0; k < cnt; k += 8) {  // eight independent loads per round trip
-    int v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = (k + u < cnt) ? (int)a[k + u] : 0;
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (k + u < cnt) mk |= 1ull << (v[u] & 63);
-  }
-  return mk;
-}
-
-// ---- the pairing loop for ONE slot of a row of any length, by one lane, when "other" is the
-// ONLY underfull class (return and shared slots overfull or absent: what p <= q, q > 1 gives on
-// every row that is not nearly a clique).  Every slot the loop absorbs from `underfull` then has
-// the same value vO -- or is the residual of the overfull slot demoted just before, which sits
-// on top of the stack -- so the fp64 sequence of :185 depends on how MANY slots an overfull
-// slot absorbs, not on which; which slot is absorbed k-th is its rank from the top among the
-// "other" slots.  The overfull slots are exactly the listed positions (wedge list + return run),
-// taken in descending order as list.pop() does.  O(return + shared) iterations, each absorbing
-// its run of equal values in closed form (absorb_skip): no pass over the row.
-// `list` = the shared positions, ascending; returns sampling_from_alias.
-// The list is consumed from its end, one entry per iteration; read straight from memory that
-// is one dependent round trip per iteration (the kernel was latency-bound on it), so the lane
-// stages kStage entries at a time in its own LDS column (`stage`: [kStage][64] entries of this
-// wave, idle outside the wave fallback): kStage independent loads per round trip.
-template <typename P>
-__device__ __forceinline__ int lane_case_a(int n, int pick, double r2, double vR, double vM,
-                                           double vO, int nR, int rpos, int nM, const P *list,
-                                           bool pickR, bool pickM, P *stage, int lane) {
-  constexpr int kStage = sizeof(P) == 2 ? 16 : 8;
-  int st_hi = -1;  // stage slot u holds list[st_hi - u]; nothing staged yet
-  auto list_at = [&](int k) -> int {
-    if (st_hi < 0 || k > st_hi || k < st_hi - (kStage - 1)) {
-      st_hi = k;
-      P v[kStage];
-#pragma unroll
-      for (int u = 0; u < kStage; ++u) v[u] = (k - u >= 0) ? list[k - u] : (P)0;
-#pragma unroll
-      for (int u = 0; u < kStage; ++u) stage[u * 64 + lane] = v[u];
-    }
-    return (int)stage[(st_hi - k) * 64 + lane];
-  };
-  const int nO = n - nR - nM;
-  int km = nM - 1, kr = nR - 1;  // next shared / return slot, descending
-  int rank = -1;                 // pick is the (rank + 1)-th "other" slot from the top
-  if (!pickR && !pickM) {
-    int lo = 0, hi = nM;  // entries of the list above pick
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if ((int)list[mid] <= pick)
-        lo = mid + 1;
-      else
-        hi = mid;
-    }
-    int above_r = rpos + nR - 1 - pick;
-    above_r = above_r < 0 ? 0 : (above_r > nR ? nR : above_r);
-    rank = (n - 1 - pick) - (nM - lo) - above_r;
-  }
-  int used = 0;  // "other" slots absorbed so far
-  bool have_carry = false;
-  int carry_i = 0, alias_pick = 0;
-  double carry_v = 0.0;
-  double p_pick = pick3(pickR, pickM, vR, vM, vO);
-  for (;;) {
-    if (!have_carry && used >= nO) break;  // underfull is empty (:182)
-    const int pm = km >= 0 ? list_at(km) : -1;
-    const int pr = kr >= 0 ? rpos + kr : -1;
-    if (pm < 0 && pr < 0) break;  // overfull is empty (:182)
-    int oi;
-    double ov;
-    if (pm > pr) {
-      oi = pm;
-      ov = vM;
-      --km;
-    } else {
-      oi = pr;
-      ov = vR;
-      --kr;
-    }
-    if (have_carry) {  // the slot demoted last is on top of underfull
-      if (carry_i == pick) {  // alias[under] = over: pick is final
-        alias_pick = oi;
-        p_pick = carry_v;
-        break;
-      }
-      ov = ov + carry_v - 1.0;  // :185
-      have_carry = false;
-      if (ov < 1.0) {
-        if (oi == pick) p_pick = ov;
-        have_carry = true;
-        carry_i = oi;
-        carry_v = ov;
-        continue;
-      }
-    }
-    // `oi` absorbs "other" slots until it drops below 1, `pick` is next, or none is left
-    int limit = nO - used;
-    if (rank >= used && rank - used < limit) limit = rank - used;
-    int j = 0;
-    absorb_skip(ov, vO, j, limit);
-    bool demoted = false;
-    while (j < limit) {
-      ov = ov + vO - 1.0;  // :185
-      ++j;
-      if (ov < 1.0) {
-        demoted = true;
-        break;
-      }
-    }
-    used += j;
-    if (oi == pick) p_pick = ov;
-    if (demoted) {
-      have_carry = true;
-      carry_i = oi;
-      carry_v = ov;
-      continue;
-    }
-    if (rank >= 0 && used == rank && used < nO) {  // the next underfull slot is pick itself
-      alias_pick = oi;
-      p_pick = vO;
-    }
-    break;  // pick paired, or underfull exhausted with `oi` still >= 1
-  }
-  return (r2 < p_pick) ? pick : alias_pick;
-}
-
-// ---- the same draw in closed form ---------------------------------------------------------
-// In exact arithmetic the loop of :182-189 under the "other is the only underfull class"
-// arrangement is a bucket process.  Scale every value by isum / n (the dyadic class values are
-// integers gR, gM, gO then, and 1.0 is isum = nR gR + nM gM + nO gO): an overfull slot brings the
-// excess E = g n - isum, an absorbed "other" slot removes D = isum - gO n, a demoted slot carries
-// its (negative) rest to its successor.  So after the first i overfull slots (descending
-// position) X_i = sum of their excesses has been offered and floor(X_i / D) + 1 "other" slots
-// have been absorbed: the slot of rank r (from the top) is absorbed by the first i with
-// X_i >= r D, and overfull slot i is demoted at 1 + (X_i - (floor(X_i / D) + 1) D) / isum and
-// paired with slot i + 1.  X_i is piecewise linear in i (shared slots above the return run,
-// the return run, shared slots below), so i is an integer division -- no loop at all.
-// The reference computes in fp64, one rounding per operation; its decisions can differ from the
-// exact ones only where an exact quantity is 0 (a tie) or within the accumulated rounding
-// (< 4 n 1e-15) of the decision point, and nonzero exact quantities are >= 1 / isum apart.  Ties,
-// rows where that margin does not hold, and a final comparison too close to r2 return -1: the
-// caller then replays the loop step by step (lane_pairing / lane_case_a).  Checked against the
-// reference loop in Python (0 mismatches in 85 k short and 1 k long rows, 5-20 % returned -1).
-template <typename P>
-__device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, const UnitConsts &K,
-                                                int nR, int rpos, int nM, const P *list,
-                                                bool pickR, bool pickM, int lo_pick) {
-  const int nO = n - nR - nM;
-  const int64_t isum = (int64_t)nR * K.gR + (int64_t)nM * K.gM + (int64_t)nO * K.gO;
-  const int64_t EM = K.gM * n - isum, ER = K.gR * n - isum, D = isum - K.gO * n;
-  if (D <= 0 || (nM > 0 && EM <= 0) || (nR > 0 && ER <= 0)) return -1;
-  const double big = (double)(K.gR > K.gM ? K.gR : K.gM);
-  if ((double)n * (double)isum > 2.0e14 || (double)n * (double)n * big > 4.0e18) return -1;
-  int mA = nM;  // shared slots above the return run come first in descending order
-  if (nR > 0 && nM > 0) {
-    int lo = 0, hi = nM;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if ((int)list[mid] < rpos)
-        lo = mid + 1;
-      else
-        hi = mid;
-    }
-    mA = nM - lo;
-  }
-  const int N = nM + nR;
-  auto X_of = [&](int64_t i) -> int64_t {
-    if (i <= mA) return i * EM;
-    if (i <= mA + nR) return (int64_t)mA * EM + (i - mA) * ER;
-    return (int64_t)mA * EM + (int64_t)nR * ER + (i - mA - nR) * EM;
-  };
-  auto pos_of = [&](int i) -> int {  // position of the i-th overfull slot, i = 1 .. N
-    if (i <= mA) return (int)list[nM - i];
-    if (i <= mA + nR) return rpos + nR - (i - mA);
-    return (int)list[nM - (i - nR)];
-  };
-  if (!pickR && !pickM) {
-    int above_r = rpos + nR - 1 - pick;
-    above_r = above_r < 0 ? 0 : (above_r > nR ? nR : above_r);
-    const int64_t r = (int64_t)(n - 1 - pick) - (nM - lo_pick) - above_r;
-    const int64_t T = r * D;
-    int64_t i;
-    if (T <= 0) {
-      i = 1;
-    } else if (mA > 0 && (int64_t)mA * EM >= T) {
-      i = (T + EM - 1) / EM;
-    } else {
-      const int64_t X1 = (int64_t)mA * EM;
-      if (nR > 0 && X1 + (int64_t)nR * ER >= T)
-        i = mA + (T - X1 + ER - 1) / ER;
-      else
-        i = mA + nR + (T - X1 - (int64_t)nR * ER + EM - 1) / EM;
-    }
-    if (i < 1 || i > N || X_of(i) == T) return -1;  // a tie: fp64 rounding decides
-    return pos_of((int)i);  // r2 >= probs[pick] here: the caller's quick exit took the other case
-  }
-  int64_t i0;
-  if (pickR) {
-    i0 = mA + (nR - (pick - rpos));
-  } else {
-    const int d = nM - lo_pick;  // pick is the d-th shared slot from the top
-    i0 = d <= mA ? d : d + nR;
-  }
-  if (i0 < 1 || i0 >= N) return -1;  // the last overfull slot ends at exactly 1.0: fp64 decides
-  const int64_t X = X_of(i0);
-  if (X % D == 0) return -1;
-  const int64_t rem = X - (X / D + 1) * D;  // in (-D, 0)
-  const double prob = 1.0 + (double)rem / (double)isum;
-  if (fabs(prob - r2) < 1e-9) return -1;
-  return (r2 < prob) ? pick : pos_of((int)i0 + 1);
-}
-
-__device__ __forceinline__ uint64_t wedge_mask(const void *base, int64_t off, int cnt, bool wide) {
-  if (wide) return wedge_mask_t<uint32_t>(base, off, cnt);
-  return wedge_mask_t<uint16_t>(base, off, cnt);
-}
-
-// ---- the pairing loop of generate_alias_tables (randomwalk.py:175-189) for ONE slot of a row
-// of at most 64 neighbours, by one lane: the two stacks are bit masks (popped from the highest
-// index, as list.pop() does on ascending lists), a demoted overfull slot is the next underfull
-// one, an overfull slot that stays >= 1 is the next overfull one.  Slot values are the three
-// class values; only probs[pick] and alias[pick] are tracked, and the loop stops when `pick`
-// has been paired as an underfull slot (it never changes afterwards).  Returns
-// sampling_from_alias: pick if r2 < probs[pick] else alias[pick].
-__device__ __forceinline__ int lane_pairing(int n, uint64_t Rm, uint64_t Mm, int pick, double r2,
-                                            double vR, double vM, double vO) {
-  const uint64_t valid = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
-  Rm &= valid;
-  Mm &= valid & ~Rm;
-  const uint64_t Om = valid & ~(Rm | Mm);
-  uint64_t under = ((vR < 1.0) ? Rm : 0ull) | ((vM < 1.0) ? Mm : 0ull) | ((vO < 1.0) ? Om : 0ull);
-  uint64_t over = valid & ~under;
-  auto val0 = [&](int i) -> double {
-    return pick3(((Rm >> i) & 1ull) != 0, ((Mm >> i) & 1ull) != 0, vR, vM, vO);
-  };
-  double p_pick = val0(pick);
-  int alias_pick = 0;
-  bool have_carry = false, have_cur = false;
-  int carry_i = 0, cur_i = 0;
-  double carry_v = 0.0, cur_v = 0.0;
-  while ((have_carry || under != 0ull) && (have_cur || over != 0ull)) {  // :182
-    int ui, oi;
-    double uv, ov;
-    if (have_carry) {
-      ui = carry_i;
-      uv = carry_v;
-      have_carry = false;
-    } else {
-      ui = 63 - __clzll((long long)under);
-      under &= ~(1ull << ui);
-      uv = val0(ui);
-    }
-    if (have_cur) {
-      oi = cur_i;
-      ov = cur_v;
-      have_cur = false;
-    } else {
-      oi = 63 - __clzll((long long)over);
-      over &= ~(1ull << oi);
-      ov = val0(oi);
-    }
-    if (ui == pick) {  // alias[under] = over (:184); probs[under] is final
-      alias_pick = oi;
-      p_pick = uv;
-      break;
-    }
-    ov = ov + uv - 1.0;  // :185, two roundings
-    if (oi == pick) p_pick = ov;
-    if (ov < 1.0) {  // :186-189
-      have_carry = true;
-      carry_i = oi;
-      carry_v = ov;
-    } else {
-      have_cur = true;
-      cur_i = oi;
-      cur_v = ov;
-    }
-  }
-  return (r2 < p_pick) ? pick : alias_pick;
-}
 
 __device__ __forceinline__ uint64_t valid_mask(const UnitStep &c, int chunk) {
   const int rem = c.n - chunk * 64;
@@ -1983,6 +1624,12 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
   // pairing, and one wave per walker (below) is the better shape (measured: cfg 2, p = 4,
   // q = 0.25: 344 against 241 M steps/s; p = 2, q = 1: 938 against 711).
   const bool lanes_regime = (p == 1.0 && q == 1.0) || (K.bO <= 1.0 && K.bR >= K.bO);
+  if (dyadic && lanes_regime && !(p == 1.0 && q == 1.0) && !(g->reserved & 1)) {
+    // every per-edge table is at hand: the kernel in which no step needs the wave
+    const int rw = n2v_walk_wedge_try(g, start_ids, n_start, num_walks, walk_length, p, q, K, seed,
+                                      walks_out, valid_out, status, stream);
+    if (rw != 0) return rw;
+  }
   if (dyadic && lanes_regime && total < 0xffffff00ll &&
       (g->edge_classes || g->hops || (p == 1.0 && q == 1.0))) {
     int64_t blocks = (total + 255) / 256;

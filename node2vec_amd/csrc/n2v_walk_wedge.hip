@@ -1,0 +1,242 @@
+// n2v_walk_wedge.hip -- K2 exact mode, biased, on a unit-weight graph that carries all three
+// per-edge tables: class counts (inside the hop table), hop table and wedge table
+// (include/n2v_hip.h; built once by n2v_edge_classes_build, n2v_wedge_build, n2v_hops_build).
+//
+// Same contract and same bits as the other exact kernels: per step the index
+// sampling_from_alias(r1, r2) returns on the table generate_edge_alias_tables builds (reference
+// randomwalk.py:86-99, :157-232).  With the tables at hand NO step needs the wave: one lane per
+// walker, and per step
+//   1. hop gather: the drawn neighbour, its row pointer and degree, the class counts of the edge
+//      walked (used at the next step); the offset of this step's wedge list is requested first,
+//      so both loads share one latency;
+//   2. the table by counts: avg = (nR / p + nM + nO / q) / n in exact integers * 2^-20; the class
+//      of slot `pick`: return if the neighbour is s, shared if `pick` is in the edge's wedge list;
+//   3. exits without pairing (~80 % of the steps): an accepted underfull `pick`; an empty stack;
+//   4. the pairing loop (:182-189) for slot `pick`, by the lane itself (n2v_unit_core.h): closed
+//      form when "other" is the only underfull class (exact integer bucket arithmetic; ties and
+//      thin margins fall through), else bit masks (rows of <= 64 slots), else the run-by-run
+//      replay over the list, else slot by slot.
+// The path is written as whole 64-byte sectors through an LDS tile (a 4-byte store into a
+// 324-byte-pitch row costs a 32-byte write request each: 12x write amplification measured on the
+// lanes kernel).  Dyadic p, q in the "other is the smallest class" regime (1/q <= 1, 1/p >= 1/q),
+// the same predicate as the lanes kernel of n2v_walk_unit.hip, which remains the path for graphs
+// without the tables.
+#include "n2v_unit_core.h"
+
+namespace n2v {
+
+constexpr int kWedgeThreads = 256;
+#ifndef N2V_WEDGE_WAVES
+#define N2V_WEDGE_WAVES 6
+#endif
+
+__global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wedge_kernel(
+    n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
+    int32_t walk_length, double p, double q, UnitConsts K, uint64_t seed,
+    int32_t *__restrict__ walks_out, uint8_t *__restrict__ valid_out,
+    uint32_t *__restrict__ status) {
+  __shared__ int32_t path_tile[16][kWedgeThreads];             // word k of thread t at [k][t]
+  __shared__ uint32_t stage_all[kWedgeThreads / 64][16 * 32];  // 2 KB per wave (lane_case_a)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  uint32_t *stage = stage_all[tid >> 6];
+  const int64_t total = n_start * (int64_t)num_walks;
+  const int L1 = walk_length + 1;
+  const bool biased = !(p == 1.0 && q == 1.0);
+  const bool need_mem = q != 1.0;
+  const bool w_wide = g.wedge_wide != 0;
+  const bool base_aligned = (reinterpret_cast<uintptr_t>(walks_out) & 63u) == 0;
+#ifdef N2V_CHECK
+  n2v_check_status = status;
+#endif
+
+  int64_t w0 = 0;  // absolute word index of path position 0 of the current walker
+  int lo = 0;      // first word of the current sector that belongs to this row
+  auto flush = [&](int64_t a) {  // words [sector(a) + lo, a] are complete: store them
+    const int k = (int)(a & 15);
+    int32_t *sec = walks_out + (a & ~(int64_t)15);
+    if (lo == 0 && k == 15 && base_aligned) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        reinterpret_cast<int4 *>(sec)[u] =
+            make_int4(path_tile[4 * u][tid], path_tile[4 * u + 1][tid], path_tile[4 * u + 2][tid],
+                      path_tile[4 * u + 3][tid]);
+    } else {
+      for (int kk = lo; kk <= k; ++kk) sec[kk] = path_tile[kk][tid];
+    }
+    lo = 0;
+  };
+  auto emit = [&](int pos, int32_t x) {  // path position pos of the current walker
+    const int64_t a = w0 + pos;
+    path_tile[(int)(a & 15)][tid] = x;
+    if ((a & 15) == 15 || pos == walk_length) flush(a);
+  };
+
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&status[1], 64u);
+    const int64_t base = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (base >= total) break;
+    const int64_t r = base + lane;
+    const bool have = r < total;
+    int32_t start = -1;
+    uint64_t h0 = 0;
+    bool alive = have;
+    if (have) {
+      start = start_ids[r / num_walks];
+      const int32_t ordinal = (int32_t)(r % num_walks) + 1;
+      h0 = walker_stream(seed, (uint64_t)start * (uint64_t)num_walks + (uint64_t)(ordinal - 1));
+      if (start < 0 || (int64_t)start >= g.n_vertices) {
+        atomicOr(status, N2V_ST_RANGE);
+        alive = false;
+      }
+    }
+    int64_t vb = 0, e_prev = 0;
+    uint32_t ec_prev = 0;  // class counts of the edge (s -> v), from the hop that walked it
+    int n = 0;
+    if (alive) {
+      vb = g.rowptr[start];
+      n = (int)(g.rowptr[start + 1] - vb);
+      alive = n > 0;  // fugue.py:132
+    }
+    w0 = r * (int64_t)L1;
+    lo = (int)(w0 & 15);
+    if (have) {
+      emit(0, alive ? start : -1);
+      if (!alive)  // no such vertex / no out-edges: the row is all -1, like the other kernels
+        for (int tt = 1; tt < L1; ++tt) emit(tt, -1);
+    }
+    int32_t s = -1, v = start;
+    bool walking = alive;
+    for (int step = 0; step < walk_length; ++step) {
+      if (ballot64(walking) == 0ull) break;
+      if (!walking) continue;
+      const uint64_t bits = step_bits(h0, (uint32_t)step);
+      const uint32_t u1 = (uint32_t)(bits >> 32), u2 = (uint32_t)bits;
+      const int pick = pick_index(u1, n);
+      int idx = pick;
+      const bool step_biased = s >= 0 && biased;
+      uint32_t fR = 0, fM = 0;
+      if (step_biased) {
+        fR = ec_prev >> N2V_EC_RETURN_SHIFT;
+        fM = ec_prev & N2V_EC_SHARED_MASK;
+      }
+      const bool counts_ok = step_biased && fR != N2V_EC_RETURN_SAT && fM != N2V_EC_SHARED_MASK;
+      // this step's wedge list: its offset is requested before the hop so both loads overlap.
+      // Steps whose edge has no shared neighbour need it only if the pairing runs (lazy).
+      uint64_t wraw = 0;
+      bool w_loaded = false;
+      if (counts_ok && need_mem && fM > 0) {
+        N2V_CHECK_RANGE(3, e_prev, (int64_t)0, g.n_edges);
+        wraw = g.wedge_off[e_prev];
+        w_loaded = true;
+      }
+      n2v_hop h = load_hop(g.hops + vb + pick);
+      int32_t x = h.col;
+      if (step_biased) {
+        if (!counts_ok) {
+          // a saturated count: the tables of this graph must not have been passed (include/
+          // n2v_hip.h, n2v_wedge_build); flag it and keep `pick` rather than read garbage
+          atomicOr(status, N2V_ST_RANGE);
+        } else {
+          const int nR = (int)fR, nM = need_mem ? (int)fM : 0, nO = n - nR - nM;
+          const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
+          const double avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;  // :172
+          const bool isR = x == s;
+          bool isM = false;
+          int64_t w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
+          int lo_pick = 0;  // entries of the edge's list below `pick`
+          if (need_mem && !isR && nM > 0)  // :226
+            lo_pick = wedge_lower(g.wedge_pos, w_off, nM, pick, w_wide, isM);
+          const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) / avg;  // :173
+          const double r2 = (double)u2 * (1.0 / 4294967296.0);
+          if (!(p_pick < 1.0 && r2 < p_pick)) {
+            const double vR = K.bR / avg, vM = K.bM / avg, vO = K.bO / avg;
+            const bool uR = vR < 1.0, uM = vM < 1.0, uO = vO < 1.0;
+            const bool any_under = (nR && uR) || (nM && uM) || (nO && uO);
+            const bool any_over = (nR && !uR) || (nM && !uM) || (nO && !uO);
+            if (!any_under || !any_over) {  // the loop of :182 never runs
+              if (!(r2 < p_pick)) idx = 0;
+            } else {
+              if (!w_loaded) {  // the return position (and an empty list)
+                N2V_CHECK_RANGE(3, e_prev, (int64_t)0, g.n_edges);
+                wraw = g.wedge_off[e_prev];
+                w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
+              }
+              const int w_rpos = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
+              const bool case_a = uO && !(nR && uR) && !(nM && uM);
+              int res = -1;
+              // plain branches on the (uniform) list width: never a select between two loads
+              if (w_wide) {
+                const uint32_t *list = reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off;
+                if (case_a)
+                  res = lane_case_a_jump<uint32_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
+                if (res < 0 && n > 64)
+                  res = case_a ? lane_case_a<uint32_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR,
+                                                       isM, stage, lane)
+                               : lane_pairing_list<uint32_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list);
+              } else {
+                const uint16_t *list = reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off;
+                if (case_a)
+                  res = lane_case_a_jump<uint16_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
+                if (res < 0 && n > 64)
+                  res = case_a ? lane_case_a<uint16_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR,
+                                                       isM, reinterpret_cast<uint16_t *>(stage), lane)
+                               : lane_pairing_list<uint16_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list);
+              }
+              if (res < 0) {  // a short row: the two stacks as bit masks
+                uint64_t Rm = 0ull;
+                if (nR) Rm = ((nR >= 64) ? ~0ull : ((1ull << nR) - 1ull)) << w_rpos;
+                const uint64_t Mm = wedge_mask(g.wedge_pos, w_off, nM, w_wide);
+                res = lane_pairing(n, Rm, Mm, pick, r2, vR, vM, vO);
+              }
+              idx = res;
+              N2V_CHECK_RANGE(2, idx, 0, n);
+            }
+            if (idx != pick) {
+              h = load_hop(g.hops + vb + idx);
+              x = h.col;
+            }
+          }
+        }
+      }
+      emit(step + 1, x);
+      e_prev = vb + idx;
+      ec_prev = h.classes;
+      s = v;
+      v = x;
+      if (step + 1 < walk_length) {
+        vb = hop_row(h);
+        n = hop_deg(h);
+        if (n == 0) {  // fugue.py:147: the walker vanishes at a sink, the rest of its row is -1
+          walking = false;
+          alive = false;
+          for (int tt = step + 2; tt < L1; ++tt) emit(tt, -1);
+        }
+      }
+    }
+    if (have) valid_out[r] = alive ? 1 : 0;
+  }
+}
+
+}  // namespace n2v
+
+// returns 1 when the kernel applies (and was launched), 0 when it does not, < 0 on error
+int n2v_walk_wedge_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
+                       int32_t num_walks, int32_t walk_length, double p, double q,
+                       const n2v::UnitConsts &K, uint64_t seed, int32_t *walks_out,
+                       uint8_t *valid_out, uint32_t *status, void *stream) {
+  if (!g->hops || !g->wedge_off || !g->wedge_pos || g->w || g->w64) return 0;
+  const int64_t total = n_start * (int64_t)num_walks;
+  if (total >= 0xffffff00ll) return 0;
+  if (total == 0) return 1;
+  int64_t blocks = (total + n2v::kWedgeThreads - 1) / n2v::kWedgeThreads;
+  const int64_t cap = n2v::resident_blocks((const void *)n2v::walk_exact_wedge_kernel,
+                                           n2v::kWedgeThreads, 0);
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(n2v::walk_exact_wedge_kernel, dim3((unsigned)blocks), dim3(n2v::kWedgeThreads), 0,
+                     (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, p, q, K, seed,
+                     walks_out, valid_out, status);
+  if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
+  return 1;
+}

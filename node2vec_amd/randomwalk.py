@@ -54,7 +54,7 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
          return_param: float, inout_param: float, seed: int, mode: str = "exact",
          out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, check: bool = True,
          stats: Optional[dict] = None, use_edge_classes: bool = True, use_hops: bool = True,
-         use_wedges: bool = True):
+         use_wedges: bool = True, use_wedge_kernel: bool = True):
     """Launch K2.  Returns (walks int32 [n_start*num_walks, walk_length+1], valid bool).
 
     mode "fast", and on weighted graphs mode "exact" with return_param == inout_param == 1
@@ -67,7 +67,9 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     first use; use_hops=False walks the CSR arrays instead: same bits, more gathers per step)
     and, for biased exact walks, the wedge table (graph.build_wedges(): the shared neighbours of
     every edge by position, 8 bytes per edge + 2 per entry, skipped when it would not fit;
-    use_wedges=False walks without it: same bits, searches at the steps that need the pairing)."""
+    use_wedges=False walks without it: same bits, searches at the steps that need the pairing).
+    With all three tables the walk runs in the kernel where no step needs the wave
+    (n2v_walk_wedge.hip); use_wedge_kernel=False keeps the class-count kernel: same bits."""
     L = _lib.load()
     _lib.require_gpu()
     if mode not in MODES:
@@ -130,6 +132,8 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     if not use_wedges or not use_edge_classes:
         g.wedge_off = 0
         g.wedge_pos = 0
+    if not use_wedge_kernel:  # keep the tables but walk with the lanes kernel (tests: same bits)
+        g.reserved = 1
     with torch.cuda.device(graph.device):
         rc = L.n2v_walk(g, start_ids.data_ptr(), n_start, num_walks, walk_length,
                         float(return_param), float(inout_param), seed & (2 ** 64 - 1),
