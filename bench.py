@@ -327,6 +327,8 @@ def kernel_name(g, p, q):
     if g.unit_weights:
         if p == 1.0 and q == 1.0:
             return "walk_uniform_kernel"
+        if lanes_regime(p, q) and g.hops is not None and g.wedge_off is not None:
+            return "walk_exact_wedge_kernel"
         if lanes_regime(p, q) and g.edge_classes is not None:
             return "walk_exact_unit_lanes_kernel"
         return "walk_exact_unit_kernel"
@@ -358,10 +360,14 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
                    "16 (rowptr pair of v) + 4 (col[pick]) + 4 (path write) per step")
     else:
         alg = (16 + 4) if hops else (16 + 4 + 4 + 4)
+        wedges = leg.g.wedge_off is not None
         formula = (("16 (hop entry) + 4 (path write)" if hops else
                     "16 (rowptr pair) + 4 (edge class word) + 4 (col[pick]) + 4 (path write)") +
-                   " per step, + 4 per probe of the membership search; steps that run the pairing "
-                   "read both rows")
+                   " per step" +
+                   (", + 8 (wedge offset) + 2 per probe of the edge's shared-position list on steps "
+                    "whose edge has shared neighbours; the steps that run the pairing read 2 bytes per "
+                    "shared neighbour at most" if wedges else
+                    ", + 4 per probe of the membership search; steps that run the pairing read both rows"))
     kernel_key = kernel + (":hops" if hops else "") + (
         ":wedges" if (leg.g.wedge_off is not None and mode == "exact" and not (p == 1.0 and q == 1.0)) else "")
     traffic = pmc_traffic(config, kernel_key, p, q, leg.batch)

@@ -47,7 +47,8 @@ for line in open(os.path.join(src, "trace.log")):
     if line.startswith("{") and '"metric"' in line:
         bench = json.loads(line)
 
-kernels = {"walk_uniform_kernel": "exact p=q=1", "walk_exact_unit_lanes_kernel": "exact biased",
+kernels = {"walk_uniform_kernel": "exact p=q=1", "walk_exact_wedge_kernel": "exact biased (all tables)",
+           "walk_exact_unit_lanes_kernel": "exact biased",
            "walk_exact_unit_kernel": "exact biased (wave per walker)",
            "walk_fast_kernel": "fast", "sgns_kernel": "sgns"}
 out = {"tag": tag, "config": config, "kernels": {}}
@@ -63,7 +64,7 @@ if stats_files:
             w.writerow(r)
     for r in rows:
         for k in kernels:
-            if k + "(" in r["Name"] or k + "<" in r["Name"]:
+            if "::" + k + "(" in r["Name"] or "::" + k + "<" in r["Name"]:
                 trace[k] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                             "max_ms": float(r["MaxNs"]) / 1e6, "min_ms": float(r["MinNs"]) / 1e6}
 for k, what in kernels.items():
