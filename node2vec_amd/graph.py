@@ -231,8 +231,8 @@ class DeviceGraph:
         if self.n_edges == 0 or int(self.degrees().max()) >= self.HOP_MAX_DEGREE:
             return self
         counts = (self.edge_classes & 0xffffff).to(torch.int64)
-        if bool((counts == 0xffffff).any()):
-            return self  # a saturated count: no list for this graph
+        if bool((counts == 0xffffff).any()) or bool((((self.edge_classes >> 24) & 0xff) == 0xff).any()):
+            return self  # a saturated count (16 M shared or 255 parallel return edges): no lists
         total = int(counts.sum())
         if wide is None or int(self.degrees().max()) >= 65536:  # `wide=True` forces 32-bit positions
             wide = int(self.degrees().max()) >= 65536 or bool(wide)
