@@ -293,7 +293,7 @@ def main():
 
 def prepare_tables(torch, g, p, q, mode, setup, tag):
     """the one-off tables randomwalk.walk builds on first use for (p, q, mode), timed"""
-    from node2vec_amd.randomwalk import lanes_regime
+    from node2vec_amd.randomwalk import tables_regime
 
     biased = not (p == 1.0 and q == 1.0)
 
@@ -307,9 +307,9 @@ def prepare_tables(torch, g, p, q, mode, setup, tag):
     if g.unit_weights:
         if mode == "fast" and g.pivots is None:
             timed("pivots_build", g.build_pivots)
-        if biased and g.edge_classes is None and (mode == "fast" or lanes_regime(p, q)):
+        if biased and g.edge_classes is None and (mode == "fast" or tables_regime(p, q)):
             timed("edge_classes_build", g.build_edge_classes)
-        if biased and mode == "exact" and lanes_regime(p, q) and g.wedge_off is None and not g.wedge_tried:
+        if biased and mode == "exact" and tables_regime(p, q) and g.wedge_off is None and not g.wedge_tried:
             g.wedge_tried = True
             timed("wedge_table_build", g.build_wedges)
             setup[f"{tag}_wedge_table_GB"] = 0.0 if g.wedge_off is None else (
@@ -322,12 +322,12 @@ def prepare_tables(torch, g, p, q, mode, setup, tag):
 
 def kernel_name(g, p, q):
     """the kernel n2v_walk dispatches exact mode to (node2vec_amd/csrc/n2v_capi.hip)"""
-    from node2vec_amd.randomwalk import lanes_regime
+    from node2vec_amd.randomwalk import lanes_regime, tables_regime
 
     if g.unit_weights:
         if p == 1.0 and q == 1.0:
             return "walk_uniform_kernel"
-        if lanes_regime(p, q) and g.hops is not None and g.wedge_off is not None:
+        if tables_regime(p, q) and g.hops is not None and g.wedge_off is not None:
             return "walk_exact_wedge_kernel"
         if lanes_regime(p, q) and g.edge_classes is not None:
             return "walk_exact_unit_lanes_kernel"

@@ -373,6 +373,104 @@ __device__ __forceinline__ int lane_pairing(int n, uint64_t Rm, uint64_t Mm, int
   return (r2 < p_pick) ? pick : alias_pick;
 }
 
+// ---- the mirror arrangement in closed form: "other" is the OVERFULL class and every return /
+// shared slot is underfull (what q < 1 gives: cfg 5's p = 4, q = 0.25).  Now the few listed slots
+// are the underfull stack (popped from the highest position) and the long runs of "other" slots
+// the overfull one: an underfull slot of deficit d = isum - g n is paired with the current
+// "other" slot, whose excess e = gO n - isum is tiny, so that slot is demoted and the rest of the
+// deficit cascades down the "other" slots until their cumulative excess covers it.  In exact
+// arithmetic, with Y_j the cumulative deficit of the first j listed slots (descending position):
+//   * listed slot j is paired with the "other" slot of rank ceil(Y_(j-1) / e) (rank 1 for j = 1);
+//   * the "other" slot of rank t < nO is demoted while slot j(t) = min { j : Y_j > t e } is being
+//     absorbed, ends at 1 + (t e - Y_j(t)) / isum and is paired with the "other" slot of rank
+//     t + 1; the last one ends at exactly 1.0 (mass balance: Y_S = nO e) -- fp64 decides.
+// Same exactness argument and the same -1 cases as lane_case_a_jump; checked against the
+// reference loop in Python (0 mismatches in 180 k short and 5.7 k long rows, 2-10 % return -1).
+template <typename P>
+__device__ __forceinline__ int lane_case_b_jump(int n, int pick, double r2, const UnitConsts &K,
+                                                int nR, int rpos, int nM, const P *list,
+                                                bool pickR, bool pickM, int lo_pick) {
+  const int nO = n - nR - nM;
+  const int64_t isum = (int64_t)nR * K.gR + (int64_t)nM * K.gM + (int64_t)nO * K.gO;
+  const int64_t e = K.gO * n - isum, dR = isum - K.gR * n, dM = isum - K.gM * n;
+  if (nO <= 0 || e <= 0 || (nM > 0 && dM <= 0) || (nR > 0 && dR <= 0)) return -1;
+  if ((double)n * (double)isum > 2.0e14 || (double)n * (double)n * (double)K.gO > 4.0e18) return -1;
+  auto list_lower = [&](int pos) -> int {  // entries of the list below pos
+    int lo = 0, hi = nM;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((int)list[mid] < pos)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    return lo;
+  };
+  int mA = nM;  // shared slots above the return run come first in descending order
+  if (nR > 0 && nM > 0) mA = nM - list_lower(rpos);
+  const int S = nM + nR;
+  auto Y_of = [&](int64_t j) -> int64_t {
+    if (j <= mA) return j * dM;
+    if (j <= mA + nR) return (int64_t)mA * dM + (j - mA) * dR;
+    return (int64_t)mA * dM + (int64_t)nR * dR + (j - mA - nR) * dM;
+  };
+  auto specials_ge = [&](int pos) -> int {  // listed + return slots at positions >= pos
+    int r = rpos + nR - pos;
+    r = r < 0 ? 0 : (r > nR ? nR : r);
+    return (nM - list_lower(pos)) + r;
+  };
+  auto other_pos = [&](int64_t t) -> int {  // position of the t-th "other" slot from the top
+    int c = 0;
+    for (int it = 0; it < 64; ++it) {
+      const int c2 = specials_ge((int)(n - t - c));
+      if (c2 == c) return (int)(n - t - c);
+      c = c2;
+    }
+    return -1;
+  };
+  if (pickR || pickM) {  // underfull: r2 >= its value here (the caller's quick exit took the rest)
+    int64_t j;
+    if (pickR) {
+      j = mA + (nR - (pick - rpos));
+    } else {
+      const int d = nM - lo_pick;
+      j = d <= mA ? d : d + nR;
+    }
+    if (j < 1 || j > S) return -1;
+    int64_t t = 1;
+    if (j > 1) {
+      const int64_t Yp = Y_of(j - 1);
+      t = (Yp + e - 1) / e;
+      if (t * e == Yp) return -1;  // that slot holds exactly 1.0: fp64 decides whether it was demoted
+    }
+    if (t < 1 || t > nO) return -1;
+    return other_pos(t);
+  }
+  int ar = rpos + nR - 1 - pick;  // return slots above pick
+  ar = ar < 0 ? 0 : (ar > nR ? nR : ar);
+  const int64_t t = (int64_t)(n - pick) - (nM - lo_pick) - ar;  // rank of pick among "other", from 1
+  if (t < 1 || t >= nO) return -1;  // the last one ends at exactly 1.0
+  const int64_t T = t * e;
+  int64_t j;  // smallest j with Y_j > T
+  if (mA > 0 && (int64_t)mA * dM > T) {
+    j = T / dM + 1;
+  } else {
+    const int64_t Y1 = (int64_t)mA * dM;
+    if (nR > 0 && Y1 + (int64_t)nR * dR > T)
+      j = mA + (T - Y1) / dR + 1;
+    else if (dM > 0)
+      j = mA + nR + (T - Y1 - (int64_t)nR * dR) / dM + 1;
+    else
+      return -1;
+  }
+  if (j < 1 || j > S) return -1;
+  if (j > 1 && Y_of(j - 1) == T) return -1;  // exactly 1.0 after the previous listed slot
+  const double prob = 1.0 + (double)(T - Y_of(j)) / (double)isum;
+  if (fabs(prob - r2) < 1e-9) return -1;
+  if (r2 < prob) return pick;
+  return other_pos(t + 1);
+}
+
 // ---- any row, any arrangement of the classes: the loop of :175-189 slot by slot, by one lane.
 // The two stacks are walked as two descending cursors over the positions of the row; the class
 // of a position is read off the (ascending) shared list and the return run on the way down, so

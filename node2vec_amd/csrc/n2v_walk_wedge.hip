@@ -13,14 +13,13 @@
 //      of slot `pick`: return if the neighbour is s, shared if `pick` is in the edge's wedge list;
 //   3. exits without pairing (~80 % of the steps): an accepted underfull `pick`; an empty stack;
 //   4. the pairing loop (:182-189) for slot `pick`, by the lane itself (n2v_unit_core.h): closed
-//      form when "other" is the only underfull class (exact integer bucket arithmetic; ties and
-//      thin margins fall through), else bit masks (rows of <= 64 slots), else the run-by-run
-//      replay over the list, else slot by slot.
+//      form when "other" is the only underfull class (q > 1) or the only overfull one (q < 1) --
+//      exact integer bucket arithmetic; ties and thin margins fall through --, else bit masks
+//      (rows of <= 64 slots), else the run-by-run replay over the list, else slot by slot.
 // The path is written as whole 64-byte sectors through an LDS tile (a 4-byte store into a
 // 324-byte-pitch row costs a 32-byte write request each: 12x write amplification measured on the
-// lanes kernel).  Dyadic p, q in the "other is the smallest class" regime (1/q <= 1, 1/p >= 1/q),
-// the same predicate as the lanes kernel of n2v_walk_unit.hip, which remains the path for graphs
-// without the tables.
+// lanes kernel).  Any dyadic p, q (the row sum is then an exact integer combination of the class
+// counts); graphs without the tables keep the kernels of n2v_walk_unit.hip.
 #include "n2v_unit_core.h"
 
 namespace n2v {
@@ -165,12 +164,15 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
               }
               const int w_rpos = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
               const bool case_a = uO && !(nR && uR) && !(nM && uM);
+              const bool case_b = !uO && nO > 0 && (!nR || uR) && (!nM || uM);  // the mirror image
               int res = -1;
               // plain branches on the (uniform) list width: never a select between two loads
               if (w_wide) {
                 const uint32_t *list = reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off;
                 if (case_a)
                   res = lane_case_a_jump<uint32_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
+                else if (case_b)
+                  res = lane_case_b_jump<uint32_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
                 if (res < 0 && n > 64)
                   res = case_a ? lane_case_a<uint32_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR,
                                                        isM, stage, lane)
@@ -179,6 +181,8 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
                 const uint16_t *list = reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off;
                 if (case_a)
                   res = lane_case_a_jump<uint16_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
+                else if (case_b)
+                  res = lane_case_b_jump<uint16_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
                 if (res < 0 && n > 64)
                   res = case_a ? lane_case_a<uint16_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR,
                                                        isM, reinterpret_cast<uint16_t *>(stage), lane)

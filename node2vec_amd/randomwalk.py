@@ -31,6 +31,17 @@ def lanes_regime(p: float, q: float) -> bool:
     return _dyadic(p) and _dyadic(q) and 1.0 / q <= 1.0 and 1.0 / p >= 1.0 / q
 
 
+def tables_regime(p: float, q: float) -> bool:
+    """The (p, q) for which exact walks on a unit-weight graph run from the per-edge tables alone
+    (class counts + wedge lists + hop table, csrc/n2v_walk_wedge.hip): dyadic values for which
+    the bulk class "other" is alone on its stack on ordinary rows -- the only underfull class
+    (1/q <= 1, 1/p >= 1/q: the lanes regime) or the only overfull one (1/q > 1, 1/p < 1/q).  The
+    pairing of such a row has a closed form; other (p, q) keep the wave-per-walker kernel."""
+    if not (_dyadic(p) and _dyadic(q)) or (p == 1.0 and q == 1.0):
+        return False
+    return lanes_regime(p, q) or (1.0 / q > 1.0 and 1.0 / p < 1.0 / q)
+
+
 def fresh_seed() -> int:
     """random_seed=None in the reference means an unseeded `random` (randomwalk.py:314)."""
     return int.from_bytes(os.urandom(8), "little")
@@ -94,7 +105,7 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     if mode == "exact" and graph.unit_weights:
         # unit weights: the per-step table follows from two counts per edge, computed once
         # (n2v_edge_classes_build, 4 bytes per edge); p == q == 1 needs nothing at all
-        if use_edge_classes and biased and lanes_regime(return_param, inout_param):
+        if use_edge_classes and biased and tables_regime(return_param, inout_param):
             if graph.edge_classes is None:
                 graph.build_edge_classes()
             # which slots are which, per edge (wedge table): built once if it fits in half of the

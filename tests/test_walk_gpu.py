@@ -142,7 +142,8 @@ def test_results_independent_of_sharding():
     assert torch.equal(full, cat) and bool(v.all())
 
 
-@pytest.mark.parametrize("pq", [(1.0, 1.0), (0.5, 2.0), (1.0, 2.0), (0.25, 4.0), (4.0, 0.25), (3.0, 0.7)])
+@pytest.mark.parametrize("pq", [(1.0, 1.0), (0.5, 2.0), (1.0, 2.0), (0.25, 4.0), (4.0, 0.25), (3.0, 0.7),
+                                (2.0, 0.5), (0.25, 0.25), (0.5, 0.25), (4.0, 4.0), (1.0, 0.5), (0.25, 0.5)])
 def test_hop_table_and_class_counts_change_no_bit(oracle, pq):
     """unit-weight graph with sinks, multi-edges and hubs: the walks are the same bits with the
     hop table (one gather per step), with the CSR arrays + per-edge class counts, and with the
@@ -160,8 +161,8 @@ def test_hop_table_and_class_counts_change_no_bit(oracle, pq):
     assert g.unit_weights
     start = rw.start_vertices(g)
     a, av = rw.walk(g, start, 3, 25, p, q, 9)
-    assert g.hops is not None and (p == q == 1.0 or g.hops_have_classes or not rw.lanes_regime(p, q))
-    assert (g.wedge_off is not None) == (rw.lanes_regime(p, q) and not (p == q == 1.0))
+    assert g.hops is not None and (p == q == 1.0 or g.hops_have_classes or not rw.tables_regime(p, q))
+    assert (g.wedge_off is not None) == rw.tables_regime(p, q)  # (3, 0.7) is not dyadic: no tables
     b, bv = rw.walk(g, start, 3, 25, p, q, 9, use_hops=False)
     c, cv = rw.walk(g, start, 3, 25, p, q, 9, use_hops=False, use_edge_classes=False)
     d, dv = rw.walk(g, start, 3, 25, p, q, 9, use_wedges=False)
