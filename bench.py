@@ -43,11 +43,11 @@ GATHER_CEILING = 51.0e9
 
 CONFIGS = {
     "cfg4": dict(gen="chung_lu", n=100_000_000, draws=500_000_000, trim=10_000, p=1.0, q=1.0,
-                 batch=1 << 20, biased_batch=1 << 17, sgns_vertices=1 << 16, dim=128,
+                 batch=1 << 20, biased_batch=1 << 20, sgns_vertices=1 << 16, dim=128,
                  label="cfg4 Chung-Lu power-law gamma=2.1, 100M vertices / 5e8 undirected draws "
                        "symmetrised, out-degree trimmed at 10000"),
     "cfg3": dict(gen="chung_lu", n=10_000_000, draws=100_000_000, trim=10_000, p=1.0, q=1.0,
-                 batch=1 << 20, biased_batch=1 << 17, sgns_vertices=1 << 16, dim=128,
+                 batch=1 << 20, biased_batch=1 << 20, sgns_vertices=1 << 16, dim=128,
                  label="cfg3 Chung-Lu power-law gamma=2.1, 10M vertices / 1e8 undirected draws "
                        "symmetrised, out-degree trimmed at 10000"),
     "cfg2": dict(gen="rmat", scale=20, draws=5_000_000, trim=0, p=0.5, q=2.0,

@@ -44,6 +44,9 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
   const bool biased = !(p == 1.0 && q == 1.0);
   const bool need_mem = q != 1.0;
   const bool w_wide = g.wedge_wide != 0;
+  // 1/q > 1: "other" is overfull, an overfull `pick` has no quick exit, so nearly every step runs
+  // the pairing and needs the return position: request the wedge offset with the hop, always
+  const bool always_pair = K.bO > 1.0;
   const bool base_aligned = (reinterpret_cast<uintptr_t>(walks_out) & 63u) == 0;
 #ifdef N2V_CHECK
   n2v_check_status = status;
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
       // Steps whose edge has no shared neighbour need it only if the pairing runs (lazy).
       uint64_t wraw = 0;
       bool w_loaded = false;
-      if (counts_ok && need_mem && fM > 0) {
+      if (counts_ok && ((need_mem && fM > 0) || (always_pair && (fM > 0 || fR > 0)))) {
         N2V_CHECK_RANGE(3, e_prev, (int64_t)0, g.n_edges);
         wraw = g.wedge_off[e_prev];
         w_loaded = true;
