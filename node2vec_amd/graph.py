@@ -234,8 +234,7 @@ class DeviceGraph:
         if bool((counts == 0xffffff).any()) or bool((((self.edge_classes >> 24) & 0xff) == 0xff).any()):
             return self  # a saturated count (16 M shared or 255 parallel return edges): no lists
         total = int(counts.sum())
-        if wide is None or int(self.degrees().max()) >= 65536:  # `wide=True` forces 32-bit positions
-            wide = int(self.degrees().max()) >= 65536 or bool(wide)
+        wide = bool(wide) or int(self.degrees().max()) >= 65536  # `wide=True` forces 32-bit positions
         need = 8 * self.n_edges + total * (4 if wide else 2)
         if max_bytes is None:
             max_bytes = torch.cuda.mem_get_info(self.device)[0] // 2

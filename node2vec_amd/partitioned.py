@@ -29,7 +29,6 @@ use to prove that partitioned == unpartitioned, bit for bit.  The step function 
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence, Tuple
 
-import numpy as np
 import torch
 
 from node2vec_amd.graph import DeviceGraph
@@ -39,7 +38,7 @@ from node2vec_amd.shard import shard_range
 @dataclass
 class GraphPart:
     """rows [lo, hi) of the CSR: rowptr rebased to 0, the rows' neighbour ids (global) and
-    weights (None = unit); `bounds` = the lo of every part + the vertex count (owner lookup)"""
+    weights (None = unit); `bounds` = the lo of every part, ascending (owner lookup)"""
     rank: int
     lo: int
     hi: int
