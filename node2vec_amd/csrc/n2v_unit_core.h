@@ -218,6 +218,20 @@ __device__ __forceinline__ int lane_case_a(int n, int pick, double r2, double vR
   return (r2 < p_pick) ? pick : alias_pick;
 }
 
+// floor(a / b) for 0 <= a < 2^52, 0 < b < 2^52 through one fp64 division and an exact integer
+// correction (64-bit integer division is a ~150-instruction emulation on this hardware, and the
+// closed forms below need three to five quotients per draw)
+__device__ __forceinline__ int64_t floor_div(int64_t a, int64_t b) {
+  int64_t qd = (int64_t)((double)a / (double)b);
+  int64_t r = a - qd * b;
+  if (r < 0) {
+    --qd;
+    r += b;
+  }
+  if (r >= b) ++qd;
+  return qd;
+}
+
 // ---- the same draw in closed form ---------------------------------------------------------
 // In exact arithmetic the loop of :182-189 under the "other is the only underfull class"
 // arrangement is a bucket process.  Scale every value by isum / n (the dyadic class values are
@@ -277,13 +291,13 @@ __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, cons
     if (T <= 0) {
       i = 1;
     } else if (mA > 0 && (int64_t)mA * EM >= T) {
-      i = (T + EM - 1) / EM;
+      i = floor_div(T + EM - 1, EM);
     } else {
       const int64_t X1 = (int64_t)mA * EM;
       if (nR > 0 && X1 + (int64_t)nR * ER >= T)
-        i = mA + (T - X1 + ER - 1) / ER;
+        i = mA + floor_div(T - X1 + ER - 1, ER);
       else
-        i = mA + nR + (T - X1 - (int64_t)nR * ER + EM - 1) / EM;
+        i = mA + nR + floor_div(T - X1 - (int64_t)nR * ER + EM - 1, EM);
     }
     if (i < 1 || i > N || X_of(i) == T) return -1;  // a tie: fp64 rounding decides
     return pos_of((int)i);  // r2 >= probs[pick] here: the caller's quick exit took the other case
@@ -297,8 +311,9 @@ __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, cons
   }
   if (i0 < 1 || i0 >= N) return -1;  // the last overfull slot ends at exactly 1.0: fp64 decides
   const int64_t X = X_of(i0);
-  if (X % D == 0) return -1;
-  const int64_t rem = X - (X / D + 1) * D;  // in (-D, 0)
+  const int64_t xq = floor_div(X, D);
+  if (X - xq * D == 0) return -1;
+  const int64_t rem = X - (xq + 1) * D;  // in (-D, 0)
   const double prob = 1.0 + (double)rem / (double)isum;
   if (fabs(prob - r2) < 1e-9) return -1;
   return (r2 < prob) ? pick : pos_of((int)i0 + 1);
@@ -440,7 +455,7 @@ __device__ __forceinline__ int lane_case_b_jump(int n, int pick, double r2, cons
     int64_t t = 1;
     if (j > 1) {
       const int64_t Yp = Y_of(j - 1);
-      t = (Yp + e - 1) / e;
+      t = floor_div(Yp + e - 1, e);
       if (t * e == Yp) return -1;  // that slot holds exactly 1.0: fp64 decides whether it was demoted
     }
     if (t < 1 || t > nO) return -1;
@@ -453,13 +468,13 @@ __device__ __forceinline__ int lane_case_b_jump(int n, int pick, double r2, cons
   const int64_t T = t * e;
   int64_t j;  // smallest j with Y_j > T
   if (mA > 0 && (int64_t)mA * dM > T) {
-    j = T / dM + 1;
+    j = floor_div(T, dM) + 1;
   } else {
     const int64_t Y1 = (int64_t)mA * dM;
     if (nR > 0 && Y1 + (int64_t)nR * dR > T)
-      j = mA + (T - Y1) / dR + 1;
+      j = mA + floor_div(T - Y1, dR) + 1;
     else if (dM > 0)
-      j = mA + nR + (T - Y1 - (int64_t)nR * dR) / dM + 1;
+      j = mA + nR + floor_div(T - Y1 - (int64_t)nR * dR, dM) + 1;
     else
       return -1;
   }

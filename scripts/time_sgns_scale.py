@@ -10,7 +10,10 @@ ids = torch.arange(n_vocab, device=dev)
 vocab = sgns.Vocab(ids, counts, ids.to(torch.int32))
 # sentences: tokens drawn proportionally to the counts (what walks look like), 471 040 x 81
 probs = counts.double() / counts.sum()
-idx = torch.multinomial(probs, 471040 * 81, replacement=True).to(torch.int32).view(471040, 81).contiguous()
+cdf = torch.cumsum(probs, 0)  # inverse-CDF sampling (torch.multinomial stops at 2^24 categories)
+idx = torch.searchsorted(cdf, torch.rand(471040 * 81, device=dev, dtype=torch.float64)).clamp_(max=n_vocab - 1)
+idx = idx.to(torch.int32).view(471040, 81).contiguous()
+del cdf
 m = sgns.SgnsModel(vocab, dim, 5, 5, seed=1, sample=0.0)
 m.train_block(idx, 0.025, 0); torch.cuda.synchronize()
 best = 1e9
