@@ -270,7 +270,7 @@ def main():
         del leg
         torch.cuda.empty_cache()
     # the walk tables are not needed any more (the CPU baseline reads rowptr / col only)
-    g.slots = g.pivots = g.hops = g.hops2 = g.edge_classes = g.wedge_off = g.wedge_pos = None
+    g.slots = g.pivots = g.hops = g.edge_classes = g.wedge_off = g.wedge_pos = None
     torch.cuda.empty_cache()
 
     # ---- SGNS on the config's model ------------------------------------------------------------
@@ -314,10 +314,6 @@ def prepare_tables(torch, g, p, q, mode, setup, tag):
             timed("wedge_table_build", g.build_wedges)
             setup[f"{tag}_wedge_table_GB"] = 0.0 if g.wedge_off is None else (
                 g.wedge_off.numel() * 8 + g.wedge_pos.numel() * g.wedge_pos.element_size()) / 1e9
-            if g.wedge_off is not None:
-                g.hops2_tried = True
-                timed("hop2_table_build", g.build_hops2)
-                setup[f"{tag}_hop2_table_GB"] = 0.0 if g.hops2 is None else g.hops2.numel() * 4 / 1e9
         if g.hops is None or (g.edge_classes is not None and not g.hops_have_classes):
             timed("hop_table_build", g.build_hops)
     elif g.slots is None and (mode == "fast" or not biased):
@@ -364,8 +360,6 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
                    "16 (rowptr pair of v) + 4 (col[pick]) + 4 (path write) per step")
     else:
         alg = (16 + 4) if hops else (16 + 4 + 4 + 4)
-        if leg.g.hops2 is not None and mode == "exact":
-            alg = 32 + 4  # the 32-byte entry: hop + wedge offset + list head
         wedges = leg.g.wedge_off is not None
         formula = (("16 (hop entry) + 4 (path write)" if hops else
                     "16 (rowptr pair) + 4 (edge class word) + 4 (col[pick]) + 4 (path write)") +
@@ -374,16 +368,15 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
                     "whose edge has shared neighbours; the steps that run the pairing read 2 bytes per "
                     "shared neighbour at most" if wedges else
                     ", + 4 per probe of the membership search; steps that run the pairing read both rows"))
-    wedged = leg.g.wedge_off is not None and mode == "exact" and not (p == 1.0 and q == 1.0)
-    kernel_key = kernel + (":hops" if hops else "") + (":wedges" if wedged else "") + (
-        ":hops2" if (wedged and leg.g.hops2 is not None) else "")
+    kernel_key = kernel + (":hops" if hops else "") + (
+        ":wedges" if (leg.g.wedge_off is not None and mode == "exact" and not (p == 1.0 and q == 1.0)) else "")
     traffic = pmc_traffic(config, kernel_key, p, q, leg.batch)
     alg_launch = alg * per_launch_steps
     used = traffic if traffic else alg_launch
     ach = used / res["kernel_s"]
     r = {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
          "frac": ach / HBM_PEAK, "traffic": traffic, "kernel": kernel, "hop_table": hops,
-         "wedge_table": ":wedges" in kernel_key, "hop2_table": ":hops2" in kernel_key,
+         "wedge_table": ":wedges" in kernel_key,
          "kernel_ms": 1e3 * res["kernel_s"],
          "achieved_from": "pmc traffic" if traffic else "kernel algorithmic bytes (no pmc profile of this workload)",
          "algorithmic_bytes_per_launch": alg_launch, "algorithmic_bytes_per_walk_step": alg,

@@ -71,20 +71,6 @@ typedef struct n2v_hop {
 #define N2V_HOP_DEG_SHIFT 40
 #define N2V_HOP_ROW_MASK 0xffffffffffull
 
-/* The same entry for BIASED exact walks, with what the walker's NEXT step needs from the wedge
- * table in the same 64-byte sector: wedge = wedge_off[e] (list offset | return position << 40)
- * and the first entries of the edge's list (4 uint16 positions, or 2 uint32 when wedge_wide).
- * A step whose edge shares at most that many neighbours -- two thirds of the edges of the
- * BASELINE graphs -- is then ONE gather; the others read the rest of their list.  32 bytes per
- * edge (n2v_hops2_build; the 16-byte table remains the one of p == q == 1). */
-typedef struct n2v_hop2 {
-  int32_t col;
-  uint32_t classes;
-  uint64_t row;
-  uint64_t wedge;
-  uint64_t head; /* list[0 .. 3] as uint16 << 16 k, or list[0 .. 1] as uint32 << 32 k */
-} n2v_hop2;
-
 /* The reference's adjacency DataFrame df_adj (fugue.py:130, randomwalk.py:266-275)
  * as CSR in HBM: one row per vertex id, neighbours sorted by dst ascending,
  * multi-edges kept.  Weights: the reference carries Python floats (randomwalk.py:20,
@@ -116,7 +102,6 @@ typedef struct n2v_graph {
   const void *wedge_pos;        /* uint16 / uint32 positions, or NULL */
   int32_t wedge_wide;           /* 0: wedge_pos is uint16 (every degree < 65536), 1: uint32 */
   int32_t reserved;             /* 0 (bit 0 set: do not use the all-tables kernel; diagnostics) */
-  const struct n2v_hop2 *hops2; /* [n_edges] or NULL: see n2v_hops2_build */
 } n2v_graph;
 
 /* edge_classes[e] for e = (s -> v): bits 0..23 = number of entries x of N(v) with
@@ -164,11 +149,6 @@ int n2v_edge_classes_build(const n2v_graph *g, uint32_t *classes_out, uint32_t *
  * sets N2V_ST_RANGE in status[0] (read after synchronising): the table must then be discarded
  * (walk without it). */
 int n2v_hops_build(const n2v_graph *g, struct n2v_hop *hops_out, uint32_t *status, void *stream);
-
-/* 32-byte hop table (struct n2v_hop2 above) of a unit-weight graph whose edge_classes, wedge_off
- * and wedge_pos are set: hops2_out[e] = {col[e], edge_classes[e], rowptr[col[e]] | degree << 40,
- * wedge_off[e], head of the list of e}.  Errors as n2v_hops_build. */
-int n2v_hops2_build(const n2v_graph *g, struct n2v_hop2 *hops2_out, uint32_t *status, void *stream);
 
 /* Shared-position lists ("wedge table") of a unit-weight graph.  For edge e = (s -> v) the list
  *   wedge_pos[off .. off + n_shared)   off = wedge_off[e] & (2^40 - 1), n_shared = low 24 bits

@@ -29,65 +29,6 @@ constexpr int kWedgeThreads = 256;
 #define N2V_WEDGE_WAVES 6
 #endif
 
-// 32-byte hop entry (n2v_hop2): two 16-byte loads of one sector
-__device__ __forceinline__ void load_hop2(const n2v_hop2 *p, n2v_hop &h, uint64_t &wedge,
-                                          uint64_t &head) {
-  const int4 a = reinterpret_cast<const int4 *>(p)[0];
-  const int4 b = reinterpret_cast<const int4 *>(p)[1];
-  h.col = a.x;
-  h.classes = (uint32_t)a.y;
-  h.row = (uint64_t)(uint32_t)a.z | ((uint64_t)(uint32_t)a.w << 32);
-  wedge = (uint64_t)(uint32_t)b.x | ((uint64_t)(uint32_t)b.y << 32);
-  head = (uint64_t)(uint32_t)b.z | ((uint64_t)(uint32_t)b.w << 32);
-}
-
-// The table of step (s -> v) is decided for slot `pick`; `list` = the edge's wedge list (global
-// memory, or this lane's LDS copy of the entries that travelled inside the hop entry).  Returns
-// the slot sampling_from_alias (:86-99) picks.  `lazy_wedge` != NULL: the list offset / return
-// position was not requested yet (an edge without shared neighbours) and is read only if the
-// pairing has to run.
-template <typename P>
-__device__ __forceinline__ int wedge_step(const P *list, const uint64_t *lazy_wedge, uint64_t wraw,
-                                          int n, int pick, uint32_t u2, const UnitConsts &K, int nR,
-                                          int nM, bool isR, bool need_mem, P *stage, int lane) {
-  const int nO = n - nR - nM;
-  const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
-  const double avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;  // :172
-  bool isM = false;
-  int lo_pick = 0;  // entries of the edge's list below `pick`
-  if (need_mem && !isR && nM > 0) lo_pick = wedge_lower_t<P>(list, 0, nM, pick, isM);  // :226
-  const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) / avg;  // :173
-  const double r2 = (double)u2 * (1.0 / 4294967296.0);
-  if (p_pick < 1.0 && r2 < p_pick) return pick;  // an accepted underfull slot never changes
-  const double vR = K.bR / avg, vM = K.bM / avg, vO = K.bO / avg;
-  const bool uR = vR < 1.0, uM = vM < 1.0, uO = vO < 1.0;
-  const bool any_under = (nR && uR) || (nM && uM) || (nO && uO);
-  const bool any_over = (nR && !uR) || (nM && !uM) || (nO && !uO);
-  if (!any_under || !any_over) return (r2 < p_pick) ? pick : 0;  // the loop of :182 never runs
-  if (lazy_wedge) wraw = *lazy_wedge;  // the return position (the list is empty)
-  const int w_rpos = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
-  const bool case_a = uO && !(nR && uR) && !(nM && uM);
-  const bool case_b = !uO && nO > 0 && (!nR || uR) && (!nM || uM);  // the mirror image
-  int res = -1;
-  if (case_a)
-    res = lane_case_a_jump<P>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
-  else if (case_b)
-    res = lane_case_b_jump<P>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
-  if (res < 0 && n > 64)
-    res = case_a ? lane_case_a<P>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR, isM, stage, lane)
-                 : lane_pairing_list<P>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list);
-  if (res < 0) {  // a short row: the two stacks as bit masks
-    uint64_t Rm = 0ull;
-    if (nR) Rm = ((nR >= 64) ? ~0ull : ((1ull << nR) - 1ull)) << w_rpos;
-    res = lane_pairing(n, Rm, wedge_mask_t<P>(list, 0, nM), pick, r2, vR, vM, vO);
-  }
-  return res;
-}
-
-// kFat: the graph carries the 32-byte hop table (n2v_hops2_build): the entry that names the
-// next vertex also holds the wedge offset / return position of the edge walked and the first
-// entries of its list, so a step whose edge shares at most 4 neighbours is ONE gather.
-template <bool kFat>
 __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wedge_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double p, double q, UnitConsts K, uint64_t seed,
@@ -95,7 +36,6 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
     uint32_t *__restrict__ status) {
   __shared__ int32_t path_tile[16][kWedgeThreads];             // word k of thread t at [k][t]
   __shared__ uint32_t stage_all[kWedgeThreads / 64][16 * 32];  // 2 KB per wave (lane_case_a)
-  __shared__ uint64_t inline_all[kFat ? kWedgeThreads : 1];    // the list head of this lane's step
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   uint32_t *stage = stage_all[tid >> 6];
@@ -104,7 +44,6 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
   const bool biased = !(p == 1.0 && q == 1.0);
   const bool need_mem = q != 1.0;
   const bool w_wide = g.wedge_wide != 0;
-  const int inline_cap = w_wide ? 2 : 4;  // list entries that fit the 8 spare bytes of n2v_hop2
   // 1/q > 1: "other" is overfull, an overfull `pick` has no quick exit, so nearly every step runs
   // the pairing and needs the return position: request the wedge offset with the hop, always
   const bool always_pair = K.bO > 1.0;
@@ -134,15 +73,6 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
     path_tile[(int)(a & 15)][tid] = x;
     if ((a & 15) == 15 || pos == walk_length) flush(a);
   };
-  auto gather = [&](int64_t e, n2v_hop &h, uint64_t &wedge, uint64_t &head) {
-    if (kFat) {
-      load_hop2(g.hops2 + e, h, wedge, head);
-    } else {
-      h = load_hop(g.hops + e);
-      wedge = 0;
-      head = 0;
-    }
-  };
 
   for (;;) {
     uint32_t t = 0;
@@ -164,8 +94,7 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
       }
     }
     int64_t vb = 0, e_prev = 0;
-    uint32_t ec_prev = 0;    // class counts of the edge (s -> v), from the hop that walked it
-    uint64_t wedge_prev = 0, head_prev = 0;  // kFat: its wedge offset | return position, list head
+    uint32_t ec_prev = 0;  // class counts of the edge (s -> v), from the hop that walked it
     int n = 0;
     if (alive) {
       vb = g.rowptr[start];
@@ -195,18 +124,16 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
         fM = ec_prev & N2V_EC_SHARED_MASK;
       }
       const bool counts_ok = step_biased && fR != N2V_EC_RETURN_SAT && fM != N2V_EC_SHARED_MASK;
-      // this step's wedge list: kFat has its offset already; otherwise it is requested before the
-      // hop so both loads overlap (edges without shared neighbours: only if the pairing runs)
-      uint64_t wraw = wedge_prev;
-      bool w_loaded = kFat;
-      if (!kFat && counts_ok && ((need_mem && fM > 0) || (always_pair && (fM > 0 || fR > 0)))) {
+      // this step's wedge list: its offset is requested before the hop so both loads overlap.
+      // Steps whose edge has no shared neighbour need it only if the pairing runs (lazy).
+      uint64_t wraw = 0;
+      bool w_loaded = false;
+      if (counts_ok && ((need_mem && fM > 0) || (always_pair && (fM > 0 || fR > 0)))) {
         N2V_CHECK_RANGE(3, e_prev, (int64_t)0, g.n_edges);
         wraw = g.wedge_off[e_prev];
         w_loaded = true;
       }
-      n2v_hop h;
-      uint64_t wedge_new, head_new;
-      gather(vb + pick, h, wedge_new, head_new);
+      n2v_hop h = load_hop(g.hops + vb + pick);
       int32_t x = h.col;
       if (step_biased) {
         if (!counts_ok) {
@@ -214,35 +141,75 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
           // n2v_hip.h, n2v_wedge_build); flag it and keep `pick` rather than read garbage
           atomicOr(status, N2V_ST_RANGE);
         } else {
-          const int nR = (int)fR, nM = need_mem ? (int)fM : 0;
-          const int64_t w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
-          const uint64_t *lazy = w_loaded ? nullptr : g.wedge_off + e_prev;
-          const bool inl = kFat && nM <= inline_cap;  // the whole list came with the hop entry
-          if (inl) inline_all[kFat ? tid : 0] = head_prev;
-          // plain branches on the (uniform) list width: never a select between two loads
-          if (w_wide) {
-            const uint32_t *list = inl ? reinterpret_cast<const uint32_t *>(&inline_all[kFat ? tid : 0])
-                                       : reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off;
-            idx = wedge_step<uint32_t>(list, lazy, wraw, n, pick, u2, K, nR, nM, x == s, need_mem, stage,
-                                       lane);
-          } else {
-            const uint16_t *list = inl ? reinterpret_cast<const uint16_t *>(&inline_all[kFat ? tid : 0])
-                                       : reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off;
-            idx = wedge_step<uint16_t>(list, lazy, wraw, n, pick, u2, K, nR, nM, x == s, need_mem,
-                                       reinterpret_cast<uint16_t *>(stage), lane);
-          }
-          N2V_CHECK_RANGE(2, idx, 0, n);
-          if (idx != pick) {
-            gather(vb + idx, h, wedge_new, head_new);
-            x = h.col;
+          const int nR = (int)fR, nM = need_mem ? (int)fM : 0, nO = n - nR - nM;
+          const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
+          const double avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;  // :172
+          const bool isR = x == s;
+          bool isM = false;
+          int64_t w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
+          int lo_pick = 0;  // entries of the edge's list below `pick`
+          if (need_mem && !isR && nM > 0)  // :226
+            lo_pick = wedge_lower(g.wedge_pos, w_off, nM, pick, w_wide, isM);
+          const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) / avg;  // :173
+          const double r2 = (double)u2 * (1.0 / 4294967296.0);
+          if (!(p_pick < 1.0 && r2 < p_pick)) {
+            const double vR = K.bR / avg, vM = K.bM / avg, vO = K.bO / avg;
+            const bool uR = vR < 1.0, uM = vM < 1.0, uO = vO < 1.0;
+            const bool any_under = (nR && uR) || (nM && uM) || (nO && uO);
+            const bool any_over = (nR && !uR) || (nM && !uM) || (nO && !uO);
+            if (!any_under || !any_over) {  // the loop of :182 never runs
+              if (!(r2 < p_pick)) idx = 0;
+            } else {
+              if (!w_loaded) {  // the return position (and an empty list)
+                N2V_CHECK_RANGE(3, e_prev, (int64_t)0, g.n_edges);
+                wraw = g.wedge_off[e_prev];
+                w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
+              }
+              const int w_rpos = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
+              const bool case_a = uO && !(nR && uR) && !(nM && uM);
+              const bool case_b = !uO && nO > 0 && (!nR || uR) && (!nM || uM);  // the mirror image
+              int res = -1;
+              // plain branches on the (uniform) list width: never a select between two loads
+              if (w_wide) {
+                const uint32_t *list = reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off;
+                if (case_a)
+                  res = lane_case_a_jump<uint32_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
+                else if (case_b)
+                  res = lane_case_b_jump<uint32_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
+                if (res < 0 && n > 64)
+                  res = case_a ? lane_case_a<uint32_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR,
+                                                       isM, stage, lane)
+                               : lane_pairing_list<uint32_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list);
+              } else {
+                const uint16_t *list = reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off;
+                if (case_a)
+                  res = lane_case_a_jump<uint16_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
+                else if (case_b)
+                  res = lane_case_b_jump<uint16_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
+                if (res < 0 && n > 64)
+                  res = case_a ? lane_case_a<uint16_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR,
+                                                       isM, reinterpret_cast<uint16_t *>(stage), lane)
+                               : lane_pairing_list<uint16_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list);
+              }
+              if (res < 0) {  // a short row: the two stacks as bit masks
+                uint64_t Rm = 0ull;
+                if (nR) Rm = ((nR >= 64) ? ~0ull : ((1ull << nR) - 1ull)) << w_rpos;
+                const uint64_t Mm = wedge_mask(g.wedge_pos, w_off, nM, w_wide);
+                res = lane_pairing(n, Rm, Mm, pick, r2, vR, vM, vO);
+              }
+              idx = res;
+              N2V_CHECK_RANGE(2, idx, 0, n);
+            }
+            if (idx != pick) {
+              h = load_hop(g.hops + vb + idx);
+              x = h.col;
+            }
           }
         }
       }
       emit(step + 1, x);
       e_prev = vb + idx;
       ec_prev = h.classes;
-      wedge_prev = wedge_new;
-      head_prev = head_new;
       s = v;
       v = x;
       if (step + 1 < walk_length) {
@@ -259,88 +226,24 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
   }
 }
 
-// hop entry + wedge offset + list head in one 32-byte record (struct n2v_hop2)
-__global__ __launch_bounds__(256) void hops2_build_kernel(n2v_graph g, n2v_hop2 *__restrict__ out,
-                                                          uint32_t *__restrict__ status) {
-  bool bad = false;
-  const bool wide = g.wedge_wide != 0;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < g.n_edges;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    const int32_t x = g.col[e];
-    const int64_t b = g.rowptr[x];
-    const int64_t d = g.rowptr[x + 1] - b;
-    bad = bad || d >= (1ll << (64 - N2V_HOP_DEG_SHIFT));
-    const uint64_t row = (uint64_t)b | ((uint64_t)d << N2V_HOP_DEG_SHIFT);
-    const uint32_t cls = g.edge_classes[e];
-    const uint64_t wraw = g.wedge_off[e];
-    const int64_t off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
-    const int cnt = (int)(cls & N2V_EC_SHARED_MASK);
-    uint64_t head = 0;
-    if (wide) {
-      const uint32_t *a = reinterpret_cast<const uint32_t *>(g.wedge_pos) + off;
-      for (int k = 0; k < 2 && k < cnt; ++k) head |= (uint64_t)a[k] << (32 * k);
-    } else {
-      const uint16_t *a = reinterpret_cast<const uint16_t *>(g.wedge_pos) + off;
-      for (int k = 0; k < 4 && k < cnt; ++k) head |= (uint64_t)a[k] << (16 * k);
-    }
-    int4 lo4, hi4;
-    lo4.x = x;
-    lo4.y = (int)cls;
-    lo4.z = (int)(uint32_t)row;
-    lo4.w = (int)(uint32_t)(row >> 32);
-    hi4.x = (int)(uint32_t)wraw;
-    hi4.y = (int)(uint32_t)(wraw >> 32);
-    hi4.z = (int)(uint32_t)head;
-    hi4.w = (int)(uint32_t)(head >> 32);
-    reinterpret_cast<int4 *>(out + e)[0] = lo4;
-    reinterpret_cast<int4 *>(out + e)[1] = hi4;
-  }
-  if (bad) atomicOr(status, N2V_ST_RANGE);
-}
-
 }  // namespace n2v
-
-extern "C" int n2v_hops2_build(const n2v_graph *g, n2v_hop2 *hops2_out, uint32_t *status,
-                               void *stream) {
-  if (!g || !g->rowptr || g->n_vertices < 0 || g->n_edges < 0) return N2V_EINVAL;
-  if (g->w || g->w64) return N2V_EINVAL;  // unit-weight graphs only
-  if (g->n_edges >= (1ll << N2V_HOP_DEG_SHIFT)) return N2V_EINVAL;
-  if (g->n_edges == 0) return N2V_OK;
-  if (!g->col || !g->edge_classes || !g->wedge_off || !g->wedge_pos || !hops2_out || !status)
-    return N2V_EINVAL;
-  int64_t blocks = (g->n_edges + 255) / 256;
-  const int64_t cap = n2v::resident_blocks((const void *)n2v::hops2_build_kernel, 256, 0) * 2;
-  if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(n2v::hops2_build_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                     (hipStream_t)stream, *g, hops2_out, status);
-  N2V_HIP_CHECK(hipGetLastError());
-  return N2V_OK;
-}
 
 // returns 1 when the kernel applies (and was launched), 0 when it does not, < 0 on error
 int n2v_walk_wedge_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
                        int32_t num_walks, int32_t walk_length, double p, double q,
                        const n2v::UnitConsts &K, uint64_t seed, int32_t *walks_out,
                        uint8_t *valid_out, uint32_t *status, void *stream) {
-  if (g->w || g->w64 || !g->wedge_pos) return 0;
-  const bool fat = g->hops2 != nullptr;
-  if (!fat && (!g->hops || !g->wedge_off)) return 0;
+  if (!g->hops || !g->wedge_off || !g->wedge_pos || g->w || g->w64) return 0;
   const int64_t total = n_start * (int64_t)num_walks;
   if (total >= 0xffffff00ll) return 0;
   if (total == 0) return 1;
   int64_t blocks = (total + n2v::kWedgeThreads - 1) / n2v::kWedgeThreads;
-  const void *fn = fat ? (const void *)n2v::walk_exact_wedge_kernel<true>
-                       : (const void *)n2v::walk_exact_wedge_kernel<false>;
-  const int64_t cap = n2v::resident_blocks(fn, n2v::kWedgeThreads, 0);
+  const int64_t cap = n2v::resident_blocks((const void *)n2v::walk_exact_wedge_kernel,
+                                           n2v::kWedgeThreads, 0);
   if (blocks > cap) blocks = cap;
-  if (fat)
-    hipLaunchKernelGGL(n2v::walk_exact_wedge_kernel<true>, dim3((unsigned)blocks),
-                       dim3(n2v::kWedgeThreads), 0, (hipStream_t)stream, *g, start_ids, n_start,
-                       num_walks, walk_length, p, q, K, seed, walks_out, valid_out, status);
-  else
-    hipLaunchKernelGGL(n2v::walk_exact_wedge_kernel<false>, dim3((unsigned)blocks),
-                       dim3(n2v::kWedgeThreads), 0, (hipStream_t)stream, *g, start_ids, n_start,
-                       num_walks, walk_length, p, q, K, seed, walks_out, valid_out, status);
+  hipLaunchKernelGGL(n2v::walk_exact_wedge_kernel, dim3((unsigned)blocks), dim3(n2v::kWedgeThreads), 0,
+                     (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, p, q, K, seed,
+                     walks_out, valid_out, status);
   if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
   return 1;
 }

@@ -40,8 +40,6 @@ class DeviceGraph:
         self.wedge_off: Optional[torch.Tensor] = None  # int64 [E]: list offset | return position << 40
         self.wedge_pos: Optional[torch.Tensor] = None  # int16 / int32 [sum of shared counts]
         self.wedge_tried = False  # randomwalk.walk tries to build the table once
-        self.hops2: Optional[torch.Tensor] = None  # int32 [E, 8] view of n2v_hop2[E] (biased walks)
-        self.hops2_tried = False
 
     @property
     def w(self) -> torch.Tensor:
@@ -130,7 +128,7 @@ class DeviceGraph:
     def to(self, device) -> "DeviceGraph":
         g = DeviceGraph(self.rowptr.to(device), self.col.to(device),
                         None if self._w is None else self._w.to(device))
-        for name in ("slots", "pivots", "edge_classes", "hops", "wedge_off", "wedge_pos", "hops2"):
+        for name in ("slots", "pivots", "edge_classes", "hops", "wedge_off", "wedge_pos"):
             t = getattr(self, name)
             if t is not None:
                 setattr(g, name, t.to(device))
@@ -149,8 +147,7 @@ class DeviceGraph:
                           0 if self.hops is None else self.hops.data_ptr(),
                           0 if self.wedge_off is None else self.wedge_off.data_ptr(),
                           0 if self.wedge_pos is None else self.wedge_pos.data_ptr(),
-                          0 if self.wedge_pos is None else int(self.wedge_pos.dtype == torch.int32), 0,
-                          0 if self.hops2 is None else self.hops2.data_ptr())
+                          0 if self.wedge_pos is None else int(self.wedge_pos.dtype == torch.int32), 0)
 
     # -- a9 -----------------------------------------------------------------------
     def trimmed(self, max_out_degree: int, seed: int) -> "DeviceGraph":
@@ -254,31 +251,6 @@ class DeviceGraph:
         if int(status[0].item()) & _lib.ST_RANGE:
             raise RuntimeError("n2v_wedge_build: list lengths disagree with edge_classes")
         self.wedge_off, self.wedge_pos = off, pos
-        return self
-
-    def build_hops2(self, max_bytes: Optional[int] = None) -> "DeviceGraph":
-        """32-byte hop table for biased exact walks (n2v_hops2_build): the hop entry plus the wedge
-        offset / return position of the edge and the head of its list, so that a step whose edge
-        shares at most 4 neighbours is one gather.  Needs the wedge table; 32 bytes per edge,
-        skipped when it would not fit in `max_bytes` (default: half of the free memory)."""
-        L = _lib.load()
-        _lib.require_gpu()
-        self.hops2 = None
-        if self.wedge_off is None or self.wedge_pos is None or self.n_edges == 0:
-            return self
-        if max_bytes is None:
-            max_bytes = torch.cuda.mem_get_info(self.device)[0] // 2
-        if 32 * self.n_edges > max_bytes or int(self.degrees().max()) >= self.HOP_MAX_DEGREE:
-            return self
-        out = torch.empty((self.n_edges, 8), dtype=torch.int32, device=self.device)
-        status = torch.zeros(4, dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
-            rc = L.n2v_hops2_build(self.c_struct(), out.data_ptr(), status.data_ptr(),
-                                   _lib.current_stream_ptr())
-        _lib.check(rc, "n2v_hops2_build")
-        if int(status[0].item()) & _lib.ST_RANGE:
-            return self
-        self.hops2 = out
         return self
 
     HOP_MAX_DEGREE = 1 << 24  # n2v_hop packs the degree into 24 bits

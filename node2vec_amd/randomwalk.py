@@ -65,7 +65,7 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
          return_param: float, inout_param: float, seed: int, mode: str = "exact",
          out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, check: bool = True,
          stats: Optional[dict] = None, use_edge_classes: bool = True, use_hops: bool = True,
-         use_wedges: bool = True, use_wedge_kernel: bool = True, use_hops2: bool = True):
+         use_wedges: bool = True, use_wedge_kernel: bool = True):
     """Launch K2.  Returns (walks int32 [n_start*num_walks, walk_length+1], valid bool).
 
     mode "fast", and on weighted graphs mode "exact" with return_param == inout_param == 1
@@ -113,10 +113,6 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
             if use_wedges and graph.wedge_off is None and not graph.wedge_tried:
                 graph.wedge_tried = True
                 graph.build_wedges()
-            if (use_hops and use_hops2 and graph.wedge_off is not None and graph.hops2 is None
-                    and not graph.hops2_tried):
-                graph.hops2_tried = True
-                graph.build_hops2()  # the wedge offset and list head inside the hop entry
     elif mode == "exact" and not biased and graph.slots is None:
         # the reference's default p = q = 1: every per-step table is the first-order table of
         # the current vertex, i.e. the K1 slots (bit-identical); build them once (milliseconds)
@@ -149,8 +145,6 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
         g.wedge_pos = 0
     if not use_wedge_kernel:  # keep the tables but walk with the lanes kernel (tests: same bits)
         g.reserved = 1
-    if not use_hops2 or not use_hops or not use_wedges or not use_edge_classes:
-        g.hops2 = 0
     with torch.cuda.device(graph.device):
         rc = L.n2v_walk(g, start_ids.data_ptr(), n_start, num_walks, walk_length,
                         float(return_param), float(inout_param), seed & (2 ** 64 - 1),

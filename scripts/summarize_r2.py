@@ -104,10 +104,10 @@ json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
 tpath = "profiles/pmc_traffic.json"
 table = json.load(open(tpath)) if os.path.exists(tpath) else {}
 if bench:
-    def put(kernel, p, q, batch, hops=False, wedges=False, hops2=False):
+    def put(kernel, p, q, batch, hops=False, wedges=False):
         e = out["kernels"].get(kernel)
         if e:
-            table[f"{config}:{kernel}{':hops' if hops else ''}{':wedges' if wedges else ''}{':hops2' if hops2 else ''}:p{p}:q{q}:batch{batch}"] = {
+            table[f"{config}:{kernel}{':hops' if hops else ''}{':wedges' if wedges else ''}:p{p}:q{q}:batch{batch}"] = {
                 "hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "source": f"profiles/{tag}_summary.json",
                 "FETCH_SIZE_KB": e["FETCH_SIZE_KB"], "WRITE_SIZE_KB": e["WRITE_SIZE_KB"],
                 "tcc_hit_rate": e["tcc_hit_rate"]}
@@ -118,8 +118,7 @@ if bench:
     if "biased" in bench:
         b = bench["biased"]
         put(b["roofline"]["kernel"], b["p"], b["q"], b["start_vertices_per_step"],
-            b["roofline"].get("hop_table", False), b["roofline"].get("wedge_table", False),
-            b["roofline"].get("hop2_table", False))
+            b["roofline"].get("hop_table", False), b["roofline"].get("wedge_table", False))
     if "fast_mode" in bench:
         b = bench["fast_mode"]
         put("walk_fast_kernel", b["p"], b["q"], b["start_vertices_per_step"],
