@@ -486,9 +486,12 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
     return N2V_ELAUNCH;
   // lookahead depth: 1 pair for dim <= 512, none above (registers).  Depth 2 was measured
   // twice at dim 128 and lost both times (628 vs 674 M pairs/s at equal occupancy).
+#ifndef N2V_SGNS_DEPTH
+#define N2V_SGNS_DEPTH(VV) ((VV) <= 8 ? 1 : 0)
+#endif
 #define N2V_LAUNCH(VV)                                                                       \
   do {                                                                                       \
-    constexpr int kD = (VV) <= 8 ? 1 : 0;                                                     \
+    constexpr int kD = N2V_SGNS_DEPTH(VV);                                                    \
     if (!P->deterministic) {                                                                 \
       const int64_t cap = resident_blocks((const void *)sgns_kernel<VV, kD>, (int)block.x, lds); \
       if (blocks > cap) blocks = cap;                                                        \

@@ -2,6 +2,9 @@
 tokens, count^0.75 table from Zipf-like counts.  python scripts/time_sgns_scale.py n_vocab [dim]"""
 import os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+from node2vec_amd import _lib
+if os.environ.get("N2V_VARIANT_LIB"):
+    _lib.LIB_PATH = os.environ["N2V_VARIANT_LIB"]  # developer build, loaded by path
 from node2vec_amd import sgns
 n_vocab = int(float(sys.argv[1])); dim = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 dev = "cuda"
@@ -21,4 +24,4 @@ for it in range(3):
     m.pairs.zero_(); torch.cuda.synchronize(); t = time.time()
     m.train_block(idx, 0.025, (it + 1) * idx.shape[0]); torch.cuda.synchronize(); best = min(best, time.time() - t)
 pairs = int(m.pairs.item())
-print(f"{os.path.basename(os.environ.get('N2V_HIP_LIB', 'in-tree'))} n_vocab {n_vocab} dim {dim}: {best*1e3:.1f} ms {pairs/best/1e6:.1f} Mpairs/s = {pairs/best*8*dim*7/1e12:.2f} TB/s algorithmic", flush=True)
+print(f"{os.path.basename(os.environ.get('N2V_VARIANT_LIB', 'in-tree'))} n_vocab {n_vocab} dim {dim}: {best*1e3:.1f} ms {pairs/best/1e6:.1f} Mpairs/s = {pairs/best*8*dim*7/1e12:.2f} TB/s algorithmic", flush=True)
