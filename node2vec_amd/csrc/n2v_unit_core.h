@@ -37,6 +37,7 @@ struct UnitConsts {
   double bR, bM, bO;     // 1/p, 1, 1/q
   int64_t TR, TM, TO;    // the same times 2^20 (exact integers; dyadic kernel only)
   int64_t gR, gM, gO;    // TR, TM, TO divided by their greatest common divisor
+  double fR, fM, fO;     // the same as fp64 (exact): the closed forms compute in doubles
 };
 
 __device__ __forceinline__ int biased_exp(double x) {
@@ -218,17 +219,16 @@ __device__ __forceinline__ int lane_case_a(int n, int pick, double r2, double vR
   return (r2 < p_pick) ? pick : alias_pick;
 }
 
-// floor(a / b) for 0 <= a < 2^52, 0 < b < 2^52 through one fp64 division and an exact integer
-// correction (64-bit integer division is a ~150-instruction emulation on this hardware, and the
-// closed forms below need three to five quotients per draw)
-__device__ __forceinline__ int64_t floor_div(int64_t a, int64_t b) {
-  int64_t qd = (int64_t)((double)a / (double)b);
-  int64_t r = a - qd * b;
-  if (r < 0) {
-    --qd;
-    r += b;
-  }
-  if (r >= b) ++qd;
+// The closed forms below do exact INTEGER arithmetic in fp64: every quantity is an integer below
+// 2^53 (guarded), for which +, -, * and fma are exact, and a quotient is one fp64 division plus an
+// exact correction.  (As int64 the same code cost ~5x the instructions -- 64-bit multiply, divide
+// and int64 <-> fp64 conversion are emulated on this hardware -- and the kernel is bound by
+// instruction issue: profiles/r02n_cfg4_summary.json, 6 waves x 18 % issuing.)
+__device__ __forceinline__ double floor_div(double a, double b) {  // 0 <= a, 0 < b, integers
+  double qd = floor(a / b);
+  const double r = fma(-qd, b, a);  // exact
+  if (r < 0.0) qd -= 1.0;
+  if (r >= b) qd += 1.0;
   return qd;
 }
 
@@ -254,11 +254,12 @@ __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, cons
                                                 int nR, int rpos, int nM, const P *list,
                                                 bool pickR, bool pickM, int lo_pick) {
   const int nO = n - nR - nM;
-  const int64_t isum = (int64_t)nR * K.gR + (int64_t)nM * K.gM + (int64_t)nO * K.gO;
-  const int64_t EM = K.gM * n - isum, ER = K.gR * n - isum, D = isum - K.gO * n;
-  if (D <= 0 || (nM > 0 && EM <= 0) || (nR > 0 && ER <= 0)) return -1;
-  const double big = (double)(K.gR > K.gM ? K.gR : K.gM);
-  if ((double)n * (double)isum > 2.0e14 || (double)n * (double)n * big > 4.0e18) return -1;
+  const double dn = (double)n;
+  const double isum = (double)nR * K.fR + (double)nM * K.fM + (double)nO * K.fO;
+  const double EM = K.fM * dn - isum, ER = K.fR * dn - isum, D = isum - K.fO * dn;
+  if (!(D > 0.0) || (nM > 0 && !(EM > 0.0)) || (nR > 0 && !(ER > 0.0))) return -1;
+  // exactness of the arithmetic (products < 2^52) and of the decisions (4 n 1e-15 < 1 / isum)
+  if (dn * isum > 2.0e14 || dn * dn * fmax(K.fR, K.fM) > 4.0e15) return -1;
   int mA = nM;  // shared slots above the return run come first in descending order
   if (nR > 0 && nM > 0) {
     int lo = 0, hi = nM;
@@ -272,10 +273,11 @@ __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, cons
     mA = nM - lo;
   }
   const int N = nM + nR;
-  auto X_of = [&](int64_t i) -> int64_t {
-    if (i <= mA) return i * EM;
-    if (i <= mA + nR) return (int64_t)mA * EM + (i - mA) * ER;
-    return (int64_t)mA * EM + (int64_t)nR * ER + (i - mA - nR) * EM;
+  const double dmA = (double)mA, dnR = (double)nR;
+  auto X_of = [&](double i) -> double {
+    if (i <= dmA) return i * EM;
+    if (i <= dmA + dnR) return dmA * EM + (i - dmA) * ER;
+    return dmA * EM + dnR * ER + (i - dmA - dnR) * EM;
   };
   auto pos_of = [&](int i) -> int {  // position of the i-th overfull slot, i = 1 .. N
     if (i <= mA) return (int)list[nM - i];
@@ -285,24 +287,24 @@ __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, cons
   if (!pickR && !pickM) {
     int above_r = rpos + nR - 1 - pick;
     above_r = above_r < 0 ? 0 : (above_r > nR ? nR : above_r);
-    const int64_t r = (int64_t)(n - 1 - pick) - (nM - lo_pick) - above_r;
-    const int64_t T = r * D;
-    int64_t i;
-    if (T <= 0) {
-      i = 1;
-    } else if (mA > 0 && (int64_t)mA * EM >= T) {
-      i = floor_div(T + EM - 1, EM);
+    const double r = (double)((n - 1 - pick) - (nM - lo_pick) - above_r);
+    const double T = r * D;
+    double i;
+    if (T <= 0.0) {
+      i = 1.0;
+    } else if (mA > 0 && dmA * EM >= T) {
+      i = floor_div(T + EM - 1.0, EM);
     } else {
-      const int64_t X1 = (int64_t)mA * EM;
-      if (nR > 0 && X1 + (int64_t)nR * ER >= T)
-        i = mA + floor_div(T - X1 + ER - 1, ER);
+      const double X1 = dmA * EM;
+      if (nR > 0 && X1 + dnR * ER >= T)
+        i = dmA + floor_div(T - X1 + ER - 1.0, ER);
       else
-        i = mA + nR + floor_div(T - X1 - (int64_t)nR * ER + EM - 1, EM);
+        i = dmA + dnR + floor_div(T - X1 - dnR * ER + EM - 1.0, EM);
     }
-    if (i < 1 || i > N || X_of(i) == T) return -1;  // a tie: fp64 rounding decides
+    if (!(i >= 1.0) || i > (double)N || X_of(i) == T) return -1;  // a tie: fp64 rounding decides
     return pos_of((int)i);  // r2 >= probs[pick] here: the caller's quick exit took the other case
   }
-  int64_t i0;
+  int i0;
   if (pickR) {
     i0 = mA + (nR - (pick - rpos));
   } else {
@@ -310,13 +312,113 @@ __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, cons
     i0 = d <= mA ? d : d + nR;
   }
   if (i0 < 1 || i0 >= N) return -1;  // the last overfull slot ends at exactly 1.0: fp64 decides
-  const int64_t X = X_of(i0);
-  const int64_t xq = floor_div(X, D);
-  if (X - xq * D == 0) return -1;
-  const int64_t rem = X - (xq + 1) * D;  // in (-D, 0)
-  const double prob = 1.0 + (double)rem / (double)isum;
+  const double X = X_of((double)i0);
+  const double xq = floor_div(X, D);
+  const double rem0 = fma(-xq, D, X);  // X mod D, exact
+  if (rem0 == 0.0) return -1;
+  const double prob = 1.0 + (rem0 - D) / isum;  // demoted at 1 + (X - (xq + 1) D) / isum
   if (fabs(prob - r2) < 1e-9) return -1;
-  return (r2 < prob) ? pick : pos_of((int)i0 + 1);
+  return (r2 < prob) ? pick : pos_of(i0 + 1);
+}
+
+// ---- the mirror arrangement in closed form: "other" is the OVERFULL class and every return /
+// shared slot is underfull (what q < 1 gives: cfg 5's p = 4, q = 0.25).  Now the few listed slots
+// are the underfull stack (popped from the highest position) and the long runs of "other" slots
+// the overfull one: an underfull slot of deficit d = isum - g n is paired with the current
+// "other" slot, whose excess e = gO n - isum is tiny, so that slot is demoted and the rest of the
+// deficit cascades down the "other" slots until their cumulative excess covers it.  In exact
+// arithmetic, with Y_j the cumulative deficit of the first j listed slots (descending position):
+//   * listed slot j is paired with the "other" slot of rank ceil(Y_(j-1) / e) (rank 1 for j = 1);
+//   * the "other" slot of rank t < nO is demoted while slot j(t) = min { j : Y_j > t e } is being
+//     absorbed, ends at 1 + (t e - Y_j(t)) / isum and is paired with the "other" slot of rank
+//     t + 1; the last one ends at exactly 1.0 (mass balance: Y_S = nO e) -- fp64 decides.
+// Same exactness argument and the same -1 cases as lane_case_a_jump; checked against the
+// reference loop in Python (0 mismatches in 180 k short and 5.7 k long rows, 2-10 % return -1).
+template <typename P>
+__device__ __forceinline__ int lane_case_b_jump(int n, int pick, double r2, const UnitConsts &K,
+                                                int nR, int rpos, int nM, const P *list,
+                                                bool pickR, bool pickM, int lo_pick) {
+  const int nO = n - nR - nM;
+  const double dn = (double)n;
+  const double isum = (double)nR * K.fR + (double)nM * K.fM + (double)nO * K.fO;
+  const double e = K.fO * dn - isum, dR = isum - K.fR * dn, dM = isum - K.fM * dn;
+  if (nO <= 0 || !(e > 0.0) || (nM > 0 && !(dM > 0.0)) || (nR > 0 && !(dR > 0.0))) return -1;
+  if (dn * isum > 2.0e14 || dn * dn * K.fO > 4.0e15) return -1;
+  auto list_lower = [&](int pos) -> int {  // entries of the list below pos
+    int lo = 0, hi = nM;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((int)list[mid] < pos)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    return lo;
+  };
+  int mA = nM;  // shared slots above the return run come first in descending order
+  if (nR > 0 && nM > 0) mA = nM - list_lower(rpos);
+  const int S = nM + nR;
+  const double dmA = (double)mA, dnR = (double)nR;
+  auto Y_of = [&](double j) -> double {
+    if (j <= dmA) return j * dM;
+    if (j <= dmA + dnR) return dmA * dM + (j - dmA) * dR;
+    return dmA * dM + dnR * dR + (j - dmA - dnR) * dM;
+  };
+  auto specials_ge = [&](int pos) -> int {  // listed + return slots at positions >= pos
+    int r = rpos + nR - pos;
+    r = r < 0 ? 0 : (r > nR ? nR : r);
+    return (nM - list_lower(pos)) + r;
+  };
+  auto other_pos = [&](int t) -> int {  // position of the t-th "other" slot from the top
+    int c = 0;
+    for (int it = 0; it < 64; ++it) {
+      const int c2 = specials_ge(n - t - c);
+      if (c2 == c) return n - t - c;
+      c = c2;
+    }
+    return -1;
+  };
+  if (pickR || pickM) {  // underfull: r2 >= its value here (the caller's quick exit took the rest)
+    int j;
+    if (pickR) {
+      j = mA + (nR - (pick - rpos));
+    } else {
+      const int d = nM - lo_pick;
+      j = d <= mA ? d : d + nR;
+    }
+    if (j < 1 || j > S) return -1;
+    double t = 1.0;
+    if (j > 1) {
+      const double Yp = Y_of((double)(j - 1));
+      t = floor_div(Yp + e - 1.0, e);
+      if (t * e == Yp) return -1;  // that slot holds exactly 1.0: fp64 decides whether it was demoted
+    }
+    if (!(t >= 1.0) || t > (double)nO) return -1;
+    return other_pos((int)t);
+  }
+  int ar = rpos + nR - 1 - pick;  // return slots above pick
+  ar = ar < 0 ? 0 : (ar > nR ? nR : ar);
+  const int t = (n - pick) - (nM - lo_pick) - ar;  // rank of pick among "other", from 1
+  if (t < 1 || t >= nO) return -1;  // the last one ends at exactly 1.0
+  const double T = (double)t * e;
+  double j;  // smallest j with Y_j > T
+  if (mA > 0 && dmA * dM > T) {
+    j = floor_div(T, dM) + 1.0;
+  } else {
+    const double Y1 = dmA * dM;
+    if (nR > 0 && Y1 + dnR * dR > T)
+      j = dmA + floor_div(T - Y1, dR) + 1.0;
+    else if (dM > 0.0)
+      j = dmA + dnR + floor_div(T - Y1 - dnR * dR, dM) + 1.0;
+    else
+      return -1;
+  }
+  if (!(j >= 1.0) || j > (double)S) return -1;
+  if (j > 1.0 && Y_of(j - 1.0) == T) return -1;  // exactly 1.0 after the previous listed slot
+  const double prob = 1.0 + (T - Y_of(j)) / isum;
+  if (fabs(prob - r2) < 1e-9) return -1;
+  if (r2 < prob) return pick;
+  return other_pos(t + 1);
 }
 
 __device__ __forceinline__ uint64_t wedge_mask(const void *base, int64_t off, int cnt, bool wide) {
@@ -386,104 +488,6 @@ __device__ __forceinline__ int lane_pairing(int n, uint64_t Rm, uint64_t Mm, int
     }
   }
   return (r2 < p_pick) ? pick : alias_pick;
-}
-
-// ---- the mirror arrangement in closed form: "other" is the OVERFULL class and every return /
-// shared slot is underfull (what q < 1 gives: cfg 5's p = 4, q = 0.25).  Now the few listed slots
-// are the underfull stack (popped from the highest position) and the long runs of "other" slots
-// the overfull one: an underfull slot of deficit d = isum - g n is paired with the current
-// "other" slot, whose excess e = gO n - isum is tiny, so that slot is demoted and the rest of the
-// deficit cascades down the "other" slots until their cumulative excess covers it.  In exact
-// arithmetic, with Y_j the cumulative deficit of the first j listed slots (descending position):
-//   * listed slot j is paired with the "other" slot of rank ceil(Y_(j-1) / e) (rank 1 for j = 1);
-//   * the "other" slot of rank t < nO is demoted while slot j(t) = min { j : Y_j > t e } is being
-//     absorbed, ends at 1 + (t e - Y_j(t)) / isum and is paired with the "other" slot of rank
-//     t + 1; the last one ends at exactly 1.0 (mass balance: Y_S = nO e) -- fp64 decides.
-// Same exactness argument and the same -1 cases as lane_case_a_jump; checked against the
-// reference loop in Python (0 mismatches in 180 k short and 5.7 k long rows, 2-10 % return -1).
-template <typename P>
-__device__ __forceinline__ int lane_case_b_jump(int n, int pick, double r2, const UnitConsts &K,
-                                                int nR, int rpos, int nM, const P *list,
-                                                bool pickR, bool pickM, int lo_pick) {
-  const int nO = n - nR - nM;
-  const int64_t isum = (int64_t)nR * K.gR + (int64_t)nM * K.gM + (int64_t)nO * K.gO;
-  const int64_t e = K.gO * n - isum, dR = isum - K.gR * n, dM = isum - K.gM * n;
-  if (nO <= 0 || e <= 0 || (nM > 0 && dM <= 0) || (nR > 0 && dR <= 0)) return -1;
-  if ((double)n * (double)isum > 2.0e14 || (double)n * (double)n * (double)K.gO > 4.0e18) return -1;
-  auto list_lower = [&](int pos) -> int {  // entries of the list below pos
-    int lo = 0, hi = nM;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if ((int)list[mid] < pos)
-        lo = mid + 1;
-      else
-        hi = mid;
-    }
-    return lo;
-  };
-  int mA = nM;  // shared slots above the return run come first in descending order
-  if (nR > 0 && nM > 0) mA = nM - list_lower(rpos);
-  const int S = nM + nR;
-  auto Y_of = [&](int64_t j) -> int64_t {
-    if (j <= mA) return j * dM;
-    if (j <= mA + nR) return (int64_t)mA * dM + (j - mA) * dR;
-    return (int64_t)mA * dM + (int64_t)nR * dR + (j - mA - nR) * dM;
-  };
-  auto specials_ge = [&](int pos) -> int {  // listed + return slots at positions >= pos
-    int r = rpos + nR - pos;
-    r = r < 0 ? 0 : (r > nR ? nR : r);
-    return (nM - list_lower(pos)) + r;
-  };
-  auto other_pos = [&](int64_t t) -> int {  // position of the t-th "other" slot from the top
-    int c = 0;
-    for (int it = 0; it < 64; ++it) {
-      const int c2 = specials_ge((int)(n - t - c));
-      if (c2 == c) return (int)(n - t - c);
-      c = c2;
-    }
-    return -1;
-  };
-  if (pickR || pickM) {  // underfull: r2 >= its value here (the caller's quick exit took the rest)
-    int64_t j;
-    if (pickR) {
-      j = mA + (nR - (pick - rpos));
-    } else {
-      const int d = nM - lo_pick;
-      j = d <= mA ? d : d + nR;
-    }
-    if (j < 1 || j > S) return -1;
-    int64_t t = 1;
-    if (j > 1) {
-      const int64_t Yp = Y_of(j - 1);
-      t = floor_div(Yp + e - 1, e);
-      if (t * e == Yp) return -1;  // that slot holds exactly 1.0: fp64 decides whether it was demoted
-    }
-    if (t < 1 || t > nO) return -1;
-    return other_pos(t);
-  }
-  int ar = rpos + nR - 1 - pick;  // return slots above pick
-  ar = ar < 0 ? 0 : (ar > nR ? nR : ar);
-  const int64_t t = (int64_t)(n - pick) - (nM - lo_pick) - ar;  // rank of pick among "other", from 1
-  if (t < 1 || t >= nO) return -1;  // the last one ends at exactly 1.0
-  const int64_t T = t * e;
-  int64_t j;  // smallest j with Y_j > T
-  if (mA > 0 && (int64_t)mA * dM > T) {
-    j = floor_div(T, dM) + 1;
-  } else {
-    const int64_t Y1 = (int64_t)mA * dM;
-    if (nR > 0 && Y1 + (int64_t)nR * dR > T)
-      j = mA + floor_div(T - Y1, dR) + 1;
-    else if (dM > 0)
-      j = mA + nR + floor_div(T - Y1 - (int64_t)nR * dR, dM) + 1;
-    else
-      return -1;
-  }
-  if (j < 1 || j > S) return -1;
-  if (j > 1 && Y_of(j - 1) == T) return -1;  // exactly 1.0 after the previous listed slot
-  const double prob = 1.0 + (double)(T - Y_of(j)) / (double)isum;
-  if (fabs(prob - r2) < 1e-9) return -1;
-  if (r2 < prob) return pick;
-  return other_pos(t + 1);
 }
 
 // ---- any row, any arrangement of the classes: the loop of :175-189 slot by slot, by one lane.

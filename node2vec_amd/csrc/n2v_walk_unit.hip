@@ -1610,6 +1610,9 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
       K.gO = K.TO / a;
     }
   }
+  K.fR = (double)K.gR;
+  K.fM = (double)K.gM;
+  K.fO = (double)K.gO;
   const bool ordinary = K.bR >= 0x1p-20 && K.bR <= 0x1p20 && K.bO >= 0x1p-20 && K.bO <= 0x1p20;
   if (!dyadic && !ordinary) return 0;
   const int64_t total = n_start * (int64_t)num_walks;

@@ -153,8 +153,11 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
           const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) / avg;  // :173
           const double r2 = (double)u2 * (1.0 / 4294967296.0);
           if (!(p_pick < 1.0 && r2 < p_pick)) {
-            const double vR = K.bR / avg, vM = K.bM / avg, vO = K.bO / avg;
-            const bool uR = vR < 1.0, uM = vM < 1.0, uO = vO < 1.0;
+            // underfull / overfull by class without dividing: for correctly rounded fp64 division
+            // fl(b / avg) < 1.0 <=> b < avg (b < avg gives a quotient <= 1 - ulp(avg) / avg <=
+            // 1 - 2^-53, which rounds below 1.0; b >= avg gives >= 1).  The class VALUES are only
+            // needed by the step-by-step replays.
+            const bool uR = K.bR < avg, uM = K.bM < avg, uO = K.bO < avg;
             const bool any_under = (nR && uR) || (nM && uM) || (nO && uO);
             const bool any_over = (nR && !uR) || (nM && !uM) || (nO && !uO);
             if (!any_under || !any_over) {  // the loop of :182 never runs
@@ -176,26 +179,33 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
                   res = lane_case_a_jump<uint32_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
                 else if (case_b)
                   res = lane_case_b_jump<uint32_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
-                if (res < 0 && n > 64)
-                  res = case_a ? lane_case_a<uint32_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR,
-                                                       isM, stage, lane)
-                               : lane_pairing_list<uint32_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list);
               } else {
                 const uint16_t *list = reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off;
                 if (case_a)
                   res = lane_case_a_jump<uint16_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
                 else if (case_b)
                   res = lane_case_b_jump<uint16_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
-                if (res < 0 && n > 64)
-                  res = case_a ? lane_case_a<uint16_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR,
-                                                       isM, reinterpret_cast<uint16_t *>(stage), lane)
-                               : lane_pairing_list<uint16_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list);
               }
-              if (res < 0) {  // a short row: the two stacks as bit masks
-                uint64_t Rm = 0ull;
-                if (nR) Rm = ((nR >= 64) ? ~0ull : ((1ull << nR) - 1ull)) << w_rpos;
-                const uint64_t Mm = wedge_mask(g.wedge_pos, w_off, nM, w_wide);
-                res = lane_pairing(n, Rm, Mm, pick, r2, vR, vM, vO);
+              if (res < 0) {  // fp64 rounding decides: replay the loop
+                const double vR = K.bR / avg, vM = K.bM / avg, vO = K.bO / avg;
+                if (n > 64) {
+                  if (w_wide) {
+                    const uint32_t *list = reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off;
+                    res = case_a ? lane_case_a<uint32_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR,
+                                                         isM, stage, lane)
+                                 : lane_pairing_list<uint32_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list);
+                  } else {
+                    const uint16_t *list = reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off;
+                    res = case_a ? lane_case_a<uint16_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR,
+                                                         isM, reinterpret_cast<uint16_t *>(stage), lane)
+                                 : lane_pairing_list<uint16_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list);
+                  }
+                } else {  // a short row: the two stacks as bit masks
+                  uint64_t Rm = 0ull;
+                  if (nR) Rm = ((nR >= 64) ? ~0ull : ((1ull << nR) - 1ull)) << w_rpos;
+                  const uint64_t Mm = wedge_mask(g.wedge_pos, w_off, nM, w_wide);
+                  res = lane_pairing(n, Rm, Mm, pick, r2, vR, vM, vO);
+                }
               }
               idx = res;
               N2V_CHECK_RANGE(2, idx, 0, n);
