@@ -311,7 +311,11 @@ __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, cons
     const int d = nM - lo_pick;  // pick is the d-th shared slot from the top
     i0 = d <= mA ? d : d + nR;
   }
-  if (i0 < 1 || i0 >= N) return -1;  // the last overfull slot ends at exactly 1.0: fp64 decides
+  if (i0 < 1 || i0 > N) return -1;
+  // the last overfull slot ends at exactly 1.0 in exact arithmetic (mass balance), i.e. within the
+  // accumulated rounding of it in fp64 -- or is never reached and keeps its value >= 1; either way
+  // probs[pick] > 1 - 1e-9 > r2 (r2 <= 1 - 2^-32): sampling_from_alias returns pick
+  if (i0 == N) return pick;
   const double X = X_of((double)i0);
   const double xq = floor_div(X, D);
   const double rem0 = fma(-xq, D, X);  // X mod D, exact
@@ -399,7 +403,11 @@ __device__ __forceinline__ int lane_case_b_jump(int n, int pick, double r2, cons
   int ar = rpos + nR - 1 - pick;  // return slots above pick
   ar = ar < 0 ? 0 : (ar > nR ? nR : ar);
   const int t = (n - pick) - (nM - lo_pick) - ar;  // rank of pick among "other", from 1
-  if (t < 1 || t >= nO) return -1;  // the last one ends at exactly 1.0
+  if (t < 1 || t > nO) return -1;
+  // the last "other" slot ends at exactly 1.0 in exact arithmetic (mass balance: Y_S = nO e), i.e.
+  // within the accumulated rounding of it in fp64 -- or is never reached and keeps its value
+  // >= 1; either way probs[pick] > 1 - 1e-9 > r2 (r2 <= 1 - 2^-32): the draw returns pick
+  if (t == nO) return pick;
   const double T = (double)t * e;
   double j;  // smallest j with Y_j > T
   if (mA > 0 && dmA * dM > T) {

@@ -128,7 +128,12 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
       // Steps whose edge has no shared neighbour need it only if the pairing runs (lazy).
       uint64_t wraw = 0;
       bool w_loaded = false;
-      if (counts_ok && ((need_mem && fM > 0) || (always_pair && (fM > 0 || fR > 0)))) {
+#ifdef N2V_ABLATE_W
+      const bool early_ok = N2V_ABLATE_W != 3;
+#else
+      const bool early_ok = true;
+#endif
+      if (counts_ok && ((need_mem && fM > 0) || (early_ok && always_pair && (fM > 0 || fR > 0)))) {
         N2V_CHECK_RANGE(3, e_prev, (int64_t)0, g.n_edges);
         wraw = g.wedge_off[e_prev];
         w_loaded = true;
@@ -186,6 +191,9 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
                 else if (case_b)
                   res = lane_case_b_jump<uint16_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
               }
+#ifdef N2V_ABLATE_W
+              if (N2V_ABLATE_W == 1 && case_b) res = pick;  // timing-only: no closed form at all
+#endif
               if (res < 0) {  // fp64 rounding decides: replay the loop
                 const double vR = K.bR / avg, vM = K.bM / avg, vO = K.bO / avg;
                 if (n > 64) {
@@ -210,6 +218,9 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
               idx = res;
               N2V_CHECK_RANGE(2, idx, 0, n);
             }
+#ifdef N2V_ABLATE_W
+            if (N2V_ABLATE_W == 2) idx = pick;  // timing-only: never a second gather
+#endif
             if (idx != pick) {
               h = load_hop(g.hops + vb + idx);
               x = h.col;
