@@ -498,6 +498,128 @@ __device__ __forceinline__ int lane_pairing(int n, uint64_t Rm, uint64_t Mm, int
   return (r2 < p_pick) ? pick : alias_pick;
 }
 
+// ---- the mirror arrangement replayed run by run (the fallback of lane_case_b_jump on long
+// rows): the listed slots are the underfull stack, the "other" slots ONE run of equal overfull
+// values vO in [1, 2).  A listed slot is absorbed by the current "other" slot; if that drops
+// below 1 its rest cascades down the run, and a cascade through equal values has a closed form
+// (the one of unit_draw, n2v_walk_unit.hip): the first slot is fl(fl(vO + a) - 1) -- the
+// reference's two operations --, and while slots keep being demoted vO + a < 2, every operand is
+// a multiple of 2^-52 below 2 and the sums are exact: slot i holds a1 + (i - 1)(vO - 1) EXACTLY,
+// so the number of demoted slots is an integer search seeded by one multiplication and fixed up
+// with exact products, and only the slot that settles (its sum reaches [2, 3) and may round) is
+// recomputed with the two real operations.  O(listed slots) iterations, no pass over the row.
+// `list` = the shared positions, ascending.
+template <typename P>
+__device__ __forceinline__ int lane_case_b(int n, int pick, double r2, double vR, double vM,
+                                           double vO, int nR, int rpos, int nM, const P *list,
+                                           bool pickR, bool pickM) {
+  const int nO = n - nR - nM;
+  auto list_lower = [&](int pos) -> int {  // entries of the list below pos
+    int lo = 0, hi = nM;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((int)list[mid] < pos)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    return lo;
+  };
+  auto specials_ge = [&](int pos) -> int {
+    int r = rpos + nR - pos;
+    r = r < 0 ? 0 : (r > nR ? nR : r);
+    return (nM - list_lower(pos)) + r;
+  };
+  auto other_pos = [&](int t) -> int {  // position of the t-th "other" slot from the top; 0 if none
+    if (t < 1 || t > nO) return 0;
+    int c = 0;
+    for (int it = 0; it < 64; ++it) {
+      const int c2 = specials_ge(n - t - c);
+      if (c2 == c) return n - t - c;
+      c = c2;
+    }
+    // more than 64 corrections: count the "other" slots from the top one by one (never observed)
+    int seen = 0, km = nM - 1;
+    for (int i = n - 1; i >= 0; --i) {
+      while (km >= 0 && (int)list[km] > i) --km;
+      const bool special = (i >= rpos && i < rpos + nR) || (km >= 0 && (int)list[km] == i);
+      if (!special && ++seen == t) return i;
+    }
+    return 0;
+  };
+  // rank of pick among the "other" slots (1 = highest position), 0 if pick is listed
+  int pick_rank = 0;
+  if (!pickR && !pickM) pick_rank = (n - pick) - specials_ge(pick + 1);
+  const double d = vO - 1.0;  // exact (vO in [1, 2))
+  const double inv = d > 0.0 ? 1.0 / d : 0.0;
+  int km = nM - 1, kr = nR - 1;  // next shared / return slot, descending
+  int t_used = 0;                // "other" slots of rank <= t_used have been demoted
+  bool have_cur = false;         // rank t_used + 1 is the current overfull slot, at cur_val >= 1
+  double cur_val = 0.0;
+  for (;;) {
+    const int pm = km >= 0 ? (int)list[km] : -1;
+    const int pr = kr >= 0 ? rpos + kr : -1;
+    if (pm < 0 && pr < 0) break;  // underfull is empty (:182)
+    if (!have_cur && t_used >= nO) break;  // overfull is empty (:182)
+    int ui;
+    double uv;
+    if (pm > pr) {
+      ui = pm;
+      uv = vM;
+      --km;
+    } else {
+      ui = pr;
+      uv = vR;
+      --kr;
+    }
+    const int over_rank = t_used + 1;
+    if (ui == pick) return other_pos(over_rank);  // alias[pick]; r2 >= probs[pick] here
+    double a = (have_cur ? cur_val : vO) + uv - 1.0;  // :185
+    if (!(a < 1.0)) {
+      cur_val = a;
+      have_cur = true;
+      continue;
+    }
+    // rank `over_rank` is demoted at a, paired next with rank over_rank + 1 (if any)
+    if (pick_rank == over_rank) return (r2 < a) ? pick : other_pos(over_rank + 1);
+    t_used = over_rank;
+    have_cur = false;
+    const int avail = nO - t_used;  // untouched "other" slots, all at vO
+    if (avail <= 0) break;          // overfull is empty: the rest stays on underfull
+    const double a1 = vO + a - 1.0;  // slot 1 of the cascade, the reference's two operations
+    if (!(a1 < 1.0)) {
+      cur_val = a1;
+      have_cur = true;
+      continue;
+    }
+    const double need = 1.0 - a1;  // exact, > 0
+    const double m1 = (double)(avail - 1);
+    if (m1 * d < need) {  // every remaining slot is demoted: slot i holds a1 + (i - 1) d exactly
+      if (pick_rank > t_used) {
+        const double pv = a1 + (double)(pick_rank - t_used - 1) * d;
+        return (r2 < pv) ? pick : other_pos(pick_rank + 1);  // the last one keeps alias 0
+      }
+      break;
+    }
+    // j = the first i >= 1 with a1 + i d >= 1: slots 1 .. j are demoted, slot j + 1 settles
+    double j = fmin(fmax(ceil(need * inv), 1.0), m1);
+    while (j * d < need) j += 1.0;
+    while (j >= 2.0 && (j - 1.0) * d >= need) j -= 1.0;
+    const int jd = (int)j;
+    if (pick_rank > t_used && pick_rank <= t_used + jd) {
+      const double pv = a1 + (double)(pick_rank - t_used - 1) * d;
+      return (r2 < pv) ? pick : other_pos(pick_rank + 1);
+    }
+    const double a_prev = a1 + (j - 1.0) * d;  // slot j: exact, < 1
+    cur_val = vO + a_prev - 1.0;               // the slot that settles: real operations
+    t_used += jd;
+    have_cur = true;
+  }
+  // pick was never paired: an "other" slot keeps a value >= 1 (returns pick: r2 < 1), a listed
+  // slot keeps its value <= r2 and alias 0
+  return (pickR || pickM) ? 0 : pick;
+}
+
 // ---- any row, any arrangement of the classes: the loop of :175-189 slot by slot, by one lane.
 // The two stacks are walked as two descending cursors over the positions of the row; the class
 // of a position is read off the (ascending) shared list and the return run on the way down, so

@@ -201,12 +201,14 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
                     const uint32_t *list = reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off;
                     res = case_a ? lane_case_a<uint32_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR,
                                                          isM, stage, lane)
-                                 : lane_pairing_list<uint32_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list);
+                          : case_b ? lane_case_b<uint32_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR, isM)
+                                   : lane_pairing_list<uint32_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list);
                   } else {
                     const uint16_t *list = reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off;
                     res = case_a ? lane_case_a<uint16_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR,
                                                          isM, reinterpret_cast<uint16_t *>(stage), lane)
-                                 : lane_pairing_list<uint16_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list);
+                          : case_b ? lane_case_b<uint16_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR, isM)
+                                   : lane_pairing_list<uint16_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list);
                   }
                 } else {  // a short row: the two stacks as bit masks
                   uint64_t Rm = 0ull;
