@@ -47,6 +47,7 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
   // 1/q > 1: "other" is overfull, an overfull `pick` has no quick exit, so nearly every step runs
   // the pairing and needs the return position: request the wedge offset with the hop, always
   const bool always_pair = K.bO > 1.0;
+  const bool merge_r = K.bR == K.bO;
   const bool base_aligned = (reinterpret_cast<uintptr_t>(walks_out) & 63u) == 0;
 #ifdef N2V_CHECK
   n2v_check_status = status;
@@ -146,10 +147,12 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
           // n2v_hip.h, n2v_wedge_build); flag it and keep `pick` rather than read garbage
           atomicOr(status, N2V_ST_RANGE);
         } else {
-          const int nR = (int)fR, nM = need_mem ? (int)fM : 0, nO = n - nR - nM;
+          // p == q: the return slot carries the same value as an "other" slot -- it IS one, as far
+          // as the table is concerned (randomwalk.py:223-230 give both w / p == w / q)
+          const int nR = merge_r ? 0 : (int)fR, nM = need_mem ? (int)fM : 0, nO = n - nR - nM;
           const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
           const double avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;  // :172
-          const bool isR = x == s;
+          const bool isR = !merge_r && x == s;
           bool isM = false;
           int64_t w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
           int lo_pick = 0;  // entries of the edge's list below `pick`

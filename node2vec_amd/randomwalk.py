@@ -35,11 +35,13 @@ def tables_regime(p: float, q: float) -> bool:
     """The (p, q) for which exact walks on a unit-weight graph run from the per-edge tables alone
     (class counts + wedge lists + hop table, csrc/n2v_walk_wedge.hip): dyadic values for which
     the bulk class "other" is alone on its stack on ordinary rows -- the only underfull class
-    (1/q <= 1, 1/p >= 1/q: the lanes regime) or the only overfull one (1/q > 1, 1/p < 1/q).  The
-    pairing of such a row has a closed form; other (p, q) keep the wave-per-walker kernel."""
+    (q >= 1 and p <= q: the lanes regime) or the only overfull one (q <= 1 and p >= q; with
+    p == q the return slot counts as an "other" slot).  The pairing of such a row has a closed
+    form; the remaining (p, q) -- q > 1 with p > q, q < 1 with p < q, non-dyadic values -- keep
+    the wave-per-walker kernel."""
     if not (_dyadic(p) and _dyadic(q)) or (p == 1.0 and q == 1.0):
         return False
-    return lanes_regime(p, q) or (1.0 / q > 1.0 and 1.0 / p < 1.0 / q)
+    return lanes_regime(p, q) or (1.0 / q >= 1.0 and 1.0 / p <= 1.0 / q)
 
 
 def fresh_seed() -> int:
