@@ -1627,10 +1627,11 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
   // pairing, and one wave per walker (below) is the better shape (measured: cfg 2, p = 4,
   // q = 0.25: 344 against 241 M steps/s; p = 2, q = 1: 938 against 711).
   const bool lanes_regime = (p == 1.0 && q == 1.0) || (K.bO <= 1.0 && K.bR >= K.bO);
-  // regimes in which "other" is alone on its stack on ordinary rows (closed-form pairing): the
-  // only underfull class (1/q <= 1, 1/p >= 1/q) or the only overfull one (1/q >= 1, 1/p <= 1/q)
-  const bool regime_b = K.bO >= 1.0 && K.bR <= K.bO;  // (p == q: the return slot is an "other" slot)
-  if (dyadic && !(p == 1.0 && q == 1.0) && (lanes_regime || regime_b) && !(g->reserved & 1)) {
+  // every dyadic (p, q) has its pairing in closed form (n2v_unit_core.h): "other" alone on its
+  // stack -- the only underfull class (1/q <= 1, 1/p >= 1/q) or the only overfull one (1/q >= 1,
+  // 1/p <= 1/q; with p == q the return slot is an "other" slot) --, or sharing it with the return
+  // run (q > 1 with p > q; q < 1 with p < q)
+  if (dyadic && !(p == 1.0 && q == 1.0) && !(g->reserved & 1)) {
     // every per-edge table is at hand: the kernel in which no step needs the wave
     const int rw = n2v_walk_wedge_try(g, start_ids, n_start, num_walks, walk_length, p, q, K, seed,
                                       walks_out, valid_out, status, stream);

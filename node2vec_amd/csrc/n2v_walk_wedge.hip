@@ -29,6 +29,52 @@ constexpr int kWedgeThreads = 256;
 #define N2V_WEDGE_WAVES 6
 #endif
 
+// fp64 rounding decides a draw (a tie or a thin margin in the closed form): replay the loop.
+// Rare, and kept out of line so that its registers are not the walk loop's.
+#ifdef N2V_REPLAY_INLINE
+#define N2V_REPLAY_ATTR __forceinline__
+#else
+#define N2V_REPLAY_ATTR __noinline__
+#endif
+template <typename P>
+__device__ N2V_REPLAY_ATTR int pair_replay(int arr, int n, int pick, double r2, const UnitConsts &K,
+                                        double avg, int nR, int rpos, int nM, const P *list,
+                                        bool isR, bool isM, P *stage, int lane) {
+  const double vR = K.bR / avg, vM = K.bM / avg, vO = K.bO / avg;
+  if (n <= 64) {  // a short row: the two stacks as bit masks
+    uint64_t Rm = 0ull;
+    if (nR) Rm = ((nR >= 64) ? ~0ull : ((1ull << nR) - 1ull)) << rpos;
+    const uint64_t Mm = wedge_mask_t<P>(list, 0, nM);
+    return lane_pairing(n, Rm, Mm, pick, r2, vR, vM, vO);
+  }
+  if (arr == 1) return lane_case_a<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM, stage, lane);
+  if (arr == 2) return lane_case_b<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM);
+  if (arr == 3) return lane_case_a2<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM, stage, lane);
+  if (arr == 4) return lane_case_b2<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM);
+  return lane_pairing_list<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list);
+}
+
+// the pairing loop for slot `pick` by one lane: closed form by arrangement, else the replays
+template <typename P>
+__device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, const UnitConsts &K,
+                                           double avg, int nR, int rpos, int nM, const P *list,
+                                           bool isR, bool isM, int lo_pick, P *stage, int lane) {
+  int res = -1;
+  if (arr == 1)
+    res = lane_case_a_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+  else if (arr == 2)
+    res = lane_case_b_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+  else if (arr == 3)
+    res = lane_case_a2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+  else if (arr == 4)
+    res = lane_case_b2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+#ifdef N2V_ABLATE_W
+  if (N2V_ABLATE_W == 1 && arr == 2) res = pick;  // timing-only: no closed form at all
+#endif
+  if (res >= 0) return res;
+  return pair_replay<P>(arr, n, pick, r2, K, avg, nR, rpos, nM, list, isR, isM, stage, lane);
+}
+
 __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wedge_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double p, double q, UnitConsts K, uint64_t seed,
@@ -177,49 +223,23 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
                 w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
               }
               const int w_rpos = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
-              const bool case_a = uO && !(nR && uR) && !(nM && uM);
-              const bool case_b = !uO && nO > 0 && (!nR || uR) && (!nM || uM);  // the mirror image
-              int res = -1;
-              // plain branches on the (uniform) list width: never a select between two loads
-              if (w_wide) {
-                const uint32_t *list = reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off;
-                if (case_a)
-                  res = lane_case_a_jump<uint32_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
-                else if (case_b)
-                  res = lane_case_b_jump<uint32_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
-              } else {
-                const uint16_t *list = reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off;
-                if (case_a)
-                  res = lane_case_a_jump<uint16_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
-                else if (case_b)
-                  res = lane_case_b_jump<uint16_t>(n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
-              }
-#ifdef N2V_ABLATE_W
-              if (N2V_ABLATE_W == 1 && case_b) res = pick;  // timing-only: no closed form at all
-#endif
-              if (res < 0) {  // fp64 rounding decides: replay the loop
-                const double vR = K.bR / avg, vM = K.bM / avg, vO = K.bO / avg;
-                if (n > 64) {
-                  if (w_wide) {
-                    const uint32_t *list = reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off;
-                    res = case_a ? lane_case_a<uint32_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR,
-                                                         isM, stage, lane)
-                          : case_b ? lane_case_b<uint32_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR, isM)
-                                   : lane_pairing_list<uint32_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list);
-                  } else {
-                    const uint16_t *list = reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off;
-                    res = case_a ? lane_case_a<uint16_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR,
-                                                         isM, reinterpret_cast<uint16_t *>(stage), lane)
-                          : case_b ? lane_case_b<uint16_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list, isR, isM)
-                                   : lane_pairing_list<uint16_t>(n, pick, r2, vR, vM, vO, nR, w_rpos, nM, list);
-                  }
-                } else {  // a short row: the two stacks as bit masks
-                  uint64_t Rm = 0ull;
-                  if (nR) Rm = ((nR >= 64) ? ~0ull : ((1ull << nR) - 1ull)) << w_rpos;
-                  const uint64_t Mm = wedge_mask(g.wedge_pos, w_off, nM, w_wide);
-                  res = lane_pairing(n, Rm, Mm, pick, r2, vR, vM, vO);
-                }
-              }
+              // which classes share a stack: 1 = "other" alone underfull, 2 = "other" alone
+              // overfull, 3 = return + "other" underfull, 4 = return + "other" overfull, 0 = else
+              int arr = 0;
+              if (uO && !(nR && uR) && !(nM && uM)) arr = 1;
+              else if (!uO && nO > 0 && (!nR || uR) && (!nM || uM)) arr = 2;
+              else if (uO && nR && uR && nM && !uM) arr = 3;
+              else if (!uO && nO > 0 && nR && !uR && nM && uM) arr = 4;
+              int res;
+              // a plain branch on the (uniform) list width: never a select between two loads
+              if (w_wide)
+                res = pair_listed<uint32_t>(arr, n, pick, r2, K, avg, nR, w_rpos, nM,
+                                            reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off,
+                                            isR, isM, lo_pick, stage, lane);
+              else
+                res = pair_listed<uint16_t>(arr, n, pick, r2, K, avg, nR, w_rpos, nM,
+                                            reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off,
+                                            isR, isM, lo_pick, reinterpret_cast<uint16_t *>(stage), lane);
               idx = res;
               N2V_CHECK_RANGE(2, idx, 0, n);
             }

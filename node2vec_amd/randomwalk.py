@@ -33,15 +33,12 @@ def lanes_regime(p: float, q: float) -> bool:
 
 def tables_regime(p: float, q: float) -> bool:
     """The (p, q) for which exact walks on a unit-weight graph run from the per-edge tables alone
-    (class counts + wedge lists + hop table, csrc/n2v_walk_wedge.hip): dyadic values for which
-    the bulk class "other" is alone on its stack on ordinary rows -- the only underfull class
-    (q >= 1 and p <= q: the lanes regime) or the only overfull one (q <= 1 and p >= q; with
-    p == q the return slot counts as an "other" slot).  The pairing of such a row has a closed
-    form; the remaining (p, q) -- q > 1 with p > q, q < 1 with p < q, non-dyadic values -- keep
+    (class counts + wedge lists + hop table, csrc/n2v_walk_wedge.hip): every dyadic pair but
+    p = q = 1 (which needs no table but the hop table).  The pairing of a row has a closed form
+    whether the bulk class "other" is alone on its stack (q >= 1 with p <= q, q <= 1 with p >= q)
+    or shares it with the return slot (q > 1 with p > q, q < 1 with p < q); non-dyadic values keep
     the wave-per-walker kernel."""
-    if not (_dyadic(p) and _dyadic(q)) or (p == 1.0 and q == 1.0):
-        return False
-    return lanes_regime(p, q) or (1.0 / q >= 1.0 and 1.0 / p <= 1.0 / q)
+    return _dyadic(p) and _dyadic(q) and not (p == 1.0 and q == 1.0)
 
 
 def fresh_seed() -> int:

@@ -63,6 +63,11 @@ while time.time() - t0 < budget:
     if os.environ.get("FUZZ_PQ") == "extreme":
         vals = [0.001, 0.01, 0.03125, 0.03, 1.0 / 3.0, 0.999, 1.001, 16.0, 37.5, 100.0, 1000.0, 1024.0]
         p, q = float(rng.choice(vals)), float(rng.choice(vals))
+    elif os.environ.get("FUZZ_PQ") == "two":
+        # the return slot shares a stack with "other": q > 1 with p > q, q < 1 with p < q
+        pairs = [(4.0, 2.0), (8.0, 2.0), (8.0, 4.0), (16.0, 2.0), (0.25, 0.5), (0.125, 0.5),
+                 (0.125, 0.25), (0.0625, 0.5)]
+        p, q = pairs[int(rng.integers(len(pairs)))]
     else:
         p = float(rng.choice([0.25, 0.5, 1.0, 2.0, 4.0, 3.0, 0.7]))
         q = float(rng.choice([0.25, 0.5, 1.0, 2.0, 4.0, 1.3, 0.1]))

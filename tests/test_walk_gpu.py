@@ -144,7 +144,8 @@ def test_results_independent_of_sharding():
 
 @pytest.mark.parametrize("pq", [(1.0, 1.0), (0.5, 2.0), (1.0, 2.0), (0.25, 4.0), (4.0, 0.25), (3.0, 0.7),
                                 (2.0, 0.5), (0.25, 0.25), (0.5, 0.25), (4.0, 4.0), (1.0, 0.5), (0.25, 0.5),
-                                (2.0, 1.0), (4.0, 2.0), (2.0, 2.0), (0.5, 0.5)])
+                                (2.0, 1.0), (4.0, 2.0), (2.0, 2.0), (0.5, 0.5),
+                                (8.0, 2.0), (0.125, 0.25)])
 def test_hop_table_and_class_counts_change_no_bit(oracle, pq):
     """unit-weight graph with sinks, multi-edges and hubs: the walks are the same bits with the
     hop table (one gather per step), with the CSR arrays + per-edge class counts, and with the
