@@ -957,6 +957,113 @@ __device__ __forceinline__ int lane_case_b2(int n, int pick, double r2, double v
   return pickM ? 0 : pick;
 }
 
+// ---- the return run alone on the overfull stack (p < q < 1 on rows with few shared neighbours:
+// 1/p is overfull, "other" and shared are both underfull).  The nR return slots absorb the other
+// slots from the top of the row down: a slot whose predecessors' deficits sum to T is paired with
+// return slot floor(T / ER) + 1, counted from the top of the run, if there is one.  An overfull
+// `pick` is the last return slot on every graph without multi-edges: mass balance, as above.
+template <typename P>
+__device__ __forceinline__ int lane_case_a3_jump(int n, int pick, double r2, const UnitConsts &K,
+                                                 int nR, int rpos, int nM, bool pickR, bool pickM,
+                                                 int lo_pick) {
+  const int nO = n - nR - nM;
+  const double dn = (double)n;
+  const double isum = (double)nR * K.fR + (double)nM * K.fM + (double)nO * K.fO;
+  const double ER = K.fR * dn - isum, D = isum - K.fO * dn, DM = isum - K.fM * dn;
+  if (nR <= 0 || nM <= 0 || !(ER > 0.0) || !(D > 0.0) || !(DM > 0.0)) return -1;
+  if (dn * isum > 2.0e14 || dn * dn * K.fR > 4.0e15) return -1;
+  if (pickR) return (rpos + nR - pick == nR) ? pick : -1;
+  const int m_above = nM - lo_pick - (pickM ? 1 : 0);
+  int ar = rpos + nR - 1 - pick;  // return slots above pick
+  ar = ar < 0 ? 0 : (ar > nR ? nR : ar);
+  const int o_above = (n - 1 - pick) - ar - m_above;
+  const double T = (double)o_above * D + (double)m_above * DM;
+  const double iq = floor_div(T, ER);
+  if (T > 0.0 && fma(-iq, ER, T) == 0.0) return -1;  // that return slot holds exactly 1.0
+  if (iq >= (double)nR) return 0;  // never paired: alias stays 0 (:170)
+  return rpos + nR - 1 - (int)iq;
+}
+
+// the same arrangement replayed run by run: lane_case_a with the overfull stack = the return run
+// alone and the underfull values = runs of vO split by the listed slots (vM).
+template <typename P>
+__device__ __forceinline__ int lane_case_a3(int n, int pick, double r2, double vR, double vM,
+                                            double vO, int nR, int rpos, int nM, const P *list,
+                                            bool pickR, bool pickM) {
+  const int nU = n - nR;
+  auto urank = [&](int pos) -> int {  // underfull slots above position pos
+    int ar = rpos + nR - 1 - pos;
+    ar = ar < 0 ? 0 : (ar > nR ? nR : ar);
+    return (n - 1 - pos) - ar;
+  };
+  const int rank = pickR ? -1 : urank(pick);
+  int km = nM - 1, kr = nR - 1, used = 0;
+  bool have_carry = false;
+  int carry_i = 0, alias_pick = 0;
+  double carry_v = 0.0;
+  double p_pick = pick3(pickR, pickM, vR, vM, vO);
+  for (;;) {
+    if (!have_carry && used >= nU) break;  // underfull is empty (:182)
+    if (kr < 0) break;                     // overfull is empty (:182)
+    const int oi = rpos + kr;
+    double ov = vR;
+    --kr;
+    if (have_carry) {
+      if (carry_i == pick) {
+        alias_pick = oi;
+        p_pick = carry_v;
+        break;
+      }
+      ov = ov + carry_v - 1.0;  // :185
+      have_carry = false;
+      if (ov < 1.0) {
+        if (oi == pick) p_pick = ov;
+        have_carry = true;
+        carry_i = oi;
+        carry_v = ov;
+        continue;
+      }
+    }
+    bool demoted = false;
+    while (used < nU && !(rank >= 0 && used == rank)) {
+      const int mrank = km >= 0 ? urank((int)list[km]) : nU;
+      double val = vO;
+      int limit = mrank - used;
+      if (used == mrank) {
+        val = vM;
+        limit = 1;
+        --km;
+      }
+      if (rank >= used && rank - used < limit) limit = rank - used;
+      int j = 0;
+      absorb_skip(ov, val, j, limit);
+      while (j < limit) {
+        ov = ov + val - 1.0;  // :185
+        ++j;
+        if (ov < 1.0) {
+          demoted = true;
+          break;
+        }
+      }
+      used += j;
+      if (demoted) break;
+    }
+    if (oi == pick) p_pick = ov;
+    if (demoted) {
+      have_carry = true;
+      carry_i = oi;
+      carry_v = ov;
+      continue;
+    }
+    if (rank >= 0 && used == rank && used < nU) {  // the next underfull slot is pick itself
+      alias_pick = oi;
+      p_pick = pickM ? vM : vO;
+    }
+    break;
+  }
+  return (r2 < p_pick) ? pick : alias_pick;
+}
+
 // ---- any row, any arrangement of the classes: the loop of :175-189 slot by slot, by one lane.
 // The two stacks are walked as two descending cursors over the positions of the row; the class
 // of a position is read off the (ascending) shared list and the return run on the way down, so

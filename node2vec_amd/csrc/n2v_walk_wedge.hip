@@ -29,17 +29,31 @@ constexpr int kWedgeThreads = 256;
 #define N2V_WEDGE_WAVES 6
 #endif
 
-// fp64 rounding decides a draw (a tie or a thin margin in the closed form): replay the loop.
-// Rare, and kept out of line so that its registers are not the walk loop's.
-#ifdef N2V_REPLAY_INLINE
-#define N2V_REPLAY_ATTR __forceinline__
-#else
-#define N2V_REPLAY_ATTR __noinline__
+// the pairing loop for slot `pick` by one lane: closed form by arrangement `arr` (see the kernel),
+// else -- fp64 rounding decides the draw: a tie or a thin margin -- the replays.
+// kShared: the (p, q) for which the return run shares a stack with "other" (arrangements 3-5);
+// compiled out of the other instance, whose registers they would cost.
+template <typename P, bool kShared>
+__device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, const UnitConsts &K,
+                                           double avg, int nR, int rpos, int nM, const P *list,
+                                           bool isR, bool isM, int lo_pick, P *stage, int lane) {
+  int res = -1;
+  if (arr == 1)
+    res = lane_case_a_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+  else if (arr == 2)
+    res = lane_case_b_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+  if constexpr (kShared) {
+    if (arr == 3)
+      res = lane_case_a2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+    else if (arr == 4)
+      res = lane_case_b2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+    else if (arr == 5)
+      res = lane_case_a3_jump<P>(n, pick, r2, K, nR, rpos, nM, isR, isM, lo_pick);
+  }
+#ifdef N2V_ABLATE_W
+  if (N2V_ABLATE_W == 1 && arr == 2) res = pick;  // timing-only: no closed form at all
 #endif
-template <typename P>
-__device__ N2V_REPLAY_ATTR int pair_replay(int arr, int n, int pick, double r2, const UnitConsts &K,
-                                        double avg, int nR, int rpos, int nM, const P *list,
-                                        bool isR, bool isM, P *stage, int lane) {
+  if (res >= 0) return res;
   const double vR = K.bR / avg, vM = K.bM / avg, vO = K.bO / avg;
   if (n <= 64) {  // a short row: the two stacks as bit masks
     uint64_t Rm = 0ull;
@@ -49,32 +63,15 @@ __device__ N2V_REPLAY_ATTR int pair_replay(int arr, int n, int pick, double r2, 
   }
   if (arr == 1) return lane_case_a<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM, stage, lane);
   if (arr == 2) return lane_case_b<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM);
-  if (arr == 3) return lane_case_a2<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM, stage, lane);
-  if (arr == 4) return lane_case_b2<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM);
+  if constexpr (kShared) {
+    if (arr == 3) return lane_case_a2<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM, stage, lane);
+    if (arr == 4) return lane_case_b2<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM);
+    if (arr == 5) return lane_case_a3<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM);
+  }
   return lane_pairing_list<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list);
 }
 
-// the pairing loop for slot `pick` by one lane: closed form by arrangement, else the replays
-template <typename P>
-__device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, const UnitConsts &K,
-                                           double avg, int nR, int rpos, int nM, const P *list,
-                                           bool isR, bool isM, int lo_pick, P *stage, int lane) {
-  int res = -1;
-  if (arr == 1)
-    res = lane_case_a_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
-  else if (arr == 2)
-    res = lane_case_b_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
-  else if (arr == 3)
-    res = lane_case_a2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
-  else if (arr == 4)
-    res = lane_case_b2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
-#ifdef N2V_ABLATE_W
-  if (N2V_ABLATE_W == 1 && arr == 2) res = pick;  // timing-only: no closed form at all
-#endif
-  if (res >= 0) return res;
-  return pair_replay<P>(arr, n, pick, r2, K, avg, nR, rpos, nM, list, isR, isM, stage, lane);
-}
-
+template <bool kShared>
 __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wedge_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double p, double q, UnitConsts K, uint64_t seed,
@@ -223,21 +220,22 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
                 w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
               }
               const int w_rpos = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
-              // which classes share a stack: 1 = "other" alone underfull, 2 = "other" alone
-              // overfull, 3 = return + "other" underfull, 4 = return + "other" overfull, 0 = else
+              // the stacks: 1 = "other" alone underfull, 2 = "other" alone overfull, 3 = return +
+              // "other" underfull, 4 = return + "other" overfull, 5 = return alone overfull, 0 = else
               int arr = 0;
               if (uO && !(nR && uR) && !(nM && uM)) arr = 1;
               else if (!uO && nO > 0 && (!nR || uR) && (!nM || uM)) arr = 2;
-              else if (uO && nR && uR && nM && !uM) arr = 3;
-              else if (!uO && nO > 0 && nR && !uR && nM && uM) arr = 4;
+              else if (kShared && uO && nR && uR && nM && !uM) arr = 3;
+              else if (kShared && !uO && nO > 0 && nR && !uR && nM && uM) arr = 4;
+              else if (kShared && uO && nR && !uR && nM && uM) arr = 5;
               int res;
               // a plain branch on the (uniform) list width: never a select between two loads
               if (w_wide)
-                res = pair_listed<uint32_t>(arr, n, pick, r2, K, avg, nR, w_rpos, nM,
+                res = pair_listed<uint32_t, kShared>(arr, n, pick, r2, K, avg, nR, w_rpos, nM,
                                             reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off,
                                             isR, isM, lo_pick, stage, lane);
               else
-                res = pair_listed<uint16_t>(arr, n, pick, r2, K, avg, nR, w_rpos, nM,
+                res = pair_listed<uint16_t, kShared>(arr, n, pick, r2, K, avg, nR, w_rpos, nM,
                                             reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off,
                                             isR, isM, lo_pick, reinterpret_cast<uint16_t *>(stage), lane);
               idx = res;
@@ -283,11 +281,13 @@ int n2v_walk_wedge_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_s
   const int64_t total = n_start * (int64_t)num_walks;
   if (total >= 0xffffff00ll) return 0;
   if (total == 0) return 1;
+  // the return run shares a stack with "other" on ordinary rows: q > 1 with p > q, q < 1 with p < q
+  const bool alone = (K.bO <= 1.0 && K.bR >= K.bO) || (K.bO >= 1.0 && K.bR <= K.bO);
+  auto kernel = alone ? n2v::walk_exact_wedge_kernel<false> : n2v::walk_exact_wedge_kernel<true>;
   int64_t blocks = (total + n2v::kWedgeThreads - 1) / n2v::kWedgeThreads;
-  const int64_t cap = n2v::resident_blocks((const void *)n2v::walk_exact_wedge_kernel,
-                                           n2v::kWedgeThreads, 0);
+  const int64_t cap = n2v::resident_blocks((const void *)kernel, n2v::kWedgeThreads, 0);
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(n2v::walk_exact_wedge_kernel, dim3((unsigned)blocks), dim3(n2v::kWedgeThreads), 0,
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(n2v::kWedgeThreads), 0,
                      (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, p, q, K, seed,
                      walks_out, valid_out, status);
   if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
