@@ -13,9 +13,10 @@
 //      of slot `pick`: return if the neighbour is s, shared if `pick` is in the edge's wedge list;
 //   3. exits without pairing (~80 % of the steps): an accepted underfull `pick`; an empty stack;
 //   4. the pairing loop (:182-189) for slot `pick`, by the lane itself (n2v_unit_core.h): closed
-//      form when "other" is the only underfull class (q > 1) or the only overfull one (q < 1) --
-//      exact integer bucket arithmetic; ties and thin margins fall through --, else bit masks
-//      (rows of <= 64 slots), else the run-by-run replay over the list, else slot by slot.
+//      form by the arrangement of the classes on the two stacks -- "other" alone underfull or
+//      alone overfull; with the return run beside it (instance <true>: q > 1 with p > q, q < 1
+//      with p < q) -- in exact integer bucket arithmetic; ties and thin margins fall through to
+//      bit masks (rows of <= 64 slots), else the run-by-run replay over the list, else slot by slot.
 // The path is written as whole 64-byte sectors through an LDS tile (a 4-byte store into a
 // 324-byte-pitch row costs a 32-byte write request each: 12x write amplification measured on the
 // lanes kernel).  Any dyadic p, q (the row sum is then an exact integer combination of the class
