@@ -83,8 +83,9 @@ def test_cfg3_power_law_10m_trimmed(oracle):
     gen = torch.Generator().manual_seed(3)
     pick = torch.sort(torch.randperm(start_all.numel(), generator=gen)[:60_000]).values
     start = start_all[pick.to("cuda")].contiguous()
-    # (4, 0.25): "other" is the overfull class (the mirror closed form and its run-by-run replay)
-    for p, q in ((1.0, 1.0), (0.5, 2.0), (4.0, 0.25)):
+    # (4, 0.25): "other" is the overfull class (the mirror closed form and its run-by-run replay);
+    # (4, 2) and (0.25, 0.5): the return slot shares a stack with "other" (rows of 10^4 slots)
+    for p, q in ((1.0, 1.0), (0.5, 2.0), (4.0, 0.25), (4.0, 2.0), (0.25, 0.5)):
         _check_config(oracle, g, start, p, q, 42, n_oracle=48, n_hubs=16, oracle_len=40)
 
 
@@ -103,7 +104,7 @@ def test_cfg4_power_law_100m(oracle):
     gen = torch.Generator().manual_seed(4)
     pick = torch.sort(torch.randperm(start_all.numel(), generator=gen)[:100_000]).values
     start = start_all[pick.to("cuda")].contiguous()
-    for p, q in ((1.0, 1.0), (0.5, 2.0)):
+    for p, q in ((1.0, 1.0), (0.5, 2.0), (0.25, 0.5)):
         _check_config(oracle, g, start, p, q, 42, n_oracle=48, n_hubs=16, oracle_len=40)
 
 
