@@ -38,6 +38,7 @@ struct UnitConsts {
   int64_t TR, TM, TO;    // the same times 2^20 (exact integers; dyadic kernel only)
   int64_t gR, gM, gO;    // TR, TM, TO divided by their greatest common divisor
   double fR, fM, fO;     // the same as fp64 (exact): the closed forms compute in doubles
+  int dyadic;            // 1/p, 1/q are multiples of 2^-20: TR .. fO are valid
 };
 
 __device__ __forceinline__ int biased_exp(double x) {
@@ -86,6 +87,74 @@ __device__ __forceinline__ void absorb_skip(double &r, double val, int &j, int l
     }
     if (nn < 4.0) return;  // at the edge of the binade: let the exact loop cross it
   }
+}
+
+// ---- the reference's row sum when 1/p or 1/q is not dyadic, by one lane -----------------
+// sum(node_weights) (:172) adds left to right in fp64; a run of k equal addends needs no loop
+// (the argument of rep_add, n2v_walk_unit.hip, of which this is the per-lane form): while s stays
+// inside one binade the rounded step of s + c is the same at every addition.
+__device__ __forceinline__ double rep_add_lane(double s, double c, int k) {
+  const uint64_t c_man =
+      ((uint64_t)__double_as_longlong(c) & 0x000fffffffffffffull) | 0x0010000000000000ull;
+  const int c_exp = biased_exp(c);
+  while (k > 0) {
+    const int es = biased_exp(s);
+    if (es == 0) {  // s == 0.0: the first addend, exact
+      s = s + c;
+      --k;
+      continue;
+    }
+    const int shift = es - c_exp;  // low bits of c below ulp(s)
+    if (shift >= 1 && shift <= 53 && (c_man & ((1ull << shift) - 1ull)) == (1ull << (shift - 1))) {
+      s = s + c;  // a tie: one real addition makes s an even multiple of ulp
+      --k;
+      if (k == 0 || biased_exp(s) != es) continue;
+    }
+    const double t = s + c;
+    if (biased_exp(t) != es) {  // this addition leaves the binade: the real operation
+      s = t;
+      --k;
+      continue;
+    }
+    const double step = t - s;  // exact
+    if (step == 0.0) return s;  // c vanishes against s
+    const double need = __longlong_as_double((long long)(es + 1) << 52) - s;  // exact
+    if ((double)k * step < need) return s + (double)k * step;  // the run stays in the binade: exact
+    double j = ceil(need / step) - 1.0;
+    while ((j + 1.0) * step < need) j += 1.0;
+    while (j * step >= need) j -= 1.0;
+    j = fmin(j, (double)k);
+    s = s + j * step;  // exact: a multiple of ulp below 2^(e+1)
+    k -= (int)j;
+  }
+  return s;
+}
+
+// the row sum of a unit-weight row by classes, left to right: runs of "other" slots between the
+// listed (shared) positions and the return run
+template <typename P>
+__device__ __forceinline__ double lane_row_sum(int n, const UnitConsts &K, int nR, int rpos, int nM,
+                                               const P *list) {
+  double sum = 0.0;
+  int pos = 0, km = 0;
+  bool run_done = nR == 0;
+  for (;;) {
+    const int pm = km < nM ? (int)list[km] : n;
+    const int pr = run_done ? n : rpos;
+    if (pm >= n && pr >= n) break;
+    if (pr < pm) {
+      sum = rep_add_lane(sum, K.bO, pr - pos);
+      sum = rep_add_lane(sum, K.bR, nR);
+      pos = pr + nR;
+      run_done = true;
+    } else {
+      sum = rep_add_lane(sum, K.bO, pm - pos);
+      sum = sum + K.bM;
+      pos = pm + 1;
+      ++km;
+    }
+  }
+  return rep_add_lane(sum, K.bO, n - pos);
 }
 
 // OR of 1 << list[k] for k < cnt (a row of at most 64 neighbours); one lane

@@ -1613,6 +1613,7 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
   K.fR = (double)K.gR;
   K.fM = (double)K.gM;
   K.fO = (double)K.gO;
+  K.dyadic = dyadic ? 1 : 0;
   const bool ordinary = K.bR >= 0x1p-20 && K.bR <= 0x1p20 && K.bO >= 0x1p-20 && K.bO <= 0x1p20;
   if (!dyadic && !ordinary) return 0;
   const int64_t total = n_start * (int64_t)num_walks;
@@ -1631,7 +1632,9 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
   // stack -- the only underfull class (1/q <= 1, 1/p >= 1/q) or the only overfull one (1/q >= 1,
   // 1/p <= 1/q; with p == q the return slot is an "other" slot) --, or sharing it with the return
   // run (q > 1 with p > q; q < 1 with p < q)
-  if (dyadic && !(p == 1.0 && q == 1.0) && !(g->reserved & 1)) {
+  // (values that are not dyadic: the same kernel adds the row up in the reference's order and
+  // replays every pairing run by run)
+  if (!(p == 1.0 && q == 1.0) && !(g->reserved & 1)) {
     // every per-edge table is at hand: the kernel in which no step needs the wave
     const int rw = n2v_walk_wedge_try(g, start_ids, n_start, num_walks, walk_length, p, q, K, seed,
                                       walks_out, valid_out, status, stream);

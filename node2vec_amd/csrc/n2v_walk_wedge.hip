@@ -32,18 +32,23 @@ constexpr int kWedgeThreads = 256;
 
 // the pairing loop for slot `pick` by one lane: closed form by arrangement `arr` (see the kernel),
 // else -- fp64 rounding decides the draw: a tie or a thin margin -- the replays.
-// kShared: the (p, q) for which the return run shares a stack with "other" (arrangements 3-5);
-// compiled out of the other instance, whose registers they would cost.
-template <typename P, bool kShared>
+// kMode 0: the (p, q) that leave "other" alone on its stack on ordinary rows; 1: those for which
+// the return run shares a stack with it (arrangements 3-5: compiled out of instance 0, whose
+// registers they would cost); 2: 1/p or 1/q not dyadic -- no exact integer arithmetic, so no
+// closed form: every pairing is replayed run by run in fp64.
+template <typename P, int kMode>
 __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, const UnitConsts &K,
                                            double avg, int nR, int rpos, int nM, const P *list,
                                            bool isR, bool isM, int lo_pick, P *stage, int lane) {
+  constexpr bool kShared = kMode != 0;
   int res = -1;
-  if (arr == 1)
-    res = lane_case_a_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
-  else if (arr == 2)
-    res = lane_case_b_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
-  if constexpr (kShared) {
+  if constexpr (kMode != 2) {
+    if (arr == 1)
+      res = lane_case_a_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+    else if (arr == 2)
+      res = lane_case_b_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+  }
+  if constexpr (kMode == 1) {
     if (arr == 3)
       res = lane_case_a2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
     else if (arr == 4)
@@ -72,7 +77,7 @@ __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, 
   return lane_pairing_list<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list);
 }
 
-template <bool kShared>
+template <int kMode>
 __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wedge_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double p, double q, UnitConsts K, uint64_t seed,
@@ -92,6 +97,7 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
   // the pairing and needs the return position: request the wedge offset with the hop, always
   const bool always_pair = K.bO > 1.0;
   const bool merge_r = K.bR == K.bO;
+  constexpr bool kShared = kMode != 0;
   const bool base_aligned = (reinterpret_cast<uintptr_t>(walks_out) & 63u) == 0;
 #ifdef N2V_CHECK
   n2v_check_status = status;
@@ -178,7 +184,8 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
 #else
       const bool early_ok = true;
 #endif
-      if (counts_ok && ((need_mem && fM > 0) || (early_ok && always_pair && (fM > 0 || fR > 0)))) {
+      // (not dyadic: the row sum needs the list and the return position at every step)
+      if (counts_ok && ((need_mem && fM > 0) || ((kMode == 2 || (early_ok && always_pair)) && (fM > 0 || fR > 0)))) {
         N2V_CHECK_RANGE(3, e_prev, (int64_t)0, g.n_edges);
         wraw = g.wedge_off[e_prev];
         w_loaded = true;
@@ -194,11 +201,24 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
           // p == q: the return slot carries the same value as an "other" slot -- it IS one, as far
           // as the table is concerned (randomwalk.py:223-230 give both w / p == w / q)
           const int nR = merge_r ? 0 : (int)fR, nM = need_mem ? (int)fM : 0, nO = n - nR - nM;
-          const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
-          const double avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;  // :172
+          int64_t w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
+          double avg;  // :172
+          if constexpr (kMode == 2) {
+            const int rp = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
+            double sum;
+            if (w_wide)
+              sum = lane_row_sum<uint32_t>(n, K, nR, rp, nM,
+                                           reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off);
+            else
+              sum = lane_row_sum<uint16_t>(n, K, nR, rp, nM,
+                                           reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off);
+            avg = sum / (double)n;
+          } else {
+            const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
+            avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;
+          }
           const bool isR = !merge_r && x == s;
           bool isM = false;
-          int64_t w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
           int lo_pick = 0;  // entries of the edge's list below `pick`
           if (need_mem && !isR && nM > 0)  // :226
             lo_pick = wedge_lower(g.wedge_pos, w_off, nM, pick, w_wide, isM);
@@ -232,11 +252,11 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
               int res;
               // a plain branch on the (uniform) list width: never a select between two loads
               if (w_wide)
-                res = pair_listed<uint32_t, kShared>(arr, n, pick, r2, K, avg, nR, w_rpos, nM,
+                res = pair_listed<uint32_t, kMode>(arr, n, pick, r2, K, avg, nR, w_rpos, nM,
                                             reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off,
                                             isR, isM, lo_pick, stage, lane);
               else
-                res = pair_listed<uint16_t, kShared>(arr, n, pick, r2, K, avg, nR, w_rpos, nM,
+                res = pair_listed<uint16_t, kMode>(arr, n, pick, r2, K, avg, nR, w_rpos, nM,
                                             reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off,
                                             isR, isM, lo_pick, reinterpret_cast<uint16_t *>(stage), lane);
               idx = res;
@@ -284,7 +304,9 @@ int n2v_walk_wedge_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_s
   if (total == 0) return 1;
   // the return run shares a stack with "other" on ordinary rows: q > 1 with p > q, q < 1 with p < q
   const bool alone = (K.bO <= 1.0 && K.bR >= K.bO) || (K.bO >= 1.0 && K.bR <= K.bO);
-  auto kernel = alone ? n2v::walk_exact_wedge_kernel<false> : n2v::walk_exact_wedge_kernel<true>;
+  auto kernel = !K.dyadic ? n2v::walk_exact_wedge_kernel<2>
+                : alone   ? n2v::walk_exact_wedge_kernel<0>
+                          : n2v::walk_exact_wedge_kernel<1>;
   int64_t blocks = (total + n2v::kWedgeThreads - 1) / n2v::kWedgeThreads;
   const int64_t cap = n2v::resident_blocks((const void *)kernel, n2v::kWedgeThreads, 0);
   if (blocks > cap) blocks = cap;

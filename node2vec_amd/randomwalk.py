@@ -33,12 +33,17 @@ def lanes_regime(p: float, q: float) -> bool:
 
 def tables_regime(p: float, q: float) -> bool:
     """The (p, q) for which exact walks on a unit-weight graph run from the per-edge tables alone
-    (class counts + wedge lists + hop table, csrc/n2v_walk_wedge.hip): every dyadic pair but
-    p = q = 1 (which needs no table but the hop table).  The pairing of a row has a closed form
-    whether the bulk class "other" is alone on its stack (q >= 1 with p <= q, q <= 1 with p >= q)
-    or shares it with the return slot (q > 1 with p > q, q < 1 with p < q); non-dyadic values keep
-    the wave-per-walker kernel."""
-    return _dyadic(p) and _dyadic(q) and not (p == 1.0 and q == 1.0)
+    (class counts + wedge lists + hop table, csrc/n2v_walk_wedge.hip): every pair but p = q = 1
+    (which needs no table but the hop table).  Dyadic 1/p, 1/q: the pairing of a row has a closed
+    form whether the bulk class "other" is alone on its stack (q >= 1 with p <= q, q <= 1 with
+    p >= q) or shares it with the return slot; other values of ordinary magnitude (2^-20 .. 2^20,
+    the bound of n2v_walk_exact_unit_try): the row is summed in the reference's order and the
+    pairing replayed run by run, one lane per walker all the same."""
+    if p == 1.0 and q == 1.0:
+        return False
+    if _dyadic(p) and _dyadic(q):
+        return True
+    return all(2.0 ** -20 <= 1.0 / x <= 2.0 ** 20 for x in (p, q))
 
 
 def fresh_seed() -> int:
