@@ -164,7 +164,7 @@ def test_hop_table_and_class_counts_change_no_bit(oracle, pq):
     start = rw.start_vertices(g)
     a, av = rw.walk(g, start, 3, 25, p, q, 9)
     assert g.hops is not None and (p == q == 1.0 or g.hops_have_classes or not rw.tables_regime(p, q))
-    assert (g.wedge_off is not None) == rw.tables_regime(p, q)  # (3, 0.7) is not dyadic: no tables
+    assert (g.wedge_off is not None) == rw.tables_regime(p, q)  # (3, 0.7) is not dyadic: tables all the same
     b, bv = rw.walk(g, start, 3, 25, p, q, 9, use_hops=False)
     c, cv = rw.walk(g, start, 3, 25, p, q, 9, use_hops=False, use_edge_classes=False)
     d, dv = rw.walk(g, start, 3, 25, p, q, 9, use_wedges=False)
