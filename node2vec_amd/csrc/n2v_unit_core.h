@@ -136,23 +136,31 @@ template <typename P>
 __device__ __forceinline__ double lane_row_sum(int n, const UnitConsts &K, int nR, int rpos, int nM,
                                                const P *list) {
   double sum = 0.0;
-  int pos = 0, km = 0;
+  int pos = 0;
   bool run_done = nR == 0;
-  for (;;) {
-    const int pm = km < nM ? (int)list[km] : n;
-    const int pr = run_done ? n : rpos;
-    if (pm >= n && pr >= n) break;
-    if (pr < pm) {
-      sum = rep_add_lane(sum, K.bO, pr - pos);
-      sum = rep_add_lane(sum, K.bR, nR);
-      pos = pr + nR;
-      run_done = true;
-    } else {
+  for (int k0 = 0; k0 < nM; k0 += 8) {  // eight independent loads per round trip
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (k0 + u < nM) ? (int)list[k0 + u] : n;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int pm = v[u];
+      if (pm >= n) break;
+      if (!run_done && rpos < pm) {
+        sum = rep_add_lane(sum, K.bO, rpos - pos);
+        sum = rep_add_lane(sum, K.bR, nR);
+        pos = rpos + nR;
+        run_done = true;
+      }
       sum = rep_add_lane(sum, K.bO, pm - pos);
       sum = sum + K.bM;
       pos = pm + 1;
-      ++km;
     }
+  }
+  if (!run_done) {
+    sum = rep_add_lane(sum, K.bO, rpos - pos);
+    sum = rep_add_lane(sum, K.bR, nR);
+    pos = rpos + nR;
   }
   return rep_add_lane(sum, K.bO, n - pos);
 }

@@ -202,26 +202,37 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
           // as the table is concerned (randomwalk.py:223-230 give both w / p == w / q)
           const int nR = merge_r ? 0 : (int)fR, nM = need_mem ? (int)fM : 0, nO = n - nR - nM;
           int64_t w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
-          double avg;  // :172
-          if constexpr (kMode == 2) {
-            const int rp = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
-            double sum;
-            if (w_wide)
-              sum = lane_row_sum<uint32_t>(n, K, nR, rp, nM,
-                                           reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off);
-            else
-              sum = lane_row_sum<uint16_t>(n, K, nR, rp, nM,
-                                           reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off);
-            avg = sum / (double)n;
-          } else {
-            const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
-            avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;
-          }
           const bool isR = !merge_r && x == s;
           bool isM = false;
           int lo_pick = 0;  // entries of the edge's list below `pick`
           if (need_mem && !isR && nM > 0)  // :226
             lo_pick = wedge_lower(g.wedge_pos, w_off, nM, pick, w_wide, isM);
+          double avg;  // :172
+          if constexpr (kMode == 2) {
+            // the reference's sum is rounded at every addition; any order of the same positive
+            // addends agrees with it to (n - 1) 2^-53 relatively, so an underfull `pick` whose
+            // acceptance clears that margin is decided from the counts alone
+            const double b_pick = pick3(isR, isM, K.bR, K.bM, K.bO);
+            const double approx = ((double)nR * K.bR + (double)nM * K.bM + (double)nO * K.bO) / (double)n;
+            const double eps = ((double)n + 8.0) * 4.5e-16;
+            const double r2a = (double)u2 * (1.0 / 4294967296.0);
+            if (b_pick < approx * (1.0 - eps) && r2a < (b_pick / approx) * (1.0 - 2.0 * eps)) {
+              avg = approx;  // only the (decided) comparison below reads it
+            } else {
+              const int rp = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
+              double sum;
+              if (w_wide)
+                sum = lane_row_sum<uint32_t>(n, K, nR, rp, nM,
+                                             reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off);
+              else
+                sum = lane_row_sum<uint16_t>(n, K, nR, rp, nM,
+                                             reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off);
+              avg = sum / (double)n;
+            }
+          } else {
+            const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
+            avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;
+          }
           const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) / avg;  // :173
           const double r2 = (double)u2 * (1.0 / 4294967296.0);
           if (!(p_pick < 1.0 && r2 < p_pick)) {
