@@ -1,11 +1,12 @@
 # GPU call 28: return slot sharing a stack with "other" (p > q > 1, p < q < 1): parity, fuzz, timings;
+# (the variant library was the build with the rare replays inline, then switchable by -DN2V_REPLAY_INLINE)
 # replays out of line against inline
 set -x
 R=$GRAFT_REPO_ROOT
 cd $R
 O=gpurun_out/r03b
 mkdir -p $O build_stats
-(cd node2vec_amd/csrc && /opt/rocm/bin/hipcc -O3 -fPIC --offload-arch=gfx950 -std=c++17 -I../../include -ffp-contract=off -DN2V_REPLAY_INLINE=1 -shared -o ../../build_stats/libn2v_inl.so n2v_capi.hip n2v_walk.hip n2v_walk_unit.hip n2v_walk_fast.hip n2v_walk_uniform.hip n2v_alias.hip n2v_sgns.hip n2v_trim.hip n2v_edge_classes.hip n2v_sync.hip n2v_transform.hip n2v_hops.hip n2v_wedge.hip n2v_walk_wedge.hip) > $O/variant_build.log 2>&1 &
+(cd node2vec_amd/csrc && /opt/rocm/bin/hipcc -O3 -fPIC --offload-arch=gfx950 -std=c++17 -I../../include -ffp-contract=off -shared -o ../../build_stats/libn2v_inl.so n2v_capi.hip n2v_walk.hip n2v_walk_unit.hip n2v_walk_fast.hip n2v_walk_uniform.hip n2v_alias.hip n2v_sgns.hip n2v_trim.hip n2v_edge_classes.hip n2v_sync.hip n2v_transform.hip n2v_hops.hip n2v_wedge.hip n2v_walk_wedge.hip) > $O/variant_build.log 2>&1 &
 timeout -k 10 600 python -m pytest tests/test_walk_gpu.py tests/test_edge_cases_gpu.py tests/test_wedge_gpu.py -x -q > $O/tests.log 2>&1
 rc=$?; tail -3 $O/tests.log; [ $rc -eq 0 ] || exit 1
 FUZZ_PQ=two timeout -k 10 300 python scripts/fuzz_walk.py 180 881 > $O/fuzz_walk_two.log 2>&1
