@@ -40,7 +40,6 @@ struct SumState {
   int64_t isum;
   bool exact;
   double b_pick, bmin, bmax;
-  double fsum;  // this lane's share of the row sum, in stream order (arbitrary weights)
 };
 
 __device__ __forceinline__ void account(SumState &st, WaveLds &L, const StepCtx &c, int i,
@@ -49,7 +48,6 @@ __device__ __forceinline__ void account(SumState &st, WaveLds &L, const StepCtx 
   const bool ok = (t >= 0.0) && (t < 2147483648.0) && (t == trunc(t));
   st.exact = st.exact && (ok || !act);
   st.isum += (ok && act) ? (int64_t)t : 0;
-  st.fsum += act ? b : 0.0;
   if (act) {
     const int pos = c.n - 1 - i;
     if (pos < kBqCap) L.bq[pos] = ok ? (int32_t)t : 0;
@@ -280,7 +278,6 @@ __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_
   st.isum = 0;
   st.exact = true;
   st.b_pick = 0.0;
-  st.fsum = 0.0;
   st.bmin = __builtin_huge_val();
   st.bmax = -__builtin_huge_val();
   int mcount = 0;
@@ -371,21 +368,6 @@ __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_
     // avg, the shortcuts and the pairing loops below stay wave-uniform)
     total = (double)readfirstlane_i64(wave_sum_i64(st.isum)) * (1.0 / 1048576.0);
   } else {
-    // The reference's sum is rounded at every addition, but ANY order of the same n
-    // non-negative addends agrees with it to (n - 1) 2^-53 relatively: an underfull `pick`
-    // whose acceptance clears that margin is decided from the lanes' partial sums, without the
-    // serial pass over the row (most steps when "other" is the underfull bulk of the row).
-    double part = st.fsum, lo = st.bmin;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      part += __shfl_xor(part, off, 64);
-      lo = fmin(lo, __shfl_xor(lo, off, 64));
-    }
-    const double approx = readfirstlane_f64(part) / (double)n;
-    const double eps = ((double)n + 8.0) * 4.5e-16;
-    if (readfirstlane_f64(lo) >= 0.0 && approx > 0.0 && b_pick < approx * (1.0 - eps) &&
-        r2 < (b_pick / approx) * (1.0 - 2.0 * eps))
-      return pick;
     total = 0.0;  // left to right, one rounding per add
     for (int chunk = 0; chunk < c.nch; ++chunk) {
       bool valid;
