@@ -1,11 +1,16 @@
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
-os.environ["N2V_HIP_LIB"] = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "build_variants/libn2v_stats.so")
-from node2vec_amd import synthetic, randomwalk as rw, _lib
+from node2vec_amd import _lib
+_lib.LIB_PATH = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "build_stats/libn2v_stats.so")  # scripts/build_stats.sh
+from node2vec_amd import synthetic, randomwalk as rw
 from node2vec_amd.graph import DeviceGraph
 base = synthetic.rmat(20, 5_000_000, device="cuda")
 gen = torch.Generator(device="cuda").manual_seed(1)
-g = DeviceGraph(base.rowptr, base.col, torch.randint(1, 6, (base.n_edges,), generator=gen, device="cuda").float())
+if os.environ.get("WEIGHTS", "integer") == "integer":
+    w = torch.randint(1, 6, (base.n_edges,), generator=gen, device="cuda").float()
+else:
+    w = torch.rand(base.n_edges, generator=gen, device="cuda") * 1.9 + 0.1
+g = DeviceGraph(base.rowptr, base.col, w)
 start = rw.start_vertices(g)[:47104].contiguous()
 L = _lib.load()
 names = {0: "steps", 1: "filter_steps", 2: "direct_steps", 3: "maybes", 5: "past_quick_exit", 6: "pair_invocations", 7: "pair_inv_n<=64", 8: "pair_iterations", 9: "overfull_consumed", 10: "pair_uncached_inv"}
