@@ -503,6 +503,22 @@ __device__ __forceinline__ int lane_case_b_jump(int n, int pick, double r2, cons
   const double prob = 1.0 + (T - Y_of(j)) / isum;
   if (fabs(prob - r2) < 1e-9) return -1;
   if (r2 < prob) return pick;
+  // the "other" slot of rank t + 1 is the next one below pick: usually pick - 1, found from the
+  // rank of pick in the list (no search); other_pos() if the row runs out (it cannot: t < nO)
+  int cpos = pick - 1, k = lo_pick - 1;
+  while (cpos >= 0) {
+    if (nR > 0 && cpos >= rpos && cpos < rpos + nR) {
+      cpos = rpos - 1;
+      continue;
+    }
+    while (k >= 0 && (int)list[k] > cpos) --k;
+    if (k >= 0 && (int)list[k] == cpos) {
+      --cpos;
+      --k;
+      continue;
+    }
+    return cpos;
+  }
   return other_pos(t + 1);
 }
 
@@ -947,7 +963,20 @@ __device__ __forceinline__ int lane_case_b2_jump(int n, int pick, double r2, con
   if (j > 1.0 && (j - 1.0) * dM == T) return -1;
   const double prob = 1.0 + (T - j * dM) / isum;
   if (fabs(prob - r2) < 1e-9) return -1;
-  return (r2 < prob) ? pick : G.stack_pos(t + 1);
+  if (r2 < prob) return pick;
+  if (!pickR) {  // the next slot of the stack is the next position below pick that is not listed
+    int cpos = pick - 1, k = lo_pick - 1;
+    while (cpos >= 0) {
+      while (k >= 0 && (int)list[k] > cpos) --k;
+      if (k >= 0 && (int)list[k] == cpos) {
+        --cpos;
+        --k;
+        continue;
+      }
+      return cpos;
+    }
+  }
+  return G.stack_pos(t + 1);
 }
 
 // the same arrangement replayed run by run: lane_case_b with the underfull stack = the list alone
