@@ -415,7 +415,7 @@ __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, cons
 //     t + 1; the last one ends at exactly 1.0 (mass balance: Y_S = nO e) -- fp64 decides.
 // Same exactness argument and the same -1 cases as lane_case_a_jump; checked against the
 // reference loop in Python (0 mismatches in 180 k short and 5.7 k long rows, 2-10 % return -1).
-template <typename P>
+template <typename P, bool kNextSlot>
 __device__ __forceinline__ int lane_case_b_jump(int n, int pick, double r2, const UnitConsts &K,
                                                 int nR, int rpos, int nM, const P *list,
                                                 bool pickR, bool pickM, int lo_pick) {
@@ -505,7 +505,7 @@ __device__ __forceinline__ int lane_case_b_jump(int n, int pick, double r2, cons
   if (r2 < prob) return pick;
   // the "other" slot of rank t + 1 is the next one below pick: usually pick - 1, found from the
   // rank of pick in the list (no search); other_pos() if the row runs out (it cannot: t < nO)
-  int cpos = pick - 1, k = lo_pick - 1;
+  int cpos = kNextSlot ? pick - 1 : -1, k = lo_pick - 1;
   while (cpos >= 0) {
     if (nR > 0 && cpos >= rpos && cpos < rpos + nR) {
       cpos = rpos - 1;

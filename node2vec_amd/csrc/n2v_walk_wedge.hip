@@ -32,7 +32,9 @@ constexpr int kWedgeThreads = 256;
 
 // the pairing loop for slot `pick` by one lane: closed form by arrangement `arr` (see the kernel),
 // else -- fp64 rounding decides the draw: a tie or a thin margin -- the replays.
-// kMode 0: the (p, q) that leave "other" alone on its stack on ordinary rows; 1: those for which
+// kMode 0 / 3: the (p, q) that leave "other" alone on its stack on ordinary rows, underfull (0) or
+// overfull (3: the mirror closed form then runs at every step and finds the next slot without a
+// search -- code instance 0 does without: its registers are the flagship configuration's); 1: those for which
 // the return run shares a stack with it (arrangements 3-5: compiled out of instance 0, whose
 // registers they would cost); 2: 1/p or 1/q not dyadic -- no exact integer arithmetic, so no
 // closed form: every pairing is replayed run by run in fp64.
@@ -40,13 +42,13 @@ template <typename P, int kMode>
 __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, const UnitConsts &K,
                                            double avg, int nR, int rpos, int nM, const P *list,
                                            bool isR, bool isM, int lo_pick, P *stage, int lane) {
-  constexpr bool kShared = kMode != 0;
+  constexpr bool kShared = kMode == 1 || kMode == 2;
   int res = -1;
   if constexpr (kMode != 2) {
     if (arr == 1)
       res = lane_case_a_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
     else if (arr == 2)
-      res = lane_case_b_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+      res = lane_case_b_jump<P, kMode != 0>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
   }
   if constexpr (kMode == 1) {
     if (arr == 3)
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
   // the pairing and needs the return position: request the wedge offset with the hop, always
   const bool always_pair = K.bO > 1.0;
   const bool merge_r = K.bR == K.bO;
-  constexpr bool kShared = kMode != 0;
+  constexpr bool kShared = kMode == 1 || kMode == 2;
   const bool base_aligned = (reinterpret_cast<uintptr_t>(walks_out) & 63u) == 0;
 #ifdef N2V_CHECK
   n2v_check_status = status;
@@ -314,10 +316,11 @@ int n2v_walk_wedge_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_s
   if (total >= 0xffffff00ll) return 0;
   if (total == 0) return 1;
   // the return run shares a stack with "other" on ordinary rows: q > 1 with p > q, q < 1 with p < q
-  const bool alone = (K.bO <= 1.0 && K.bR >= K.bO) || (K.bO >= 1.0 && K.bR <= K.bO);
-  auto kernel = !K.dyadic ? n2v::walk_exact_wedge_kernel<2>
-                : alone   ? n2v::walk_exact_wedge_kernel<0>
-                          : n2v::walk_exact_wedge_kernel<1>;
+  const bool alone_under = K.bO <= 1.0 && K.bR >= K.bO, alone_over = K.bO >= 1.0 && K.bR <= K.bO;
+  auto kernel = !K.dyadic    ? n2v::walk_exact_wedge_kernel<2>
+                : alone_under ? n2v::walk_exact_wedge_kernel<0>
+                : alone_over  ? n2v::walk_exact_wedge_kernel<3>
+                              : n2v::walk_exact_wedge_kernel<1>;
   int64_t blocks = (total + n2v::kWedgeThreads - 1) / n2v::kWedgeThreads;
   const int64_t cap = n2v::resident_blocks((const void *)kernel, n2v::kWedgeThreads, 0);
   if (blocks > cap) blocks = cap;
