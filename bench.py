@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--no-sgns", action="store_true")
     ap.add_argument("--no-fast", action="store_true")
     ap.add_argument("--no-biased", action="store_true")
+    ap.add_argument("--no-regimes", action="store_true", help="skip the other (p, q) regimes of the exact sampler")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU time budget per baseline leg")
     return ap.parse_args()
 
@@ -253,6 +254,23 @@ def main():
                                                   bq, "exact", rb)}
         del leg
         torch.cuda.empty_cache()
+    # the other arrangements of the three classes on the two stacks of the alias pairing, each
+    # with its own closed form: "other" overfull (cfg 5's p, q), the return slot
+    # sharing a stack with "other", the return slot alone overfull.  Same tables, same launches.
+    if not args.no_biased and not args.no_regimes:
+        regimes = []
+        for rp, rq, what in ((4.0, 0.25, "other alone overfull"), (4.0, 2.0, "return + other underfull"),
+                             (0.25, 0.5, "return + other overfull / return alone overfull")):
+            leg = WalkLeg(torch, rw, g, start_all, W, L, rp, rq, "exact", cfg["biased_batch"], rank, world)
+            rr = leg.run(args.steps, args.warmup, barrier)
+            er, sr = reduce_job(torch, dist, use_dist, dev, rr["elapsed"], rr["steps_done"])
+            regimes.append({"p": rp, "q": rq, "arrangement": what, "value": sr / er,
+                            "unit": "walk-steps/s", "ms_per_step": 1e3 * er / args.steps,
+                            "kernel": kernel_name(g, rp, rq)})
+            del leg
+            torch.cuda.empty_cache()
+        if rank == 0:
+            out["biased_other_regimes"] = regimes
     if not args.no_fast:
         prepare_tables(torch, g, bp, bq, "fast", setup, "fast")
         leg = WalkLeg(torch, rw, g, start_all, W, L, bp, bq, "fast", batch, rank, world)
