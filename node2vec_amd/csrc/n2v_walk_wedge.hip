@@ -14,7 +14,7 @@
 //   3. exits without pairing (~80 % of the steps): an accepted underfull `pick`; an empty stack;
 //   4. the pairing loop (:182-189) for slot `pick`, by the lane itself (n2v_unit_core.h): closed
 //      form by the arrangement of the classes on the two stacks -- "other" alone underfull or
-//      alone overfull; with the return run beside it (instance <true>: q > 1 with p > q, q < 1
+//      alone overfull; with the return run beside it (instance <1>: q > 1 with p > q, q < 1
 //      with p < q) -- in exact integer bucket arithmetic; ties and thin margins fall through to
 //      bit masks (rows of <= 64 slots), else the run-by-run replay over the list, else slot by slot.
 // The path is written as whole 64-byte sectors through an LDS tile (a 4-byte store into a
