@@ -273,3 +273,20 @@ def test_pandas_twin_id_rule_numbers_by_first_appearance():
             sorted(zip(e["src"], e["dst"], e["weight"].astype(np.float32)))
         assert names[torch.from_numpy(vid["vertex_id"].to_numpy())].tolist() == vid["vertex_name"].tolist()
         assert int((names >= 0).sum()) == len(vid)
+
+
+def test_kernel_choice_predicates():
+    """which (p, q) walk from the per-edge tables (randomwalk.tables_regime; the same rule as
+    n2v_walk_exact_unit_try, csrc/n2v_walk_unit.hip): every pair but (1, 1) whose 1/p, 1/q are
+    dyadic or of ordinary magnitude"""
+    from node2vec_amd.randomwalk import lanes_regime, tables_regime
+
+    grid = (0.25, 0.5, 1.0, 2.0, 4.0)
+    assert sum(tables_regime(p, q) for p in grid for q in grid) == 24
+    assert not tables_regime(1.0, 1.0)
+    assert tables_regime(3.0, 0.7) and tables_regime(1.3, 1.3) and tables_regime(1000.0, 0.001)
+    assert not tables_regime(1e-9, 3.0) and not tables_regime(3.0, 1e9)  # outside 2^-20 .. 2^20
+    assert tables_regime(2.0 ** -10, 2.0) and not tables_regime(2.0 ** -30, 2.0)  # 1/p * 2^20 < 2^31
+    # the class-count kernel (graphs without the wedge table): "other" alone and underfull
+    assert lanes_regime(0.5, 2.0) and lanes_regime(1.0, 2.0) and lanes_regime(2.0, 2.0)
+    assert not lanes_regime(4.0, 0.25) and not lanes_regime(4.0, 2.0) and not lanes_regime(3.0, 4.0)
