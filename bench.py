@@ -36,10 +36,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 FP32_PEAK = 157.3e12
-# random 64-byte sector reads per second the chip sustains over a 16 GB table, measured with
-# scripts/micro/gather_ceiling.hip (profiles/r02_gather_ceiling.log: 48.9 G/s independent,
-# 51.0 G/s as dependent chains, 25.5 G "walk-like" steps/s of two dependent gathers)
-GATHER_CEILING = 51.0e9
+# What the memory system of THIS box sustains for the access shapes of the two kernels is
+# measured in this process, untimed, by n2v_mem_probe (measure_ceilings below): random 16-byte
+# gathers over the hop table (K2) and random 512-byte row reads / read-modify-writes over the
+# model (K3).  MEASURED holds the results; nothing is hard-coded.
+MEASURED = {}
 
 CONFIGS = {
     "cfg4": dict(gen="chung_lu", n=100_000_000, draws=500_000_000, trim=10_000, p=1.0, q=1.0,
@@ -155,7 +156,7 @@ class WalkLeg:
             steps_done += int(self.valid.sum()) * self.L
             if self.mode == "fast":
                 trials += int(self.stats["trials"].item())
-        return {"elapsed": elapsed, "steps_done": steps_done, "trials": trials,
+        return {"elapsed": elapsed, "steps_done": steps_done, "trials": trials, "launches": steps,
                 "kernel_s": 1e-3 * sum(kernel_ms) / steps}
 
 
@@ -210,6 +211,11 @@ def main():
     # every launch of a walk kernel in this process has the bench's size: the rocprofv3
     # --kernel-trace average of the kernel is then the HIP-event average reported below
     prepare_tables(torch, g, p, q, "exact", setup, "headline")
+    if rank == 0 and g.hops is not None:
+        # the ceiling the walk kernels are compared with, observed on THIS box: random 16-byte
+        # gathers over this graph's own hop table (untimed; before the K steps)
+        c = measure_ceilings(torch, g.hops)
+        setup["measured_gather_ceiling"] = dict(c, table_GB=g.hops.numel() * g.hops.element_size() / 1e9)
     leg = WalkLeg(torch, rw, g, start_all, W, L, p, q, "exact", batch, rank, world)
     res = leg.run(args.steps, args.warmup, barrier)
     elapsed, steps_total = reduce_job(torch, dist, use_dist, dev, res["elapsed"], res["steps_done"])
@@ -252,6 +258,17 @@ def main():
                              "parity": "bit-identical to the per-step alias rebuild of the reference",
                              "roofline": roofline(kernel_name(g, bp, bq), r2, leg, args.config, bp,
                                                   bq, "exact", rb)}
+            # the one-off tables of the biased kernel amortised over ONE pass over the whole graph
+            # (every start vertex x W walks x L steps at the measured rate): what a single
+            # random_walk() call on a fresh graph gets
+            tables_s = sum(v for k, v in setup.items() if k.startswith("biased_") and k.endswith("_s"))
+            tables_s += setup.get("headline_hop_table_build_s", 0.0)
+            pass_steps = float(start_all.numel()) * W * L  # symmetrised graph: no sinks
+            pass_s = pass_steps / (s2 / e2)
+            out["biased"]["value_incl_setup"] = pass_steps / (pass_s + tables_s)
+            out["biased"]["setup_amortisation"] = {
+                "tables_s": tables_s, "one_pass_walk_s": pass_s, "one_pass_walk_steps": pass_steps,
+                "note": "edge classes + wedge table + hop table, built once per graph"}
         del leg
         torch.cuda.empty_cache()
     # the other arrangements of the three classes on the two stacks of the alias pairing, each
@@ -390,32 +407,84 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
         ":wedges" if (leg.g.wedge_off is not None and mode == "exact" and not (p == 1.0 and q == 1.0)) else "")
     traffic = pmc_traffic(config, kernel_key, p, q, leg.batch)
     alg_launch = alg * per_launch_steps
-    used = traffic if traffic else alg_launch
-    ach = used / res["kernel_s"]
+    ach = alg_launch / res["kernel_s"]
     r = {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
          "frac": ach / HBM_PEAK, "traffic": traffic, "kernel": kernel, "hop_table": hops,
          "wedge_table": ":wedges" in kernel_key,
          "kernel_ms": 1e3 * res["kernel_s"],
-         "achieved_from": "pmc traffic" if traffic else "kernel algorithmic bytes (no pmc profile of this workload)",
+         "achieved_from": "ALGORITHMIC bytes of the kernel (formula below) x walk-steps per launch / "
+                          "HIP-event duration of the launch",
+         "frac_algorithmic": ach / HBM_PEAK,
          "algorithmic_bytes_per_launch": alg_launch, "algorithmic_bytes_per_walk_step": alg,
          "algorithmic_formula": formula,
-         "binding_resource": "random 64-byte sector reads: the chip sustains ~50 G/s = 3.2 TB/s of them "
-                             "(profiles/r02_gather_ceiling.log), i.e. frac <= ~0.4 for a gather-bound "
-                             "kernel; what a kernel can lower is its sectors per step"}
+         "traffic_source": None if not traffic else
+         "profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+         "command on an earlier box (a committed measurement, not observed in this run)"}
     if traffic:
-        # the walk kernels' reads are random gathers: each costs one 64-byte sector on the memory
-        # side of L2 (profiles/r02_gather_fetch_calibration.txt), and sectors/s is what the chip
-        # caps (GATHER_CEILING), long before bytes/s
+        # counter bytes: what crossed the memory side of L2.  The walk kernels' reads are random
+        # gathers and each costs one 64-byte sector whatever it uses of it
+        # (profiles/r02_gather_fetch_calibration.txt), so counter bytes / algorithmic bytes is the
+        # sector overhead of a gather, not re-reads.
         sectors = traffic / 64.0
+        r["frac_counter"] = traffic / res["kernel_s"] / HBM_PEAK
+        r["counter_over_algorithmic"] = traffic / alg_launch
         r["sectors_per_walk_step"] = sectors / per_launch_steps
-        r["gather_ceiling"] = {"achieved_Gsectors_per_s": sectors / res["kernel_s"] / 1e9,
-                               "ceiling_Gsectors_per_s": GATHER_CEILING / 1e9,
-                               "frac": sectors / res["kernel_s"] / GATHER_CEILING,
-                               "source": "profiles/r02_gather_ceiling.log (scripts/micro/gather_ceiling.hip)"}
+    g_meas = MEASURED.get("gather16_independent")
+    if g_meas:
+        # the binding resource, observed on this box: random 16-byte gathers per second
+        gathers = (res["trials"] if mode == "fast" and res.get("trials") else res["steps_done"]) / \
+            max(res["launches"], 1) / res["kernel_s"]
+        r["gather_ceiling"] = {
+            "gathers_per_walk_step_min": 1.0 if hops else 2.0,
+            "kernel_Ggathers_per_s": gathers / 1e9,
+            "measured_Ggathers_per_s_independent": g_meas / 1e9,
+            "measured_Ggathers_per_s_dependent_chain": MEASURED.get("gather16_chain", 0.0) / 1e9,
+            "frac": gathers / g_meas,
+            "source": "n2v_mem_probe modes 0 / 1 over the hop table of this graph, in this process "
+                      "(untimed); counts ONE table gather per step (per trial in fast mode) -- list and "
+                      "membership probes of the biased kernels are extra"}
     if ref_bytes:
         r["reference_algorithmic_bytes_per_walk_step"] = ref_bytes
         r["reference_algorithmic_GBps_equivalent"] = ref_bytes * per_launch_steps / res["kernel_s"] / 1e9
     return r
+
+
+def measure_ceilings(torch, buffer, tag_rows=None):
+    """n2v_mem_probe on `buffer` (a device tensor >> Infinity Cache): random 16-byte gathers,
+    and -- when tag_rows names a row size -- random row reads / read-modify-writes.  Untimed
+    with respect to the bench's K steps; HIP events around each probe launch."""
+    import ctypes as C
+
+    from node2vec_amd import _lib
+
+    L = _lib.load()
+    nbytes = buffer.numel() * buffer.element_size()
+    sink = torch.zeros(4, dtype=torch.int32, device=buffer.device)
+    out = {}
+
+    def run(mode, iters, row_bytes):
+        n = C.c_int64(0)
+        best = None
+        for rep in range(3):  # first = warm-up
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            _lib.check(L.n2v_mem_probe(buffer.data_ptr(), nbytes, mode, iters, row_bytes, C.byref(n),
+                                       sink.data_ptr(), _lib.current_stream_ptr()), "n2v_mem_probe")
+            b.record()
+            torch.cuda.synchronize()
+            dt = 1e-3 * a.elapsed_time(b)
+            if rep:
+                best = dt if best is None else min(best, dt)
+        return n.value / best
+
+    if tag_rows is None:
+        out["gather16_independent"] = run(0, 256, 0)
+        out["gather16_chain"] = run(1, 256, 0)
+    else:
+        out[f"rows{tag_rows}_read"] = run(2, 512, tag_rows)
+        out[f"rows{tag_rows}_read_modify_write"] = run(3, 512, tag_rows)
+    MEASURED.update(out)
+    return out
 
 
 def pmc_traffic(config, kernel, p, q, batch):
@@ -450,6 +519,22 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist)
     model = sgns.SgnsModel(vocab, dim, 5, 5, seed=1, sample=0.0, device=dev)
     idx = index_of[walks.long()].contiguous()
     rows = idx.shape[0]
+    row_ceiling = None
+    if rank == 0:
+        # K3's ceiling on this box: random `dim * 4`-byte rows read / read-modified-written by one
+        # wave each over a scratch buffer far beyond the Infinity Cache (untimed)
+        free = torch.cuda.mem_get_info()[0]
+        nb = int(min(16 << 30, free // 4)) // 4096 * 4096
+        if nb >= (1 << 30) and dim * 4 in (512, 1024, 2048):
+            scratch = torch.empty(nb // 4, dtype=torch.float32, device=dev)
+            scratch.zero_()
+            row_ceiling = measure_ceilings(torch, scratch, dim * 4)
+            # GB/s of row bytes; a read-modify-write moves the row twice (as 8*D*(2+k) counts it)
+            row_ceiling = {k: v * dim * 4 * (2 if k.endswith("write") else 1) / 1e9
+                           for k, v in row_ceiling.items()}
+            row_ceiling["buffer_GB"] = nb / 1e9
+            del scratch
+            torch.cuda.empty_cache()
     for k in range(args.warmup):
         model.train_block(idx, 0.025, k * rows)
     model.pairs.zero_()
@@ -483,6 +568,9 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist)
                                          "algorithmic bytes: the centre row stays in registers and hot "
                                          "rows hit L2)",
                         "traffic_GBps": None if not traffic else traffic / kernel_s / 1e9,
+                        "frac_algorithmic": ach / HBM_PEAK,
+                        "frac_counter": None if not traffic else traffic / kernel_s / HBM_PEAK,
+                        "measured_row_ceiling_GBps": row_ceiling,
                         "algorithmic_bytes_per_pair": bytes_per_pair,
                         "fma_utilisation": pairs / args.steps * flops_per_pair / kernel_s / FP32_PEAK}}
     if use_dist:  # the exchange step of the multi-GPU path, timed once (blocking, bf16 deltas)

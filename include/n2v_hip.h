@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define N2V_ABI_VERSION 5
+#define N2V_ABI_VERSION 6
 
 #define N2V_OK 0
 #define N2V_EINVAL (-1)  /* maps to ValueError (randomwalk.py:212-217)      */
@@ -282,6 +282,12 @@ typedef struct n2v_sgns_params {
   int32_t deterministic;
   int32_t cum_index_bits;   /* log2 of the number of buckets of cum_index (1 .. 30) */
   const int32_t *cum_index; /* device, [2^bits + 1] from n2v_cum_index_build, or NULL */
+  int32_t max_waves; /* 0: hogwild concurrency = one wave per 32 vocabulary rows, up to the whole
+                        chip; > 0: at most this many waves train concurrently */
+  int32_t batched;   /* 0: gensim's sampling -- k negatives drawn per (centre, context) pair;
+                        1 (opt-in, NOT gensim's sampling): the k negatives are drawn once per
+                        centre position and shared by its <= 2 * window pairs, which turns a
+                        position into one small dense product (see n2v_sgns_train) */
 } n2v_sgns_params;
 
 #define N2V_SGNS_MAX_SENTENCE 256 /* longer walks: split rows on the host */
@@ -326,6 +332,20 @@ int n2v_delta_pack(const float *cur, const uint16_t *ref_bf16, int64_t n, float 
                    void *wire_out, int32_t wire_dtype, void *stream);
 int n2v_delta_apply(float *cur, uint16_t *ref_bf16, const float *before, const void *wire_sum,
                     int32_t wire_dtype, int32_t world, int64_t n, void *stream);
+
+/* Measurement aid (bench.py; nothing on the product path calls it): the rate this device
+ * sustains for the access shapes of K2 and K3 on the CALLER's buffer, so that the ceilings the
+ * kernels are compared with are observed on the box the bench runs on.  One launch; the caller
+ * times it (HIP events on `stream`).
+ *   mode 0  independent random 16-byte reads (a hop-table gather), 4 in flight per lane
+ *   mode 1  one dependent chain of random 16-byte reads per lane (a walker)
+ *   mode 2  random rows of row_bytes (512 | 1024 | 2048) read by one wave each (a syn0 row)
+ *   mode 3  the same rows read, modified and written back (a trained row)
+ * iters: accesses per lane (modes 0, 1) / rows per wave (modes 2, 3), a multiple of 4.
+ * *accesses_host (host pointer, optional) receives the number of accesses the launch makes.
+ * buffer: 16-byte aligned device memory, overwritten in mode 3.  sink: one device word. */
+int n2v_mem_probe(void *buffer, int64_t buffer_bytes, int32_t mode, int32_t iters,
+                  int32_t row_bytes, int64_t *accesses_host, uint32_t *sink, void *stream);
 
 #ifdef __cplusplus
 }

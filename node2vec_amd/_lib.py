@@ -1,13 +1,16 @@
 """ctypes binding of node2vec_amd/libn2v_hip.so (the C ABI of include/n2v_hip.h).
 
 There is deliberately no fallback: a missing library or a missing GPU raises.
+N2V_HIP_LIB (environment) names another build of the SAME library (a -DN2V_CHECK / -DN2V_STATS
+diagnostic build, a timing variant of scripts/build_variants.sh): it must export every symbol of
+include/n2v_hip.h and the same ABI version, or the import fails.
 """
 import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libn2v_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OK, EINVAL, ELAUNCH, ENOGPU = 0, -1, -2, -3
 ST_ZERODIV, ST_RANGE = 1, 2
@@ -18,7 +21,8 @@ WIRE_F32, WIRE_BF16 = 0, 1
 SYMBOLS = ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alias_build",
            "n2v_pivots_build", "n2v_edge_classes_build", "n2v_walk", "n2v_trim_mark",
            "n2v_sgns_train", "n2v_delta_ref_init", "n2v_delta_pack", "n2v_delta_apply",
-           "n2v_edge_bias", "n2v_alias_draw", "n2v_hops_build", "n2v_cum_index_build", "n2v_walk_uniforms", "n2v_wedge_build")
+           "n2v_edge_bias", "n2v_alias_draw", "n2v_hops_build", "n2v_cum_index_build", "n2v_walk_uniforms", "n2v_wedge_build",
+           "n2v_mem_probe")
 
 
 class Graph(C.Structure):
@@ -36,7 +40,7 @@ class SgnsParams(C.Structure):
     _fields_ = [("n_vocab", C.c_int64), ("sentence_base", C.c_int64), ("seed", C.c_uint64),
                 ("dim", C.c_int32), ("window", C.c_int32), ("negative", C.c_int32),
                 ("alpha", C.c_float), ("deterministic", C.c_int32), ("cum_index_bits", C.c_int32),
-                ("cum_index", C.c_void_p)]
+                ("cum_index", C.c_void_p), ("max_waves", C.c_int32), ("batched", C.c_int32)]
 
 
 _lib = None
@@ -47,19 +51,23 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("N2V_HIP_LIB") or LIB_PATH
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `make -C node2vec_amd/csrc` "
+            f"{path} is missing: build it with `make -C node2vec_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
             "node2vec_amd has no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
+    missing = [s for s in SYMBOLS if not hasattr(L, s)]
+    if missing:
+        raise ImportError(f"{path} lacks {missing}: not a build of include/n2v_hip.h")
     L.n2v_abi_version.restype = C.c_int
     L.n2v_status_string.restype = C.c_char_p
     L.n2v_status_string.argtypes = [C.c_int]
     L.n2v_device_count.restype = C.c_int
     L.n2v_alias_build.restype = C.c_int
     if L.n2v_abi_version() != ABI_VERSION:
-        raise ImportError(f"{LIB_PATH} has ABI version {L.n2v_abi_version()}, this package needs "
+        raise ImportError(f"{path} has ABI version {L.n2v_abi_version()}, this package needs "
                           f"{ABI_VERSION}: rebuild it (make -C node2vec_amd/csrc)")
     L.n2v_alias_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p]
     L.n2v_edge_classes_build.restype = C.c_int
@@ -102,6 +110,9 @@ def load():
     L.n2v_alias_draw.restype = C.c_int
     L.n2v_alias_draw.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]
+    L.n2v_mem_probe.restype = C.c_int
+    L.n2v_mem_probe.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

@@ -1,0 +1,108 @@
+// n2v_probe.hip -- n2v_mem_probe: what the memory system of THIS device sustains for the access
+// shapes of the two hot kernels, measured on the caller's own buffer (bench.py times it with HIP
+// events and reports it beside the kernels' rates; nothing on the product path calls it).
+//
+//   mode 0  independent random 16-byte reads, 4 in flight per lane -- a hop-table gather (K2)
+//   mode 1  one dependent chain of random 16-byte reads per lane     -- a walker (K2)
+//   mode 2  random rows of `row_bytes` read by one wave, 8 bytes per lane at 512 bytes, two rows
+//           in flight                                              -- a syn0 / syn1neg row (K3)
+//   mode 3  the same rows read, changed and written back           -- a trained row (K3)
+//
+// Addresses come from the counter-based mixer of the walk RNG: uniform over the buffer, so with
+// a buffer much larger than the 256 MB Infinity Cache every access is a miss.
+#include "n2v_common.h"
+
+namespace n2v {
+
+__global__ __launch_bounds__(256) void probe_gather_kernel(const uint4 *__restrict__ t, uint64_t n16,
+                                                           int iters, int dependent,
+                                                           uint32_t *sink) {
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t acc = 0;
+  if (dependent) {
+    uint64_t idx = mix64(gid) % n16;
+    for (int k = 0; k < iters; ++k) {
+      const uint4 r = t[idx];
+      acc += r.w;
+      idx = mix64(((uint64_t)r.x << 32 | r.y) ^ (gid + (uint64_t)k * 0x9E3779B97F4A7C15ULL)) % n16;
+    }
+  } else {
+    for (int k = 0; k < iters; k += 4) {
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = t[mix64(gid * 0x100000001B3ULL + (uint64_t)(k + u)) % n16];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc += v[u].x + v[u].w;
+    }
+  }
+  if (acc == 0x12345678u) sink[0] = acc;  // keeps the loads alive
+}
+
+template <bool kWrite>
+__global__ __launch_bounds__(256) void probe_rows_kernel(float *t, uint64_t n_rows, int row_floats,
+                                                         int iters, uint32_t *sink) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int per_lane = row_floats / 64;  // 2 at 512-byte rows (float2 per lane), 4 at 1024
+  float acc = 0.0f;
+  for (int k = 0; k < iters; k += 2) {
+    float *r0 = t + (mix64(wave * 0x100000001B3ULL + (uint64_t)k) % n_rows) * (uint64_t)row_floats;
+    float *r1 = t + (mix64(wave * 0x100000001B3ULL + (uint64_t)k + 1) % n_rows) * (uint64_t)row_floats;
+    if (per_lane == 2) {
+      float2 a = reinterpret_cast<const float2 *>(r0)[lane];
+      float2 b = reinterpret_cast<const float2 *>(r1)[lane];
+      acc += a.x + b.y;
+      if (kWrite) {
+        reinterpret_cast<float2 *>(r0)[lane] = make_float2(a.x + 1.0f, a.y);
+        reinterpret_cast<float2 *>(r1)[lane] = make_float2(b.x, b.y + 1.0f);
+      }
+    } else {
+      for (int q = 0; q < per_lane / 4; ++q) {
+        float4 a = reinterpret_cast<const float4 *>(r0)[lane * (per_lane / 4) + q];
+        float4 b = reinterpret_cast<const float4 *>(r1)[lane * (per_lane / 4) + q];
+        acc += a.x + b.w;
+        if (kWrite) {
+          a.x += 1.0f;
+          b.w += 1.0f;
+          reinterpret_cast<float4 *>(r0)[lane * (per_lane / 4) + q] = a;
+          reinterpret_cast<float4 *>(r1)[lane * (per_lane / 4) + q] = b;
+        }
+      }
+    }
+  }
+  if (acc == 1234.5f) sink[0] = 1;
+}
+
+}  // namespace n2v
+
+extern "C" int n2v_mem_probe(void *buffer, int64_t buffer_bytes, int32_t mode, int32_t iters,
+                             int32_t row_bytes, int64_t *accesses_host, uint32_t *sink,
+                             void *stream) {
+  if (!buffer || !sink || buffer_bytes < 4096 || iters < 4 || (iters & 3) || mode < 0 || mode > 3)
+    return N2V_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(buffer) & 15u) != 0) return N2V_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int threads = 256;
+  if (mode <= 1) {
+    const int64_t blocks = n2v::resident_blocks((const void *)n2v::probe_gather_kernel, threads, 0);
+    if (accesses_host) *accesses_host = blocks * threads * (int64_t)iters;
+    hipLaunchKernelGGL(n2v::probe_gather_kernel, dim3((unsigned)blocks), dim3(threads), 0, st,
+                       (const uint4 *)buffer, (uint64_t)(buffer_bytes / 16), iters, mode, sink);
+  } else {
+    if (row_bytes != 512 && row_bytes != 1024 && row_bytes != 2048) return N2V_EINVAL;
+    const uint64_t n_rows = (uint64_t)(buffer_bytes / row_bytes);
+    if (n_rows < 2) return N2V_EINVAL;
+    const void *fn = mode == 2 ? (const void *)n2v::probe_rows_kernel<false>
+                               : (const void *)n2v::probe_rows_kernel<true>;
+    const int64_t blocks = n2v::resident_blocks(fn, threads, 0);
+    if (accesses_host) *accesses_host = blocks * (threads / 64) * (int64_t)iters;
+    if (mode == 2)
+      hipLaunchKernelGGL(n2v::probe_rows_kernel<false>, dim3((unsigned)blocks), dim3(threads), 0, st,
+                         (float *)buffer, n_rows, row_bytes / 4, iters, sink);
+    else
+      hipLaunchKernelGGL(n2v::probe_rows_kernel<true>, dim3((unsigned)blocks), dim3(threads), 0, st,
+                         (float *)buffer, n_rows, row_bytes / 4, iters, sink);
+  }
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}

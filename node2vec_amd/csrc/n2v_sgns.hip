@@ -446,6 +446,13 @@ extern "C" int n2v_cum_index_build(const uint32_t *cum_table, int64_t n_vocab, i
   return N2V_OK;
 }
 
+// the opt-in batched variant (n2v_sgns_batched.hip)
+extern "C" int n2v_sgns_batched_launch(const int32_t *walks, int64_t n_walks, int32_t walk_len,
+                                       float *syn0, float *syn1neg, const uint32_t *cum_table,
+                                       const uint32_t *sample_int, const float *exp_table,
+                                       const n2v_sgns_params *P, unsigned long long *pairs_out,
+                                       void *stream);
+
 extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t walk_len,
                               float *syn0, float *syn1neg, const uint32_t *cum_table,
                               const uint32_t *sample_int, const float *exp_table,
@@ -456,7 +463,10 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   if (P->n_vocab < 1 || P->dim < 1 || P->dim > 1024 || P->window < 1 || P->window > 32 ||
       P->negative < 1 || P->negative > 32)
     return N2V_EINVAL;
+  if (P->batched != 0 && P->batched != 1) return N2V_EINVAL;
   if (n_walks == 0) return N2V_OK;
+  if (P->batched) return n2v_sgns_batched_launch(walks, n_walks, walk_len, syn0, syn1neg, cum_table,
+                                                 sample_int, exp_table, P, pairs_out, stream);
   using namespace n2v;
   const size_t lds = kExpTable * sizeof(float) + (kBuckets + 1) * sizeof(int32_t) +
                      (size_t)kSgnsWaves * (2 * kMaxSent + (2 * P->window + 1) * P->negative) * 4;
@@ -467,6 +477,7 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   int64_t waves = P->n_vocab / 32;
   if (waves < 1) waves = 1;
   if (waves > n_walks) waves = n_walks;
+  if (P->max_waves > 0 && waves > P->max_waves) waves = P->max_waves;
   int64_t blocks = (waves + kSgnsWaves - 1) / kSgnsWaves;
   if (P->cum_index && (P->cum_index_bits < 1 || P->cum_index_bits > 30)) return N2V_EINVAL;
 #ifdef N2V_SGNS_TUNE

@@ -74,10 +74,14 @@ __device__ __forceinline__ int lower_bound_lane(const int32_t *a, int m, int32_t
 // col[row + int(r1 * n)] (4-byte gather, no slots needed, and the index of the edge walked is
 // known).  With the per-edge class counts (g.edge_classes, n2v_edge_classes_build) two more
 // things follow for the step (s -> v): the multiplicity nR of the return edge, which takes the
-// return edge OUT of the rejection envelope (choose "return" with its exact share
-// (nR/p) / (nR/p + (n - nR) b'), otherwise draw among the other entries and accept with
-// beta(x) / b', b' = max(1, 1/q): P(x) ~ beta(x) as before, but p no longer inflates the
-// envelope -- 3.5 -> 2.1 trials per step at p = 0.5, q = 2); and the number nM of neighbours of
+// return edge OUT of the rejection envelope.  One trial = with probability rho propose "return"
+// (always accepted), otherwise propose one of ALL n entries uniformly, reject it if it is the
+// return edge and accept any other x with beta(x) / b', b' = max(1, 1/q).  Per trial
+// P(return) = rho and P(x) = (1 - rho) beta(x) / (n b'), so P(return) : P(x) = (nR/p) : beta(x)
+// -- the reference's rule, randomwalk.py:219-231 -- needs rho / (1 - rho) = (nR/p) / (n b'):
+// rho = (nR/p) / (nR/p + n b').  (Round 2 had (n - nR) b' there, which over-weights the return
+// edge by n / (n - nR): the candidate is drawn over n entries, not n - nR.)  p no longer
+// inflates the envelope: 3.5 -> ~2 trials per step at p = 0.5, q = 2.  And the number nM of neighbours of
 // v that are neighbours of s: when it is 0 the test "x in N(s)" (:226) is known to fail and
 // its binary search is skipped.
 // kHops (unit weights): candidates come from the hop table (n2v_hops_build) -- the accepted
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
         if (fM != N2V_EC_SHARED_MASK) shared = (int)fM;
         if (fold_return && fR != N2V_EC_RETURN_SAT) {
           const double wr = (double)fR * inv_p;
-          rho = wr / (wr + (double)(n - (int)fR) * b_hi);
+          rho = wr / (wr + (double)n * b_hi);  // candidates are drawn over all n entries
         }
       }
     }

@@ -156,8 +156,8 @@ __device__ __forceinline__ int wedge_wave(const int32_t *scol, int ds, const int
 
 template <typename P>
 __global__ __launch_bounds__(256) void wedge_fill_kernel(n2v_graph g,
-                                                        const uint64_t *__restrict__ list_off,
-                                                        uint64_t *__restrict__ wedge_off,
+                                                        const uint64_t *list_off,  // may alias wedge_off (in-place use is allowed)
+                                                        uint64_t *wedge_off,
                                                         P *__restrict__ wedge_pos,
                                                         uint32_t *__restrict__ status,
                                                         uint32_t *__restrict__ counter) {

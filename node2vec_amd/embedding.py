@@ -141,14 +141,11 @@ class Node2VecHIP(Node2VecBase):
     def _walk_tensor(self, device) -> torch.Tensor:
         if isinstance(self.walks, torch.Tensor):
             return self.walks.to(device=device, dtype=torch.int32)
-        dev_walks = getattr(self.walks, "attrs", {}).get("n2v_device_walks")
-        if isinstance(dev_walks, torch.Tensor) and dev_walks.shape[0] == len(self.walks) > 0:
-            # the frame random_walk() returned: its walks are still in HBM.  Trust them only if
-            # the frame's first and last rows still say the same (a filtered / edited frame
-            # falls through to the conversion below).
-            ends = dev_walks[[0, -1]].cpu().numpy().tolist()
-            if [list(self.walks["walk"].iloc[0]), list(self.walks["walk"].iloc[-1])] == ends:
-                return dev_walks.to(device=device, dtype=torch.int32)
+        from node2vec_amd import corpus
+
+        dev_walks = corpus.lookup(self.walks)  # the frame random_walk() returned, unchanged
+        if dev_walks is not None:
+            return dev_walks.to(device=device, dtype=torch.int32)
         # embedding.py:125 requires equal-length walks (np.array(walks.tolist()))
         arr = np.array(self.walks["walk"].tolist())
         if arr.ndim != 2:

@@ -16,7 +16,7 @@ import numpy as np
 import pandas as pd
 import torch
 
-from node2vec_amd import _lib
+from node2vec_amd import _lib, corpus
 from node2vec_amd import randomwalk as rw
 from node2vec_amd.constants import MAX_OUT_DEGREES, NODE2VEC_PARAMS
 from node2vec_amd.graph import DeviceGraph
@@ -158,7 +158,8 @@ def random_walk(
     # the list-of-lists column in one C call (a Python loop over rows is 10x slower).
     df = pd.DataFrame({"src": w[:, 0].astype(np.int64) if len(w) else np.zeros(0, np.int64),
                        "walk": w.tolist()})
-    # the same walks as an on-device corpus: Node2VecHIP.fit() trains from it when the frame
-    # reaches it unchanged, instead of converting the list column back (embedding.py:125)
-    df.attrs["n2v_device_walks"] = kept
+    # the same walks as an on-device corpus: Node2VecHIP.fit() trains from it when THIS frame
+    # reaches it unchanged, instead of converting the list column back (embedding.py:125).  The
+    # frame carries a plain integer token only (pandas copies / compares / serialises attrs).
+    corpus.attach(df, kept)
     return df

@@ -136,6 +136,8 @@ class SgnsModel:
                     self.cum_table.data_ptr(), n, self.cum_index_bits, self.cum_index.data_ptr(),
                     _lib.current_stream_ptr()), "n2v_cum_index_build")
         # include/n2v_hip.h: pairs_out is two uint64, [0] the pair counter, [1] kernel scratch
+        self.max_waves = 0  # hogwild concurrency cap (0 = the library's rule, n2v_sgns_params)
+        self.batched = False  # opt-in: negatives shared by the pairs of a centre position
         self._counters = torch.zeros(2, dtype=torch.int64, device=device)
         self.pairs = self._counters[:1]
         self.sentences_seen = 0
@@ -153,7 +155,8 @@ class SgnsModel:
         walks_idx = walks_idx.contiguous()
         P = _lib.SgnsParams(len(self.vocab), int(sentence_base), self.seed, self.dim, self.window,
                             self.negative, float(alpha), int(bool(deterministic)),
-                            self.cum_index_bits, 0 if self.cum_index is None else self.cum_index.data_ptr())
+                            self.cum_index_bits, 0 if self.cum_index is None else self.cum_index.data_ptr(),
+                            int(self.max_waves), int(bool(self.batched)))
         with torch.cuda.device(walks_idx.device):
             rc = L.n2v_sgns_train(walks_idx.data_ptr(), walks_idx.shape[0], walks_idx.shape[1],
                                   self.syn0.data_ptr(), self.syn1neg.data_ptr(),
@@ -182,6 +185,10 @@ class SgnsModel:
             block_rows = max(1, min(max(grid_rows, 1), max(65536, math.ceil(grid_rows / 64))))
         total = max(1, grid_rows * max(epochs, 1))
         done = 0
+        if sync is not None and not hasattr(sync, "step"):
+            sync = _CallableSync(sync)  # the round-1 protocol: a plain callable, called per launch
+        if sync is not None and getattr(sync, "max_every", 0) is None:
+            sync.max_every = max(1, math.ceil(max(grid_rows, 1) / block_rows))  # launches per epoch
         for ep in range(epochs):
             for lo in range(0, max(grid_rows, 1), block_rows):
                 hi = min(grid_rows, lo + block_rows)
@@ -196,6 +203,19 @@ class SgnsModel:
             sync.finish()
         self.sentences_seen += rows * epochs
         return self
+
+
+class _CallableSync:
+    """adapter: SgnsModel.train(sync=f) with a plain callable f (called after every launch)"""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def step(self):
+        self.fn()
+
+    def finish(self):
+        pass
 
 
 def split_rows(walks_idx: torch.Tensor, max_len: int = MAX_SENTENCE) -> torch.Tensor:
@@ -250,6 +270,7 @@ class DeltaSync:
         self.sync_every = None if sync_every is None else max(1, int(sync_every))
         self.calls = 0
         self.syncs = 0
+        self.max_every: Optional[int] = None  # ceiling of the autotuned period (set by train())
         self.on_gpu = all(t.is_cuda for t in self.tensors)
         self.side = torch.cuda.Stream(self.tensors[0].device) if (overlap and self.on_gpu) else None
         self._pending = None
@@ -385,14 +406,26 @@ class DeltaSync:
             self._t_mark = now()
             self._t_sync = self._t_mark - t0
             return
-        t_launch = max(now() - self._t_mark, 1e-6)  # one training launch since then
-        share = min(max(self.comm_share, 1e-3), 0.999)
-        every = max(1, math.ceil(self._t_sync * (1.0 - share) / (share * t_launch)))
+        # The MEASUREMENTS are agreed (MAX over ranks), not the derived period: a rank whose
+        # shard is empty or shorter than a block measures t_launch ~ 0 and would otherwise push
+        # an astronomically long period onto everybody -- the replicas would then
+        # train independently and only be averaged once, at finish().
+        t_launch = max(now() - self._t_mark, 0.0)  # one training launch since then
         dev = self.tensors[0].device
-        v = torch.tensor([every], dtype=torch.int64, device=dev)
+        v = torch.tensor([self._t_sync, t_launch], dtype=torch.float64, device=dev)
         self.dist.all_reduce(v, op=self.dist.ReduceOp.MAX, group=self.group)
-        self.sync_every = int(v.item())
+        self.sync_every = self.period_for(float(v[0]), float(v[1]))
         self.calls = 0  # periods count from here
+
+    def period_for(self, t_sync: float, t_launch: float) -> int:
+        """launches between two exchanges so that the collective takes <= comm_share of the time;
+        never longer than `max_every` (SgnsModel.train: the launches of one epoch), so that the
+        replicas are averaged at least once per epoch whatever the timings say"""
+        share = min(max(self.comm_share, 1e-3), 0.999)
+        every = max(1, math.ceil(t_sync * (1.0 - share) / (share * max(t_launch, 1e-6))))
+        if self.max_every is not None:
+            every = min(every, max(1, int(self.max_every)))
+        return every
 
     def finish(self):
         """drain the side stream and average once more, blocking: all replicas identical"""

@@ -98,6 +98,7 @@ def test_trim_mark_equals_oracle_and_reference_properties(oracle):
     assert (keep != keep2).any()
 
 
+@pytest.mark.statistical
 def test_trim_is_uniform():
     """each edge of a hot row survives with probability cap / degree"""
     from node2vec_amd.fugue import trim_hotspot_edges
@@ -121,6 +122,7 @@ def test_fast_mode_first_step_equals_exact_mode():
     assert torch.equal(a, b) and torch.equal(va, vb)
 
 
+@pytest.mark.statistical
 @pytest.mark.parametrize("pq", [(0.5, 2.0), (4.0, 0.25), (1.0, 1.0), (1.0, 3.0)])
 def test_fast_mode_transition_distribution(oracle, pq):
     """chi-square of the second step given (s, v) against the exact transition

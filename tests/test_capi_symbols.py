@@ -18,7 +18,8 @@ def test_header_declares_the_expected_entry_points():
     for want in ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alias_build", "n2v_pivots_build",
                  "n2v_edge_classes_build", "n2v_walk", "n2v_trim_mark", "n2v_sgns_train",
                  "n2v_delta_ref_init", "n2v_delta_pack", "n2v_delta_apply", "n2v_edge_bias", "n2v_alias_draw",
-                 "n2v_hops_build", "n2v_cum_index_build", "n2v_walk_uniforms", "n2v_wedge_build"):
+                 "n2v_hops_build", "n2v_cum_index_build", "n2v_walk_uniforms", "n2v_wedge_build",
+                 "n2v_mem_probe"):
         assert want in names
 
 
@@ -33,7 +34,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert sorted(_lib.SYMBOLS) == _declared()
     lib.n2v_abi_version.restype = ctypes.c_int
-    assert lib.n2v_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.n2v_abi_version() == _lib.ABI_VERSION == 6
     lib.n2v_status_string.restype = ctypes.c_char_p
     assert lib.n2v_status_string(-1) == b"invalid argument"
 
@@ -51,10 +52,13 @@ def test_ctypes_structs_match_header_layout():
     body = text[text.index("typedef struct n2v_graph {"):text.index("} n2v_graph;")]
     fields = re.findall(r"\*?\s*\b(\w+);", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
     assert fields == [f[0] for f in _lib.Graph._fields_]
-    assert ctypes.sizeof(_lib.SgnsParams) == 3 * 8 + 6 * 4 + 8
+    assert ctypes.sizeof(_lib.SgnsParams) == 3 * 8 + 6 * 4 + 8 + 2 * 4
     assert [f[0] for f in _lib.SgnsParams._fields_] == [
         "n_vocab", "sentence_base", "seed", "dim", "window", "negative", "alpha",
-        "deterministic", "cum_index_bits", "cum_index"]
+        "deterministic", "cum_index_bits", "cum_index", "max_waves", "batched"]
+    body = text[text.index("typedef struct n2v_sgns_params {"):text.index("} n2v_sgns_params;")]
+    fields = re.findall(r"\*?\s*\b(\w+);", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    assert fields == [f[0] for f in _lib.SgnsParams._fields_]
 
 
 def test_product_package_never_touches_the_oracle():

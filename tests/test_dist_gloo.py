@@ -93,6 +93,36 @@ def _worker(rank, world, port, ret):
         want_rows = [4, 1, 4, 1] if rank == 0 else [4, 4, 1, 4, 4, 1]
         ok = ok and [r for r, _ in m.launched] == want_rows
         ok = ok and len({b for _, b in m.launched}) == len(m.launched)  # sentence ids never repeat
+        # autotuned period with an EMPTY shard: rank 1 trains nothing, so its own
+        # launch time is ~0; the period must come from the MAX of the measured times (rank 0's
+        # 20 ms launches), be the same on both ranks and stay below the launches of one epoch
+        import time as _time
+
+        class _Slow(sgns.SgnsModel):
+            def __init__(self):
+                self.sentences_seen = 0
+                self.launched = 0
+
+            def train_block(self, walks_idx, alpha, sentence_base, deterministic=False):
+                self.launched += 1
+                _time.sleep(0.02)
+
+        tt = torch.zeros(64, 4) + rank
+        auto = DeltaSync([tt], sync_every=None, comm_share=0.5)
+        rows = 40 if rank == 0 else 0
+        ms = _Slow()
+        ms.train(torch.zeros((rows, 3), dtype=torch.int32), epochs=1, block_rows=4, sync=auto,
+                 rows_global_max=40)
+        every = torch.tensor([auto.sync_every or 0])
+        both = [torch.zeros_like(every) for _ in range(world)]
+        dist.all_gather(both, every)
+        ok = ok and int(both[0]) == int(both[1]) and 1 <= int(both[0]) <= 10  # 10 launches per epoch
+        ok = ok and auto.max_every == 10 and ms.launched == (10 if rank == 0 else 0)
+        ok = ok and auto.syncs >= 2  # the timed first exchange + finish(), at least
+        # the period function itself: a zero launch time is clamped, not propagated
+        ok = ok and auto.period_for(1.0, 0.0) == 10
+        auto.max_every = None
+        ok = ok and auto.period_for(0.1, 1.0) == 1 and auto.period_for(1.0, 0.1) == 10
         # walk sharding: ranges are disjoint and cover all start vertices
         lo, hi = shard_range(1001, rank, world)
         cover = torch.zeros(1001)

@@ -290,3 +290,43 @@ def test_kernel_choice_predicates():
     # the class-count kernel (graphs without the wedge table): "other" alone and underfull
     assert lanes_regime(0.5, 2.0) and lanes_regime(1.0, 2.0) and lanes_regime(2.0, 2.0)
     assert not lanes_regime(4.0, 0.25) and not lanes_regime(4.0, 2.0) and not lanes_regime(3.0, 4.0)
+
+
+def test_device_corpus_token_survives_pandas(tmp_path):
+    """the frame random_walk() returns must survive to_parquet / concat / head /
+    filters; pandas copies, compares and JSON-serialises DataFrame.attrs, so the frame carries an
+    integer token and the device tensor lives in node2vec_amd.corpus"""
+    import gc
+
+    import pandas as pd
+    import torch
+
+    from node2vec_amd import corpus
+
+    def frame(seed):
+        w = torch.randint(0, 50, (200, 6), generator=torch.Generator().manual_seed(seed), dtype=torch.int32)
+        df = pd.DataFrame({"src": w[:, 0].numpy().astype("int64"), "walk": w.numpy().tolist()})
+        corpus.attach(df, w)
+        return df, w
+
+    a, wa = frame(1)
+    b, wb = frame(2)
+    assert corpus.lookup(a) is wa and corpus.lookup(b) is wb
+    assert isinstance(a.attrs[corpus.ATTR], int)
+    a.to_parquet(tmp_path / "walks.parquet")  # raised TypeError with a tensor in attrs
+    both = pd.concat([a, b])  # raised RuntimeError (attrs compared with ==)
+    assert len(both) == 400 and corpus.lookup(both) is None
+    merged = a.merge(b, on="src", how="inner")
+    assert corpus.lookup(merged) is None
+    assert corpus.lookup(a.head(1)) is None  # derived frames: converted from their own rows
+    assert corpus.lookup(a[a["src"] > 10]) is None
+    back = pd.read_parquet(tmp_path / "walks.parquet")
+    assert corpus.lookup(back) is None
+    # an edited frame of the same length no longer matches its tensor
+    c, wc = frame(3)
+    c["walk"] = [[0] * 6] * len(c)
+    assert corpus.lookup(c) is None
+    n_before = len(corpus._registry)
+    del a, both, merged
+    gc.collect()
+    assert len(corpus._registry) == n_before - 1  # the entry dies with its frame

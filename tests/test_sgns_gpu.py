@@ -77,6 +77,7 @@ def test_hogwild_pair_count_equals_oracle(oracle):
     assert 0.5 < np.linalg.norm(got) / np.linalg.norm(s0) < 2.0
 
 
+@pytest.mark.statistical
 def test_hogwild_learns_community_structure(oracle):
     """two 20-vertex cliques joined by one edge: after training, vectors of the
     same clique are closer than vectors of different cliques (GPU and oracle)."""
@@ -121,6 +122,7 @@ def test_hogwild_learns_community_structure(oracle):
     assert abs(g_gpu - g_cpu) < 0.15
 
 
+@pytest.mark.statistical
 def test_hogwild_vs_deterministic_statistical_parity():
     """Full-speed (hogwild) mode cannot be bit-compared; the claim is statistical
     (SURVEY.md 8c): on a planted-partition graph (50 communities x 40 vertices) the

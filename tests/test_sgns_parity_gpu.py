@@ -24,7 +24,7 @@ import torch
 
 from conftest import load_golden
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.statistical]
 
 
 def _procrustes_cos(x, y):
