@@ -4,7 +4,7 @@
 //
 //   mode 0  independent random 16-byte reads, 4 in flight per lane -- a hop-table gather (K2)
 //   mode 1  one dependent chain of random 16-byte reads per lane     -- a walker (K2)
-//   mode 2  random rows of `row_bytes` read by one wave, 8 bytes per lane at 512 bytes, two rows
+//   mode 2  random rows of `row_bytes` read by one wave, 8 bytes per lane at 512 bytes, four rows
 //           in flight                                              -- a syn0 / syn1neg row (K3)
 //   mode 3  the same rows read, changed and written back           -- a trained row (K3)
 //
@@ -45,27 +45,32 @@ __global__ __launch_bounds__(256) void probe_rows_kernel(float *t, uint64_t n_ro
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int per_lane = row_floats / 64;  // 2 at 512-byte rows (float2 per lane), 4 at 1024
   float acc = 0.0f;
-  for (int k = 0; k < iters; k += 2) {
-    float *r0 = t + (mix64(wave * 0x100000001B3ULL + (uint64_t)k) % n_rows) * (uint64_t)row_floats;
-    float *r1 = t + (mix64(wave * 0x100000001B3ULL + (uint64_t)k + 1) % n_rows) * (uint64_t)row_floats;
+  for (int k = 0; k < iters; k += 4) {  // four rows in flight per wave
+    float *rp[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      rp[u] = t + (mix64(wave * 0x100000001B3ULL + (uint64_t)(k + u)) % n_rows) * (uint64_t)row_floats;
     if (per_lane == 2) {
-      float2 a = reinterpret_cast<const float2 *>(r0)[lane];
-      float2 b = reinterpret_cast<const float2 *>(r1)[lane];
-      acc += a.x + b.y;
-      if (kWrite) {
-        reinterpret_cast<float2 *>(r0)[lane] = make_float2(a.x + 1.0f, a.y);
-        reinterpret_cast<float2 *>(r1)[lane] = make_float2(b.x, b.y + 1.0f);
+      float2 a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = reinterpret_cast<const float2 *>(rp[u])[lane];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc += a[u].x;
+        if (kWrite) reinterpret_cast<float2 *>(rp[u])[lane] = make_float2(a[u].x + 1.0f, a[u].y);
       }
     } else {
       for (int q = 0; q < per_lane / 4; ++q) {
-        float4 a = reinterpret_cast<const float4 *>(r0)[lane * (per_lane / 4) + q];
-        float4 b = reinterpret_cast<const float4 *>(r1)[lane * (per_lane / 4) + q];
-        acc += a.x + b.w;
-        if (kWrite) {
-          a.x += 1.0f;
-          b.w += 1.0f;
-          reinterpret_cast<float4 *>(r0)[lane * (per_lane / 4) + q] = a;
-          reinterpret_cast<float4 *>(r1)[lane * (per_lane / 4) + q] = b;
+        float4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = reinterpret_cast<const float4 *>(rp[u])[lane * (per_lane / 4) + q];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc += a[u].x;
+          if (kWrite) {
+            a[u].x += 1.0f;
+            reinterpret_cast<float4 *>(rp[u])[lane * (per_lane / 4) + q] = a[u];
+          }
         }
       }
     }

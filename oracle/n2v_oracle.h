@@ -115,6 +115,12 @@ int64_t n2v_oracle_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
                               const uint32_t *sample_int, const float *exp_table,
                               int64_t n_vocab, int64_t sentence_base, uint64_t seed,
                               int32_t dim, int32_t window, int32_t negative, float alpha);
+/* the opt-in batched variant (negatives shared by the pairs of a centre position) */
+int64_t n2v_oracle_sgns_train_batched(const int32_t *walks, int64_t n_walks, int32_t walk_len,
+                              float *syn0, float *syn1neg, const uint32_t *cum_table,
+                              const uint32_t *sample_int, const float *exp_table,
+                              int64_t n_vocab, int64_t sentence_base, uint64_t seed,
+                              int32_t dim, int32_t window, int32_t negative, float alpha);
 
 #ifdef __cplusplus
 }

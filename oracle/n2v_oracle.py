@@ -56,6 +56,7 @@ def lib():
         L.n2v_oracle_transition_probs.restype = C.c_int
         L.n2v_oracle_edge_classes.restype = C.c_int
         L.n2v_oracle_sgns_train.restype = C.c_int64
+        L.n2v_oracle_sgns_train_batched.restype = C.c_int64
         _LIB = L
     return _LIB
 
@@ -178,7 +179,7 @@ def edge_classes(rowptr, col):
 
 
 def sgns_train(walks_idx, syn0, syn1neg, cum_table, sample_int, exp_table, n_vocab,
-               sentence_base, seed, dim, window, negative, alpha):
+               sentence_base, seed, dim, window, negative, alpha, batched=False):
     """oracle/n2v_oracle_sgns.c: trains in place (syn0, syn1neg float32 C-contiguous),
     rows in order on one thread.  Returns the number of pairs trained."""
     walks_idx = np.ascontiguousarray(walks_idx, np.int32)
@@ -187,7 +188,8 @@ def sgns_train(walks_idx, syn0, syn1neg, cum_table, sample_int, exp_table, n_voc
     cum = np.ascontiguousarray(cum_table).view(np.uint32)
     si = None if sample_int is None else np.ascontiguousarray(sample_int).view(np.uint32)
     et = np.ascontiguousarray(exp_table, np.float32)
-    n = lib().n2v_oracle_sgns_train(
+    fn = lib().n2v_oracle_sgns_train_batched if batched else lib().n2v_oracle_sgns_train
+    n = fn(
         _p(walks_idx), C.c_int64(walks_idx.shape[0]), C.c_int32(walks_idx.shape[1]),
         _p(syn0), _p(syn1neg), _p(cum), None if si is None else _p(si), _p(et),
         C.c_int64(n_vocab), C.c_int64(sentence_base), C.c_uint64(seed), C.c_int32(dim),

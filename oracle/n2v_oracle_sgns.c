@@ -158,3 +158,134 @@ int64_t n2v_oracle_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   free(work);
   return pairs;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * The opt-in BATCHED variant (n2v_sgns_params.batched = 1; node2vec_amd/csrc/n2v_sgns_batched.hip).
+ * NOT gensim's sampling: the `negative` draws are made once per centre position and shared by
+ * its <= 2 * window (centre, context) pairs, and all pairs of a position are trained from one
+ * snapshot of the rows (Ji et al., "Parallelizing Word2Vec in Shared and Distributed Memory",
+ * 2016: the position becomes one small dense product).  Per position i with contexts J:
+ *   context rows  = the distinct words of J in order of first appearance, multiplicity mu_c
+ *   target rows   = centre (label 1), then the distinct negative words != centre in draw
+ *                   order, multiplicity mu_t (a repeated draw counts twice)
+ *   F[c][t]       = syn0[c] . syn1neg[t]
+ *   G[c][t]       = 0 if |F| >= 6 else ((label_t - sigma(F)) * alpha) * (mu_c * mu_t)
+ *   syn1neg[t]   += sum_c G[c][t] * syn0_old[c];   syn0[c] += sum_t G[c][t] * syn1neg_old[t]
+ * The summation orders below are those of the kernel's v_mfma_f32_16x16x4_f32 chains (an f32
+ * MFMA is bit-for-bit a k-ordered fmaf chain), so the deterministic GPU mode is bit-identical.
+ * Negative draws of position i use the indices the per-pair mode gives relative position 0. */
+int64_t n2v_oracle_sgns_train_batched(const int32_t *walks, int64_t n_walks, int32_t walk_len,
+                                      float *syn0, float *syn1neg, const uint32_t *cum_table,
+                                      const uint32_t *sample_int, const float *exp_table,
+                                      int64_t n_vocab, int64_t sentence_base, uint64_t seed,
+                                      int32_t dim, int32_t window, int32_t negative, float alpha) {
+  if (walk_len > 256 || dim < 4 || dim > 1024 || (dim & 3) || window < 1 || 2 * window + 1 > 16 ||
+      negative < 1 || negative > 15)
+    return -1;
+  const int Q = dim / 4;
+  const int KC = (2 * window + 1 <= 12) ? 3 : 4; /* k-steps over context rows */
+  const int KT = (1 + negative <= 8) ? 2 : 4;    /* k-steps over target rows */
+  int32_t sent[256];
+  uint32_t red[256];
+  float *cold = (float *)malloc(sizeof(float) * (size_t)dim * 16);
+  float *told = (float *)malloc(sizeof(float) * (size_t)dim * 16);
+  int64_t pairs = 0;
+  const uint32_t domain = cum_table[n_vocab - 1];
+  for (int64_t r = 0; r < n_walks; ++r) {
+    const uint64_t hs = sentence_stream(seed, (uint64_t)(sentence_base + r));
+    int nf = 0;
+    for (int t = 0; t < walk_len; ++t) {
+      int32_t tok = walks[r * walk_len + t];
+      if (tok < 0 || tok >= n_vocab) continue;
+      uint32_t rnd = (uint32_t)(draw(hs, 2ULL * (uint64_t)t) >> 32);
+      if (sample_int && sample_int[tok] < rnd) continue;
+      sent[nf] = tok;
+      red[nf] = (uint32_t)(draw(hs, 2ULL * (uint64_t)t + 1ULL) >> 32) % (uint32_t)window;
+      ++nf;
+    }
+    for (int i = 0; i < nf; ++i) {
+      const int32_t centre = sent[i];
+      int lo = i - window + (int)red[i];
+      if (lo < 0) lo = 0;
+      int hi = i + window + 1 - (int)red[i];
+      if (hi > nf) hi = nf;
+      int32_t uword[16], tword[16];
+      int umult[16], tmult[16], nu = 0, nt = 0, npairs = 0;
+      for (int j = lo; j < hi; ++j) {
+        if (j == i) continue;
+        ++npairs;
+        int k = 0;
+        while (k < nu && uword[k] != sent[j]) ++k;
+        if (k < nu) {
+          ++umult[k];
+        } else {
+          uword[nu] = sent[j];
+          umult[nu++] = 1;
+        }
+      }
+      if (nu == 0) continue;
+      tword[0] = centre;
+      tmult[0] = 1;
+      nt = 1;
+      for (int d = 0; d < negative; ++d) {
+        uint64_t idx = 2ULL * (uint64_t)walk_len +
+                       ((uint64_t)i * 2ULL * (uint64_t)window) * (uint64_t)negative + (uint64_t)d;
+        uint32_t rr = (uint32_t)((draw(hs, idx) >> 16) % (uint64_t)domain);
+        int32_t target = (int32_t)bisect_left_u32(cum_table, n_vocab, rr);
+        if (target == centre) continue;
+        int k = 1;
+        while (k < nt && tword[k] != target) ++k;
+        if (k < nt) {
+          ++tmult[k];
+        } else {
+          tword[nt] = target;
+          tmult[nt++] = 1;
+        }
+      }
+      float G[16][16];
+      for (int u = 0; u < nu; ++u) memcpy(cold + (size_t)u * dim, syn0 + (int64_t)uword[u] * dim, sizeof(float) * (size_t)dim);
+      for (int t = 0; t < nt; ++t) memcpy(told + (size_t)t * dim, syn1neg + (int64_t)tword[t] * dim, sizeof(float) * (size_t)dim);
+      for (int u = 0; u < nu; ++u)
+        for (int t = 0; t < nt; ++t) {
+          const float *a = cold + (size_t)u * dim, *b = told + (size_t)t * dim;
+          float acc = 0.0f;
+          for (int s = 0; s < Q; ++s)
+            for (int g = 0; g < 4; ++g) acc = fmaf(a[g * Q + s], b[g * Q + s], acc);
+          float gg = 0.0f;
+          if (!(acc <= -6.0f || acc >= 6.0f)) {
+            const float label = t == 0 ? 1.0f : 0.0f;
+            gg = ((label - exp_table[(int)((acc + 6.0f) * 83.0f)]) * alpha) * (float)(umult[u] * tmult[t]);
+          }
+          G[u][t] = gg;
+        }
+      for (int t = 0; t < nt; ++t) { /* syn1neg[t] from the OLD context rows */
+        float *row = syn1neg + (int64_t)tword[t] * dim;
+        for (int e = 0; e < dim; ++e) {
+          float acc = told[(size_t)t * dim + e];
+          for (int s = 0; s < KC; ++s)
+            for (int g = 0; g < 4; ++g) {
+              const int u = KC == 3 ? 3 * g + s : 4 * g + s;
+              if (u < nu) acc = fmaf(G[u][t], cold[(size_t)u * dim + e], acc);
+            }
+          row[e] = acc;
+        }
+      }
+      for (int u = 0; u < nu; ++u) { /* syn0[c] from the OLD target rows */
+        float *row = syn0 + (int64_t)uword[u] * dim;
+        for (int e = 0; e < dim; ++e) {
+          float acc = cold[(size_t)u * dim + e];
+          for (int s = 0; s < KT; ++s)
+            for (int g = 0; g < 4; ++g) {
+              const int t = KT == 2 ? 2 * g + s : 4 * g + s;
+              if (t < nt) acc = fmaf(G[u][t], told[(size_t)t * dim + e], acc);
+            }
+          row[e] = acc;
+        }
+      }
+      pairs += npairs;
+    }
+  }
+  free(cold);
+  free(told);
+  return pairs;
+}

@@ -1,0 +1,167 @@
+"""The opt-in BATCHED SGNS kernel (n2v_sgns_params.batched = 1, csrc/n2v_sgns_batched.hip): the
+negatives of a centre position are drawn once and shared by its pairs, and the position is
+trained as three small dense products on the matrix cores (v_mfma_f32_16x16x4_f32).
+
+It is NOT gensim's sampling (the default kernel is), so it has its own normative CPU restatement,
+oracle/n2v_oracle_sgns.c::n2v_oracle_sgns_train_batched.  An f32 MFMA is bit-for-bit a k-ordered
+fmaf chain, so deterministic mode must equal that restatement BIT FOR BIT -- through the context
+ring in LDS (rows shared by positions that hold the same word, written back when the last one
+leaves), the target prefetch and its hazard rule.  The statistical test compares the embedding
+quality of the batched and the default trainer on a planted-partition graph.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _corpus(n_tok, rows, ln, seed, walk_like):
+    gen = torch.Generator().manual_seed(seed)
+    if walk_like:
+        # random-walk-like rows: frequent immediate returns (a b a) and short cycles, so that the
+        # window holds the same word at several positions (shared ring rows, multiplicities > 1)
+        steps = torch.randint(-2, 3, (rows, ln), generator=gen)
+        walks = (torch.cumsum(steps, 1) + torch.randint(0, n_tok, (rows, 1), generator=gen)) % n_tok
+        back = torch.rand((rows, ln), generator=gen) < 0.3
+        walks[:, 2:] = torch.where(back[:, 2:], walks[:, :-2], walks[:, 2:])
+        return walks.to(torch.int32).cuda()
+    p = 1.0 / torch.arange(1, n_tok + 1, dtype=torch.float64)
+    return torch.multinomial(p, rows * ln, replacement=True, generator=gen).reshape(rows, ln).to(torch.int32).cuda()
+
+
+def _model(walks, dim, window, negative, seed, sample, min_count=1):
+    from node2vec_amd import sgns
+
+    vocab = sgns.build_vocab(walks, min_count)
+    m = sgns.SgnsModel(vocab, dim, window, negative, seed=seed, sample=sample)
+    m.batched = True
+    return sgns, m, vocab.index_of[walks.long()]
+
+
+def _check_bits(oracle, sgns, m, idx, dim, window, negative, launches=((0, 0.025), (1, 0.02))):
+    s0, s1 = m.syn0.cpu().numpy().copy(), m.syn1neg.cpu().numpy().copy()
+    n = 0
+    for blk, alpha in launches:
+        m.train_block(idx, alpha, blk * idx.shape[0], deterministic=True)
+        n += oracle.sgns_train(idx.cpu().numpy(), s0, s1, m.cum_table.cpu().numpy(),
+                               None if m.sample_int is None else m.sample_int.cpu().numpy(),
+                               sgns.exp_table(), len(m.vocab), blk * idx.shape[0], m.seed, dim,
+                               window, negative, alpha, batched=True)
+    torch.cuda.synchronize()
+    assert n > 0 and int(m.pairs.item()) == n
+    got0, got1 = m.syn0.cpu().numpy(), m.syn1neg.cpu().numpy()
+    assert np.isfinite(got0).all() and np.isfinite(got1).all()
+    assert np.array_equal(got0, s0), float(np.abs(got0 - s0).max())
+    assert np.array_equal(got1, s1), float(np.abs(got1 - s1).max())
+    assert np.abs(s1).max() > 0
+
+
+@pytest.mark.parametrize("dim", [64, 128, 256])
+@pytest.mark.parametrize("sample", [0.0, 1e-2])
+@pytest.mark.parametrize("walk_like", [False, True])
+def test_batched_deterministic_bit_identical_to_its_oracle(oracle, dim, sample, walk_like):
+    walks = _corpus(60, 40, 21, 5 + dim, walk_like)
+    sgns, m, idx = _model(walks, dim, 5, 5, 5 + dim, sample)
+    _check_bits(oracle, sgns, m, idx, dim, 5, 5)
+
+
+@pytest.mark.parametrize("window,negative", [(5, 7), (5, 10), (7, 5), (7, 15), (3, 2), (1, 1)])
+def test_batched_tile_shapes(oracle, window, negative):
+    """both k-step counts over the context rows (2w + 1 <= 12 or not) and over the target rows
+    (1 + k <= 8 or not), the smallest window, out-of-vocabulary tokens"""
+    walks = _corpus(80, 30, 33, 100 * window + negative, True)
+    sgns, m, idx = _model(walks, 128, window, negative, 3, 1e-3, min_count=3)
+    assert int((idx < 0).sum()) > 0
+    _check_bits(oracle, sgns, m, idx, 128, window, negative, launches=((0, 0.025),))
+
+
+def test_batched_cfg_sized_rows_and_tiny_sentences(oracle):
+    """81-token rows (BASELINE walk length 80), rows that shrink to 0, 1 or 2 kept tokens"""
+    walks = _corpus(300, 24, 81, 77, True)
+    walks[3, 1:] = -1      # one token: no pair
+    walks[4, 2:] = -1      # two tokens
+    walks[5, :] = -1       # nothing
+    sgns, m, idx = _model(walks, 128, 5, 5, 9, 0.0)
+    idx = torch.where(walks >= 0, idx, torch.full_like(idx, -1))
+    _check_bits(oracle, sgns, m, idx, 128, 5, 5, launches=((0, 0.025),))
+
+
+def test_batched_rejects_what_its_tiles_do_not_hold():
+    from node2vec_amd import sgns
+
+    walks = _corpus(50, 8, 12, 1, False)
+    for dim, window, negative in ((100, 5, 5), (512, 5, 5), (128, 8, 5), (128, 5, 16)):
+        vocab = sgns.build_vocab(walks, 1)
+        m = sgns.SgnsModel(vocab, dim, window, negative, seed=1)
+        m.batched = True
+        with pytest.raises(ValueError):
+            m.train_block(vocab.index_of[walks.long()], 0.025, 0)
+
+
+def test_batched_hogwild_pair_count_and_sanity(oracle):
+    walks = _corpus(500, 3000, 41, 1, True)
+    sgns, m, idx = _model(walks, 128, 5, 5, 1, 1e-3)
+    s0, s1 = m.syn0.cpu().numpy().copy(), m.syn1neg.cpu().numpy().copy()
+    m.train_block(idx, 0.025, 0)
+    torch.cuda.synchronize()
+    n = oracle.sgns_train(idx.cpu().numpy(), s0, s1, m.cum_table.cpu().numpy(),
+                          m.sample_int.cpu().numpy(), sgns.exp_table(), len(m.vocab), 0, m.seed,
+                          128, 5, 5, 0.025, batched=True)
+    assert int(m.pairs.item()) == n  # the pairs trained do not depend on launch geometry
+    got = m.syn0.cpu().numpy()
+    assert np.isfinite(got).all() and np.isfinite(m.syn1neg.cpu().numpy()).all()
+    assert 0.5 < np.linalg.norm(got) / np.linalg.norm(s0) < 2.0
+
+
+def _planted(nc=50, sz=40, seed=0):
+    from node2vec_amd.graph import DeviceGraph
+
+    rng = np.random.default_rng(seed)
+    nv = nc * sz
+    comm = np.repeat(np.arange(nc), sz)
+    src, dst = [], []
+    for v in range(nv):
+        inside = rng.choice(np.nonzero(comm == comm[v])[0], 8)
+        for u in list(inside) + list(rng.integers(0, nv, 2)):
+            if u != v:
+                src += [v, int(u)]
+                dst += [int(u), v]
+    return DeviceGraph.from_edges(src, dst, None, n_vertices=nv, device="cuda"), comm
+
+
+@pytest.mark.statistical
+def test_batched_quality_matches_default_trainer_on_planted_partition():
+    """same walks, same epochs: community AUC of the batched trainer within 0.02 of the default
+    (per-pair negatives) trainer, both > 0.97; deterministic batched run as the reference point"""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd import sgns
+
+    g, comm = _planted()
+    walks, _ = rw.walk(g, rw.start_vertices(g), 10, 40, 1.0, 1.0, 1)
+    vocab = sgns.build_vocab(walks, 1)
+    idx = vocab.index_of[walks.long()]
+    ids = vocab.ids.cpu().numpy()
+    rng = np.random.default_rng(1)
+    a, b = rng.integers(0, len(ids), 200000), rng.integers(0, len(ids), 200000)
+    same = comm[ids[a]] == comm[ids[b]]
+
+    def auc(m):
+        v = m.syn0.cpu().numpy()
+        v = v - v.mean(0)
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        s = (v[a] * v[b]).sum(1)
+        return float((s[same][:, None] > s[~same][None, :3000]).mean())
+
+    out = {}
+    for name, batched, det in (("default", False, False), ("batched", True, False),
+                               ("batched_det", True, True)):
+        m = sgns.SgnsModel(vocab, 64, 5, 5, seed=7, sample=0.0)
+        m.batched = batched
+        m.train(idx, epochs=3, alpha=0.025, deterministic=det)
+        torch.cuda.synchronize()
+        out[name] = auc(m)
+    print("planted partition AUC:", out)
+    assert min(out.values()) > 0.97, out
+    assert abs(out["batched"] - out["default"]) < 0.02, out
+    assert abs(out["batched"] - out["batched_det"]) < 0.02, out
