@@ -122,7 +122,7 @@ __device__ __forceinline__ int b_bisect(const uint32_t *a, int lo, int hi, uint3
 }
 
 // VEC = dim / 64; TROWS = rows of the target tile (8: 1 + negative <= 8, two k-steps; else 16)
-template <int VEC, int TROWS>
+template <int VEC, int TROWS, int KC>  // KC: k-steps over context rows (3: 2 * window + 1 <= 12)
 __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
     const int32_t *__restrict__ walks, int64_t n_walks, int32_t walk_len, float *syn0,
     float *syn1neg, const uint32_t *__restrict__ cum_table,
@@ -133,7 +133,6 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
   constexpr int KT = TROWS == 8 ? 2 : 4;           // k-steps over target rows
   const int PR = (rrows * RS + 63) / 64 * 64;      // plane stride of the context ring
   const int window = P.window, K = P.negative;
-  const int KC = (2 * window + 1 <= 12) ? 3 : 4;   // k-steps over context rows
   const float alpha = P.alpha;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -350,6 +349,10 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
         }
         if (lane == row) ++cm;
       }
+      f32x4 newt[NCH];
+      float *st_dst[4];
+      bool st_ok[4];
+      bool trained = false;
       if (nu > 0) {
         const int row0 = (int)__builtin_ctzll(ballot64(lane < 16 && rank == 0));
         if (lane < 16) {
@@ -401,7 +404,6 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
         for (int s = 0; s < KT; ++s) ga[s] = gs[j16 * 17 + 4 * g4 + s];
 
         // ---- Tgt_new = Tgt_old + G^T . Ctx_old  (kept in registers until Ctx is done) ----
-        f32x4 newt[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
           const int plane = c / VEC, off = (c % VEC) * 16 + j16;
@@ -442,31 +444,46 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
           for (int rI = 0; rI < 4; ++rI)
             if (mmultM[4 * g4 + rI] > 0) ring[plane * PR + mp[rI] * RS + off] = acc[rI];
         }
-        // ---- C. the target rows go back to HBM from the accumulator layout (64 B per row
-        //         and instruction) ----
+        // where the new target rows go: fixed now, the target list is replaced below
 #pragma unroll
         for (int rI = 0; rI < 4; ++rI) {
           const int t = tgt_of(4 * g4 + rI);
-          if (t >= 0 && t < nt_c) {
-            float *dst = syn1neg + (int64_t)twc[t] * D + j16;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) dst[16 * c] = newt[c][rI];
-          }
+          st_ok[rI] = t >= 0 && t < nt_c;
+          st_dst[rI] = syn1neg + (int64_t)twc[st_ok[rI] ? t : 0] * D + j16;
         }
+        trained = true;
         pairs += (unsigned long long)npairs;
         wave_sync();
       }
-      // position i - window is outside every later window
-      if (i - window >= 0) leave(i - window);
-      // ---- D. what was requested for position i + 1 arrives ----
+      // ---- C. what was requested for position i + 1 has arrived (asked for a whole position
+      //         ago): it is consumed BEFORE this position's stores are issued, so that the wait
+      //         for the loads never waits for a store ----
       if (have_next) {
         if (enter_row >= 0) lds_put<VEC>(ring, PR, enter_row, lane, crow_in);
 #pragma unroll
         for (int t = 0; t < TROWS; ++t)
-          if (t < nt_n) {
-            if ((late >> t) & 1ull) g_load<VEC>(syn1neg + (int64_t)rl(tw_n, t) * D, lane, nrow[t]);
-            lds_put<VEC>(tgt, PT, t, lane, nrow[t]);
+          if (t < nt_n && !((late >> t) & 1ull)) lds_put<VEC>(tgt, PT, t, lane, nrow[t]);
+      }
+      // ---- D. the target rows go back to HBM from the accumulator layout (64 B per row and
+      //         instruction); position i - window is outside every later window ----
+      if (trained) {
+#pragma unroll
+        for (int rI = 0; rI < 4; ++rI)
+          if (st_ok[rI]) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) st_dst[rI][16 * c] = newt[c][rI];
           }
+      }
+      if (i - window >= 0) leave(i - window);
+      if (have_next) {
+        if (late) {  // rows this position has just written: read them back now, in order
+#pragma unroll
+          for (int t = 0; t < TROWS; ++t)
+            if (t < nt_n && ((late >> t) & 1ull)) {
+              g_load<VEC>(syn1neg + (int64_t)rl(tw_n, t) * D, lane, nrow[t]);
+              lds_put<VEC>(tgt, PT, t, lane, nrow[t]);
+            }
+        }
         tw_c = tw_n;
         tm_c = tm_n;
         nt_c = nt_n;
@@ -496,6 +513,7 @@ extern "C" int n2v_sgns_batched_launch(const int32_t *walks, int64_t n_walks, in
   const int VEC = P->dim / 64;
   const int rrows = 2 * P->window + 2 <= 12 ? 12 : 16;
   const int trows = 1 + P->negative <= 8 ? 8 : 16;
+  const int kc = 2 * P->window + 1 <= 12 ? 3 : 4;
   const int RS = 16 * VEC + 4;
   const int PR = (rrows * RS + 63) / 64 * 64, PT = (trows * RS + 63) / 64 * 64;
   const size_t per_wave = ((size_t)(4 * PR + 4 * PT + 16 * 17) +
@@ -513,9 +531,9 @@ extern "C" int n2v_sgns_batched_launch(const int32_t *walks, int64_t n_walks, in
   hipStream_t st = (hipStream_t)stream;
   if (pairs_out && hipMemsetAsync(pairs_out + 1, 0, sizeof(unsigned long long), st) != hipSuccess)
     return N2V_ELAUNCH;
-#define N2V_BLAUNCH(VV, TT)                                                                       \
+#define N2V_BLAUNCH(VV, TT, KK)                                                                       \
   do {                                                                                            \
-    const void *fn = (const void *)sgns_batched_kernel<VV, TT>;                                   \
+    const void *fn = (const void *)sgns_batched_kernel<VV, TT, KK>;                                   \
     if (lds > 64 * 1024 &&                                                                        \
         hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
       return N2V_ELAUNCH;                                                                         \
@@ -523,16 +541,20 @@ extern "C" int n2v_sgns_batched_launch(const int32_t *walks, int64_t n_walks, in
       const int64_t cap = resident_blocks(fn, wpb * 64, lds);                                     \
       if (blocks > cap) blocks = cap;                                                             \
     }                                                                                             \
-    hipLaunchKernelGGL((sgns_batched_kernel<VV, TT>), dim3((unsigned)blocks), dim3(wpb * 64), lds, \
+    hipLaunchKernelGGL((sgns_batched_kernel<VV, TT, KK>), dim3((unsigned)blocks), dim3(wpb * 64), lds, \
                        st, walks, n_walks, walk_len, syn0, syn1neg, cum_table, sample_int,        \
                        exp_table, *P, pairs_out, rrows);                                          \
   } while (0)
 #define N2V_BLAUNCH_T(VV)     \
   do {                        \
-    if (trows == 8)           \
-      N2V_BLAUNCH(VV, 8);     \
-    else                      \
-      N2V_BLAUNCH(VV, 16);    \
+    if (trows == 8 && kc == 3)      \
+      N2V_BLAUNCH(VV, 8, 3);        \
+    else if (trows == 8)            \
+      N2V_BLAUNCH(VV, 8, 4);        \
+    else if (kc == 3)               \
+      N2V_BLAUNCH(VV, 16, 3);       \
+    else                            \
+      N2V_BLAUNCH(VV, 16, 4);       \
   } while (0)
   switch (VEC) {
     case 1: N2V_BLAUNCH_T(1); break;

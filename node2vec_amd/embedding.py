@@ -50,28 +50,132 @@ class Node2VecBase(object):
         raise NotImplementedError()
 
 
+class _Tokens:
+    """index -> token, lazily: the tokens of a fitted model are the decimal strings of its vertex
+    ids (embedding.py:125); at BASELINE cfg 4 a list of 10^8 Python strings is ~6 GB of objects
+    nobody reads, so the ids stay an int64 array and strings are made on access."""
+
+    def __init__(self, ids: np.ndarray):
+        self.ids = ids
+
+    def __len__(self):
+        return int(self.ids.shape[0])
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [str(int(x)) for x in self.ids[i]]
+        return str(int(self.ids[i]))
+
+    def __iter__(self):
+        for lo in range(0, len(self), 1 << 16):
+            yield from map(str, self.ids[lo:lo + (1 << 16)].tolist())
+
+    def __eq__(self, other):
+        return len(self) == len(other) and all(a == b for a, b in zip(self, other))
+
+
+class _Vocab:
+    """token -> row, lazily (what callers of the reference do with model.wv.vocab: `in`, `[]`,
+    `len`, iteration in index order -- embedding.py:135-136).  Lookup through a sorted copy of the
+    id array, built on first use (searchsorted): no 10^8-entry dict."""
+
+    def __init__(self, ids: np.ndarray):
+        self.ids = ids
+        self._sorted = None
+
+    def _row(self, token) -> int:
+        try:
+            v = int(token)
+        except (TypeError, ValueError):
+            return -1
+        if str(v) != str(token):  # "07", " 7": not a token this vocabulary ever produced
+            return -1
+        if self._sorted is None:
+            order = np.argsort(self.ids, kind="stable")
+            self._sorted = (self.ids[order], order)
+        keys, order = self._sorted
+        k = int(np.searchsorted(keys, v))
+        return int(order[k]) if k < keys.shape[0] and keys[k] == v else -1
+
+    def __contains__(self, token):
+        return self._row(token) >= 0
+
+    def __getitem__(self, token):
+        r = self._row(token)
+        if r < 0:
+            raise KeyError(token)
+        return r
+
+    def get(self, token, default=None):
+        r = self._row(token)
+        return default if r < 0 else r
+
+    def __len__(self):
+        return int(self.ids.shape[0])
+
+    def __iter__(self):
+        return iter(_Tokens(self.ids))
+
+    def keys(self):
+        return iter(self)
+
+    def items(self):
+        return ((t, i) for i, t in enumerate(self))
+
+
 class KeyedVectors:
     """What callers of the reference touch on model.wv: `vocab` (token -> row; tokens
-    are decimal strings of vertex ids, embedding.py:125), `wv[token]`, and the
-    word2vec text format."""
+    are decimal strings of vertex ids, embedding.py:125), `wv[token]`, `index2word`, `vectors`
+    and the word2vec text format.
 
-    def __init__(self, tokens: List[str], vectors: np.ndarray):
-        self.index2word = list(tokens)
-        self.vocab = {t: i for i, t in enumerate(self.index2word)}
-        self.vectors = vectors
-        self.vector_size = vectors.shape[1] if vectors.ndim == 2 else 0
+    `tokens`: a list of strings (a loaded text file), or an integer id array / tensor (a fitted
+    model: tokens and the token -> row map are then lazy).  `vectors`: numpy [n, dim], or the
+    trainer's device tensor -- it stays in HBM; `wv[token]` copies one row, `.vectors` converts
+    the whole matrix to numpy on first access (51 GB at cfg 4: ask for rows or chunks instead,
+    `rows(lo, hi)`)."""
+
+    def __init__(self, tokens, vectors):
+        if isinstance(tokens, torch.Tensor):
+            tokens = tokens.cpu().numpy()
+        if isinstance(tokens, np.ndarray) and tokens.dtype.kind in "iu":
+            self.ids: Optional[np.ndarray] = tokens.astype(np.int64, copy=False)
+            self.index2word = _Tokens(self.ids)
+            self.vocab = _Vocab(self.ids)
+        else:
+            self.ids = None
+            self.index2word = list(tokens)
+            self.vocab = {t: i for i, t in enumerate(self.index2word)}
+        self._vectors = vectors
+        self.vector_size = int(vectors.shape[1]) if vectors.ndim == 2 else 0
+
+    @property
+    def vectors(self) -> np.ndarray:
+        if isinstance(self._vectors, torch.Tensor):
+            self._vectors = self._vectors.cpu().numpy()
+        return self._vectors
+
+    def rows(self, lo: int, hi: int) -> np.ndarray:
+        """vectors[lo:hi] as numpy without converting the whole matrix"""
+        v = self._vectors[lo:hi]
+        return v.cpu().numpy() if isinstance(v, torch.Tensor) else v
+
+    def __len__(self):
+        return len(self.index2word)
 
     def __getitem__(self, token: str) -> np.ndarray:
-        return self.vectors[self.vocab[token]]
+        r = self.vocab[token]
+        return self.rows(r, r + 1)[0]
 
     def __contains__(self, token: str) -> bool:
         return token in self.vocab
 
-    def save_word2vec_format(self, fname: str) -> None:
+    def save_word2vec_format(self, fname: str, chunk_rows: int = 1 << 16) -> None:
         with open(fname, "w") as f:
             f.write(f"{len(self.index2word)} {self.vector_size}\n")
-            for t, v in zip(self.index2word, self.vectors):
-                f.write(t + " " + " ".join(repr(float(x)) for x in v) + "\n")
+            for lo in range(0, len(self), chunk_rows):
+                block = self.rows(lo, lo + chunk_rows).astype(np.float64).tolist()
+                toks = self.index2word[lo:lo + chunk_rows]
+                f.writelines(t + " " + " ".join(map(repr, v)) + "\n" for t, v in zip(toks, block))
 
     @classmethod
     def load_word2vec_format(cls, fname: str) -> "KeyedVectors":
@@ -87,13 +191,21 @@ class KeyedVectors:
 
 class HipW2V:
     """The fitted model object returned by fit() (stands where gensim's Word2Vec
-    object stands): .wv plus the output matrix and the training parameters."""
+    object stands): .wv plus the output matrix and the training parameters.  The matrices may be
+    the trainer's device tensors (they are converted when saved or read as numpy)."""
 
-    def __init__(self, wv: KeyedVectors, syn1neg: np.ndarray, params: Dict[str, Any], pairs: int):
-        self.wv, self.syn1neg, self.params, self.pairs_trained = wv, syn1neg, dict(params), pairs
+    def __init__(self, wv: KeyedVectors, syn1neg, params: Dict[str, Any], pairs: int):
+        self.wv, self._syn1neg, self.params, self.pairs_trained = wv, syn1neg, dict(params), pairs
+
+    @property
+    def syn1neg(self) -> np.ndarray:
+        if isinstance(self._syn1neg, torch.Tensor):
+            self._syn1neg = self._syn1neg.cpu().numpy()
+        return self._syn1neg
 
     def save(self, fname: str) -> None:
-        torch.save({"tokens": self.wv.index2word, "vectors": self.wv.vectors,
+        tokens = self.wv.ids if self.wv.ids is not None else self.wv.index2word
+        torch.save({"tokens": tokens, "vectors": self.wv.vectors,
                     "syn1neg": self.syn1neg, "params": self.params,
                     "pairs": self.pairs_trained}, fname)
 
@@ -185,10 +297,10 @@ class Node2VecHIP(Node2VecBase):
         idx = sgns.split_rows(idx)
         rows_max = None
         if sync is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            from node2vec_amd.shard import sentence_base as rank_base
+            from node2vec_amd.shard import all_reduce, sentence_base as rank_base
 
             rows = torch.tensor([idx.shape[0]], device=dev)
-            dist.all_reduce(rows, op=dist.ReduceOp.MAX)
+            all_reduce(rows, dist.ReduceOp.MAX)
             rows_max = int(rows.item())  # every rank lays the same block grid over this
             sentence_base = rank_base(dist.get_rank(), dist.get_world_size(),
                                       rows_max * max(int(p["iter"]), 1))
@@ -196,24 +308,47 @@ class Node2VecHIP(Node2VecBase):
         m.train(idx, int(p["iter"]), float(p["alpha"]), float(p["min_alpha"]),
                 sentence_base=sentence_base, sync=sync, rows_global_max=rows_max)
         torch.cuda.synchronize(dev)
-        tokens = [str(int(i)) for i in vocab.ids.cpu().numpy()]
         p["negative"] = negative
-        self.model = HipW2V(KeyedVectors(tokens, m.syn0.cpu().numpy()), m.syn1neg.cpu().numpy(),
-                            p, int(m.pairs.item()))
+        # the matrices stay in HBM and the tokens stay integer ids (lazy strings): at cfg 4 the
+        # host copies would be 2 x 51 GB + 10^8 Python strings that most callers never read
+        self.model = HipW2V(KeyedVectors(vocab.ids, m.syn0), m.syn1neg, p, int(m.pairs.item()))
         return self.model
 
     # -- results ------------------------------------------------------------------
-    def embedding(self) -> pd.DataFrame:
-        """embedding.py:129-143"""
+    def iter_embedding(self, chunk_rows: int = 1 << 18):
+        """embedding() in chunks of `chunk_rows` rows: DataFrames ["id" | "name", "vector"] of the
+        reference's shape, made without ever holding the whole model as Python objects"""
         if self.model is None:
             raise ValueError("Model is not available. Please run fit()")
-        ids = [int(t) for t in self.model.wv.vocab]
-        vectors = [list(self.model.wv[t]) for t in self.model.wv.vocab]
+        wv = self.model.wv
+        names = None
         if self.name_id is not None:
-            dic = self.name_id.set_index("id").to_dict()["name"]
-            names = [dic[i] for i in ids]
-            return pd.DataFrame.from_dict({"name": names, "vector": vectors})
-        return pd.DataFrame.from_dict({"id": ids, "vector": vectors})
+            names = self.name_id.set_index("id")["name"]
+        for lo in range(0, len(wv), chunk_rows):
+            hi = min(len(wv), lo + chunk_rows)
+            if wv.ids is not None:
+                ids = wv.ids[lo:hi]
+            else:
+                ids = np.array([int(t) for t in wv.index2word[lo:hi]], dtype=np.int64)
+            vectors = wv.rows(lo, hi).tolist()
+            if names is not None:
+                yield pd.DataFrame({"name": names.reindex(ids).to_numpy(), "vector": vectors})
+            else:
+                yield pd.DataFrame({"id": ids, "vector": vectors})
+
+    def embedding(self) -> pd.DataFrame:
+        """embedding.py:129-143.  One DataFrame of Python lists, as the reference returns: fine
+        up to a few million vertices; beyond 2^31 vector elements use iter_embedding()."""
+        if self.model is None:
+            raise ValueError("Model is not available. Please run fit()")
+        wv = self.model.wv
+        if len(wv) * max(wv.vector_size, 1) >= 2 ** 31:
+            raise MemoryError(f"embedding(): {len(wv)} x {wv.vector_size} values as Python lists do "
+                              "not fit a DataFrame; use iter_embedding(chunk_rows) or model.wv.rows()")
+        parts = list(self.iter_embedding())
+        if not parts:
+            return pd.DataFrame({("name" if self.name_id is not None else "id"): [], "vector": []})
+        return parts[0] if len(parts) == 1 else pd.concat(parts, ignore_index=True)
 
     def get_vector(self, vertex_id: Union[str, int]) -> List[float]:
         """embedding.py:145-151"""

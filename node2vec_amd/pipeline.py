@@ -10,6 +10,12 @@ training), then per epoch each batch is walked (K2) and trained on (K3) while it
 HBM.  Row r of the virtual corpus is (start index r // W, ordinal r % W + 1), exactly the
 row order of fugue.random_walk_tensors, and its SGNS sentence id is epoch * rows + r, so
 training on the batches equals training on the materialised corpus with the same blocks.
+
+Under an initialised torch.distributed process group (one process per GPU, graph replicated)
+each rank streams its contiguous range of the start vertices (shard.shard_range): token counts
+and row counts are summed over the ranks, so every rank builds the same vocabulary and model;
+the replicas are averaged by sgns.DeltaSync (RCCL all-reduce of the model deltas) every few
+launches and once more at the end.  No collective is on the walk path.
 """
 import logging
 from typing import Any, Dict, Optional
@@ -25,12 +31,20 @@ from node2vec_amd.graph import DeviceGraph
 
 def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Dict[str, Any],
                   random_seed: int, batch_vertices: int = 65536, walk_seed_ids=None,
-                  mode: str = "exact", return_model: bool = False):
+                  mode: str = "exact", return_model: bool = False, timings: Optional[dict] = None):
     """node2vec end to end on the GPU: returns a HipW2V (and the SgnsModel when asked).
 
     n2v_params / w2v_params take the reference's keys (NODE2VEC_PARAMS, GENSIM_PARAMS plus
     the pass-through names of HIP_SGNS_PARAMS); missing keys are filled in the caller's
-    dicts as the reference does (fugue.py:120-122, embedding.py:105-107)."""
+    dicts as the reference does (fugue.py:120-122, embedding.py:105-107).  w2v_params["batched"]
+    selects the opt-in shared-negative trainer; "sync_every" / "sync_wire" the multi-GPU exchange.
+    `timings` (optional dict) receives the seconds spent walking and training."""
+    import time
+
+    import torch.distributed as dist
+
+    from node2vec_amd.shard import all_reduce, shard_range
+
     for k, v in NODE2VEC_PARAMS.items():
         n2v_params.setdefault(k, v)
     for k, v in GENSIM_PARAMS.items():
@@ -43,58 +57,92 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
     W, L = int(n2v_params["num_walks"]), int(n2v_params["walk_length"])
     pp, qq = float(n2v_params["return_param"]), float(n2v_params["inout_param"])
     seed = int(random_seed)
-    start = rw.start_vertices(graph, walk_seed_ids)
+    dev = graph.device
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank, world = (dist.get_rank(), dist.get_world_size()) if multi else (0, 1)
+    start_all = rw.start_vertices(graph, walk_seed_ids)
+    lo_r, hi_r = shard_range(start_all.numel(), rank, world)
+    start = start_all[lo_r:hi_r]
     n_start = start.numel()
     batch_vertices = max(1, int(batch_vertices))
-    dev = graph.device
+    # every rank lays the same batch grid over the LARGEST shard, so that ranks with fewer
+    # start vertices still take part in every exchange
+    n_start_max = shard_range(start_all.numel(), 0, world)[1]
+    n_batches = max(1, -(-n_start_max // batch_vertices))
+    t_walk = t_train = 0.0
 
-    def batches():
-        for lo in range(0, n_start, batch_vertices):
-            yield lo, start[lo:lo + batch_vertices].contiguous()
+    def clock():
+        if timings is not None:
+            torch.cuda.synchronize(dev)
+        return time.perf_counter()
 
-    def walk(batch):
-        return rw.walk(graph, batch, W, L, pp, qq, seed, mode)
+    def walk(k):
+        return rw.walk(graph, start[k * batch_vertices:(k + 1) * batch_vertices].contiguous(), W, L,
+                       pp, qq, seed, mode, check=False)
 
-    # ---- pass 1: token counts of the virtual corpus (vocabulary, cum_table, subsampling)
+    # ---- pass 1: token counts of the virtual corpus (vocabulary, cum_table, subsampling).  No
+    # host synchronisation per batch: invalid rows are masked out, not compacted.
     counts = torch.zeros(graph.n_vertices, dtype=torch.int64, device=dev)
-    rows_total = 0
-    for _, b in batches():
-        walks, valid = walk(b)
-        w = walks[valid]
-        rows_total += int(valid.numel())  # rows keep their index; dropped walkers stay as gaps
-        counts += torch.bincount(w.reshape(-1).long(), minlength=graph.n_vertices)
+    t0 = clock()
+    for k in range(n_batches):
+        walks, valid = walk(k)
+        if walks.numel() == 0:
+            continue
+        keep = (valid.bool().unsqueeze(1) & (walks >= 0)).reshape(-1)
+        counts.index_add_(0, walks.reshape(-1).clamp(min=0).long(), keep.long())
+    if multi:
+        all_reduce(counts, dist.ReduceOp.SUM)
+    t_walk += clock() - t0
+    rows_rank_max = n_start_max * W  # rows of the largest shard: the sentence-id stride of a rank
     ids = torch.nonzero(counts >= max(int(p["min_count"]), 1)).reshape(-1)
     if ids.numel() == 0:
         raise RuntimeError("you must first build vocabulary before training the model")
     cnt = counts[ids]
     order = torch.sort(cnt, descending=True, stable=True).indices  # ties: ascending id
     ids, cnt = ids[order], cnt[order]
+    del counts, order
     index_of = torch.full((graph.n_vertices,), -1, dtype=torch.int32, device=dev)
     index_of[ids] = torch.arange(ids.numel(), dtype=torch.int32, device=dev)
     vocab = sgns.Vocab(ids, cnt, index_of)
     model = sgns.SgnsModel(vocab, int(p["size"]), int(p["window"]), negative, int(p["seed"] or seed),
                            sample=float(p["sample"] or 0.0), ns_exponent=float(p["ns_exponent"]),
                            device=dev)
-    logging.info("fit_streaming: %d rows, vocabulary %d", rows_total, len(vocab))
+    model.batched = bool(p.get("batched", False))
+    logging.info("fit_streaming: %d start vertices on this rank, vocabulary %d", n_start, len(vocab))
+    sync = None
+    if multi:
+        sync = sgns.DeltaSync(model, sync_every=p.get("sync_every"), wire=p.get("sync_wire", "fp32"))
+        sync.max_every = n_batches
 
     # ---- pass 2: per epoch, walk a batch and train on it while it is resident
     epochs = max(int(p["iter"]), 1)
     alpha, min_alpha = float(p["alpha"]), float(p["min_alpha"])
-    total, done = rows_total * epochs, 0
-    submitted = 0  # SGNS sentence ids: rows handed to the kernel so far (after split_rows)
+    parts_per_row = -(-(L + 1) // sgns.MAX_SENTENCE)
     for ep in range(epochs):
-        for lo, b in batches():
-            walks, valid = walk(b)
-            idx = index_of[walks.long().clamp(min=0)]
-            idx = torch.where(valid.bool().unsqueeze(1) & (walks >= 0), idx, torch.full_like(idx, -1))
-            a = max(min_alpha, alpha - (alpha - min_alpha) * (done / max(total, 1)))
-            for part in torch.split(sgns.split_rows(idx), 1 << 22):
-                model.train_block(part, a, submitted)
-                submitted += part.shape[0]
-            done += idx.shape[0]
+        for k in range(n_batches):
+            t0 = clock()
+            walks, valid = walk(k)
+            t1 = clock()
+            t_walk += t1 - t0
+            if walks.numel():
+                idx = index_of[walks.long().clamp(min=0)]
+                idx = torch.where(valid.bool().unsqueeze(1) & (walks >= 0), idx, torch.full_like(idx, -1))
+                done = (ep * n_batches + k) / (epochs * n_batches)
+                a = max(min_alpha, alpha - (alpha - min_alpha) * done)
+                # sentence id = (epoch, rank, row of the rank's virtual corpus): never repeats
+                base = ((ep * world + rank) * rows_rank_max + k * batch_vertices * W) * parts_per_row
+                for j, part in enumerate(torch.split(sgns.split_rows(idx), 1 << 22)):
+                    model.train_block(part, a, base + j * (1 << 22))
+            if sync is not None:
+                sync.step()
+            t_train += clock() - t1
+    if sync is not None:
+        sync.finish()
     torch.cuda.synchronize(dev)
-    tokens = [str(int(i)) for i in vocab.ids.cpu().numpy()]
+    if timings is not None:
+        timings.update(walk_s=t_walk, train_s=t_train, batches=n_batches, epochs=epochs,
+                       rows_this_rank=n_start * W, world=world)
     p["negative"] = negative
-    out = HipW2V(KeyedVectors(tokens, model.syn0.cpu().numpy()), model.syn1neg.cpu().numpy(), p,
-                 int(model.pairs.item()))
+    # device-backed result: no host copy of the matrices, integer ids instead of token strings
+    out = HipW2V(KeyedVectors(vocab.ids, model.syn0), model.syn1neg, p, int(model.pairs.item()))
     return (out, model) if return_model else out

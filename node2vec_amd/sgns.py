@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from node2vec_amd import _lib
+from node2vec_amd.shard import all_reduce
 
 EXP_TABLE_SIZE = 1000
 MAX_EXP = 6
@@ -54,10 +55,10 @@ def build_vocab(walks: torch.Tensor, min_count: int, group=None) -> Vocab:
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         size = torch.tensor([int(flat.max()) + 1 if flat.numel() else 0], device=walks.device)
-        dist.all_reduce(size, op=dist.ReduceOp.MAX, group=group)
+        all_reduce(size, dist.ReduceOp.MAX, group)
         n_ids = int(size.item())  # the same on every rank
         dense = torch.bincount(flat, minlength=n_ids)
-        dist.all_reduce(dense, op=dist.ReduceOp.SUM, group=group)
+        all_reduce(dense, dist.ReduceOp.SUM, group)
         ids = torch.nonzero(dense).reshape(-1)
         counts = dense[ids]
     else:
@@ -356,7 +357,7 @@ class DeltaSync:
                 n = cur.numel()
                 snap = None if exact else before[:n]
                 self._pack(cur, None if ref is None else ref[lo:hi], snap, wire[:n])
-                self.dist.all_reduce(wire[:n], op=self.dist.ReduceOp.SUM, group=self.group)
+                all_reduce(wire[:n], self.dist.ReduceOp.SUM, self.group, self.dist)
                 self._apply(cur, None if ref is None else ref[lo:hi], snap, wire[:n])
 
     # -- the protocol -------------------------------------------------------------------------
@@ -413,7 +414,7 @@ class DeltaSync:
         t_launch = max(now() - self._t_mark, 0.0)  # one training launch since then
         dev = self.tensors[0].device
         v = torch.tensor([self._t_sync, t_launch], dtype=torch.float64, device=dev)
-        self.dist.all_reduce(v, op=self.dist.ReduceOp.MAX, group=self.group)
+        all_reduce(v, self.dist.ReduceOp.MAX, self.group, self.dist)
         self.sync_every = self.period_for(float(v[0]), float(v[1]))
         self.calls = 0  # periods count from here
 

@@ -21,3 +21,32 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
 def sentence_base(rank: int, world: int, rows_per_rank_max: int, epoch: int = 0) -> int:
     """Disjoint SGNS sentence-id ranges per (epoch, rank): RNG keys never collide."""
     return (epoch * world + rank) * rows_per_rank_max
+
+
+def all_reduce(t, op=None, group=None, dist=None):
+    """torch.distributed.all_reduce of `t` in place.  RCCL (backend "nccl") reduces device
+    tensors directly over xGMI; under gloo -- the CPU tests, and the 2-ranks-on-one-GPU rehearsal
+    of tests/test_multirank_gpu.py (RCCL refuses two ranks on one device) -- a device tensor is
+    staged through host memory, so every multi-rank code path runs unchanged on both."""
+    if dist is None:
+        import torch.distributed as dist
+    op = dist.ReduceOp.SUM if op is None else op
+    backend = dist.get_backend(group) if hasattr(dist, "get_backend") else None  # tests stand in
+    if backend is None:
+        dist.all_reduce(t, op=op, group=group)
+        return t
+    if t.is_cuda and backend == "gloo":
+        if t.dtype.is_floating_point and t.element_size() < 4:
+            host = t.float().cpu()  # gloo has no bf16 / fp16 sum
+        else:
+            host = t.cpu()
+        dist.all_reduce(host, op=op, group=group)
+        t.copy_(host.to(t.dtype))
+        return t
+    if not t.is_cuda and t.dtype.is_floating_point and t.element_size() < 4:
+        host = t.float()
+        dist.all_reduce(host, op=op, group=group)
+        t.copy_(host.to(t.dtype))
+        return t
+    dist.all_reduce(t, op=op, group=group)
+    return t

@@ -330,3 +330,44 @@ def test_device_corpus_token_survives_pandas(tmp_path):
     del a, both, merged
     gc.collect()
     assert len(corpus._registry) == n_before - 1  # the entry dies with its frame
+
+
+def test_keyed_vectors_from_ids_is_lazy_and_reference_shaped(tmp_path):
+    """a fitted model keeps integer ids and a (device) tensor: tokens, the token -> row map and
+    the numpy matrix are made on access (no 10^8-element Python lists)"""
+    import pandas as pd
+    import torch
+
+    from node2vec_amd.embedding import HipW2V, KeyedVectors, Node2VecHIP
+
+    ids = np.array([30, 7, 1000003, 0, 12], dtype=np.int64)
+    vec = torch.arange(5 * 4, dtype=torch.float32).reshape(5, 4)
+    kv = KeyedVectors(torch.from_numpy(ids), vec)
+    assert len(kv) == 5 and kv.vector_size == 4
+    assert list(kv.vocab) == ["30", "7", "1000003", "0", "12"] == list(kv.index2word)
+    assert kv.index2word[2] == "1000003" and kv.index2word[1:3] == ["7", "1000003"]
+    assert "7" in kv and "8" not in kv and "07" not in kv and "x" not in kv
+    assert kv.vocab["1000003"] == 2 and kv.vocab.get("5") is None and len(kv.vocab) == 5
+    with pytest.raises(KeyError):
+        kv.vocab["5"]
+    assert np.array_equal(kv["0"], vec[3].numpy()) and isinstance(kv._vectors, torch.Tensor)
+    assert np.array_equal(kv.rows(1, 3), vec[1:3].numpy())
+    kv.save_word2vec_format(str(tmp_path / "v.txt"), chunk_rows=2)
+    back = KeyedVectors.load_word2vec_format(str(tmp_path / "v.txt"))
+    assert back.index2word == ["30", "7", "1000003", "0", "12"] and np.array_equal(back.vectors, vec.numpy())
+    m = HipW2V(kv, vec * 2, {"size": 4}, 3)
+    m.save(str(tmp_path / "m.model"))
+    m2 = HipW2V.load(str(tmp_path / "m.model"))
+    assert list(m2.wv.vocab) == list(kv.vocab) and np.array_equal(m2.syn1neg, (vec * 2).numpy())
+    # embedding(): the reference's frame, from chunks; names through name_id
+    n2v = Node2VecHIP(pd.DataFrame({"src": [0], "walk": [[0, 7]]}), {}, random_seed=1)
+    n2v.model = m
+    frame = n2v.embedding()
+    assert list(frame.columns) == ["id", "vector"] and frame["id"].tolist() == ids.tolist()
+    assert frame["vector"].iloc[2] == vec[2].tolist()
+    chunks = list(n2v.iter_embedding(chunk_rows=2))
+    assert [len(c) for c in chunks] == [2, 2, 1]
+    n2v.name_id = pd.DataFrame({"name": ["a", "b", "c", "d", "e"], "id": [0, 7, 12, 30, 1000003]})
+    named = n2v.embedding()
+    assert list(named.columns) == ["name", "vector"] and named["name"].tolist() == ["d", "b", "e", "a", "c"]
+    assert n2v.get_vector(7) == vec[1].tolist()
