@@ -1,0 +1,149 @@
+"""The multi-GPU paths with TWO real ranks on real kernels.
+
+One MI355X box has one GPU and RCCL refuses two ranks on one device, so the two ranks are two
+processes on cuda:0 joined by gloo (device tensors are staged through the host by
+shard.all_reduce; everything else -- the walk sharding, the globally summed vocabulary, the block
+grid over the largest shard, DeltaSync's pack / apply kernels, its side-stream overlap, the
+period autotune -- is the code that runs under RCCL).  Checked:
+  * Node2VecHIP.fit() under the group with uneven shards, and with one EMPTY shard; fp32 and
+    bf16 wire; overlap on; sync_every fixed and autotuned: every rank returns bit-identical
+    matrices, and each rank trained exactly the pairs a single process trains on that shard with
+    that rank's sentence ids;
+  * pipeline.fit_streaming under the group: identical replicas, the vocabulary of the whole
+    corpus, the pair count of the two shards.
+"""
+import hashlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+N2V = {"num_walks": 4, "walk_length": 20, "return_param": 0.5, "inout_param": 2.0}
+W2V = {"min_count": 1, "iter": 2, "size": 64, "negative": 5, "sample": 0.0, "seed": 5, "window": 5}
+SCENARIOS = [  # (name, share of the walks on rank 0, wire, sync_every)
+    ("uneven_fp32", 0.7, "fp32", 2),
+    ("uneven_bf16_autotune", 0.7, "bf16", None),
+    ("empty_shard_fp32_autotune", 1.0, "fp32", None),
+    ("empty_shard_bf16", 1.0, "bf16", 1),
+]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _digest(t):
+    return hashlib.sha1(t.detach().cpu().numpy().tobytes()).hexdigest()
+
+
+def _corpus():
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd import synthetic
+
+    g = synthetic.rmat(11, 12000, seed=3, device="cuda:0")
+    start = rw.start_vertices(g)
+    walks, valid = rw.walk(g, start, N2V["num_walks"], N2V["walk_length"], N2V["return_param"],
+                           N2V["inout_param"], 17)
+    return g, walks[valid]
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from node2vec_amd.embedding import Node2VecHIP
+        from node2vec_amd.pipeline import fit_streaming
+
+        g, walks = _corpus()
+        out = {}
+        for name, share0, wire, every in SCENARIOS:
+            cut = int(round(share0 * walks.shape[0]))
+            mine = walks[:cut] if rank == 0 else walks[cut:]
+            params = dict(W2V, sync_wire=wire)
+            if every is not None:
+                params["sync_every"] = every
+            n2v = Node2VecHIP(mine.clone(), params, random_seed=5)
+            model = n2v.fit()
+            out[name] = {"rows": int(mine.shape[0]), "pairs": int(model.pairs_trained),
+                         "syn0": _digest(model.wv._vectors), "syn1neg": _digest(model._syn1neg),
+                         "n_vocab": len(model.wv), "finite": bool(torch.isfinite(model.wv._vectors).all())}
+        t = {}
+        sm, raw = fit_streaming(g, dict(N2V), dict(W2V, sync_wire="fp32", sync_every=3), random_seed=17,
+                                batch_vertices=200, return_model=True, timings=t)
+        out["streaming"] = {"pairs": int(sm.pairs_trained), "syn0": _digest(raw.syn0),
+                            "syn1neg": _digest(raw.syn1neg), "n_vocab": len(sm.wv),
+                            "ids": _digest(raw.vocab.ids), "counts": _digest(raw.vocab.counts),
+                            "world": t["world"], "rows": t["rows_this_rank"]}
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_fit_and_fit_streaming():
+    import torch.multiprocessing as mp
+
+    from node2vec_amd import sgns
+    from node2vec_amd.pipeline import fit_streaming
+    from node2vec_amd.shard import sentence_base, shard_range
+
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+
+    g, walks = _corpus()
+    vocab = sgns.build_vocab(walks, 1)
+    idx_all = vocab.index_of[walks.long()]
+    for name, share0, wire, every in SCENARIOS:
+        a, b = r0[name], r1[name]
+        assert a["finite"] and b["finite"], name
+        # identical replicas after the final blocking exchange
+        assert a["syn0"] == b["syn0"] and a["syn1neg"] == b["syn1neg"], name
+        assert a["n_vocab"] == b["n_vocab"] == len(vocab), name
+        cut = int(round(share0 * walks.shape[0]))
+        assert (a["rows"], b["rows"]) == (cut, walks.shape[0] - cut), name
+        # each rank trained the pairs a single process trains on that shard with that rank's
+        # sentence ids (the block grid is laid over the largest shard)
+        rows_max = max(cut, walks.shape[0] - cut)
+        for rank, got in ((0, a), (1, b)):
+            shard = idx_all[:cut] if rank == 0 else idx_all[cut:]
+            m = sgns.SgnsModel(vocab, 64, 5, 5, seed=5, sample=0.0)
+            m.train(shard, 2, 0.025, 1e-4, rows_global_max=rows_max,
+                    sentence_base=sentence_base(rank, world, rows_max * 2))
+            torch.cuda.synchronize()
+            assert int(m.pairs.item()) == got["pairs"], (name, rank)
+        if share0 == 1.0:
+            assert b["pairs"] == 0 and a["pairs"] > 0
+
+    sa, sb = r0["streaming"], r1["streaming"]
+    assert sa["world"] == sb["world"] == 2
+    assert sa["syn0"] == sb["syn0"] and sa["syn1neg"] == sb["syn1neg"]
+    assert sa["ids"] == sb["ids"] == _digest(vocab.ids) and sa["counts"] == sb["counts"] == _digest(vocab.counts)
+    assert sa["n_vocab"] == len(vocab)
+    from node2vec_amd import randomwalk as rw
+
+    n_start = int(rw.start_vertices(g).numel())
+    lo0, hi0 = shard_range(n_start, 0, 2)
+    assert sa["rows"] == (hi0 - lo0) * N2V["num_walks"] and sa["rows"] + sb["rows"] == n_start * N2V["num_walks"]
+    # a single process streaming the whole graph trains a different schedule (other sentence
+    # ids), but the same corpus: pair counts agree to a fraction of a per cent
+    single = fit_streaming(g, dict(N2V), dict(W2V), random_seed=17, batch_vertices=200)
+    tot = sa["pairs"] + sb["pairs"]
+    assert abs(tot - single.pairs_trained) / single.pairs_trained < 0.01, (tot, single.pairs_trained)
+    assert np.isfinite(single.wv.vectors).all()

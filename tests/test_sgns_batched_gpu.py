@@ -70,7 +70,7 @@ def test_batched_deterministic_bit_identical_to_its_oracle(oracle, dim, sample, 
 def test_batched_tile_shapes(oracle, window, negative):
     """both k-step counts over the context rows (2w + 1 <= 12 or not) and over the target rows
     (1 + k <= 8 or not), the smallest window, out-of-vocabulary tokens"""
-    walks = _corpus(80, 30, 33, 100 * window + negative, True)
+    walks = _corpus(400, 30, 33, 100 * window + negative, True)
     sgns, m, idx = _model(walks, 128, window, negative, 3, 1e-3, min_count=3)
     assert int((idx < 0).sum()) > 0
     _check_bits(oracle, sgns, m, idx, 128, window, negative, launches=((0, 0.025),))

@@ -12,11 +12,19 @@ the planted-partition test of tests/test_sgns_gpu.py is the case with real concu
   * overlap of the 5 nearest neighbours of every vertex    >= 0.55   (measured 1.00; chance 0.15)
   * edge-vs-non-edge AUC of the cosine similarity          |hogwild - deterministic| <= 0.03
 R-MAT scale 20 (BASELINE cfg 2, all 471 k start vertices x 10 walks x 80 steps, 2.2 G pairs per
-epoch, dim 128), 5 seeds, hogwild only (one wave would need hours):
-  * edge-vs-random-pair AUC >= 0.88 for every seed, spread (max - min) <= 0.01
-    (measured 0.898 .. 0.900)
+epoch, dim 128), 5 seeds, hogwild only (one wave would need hours).  Tolerances re-derived in
+round 3 from 20 runs (profiles/r3a_hogwild_auc_runs.log, scripts/r3/hogwild_auc_runs.py): link AUC
+mean 0.8970, sd 0.0024, min 0.8915, max 0.9020 -- round 2 had asserted a 5-seed spread <= 0.01
+from ONE measurement (0.0026); the expected range of 5 draws at sd 0.0024 is 0.0056 and 0.01 is
+exceeded about one time in 20, which is what the driver's box saw (0.0112).  The variance is
+between seeds, not between launch geometries: capped at 2048 / 512 concurrent waves the same
+statistic has sd 0.0020 / 0.0024 around 0.8974 / 0.8991.  (Capped at 64 waves -- gensim's
+regime -- it is 0.908 .. 0.914: lost updates on hub rows cost ~0.014 AUC at the full 8192 waves;
+DESIGN.md "hogwild".)
+  * edge-vs-random-pair AUC of every seed within mean +- 6 sd: 0.8826 .. 0.9114
+  * spread (max - min) of the 5 seeds <= 0.025 (10 sd; informative, not tight)
   * 10-nearest-neighbour overlap between seeds, over 2 000 probe vertices of degree >= 20: >= 0.45
-    (measured 0.56; chance: 10 / 471 k)
+    (20 runs: 0.559 .. 0.567; chance: 10 / 471 k)
 """
 import numpy as np
 import pytest
@@ -134,5 +142,6 @@ def test_rmat_1m_hogwild_quality_is_stable_over_five_seeds():
         del m, u, s
     ov = [_overlap(nbrs[0], nbrs[i]) for i in range(1, 5)]
     print("rmat-1m: link AUC per seed", aucs, "knn@10 overlap vs seed 0", ov)
-    assert min(aucs) >= 0.88 and max(aucs) - min(aucs) <= 0.01
+    assert 0.8826 <= min(aucs) and max(aucs) <= 0.9114, aucs  # mean +- 6 sd of 20 runs
+    assert max(aucs) - min(aucs) <= 0.025, aucs
     assert min(ov) >= 0.45
