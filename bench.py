@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sgns", action="store_true")
     ap.add_argument("--no-fast", action="store_true")
+    ap.add_argument("--no-batched", action="store_true", help="skip the opt-in batched SGNS leg")
     ap.add_argument("--no-biased", action="store_true")
     ap.add_argument("--no-regimes", action="store_true", help="skip the other (p, q) regimes of the exact sampler")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU time budget per baseline leg")
@@ -297,8 +298,10 @@ def main():
             out["fast_mode"] = {"value": s3 / e3, "unit": "walk-steps/s", "walk_mode": "fast",
                                 "p": bp, "q": bq, "ms_per_step": 1e3 * e3 / args.steps,
                                 "start_vertices_per_step": leg.batch,
-                                "parity": "same transition distribution (chi-square tested), "
-                                          "not the same draws",
+                                "parity": "same transition distribution as generate_edge_alias_tables, not the "
+                                          "same draws (chi-square against the oracle's exact probabilities: "
+                                          "weighted tests/test_alias_trim_fast_gpu.py, unit-weight + every "
+                                          "table combination tests/test_fast_unit_gpu.py)",
                                 "trials_per_step": r3["trials"] / max(r3["steps_done"], 1),
                                 "roofline": roofline("walk_fast_kernel", r3, leg, args.config, bp,
                                                      bq, "fast", None)}
@@ -573,6 +576,9 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist)
                         "measured_row_ceiling_GBps": row_ceiling,
                         "algorithmic_bytes_per_pair": bytes_per_pair,
                         "fma_utilisation": pairs / args.steps * flops_per_pair / kernel_s / FP32_PEAK}}
+    if not args.no_batched and dim in (64, 128, 256):
+        res["batched"] = bench_sgns_batched(args, torch, dist, model, idx, rows, rank, barrier,
+                                            use_dist, dev, dim)
     if use_dist:  # the exchange step of the multi-GPU path, timed once (blocking, bf16 deltas)
         sync = sgns.DeltaSync(model, wire="bf16")
         barrier()
@@ -590,6 +596,56 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist)
                            "share_at_that_period": dt / (dt + every * step_s)}
         del sync
     return res, model
+
+
+def bench_sgns_batched(args, torch, dist, model, idx, rows, rank, barrier, use_dist, dev, dim):
+    """The opt-in batched trainer (n2v_sgns_params.batched: the k negatives are drawn once per
+    centre position and shared by its pairs -- NOT gensim's sampling) on the same model and
+    corpus: K launches.  A position is three small dense products on v_mfma_f32_16x16x4_f32 and
+    moves 8*D*(2+k) bytes of HBM per POSITION instead of per pair."""
+    model.batched = True
+    try:
+        for k in range(args.warmup):
+            model.train_block(idx, 0.025, (100 + k) * rows)
+        model.pairs.zero_()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            ev[k][0].record()
+            model.train_block(idx, 0.025, (200 + k + rank * 1000) * rows)
+            ev[k][1].record()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        pairs = float(model.pairs.item())
+    finally:
+        model.batched = False
+    elapsed, pairs_total = reduce_job(torch, dist, use_dist, dev, elapsed, pairs)
+    kernel_s = 1e-3 * sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    positions = float((idx >= 0).sum().item())  # per launch: every token is a centre position
+    bytes_per_position = 8 * dim * (2 + 5)
+    ach = positions * bytes_per_position / kernel_s
+    mfma_per_position = dim // 4 + (dim // 16) * 3 + (dim // 16) * 2  # F + Tgt update + Ctx update
+    sclk = 2.4e9
+    return {"value": pairs_total / elapsed, "unit": "embedding-updates/s (pairs; k=5 negatives shared "
+                                                    "by the pairs of a centre position)",
+            "ms_per_step": 1e3 * elapsed / args.steps, "dtype": "f32",
+            "sampling": "opt-in, NOT gensim's per-pair negatives: one draw of k negatives per centre "
+                        "position (Ji et al. 2016); bit-identical to its own oracle in deterministic mode",
+            "pairs_per_position": pairs / args.steps / max(positions, 1.0),
+            "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK, "traffic": None, "kernel": "sgns_batched_kernel",
+                         "kernel_ms": 1e3 * kernel_s,
+                         "achieved_from": "algorithmic bytes 8*D*(2+k) per centre POSITION (centre + k "
+                                          "negative rows and one context row, read and written once)",
+                         "algorithmic_bytes_per_position": bytes_per_position,
+                         "mfma": {"instruction": "v_mfma_f32_16x16x4_f32 (exact f32, 32 cycles)",
+                                  "instructions_per_position": mfma_per_position,
+                                  "busy_fraction_analytic": positions * mfma_per_position * 32 /
+                                  (kernel_s * sclk * 1024),
+                                  "note": "instructions x 32 cycles / (1024 SIMDs x 2.4 GHz x kernel time); "
+                                          "the measured SQ_VALU_MFMA_BUSY_CYCLES are in profiles/"}}}
 
 
 def host_cores():

@@ -121,27 +121,32 @@ __device__ __forceinline__ int b_bisect(const uint32_t *a, int lo, int hi, uint3
   return lo;
 }
 
-// VEC = dim / 64; TROWS = rows of the target tile (8: 1 + negative <= 8, two k-steps; else 16)
-template <int VEC, int TROWS, int KC>  // KC: k-steps over context rows (3: 2 * window + 1 <= 12)
+// VEC = dim / 64; TROWS = rows of the target tile (8: 1 + negative <= 8, two k-steps; else 16);
+// KC = k-steps over the context rows (3: 2 * window + 2 <= 12 ring rows, else 4 and 16 rows)
+template <int VEC, int TROWS, int KC>
 __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
     const int32_t *__restrict__ walks, int64_t n_walks, int32_t walk_len, float *syn0,
     float *syn1neg, const uint32_t *__restrict__ cum_table,
     const uint32_t *__restrict__ sample_int, const float *__restrict__ exp_table_g,
-    n2v_sgns_params P, unsigned long long *pairs_out, int rrows) {
+    n2v_sgns_params P, unsigned long long *pairs_out) {
   constexpr int D = 64 * VEC, Q = 16 * VEC, RS = Q + 4, NCH = D / 16;
-  constexpr int PT = (TROWS * RS + 63) / 64 * 64;  // plane stride of the target tile
-  constexpr int KT = TROWS == 8 ? 2 : 4;           // k-steps over target rows
-  const int PR = (rrows * RS + 63) / 64 * 64;      // plane stride of the context ring
+  constexpr int RROWS = KC == 3 ? 12 : 16;          // physical rows of the context ring
+  constexpr int PR = (RROWS * RS + 63) / 64 * 64;   // plane stride of the context ring
+  constexpr int PT = (TROWS * RS + 63) / 64 * 64;   // plane stride of the target tile
+  constexpr int KT = TROWS == 8 ? 2 : 4;            // k-steps over target rows
+  constexpr int TM_WORDS = TROWS == 8 ? 1 : 2;      // packed multiplicities: 4 bits per target
   const int window = P.window, K = P.negative;
+  const int PL = K + 1 + TM_WORDS + 1;              // plan ints per position (below)
   const float alpha = P.alpha;
+  const bool hogwild = P.deterministic == 0;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *exp_lds = reinterpret_cast<float *>(smem);
   const int wave_in_block = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int j16 = lane & 15, g4 = lane >> 4;
-  const int per_wave_floats = 4 * PR + 4 * PT + 16 * 17;
-  const int per_wave_ints = (2 * walk_len + walk_len * K + 64 + 3) & ~3;  // regions stay 16-byte aligned
+  constexpr int per_wave_floats = 4 * PR + 4 * PT + 16 * 17;
+  const int per_wave_ints = (2 * walk_len + walk_len * K + walk_len * PL + 32 + 3) & ~3;
   unsigned char *mine = smem + kBExpTable * sizeof(float) +
                         (size_t)wave_in_block * ((size_t)per_wave_floats + per_wave_ints) * 4;
   float *ring = reinterpret_cast<float *>(mine);
@@ -150,10 +155,12 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
   int32_t *sent = reinterpret_cast<int32_t *>(gs + 16 * 17);
   int32_t *red = sent + walk_len;
   int32_t *negw = red + walk_len;
-  int32_t *mphys = negw + walk_len * K;  // [16] M index -> physical ring row
-  int32_t *mmultM = mphys + 16;          // [16] multiplicity by M index (0: unused)
-  int32_t *twc = mmultM + 16;            // [16] target word by target index
-  int32_t *colmult = twc + 16;           // [16] multiplicity by tile column (0: unused)
+  // the plan of a sentence, per position i: [0 .. K] the target words (centre, then the distinct
+  // negatives != centre in draw order), [K + 1 ..] their multiplicities (4 bits each), then one
+  // word: bits 0..4 the number of targets, bits 8.. a mask of the targets position i - 1 writes
+  int32_t *plan = negw + walk_len * K;
+  int32_t *mphys = plan + walk_len * PL;  // [16] M index -> physical ring row
+  int32_t *mmultM = mphys + 16;           // [16] multiplicity by M index (0: unused)
   for (int i = threadIdx.x; i < kBExpTable; i += blockDim.x) exp_lds[i] = exp_table_g[i];
   __syncthreads();
 
@@ -168,6 +175,11 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
   // target index of tile column n (-1: no target there); target t sits in column
   // 4 * (t / 2) + t % 2 when two k-steps cover the targets, else in column t
   auto tgt_of = [&](int n) { return KT == 2 ? ((n & 3) < 2 ? 2 * (n >> 2) + (n & 3) : -1) : n; };
+  auto tm_of = [&](const int32_t *pl, int t) { return (pl[K + 1 + (t >> 3)] >> (4 * (t & 7))) & 15; };
+  // per-lane constants of the accumulator layout: lane (g4, j16) holds rows 4 g4 + r, column j16
+  int t_of_r[4], t_of_col = tgt_of(j16);
+#pragma unroll
+  for (int rI = 0; rI < 4; ++rI) t_of_r[rI] = tgt_of(4 * g4 + rI);
 
   for (;;) {
     if (dynamic) {
@@ -214,28 +226,71 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
     }
     wave_sync();
     if (nf < 2) continue;  // a single token has no context: nothing to train
+    // ---- the plan: one lane per position dedupes its draws into the target list ----
+    for (int i = lane; i < nf; i += 64) {
+      int32_t *pl = plan + i * PL;
+      const int centre = sent[i];
+      pl[0] = centre;
+      int nt = 1;
+      int tm[TM_WORDS];
+#pragma unroll
+      for (int wI = 0; wI < TM_WORDS; ++wI) tm[wI] = 0;
+      tm[0] = 1;  // the centre word: multiplicity 1
+      for (int d = 0; d < K; ++d) {
+        const int x = negw[i * K + d];
+        bool first = x != centre;  // gensim: a negative equal to the positive target is skipped
+        for (int e = 0; e < d; ++e) first = first && negw[i * K + e] != x;
+        if (!first) continue;
+        int mult = 1;
+        for (int e = d + 1; e < K; ++e) mult += negw[i * K + e] == x;
+        pl[nt] = x;
+        if (TM_WORDS == 1 || nt < 8)
+          tm[0] |= mult << (4 * (nt & 7));
+        else
+          tm[TM_WORDS - 1] |= mult << (4 * (nt & 7));
+        ++nt;
+      }
+      for (int t = nt; t <= K; ++t) pl[t] = centre;  // unused slots name a real row
+#pragma unroll
+      for (int wI = 0; wI < TM_WORDS; ++wI) pl[K + 1 + wI] = tm[wI];
+      pl[K + 1 + TM_WORDS] = nt;
+    }
+    wave_sync();
+    // which targets of position i does position i - 1 write (they are read after that write)
+    for (int i = lane; i < nf; i += 64) {
+      if (i == 0) continue;
+      int32_t *pl = plan + i * PL;
+      const int32_t *pp = pl - PL;
+      const int nt = pl[K + 1 + TM_WORDS], np = pp[K + 1 + TM_WORDS] & 31;
+      int late = 0;
+      for (int t = 0; t < nt; ++t) {
+        const int x = pl[t];
+        for (int sI = 0; sI < np; ++sI) late |= (pp[sI] == x) << t;
+      }
+      pl[K + 1 + TM_WORDS] = nt | (late << 8);
+    }
+    wave_sync();
 
     // ---- the context ring: lane p < 16 is physical row p / position residue p ----
-    int row_word = -1, row_ref = 0, pos_row = 0;
+    int row_word = -1, row_ref = 0, row_pos = 0 /* residues held by this row */, pos_row = 0;
+    BRow<VEC> loaded[RROWS];  // the rows as they were read (hogwild: deltas go back atomically)
 
     // position j enters the window.  Returns the physical row, and in `fresh` whether the row
     // was allocated now (its syn0 row must be brought in by the caller).
-    auto enter = [&](int j, bool &fresh) -> int {
-      const int word = rfl(sent[j]);
+    auto enter = [&](int j, int word, bool &fresh) -> int {
       const uint64_t hit = ballot64(lane < 16 && row_ref > 0 && row_word == word);
       int row;
       if (hit) {
         row = __builtin_ctzll(hit);
         fresh = false;
-        if (lane == row) ++row_ref;
       } else {
-        const uint64_t freem = ballot64(lane < rrows && row_ref == 0);
-        row = __builtin_ctzll(freem);  // 2 * window + 2 <= rrows: a row is always free
+        row = __builtin_ctzll(ballot64(lane < RROWS && row_ref == 0));  // 2 * window + 2 <= RROWS
         fresh = true;
-        if (lane == row) {
-          row_word = word;
-          row_ref = 1;
-        }
+      }
+      if (lane == row) {
+        row_word = word;
+        ++row_ref;
+        row_pos |= 1 << (j & 15);
       }
       if (lane == (j & 15)) pos_row = row;
       return row;
@@ -243,124 +298,107 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
     // position j leaves: the row goes back to HBM with its last position
     auto leave = [&](int j) {
       const int row = rl(pos_row, j & 15);
-      if (lane == row) --row_ref;
+      if (lane == row) {
+        --row_ref;
+        row_pos &= ~(1 << (j & 15));
+      }
       if (rl(row_ref, row) == 0) {
         BRow<VEC> t;
         lds_get<VEC>(ring, PR, row, lane, t);
-        g_store<VEC>(syn0 + (int64_t)rl(row_word, row) * D, lane, t);
-      }
-    };
-
-    // target list of a position: lane t < 16 holds (word, multiplicity) of target t
-    auto build_targets = [&](int i, int &tw, int &tm) -> int {
-      const int centre = rfl(sent[i]);
-      int nt = 1;
-      tw = lane == 0 ? centre : -1;
-      tm = lane == 0 ? 1 : 0;
-      for (int d = 0; d < K; ++d) {
-        const int x = rfl(negw[i * K + d]);
-        if (x == centre) continue;  // gensim: a negative equal to the positive target is skipped
-        const uint64_t hit = ballot64(lane >= 1 && lane < nt && tw == x);
-        if (hit) {
-          if (lane == (int)__builtin_ctzll(hit)) ++tm;
+        float *dst = syn0 + (int64_t)rl(row_word, row) * D;
+        if (hogwild) {
+          // other waves may have trained this row meanwhile: add what THIS wave learned
+#pragma unroll
+          for (int rI = 0; rI < RROWS; ++rI)
+            if (row == rI) {
+#pragma unroll
+              for (int v = 0; v < VEC; ++v)
+                unsafeAtomicAdd(dst + lane * VEC + v, t.v[v] - loaded[rI].v[v]);
+            }
         } else {
-          if (lane == nt) {
-            tw = x;
-            tm = 1;
-          }
-          ++nt;
+          g_store<VEC>(dst, lane, t);
         }
-      }
-      return nt;
-    };
-    // publish the current target list: words by target index, multiplicities by tile column
-    auto publish_targets = [&](int tw, int tm, int nt) {
-      if (lane < 16) {
-        twc[lane] = lane < nt ? tw : rl(tw, 0);
-        const int t = tgt_of(lane);
-        const int m = __shfl(tm, t < 0 ? 0 : t, 64);
-        colmult[lane] = (t >= 0 && t < nt) ? m : 0;
       }
     };
 
     // ---- prologue: positions 0 .. window enter, targets of position 0 arrive ----
     for (int j = 0; j <= window && j < nf; ++j) {
       bool fresh;
-      const int row = enter(j, fresh);
+      const int word = sent[j];
+      const int row = enter(j, word, fresh);
       if (fresh) {
         BRow<VEC> t;
-        g_load<VEC>(syn0 + (int64_t)rfl(sent[j]) * D, lane, t);
+        g_load<VEC>(syn0 + (int64_t)word * D, lane, t);
         lds_put<VEC>(ring, PR, row, lane, t);
+#pragma unroll
+        for (int rI = 0; rI < RROWS; ++rI)
+          if (row == rI) loaded[rI] = t;
       }
     }
-    int tw_c, tm_c;
-    int nt_c = build_targets(0, tw_c, tm_c);
+    int nt_c = rfl(plan[K + 1 + TM_WORDS]) & 31;
 #pragma unroll
     for (int t = 0; t < TROWS; ++t)
       if (t < nt_c) {
         BRow<VEC> row;
-        g_load<VEC>(syn1neg + (int64_t)rl(tw_c, t) * D, lane, row);
+        g_load<VEC>(syn1neg + (int64_t)plan[t] * D, lane, row);
         lds_put<VEC>(tgt, PT, t, lane, row);
       }
-    publish_targets(tw_c, tm_c, nt_c);
     wave_sync();
 
     for (int i = 0; i < nf; ++i) {
+      const int32_t *plc = plan + i * PL;
       const int b = rfl(red[i]);
       const int lo = max(0, i - window + b);
       const int hi = min(nf, i + window + 1 - b);
       // ---- A. requests for position i + 1: its entering context row and its target rows ----
       const bool have_next = i + 1 < nf;
-      int tw_n = -1, tm_n = 0, nt_n = 0;
-      uint64_t late = 0;
+      int nt_n = 0, late = 0;
       BRow<VEC> nrow[TROWS];
       BRow<VEC> crow_in;
       int enter_row = -1;
       if (have_next) {
+        const int32_t *pln = plc + PL;
         const int jn = i + 1 + window;
         if (jn < nf) {
           bool fresh;
-          const int row = enter(jn, fresh);
+          const int word = sent[jn];
+          const int row = enter(jn, word, fresh);
           if (fresh) {
             enter_row = row;
-            g_load<VEC>(syn0 + (int64_t)rfl(sent[jn]) * D, lane, crow_in);
+            g_load<VEC>(syn0 + (int64_t)word * D, lane, crow_in);
           }
         }
-        nt_n = build_targets(i + 1, tw_n, tm_n);
-        // a row this position is about to write must be read after the write (stays in order)
-        bool mylate = false;
-        for (int t = 0; t < nt_c; ++t) mylate = mylate || (tw_n == rl(tw_c, t));
-        late = ballot64(mylate && lane < nt_n);
+        const int w = rfl(pln[K + 1 + TM_WORDS]);
+        nt_n = w & 31;
+        late = w >> 8;  // rows position i writes: read after its stores (stays in order)
 #pragma unroll
         for (int t = 0; t < TROWS; ++t)
-          if (t < nt_n && !((late >> t) & 1ull))
-            g_load<VEC>(syn1neg + (int64_t)rl(tw_n, t) * D, lane, nrow[t]);
+          if (t < nt_n && !((late >> t) & 1))
+            g_load<VEC>(syn1neg + (int64_t)pln[t] * D, lane, nrow[t]);
       }
 
-      // ---- B. the position's context rows: distinct physical rows, multiplicity, M index ----
-      int cm = 0, rank = -1, nu = 0, npairs = 0;
-      for (int j = lo; j < hi; ++j) {
-        if (j == i) continue;
-        ++npairs;
-        const int row = rl(pos_row, j & 15);
-        if (rl(cm, row) == 0) {
-          if (lane == row) rank = nu;
-          ++nu;
-        }
-        if (lane == row) ++cm;
-      }
+      // ---- B. the position's context rows: the physical rows whose positions lie in the
+      //         reduced window, ascending; multiplicity = how many of its positions do ----
+      const int span = hi - lo;  // <= 2 * window + 1 <= 15 positions, i among them
+      uint32_t jmask = ((1u << span) - 1u) << (lo & 15);
+      jmask = (jmask | (jmask >> 16)) & 0xffffu;
+      jmask &= ~(1u << (i & 15));
+      const int npairs = __popc(jmask);
+      const int cm = lane < 16 ? __popc((uint32_t)row_pos & jmask) : 0;
+      const uint64_t used = ballot64(cm > 0);
       f32x4 newt[NCH];
       float *st_dst[4];
       bool st_ok[4];
       bool trained = false;
-      if (nu > 0) {
-        const int row0 = (int)__builtin_ctzll(ballot64(lane < 16 && rank == 0));
+      if (used) {
+        const int rank = __popcll(used & ((1ull << lane) - 1ull));
+        const int row0 = (int)__builtin_ctzll(used);
         if (lane < 16) {
           mphys[lane] = row0;
           mmultM[lane] = 0;
         }
         wave_sync();
-        if (lane < 16 && cm > 0) {
+        if (cm > 0) {
           const int m = KC == 3 ? 4 * (rank / 3) + rank % 3 : rank;
           mphys[m] = lane;
           mmultM[m] = cm;
@@ -368,10 +406,10 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
         wave_sync();
 
         // ---- F = Ctx . Tgt^T : one fmaf chain per (context row, target row) over d ----
-        const int tcol = tgt_of(j16);
+        const bool col_ok = t_of_col >= 0 && t_of_col < nt_c;
         const float4 *ap = reinterpret_cast<const float4 *>(ring + g4 * PR + mphys[j16] * RS);
-        const float4 *bp = reinterpret_cast<const float4 *>(
-            tgt + g4 * PT + ((tcol >= 0 && tcol < nt_c) ? tcol : 0) * RS);
+        const float4 *bp =
+            reinterpret_cast<const float4 *>(tgt + g4 * PT + (col_ok ? t_of_col : 0) * RS);
         f32x4 f = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int q = 0; q < Q / 4; ++q) {
@@ -382,15 +420,15 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
           f = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, f, 0, 0, 0);
         }
         // ---- G[m = 4 g + r][n = l & 15] ----
-        const int cmult = colmult[j16];
+        const int cmult = col_ok ? tm_of(plc, t_of_col) : 0;
         const float label = j16 == 0 ? 1.0f : 0.0f;
         float gv[4];
-        int mp[4];
+        const float *rbase[4];  // ring row of M index 4 g4 + r, at column j16
 #pragma unroll
         for (int rI = 0; rI < 4; ++rI) {
           const int m = 4 * g4 + rI;
           const int mult = mmultM[m] * cmult;
-          mp[rI] = mphys[m];
+          rbase[rI] = ring + mphys[m] * RS + j16;
           const float fv = f[rI];
           const bool live = mult > 0 && !(fv <= -6.0f || fv >= 6.0f);
           const int e = live ? (int)((fv + 6.0f) * 83.0f) : 0;
@@ -402,55 +440,44 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
         float ga[KT];  // A operand of Ctx += G . Tgt: G[m = l & 15][column 4 g + s]
 #pragma unroll
         for (int s = 0; s < KT; ++s) ga[s] = gs[j16 * 17 + 4 * g4 + s];
+        const float *tbase[4];  // target row of tile column 4 g4 + r (row 0 when there is none)
+#pragma unroll
+        for (int rI = 0; rI < 4; ++rI) {
+          st_ok[rI] = t_of_r[rI] >= 0 && t_of_r[rI] < nt_c;
+          tbase[rI] = tgt + (st_ok[rI] ? t_of_r[rI] : 0) * RS + j16;
+        }
 
         // ---- Tgt_new = Tgt_old + G^T . Ctx_old  (kept in registers until Ctx is done) ----
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-          const int plane = c / VEC, off = (c % VEC) * 16 + j16;
+          const int po = (c / VEC) * PT + (c % VEC) * 16, ro = (c / VEC) * PR + (c % VEC) * 16;
           f32x4 acc;
 #pragma unroll
-          for (int rI = 0; rI < 4; ++rI) {
-            const int t = tgt_of(4 * g4 + rI);
-            acc[rI] = (t >= 0 && t < nt_c) ? tgt[plane * PT + t * RS + off] : 0.0f;
-          }
+          for (int rI = 0; rI < 4; ++rI) acc[rI] = st_ok[rI] ? tbase[rI][po] : 0.0f;
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
-            if (s < KC) {
-              const float bv = ring[plane * PR + mp[s] * RS + off];
-              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[s], bv, acc, 0, 0, 0);
-            }
+          for (int s = 0; s < KC; ++s)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[s], rbase[s][ro], acc, 0, 0, 0);
           newt[c] = acc;
         }
         wave_sync();
         // ---- Ctx += G . Tgt_old, in place in the ring ----
-        int tk[KT];
-#pragma unroll
-        for (int s = 0; s < KT; ++s) {
-          const int t = tgt_of(4 * g4 + s);
-          tk[s] = (t >= 0 && t < nt_c) ? t : 0;
-        }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-          const int plane = c / VEC, off = (c % VEC) * 16 + j16;
+          const int po = (c / VEC) * PT + (c % VEC) * 16, ro = (c / VEC) * PR + (c % VEC) * 16;
           f32x4 acc;
 #pragma unroll
-          for (int rI = 0; rI < 4; ++rI) acc[rI] = ring[plane * PR + mp[rI] * RS + off];
+          for (int rI = 0; rI < 4; ++rI) acc[rI] = rbase[rI][ro];
 #pragma unroll
-          for (int s = 0; s < KT; ++s) {
-            const float bv = tgt[plane * PT + tk[s] * RS + off];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], bv, acc, 0, 0, 0);
-          }
+          for (int s = 0; s < KT; ++s)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], tbase[s][po], acc, 0, 0, 0);
 #pragma unroll
           for (int rI = 0; rI < 4; ++rI)
-            if (mmultM[4 * g4 + rI] > 0) ring[plane * PR + mp[rI] * RS + off] = acc[rI];
+            if (mmultM[4 * g4 + rI] > 0) const_cast<float *>(rbase[rI])[ro] = acc[rI];
         }
-        // where the new target rows go: fixed now, the target list is replaced below
+        // where the new target rows go (the tile is refilled below)
 #pragma unroll
-        for (int rI = 0; rI < 4; ++rI) {
-          const int t = tgt_of(4 * g4 + rI);
-          st_ok[rI] = t >= 0 && t < nt_c;
-          st_dst[rI] = syn1neg + (int64_t)twc[st_ok[rI] ? t : 0] * D + j16;
-        }
+        for (int rI = 0; rI < 4; ++rI)
+          st_dst[rI] = syn1neg + (int64_t)plc[st_ok[rI] ? t_of_r[rI] : 0] * D + j16;
         trained = true;
         pairs += (unsigned long long)npairs;
         wave_sync();
@@ -459,10 +486,15 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
       //         ago): it is consumed BEFORE this position's stores are issued, so that the wait
       //         for the loads never waits for a store ----
       if (have_next) {
-        if (enter_row >= 0) lds_put<VEC>(ring, PR, enter_row, lane, crow_in);
+        if (enter_row >= 0) {
+          lds_put<VEC>(ring, PR, enter_row, lane, crow_in);
+#pragma unroll
+          for (int rI = 0; rI < RROWS; ++rI)
+            if (enter_row == rI) loaded[rI] = crow_in;
+        }
 #pragma unroll
         for (int t = 0; t < TROWS; ++t)
-          if (t < nt_n && !((late >> t) & 1ull)) lds_put<VEC>(tgt, PT, t, lane, nrow[t]);
+          if (t < nt_n && !((late >> t) & 1)) lds_put<VEC>(tgt, PT, t, lane, nrow[t]);
       }
       // ---- D. the target rows go back to HBM from the accumulator layout (64 B per row and
       //         instruction); position i - window is outside every later window ----
@@ -477,17 +509,15 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
       if (i - window >= 0) leave(i - window);
       if (have_next) {
         if (late) {  // rows this position has just written: read them back now, in order
+          const int32_t *pln = plc + PL;
 #pragma unroll
           for (int t = 0; t < TROWS; ++t)
-            if (t < nt_n && ((late >> t) & 1ull)) {
-              g_load<VEC>(syn1neg + (int64_t)rl(tw_n, t) * D, lane, nrow[t]);
+            if (t < nt_n && ((late >> t) & 1)) {
+              g_load<VEC>(syn1neg + (int64_t)pln[t] * D, lane, nrow[t]);
               lds_put<VEC>(tgt, PT, t, lane, nrow[t]);
             }
         }
-        tw_c = tw_n;
-        tm_c = tm_n;
         nt_c = nt_n;
-        publish_targets(tw_c, tm_c, nt_c);
         wave_sync();
       }
     }
@@ -511,13 +541,14 @@ extern "C" int n2v_sgns_batched_launch(const int32_t *walks, int64_t n_walks, in
   if (P->dim != 64 && P->dim != 128 && P->dim != 256) return N2V_EINVAL;
   if (2 * P->window + 2 > 16 || 1 + P->negative > 16) return N2V_EINVAL;
   const int VEC = P->dim / 64;
-  const int rrows = 2 * P->window + 2 <= 12 ? 12 : 16;
+  const int kc = 2 * P->window + 2 <= 12 ? 3 : 4;
+  const int rrows = kc == 3 ? 12 : 16;
   const int trows = 1 + P->negative <= 8 ? 8 : 16;
-  const int kc = 2 * P->window + 1 <= 12 ? 3 : 4;
   const int RS = 16 * VEC + 4;
   const int PR = (rrows * RS + 63) / 64 * 64, PT = (trows * RS + 63) / 64 * 64;
+  const int PL = P->negative + 1 + (trows == 8 ? 1 : 2) + 1;
   const size_t per_wave = ((size_t)(4 * PR + 4 * PT + 16 * 17) +
-                           (size_t)((2 * walk_len + walk_len * P->negative + 64 + 3) & ~3)) * 4;
+                           (size_t)((2 * walk_len + walk_len * P->negative + walk_len * PL + 32 + 3) & ~3)) * 4;
   int64_t waves = P->n_vocab / 32;
   if (waves < 1) waves = 1;
   if (waves > n_walks) waves = n_walks;
@@ -543,7 +574,7 @@ extern "C" int n2v_sgns_batched_launch(const int32_t *walks, int64_t n_walks, in
     }                                                                                             \
     hipLaunchKernelGGL((sgns_batched_kernel<VV, TT, KK>), dim3((unsigned)blocks), dim3(wpb * 64), lds, \
                        st, walks, n_walks, walk_len, syn0, syn1neg, cum_table, sample_int,        \
-                       exp_table, *P, pairs_out, rrows);                                          \
+                       exp_table, *P, pairs_out);                                          \
   } while (0)
 #define N2V_BLAUNCH_T(VV)     \
   do {                        \

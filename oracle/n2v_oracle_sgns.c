@@ -165,7 +165,8 @@ int64_t n2v_oracle_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
  * its <= 2 * window (centre, context) pairs, and all pairs of a position are trained from one
  * snapshot of the rows (Ji et al., "Parallelizing Word2Vec in Shared and Distributed Memory",
  * 2016: the position becomes one small dense product).  Per position i with contexts J:
- *   context rows  = the distinct words of J in order of first appearance, multiplicity mu_c
+ *   context rows  = the distinct words of J (in the order of the kernel's LDS ring rows, which
+ *                   the code below simulates), multiplicity mu_c
  *   target rows   = centre (label 1), then the distinct negative words != centre in draw
  *                   order, multiplicity mu_t (a repeated draw counts twice)
  *   F[c][t]       = syn0[c] . syn1neg[t]
@@ -203,26 +204,53 @@ int64_t n2v_oracle_sgns_train_batched(const int32_t *walks, int64_t n_walks, int
       red[nf] = (uint32_t)(draw(hs, 2ULL * (uint64_t)t + 1ULL) >> 32) % (uint32_t)window;
       ++nf;
     }
+    /* The kernel keeps the syn0 rows of the window in an LDS ring of `rrows` physical rows (one
+     * per distinct word, shared by the positions that hold it, lowest free row first) and sums
+     * over the context rows in ascending PHYSICAL row order: the ring is simulated here so that
+     * the fmaf chains have the kernel's order.  Events: positions 0 .. window enter; then per
+     * centre i: position i + 1 + window enters (the kernel prefetches it), i is trained,
+     * position i - window leaves. */
+    if (nf < 2) continue;
+    const int rrows = (2 * window + 2 <= 12) ? 12 : 16;
+    int32_t row_word[16];
+    int row_ref[16], pos_row[256];
+    for (int k = 0; k < 16; ++k) row_ref[k] = 0;
+#define RING_ENTER(J)                                                        \
+  do {                                                                       \
+    int k_ = 0;                                                              \
+    while (k_ < 16 && !(row_ref[k_] > 0 && row_word[k_] == sent[(J)])) ++k_; \
+    if (k_ == 16) {                                                          \
+      k_ = 0;                                                                \
+      while (k_ < rrows && row_ref[k_] != 0) ++k_;                           \
+      row_word[k_] = sent[(J)];                                              \
+    }                                                                        \
+    ++row_ref[k_];                                                           \
+    pos_row[(J)] = k_;                                                       \
+  } while (0)
+    for (int j = 0; j <= window && j < nf; ++j) RING_ENTER(j);
     for (int i = 0; i < nf; ++i) {
       const int32_t centre = sent[i];
       int lo = i - window + (int)red[i];
       if (lo < 0) lo = 0;
       int hi = i + window + 1 - (int)red[i];
       if (hi > nf) hi = nf;
+      if (i + 1 < nf && i + 1 + window < nf) RING_ENTER(i + 1 + window);
       int32_t uword[16], tword[16];
       int umult[16], tmult[16], nu = 0, nt = 0, npairs = 0;
+      int cmr[16];
+      for (int k = 0; k < 16; ++k) cmr[k] = 0;
       for (int j = lo; j < hi; ++j) {
         if (j == i) continue;
         ++npairs;
-        int k = 0;
-        while (k < nu && uword[k] != sent[j]) ++k;
-        if (k < nu) {
-          ++umult[k];
-        } else {
-          uword[nu] = sent[j];
-          umult[nu++] = 1;
-        }
+        ++cmr[pos_row[j]];
       }
+      for (int k = 0; k < 16; ++k)
+        if (cmr[k] > 0) {
+          uword[nu] = row_word[k];
+          umult[nu++] = cmr[k];
+        }
+      if (i - window >= 0) --row_ref[pos_row[i - window]]; /* leaves after this position; its
+                                                              row is not reused before then */
       if (nu == 0) continue;
       tword[0] = centre;
       tmult[0] = 1;
@@ -284,6 +312,7 @@ int64_t n2v_oracle_sgns_train_batched(const int32_t *walks, int64_t n_walks, int
       }
       pairs += npairs;
     }
+#undef RING_ENTER
   }
   free(cold);
   free(told);

@@ -14,6 +14,8 @@ from node2vec_amd import randomwalk as rw  # noqa: E402
 from node2vec_amd import sgns, synthetic  # noqa: E402
 
 n_runs = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+BATCHED = len(sys.argv) > 2 and sys.argv[2] == "batched"
+WAVES = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 2048, 512, 64]
 g = synthetic.rmat(20, 5_000_000, device="cuda")
 start = rw.start_vertices(g)
 walks, valid = rw.walk(g, start, 10, 80, 0.5, 2.0, 42)
@@ -39,6 +41,7 @@ print(f"corpus: {idx.shape[0]} rows, vocabulary {len(vocab)}", flush=True)
 def run(seed, max_waves=0):
     m = sgns.SgnsModel(vocab, 128, 5, 5, seed=seed, sample=1e-3)
     m.max_waves = max_waves
+    m.batched = BATCHED
     t0 = time.perf_counter()
     m.train(idx, epochs=1, alpha=0.025, min_alpha=1e-4)
     torch.cuda.synchronize()
@@ -61,7 +64,8 @@ def overlap(a, b):
     return float(np.mean([len(set(x) & set(y)) / len(x) for x, y in zip(a, b)]))
 
 
-for waves in (0, 2048, 512, 64):
+print(f'batched={BATCHED}', flush=True)
+for waves in WAVES:
     aucs, first = [], None
     n = n_runs if waves == 0 else 5
     for seed in range(n):

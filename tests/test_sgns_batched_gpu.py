@@ -111,7 +111,11 @@ def test_batched_hogwild_pair_count_and_sanity(oracle):
     assert int(m.pairs.item()) == n  # the pairs trained do not depend on launch geometry
     got = m.syn0.cpu().numpy()
     assert np.isfinite(got).all() and np.isfinite(m.syn1neg.cpu().numpy()).all()
-    assert 0.5 < np.linalg.norm(got) / np.linalg.norm(s0) < 2.0
+    # 500 rows under ~15 racing waves: the values differ from the serial order, the scale does not
+    # (context rows go back as atomic deltas, so no wave's training of a syn0 row is lost)
+    ratio = float(np.linalg.norm(got) / np.linalg.norm(s0))
+    print("batched hogwild / serial norm of syn0:", ratio)
+    assert 0.5 < ratio < 2.0
 
 
 def _planted(nc=50, sz=40, seed=0):
