@@ -110,6 +110,10 @@ __device__ __forceinline__ void lds_get(float *tile, int plane_stride, int row, 
   for (int v = 0; v < VEC; ++v) r.v[v] = p[v];
 }
 
+__device__ __forceinline__ float f4_at(const float4 &v, int k) {
+  return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
+}
+
 __device__ __forceinline__ int b_bisect(const uint32_t *a, int lo, int hi, uint32_t x) {
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
     n2v_sgns_params P, unsigned long long *pairs_out) {
   constexpr int D = 64 * VEC, Q = 16 * VEC, RS = Q + 4, NCH = D / 16;
   constexpr int RROWS = KC == 3 ? 12 : 16;          // physical rows of the context ring
-  constexpr int PR = (RROWS * RS + 63) / 64 * 64;   // plane stride of the context ring
+  constexpr int PR = ((RROWS + 1) * RS + 63) / 64 * 64;  // plane stride of the ring (+ a spare row)
   constexpr int PT = (TROWS * RS + 63) / 64 * 64;   // plane stride of the target tile
   constexpr int KT = TROWS == 8 ? 2 : 4;            // k-steps over target rows
   constexpr int TM_WORDS = TROWS == 8 ? 1 : 2;      // packed multiplicities: 4 bits per target
@@ -162,6 +166,12 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
   int32_t *mphys = plan + walk_len * PL;  // [16] M index -> physical ring row
   int32_t *mmultM = mphys + 16;           // [16] multiplicity by M index (0: unused)
   for (int i = threadIdx.x; i < kBExpTable; i += blockDim.x) exp_lds[i] = exp_table_g[i];
+  {  // the spare ring row: all zero, for ever (it only ever receives 0 + 0 * x)
+    BRow<VEC> z;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) z.v[v] = 0.0f;
+    lds_put<VEC>(ring, PR, RROWS, lane, z);
+  }
   __syncthreads();
 
   const uint32_t domain = cum_table[P.n_vocab - 1];
@@ -387,14 +397,13 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
       const int cm = lane < 16 ? __popc((uint32_t)row_pos & jmask) : 0;
       const uint64_t used = ballot64(cm > 0);
       f32x4 newt[NCH];
-      float *st_dst[4];
+      int64_t st_off[4];
       bool st_ok[4];
       bool trained = false;
       if (used) {
         const int rank = __popcll(used & ((1ull << lane) - 1ull));
-        const int row0 = (int)__builtin_ctzll(used);
         if (lane < 16) {
-          mphys[lane] = row0;
+          mphys[lane] = RROWS;  // M indices without a context row read the all-zero spare row
           mmultM[lane] = 0;
         }
         wave_sync();
@@ -423,12 +432,12 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
         const int cmult = col_ok ? tm_of(plc, t_of_col) : 0;
         const float label = j16 == 0 ? 1.0f : 0.0f;
         float gv[4];
-        const float *rbase[4];  // ring row of M index 4 g4 + r, at column j16
+        int roff[4];  // this lane's NCH-float vector of the ring row of M index 4 g4 + r
 #pragma unroll
         for (int rI = 0; rI < 4; ++rI) {
           const int m = 4 * g4 + rI;
           const int mult = mmultM[m] * cmult;
-          rbase[rI] = ring + mphys[m] * RS + j16;
+          roff[rI] = (j16 >> 2) * PR + mphys[m] * RS + NCH * (j16 & 3);
           const float fv = f[rI];
           const bool live = mult > 0 && !(fv <= -6.0f || fv >= 6.0f);
           const int e = live ? (int)((fv + 6.0f) * 83.0f) : 0;
@@ -440,44 +449,78 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
         float ga[KT];  // A operand of Ctx += G . Tgt: G[m = l & 15][column 4 g + s]
 #pragma unroll
         for (int s = 0; s < KT; ++s) ga[s] = gs[j16 * 17 + 4 * g4 + s];
-        const float *tbase[4];  // target row of tile column 4 g4 + r (row 0 when there is none)
+        int toff[4];  // the same vector of the target row of tile column 4 g4 + r (row 0: none)
 #pragma unroll
         for (int rI = 0; rI < 4; ++rI) {
           st_ok[rI] = t_of_r[rI] >= 0 && t_of_r[rI] < nt_c;
-          tbase[rI] = tgt + (st_ok[rI] ? t_of_r[rI] : 0) * RS + j16;
+          toff[rI] = (j16 >> 2) * PT + (st_ok[rI] ? t_of_r[rI] : 0) * RS + NCH * (j16 & 3);
         }
-
+        // In the two updates tile column j of chunk c is element d = NCH * j + c: a lane's NCH
+        // columns are NCH consecutive floats of a row -- 16-byte LDS reads and writes, and the
+        // new target rows leave as whole 16-byte stores (a row = 16 lanes x NCH * 4 bytes).
         // ---- Tgt_new = Tgt_old + G^T . Ctx_old  (kept in registers until Ctx is done) ----
+        {
+          float4 cin[4][VEC], bx[KC][VEC];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          const int po = (c / VEC) * PT + (c % VEC) * 16, ro = (c / VEC) * PR + (c % VEC) * 16;
-          f32x4 acc;
+          for (int rI = 0; rI < 4; ++rI)
 #pragma unroll
-          for (int rI = 0; rI < 4; ++rI) acc[rI] = st_ok[rI] ? tbase[rI][po] : 0.0f;
+            for (int h = 0; h < VEC; ++h) {
+              const float4 v = *reinterpret_cast<const float4 *>(tgt + toff[rI] + 4 * h);
+              cin[rI][h] = st_ok[rI] ? v : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
 #pragma unroll
           for (int s = 0; s < KC; ++s)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[s], rbase[s][ro], acc, 0, 0, 0);
-          newt[c] = acc;
+#pragma unroll
+            for (int h = 0; h < VEC; ++h)
+              bx[s][h] = *reinterpret_cast<const float4 *>(ring + roff[s] + 4 * h);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            f32x4 acc;
+#pragma unroll
+            for (int rI = 0; rI < 4; ++rI) acc[rI] = f4_at(cin[rI][c >> 2], c & 3);
+#pragma unroll
+            for (int s = 0; s < KC; ++s)
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[s], f4_at(bx[s][c >> 2], c & 3), acc, 0, 0, 0);
+            newt[c] = acc;
+          }
         }
         wave_sync();
         // ---- Ctx += G . Tgt_old, in place in the ring ----
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          const int po = (c / VEC) * PT + (c % VEC) * 16, ro = (c / VEC) * PR + (c % VEC) * 16;
-          f32x4 acc;
-#pragma unroll
-          for (int rI = 0; rI < 4; ++rI) acc[rI] = rbase[rI][ro];
-#pragma unroll
-          for (int s = 0; s < KT; ++s)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], tbase[s][po], acc, 0, 0, 0);
+        {
+          float4 cin[4][VEC], bx[KT][VEC];
 #pragma unroll
           for (int rI = 0; rI < 4; ++rI)
-            if (mmultM[4 * g4 + rI] > 0) const_cast<float *>(rbase[rI])[ro] = acc[rI];
+#pragma unroll
+            for (int h = 0; h < VEC; ++h)
+              cin[rI][h] = *reinterpret_cast<const float4 *>(ring + roff[rI] + 4 * h);
+#pragma unroll
+          for (int s = 0; s < KT; ++s)
+#pragma unroll
+            for (int h = 0; h < VEC; ++h)
+              bx[s][h] = *reinterpret_cast<const float4 *>(tgt + toff[s] + 4 * h);
+          f32x4 out[NCH];
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            f32x4 acc;
+#pragma unroll
+            for (int rI = 0; rI < 4; ++rI) acc[rI] = f4_at(cin[rI][c >> 2], c & 3);
+#pragma unroll
+            for (int s = 0; s < KT; ++s)
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], f4_at(bx[s][c >> 2], c & 3), acc, 0, 0, 0);
+            out[c] = acc;
+          }
+          // rows without a context (the spare row) receive what they held + 0 * x: still zero
+#pragma unroll
+          for (int rI = 0; rI < 4; ++rI)
+#pragma unroll
+            for (int h = 0; h < VEC; ++h)
+              *reinterpret_cast<float4 *>(ring + roff[rI] + 4 * h) =
+                  make_float4(out[4 * h][rI], out[4 * h + 1][rI], out[4 * h + 2][rI], out[4 * h + 3][rI]);
         }
         // where the new target rows go (the tile is refilled below)
 #pragma unroll
         for (int rI = 0; rI < 4; ++rI)
-          st_dst[rI] = syn1neg + (int64_t)plc[st_ok[rI] ? t_of_r[rI] : 0] * D + j16;
+          st_off[rI] = (int64_t)plc[st_ok[rI] ? t_of_r[rI] : 0] * D + NCH * j16;
         trained = true;
         pairs += (unsigned long long)npairs;
         wave_sync();
@@ -503,7 +546,9 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
         for (int rI = 0; rI < 4; ++rI)
           if (st_ok[rI]) {
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) st_dst[rI][16 * c] = newt[c][rI];
+            for (int h = 0; h < VEC; ++h)
+              *reinterpret_cast<float4 *>(syn1neg + st_off[rI] + 4 * h) =
+                  make_float4(newt[4 * h][rI], newt[4 * h + 1][rI], newt[4 * h + 2][rI], newt[4 * h + 3][rI]);
           }
       }
       if (i - window >= 0) leave(i - window);
@@ -545,7 +590,7 @@ extern "C" int n2v_sgns_batched_launch(const int32_t *walks, int64_t n_walks, in
   const int rrows = kc == 3 ? 12 : 16;
   const int trows = 1 + P->negative <= 8 ? 8 : 16;
   const int RS = 16 * VEC + 4;
-  const int PR = (rrows * RS + 63) / 64 * 64, PT = (trows * RS + 63) / 64 * 64;
+  const int PR = ((rrows + 1) * RS + 63) / 64 * 64, PT = (trows * RS + 63) / 64 * 64;
   const int PL = P->negative + 1 + (trows == 8 ? 1 : 2) + 1;
   const size_t per_wave = ((size_t)(4 * PR + 4 * PT + 16 * 17) +
                            (size_t)((2 * walk_len + walk_len * P->negative + walk_len * PL + 32 + 3) & ~3)) * 4;
