@@ -110,6 +110,9 @@ __device__ __forceinline__ void lds_get(float *tile, int plane_stride, int row, 
   for (int v = 0; v < VEC; ++v) r.v[v] = p[v];
 }
 
+// smallest stride >= n floats that is 32 mod 64
+__host__ __device__ constexpr int bank_half_stride(int n) { return (n + 31) / 64 * 64 + 32; }
+
 __device__ __forceinline__ float f4_at(const float4 &v, int k) {
   return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
 }
@@ -135,8 +138,11 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
     n2v_sgns_params P, unsigned long long *pairs_out) {
   constexpr int D = 64 * VEC, Q = 16 * VEC, RS = Q + 4, NCH = D / 16;
   constexpr int RROWS = KC == 3 ? 12 : 16;          // physical rows of the context ring
-  constexpr int PR = ((RROWS + 1) * RS + 63) / 64 * 64;  // plane stride of the ring (+ a spare row)
-  constexpr int PT = (TROWS * RS + 63) / 64 * 64;   // plane stride of the target tile
+  // plane strides = 32 mod 64 floats: the four planes of a row then start on alternating bank
+  // halves, which both operand shapes want (16-byte reads of 4 rows x 4 column groups; 8-byte
+  // row vectors of two planes per half-wave)
+  constexpr int PR = bank_half_stride((RROWS + 1) * RS);  // the ring (+ a spare row)
+  constexpr int PT = bank_half_stride(TROWS * RS);      // the target tile
   constexpr int KT = TROWS == 8 ? 2 : 4;            // k-steps over target rows
   constexpr int TM_WORDS = TROWS == 8 ? 1 : 2;      // packed multiplicities: 4 bits per target
   const int window = P.window, K = P.negative;
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
   const int lane = threadIdx.x & 63;
   const int j16 = lane & 15, g4 = lane >> 4;
   constexpr int per_wave_floats = 4 * PR + 4 * PT + 16 * 17;
-  const int per_wave_ints = (2 * walk_len + walk_len * K + walk_len * PL + 32 + 3) & ~3;
+  const int per_wave_ints = (2 * walk_len + walk_len * PL + 32 + 3) & ~3;
   unsigned char *mine = smem + kBExpTable * sizeof(float) +
                         (size_t)wave_in_block * ((size_t)per_wave_floats + per_wave_ints) * 4;
   float *ring = reinterpret_cast<float *>(mine);
@@ -158,20 +164,15 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
   float *gs = tgt + 4 * PT;
   int32_t *sent = reinterpret_cast<int32_t *>(gs + 16 * 17);
   int32_t *red = sent + walk_len;
-  int32_t *negw = red + walk_len;
+  // the raw draws are only needed until the plan is built: they borrow the two row tiles
+  int32_t *negw = reinterpret_cast<int32_t *>(ring);
   // the plan of a sentence, per position i: [0 .. K] the target words (centre, then the distinct
   // negatives != centre in draw order), [K + 1 ..] their multiplicities (4 bits each), then one
   // word: bits 0..4 the number of targets, bits 8.. a mask of the targets position i - 1 writes
-  int32_t *plan = negw + walk_len * K;
+  int32_t *plan = red + walk_len;
   int32_t *mphys = plan + walk_len * PL;  // [16] M index -> physical ring row
   int32_t *mmultM = mphys + 16;           // [16] multiplicity by M index (0: unused)
   for (int i = threadIdx.x; i < kBExpTable; i += blockDim.x) exp_lds[i] = exp_table_g[i];
-  {  // the spare ring row: all zero, for ever (it only ever receives 0 + 0 * x)
-    BRow<VEC> z;
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) z.v[v] = 0.0f;
-    lds_put<VEC>(ring, PR, RROWS, lane, z);
-  }
   __syncthreads();
 
   const uint32_t domain = cum_table[P.n_vocab - 1];
@@ -280,6 +281,12 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
       pl[K + 1 + TM_WORDS] = nt | (late << 8);
     }
     wave_sync();
+    {  // the spare ring row: all zero (it only ever receives 0 + 0 * x); the draws lay here
+      BRow<VEC> z;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) z.v[v] = 0.0f;
+      lds_put<VEC>(ring, PR, RROWS, lane, z);
+    }
 
     // ---- the context ring: lane p < 16 is physical row p / position residue p ----
     int row_word = -1, row_ref = 0, row_pos = 0 /* residues held by this row */, pos_row = 0;
@@ -381,10 +388,17 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
         const int w = rfl(pln[K + 1 + TM_WORDS]);
         nt_n = w & 31;
         late = w >> 8;  // rows position i writes: read after its stores (stays in order)
+        // Straight-line: every slot of the tile is requested, slots without a target (and rows
+        // that must be re-read later anyway) name the centre row again -- the same cache lines.
+        // With a branch per row the compiler reuses the destination registers as address
+        // temporaries and guards each request with s_waitcnt vmcnt(0): the requests then go out
+        // one memory latency after the other instead of together.
+        int words[TROWS];
+#pragma unroll
+        for (int t = 0; t < TROWS; ++t) words[t] = pln[t <= K ? t : 0];
 #pragma unroll
         for (int t = 0; t < TROWS; ++t)
-          if (t < nt_n && !((late >> t) & 1))
-            g_load<VEC>(syn1neg + (int64_t)pln[t] * D, lane, nrow[t]);
+          g_load<VEC>(syn1neg + (int64_t)words[t] * D, lane, nrow[t]);
       }
 
       // ---- B. the position's context rows: the physical rows whose positions lie in the
@@ -528,6 +542,12 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
       // ---- C. what was requested for position i + 1 has arrived (asked for a whole position
       //         ago): it is consumed BEFORE this position's stores are issued, so that the wait
       //         for the loads never waits for a store ----
+      // every request of phase A is complete from here on, on EVERY path (hence outside the
+      // branch): otherwise the compiler must assume that a request it did not see consumed (a slot
+      // without a target, a row that is re-read below, the last position) is still in flight at
+      // the top of the loop, and guards the next position's requests with waits that serialise
+      // them
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), lgkmcnt / expcnt unconstrained
       if (have_next) {
         if (enter_row >= 0) {
           lds_put<VEC>(ring, PR, enter_row, lane, crow_in);
@@ -590,10 +610,11 @@ extern "C" int n2v_sgns_batched_launch(const int32_t *walks, int64_t n_walks, in
   const int rrows = kc == 3 ? 12 : 16;
   const int trows = 1 + P->negative <= 8 ? 8 : 16;
   const int RS = 16 * VEC + 4;
-  const int PR = ((rrows + 1) * RS + 63) / 64 * 64, PT = (trows * RS + 63) / 64 * 64;
+  const int PR = bank_half_stride((rrows + 1) * RS), PT = bank_half_stride(trows * RS);
+  if ((size_t)walk_len * P->negative > (size_t)4 * (PR + PT)) return N2V_EINVAL;  // the draws borrow the tiles
   const int PL = P->negative + 1 + (trows == 8 ? 1 : 2) + 1;
   const size_t per_wave = ((size_t)(4 * PR + 4 * PT + 16 * 17) +
-                           (size_t)((2 * walk_len + walk_len * P->negative + walk_len * PL + 32 + 3) & ~3)) * 4;
+                           (size_t)((2 * walk_len + walk_len * PL + 32 + 3) & ~3)) * 4;
   int64_t waves = P->n_vocab / 32;
   if (waves < 1) waves = 1;
   if (waves > n_walks) waves = n_walks;
