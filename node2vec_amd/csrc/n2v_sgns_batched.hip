@@ -433,15 +433,20 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
         const float4 *ap = reinterpret_cast<const float4 *>(ring + g4 * PR + mphys[j16] * RS);
         const float4 *bp =
             reinterpret_cast<const float4 *>(tgt + g4 * PT + (col_ok ? t_of_col : 0) * RS);
-        f32x4 f = {0.0f, 0.0f, 0.0f, 0.0f};
+        // four interleaved chains (k-steps s = a mod 4 go to chain a), summed pairwise at the
+        // end: consecutive MFMAs never wait for each other's 40-cycle accumulator latency
+        f32x4 f0 = {0.0f, 0.0f, 0.0f, 0.0f}, f1 = f0, f2 = f0, f3 = f0;
 #pragma unroll
         for (int q = 0; q < Q / 4; ++q) {
           const float4 a4 = ap[q], b4 = bp[q];
-          f = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, f, 0, 0, 0);
-          f = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, f, 0, 0, 0);
-          f = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, f, 0, 0, 0);
-          f = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, f, 0, 0, 0);
+          f0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, f0, 0, 0, 0);
+          f1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, f1, 0, 0, 0);
+          f2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, f2, 0, 0, 0);
+          f3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, f3, 0, 0, 0);
         }
+        f32x4 f;
+#pragma unroll
+        for (int rI = 0; rI < 4; ++rI) f[rI] = (f0[rI] + f1[rI]) + (f2[rI] + f3[rI]);
         // ---- G[m = 4 g + r][n = l & 15] ----
         const int cmult = col_ok ? tm_of(plc, t_of_col) : 0;
         const float label = j16 == 0 ? 1.0f : 0.0f;
@@ -488,15 +493,15 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
             for (int h = 0; h < VEC; ++h)
               bx[s][h] = *reinterpret_cast<const float4 *>(ring + roff[s] + 4 * h);
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) {
-            f32x4 acc;
+          for (int c = 0; c < NCH; ++c)
 #pragma unroll
-            for (int rI = 0; rI < 4; ++rI) acc[rI] = f4_at(cin[rI][c >> 2], c & 3);
+            for (int rI = 0; rI < 4; ++rI) newt[c][rI] = f4_at(cin[rI][c >> 2], c & 3);
 #pragma unroll
-            for (int s = 0; s < KC; ++s)
-              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[s], f4_at(bx[s][c >> 2], c & 3), acc, 0, 0, 0);
-            newt[c] = acc;
-          }
+          for (int s = 0; s < KC; ++s)  // k-step outer, chunk inner: independent accumulators
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+              newt[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[s], f4_at(bx[s][c >> 2], c & 3),
+                                                             newt[c], 0, 0, 0);
         }
         wave_sync();
         // ---- Ctx += G . Tgt_old, in place in the ring ----
@@ -514,15 +519,15 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
               bx[s][h] = *reinterpret_cast<const float4 *>(tgt + toff[s] + 4 * h);
           f32x4 out[NCH];
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) {
-            f32x4 acc;
+          for (int c = 0; c < NCH; ++c)
 #pragma unroll
-            for (int rI = 0; rI < 4; ++rI) acc[rI] = f4_at(cin[rI][c >> 2], c & 3);
+            for (int rI = 0; rI < 4; ++rI) out[c][rI] = f4_at(cin[rI][c >> 2], c & 3);
 #pragma unroll
-            for (int s = 0; s < KT; ++s)
-              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], f4_at(bx[s][c >> 2], c & 3), acc, 0, 0, 0);
-            out[c] = acc;
-          }
+          for (int s = 0; s < KT; ++s)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+              out[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], f4_at(bx[s][c >> 2], c & 3),
+                                                            out[c], 0, 0, 0);
           // rows without a context (the spare row) receive what they held + 0 * x: still zero
 #pragma unroll
           for (int rI = 0; rI < 4; ++rI)

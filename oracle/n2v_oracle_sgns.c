@@ -276,9 +276,11 @@ int64_t n2v_oracle_sgns_train_batched(const int32_t *walks, int64_t n_walks, int
       for (int u = 0; u < nu; ++u)
         for (int t = 0; t < nt; ++t) {
           const float *a = cold + (size_t)u * dim, *b = told + (size_t)t * dim;
-          float acc = 0.0f;
+          /* four interleaved chains (k-steps s = c mod 4 go to chain c), summed pairwise */
+          float ch[4] = {0.0f, 0.0f, 0.0f, 0.0f};
           for (int s = 0; s < Q; ++s)
-            for (int g = 0; g < 4; ++g) acc = fmaf(a[g * Q + s], b[g * Q + s], acc);
+            for (int g = 0; g < 4; ++g) ch[s & 3] = fmaf(a[g * Q + s], b[g * Q + s], ch[s & 3]);
+          float acc = (ch[0] + ch[1]) + (ch[2] + ch[3]);
           float gg = 0.0f;
           if (!(acc <= -6.0f || acc >= 6.0f)) {
             const float label = t == 0 ? 1.0f : 0.0f;
