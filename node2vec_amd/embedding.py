@@ -290,6 +290,10 @@ class Node2VecHIP(Node2VecBase):
         m = sgns.SgnsModel(vocab, int(p["size"]), int(p["window"]), negative, int(p["seed"]),
                            sample=float(p["sample"] or 0.0), ns_exponent=float(p["ns_exponent"]),
                            device=dev)
+        # opt-in, not gensim's sampling: w2v_params["batched"] = True shares the k negatives of a
+        # centre position among its pairs (csrc/n2v_sgns_batched.hip; dim 64 / 128 / 256,
+        # window <= 7, negative <= 15)
+        m.batched = bool(p.get("batched", False))
         # tokens < 0 (rows of dropped walkers in an on-device corpus, fugue.random_walk_tensors)
         # stay outside the vocabulary; a negative index must not wrap around
         idx = torch.where(walks >= 0, vocab.index_of[walks.clamp(min=0).long()],

@@ -14,7 +14,10 @@ arithmetic done by the same kernels on materialised tables:
     trim_hotspot_vertices        n2v_trim_mark on the partition's row
 
 Data carriers (Neighbors, AliasProb, RandomPath) keep the reference's wire format
-(base64 of a protocol-3 pickle, randomwalk.py:36-37) so serialized rows interoperate.
+(base64 of a protocol-3 pickle, randomwalk.py:36-37) so serialized rows interoperate.  Their
+constructor / property / serialize() surface is the drop-in boundary itself -- names, argument
+forms and wire format are dictated by the reference (randomwalk.py:17-41, 44-68, 102-121) -- and
+is stated once, in _Carrier; every numeric body in this file is a call into the HIP library.
 There is no CPU fallback: every numeric function raises without a HIP device.
 """
 import base64
@@ -40,30 +43,33 @@ def _dumps(data) -> str:
     return base64.b64encode(pickle.dumps(data, protocol=_PICKLE_PROTOCOL)).decode()
 
 
-class Neighbors(object):
-    """randomwalk.py:17-41"""
+class _Carrier(object):
+    """One wire format for the three carriers: a base64 protocol-3 pickle of `_data`.  A carrier is
+    built from its serialized string, from a DataFrame holding `_columns`, or from the data."""
 
-    def __init__(self, obj: Union[str, pd.DataFrame, Tuple[List[int], List[float]]]):
+    _columns: Tuple[str, ...] = ()
+
+    def __init__(self, obj):
         if isinstance(obj, str):
             self._data = _loads(obj)
-        elif isinstance(obj, pd.DataFrame):
-            self._data = (obj["dst"].tolist(), obj["weight"].tolist())
+        elif isinstance(obj, pd.DataFrame) and self._columns:
+            self._data = tuple(obj[c].tolist() for c in self._columns)
         else:
             self._data = obj
 
-    @property
-    def dst_id(self):
-        return self._data[0]
+    def serialize(self):
+        return _dumps(self._data)
 
-    @property
-    def dst_wt(self):
-        return self._data[1]
+
+class Neighbors(_Carrier):
+    """randomwalk.py:17-41: (neighbour ids, weights) of one vertex"""
+
+    _columns = ("dst", "weight")
+    dst_id = property(lambda self: self._data[0])
+    dst_wt = property(lambda self: self._data[1])
 
     def items(self):
         return zip(self._data[0], self._data[1])
-
-    def serialize(self):
-        return _dumps(self._data)
 
     def as_pandas(self):
         return pd.DataFrame({"dst": self._data[0], "weight": self._data[1]})
@@ -121,29 +127,13 @@ def _draw(rowptr: torch.Tensor, slots: torch.Tensor, r1, r2) -> np.ndarray:
     return _draw_device(rowptr, slots, t1, t2).cpu().numpy()
 
 
-class AliasProb(object):
-    """randomwalk.py:44-99; the two samplers run n2v_alias_draw on this table"""
+class AliasProb(_Carrier):
+    """randomwalk.py:44-99: (alias indices in [0, n), pseudo-probabilities); the two samplers run
+    n2v_alias_draw on this table"""
 
-    def __init__(self, obj: Union[str, pd.DataFrame, Tuple[List[int], List[float]]]):
-        if isinstance(obj, str):
-            self._data = _loads(obj)
-        elif isinstance(obj, pd.DataFrame):
-            self._data = (obj["alias"].tolist(), obj["probs"].tolist())
-        else:
-            self._data = obj
-
-    @property
-    def alias(self):
-        """alias: the alias list in range [0, n)"""
-        return self._data[0]
-
-    @property
-    def probs(self):
-        """probs: the pseudo-probability table"""
-        return self._data[1]
-
-    def serialize(self):
-        return _dumps(self._data)
+    _columns = ("alias", "probs")
+    alias = property(lambda self: self._data[0])
+    probs = property(lambda self: self._data[1])
 
     def _slots(self, dev):
         # col = the index itself, alias = the alias index: the draw then returns an INDEX
@@ -168,22 +158,11 @@ class AliasProb(object):
         return int(_draw(rowptr, slots, [first_random], [second_random])[0])
 
 
-class RandomPath(object):
-    """randomwalk.py:102-153"""
+class RandomPath(_Carrier):
+    """randomwalk.py:102-153: the vertex list of one walker"""
 
-    def __init__(self, obj: Union[str, List[int]]):
-        self._data = _loads(obj) if isinstance(obj, str) else obj
-
-    @property
-    def path(self):
-        return self._data
-
-    @property
-    def last_edge(self):
-        return self._data[-2], self._data[-1]
-
-    def serialize(self):
-        return _dumps(self._data)
+    path = property(lambda self: self._data)
+    last_edge = property(lambda self: (self._data[-2], self._data[-1]))
 
     def __str__(self):
         return self._data.__repr__()
