@@ -288,6 +288,11 @@ typedef struct n2v_sgns_params {
                         1 (opt-in, NOT gensim's sampling): the k negatives are drawn once per
                         centre position and shared by its <= 2 * window pairs, which turns a
                         position into one small dense product (see n2v_sgns_train) */
+  int32_t window_cache; /* the default kernel keeps the syn0 rows of the window in LDS (read and
+                           written once per position instead of once per pair; same values, bit
+                           for bit in deterministic mode): 0 = when it fits (dim 64 / 128,
+                           window <= 7), 1 = required (else N2V_EINVAL), -1 = off */
+  int32_t reserved0;    /* 0 */
 } n2v_sgns_params;
 
 #define N2V_SGNS_MAX_SENTENCE 256 /* longer walks: split rows on the host */

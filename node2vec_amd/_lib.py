@@ -40,7 +40,8 @@ class SgnsParams(C.Structure):
     _fields_ = [("n_vocab", C.c_int64), ("sentence_base", C.c_int64), ("seed", C.c_uint64),
                 ("dim", C.c_int32), ("window", C.c_int32), ("negative", C.c_int32),
                 ("alpha", C.c_float), ("deterministic", C.c_int32), ("cum_index_bits", C.c_int32),
-                ("cum_index", C.c_void_p), ("max_waves", C.c_int32), ("batched", C.c_int32)]
+                ("cum_index", C.c_void_p), ("max_waves", C.c_int32), ("batched", C.c_int32),
+                ("window_cache", C.c_int32), ("reserved0", C.c_int32)]
 
 
 _lib = None

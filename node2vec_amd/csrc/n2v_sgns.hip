@@ -21,7 +21,6 @@ namespace n2v {
 
 constexpr int kSgnsWaves = 4;      // waves per block
 constexpr int kExpTable = 1000;    // EXP_TABLE_SIZE
-constexpr int kMaxSent = N2V_SGNS_MAX_SENTENCE;
 constexpr int kBuckets = 1024;     // coarse index of cum_table: bucket b covers values [b<<21, (b+1)<<21)
 
 __host__ __device__ inline uint64_t sentence_stream(uint64_t seed, uint64_t sentence_id) {
@@ -131,31 +130,50 @@ __device__ __forceinline__ int bisect_left_u32(const uint32_t *a, int64_t n, uin
   return (int)lo;
 }
 
-template <int VEC, int kDepth>  // kDepth: pairs requested ahead of the one being trained
+// kDepth: pairs requested ahead of the one being trained.
+// kRing (round 3): the syn0 rows of the window live in an LDS ring -- one physical row per
+// distinct word of the <= 2 * window + 1 positions around the centre, shared by positions that
+// hold the same word, reference-counted.  A context row is then read from HBM once when its
+// position enters the window and written once when its last position leaves, instead of once per
+// pair (~6 pairs per position): 8 * dim * (2 + k) bytes per pair become 8 * dim * (1 + k + ~1/6).
+// Values are those of training pair by pair against memory (one wave, deterministic mode: bit for
+// bit the oracle); in hogwild mode a row goes back as an atomic add of what THIS wave learned, so
+// that holding it for a window's worth of positions loses no other wave's training.
+template <int VEC, int kDepth, int kRingRows>  // kRingRows: 0 (no ring), 12 or 16
 // dim <= 128 needs 56 VGPRs: hold the full 8 waves per SIMD (the kernel is latency-bound).
-// Forcing 6 waves at dim 256 was measured: it spills and is slower.
-__global__ __launch_bounds__(kSgnsWaves * 64, (VEC <= 2 ? 8 : 1)) void sgns_kernel(
+// Forcing 6 waves at dim 256 was measured: it spills and is slower.  The ring variant is bounded
+// by LDS (5 waves per SIMD at dim 128) and keeps the rows' loaded values in registers.
+__global__ __launch_bounds__(kSgnsWaves * 64, (kRingRows ? (VEC <= 2 ? 4 : 1) : (VEC <= 2 ? 8 : 1))) void sgns_kernel(
     const int32_t *__restrict__ walks, int64_t n_walks, int32_t walk_len, float *syn0,
     float *syn1neg, const uint32_t *__restrict__ cum_table,
     const uint32_t *__restrict__ sample_int, const float *__restrict__ exp_table_g,
-    n2v_sgns_params P, unsigned long long *pairs_out) {
+    n2v_sgns_params P, unsigned long long *pairs_out, int32_t sent_cap) {
+  constexpr bool kRing = kRingRows > 0;
+  constexpr int ring_rows = kRingRows;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *exp_lds = reinterpret_cast<float *>(smem);
   int32_t *bucket = reinterpret_cast<int32_t *>(smem + kExpTable * sizeof(float));
   const int negcap = (2 * P.window + 1) * P.negative;  // the window incl. the centre slot
-  const int per_wave = 2 * kMaxSent + negcap;  // int32 words
+  // per wave: sent[sent_cap], red[sent_cap], neg[negcap] (+ pad), then the ring rows
+  const int ints_per_wave = (2 * sent_cap + negcap + 3) & ~3;
+  const int per_wave = ints_per_wave + (kRing ? ring_rows * 64 * VEC : 0);  // 4-byte words
   const int wave_in_block = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
-  int32_t *sent = reinterpret_cast<int32_t *>(smem + kExpTable * sizeof(float)) +
-                  (kBuckets + 1) + wave_in_block * per_wave;
-  int32_t *red = sent + kMaxSent;
-  int32_t *neg = red + kMaxSent;
+  // the 1024-bucket index of cum_table is only needed (and only allocated) without the
+  // caller's fine index
+  const int bucket_words = P.cum_index ? 0 : (kBuckets + 1 + 3);  // + 3: 16-byte alignment
+  int32_t *sent = reinterpret_cast<int32_t *>(smem + kExpTable * sizeof(float)) + bucket_words +
+                  wave_in_block * per_wave;
+  int32_t *red = sent + sent_cap;
+  int32_t *neg = red + sent_cap;
+  float *ring = reinterpret_cast<float *>(sent + ints_per_wave);  // [ring_rows][64 * VEC]
   for (int i = threadIdx.x; i < kExpTable; i += blockDim.x) exp_lds[i] = exp_table_g[i];
   const int bis_iters = 64 - __clzll((long long)P.n_vocab);
   // bucket[b] = bisect_left(cum_table, b << 21): a draw r lies in bucket r >> 21 and its
   // bisect_left is confined to [bucket[b], bucket[b+1]] -- same index, half the probes
-  for (int b = threadIdx.x; b <= kBuckets; b += blockDim.x)
-    bucket[b] = bisect_left_u32(cum_table, P.n_vocab, (uint32_t)b << 21, bis_iters);
+  if (!P.cum_index)
+    for (int b = threadIdx.x; b <= kBuckets; b += blockDim.x)
+      bucket[b] = bisect_left_u32(cum_table, P.n_vocab, (uint32_t)b << 21, bis_iters);
   __syncthreads();
 
   const int dim = P.dim, window = P.window, K = P.negative;
@@ -204,7 +222,92 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (VEC <= 2 ? 8 : 1)) void sgns_kern
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
+    // ---- the context ring (kRing): lane p < 16 is physical row p / position residue p.  A row
+    // is lane-owned in LDS too (lane l keeps elements l * VEC ..), so ring traffic needs no
+    // cross-lane ordering: every lane reads back what it wrote itself.
+    constexpr int kRingMax = kRing ? kRingRows : 1;
+    int row_word = -1, row_ref = 0, pos_row = 0;
+    Row<VEC> loaded[kRingMax];
+    auto ring_row = [&](int row) { return ring + row * (64 * VEC) + lane * VEC; };
+    auto ring_get = [&](int row, Row<VEC> &r) {
+      const float *q = ring_row(row);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) r.v[v] = q[v];
+    };
+    auto ring_put = [&](int row, const Row<VEC> &r) {
+      float *q = ring_row(row);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) q[v] = r.v[v];
+    };
+    auto ring_enter = [&](int j, int word, bool &fresh) -> int {
+      const uint64_t hit = ballot64(lane < 16 && row_ref > 0 && row_word == word);
+      int row;
+      if (hit) {
+        row = __builtin_ctzll(hit);
+        fresh = false;
+      } else {
+        row = __builtin_ctzll(ballot64(lane < ring_rows && row_ref == 0));  // 2 w + 2 <= ring_rows
+        fresh = true;
+      }
+      if (lane == row) {
+        row_word = word;
+        ++row_ref;
+      }
+      if (lane == (j & 15)) pos_row = row;
+      return row;
+    };
+    auto ring_loaded = [&](int row, const Row<VEC> &r) {
+#pragma unroll
+      for (int q = 0; q < kRingMax; ++q)
+        if (row == q) loaded[q] = r;
+    };
+    auto ring_leave = [&](int j) {
+      const int row = __builtin_amdgcn_readlane(pos_row, j & 15);
+      if (lane == row) --row_ref;
+      if (__builtin_amdgcn_readlane(row_ref, row) == 0) {
+        Row<VEC> t;
+        ring_get(row, t);
+        float *dst = syn0 + (int64_t)__builtin_amdgcn_readlane(row_word, row) * dim;
+        if (P.deterministic) {
+          store_row<VEC>(dst, dim, lane, full, t);
+        } else {
+#pragma unroll
+          for (int q = 0; q < kRingMax; ++q)
+            if (row == q) {
+#pragma unroll
+              for (int v = 0; v < VEC; ++v)
+                unsafeAtomicAdd(dst + lane * VEC + v, t.v[v] - loaded[q].v[v]);
+            }
+        }
+      }
+    };
+    if (kRing) {
+      for (int j = 0; j <= window && j < nf; ++j) {
+        bool fresh;
+        const int word = sent[j];
+        const int row = ring_enter(j, word, fresh);
+        if (fresh) {
+          Row<VEC> t;
+          load_row<VEC>(syn0 + (int64_t)word * dim, dim, lane, full, t);
+          ring_put(row, t);
+          ring_loaded(row, t);
+        }
+      }
+    }
+
     for (int i = 0; i < nf; ++i) {
+      // the row of position i + 1 + window is requested now and lands after this position's pairs
+      Row<VEC> ring_in;
+      int ring_in_row = -1;
+      if (kRing && i + 1 + window < nf) {
+        bool fresh;
+        const int word = sent[i + 1 + window];
+        const int row = ring_enter(i + 1 + window, word, fresh);
+        if (fresh) {
+          ring_in_row = row;
+          load_row<VEC>(syn0 + (int64_t)word * dim, dim, lane, full, ring_in);
+        }
+      }
       // LDS loads at a uniform address are lane-varying to the compiler: mark them scalar
       const int32_t centre = __builtin_amdgcn_readfirstlane(sent[i]);
       const int b = __builtin_amdgcn_readfirstlane(red[i]);
@@ -258,6 +361,7 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (VEC <= 2 ? 8 : 1)) void sgns_kern
         Row<VEC> rows[KP];
         int32_t tg[KP];
         int j;
+        int rowi;          // kRing: the ring row of the context word
         bool late_row1;    // the pair trained just before writes this row: load it afterwards
         bool late[KP];
       };
@@ -296,7 +400,13 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (VEC <= 2 ? 8 : 1)) void sgns_kern
         const int32_t cj = __builtin_amdgcn_readfirstlane(sent[j]);
         B.late_row1 = (jprev >= 0 && cj == __builtin_amdgcn_readfirstlane(sent[jprev])) ||
                       (jprev2 >= 0 && cj == __builtin_amdgcn_readfirstlane(sent[jprev2]));
-        if (!B.late_row1) load_row<VEC>(syn0 + (int64_t)cj * dim, dim, lane, full, B.row1);
+        B.rowi = 0;
+        if (kRing) {
+          B.rowi = __builtin_amdgcn_readlane(pos_row, j & 15);
+          if (!B.late_row1) ring_get(B.rowi, B.row1);
+        } else if (!B.late_row1) {
+          load_row<VEC>(syn0 + (int64_t)cj * dim, dim, lane, full, B.row1);
+        }
         if (kAhead) issue_negs(j, jprev, jprev2, B);  // strict order: after the centre word
       };
       // one negative target: f, sigma, the two FMAs, store (word2vec's inner body, label 0)
@@ -314,7 +424,12 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (VEC <= 2 ? 8 : 1)) void sgns_kern
       auto process = [&](PairBuf &A) {
         const int j = A.j;
         float *p1 = syn0 + (int64_t)__builtin_amdgcn_readfirstlane(sent[j]) * dim;
-        if (A.late_row1) load_row<VEC>(p1, dim, lane, full, A.row1);
+        if (A.late_row1) {
+          if (kRing)
+            ring_get(A.rowi, A.row1);
+          else
+            load_row<VEC>(p1, dim, lane, full, A.row1);
+        }
         Row<VEC> work;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) work.v[v] = 0.0f;
@@ -362,7 +477,10 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (VEC <= 2 ? 8 : 1)) void sgns_kern
         }
 #pragma unroll
         for (int v = 0; v < VEC; ++v) A.row1.v[v] = A.row1.v[v] + work.v[v];
-        store_row<VEC>(p1, dim, lane, full, A.row1);
+        if (kRing)
+          ring_put(A.rowi, A.row1);
+        else
+          store_row<VEC>(p1, dim, lane, full, A.row1);
         ++pairs;
       };
       int j = lo + (lo == i ? 1 : 0);
@@ -408,8 +526,17 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (VEC <= 2 ? 8 : 1)) void sgns_kern
         }
       }
       store_row<VEC>(pc, dim, lane, full, crow);
+      if (kRing) {
+        if (ring_in_row >= 0) {
+          ring_put(ring_in_row, ring_in);
+          ring_loaded(ring_in_row, ring_in);
+        }
+        if (i - window >= 0) ring_leave(i - window);
+      }
       __builtin_amdgcn_wave_barrier();
     }
+    if (kRing)
+      for (int j = max(0, nf - window); j < nf; ++j) ring_leave(j);
   }
   if (pairs_out && lane == 0 && pairs) atomicAdd(pairs_out, pairs);
 }
@@ -468,8 +595,19 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   if (P->batched) return n2v_sgns_batched_launch(walks, n_walks, walk_len, syn0, syn1neg, cum_table,
                                                  sample_int, exp_table, P, pairs_out, stream);
   using namespace n2v;
-  const size_t lds = kExpTable * sizeof(float) + (kBuckets + 1) * sizeof(int32_t) +
-                     (size_t)kSgnsWaves * (2 * kMaxSent + (2 * P->window + 1) * P->negative) * 4;
+  int V = 1;
+  while (64 * V < P->dim) V *= 2;
+  // the window cache (kRing): rows of 64 * V floats, 2 * window + 2 of them (12 or 16), when the
+  // dimension fills the wave exactly and the ring fits beside the other per-wave buffers
+  const int ring_rows = 2 * P->window + 2 <= 12 ? 12 : 16;
+  const bool ring_fits = P->dim == 64 * V && V <= 2 && 2 * P->window + 2 <= 16;
+  if (P->window_cache != 0 && P->window_cache != 1 && P->window_cache != -1) return N2V_EINVAL;
+  if (P->window_cache == 1 && !ring_fits) return N2V_EINVAL;
+  const bool use_ring = ring_fits && P->window_cache != -1;
+  const int sent_cap = (walk_len + 3) & ~3;
+  const int ints_per_wave = (2 * sent_cap + (2 * P->window + 1) * P->negative + 3) & ~3;
+  const size_t lds = kExpTable * sizeof(float) + (P->cum_index ? 0 : (kBuckets + 1 + 3) * sizeof(int32_t)) +
+                     (size_t)kSgnsWaves * ((size_t)ints_per_wave + (use_ring ? (size_t)ring_rows * 64 * V : 0)) * 4;
   // Hogwild concurrency is scaled to the model: unsynchronised waves are harmless
   // while collisions on a row are rare (gensim runs <= 16 threads); on a tiny
   // vocabulary thousands of racing waves would overwrite each other's updates.
@@ -489,8 +627,6 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
     blocks = 1;
     block = dim3(64);
   }
-  int V = 1;
-  while (64 * V < P->dim) V *= 2;
   hipStream_t st = (hipStream_t)stream;
   // pairs_out[1] is the kernel's row counter: start it at zero on the same stream
   if (pairs_out && hipMemsetAsync(pairs_out + 1, 0, sizeof(unsigned long long), st) != hipSuccess)
@@ -500,25 +636,39 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
 #ifndef N2V_SGNS_DEPTH
 #define N2V_SGNS_DEPTH(VV) ((VV) <= 8 ? 1 : 0)
 #endif
-#define N2V_LAUNCH(VV)                                                                       \
+#define N2V_LAUNCH_R(VV, RR)                                                                  \
   do {                                                                                       \
     constexpr int kD = N2V_SGNS_DEPTH(VV);                                                    \
+    const void *fn = (const void *)sgns_kernel<VV, kD, RR>;                                   \
+    if (lds > 64 * 1024 &&                                                                   \
+        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+      return N2V_ELAUNCH;                                                                    \
     if (!P->deterministic) {                                                                 \
-      const int64_t cap = resident_blocks((const void *)sgns_kernel<VV, kD>, (int)block.x, lds); \
+      const int64_t cap = resident_blocks(fn, (int)block.x, lds);                            \
       if (blocks > cap) blocks = cap;                                                        \
     }                                                                                        \
-    hipLaunchKernelGGL((sgns_kernel<VV, kD>), dim3((unsigned)blocks), block, lds, st, walks,  \
-                       n_walks, walk_len, syn0, syn1neg, cum_table, sample_int, exp_table,    \
-                       *P, pairs_out);                                                        \
+    hipLaunchKernelGGL((sgns_kernel<VV, kD, RR>), dim3((unsigned)blocks), block, lds, st,     \
+                       walks, n_walks, walk_len, syn0, syn1neg, cum_table, sample_int,        \
+                       exp_table, *P, pairs_out, sent_cap);                                   \
+  } while (0)
+#define N2V_LAUNCH_RING(VV)         \
+  do {                              \
+    if (!use_ring)                  \
+      N2V_LAUNCH_R(VV, 0);          \
+    else if (ring_rows == 12)       \
+      N2V_LAUNCH_R(VV, 12);         \
+    else                            \
+      N2V_LAUNCH_R(VV, 16);         \
   } while (0)
   switch (V) {
-    case 1: N2V_LAUNCH(1); break;
-    case 2: N2V_LAUNCH(2); break;
-    case 4: N2V_LAUNCH(4); break;
-    case 8: N2V_LAUNCH(8); break;
-    default: N2V_LAUNCH(16); break;
+    case 1: N2V_LAUNCH_RING(1); break;
+    case 2: N2V_LAUNCH_RING(2); break;
+    case 4: N2V_LAUNCH_R(4, 0); break;
+    case 8: N2V_LAUNCH_R(8, 0); break;
+    default: N2V_LAUNCH_R(16, 0); break;
   }
-#undef N2V_LAUNCH
+#undef N2V_LAUNCH_RING
+#undef N2V_LAUNCH_R
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
 }

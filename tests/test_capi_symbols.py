@@ -52,10 +52,11 @@ def test_ctypes_structs_match_header_layout():
     body = text[text.index("typedef struct n2v_graph {"):text.index("} n2v_graph;")]
     fields = re.findall(r"\*?\s*\b(\w+);", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
     assert fields == [f[0] for f in _lib.Graph._fields_]
-    assert ctypes.sizeof(_lib.SgnsParams) == 3 * 8 + 6 * 4 + 8 + 2 * 4
+    assert ctypes.sizeof(_lib.SgnsParams) == 3 * 8 + 6 * 4 + 8 + 4 * 4
     assert [f[0] for f in _lib.SgnsParams._fields_] == [
         "n_vocab", "sentence_base", "seed", "dim", "window", "negative", "alpha",
-        "deterministic", "cum_index_bits", "cum_index", "max_waves", "batched"]
+        "deterministic", "cum_index_bits", "cum_index", "max_waves", "batched", "window_cache",
+        "reserved0"]
     body = text[text.index("typedef struct n2v_sgns_params {"):text.index("} n2v_sgns_params;")]
     fields = re.findall(r"\*?\s*\b(\w+);", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
     assert fields == [f[0] for f in _lib.SgnsParams._fields_]

@@ -10,6 +10,32 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("weighted", [False, True])
+def test_partitioned_equals_the_oracle_bit_for_bit(oracle, weighted):
+    """the HIP step function on every part, walkers migrating, against the ORACLE's walk over the
+    whole graph (not only against n2v_walk): 3 parts, sinks, three (p, q)"""
+    from node2vec_amd import partitioned as P
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+
+    rng = np.random.default_rng(5)
+    nv, ne = 3000, 30_000
+    src = np.concatenate([rng.integers(0, nv - 100, ne), rng.integers(0, 6, 3000)])
+    dst = np.concatenate([rng.integers(0, nv, ne), rng.integers(0, nv, 3000)])
+    w = (rng.random(len(src)) * 1.7 + 0.3) if weighted else None
+    g = DeviceGraph.from_edges(src, dst, w, n_vertices=nv, device="cuda")
+    parts = P.partition_graph(g, 3)
+    start = rw.start_vertices(g)[::3].contiguous()
+    for p, q in ((1.0, 1.0), (0.5, 2.0), (4.0, 0.25)):
+        want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(),
+                                      None if g.unit_weights else g.w.cpu().numpy(),
+                                      start.cpu().numpy(), 2, 12, p, q, 9)
+        walks, valid = P.walk_partitioned_local(parts, start, 2, 12, p, q, 9)
+        got, gv = walks.cpu().numpy(), valid.cpu().numpy().astype(bool)
+        assert np.array_equal(gv, wv) and not wv.all()
+        assert np.array_equal(got[gv], want[wv])
+
+
+@pytest.mark.parametrize("weighted", [False, True])
 def test_partitioned_equals_n2v_walk_bit_for_bit(weighted):
     from node2vec_amd import partitioned as P
     from node2vec_amd import randomwalk as rw
@@ -42,5 +68,12 @@ def test_partitioned_cfg2_sample_equals_n2v_walk():
     parts = P.partition_graph(g, 8)
     start = rw.start_vertices(g)[::400].contiguous()
     want, wv = rw.walk(g, start, 2, 80, 0.5, 2.0, 42)
+    import time
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     walks, valid = P.walk_partitioned_local(parts, start, 2, 80, 0.5, 2.0, 42)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"partitioned walking, 8 parts in one process: {int(valid.sum()) * 80 / dt / 1e6:.2f} M steps/s")
     assert bool(valid.all()) and torch.equal(valid, wv) and torch.equal(walks, want)

@@ -208,3 +208,55 @@ def test_cum_index_is_bisect_left_and_changes_no_draw(oracle):
                           64, 5, 5, 0.025)
     assert n == int(a.pairs.item()) == int(b.pairs.item())
     assert np.array_equal(a.syn0.cpu().numpy(), s0) and np.array_equal(a.syn1neg.cpu().numpy(), s1)
+
+
+@pytest.mark.parametrize("dim,window", [(64, 5), (128, 5), (128, 7), (128, 2)])
+def test_window_cache_changes_no_bit(oracle, dim, window):
+    """the default kernel with the syn0 rows of the window kept in an LDS ring (window_cache = 1:
+    one read and one write per position instead of per pair) against the same kernel without it
+    (-1) and against the oracle, on walk-like rows where the window holds the same word at
+    several positions (shared ring rows): identical bits in deterministic mode"""
+    from node2vec_amd import sgns
+
+    gen = torch.Generator().manual_seed(dim + window)
+    steps = torch.randint(-2, 3, (48, 33), generator=gen)
+    walks = (torch.cumsum(steps, 1) + torch.randint(0, 70, (48, 1), generator=gen)) % 70
+    back = torch.rand((48, 33), generator=gen) < 0.3
+    walks[:, 2:] = torch.where(back[:, 2:], walks[:, :-2], walks[:, 2:])
+    walks = walks.to(torch.int32).cuda()
+    walks[5, 1:] = -1  # a one-token sentence
+    walks[6, :] = -1   # an empty one
+    vocab = sgns.build_vocab(walks, 1)
+    idx = torch.where(walks >= 0, vocab.index_of[walks.clamp(min=0).long()], torch.full_like(walks, -1))
+    out = {}
+    for mode in (1, -1):
+        m = sgns.SgnsModel(vocab, dim, window, 5, seed=3, sample=1e-2)
+        m.window_cache = mode
+        s0, s1 = m.syn0.cpu().numpy().copy(), m.syn1neg.cpu().numpy().copy()
+        for blk, alpha in ((0, 0.025), (1, 0.02)):
+            m.train_block(idx, alpha, blk * idx.shape[0], deterministic=True)
+        torch.cuda.synchronize()
+        out[mode] = (m.syn0.cpu().numpy(), m.syn1neg.cpu().numpy(), int(m.pairs.item()))
+    n = 0
+    for blk, alpha in ((0, 0.025), (1, 0.02)):
+        n += oracle.sgns_train(idx.cpu().numpy(), s0, s1, m.cum_table.cpu().numpy(),
+                               m.sample_int.cpu().numpy(), sgns.exp_table(), len(vocab),
+                               blk * idx.shape[0], m.seed, dim, window, 5, alpha)
+    assert out[1][2] == out[-1][2] == n
+    assert np.array_equal(out[1][0], out[-1][0]) and np.array_equal(out[1][1], out[-1][1])
+    assert np.array_equal(out[1][0], s0) and np.array_equal(out[1][1], s1)
+
+
+def test_window_cache_is_refused_where_it_does_not_fit():
+    from node2vec_amd import sgns
+
+    walks = torch.randint(0, 30, (8, 12), dtype=torch.int32).cuda()
+    vocab = sgns.build_vocab(walks, 1)
+    for dim, window in ((100, 5), (256, 5), (128, 8)):
+        m = sgns.SgnsModel(vocab, dim, window, 5, seed=1)
+        m.window_cache = 1
+        with pytest.raises(ValueError):
+            m.train_block(vocab.index_of[walks.long()], 0.025, 0)
+        m.window_cache = 0  # auto: falls back to the plain kernel
+        m.train_block(vocab.index_of[walks.long()], 0.025, 0)
+    torch.cuda.synchronize()
