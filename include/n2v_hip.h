@@ -288,11 +288,16 @@ typedef struct n2v_sgns_params {
                         1 (opt-in, NOT gensim's sampling): the k negatives are drawn once per
                         centre position and shared by its <= 2 * window pairs, which turns a
                         position into one small dense product (see n2v_sgns_train) */
-  int32_t window_cache; /* the default kernel keeps the syn0 rows of the window in LDS (read and
+  int32_t window_cache; /* 1: the default kernel keeps the syn0 rows of the window in LDS (read and
                            written once per position instead of once per pair; same values, bit
-                           for bit in deterministic mode): 0 = when it fits (dim 64 / 128,
-                           window <= 7), 1 = required (else N2V_EINVAL), -1 = off */
-  int32_t reserved0;    /* 0 */
+                           for bit in deterministic mode; dim 64 / 128 and window <= 7, else
+                           N2V_EINVAL).  Measured slower than 0 on MI355X (the ring costs 3 of 8
+                           waves per SIMD and the kernel is bound by rows in flight): off by default */
+  int32_t hub_rows;     /* hogwild mode only: rows [0, hub_rows) of syn0 / syn1neg (the most frequent
+                           words: the vocabulary is in descending count order) are updated by
+                           atomic adds of each wave's contribution instead of read-modify-write
+                           stores, so that concurrent waves do not overwrite each other on hubs.
+                           0 = off (gensim's unsynchronised updates everywhere) */
 } n2v_sgns_params;
 
 #define N2V_SGNS_MAX_SENTENCE 256 /* longer walks: split rows on the host */

@@ -41,7 +41,7 @@ class SgnsParams(C.Structure):
                 ("dim", C.c_int32), ("window", C.c_int32), ("negative", C.c_int32),
                 ("alpha", C.c_float), ("deterministic", C.c_int32), ("cum_index_bits", C.c_int32),
                 ("cum_index", C.c_void_p), ("max_waves", C.c_int32), ("batched", C.c_int32),
-                ("window_cache", C.c_int32), ("reserved0", C.c_int32)]
+                ("window_cache", C.c_int32), ("hub_rows", C.c_int32)]
 
 
 _lib = None

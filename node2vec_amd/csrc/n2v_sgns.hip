@@ -177,6 +177,10 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (kRingRows ? (VEC <= 2 ? 4 : 1) : 
   __syncthreads();
 
   const int dim = P.dim, window = P.window, K = P.negative;
+  // hogwild only: rows [0, hub_rows) are updated by atomic adds (deterministic mode keeps the
+  // reference's read-modify-write, bit for bit the oracle)
+  const int hub_rows = P.deterministic ? 0 : P.hub_rows;
+  const int64_t hub_span = (int64_t)hub_rows * dim;
   const bool full = dim == 64 * VEC;
   const float alpha = P.alpha;
   const uint32_t domain = cum_table[P.n_vocab - 1];
@@ -355,6 +359,8 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (kRingRows ? (VEC <= 2 ? 4 : 1) : 
       float *pc = syn1neg + (int64_t)centre * dim;
       Row<VEC> crow;
       load_row<VEC>(pc, dim, lane, full, crow);
+      const bool hub_centre = hub_rows > 0 && centre < hub_rows;
+      Row<VEC> crow0 = crow;  // as loaded (hub rows go back as an atomic add of the difference)
       constexpr int KP = VEC <= 4 ? 5 : (VEC == 8 ? 3 : 1);  // negative rows in flight
       struct PairBuf {
         Row<VEC> row1;
@@ -419,7 +425,16 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (kRingRows ? (VEC <= 2 ? 4 : 1) : 
           work.v[v] = __fmaf_rn(g, row2.v[v], work.v[v]);
           row2.v[v] = __fmaf_rn(g, row1.v[v], row2.v[v]);
         }
-        store_row<VEC>(p2, dim, lane, full, row2);
+        if (hub_rows > 0 && (p2 - syn1neg) < hub_span) {
+          // a hub row (the vocabulary is in descending count order): hundreds of waves hold it at
+          // any moment and a plain store would overwrite what they learned -- add this wave's
+          // contribution instead
+#pragma unroll
+          for (int v = 0; v < VEC; ++v)
+            if (lane * VEC + v < dim) unsafeAtomicAdd(p2 + lane * VEC + v, g * row1.v[v]);
+        } else {
+          store_row<VEC>(p2, dim, lane, full, row2);
+        }
       };
       auto process = [&](PairBuf &A) {
         const int j = A.j;
@@ -475,12 +490,18 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (kRingRows ? (VEC <= 2 ? 4 : 1) : 
             train_negative(A.row1, work, rows[e], p2);
           }
         }
+        if (!kRing && hub_rows > 0 && (p1 - syn0) < hub_span) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) A.row1.v[v] = A.row1.v[v] + work.v[v];
-        if (kRing)
-          ring_put(A.rowi, A.row1);
-        else
-          store_row<VEC>(p1, dim, lane, full, A.row1);
+          for (int v = 0; v < VEC; ++v)
+            if (lane * VEC + v < dim) unsafeAtomicAdd(p1 + lane * VEC + v, work.v[v]);
+        } else {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) A.row1.v[v] = A.row1.v[v] + work.v[v];
+          if (kRing)
+            ring_put(A.rowi, A.row1);
+          else
+            store_row<VEC>(p1, dim, lane, full, A.row1);
+        }
         ++pairs;
       };
       int j = lo + (lo == i ? 1 : 0);
@@ -525,7 +546,13 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (kRingRows ? (VEC <= 2 ? 4 : 1) : 
           if (j == i) ++j;
         }
       }
-      store_row<VEC>(pc, dim, lane, full, crow);
+      if (hub_centre) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+          if (lane * VEC + v < dim) unsafeAtomicAdd(pc + lane * VEC + v, crow.v[v] - crow0.v[v]);
+      } else {
+        store_row<VEC>(pc, dim, lane, full, crow);
+      }
       if (kRing) {
         if (ring_in_row >= 0) {
           ring_put(ring_in_row, ring_in);
@@ -601,9 +628,10 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   // dimension fills the wave exactly and the ring fits beside the other per-wave buffers
   const int ring_rows = 2 * P->window + 2 <= 12 ? 12 : 16;
   const bool ring_fits = P->dim == 64 * V && V <= 2 && 2 * P->window + 2 <= 16;
-  if (P->window_cache != 0 && P->window_cache != 1 && P->window_cache != -1) return N2V_EINVAL;
+  if (P->window_cache != 0 && P->window_cache != 1) return N2V_EINVAL;
   if (P->window_cache == 1 && !ring_fits) return N2V_EINVAL;
-  const bool use_ring = ring_fits && P->window_cache != -1;
+  if (P->hub_rows < 0) return N2V_EINVAL;
+  const bool use_ring = P->window_cache == 1;
   const int sent_cap = (walk_len + 3) & ~3;
   const int ints_per_wave = (2 * sent_cap + (2 * P->window + 1) * P->negative + 3) & ~3;
   const size_t lds = kExpTable * sizeof(float) + (P->cum_index ? 0 : (kBuckets + 1 + 3) * sizeof(int32_t)) +

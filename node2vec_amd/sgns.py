@@ -139,7 +139,8 @@ class SgnsModel:
         # include/n2v_hip.h: pairs_out is two uint64, [0] the pair counter, [1] kernel scratch
         self.max_waves = 0  # hogwild concurrency cap (0 = the library's rule, n2v_sgns_params)
         self.batched = False  # opt-in: negatives shared by the pairs of a centre position
-        self.window_cache = 0  # default kernel: syn0 rows of the window in LDS (0 auto, 1 on, -1 off)
+        self.window_cache = 0  # default kernel: syn0 rows of the window in LDS (measured slower: off)
+        self.hub_rows = 0  # hogwild: atomic adds on rows [0, hub_rows) (the most frequent words)
         self._counters = torch.zeros(2, dtype=torch.int64, device=device)
         self.pairs = self._counters[:1]
         self.sentences_seen = 0
@@ -158,7 +159,7 @@ class SgnsModel:
         P = _lib.SgnsParams(len(self.vocab), int(sentence_base), self.seed, self.dim, self.window,
                             self.negative, float(alpha), int(bool(deterministic)),
                             self.cum_index_bits, 0 if self.cum_index is None else self.cum_index.data_ptr(),
-                            int(self.max_waves), int(bool(self.batched)), int(self.window_cache), 0)
+                            int(self.max_waves), int(bool(self.batched)), int(self.window_cache), int(self.hub_rows))
         with torch.cuda.device(walks_idx.device):
             rc = L.n2v_sgns_train(walks_idx.data_ptr(), walks_idx.shape[0], walks_idx.shape[1],
                                   self.syn0.data_ptr(), self.syn1neg.data_ptr(),

@@ -42,6 +42,7 @@ def run(seed, max_waves=0):
     m = sgns.SgnsModel(vocab, 128, 5, 5, seed=seed, sample=1e-3)
     m.max_waves = max_waves
     m.batched = BATCHED
+    m.hub_rows = int(os.environ.get('HUB_ROWS', '0'))
     t0 = time.perf_counter()
     m.train(idx, epochs=1, alpha=0.025, min_alpha=1e-4)
     torch.cuda.synchronize()
@@ -64,7 +65,7 @@ def overlap(a, b):
     return float(np.mean([len(set(x) & set(y)) / len(x) for x, y in zip(a, b)]))
 
 
-print(f'batched={BATCHED}', flush=True)
+print(f'batched={BATCHED} hub_rows={os.environ.get("HUB_ROWS", "0")}', flush=True)
 for waves in WAVES:
     aucs, first = [], None
     n = n_runs if waves == 0 else 5

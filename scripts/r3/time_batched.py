@@ -31,10 +31,12 @@ idx = index_of[walks.long()].contiguous()
 g.hops = None
 torch.cuda.empty_cache()
 print(f"{which}: {g.n_vertices} vertices, corpus {tuple(idx.shape)}, dim {dim}", flush=True)
-for batched, cache in ((False, -1), (False, 1 if dim <= 128 else -1), (True, 0)):
+HUB = int(os.environ.get('HUB_ROWS', '0'))
+for batched, cache in ((False, 0), (True, 0)):
     m = sgns.SgnsModel(vocab, dim, 5, 5, seed=1, sample=0.0)
     m.batched = batched
     m.window_cache = cache
+    m.hub_rows = HUB
     for k in range(2):
         m.train_block(idx, 0.025, k * idx.shape[0])
     m.pairs.zero_()
@@ -46,7 +48,7 @@ for batched, cache in ((False, -1), (False, 1 if dim <= 128 else -1), (True, 0))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     pairs = int(m.pairs.item())
-    print(f"batched={batched} window_cache={cache}: {pairs / dt / 1e6:9.1f} M pairs/s  {1e3 * dt / steps:8.2f} ms/launch  "
+    print(f"batched={batched} window_cache={cache} hub_rows={HUB}: {pairs / dt / 1e6:9.1f} M pairs/s  {1e3 * dt / steps:8.2f} ms/launch  "
           f"pairs/launch {pairs // steps}", flush=True)
     del m
     torch.cuda.empty_cache()

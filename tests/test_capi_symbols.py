@@ -56,7 +56,7 @@ def test_ctypes_structs_match_header_layout():
     assert [f[0] for f in _lib.SgnsParams._fields_] == [
         "n_vocab", "sentence_base", "seed", "dim", "window", "negative", "alpha",
         "deterministic", "cum_index_bits", "cum_index", "max_waves", "batched", "window_cache",
-        "reserved0"]
+        "hub_rows"]
     body = text[text.index("typedef struct n2v_sgns_params {"):text.index("} n2v_sgns_params;")]
     fields = re.findall(r"\*?\s*\b(\w+);", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
     assert fields == [f[0] for f in _lib.SgnsParams._fields_]
