@@ -108,6 +108,7 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
                            sample=float(p["sample"] or 0.0), ns_exponent=float(p["ns_exponent"]),
                            device=dev)
     model.batched = bool(p.get("batched", False))
+    model.hub_rows = int(p.get("hub_rows", 0) or 0)
     logging.info("fit_streaming: %d start vertices on this rank, vocabulary %d", n_start, len(vocab))
     sync = None
     if multi:
