@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--no-sgns", action="store_true")
     ap.add_argument("--no-fast", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the opt-in batched SGNS leg")
+    ap.add_argument("--no-hub", action="store_true", help="skip the hub_rows = 4096 SGNS leg (profiling "
+                    "runs: every sgns_kernel launch then is a headline launch)")
     ap.add_argument("--no-biased", action="store_true")
     ap.add_argument("--no-regimes", action="store_true", help="skip the other (p, q) regimes of the exact sampler")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU time budget per baseline leg")
@@ -566,16 +568,42 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist)
            "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
                         "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic,
                         "kernel": "sgns_kernel", "kernel_ms": 1e3 * kernel_s,
-                        "achieved_from": "algorithmic bytes (SURVEY 8d: 8*D*(2+k) per pair); `traffic` "
-                                         "is the measured memory-side bytes per launch (below the "
-                                         "algorithmic bytes: the centre row stays in registers and hot "
-                                         "rows hit L2)",
+                        "achieved_from": "algorithmic bytes (SURVEY 8d: 8*D*(2+k) per pair).  `traffic` = "
+                                         "2 * FETCH_SIZE + WRITE_SIZE of a committed rocprofv3 pass (the "
+                                         "counter tallies half of this kernel's row reads: calibrated in "
+                                         "profiles/r3e_fetch_write_calibration_rows.txt); it is bytes past "
+                                         "L2, Infinity-Cache hits included, so it can exceed what HBM "
+                                         "itself delivers",
                         "traffic_GBps": None if not traffic else traffic / kernel_s / 1e9,
                         "frac_algorithmic": ach / HBM_PEAK,
                         "frac_counter": None if not traffic else traffic / kernel_s / HBM_PEAK,
                         "measured_row_ceiling_GBps": row_ceiling,
                         "algorithmic_bytes_per_pair": bytes_per_pair,
                         "fma_utilisation": pairs / args.steps * flops_per_pair / kernel_s / FP32_PEAK}}
+    # the same launches with atomic adds on the 4096 most frequent rows (n2v_sgns_params.hub_rows):
+    # what hogwild loses on hubs at 8192 concurrent waves comes back (cfg 2 link AUC 0.897 -> 0.909,
+    # profiles/r3k_hogwild_auc_hub_rows.log) for this much throughput
+    model.hub_rows = 0 if args.no_hub else 4096
+    try:
+        if args.no_hub:
+            raise StopIteration
+        model.train_block(idx, 0.025, 50 * rows)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        p0 = float(model.pairs.item())
+        for k in range(args.steps):
+            model.train_block(idx, 0.025, (60 + k + rank * 1000) * rows)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res["hub_rows_4096"] = {"value": (float(model.pairs.item()) - p0) / dt,
+                                "unit": "embedding-updates/s on this GPU",
+                                "ms_per_step": 1e3 * dt / args.steps,
+                                "what": "rows [0, 4096) of syn0 / syn1neg updated by atomic adds (hogwild "
+                                        "only); opt-in (w2v_params['hub_rows'])"}
+    except StopIteration:
+        pass
+    finally:
+        model.hub_rows = 0
     if not args.no_batched and dim in (64, 128, 256):
         res["batched"] = bench_sgns_batched(args, torch, dist, model, idx, rows, rank, barrier,
                                             use_dist, dev, dim)
@@ -635,7 +663,9 @@ def bench_sgns_batched(args, torch, dist, model, idx, rows, rank, barrier, use_d
                         "position (Ji et al. 2016); bit-identical to its own oracle in deterministic mode",
             "pairs_per_position": pairs / args.steps / max(positions, 1.0),
             "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK, "traffic": None, "kernel": "sgns_batched_kernel",
+                         "frac": ach / HBM_PEAK,
+                         "traffic": pmc_traffic(args.config, "sgns_batched_kernel", 0, 0, rows),
+                         "kernel": "sgns_batched_kernel",
                          "kernel_ms": 1e3 * kernel_s,
                          "achieved_from": "algorithmic bytes 8*D*(2+k) per centre POSITION (centre + k "
                                           "negative rows and one context row, read and written once)",
