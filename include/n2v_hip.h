@@ -343,6 +343,18 @@ int n2v_delta_pack(const float *cur, const uint16_t *ref_bf16, int64_t n, float 
 int n2v_delta_apply(float *cur, uint16_t *ref_bf16, const float *before, const void *wire_sum,
                     int32_t wire_dtype, int32_t world, int64_t n, void *stream);
 
+/* The two elementwise passes between K2 and K3 when the corpus is streamed batch by batch
+ * (node2vec_amd/pipeline.py; the reference materialises the walks as strings and lets gensim's
+ * build_vocab count them, embedding.py:125-126):
+ *   n2v_corpus_count  counts[v] += occurrences of v in the rows with valid[row] != 0 (valid NULL =
+ *                     every row); tokens outside [0, n_vertices) are ignored.  counts: uint64.
+ *   n2v_corpus_index  idx_out[r][t] = index_of[walks[r][t]] for tokens of valid rows, else -1
+ *                     (the int32 vocabulary indices n2v_sgns_train takes). */
+int n2v_corpus_count(const int32_t *walks, const uint8_t *valid, int64_t n_rows, int32_t len,
+                     int64_t n_vertices, unsigned long long *counts, void *stream);
+int n2v_corpus_index(const int32_t *walks, const uint8_t *valid, const int32_t *index_of,
+                     int64_t n_rows, int32_t len, int64_t n_vertices, int32_t *idx_out, void *stream);
+
 /* Measurement aid (bench.py; nothing on the product path calls it): the rate this device
  * sustains for the access shapes of K2 and K3 on the CALLER's buffer, so that the ceilings the
  * kernels are compared with are observed on the box the bench runs on.  One launch; the caller

@@ -22,7 +22,7 @@ SYMBOLS = ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alia
            "n2v_pivots_build", "n2v_edge_classes_build", "n2v_walk", "n2v_trim_mark",
            "n2v_sgns_train", "n2v_delta_ref_init", "n2v_delta_pack", "n2v_delta_apply",
            "n2v_edge_bias", "n2v_alias_draw", "n2v_hops_build", "n2v_cum_index_build", "n2v_walk_uniforms", "n2v_wedge_build",
-           "n2v_mem_probe")
+           "n2v_mem_probe", "n2v_corpus_count", "n2v_corpus_index")
 
 
 class Graph(C.Structure):
@@ -111,6 +111,12 @@ def load():
     L.n2v_alias_draw.restype = C.c_int
     L.n2v_alias_draw.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]
+    L.n2v_corpus_count.restype = C.c_int
+    L.n2v_corpus_count.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p,
+                                   C.c_void_p]
+    L.n2v_corpus_index.restype = C.c_int
+    L.n2v_corpus_index.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
+                                   C.c_void_p, C.c_void_p]
     L.n2v_mem_probe.restype = C.c_int
     L.n2v_mem_probe.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                 C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]

@@ -512,30 +512,14 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (kRingRows ? (VEC <= 2 ? 4 : 1) : 
         // are excluded from the early request (see issue), so the result is identical to
         // training strictly in order -- deterministic mode uses the same path.
         auto next_pair = [&](int jj) { return jj + 1 == i ? jj + 2 : jj + 1; };
-        if constexpr (kDepth == 1) {
-          PairBuf bufA, bufB;
-          if (j < hi) issue(j, -1, -1, bufA);
-          while (j < hi) {
-            const int jn = next_pair(j);
-            if (jn < hi) issue(jn, j, -1, bufB);
-            process(bufA);
-            bufA = bufB;
-            j = jn;
-          }
-        } else {
-          PairBuf b0, b1, b2;
-          int j0 = j, j1 = next_pair(j0), j2 = next_pair(j1);
-          if (j0 < hi) issue(j0, -1, -1, b0);
-          if (j1 < hi) issue(j1, j0, -1, b1);
-          while (j0 < hi) {
-            if (j2 < hi) issue(j2, j1, j0, b2);  // pairs j0 and j1 are trained before j2
-            process(b0);
-            b0 = b1;
-            b1 = b2;
-            j0 = j1;
-            j1 = j2;
-            j2 = next_pair(j2);
-          }
+        PairBuf bufA, bufB;
+        if (j < hi) issue(j, -1, -1, bufA);
+        while (j < hi) {
+          const int jn = next_pair(j);
+          if (jn < hi) issue(jn, j, -1, bufB);
+          process(bufA);
+          bufA = bufB;
+          j = jn;
         }
       } else {
         PairBuf buf;
@@ -660,13 +644,13 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   if (pairs_out && hipMemsetAsync(pairs_out + 1, 0, sizeof(unsigned long long), st) != hipSuccess)
     return N2V_ELAUNCH;
   // lookahead depth: 1 pair for dim <= 512, none above (registers).  Depth 2 was measured
-  // twice at dim 128 and lost both times (628 vs 674 M pairs/s at equal occupancy).
+  // in rounds 2 and 3 (ring variant) and lost every time.
 #ifndef N2V_SGNS_DEPTH
 #define N2V_SGNS_DEPTH(VV) ((VV) <= 8 ? 1 : 0)
 #endif
 #define N2V_LAUNCH_R(VV, RR)                                                                  \
   do {                                                                                       \
-    constexpr int kD = N2V_SGNS_DEPTH(VV);                                                    \
+    constexpr int kD = N2V_SGNS_DEPTH(VV);                   \
     const void *fn = (const void *)sgns_kernel<VV, kD, RR>;                                   \
     if (lds > 64 * 1024 &&                                                                   \
         hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \

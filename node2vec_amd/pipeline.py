@@ -88,8 +88,7 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
         walks, valid = walk(k)
         if walks.numel() == 0:
             continue
-        keep = (valid.bool().unsqueeze(1) & (walks >= 0)).reshape(-1)
-        counts.index_add_(0, walks.reshape(-1).clamp(min=0).long(), keep.long())
+        sgns.corpus_count(walks, valid, counts)  # one pass, no widening / clamping / scatter ops
     if multi:
         all_reduce(counts, dist.ReduceOp.SUM)
     t_walk += clock() - t0
@@ -126,8 +125,7 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
             t1 = clock()
             t_walk += t1 - t0
             if walks.numel():
-                idx = index_of[walks.long().clamp(min=0)]
-                idx = torch.where(valid.bool().unsqueeze(1) & (walks >= 0), idx, torch.full_like(idx, -1))
+                idx = sgns.corpus_index(walks, valid, index_of)
                 done = (ep * n_batches + k) / (epochs * n_batches)
                 a = max(min_alpha, alpha - (alpha - min_alpha) * done)
                 # sentence id = (epoch, rank, row of the rank's virtual corpus): never repeats

@@ -208,6 +208,37 @@ class SgnsModel:
         return self
 
 
+def corpus_count(walks: torch.Tensor, valid: Optional[torch.Tensor], counts: torch.Tensor) -> None:
+    """counts[v] += occurrences of v in the valid rows of `walks` (n2v_corpus_count): int32 [rows,
+    len] walks, uint8 / bool [rows] valid (or None), int64 [n_vertices] counts, all on the GPU"""
+    L = _lib.load()
+    if walks.numel() == 0:
+        return
+    walks = walks.contiguous()
+    v = None if valid is None else valid.to(torch.uint8).contiguous()
+    with torch.cuda.device(walks.device):
+        _lib.check(L.n2v_corpus_count(walks.data_ptr(), 0 if v is None else v.data_ptr(), walks.shape[0],
+                                      walks.shape[1], counts.numel(), counts.data_ptr(),
+                                      _lib.current_stream_ptr()), "n2v_corpus_count")
+
+
+def corpus_index(walks: torch.Tensor, valid: Optional[torch.Tensor], index_of: torch.Tensor) -> torch.Tensor:
+    """int32 vocabulary indices of a batch of walks (n2v_corpus_index): -1 for tokens of dropped
+    rows, for negative tokens and for vertices below min_count"""
+    L = _lib.load()
+    out = torch.empty_like(walks, dtype=torch.int32)
+    if walks.numel() == 0:
+        return out
+    walks = walks.contiguous()
+    v = None if valid is None else valid.to(torch.uint8).contiguous()
+    with torch.cuda.device(walks.device):
+        _lib.check(L.n2v_corpus_index(walks.data_ptr(), 0 if v is None else v.data_ptr(),
+                                      index_of.data_ptr(), walks.shape[0], walks.shape[1],
+                                      index_of.numel(), out.data_ptr(), _lib.current_stream_ptr()),
+                   "n2v_corpus_index")
+    return out
+
+
 class _CallableSync:
     """adapter: SgnsModel.train(sync=f) with a plain callable f (called after every launch)"""
 

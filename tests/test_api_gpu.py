@@ -177,3 +177,30 @@ def test_streaming_pipeline_matches_materialised_corpus():
     torch.cuda.synchronize()
     assert int(ref.pairs.item()) == out.pairs_trained
     assert np.isfinite(out.wv.vectors).all()
+
+
+def test_corpus_count_and_index_equal_torch():
+    """n2v_corpus_count / n2v_corpus_index (the passes between K2 and K3 of fit_streaming) against
+    the framework ops they replace: dropped rows, negative tokens, out-of-range ids"""
+    from node2vec_amd import sgns
+
+    gen = torch.Generator().manual_seed(4)
+    nv = 5000
+    walks = torch.randint(-1, nv + 3, (3000, 41), generator=gen, dtype=torch.int32).cuda()
+    valid = (torch.rand(3000, generator=gen) < 0.8).cuda()
+    counts = torch.zeros(nv, dtype=torch.int64, device="cuda")
+    counts[7] = 5  # accumulates
+    sgns.corpus_count(walks, valid, counts)
+    ok = valid.unsqueeze(1) & (walks >= 0) & (walks < nv)
+    want = torch.bincount(walks[ok].long(), minlength=nv)
+    want[7] += 5
+    assert torch.equal(counts, want)
+    c2 = torch.zeros(nv, dtype=torch.int64, device="cuda")
+    sgns.corpus_count(walks, None, c2)
+    assert torch.equal(c2, torch.bincount(walks[(walks >= 0) & (walks < nv)].long(), minlength=nv))
+    index_of = torch.randperm(nv, generator=gen).to(torch.int32).cuda()
+    index_of[::7] = -1
+    idx = sgns.corpus_index(walks, valid, index_of)
+    ref = torch.where(ok, index_of[walks.clamp(0, nv - 1).long()], torch.full_like(walks, -1))
+    assert idx.dtype == torch.int32 and torch.equal(idx, ref)
+    assert sgns.corpus_index(walks[:0], valid[:0], index_of).shape == (0, 41)
