@@ -195,6 +195,10 @@ def test_corpus_count_and_index_equal_torch():
     want = torch.bincount(walks[ok].long(), minlength=nv)
     want[7] += 5
     assert torch.equal(counts, want)
+    c3 = torch.zeros(nv, dtype=torch.int64, device="cuda")
+    c3[7] = 5
+    sgns.corpus_count(walks, valid, c3, sort_above=1)  # the sort-based path of large batches
+    assert torch.equal(c3, want)
     c2 = torch.zeros(nv, dtype=torch.int64, device="cuda")
     sgns.corpus_count(walks, None, c2)
     assert torch.equal(c2, torch.bincount(walks[(walks >= 0) & (walks < nv)].long(), minlength=nv))
