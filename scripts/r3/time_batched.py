@@ -26,11 +26,14 @@ deg = g.degrees().clamp(min=1)
 order = torch.sort(deg, descending=True, stable=True).indices
 index_of = torch.empty(g.n_vertices, dtype=torch.int32, device="cuda")
 index_of[order] = torch.arange(g.n_vertices, dtype=torch.int32, device="cuda")
+FOLD = int(os.environ.get("FOLD", "0"))  # experiment: fold the vocabulary to FOLD rows (cache-resident model)
+if FOLD:
+    order, index_of = order[:FOLD], (index_of % FOLD).to(torch.int32)
 vocab = sgns.Vocab(order, deg[order], index_of)
 idx = index_of[walks.long()].contiguous()
 g.hops = None
 torch.cuda.empty_cache()
-print(f"{which}: {g.n_vertices} vertices, corpus {tuple(idx.shape)}, dim {dim}", flush=True)
+print(f"{which}: fold={FOLD} {g.n_vertices} vertices, corpus {tuple(idx.shape)}, dim {dim}", flush=True)
 HUB = int(os.environ.get('HUB_ROWS', '0'))
 for batched, cache in ((False, 0), (False, 1), (True, 0)):
     m = sgns.SgnsModel(vocab, dim, 5, 5, seed=1, sample=0.0)
