@@ -266,6 +266,14 @@ int n2v_trim_mark(const int64_t *rowptr, int64_t n_rows, int64_t max_out_degree,
  *               trained; [1] scratch, the kernel hands out rows through it (reset by the
  *               library on the stream before the launch)
  *
+ * params->batched = 1 selects the opt-in BATCHED trainer (dim 64 / 128 / 256, window <= 7,
+ * negative <= 15, else N2V_EINVAL): the `negative` draws are made once per centre position and
+ * shared by its <= 2 * window pairs, and the pairs of a position are trained from one snapshot of
+ * the rows -- NOT gensim's sampling (Ji et al. 2016).  A position then is three small dense
+ * products on v_mfma_f32_16x16x4_f32 and moves 8 * dim * (2 + negative) bytes per position
+ * instead of per pair.  Its deterministic mode is bit-identical to its own CPU restatement
+ * (oracle/n2v_oracle_sgns.c, the batched function).
+ *
  * One wave trains one walk (sentence); walks are spread over the grid hogwild
  * (unsynchronised updates, as gensim's worker threads).  deterministic != 0 runs
  * every walk in order on a single wave: bit-identical to oracle/n2v_oracle_sgns.c.

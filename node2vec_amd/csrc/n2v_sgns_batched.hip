@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
     const int32_t *__restrict__ walks, int64_t n_walks, int32_t walk_len, float *syn0,
     float *syn1neg, const uint32_t *__restrict__ cum_table,
     const uint32_t *__restrict__ sample_int, const float *__restrict__ exp_table_g,
-    n2v_sgns_params P, unsigned long long *pairs_out) {
+    n2v_sgns_params P, unsigned long long *pairs_out, int32_t own_negw) {
   constexpr int D = 64 * VEC, Q = 16 * VEC, RS = Q + 4, NCH = D / 16;
   constexpr int RROWS = KC == 3 ? 12 : 16;          // physical rows of the context ring
   // plane strides = 32 mod 64 floats: the four planes of a row then start on alternating bank
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
   const int lane = threadIdx.x & 63;
   const int j16 = lane & 15, g4 = lane >> 4;
   constexpr int per_wave_floats = 4 * PR + 4 * PT + 16 * 17;
-  const int per_wave_ints = (2 * walk_len + walk_len * PL + 32 + 3) & ~3;
+  const int per_wave_ints = (2 * walk_len + walk_len * PL + 32 + (own_negw ? walk_len * K : 0) + 3) & ~3;
   unsigned char *mine = smem + kBExpTable * sizeof(float) +
                         (size_t)wave_in_block * ((size_t)per_wave_floats + per_wave_ints) * 4;
   float *ring = reinterpret_cast<float *>(mine);
@@ -164,14 +164,15 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
   float *gs = tgt + 4 * PT;
   int32_t *sent = reinterpret_cast<int32_t *>(gs + 16 * 17);
   int32_t *red = sent + walk_len;
-  // the raw draws are only needed until the plan is built: they borrow the two row tiles
-  int32_t *negw = reinterpret_cast<int32_t *>(ring);
   // the plan of a sentence, per position i: [0 .. K] the target words (centre, then the distinct
   // negatives != centre in draw order), [K + 1 ..] their multiplicities (4 bits each), then one
   // word: bits 0..4 the number of targets, bits 8.. a mask of the targets position i - 1 writes
   int32_t *plan = red + walk_len;
   int32_t *mphys = plan + walk_len * PL;  // [16] M index -> physical ring row
   int32_t *mmultM = mphys + 16;           // [16] multiplicity by M index (0: unused)
+  // the raw draws are only needed until the plan is built: they borrow the two row tiles (long
+  // sentences with many negatives that do not fit there get their own area)
+  int32_t *negw = own_negw ? mmultM + 16 : reinterpret_cast<int32_t *>(ring);
   for (int i = threadIdx.x; i < kBExpTable; i += blockDim.x) exp_lds[i] = exp_table_g[i];
   __syncthreads();
 
@@ -616,10 +617,10 @@ extern "C" int n2v_sgns_batched_launch(const int32_t *walks, int64_t n_walks, in
   const int trows = 1 + P->negative <= 8 ? 8 : 16;
   const int RS = 16 * VEC + 4;
   const int PR = bank_half_stride((rrows + 1) * RS), PT = bank_half_stride(trows * RS);
-  if ((size_t)walk_len * P->negative > (size_t)4 * (PR + PT)) return N2V_EINVAL;  // the draws borrow the tiles
+  const int own_negw = (size_t)walk_len * P->negative > (size_t)4 * (PR + PT);  // else they borrow the tiles
   const int PL = P->negative + 1 + (trows == 8 ? 1 : 2) + 1;
   const size_t per_wave = ((size_t)(4 * PR + 4 * PT + 16 * 17) +
-                           (size_t)((2 * walk_len + walk_len * PL + 32 + 3) & ~3)) * 4;
+                           (size_t)((2 * walk_len + walk_len * PL + 32 + (own_negw ? walk_len * P->negative : 0) + 3) & ~3)) * 4;
   int64_t waves = P->n_vocab / 32;
   if (waves < 1) waves = 1;
   if (waves > n_walks) waves = n_walks;
@@ -645,7 +646,7 @@ extern "C" int n2v_sgns_batched_launch(const int32_t *walks, int64_t n_walks, in
     }                                                                                             \
     hipLaunchKernelGGL((sgns_batched_kernel<VV, TT, KK>), dim3((unsigned)blocks), dim3(wpb * 64), lds, \
                        st, walks, n_walks, walk_len, syn0, syn1neg, cum_table, sample_int,        \
-                       exp_table, *P, pairs_out);                                          \
+                       exp_table, *P, pairs_out, own_negw);                                          \
   } while (0)
 #define N2V_BLAUNCH_T(VV)     \
   do {                        \

@@ -43,7 +43,7 @@ while time.time() - t0 < budget:
     s0, s1 = m.syn0.cpu().numpy().copy(), m.syn1neg.cpu().numpy().copy()
     base, alpha = int(rng.integers(0, 10 ** 9)), float(rng.choice([0.025, 0.1, 0.5]))
     for rep in range(2):
-        m.train_block(idx, alpha, base + rep * rows, deterministic=True)
+        m.train_block(idx, alpha, base + rep * rows, deterministic=True)  # every drawn shape is supported
         pairs = n2v_oracle.sgns_train(idx.cpu().numpy(), s0, s1, m.cum_table.cpu().numpy(),
                                       None if m.sample_int is None else m.sample_int.cpu().numpy(),
                                       sgns.exp_table(), len(vocab), base + rep * rows, m.seed, dim, window, K, alpha,

@@ -87,6 +87,14 @@ def test_batched_cfg_sized_rows_and_tiny_sentences(oracle):
     _check_bits(oracle, sgns, m, idx, 128, 5, 5, launches=((0, 0.025),))
 
 
+def test_batched_long_sentences_with_many_negatives(oracle):
+    """256-token rows x 15 negatives: the raw draws no longer fit the borrowed tiles and get their
+    own LDS area (dim 64: the smallest tiles)"""
+    walks = _corpus(150, 6, 256, 21, True)
+    sgns, m, idx = _model(walks, 64, 7, 15, 4, 0.0)
+    _check_bits(oracle, sgns, m, idx, 64, 7, 15, launches=((0, 0.025),))
+
+
 def test_batched_rejects_what_its_tiles_do_not_hold():
     from node2vec_amd import sgns
 
