@@ -149,6 +149,7 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
   const int PL = K + 1 + TM_WORDS + 1;              // plan ints per position (below)
   const float alpha = P.alpha;
   const bool hogwild = P.deterministic == 0;
+  const int hub_rows = hogwild ? P.hub_rows : 0;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *exp_lds = reinterpret_cast<float *>(smem);
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
       const uint64_t used = ballot64(cm > 0);
       f32x4 newt[NCH];
       int64_t st_off[4];
-      bool st_ok[4];
+      bool st_ok[4], st_hub[4];
       bool trained = false;
       if (used) {
         const int rank = __popcll(used & ((1ull << lane) - 1ull));
@@ -474,6 +475,9 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
         for (int rI = 0; rI < 4; ++rI) {
           st_ok[rI] = t_of_r[rI] >= 0 && t_of_r[rI] < nt_c;
           toff[rI] = (j16 >> 2) * PT + (st_ok[rI] ? t_of_r[rI] : 0) * RS + NCH * (j16 & 3);
+          // hub rows (hogwild, n2v_sgns_params.hub_rows): this position's contribution is ADDED
+          // atomically instead of the row being overwritten -- the accumulator then starts from 0
+          st_hub[rI] = st_ok[rI] && plc[st_ok[rI] ? t_of_r[rI] : 0] < hub_rows;
         }
         // In the two updates tile column j of chunk c is element d = NCH * j + c: a lane's NCH
         // columns are NCH consecutive floats of a row -- 16-byte LDS reads and writes, and the
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
 #pragma unroll
             for (int h = 0; h < VEC; ++h) {
               const float4 v = *reinterpret_cast<const float4 *>(tgt + toff[rI] + 4 * h);
-              cin[rI][h] = st_ok[rI] ? v : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+              cin[rI][h] = (st_ok[rI] && !st_hub[rI]) ? v : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
 #pragma unroll
           for (int s = 0; s < KC; ++s)
@@ -571,10 +575,15 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
 #pragma unroll
         for (int rI = 0; rI < 4; ++rI)
           if (st_ok[rI]) {
+            if (st_hub[rI]) {
 #pragma unroll
-            for (int h = 0; h < VEC; ++h)
-              *reinterpret_cast<float4 *>(syn1neg + st_off[rI] + 4 * h) =
-                  make_float4(newt[4 * h][rI], newt[4 * h + 1][rI], newt[4 * h + 2][rI], newt[4 * h + 3][rI]);
+              for (int c = 0; c < NCH; ++c) unsafeAtomicAdd(syn1neg + st_off[rI] + c, newt[c][rI]);
+            } else {
+#pragma unroll
+              for (int h = 0; h < VEC; ++h)
+                *reinterpret_cast<float4 *>(syn1neg + st_off[rI] + 4 * h) =
+                    make_float4(newt[4 * h][rI], newt[4 * h + 1][rI], newt[4 * h + 2][rI], newt[4 * h + 3][rI]);
+            }
           }
       }
       if (i - window >= 0) leave(i - window);

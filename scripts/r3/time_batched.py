@@ -35,7 +35,7 @@ g.hops = None
 torch.cuda.empty_cache()
 print(f"{which}: fold={FOLD} {g.n_vertices} vertices, corpus {tuple(idx.shape)}, dim {dim}", flush=True)
 HUB = int(os.environ.get('HUB_ROWS', '0'))
-for batched, cache in ((False, 0), (False, 1), (True, 0)):
+for batched, cache in ((False, 0), (True, 0)):
     m = sgns.SgnsModel(vocab, dim, 5, 5, seed=1, sample=0.0)
     m.batched = batched
     m.window_cache = cache
