@@ -192,7 +192,19 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL prints a version banner on stdout when its communicator comes up; stdout carries
+        # the ONE JSON line, so the banner is sent to stderr (fd level: it is printed by C code)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     def barrier():
         if use_dist:
