@@ -226,11 +226,14 @@ def main():
     # every launch of a walk kernel in this process has the bench's size: the rocprofv3
     # --kernel-trace average of the kernel is then the HIP-event average reported below
     prepare_tables(torch, g, p, q, "exact", setup, "headline")
-    if rank == 0 and g.hops is not None:
-        # the ceiling the walk kernels are compared with, observed on THIS box: random 16-byte
-        # gathers over this graph's own hop table (untimed; before the K steps)
-        c = measure_ceilings(torch, g.hops)
-        setup["measured_gather_ceiling"] = dict(c, table_GB=g.hops.numel() * g.hops.element_size() / 1e9)
+    if rank == 0 and (g.hops8 is not None or g.hops is not None):
+        # the ceiling the walk kernel is compared with, observed on THIS box: random gathers of
+        # the kernel's entry width over this graph's own hop table (untimed; before the K steps)
+        table, width = (g.hops8, 8) if (g.hops8 is not None and p == 1.0 and q == 1.0) else (g.hops, 16)
+        if table is not None:
+            c = measure_ceilings(torch, table, gather_width=width)
+            setup["measured_gather_ceiling"] = dict(c, table_GB=table.numel() * table.element_size() / 1e9,
+                                                    gather_bytes=width)
     leg = WalkLeg(torch, rw, g, start_all, W, L, p, q, "exact", batch, rank, world)
     res = leg.run(args.steps, args.warmup, barrier)
     elapsed, steps_total = reduce_job(torch, dist, use_dist, dev, res["elapsed"], res["steps_done"])
@@ -322,7 +325,7 @@ def main():
         del leg
         torch.cuda.empty_cache()
     # the walk tables are not needed any more (the CPU baseline reads rowptr / col only)
-    g.slots = g.pivots = g.hops = g.edge_classes = g.wedge_off = g.wedge_pos = None
+    g.slots = g.pivots = g.hops = g.hops8 = g.edge_classes = g.wedge_off = g.wedge_pos = None
     torch.cuda.empty_cache()
 
     # ---- SGNS on the config's model ------------------------------------------------------------
@@ -366,7 +369,10 @@ def prepare_tables(torch, g, p, q, mode, setup, tag):
             timed("wedge_table_build", g.build_wedges)
             setup[f"{tag}_wedge_table_GB"] = 0.0 if g.wedge_off is None else (
                 g.wedge_off.numel() * 8 + g.wedge_pos.numel() * g.wedge_pos.element_size()) / 1e9
-        if g.hops is None or (g.edge_classes is not None and not g.hops_have_classes):
+        if not biased and mode == "exact" and g.hops8 is None and not g.hops8_tried:
+            timed("hop8_table_build", g.build_hops8)  # 8 bytes per edge; p = q = 1 only
+        if (biased or mode != "exact" or g.hops8 is None) and (
+                g.hops is None or (g.edge_classes is not None and not g.hops_have_classes)):
             timed("hop_table_build", g.build_hops)
     elif g.slots is None and (mode == "fast" or not biased):
         timed("alias_tables_build", g.build_alias)
@@ -399,12 +405,21 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
     algorithm's bytes are reported beside it, never as the roofline."""
     per_launch_steps = leg.batch * leg.W * leg.L
     hops = leg.g.hops is not None
+    hop8 = leg.g.hops8 is not None and mode == "exact" and p == 1.0 and q == 1.0
     if mode == "fast":
         t = res["trials"] / max(res["steps_done"], 1)
         alg = (t * 16 + 4) if hops else (16 + t * 16 + 4)
         formula = ("trials * 16 (hop entry: neighbour, its row and degree, edge classes) + 4 (path)"
                    if hops else "16 (rowptr pair) + trials * 16 (slot) + 4 (path)") + \
             "; membership searches extra"
+    elif hop8:
+        cb, rb = leg.g.hops8_bits
+        esc = (1 << (64 - cb - rb)) - 1
+        share = escape_share(leg)
+        alg = 8 + 4 + 16 * share
+        formula = (f"8 (hop entry: neighbour id {cb} bits | its row pointer {rb} bits | degree code "
+                   f"{64 - cb - rb} bits) + 4 (path write) + 16 x {share:.3f} (share of the steps whose "
+                   f"new vertex has degree >= {esc}: the degree is read from rowptr, cached)")
     elif p == 1.0 and q == 1.0:
         alg = (16 + 4) if hops else (16 + 4 + 4)
         formula = ("16 (hop entry: col[pick] with the row pointer and degree of that neighbour) + "
@@ -420,13 +435,14 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
                     "whose edge has shared neighbours; the steps that run the pairing read 2 bytes per "
                     "shared neighbour at most" if wedges else
                     ", + 4 per probe of the membership search; steps that run the pairing read both rows"))
-    kernel_key = kernel + (":hops" if hops else "") + (
+    kernel_key = kernel + (":hop8" if hop8 else (":hops" if hops else "")) + (
         ":wedges" if (leg.g.wedge_off is not None and mode == "exact" and not (p == 1.0 and q == 1.0)) else "")
     traffic = pmc_traffic(config, kernel_key, p, q, leg.batch)
     alg_launch = alg * per_launch_steps
     ach = alg_launch / res["kernel_s"]
     r = {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-         "frac": ach / HBM_PEAK, "traffic": traffic, "kernel": kernel, "hop_table": hops,
+         "frac": ach / HBM_PEAK, "traffic": traffic, "kernel": kernel,
+         "hop_table": "8-byte" if hop8 else hops,
          "wedge_table": ":wedges" in kernel_key,
          "kernel_ms": 1e3 * res["kernel_s"],
          "achieved_from": "ALGORITHMIC bytes of the kernel (formula below) x walk-steps per launch / "
@@ -446,16 +462,17 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
         r["frac_counter"] = traffic / res["kernel_s"] / HBM_PEAK
         r["counter_over_algorithmic"] = traffic / alg_launch
         r["sectors_per_walk_step"] = sectors / per_launch_steps
-    g_meas = MEASURED.get("gather16_independent")
+    g_meas = MEASURED.get("gather_independent")
     if g_meas:
         # the binding resource, observed on this box: random 16-byte gathers per second
         gathers = (res["trials"] if mode == "fast" and res.get("trials") else res["steps_done"]) / \
             max(res["launches"], 1) / res["kernel_s"]
         r["gather_ceiling"] = {
-            "gathers_per_walk_step_min": 1.0 if hops else 2.0,
+            "gathers_per_walk_step_min": 1.0 if (hops or hop8) else 2.0,
+            "gather_bytes": MEASURED.get("gather_bytes", 16),
             "kernel_Ggathers_per_s": gathers / 1e9,
             "measured_Ggathers_per_s_independent": g_meas / 1e9,
-            "measured_Ggathers_per_s_dependent_chain": MEASURED.get("gather16_chain", 0.0) / 1e9,
+            "measured_Ggathers_per_s_dependent_chain": MEASURED.get("gather_chain", 0.0) / 1e9,
             "frac": gathers / g_meas,
             "source": "n2v_mem_probe modes 0 / 1 over the hop table of this graph, in this process "
                       "(untimed); counts ONE table gather per step (per trial in fast mode) -- list and "
@@ -466,7 +483,17 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
     return r
 
 
-def measure_ceilings(torch, buffer, tag_rows=None):
+def escape_share(leg):
+    """share of the walk steps of the last launch whose new vertex has a degree the 8-byte hop
+    entry cannot hold (the degree is then read from rowptr)"""
+    cb, rb = leg.g.hops8_bits
+    esc = (1 << (64 - cb - rb)) - 1
+    deg = leg.g.degrees()
+    w = leg.walks[:65536][leg.valid[:65536].bool()][:, 1:].long()
+    return float((deg[w] >= esc).float().mean()) if w.numel() else 0.0
+
+
+def measure_ceilings(torch, buffer, tag_rows=None, gather_width=16):
     """n2v_mem_probe on `buffer` (a device tensor >> Infinity Cache): random 16-byte gathers,
     and -- when tag_rows names a row size -- random row reads / read-modify-writes.  Untimed
     with respect to the bench's K steps; HIP events around each probe launch."""
@@ -495,11 +522,13 @@ def measure_ceilings(torch, buffer, tag_rows=None):
         return n.value / best
 
     if tag_rows is None:
-        out["gather16_independent"] = run(0, 256, 0)
-        out["gather16_chain"] = run(1, 256, 0)
+        out["gather_independent"] = run(0, 256, gather_width)
+        out["gather_chain"] = run(1, 256, gather_width)
     else:
         out[f"rows{tag_rows}_read"] = run(2, 512, tag_rows)
         out[f"rows{tag_rows}_read_modify_write"] = run(3, 512, tag_rows)
+    if tag_rows is None:
+        out["gather_bytes"] = gather_width
     MEASURED.update(out)
     return out
 

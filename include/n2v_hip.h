@@ -102,6 +102,9 @@ typedef struct n2v_graph {
   const void *wedge_pos;        /* uint16 / uint32 positions, or NULL */
   int32_t wedge_wide;           /* 0: wedge_pos is uint16 (every degree < 65536), 1: uint32 */
   int32_t reserved;             /* 0 (bit 0 set: do not use the all-tables kernel; diagnostics) */
+  const uint64_t *hops8;        /* [n_edges] or NULL: the 8-byte hop table (n2v_hops8_build) */
+  int32_t hop8_col_bits;        /* field widths of a hops8 entry, see n2v_hops8_build */
+  int32_t hop8_row_bits;
 } n2v_graph;
 
 /* edge_classes[e] for e = (s -> v): bits 0..23 = number of entries x of N(v) with
@@ -149,6 +152,17 @@ int n2v_edge_classes_build(const n2v_graph *g, uint32_t *classes_out, uint32_t *
  * sets N2V_ST_RANGE in status[0] (read after synchronising): the table must then be discarded
  * (walk without it). */
 int n2v_hops_build(const n2v_graph *g, struct n2v_hop *hops_out, uint32_t *status, void *stream);
+
+/* The 8-byte hop table of a unit-weight graph for exact walks with p == q == 1 (no class counts
+ * needed): hops8_out[e] = col[e] | rowptr[col[e]] << col_bits | code << (col_bits + row_bits),
+ * where code = min(degree(col[e]), 2^(64 - col_bits - row_bits) - 1); the top code is an escape:
+ * the degree is then read from rowptr (the few high-degree rows: cache-resident).  The chip
+ * delivers 50 G random 8-byte gathers per second over a 6 GB table against 40 G 16-byte gathers over
+ * 12 GB (profiles/r3v_probe_gathers.log), and a walk step of this kernel IS one such gather.
+ * Requires n_vertices <= 2^col_bits, n_edges < 2^row_bits and col_bits + row_bits <= 62
+ * (N2V_EINVAL otherwise); the caller stores the widths in n2v_graph. */
+int n2v_hops8_build(const n2v_graph *g, int32_t col_bits, int32_t row_bits, uint64_t *hops8_out,
+                    void *stream);
 
 /* Shared-position lists ("wedge table") of a unit-weight graph.  For edge e = (s -> v) the list
  *   wedge_pos[off .. off + n_shared)   off = wedge_off[e] & (2^40 - 1), n_shared = low 24 bits
@@ -370,8 +384,9 @@ int n2v_corpus_index(const int32_t *walks, const uint8_t *valid, const int32_t *
  * sustains for the access shapes of K2 and K3 on the CALLER's buffer, so that the ceilings the
  * kernels are compared with are observed on the box the bench runs on.  One launch; the caller
  * times it (HIP events on `stream`).
- *   mode 0  independent random 16-byte reads (a hop-table gather), 4 in flight per lane
- *   mode 1  one dependent chain of random 16-byte reads per lane (a walker)
+ *   mode 0  independent random reads (a hop-table gather), 4 in flight per lane; element width
+ *           = row_bytes (16, 8 or 4; 0 = 16)
+ *   mode 1  one dependent chain of such reads per lane (a walker)
  *   mode 2  random rows of row_bytes (512 | 1024 | 2048) read by one wave each (a syn0 row)
  *   mode 3  the same rows read, modified and written back (a trained row)
  * iters: accesses per lane (modes 0, 1) / rows per wave (modes 2, 3), a multiple of 4.

@@ -22,7 +22,7 @@ SYMBOLS = ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alia
            "n2v_pivots_build", "n2v_edge_classes_build", "n2v_walk", "n2v_trim_mark",
            "n2v_sgns_train", "n2v_delta_ref_init", "n2v_delta_pack", "n2v_delta_apply",
            "n2v_edge_bias", "n2v_alias_draw", "n2v_hops_build", "n2v_cum_index_build", "n2v_walk_uniforms", "n2v_wedge_build",
-           "n2v_mem_probe", "n2v_corpus_count", "n2v_corpus_index")
+           "n2v_mem_probe", "n2v_corpus_count", "n2v_corpus_index", "n2v_hops8_build")
 
 
 class Graph(C.Structure):
@@ -32,7 +32,8 @@ class Graph(C.Structure):
                 ("w64", C.c_void_p), ("slots", C.c_void_p), ("pivots", C.c_void_p),
                 ("edge_classes", C.c_void_p), ("hops", C.c_void_p),
                 ("wedge_off", C.c_void_p), ("wedge_pos", C.c_void_p), ("wedge_wide", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("reserved", C.c_int32), ("hops8", C.c_void_p), ("hop8_col_bits", C.c_int32),
+                ("hop8_row_bits", C.c_int32)]
 
 
 class SgnsParams(C.Structure):
@@ -80,6 +81,8 @@ def load():
                                   C.c_void_p, C.c_void_p]
     L.n2v_hops_build.restype = C.c_int
     L.n2v_hops_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.n2v_hops8_build.restype = C.c_int
+    L.n2v_hops8_build.argtypes = [C.POINTER(Graph), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.n2v_pivots_build.restype = C.c_int
     L.n2v_pivots_build.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.n2v_walk.restype = C.c_int

@@ -35,7 +35,38 @@ __global__ __launch_bounds__(256) void hops_build_kernel(n2v_graph g, n2v_hop *_
   if (bad) atomicOr(overflow, N2V_ST_RANGE);
 }
 
+// the 8-byte form for the p == q == 1 kernel (include/n2v_hip.h, n2v_hops8_build)
+__global__ __launch_bounds__(256) void hops8_build_kernel(n2v_graph g, int col_bits, int row_bits,
+                                                          uint64_t *__restrict__ out) {
+  const uint64_t esc = (1ull << (64 - col_bits - row_bits)) - 1ull;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < g.n_edges;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t x = g.col[e];
+    const int64_t b = g.rowptr[x];
+    const uint64_t d = (uint64_t)(g.rowptr[x + 1] - b);
+    out[e] = (uint64_t)(uint32_t)x | ((uint64_t)b << col_bits) |
+             ((d < esc ? d : esc) << (col_bits + row_bits));
+  }
+}
+
 }  // namespace n2v
+
+extern "C" int n2v_hops8_build(const n2v_graph *g, int32_t col_bits, int32_t row_bits,
+                               uint64_t *hops8_out, void *stream) {
+  if (!g || !g->rowptr || g->n_vertices < 0 || g->n_edges < 0) return N2V_EINVAL;
+  if (g->w || g->w64) return N2V_EINVAL;  // unit-weight graphs only
+  if (col_bits < 1 || row_bits < 1 || col_bits > 31 || col_bits + row_bits > 62) return N2V_EINVAL;
+  if (g->n_vertices > (1ll << col_bits) || g->n_edges >= (1ll << row_bits)) return N2V_EINVAL;
+  if (g->n_edges == 0) return N2V_OK;
+  if (!g->col || !hops8_out) return N2V_EINVAL;
+  int64_t blocks = (g->n_edges + 255) / 256;
+  const int64_t cap = n2v::resident_blocks((const void *)n2v::hops8_build_kernel, 256, 0) * 2;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(n2v::hops8_build_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, *g, col_bits, row_bits, hops8_out);
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}
 
 extern "C" int n2v_hops_build(const n2v_graph *g, n2v_hop *hops_out, uint32_t *status,
                               void *stream) {

@@ -14,28 +14,57 @@
 
 namespace n2v {
 
-__global__ __launch_bounds__(256) void probe_gather_kernel(const uint4 *__restrict__ t, uint64_t n16,
+template <typename T>  // uint4 (16-byte), uint2 (8-byte) or uint32_t (4-byte) elements
+__global__ __launch_bounds__(256) void probe_gather_kernel(const T *__restrict__ t, uint64_t n_el,
                                                            int iters, int dependent,
                                                            uint32_t *sink) {
   const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t acc = 0;
+  auto first = [](const T &v) -> uint32_t {
+    if constexpr (sizeof(T) == 4) return v; else return v.x;
+  };
+  auto last = [](const T &v) -> uint32_t {
+    if constexpr (sizeof(T) == 4) return v; else if constexpr (sizeof(T) == 8) return v.y; else return v.w;
+  };
   if (dependent) {
-    uint64_t idx = mix64(gid) % n16;
+    uint64_t idx = mix64(gid) % n_el;
     for (int k = 0; k < iters; ++k) {
-      const uint4 r = t[idx];
-      acc += r.w;
-      idx = mix64(((uint64_t)r.x << 32 | r.y) ^ (gid + (uint64_t)k * 0x9E3779B97F4A7C15ULL)) % n16;
+      const T r = t[idx];
+      acc += last(r);
+      idx = mix64(((uint64_t)first(r) << 32 | last(r)) ^ (gid + (uint64_t)k * 0x9E3779B97F4A7C15ULL)) % n_el;
     }
   } else {
     for (int k = 0; k < iters; k += 4) {
-      uint4 v[4];
+      T v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = t[mix64(gid * 0x100000001B3ULL + (uint64_t)(k + u)) % n16];
+      for (int u = 0; u < 4; ++u) v[u] = t[mix64(gid * 0x100000001B3ULL + (uint64_t)(k + u)) % n_el];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc += v[u].x + v[u].w;
+      for (int u = 0; u < 4; ++u) acc += first(v[u]) + last(v[u]);
     }
   }
   if (acc == 0x12345678u) sink[0] = acc;  // keeps the loads alive
+}
+
+// experiment (scripts/r3/probe_hop8.py): a walker step as an 8-byte gather from the big table
+// followed, for a share of the steps, by a dependent 16-byte gather from a small (cache-sized) table
+__global__ __launch_bounds__(256, 8) void probe_hop8_kernel(const uint2 *__restrict__ t, uint64_t n_el,
+                                                            const uint4 *__restrict__ small,
+                                                            uint64_t n_small, int iters,
+                                                            uint32_t escape_share, uint32_t *sink) {
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t idx = mix64(gid) % n_el;
+  uint32_t acc = 0;
+  for (int k = 0; k < iters; ++k) {
+    const uint2 r = t[idx];
+    uint64_t h = mix64(((uint64_t)r.x << 32 | r.y) ^ (gid + (uint64_t)k * 0x9E3779B97F4A7C15ULL));
+    if ((uint32_t)h % 100u < escape_share) {
+      const uint4 e = small[(h >> 32) % n_small];
+      h ^= e.x + e.w;
+    }
+    acc += (uint32_t)h;
+    idx = h % n_el;
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
 }
 
 template <bool kWrite>
@@ -80,6 +109,18 @@ __global__ __launch_bounds__(256) void probe_rows_kernel(float *t, uint64_t n_ro
 
 }  // namespace n2v
 
+extern "C" int n2v_probe_hop8_experiment(const void *big, int64_t big_bytes, const void *small,
+                                         int64_t small_bytes, int32_t iters, int32_t escape_share,
+                                         int64_t *accesses_host, uint32_t *sink, void *stream) {
+  const int64_t blocks = n2v::resident_blocks((const void *)n2v::probe_hop8_kernel, 256, 0);
+  if (accesses_host) *accesses_host = blocks * 256 * (int64_t)iters;
+  hipLaunchKernelGGL(n2v::probe_hop8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const uint2 *)big, (uint64_t)(big_bytes / 8), (const uint4 *)small,
+                     (uint64_t)(small_bytes / 16), iters, (uint32_t)escape_share, sink);
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}
+
 extern "C" int n2v_mem_probe(void *buffer, int64_t buffer_bytes, int32_t mode, int32_t iters,
                              int32_t row_bytes, int64_t *accesses_host, uint32_t *sink,
                              void *stream) {
@@ -89,10 +130,24 @@ extern "C" int n2v_mem_probe(void *buffer, int64_t buffer_bytes, int32_t mode, i
   hipStream_t st = (hipStream_t)stream;
   const int threads = 256;
   if (mode <= 1) {
-    const int64_t blocks = n2v::resident_blocks((const void *)n2v::probe_gather_kernel, threads, 0);
+    // row_bytes selects the element width of the gathers here: 0 / 16 = 16-byte, 8, 4
+    const int width = row_bytes == 0 ? 16 : row_bytes;
+    if (width != 16 && width != 8 && width != 4) return N2V_EINVAL;
+    const void *fn = width == 16  ? (const void *)n2v::probe_gather_kernel<uint4>
+                     : width == 8 ? (const void *)n2v::probe_gather_kernel<uint2>
+                                  : (const void *)n2v::probe_gather_kernel<uint32_t>;
+    const int64_t blocks = n2v::resident_blocks(fn, threads, 0);
     if (accesses_host) *accesses_host = blocks * threads * (int64_t)iters;
-    hipLaunchKernelGGL(n2v::probe_gather_kernel, dim3((unsigned)blocks), dim3(threads), 0, st,
-                       (const uint4 *)buffer, (uint64_t)(buffer_bytes / 16), iters, mode, sink);
+    const uint64_t n_el = (uint64_t)(buffer_bytes / width);
+    if (width == 16)
+      hipLaunchKernelGGL(n2v::probe_gather_kernel<uint4>, dim3((unsigned)blocks), dim3(threads), 0, st,
+                         (const uint4 *)buffer, n_el, iters, mode, sink);
+    else if (width == 8)
+      hipLaunchKernelGGL(n2v::probe_gather_kernel<uint2>, dim3((unsigned)blocks), dim3(threads), 0, st,
+                         (const uint2 *)buffer, n_el, iters, mode, sink);
+    else
+      hipLaunchKernelGGL(n2v::probe_gather_kernel<uint32_t>, dim3((unsigned)blocks), dim3(threads), 0,
+                         st, (const uint32_t *)buffer, n_el, iters, mode, sink);
   } else {
     if (row_bytes != 512 && row_bytes != 1024 && row_bytes != 2048) return N2V_EINVAL;
     const uint64_t n_rows = (uint64_t)(buffer_bytes / row_bytes);

@@ -37,6 +37,9 @@ class DeviceGraph:
         self.edge_classes: Optional[torch.Tensor] = None  # uint32-in-int32 [E] (exact mode, unit weights)
         self.hops: Optional[torch.Tensor] = None  # int32 [E, 4] view of n2v_hop[E] (unit weights)
         self.hops_have_classes = False
+        self.hops8: Optional[torch.Tensor] = None  # int64 [E]: 8-byte hop entries (p = q = 1 walks)
+        self.hops8_bits = (0, 0)  # (col_bits, row_bits) of a hops8 entry
+        self.hops8_tried = False
         self.wedge_off: Optional[torch.Tensor] = None  # int64 [E]: list offset | return position << 40
         self.wedge_pos: Optional[torch.Tensor] = None  # int16 / int32 [sum of shared counts]
         self.wedge_tried = False  # randomwalk.walk tries to build the table once
@@ -128,11 +131,12 @@ class DeviceGraph:
     def to(self, device) -> "DeviceGraph":
         g = DeviceGraph(self.rowptr.to(device), self.col.to(device),
                         None if self._w is None else self._w.to(device))
-        for name in ("slots", "pivots", "edge_classes", "hops", "wedge_off", "wedge_pos"):
+        for name in ("slots", "pivots", "edge_classes", "hops", "hops8", "wedge_off", "wedge_pos"):
             t = getattr(self, name)
             if t is not None:
                 setattr(g, name, t.to(device))
         g.hops_have_classes = self.hops_have_classes
+        g.hops8_bits = self.hops8_bits
         return g
 
     def c_struct(self) -> _lib.Graph:
@@ -147,7 +151,9 @@ class DeviceGraph:
                           0 if self.hops is None else self.hops.data_ptr(),
                           0 if self.wedge_off is None else self.wedge_off.data_ptr(),
                           0 if self.wedge_pos is None else self.wedge_pos.data_ptr(),
-                          0 if self.wedge_pos is None else int(self.wedge_pos.dtype == torch.int32), 0)
+                          0 if self.wedge_pos is None else int(self.wedge_pos.dtype == torch.int32), 0,
+                          0 if self.hops8 is None else self.hops8.data_ptr(),
+                          self.hops8_bits[0], self.hops8_bits[1])
 
     # -- a9 -----------------------------------------------------------------------
     def trimmed(self, max_out_degree: int, seed: int) -> "DeviceGraph":
@@ -283,6 +289,39 @@ class DeviceGraph:
             return self
         self.hops = hops
         self.hops_have_classes = self.edge_classes is not None
+        return self
+
+    HOP8_MAX_ESCAPE_BYTES = 4 << 20  # rowptr bytes of the rows whose degree does not fit the entry
+
+    def build_hops8(self, force: bool = False, col_bits: Optional[int] = None,
+                    row_bits: Optional[int] = None) -> "DeviceGraph":
+        """The 8-byte hop table (n2v_hops8_build) for exact walks with p == q == 1: neighbour id,
+        its row pointer and (a code for) its degree in ONE 8-byte gather -- the chip serves those a
+        quarter faster than the 16-byte entries of build_hops (table half the size).  Field
+        widths follow the graph (cfg 4: 27 + 30 + 7 bits); a degree that does not fit its field
+        is read from rowptr, which pays as long as those rows are few enough to stay cached: the
+        table is built when their rowptr entries span <= 4 MB (or `force`)."""
+        L = _lib.load()
+        _lib.require_gpu()
+        self.hops8 = None
+        self.hops8_tried = True
+        if not self.unit_weights or not self.rowptr.is_cuda or self.n_edges == 0:
+            return self
+        col_bits = int(col_bits or max(1, int(self.n_vertices - 1).bit_length()))  # (tests pass wider
+        row_bits = int(row_bits or max(1, int(self.n_edges).bit_length()))         # fields: more escapes)
+        if col_bits > 31 or col_bits + row_bits > 62:
+            return self
+        esc = (1 << (64 - col_bits - row_bits)) - 1
+        if not force:
+            n_escape = int((self.degrees() >= esc).sum())
+            if n_escape * 16 > self.HOP8_MAX_ESCAPE_BYTES:
+                return self
+        hops8 = torch.empty(self.n_edges, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = L.n2v_hops8_build(self.c_struct(), col_bits, row_bits, hops8.data_ptr(),
+                                   _lib.current_stream_ptr())
+        _lib.check(rc, "n2v_hops8_build")
+        self.hops8, self.hops8_bits = hops8, (col_bits, row_bits)
         return self
 
     def build_pivots(self) -> "DeviceGraph":

@@ -69,7 +69,7 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
          return_param: float, inout_param: float, seed: int, mode: str = "exact",
          out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, check: bool = True,
          stats: Optional[dict] = None, use_edge_classes: bool = True, use_hops: bool = True,
-         use_wedges: bool = True, use_wedge_kernel: bool = True):
+         use_wedges: bool = True, use_wedge_kernel: bool = True, use_hops8: bool = True):
     """Launch K2.  Returns (walks int32 [n_start*num_walks, walk_length+1], valid bool).
 
     mode "fast", and on weighted graphs mode "exact" with return_param == inout_param == 1
@@ -124,7 +124,14 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
             graph.build_alias()
         except ZeroDivisionError:
             pass  # some row sums to 0: keep the per-step path, which raises only if it is visited
-    if graph.unit_weights and use_hops:
+    uniform8 = False
+    if graph.unit_weights and use_hops and use_hops8 and not biased and mode == "exact":
+        # p == q == 1: the 8-byte hop table (built once, when the graph's field widths allow it and
+        # its high-degree rows are few enough to stay cached) -- one 8-byte gather per step
+        if graph.hops8 is None and not graph.hops8_tried:
+            graph.build_hops8()
+        uniform8 = graph.hops8 is not None
+    if graph.unit_weights and use_hops and not uniform8:
         # hop table (16 bytes per edge): one gather per step instead of two or three.  It embeds
         # the class counts, so it is (re)built after them when a biased walk first needs them.
         want_classes = graph.edge_classes is not None
@@ -144,6 +151,8 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
         g.edge_classes = 0
     if not use_hops or (not use_edge_classes and biased):
         g.hops = 0
+    if not uniform8:
+        g.hops8 = 0
     if not use_wedges or not use_edge_classes:
         g.wedge_off = 0
         g.wedge_pos = 0

@@ -117,7 +117,8 @@ if bench:
     def put(kernel, p, q, batch, hops=False, wedges=False):
         e = out["kernels"].get(kernel)
         if e:
-            table[f"{config}:{kernel}{':hops' if hops else ''}{':wedges' if wedges else ''}:p{p}:q{q}:batch{batch}"] = {
+            tab = ":hop8" if hops == "8-byte" else (":hops" if hops else "")
+            table[f"{config}:{kernel}{tab}{':wedges' if wedges else ''}:p{p}:q{q}:batch{batch}"] = {
                 "hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "source": f"profiles/{tag}_summary.json",
                 "FETCH_SIZE_KB": e["FETCH_SIZE_KB"], "WRITE_SIZE_KB": e["WRITE_SIZE_KB"],
                 "tcc_hit_rate": e["tcc_hit_rate"]}

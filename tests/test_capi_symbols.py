@@ -19,7 +19,7 @@ def test_header_declares_the_expected_entry_points():
                  "n2v_edge_classes_build", "n2v_walk", "n2v_trim_mark", "n2v_sgns_train",
                  "n2v_delta_ref_init", "n2v_delta_pack", "n2v_delta_apply", "n2v_edge_bias", "n2v_alias_draw",
                  "n2v_hops_build", "n2v_cum_index_build", "n2v_walk_uniforms", "n2v_wedge_build",
-                 "n2v_mem_probe", "n2v_corpus_count", "n2v_corpus_index"):
+                 "n2v_mem_probe", "n2v_corpus_count", "n2v_corpus_index", "n2v_hops8_build"):
         assert want in names
 
 
@@ -43,10 +43,10 @@ def test_ctypes_structs_match_header_layout():
     """sizeof / field order of the two structs passed by pointer"""
     from node2vec_amd import _lib
 
-    assert ctypes.sizeof(_lib.Graph) == 13 * 8
+    assert ctypes.sizeof(_lib.Graph) == 15 * 8
     assert [f[0] for f in _lib.Graph._fields_] == ["n_vertices", "n_edges", "rowptr", "col", "w", "w64",
                                                     "slots", "pivots", "edge_classes", "hops", "wedge_off", "wedge_pos",
-                                                    "wedge_wide", "reserved"]
+                                                    "wedge_wide", "reserved", "hops8", "hop8_col_bits", "hop8_row_bits"]
     # the header's field order, read from the header itself
     text = open(os.path.join(ROOT, "include", "n2v_hip.h")).read()
     body = text[text.index("typedef struct n2v_graph {"):text.index("} n2v_graph;")]
