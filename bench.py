@@ -417,7 +417,8 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
         esc = (1 << (64 - cb - rb)) - 1
         share = escape_share(leg)
         alg = 8 + 4 + 16 * share
-        formula = (f"8 (hop entry: neighbour id {cb} bits | its row pointer {rb} bits | degree code "
+        formula = (f"8 (hop entry: neighbour id {cb} bits | its row start {rb} bits"
+                   f"{' (rows padded to 8 entries)' if leg.g.hops8_shift else ''} | degree code "
                    f"{64 - cb - rb} bits) + 4 (path write) + 16 x {share:.3f} (share of the steps whose "
                    f"new vertex has degree >= {esc}: the degree is read from rowptr, cached)")
     elif p == 1.0 and q == 1.0:

@@ -102,9 +102,13 @@ typedef struct n2v_graph {
   const void *wedge_pos;        /* uint16 / uint32 positions, or NULL */
   int32_t wedge_wide;           /* 0: wedge_pos is uint16 (every degree < 65536), 1: uint32 */
   int32_t reserved;             /* 0 (bit 0 set: do not use the all-tables kernel; diagnostics) */
-  const uint64_t *hops8;        /* [n_edges] or NULL: the 8-byte hop table (n2v_hops8_build) */
+  const uint64_t *hops8;        /* the 8-byte hop table (n2v_hops8_build) or NULL */
   int32_t hop8_col_bits;        /* field widths of a hops8 entry, see n2v_hops8_build */
   int32_t hop8_row_bits;
+  const int64_t *hop8_rowptr;   /* [n_vertices + 1] row starts of the hops8 table when its rows are
+                                   padded (hop8_align_shift > 0), else NULL (= rowptr) */
+  int32_t hop8_align_shift;     /* rows of the hops8 table start at multiples of 2^shift entries */
+  int32_t reserved2;            /* 0 */
 } n2v_graph;
 
 /* edge_classes[e] for e = (s -> v): bits 0..23 = number of entries x of N(v) with
@@ -154,15 +158,19 @@ int n2v_edge_classes_build(const n2v_graph *g, uint32_t *classes_out, uint32_t *
 int n2v_hops_build(const n2v_graph *g, struct n2v_hop *hops_out, uint32_t *status, void *stream);
 
 /* The 8-byte hop table of a unit-weight graph for exact walks with p == q == 1 (no class counts
- * needed): hops8_out[e] = col[e] | rowptr[col[e]] << col_bits | code << (col_bits + row_bits),
- * where code = min(degree(col[e]), 2^(64 - col_bits - row_bits) - 1); the top code is an escape:
- * the degree is then read from rowptr (the few high-degree rows: cache-resident).  The chip
- * delivers 50 G random 8-byte gathers per second over a 6 GB table against 40 G 16-byte gathers over
- * 12 GB (profiles/r3v_probe_gathers.log), and a walk step of this kernel IS one such gather.
- * Requires n_vertices <= 2^col_bits, n_edges < 2^row_bits and col_bits + row_bits <= 62
- * (N2V_EINVAL otherwise); the caller stores the widths in n2v_graph. */
-int n2v_hops8_build(const n2v_graph *g, int32_t col_bits, int32_t row_bits, uint64_t *hops8_out,
-                    void *stream);
+ * needed).  Row v of the table starts at entry T[v] = hop8_rowptr ? hop8_rowptr[v] : rowptr[v] (a
+ * multiple of 2^align_shift) and holds, for the k-th neighbour x of v,
+ *   x | (T[x] >> align_shift) << col_bits | code << (col_bits + row_bits),
+ * code = min(degree(x), 2^(64 - col_bits - row_bits) - 1); the top code is an escape: the degree is
+ * then read from rowptr (the few high-degree rows: cache-resident).  The chip delivers ~50 G random
+ * 8-byte gathers per second against ~40 G 16-byte gathers over the table of n2v_hops_build
+ * (profiles/r3v_probe_gathers.log), and a walk step of this kernel IS one such gather.  Padding
+ * the rows (align_shift 3) frees three bits of the row field for the degree code: at cfg 4
+ * (27-bit ids) 9 bits instead of 7, so that the escape rows' rowptr entries fit the L2.
+ * Requires n_vertices <= 2^col_bits, (table entries >> align_shift) < 2^row_bits and
+ * col_bits + row_bits <= 62 (N2V_EINVAL otherwise).  hops8_out: [T[n_vertices]] uint64. */
+int n2v_hops8_build(const n2v_graph *g, int32_t col_bits, int32_t row_bits, int32_t align_shift,
+                    const int64_t *hop8_rowptr, uint64_t *hops8_out, void *stream);
 
 /* Shared-position lists ("wedge table") of a unit-weight graph.  For edge e = (s -> v) the list
  *   wedge_pos[off .. off + n_shared)   off = wedge_off[e] & (2^40 - 1), n_shared = low 24 bits

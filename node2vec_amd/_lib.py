@@ -33,7 +33,8 @@ class Graph(C.Structure):
                 ("edge_classes", C.c_void_p), ("hops", C.c_void_p),
                 ("wedge_off", C.c_void_p), ("wedge_pos", C.c_void_p), ("wedge_wide", C.c_int32),
                 ("reserved", C.c_int32), ("hops8", C.c_void_p), ("hop8_col_bits", C.c_int32),
-                ("hop8_row_bits", C.c_int32)]
+                ("hop8_row_bits", C.c_int32), ("hop8_rowptr", C.c_void_p),
+                ("hop8_align_shift", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class SgnsParams(C.Structure):
@@ -82,7 +83,8 @@ def load():
     L.n2v_hops_build.restype = C.c_int
     L.n2v_hops_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p]
     L.n2v_hops8_build.restype = C.c_int
-    L.n2v_hops8_build.argtypes = [C.POINTER(Graph), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.n2v_hops8_build.argtypes = [C.POINTER(Graph), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]
     L.n2v_pivots_build.restype = C.c_int
     L.n2v_pivots_build.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.n2v_walk.restype = C.c_int

@@ -37,6 +37,8 @@ __global__ __launch_bounds__(256) void hops_build_kernel(n2v_graph g, n2v_hop *_
 
 // the 8-byte form for the p == q == 1 kernel (include/n2v_hip.h, n2v_hops8_build)
 __global__ __launch_bounds__(256) void hops8_build_kernel(n2v_graph g, int col_bits, int row_bits,
+                                                          int align_shift,
+                                                          const int64_t *__restrict__ trow,
                                                           uint64_t *__restrict__ out) {
   const uint64_t esc = (1ull << (64 - col_bits - row_bits)) - 1ull;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < g.n_edges;
@@ -44,26 +46,43 @@ __global__ __launch_bounds__(256) void hops8_build_kernel(n2v_graph g, int col_b
     const int32_t x = g.col[e];
     const int64_t b = g.rowptr[x];
     const uint64_t d = (uint64_t)(g.rowptr[x + 1] - b);
-    out[e] = (uint64_t)(uint32_t)x | ((uint64_t)b << col_bits) |
-             ((d < esc ? d : esc) << (col_bits + row_bits));
+    int64_t at = e;
+    uint64_t start = (uint64_t)b;
+    if (trow) {  // padded rows: the source vertex of edge e, then its slot in the padded table
+      int64_t lo = 0, hi = g.n_vertices;  // last v with rowptr[v] <= e
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (g.rowptr[mid] <= e)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      at = trow[lo] + (e - g.rowptr[lo]);
+      start = (uint64_t)trow[x];
+    }
+    out[at] = (uint64_t)(uint32_t)x | ((start >> align_shift) << col_bits) |
+              ((d < esc ? d : esc) << (col_bits + row_bits));
   }
 }
 
 }  // namespace n2v
 
 extern "C" int n2v_hops8_build(const n2v_graph *g, int32_t col_bits, int32_t row_bits,
+                               int32_t align_shift, const int64_t *hop8_rowptr,
                                uint64_t *hops8_out, void *stream) {
   if (!g || !g->rowptr || g->n_vertices < 0 || g->n_edges < 0) return N2V_EINVAL;
   if (g->w || g->w64) return N2V_EINVAL;  // unit-weight graphs only
   if (col_bits < 1 || row_bits < 1 || col_bits > 31 || col_bits + row_bits > 62) return N2V_EINVAL;
-  if (g->n_vertices > (1ll << col_bits) || g->n_edges >= (1ll << row_bits)) return N2V_EINVAL;
-  if (g->n_edges == 0) return N2V_OK;
+  if (align_shift < 0 || align_shift > 6 || (align_shift > 0 && !hop8_rowptr)) return N2V_EINVAL;
+  if (g->n_vertices > (1ll << col_bits)) return N2V_EINVAL;
+  if (!hop8_rowptr && g->n_edges >= (1ll << row_bits)) return N2V_EINVAL;  // (padded: the caller
+  if (g->n_edges == 0) return N2V_OK;                                       //  checked its own size)
   if (!g->col || !hops8_out) return N2V_EINVAL;
   int64_t blocks = (g->n_edges + 255) / 256;
   const int64_t cap = n2v::resident_blocks((const void *)n2v::hops8_build_kernel, 256, 0) * 2;
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(n2v::hops8_build_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                     (hipStream_t)stream, *g, col_bits, row_bits, hops8_out);
+                     (hipStream_t)stream, *g, col_bits, row_bits, align_shift, hop8_rowptr, hops8_out);
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
 }

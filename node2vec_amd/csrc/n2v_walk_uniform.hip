@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256, 8) void walk_uniform_kernel(
       vb = g.rowptr[v];
       n = (int)(g.rowptr[v + 1] - vb);
       alive = n > 0;  // fugue.py:132
+      if (kHops == 2 && g.hop8_rowptr) vb = g.hop8_rowptr[v];  // the padded table's own row start
     }
     bool walking = alive;
     // absolute word index of path position 0; word a lives in buf[a & 15]
@@ -105,11 +106,11 @@ __global__ __launch_bounds__(256, 8) void walk_uniform_kernel(
           const uint64_t h = g.hops8[vb + pick];
           const int cb = g.hop8_col_bits, rb = g.hop8_row_bits;
           x = (int32_t)(h & ((1ull << cb) - 1ull));
-          vb = (int64_t)((h >> cb) & ((1ull << rb) - 1ull));
+          vb = (int64_t)(((h >> cb) & ((1ull << rb) - 1ull)) << g.hop8_align_shift);
           const uint64_t code = h >> (cb + rb), esc = (1ull << (64 - cb - rb)) - 1ull;
           n = (int)code;
-          if (code == esc) n = (int)(g.rowptr[x + 1] - vb);  // a high-degree row: its degree is
-                                                             // read (few such rows: cached)
+          // a high-degree row: its degree is read from rowptr (few such rows: cached)
+          if (code == esc) n = (int)(g.rowptr[x + 1] - g.rowptr[x]);
         } else if (kHops == 1) {
           const n2v_hop h = load_hop(g.hops + vb + pick);
           x = h.col;
@@ -155,7 +156,8 @@ extern "C" int n2v_walk_uniform_try(const n2v_graph *g, const int32_t *start_ids
   int64_t blocks = (total + 255) / 256;
   const int form = g->hops8 ? 2 : (g->hops ? 1 : 0);
   if (form == 2 && (g->hop8_col_bits < 1 || g->hop8_row_bits < 1 ||
-                    g->hop8_col_bits + g->hop8_row_bits > 62))
+                    g->hop8_col_bits + g->hop8_row_bits > 62 || g->hop8_align_shift < 0 ||
+                    g->hop8_align_shift > 6 || (g->hop8_align_shift > 0 && !g->hop8_rowptr)))
     return N2V_EINVAL;
   const void *fn = form == 2   ? (const void *)n2v::walk_uniform_kernel<2>
                    : form == 1 ? (const void *)n2v::walk_uniform_kernel<1>

@@ -39,6 +39,8 @@ class DeviceGraph:
         self.hops_have_classes = False
         self.hops8: Optional[torch.Tensor] = None  # int64 [E]: 8-byte hop entries (p = q = 1 walks)
         self.hops8_bits = (0, 0)  # (col_bits, row_bits) of a hops8 entry
+        self.hops8_rowptr: Optional[torch.Tensor] = None  # int64 [V + 1]: padded rows of the hops8 table
+        self.hops8_shift = 0
         self.hops8_tried = False
         self.wedge_off: Optional[torch.Tensor] = None  # int64 [E]: list offset | return position << 40
         self.wedge_pos: Optional[torch.Tensor] = None  # int16 / int32 [sum of shared counts]
@@ -131,12 +133,13 @@ class DeviceGraph:
     def to(self, device) -> "DeviceGraph":
         g = DeviceGraph(self.rowptr.to(device), self.col.to(device),
                         None if self._w is None else self._w.to(device))
-        for name in ("slots", "pivots", "edge_classes", "hops", "hops8", "wedge_off", "wedge_pos"):
+        for name in ("slots", "pivots", "edge_classes", "hops", "hops8", "hops8_rowptr", "wedge_off",
+                     "wedge_pos"):
             t = getattr(self, name)
             if t is not None:
                 setattr(g, name, t.to(device))
         g.hops_have_classes = self.hops_have_classes
-        g.hops8_bits = self.hops8_bits
+        g.hops8_bits, g.hops8_shift = self.hops8_bits, self.hops8_shift
         return g
 
     def c_struct(self) -> _lib.Graph:
@@ -153,7 +156,9 @@ class DeviceGraph:
                           0 if self.wedge_pos is None else self.wedge_pos.data_ptr(),
                           0 if self.wedge_pos is None else int(self.wedge_pos.dtype == torch.int32), 0,
                           0 if self.hops8 is None else self.hops8.data_ptr(),
-                          self.hops8_bits[0], self.hops8_bits[1])
+                          self.hops8_bits[0], self.hops8_bits[1],
+                          0 if self.hops8_rowptr is None else self.hops8_rowptr.data_ptr(),
+                          self.hops8_shift, 0)
 
     # -- a9 -----------------------------------------------------------------------
     def trimmed(self, max_out_degree: int, seed: int) -> "DeviceGraph":
@@ -291,37 +296,58 @@ class DeviceGraph:
         self.hops_have_classes = self.edge_classes is not None
         return self
 
-    HOP8_MAX_ESCAPE_BYTES = 4 << 20  # rowptr bytes of the rows whose degree does not fit the entry
+    HOP8_MAX_ESCAPE_BYTES = 2 << 20  # rowptr sectors of the rows whose degree does not fit the entry
 
     def build_hops8(self, force: bool = False, col_bits: Optional[int] = None,
-                    row_bits: Optional[int] = None) -> "DeviceGraph":
+                    row_bits: Optional[int] = None, align_shift: Optional[int] = None) -> "DeviceGraph":
         """The 8-byte hop table (n2v_hops8_build) for exact walks with p == q == 1: neighbour id,
-        its row pointer and (a code for) its degree in ONE 8-byte gather -- the chip serves those a
-        quarter faster than the 16-byte entries of build_hops (table half the size).  Field
-        widths follow the graph (cfg 4: 27 + 30 + 7 bits); a degree that does not fit its field
-        is read from rowptr, which pays as long as those rows are few enough to stay cached: the
-        table is built when their rowptr entries span <= 4 MB (or `force`)."""
+        its row start and (a code for) its degree in ONE 8-byte gather -- the chip serves those a
+        quarter faster than the 16-byte entries of build_hops.  Field widths follow the graph; a
+        degree that does not fit its field is read from rowptr, which pays as long as the rowptr
+        sectors of those rows stay cached (<= HOP8_MAX_ESCAPE_BYTES).  First choice: rows as in
+        the CSR (cfg 3: 24 + 28 + 12 bits).  When the degree field is then too narrow (cfg 4:
+        27 + 30 + 7 bits, 4 x 10^5 escape rows) the rows of the table are padded to multiples of
+        8 entries, which frees 3 bits of the row field for the degree (27 + 28 + 9)."""
         L = _lib.load()
         _lib.require_gpu()
-        self.hops8 = None
+        self.hops8 = self.hops8_rowptr = None
         self.hops8_tried = True
         if not self.unit_weights or not self.rowptr.is_cuda or self.n_edges == 0:
             return self
-        col_bits = int(col_bits or max(1, int(self.n_vertices - 1).bit_length()))  # (tests pass wider
-        row_bits = int(row_bits or max(1, int(self.n_edges).bit_length()))         # fields: more escapes)
-        if col_bits > 31 or col_bits + row_bits > 62:
+        deg = self.degrees()
+        cb = int(col_bits or max(1, int(self.n_vertices - 1).bit_length()))  # (tests pass wider fields:
+        if cb > 31:                                                           #  more escapes)
             return self
-        esc = (1 << (64 - col_bits - row_bits)) - 1
-        if not force:
-            n_escape = int((self.degrees() >= esc).sum())
-            if n_escape * 16 > self.HOP8_MAX_ESCAPE_BYTES:
-                return self
-        hops8 = torch.empty(self.n_edges, dtype=torch.int64, device=self.device)
-        with torch.cuda.device(self.device):
-            rc = L.n2v_hops8_build(self.c_struct(), col_bits, row_bits, hops8.data_ptr(),
-                                   _lib.current_stream_ptr())
-        _lib.check(rc, "n2v_hops8_build")
-        self.hops8, self.hops8_bits = hops8, (col_bits, row_bits)
+
+        def escape_bytes(esc):
+            # the escape reads rowptr[x], rowptr[x + 1]: what must stay cached are the 64-byte
+            # sectors of rowptr holding such x (dense when the big vertices have neighbouring ids)
+            hub = torch.nonzero(deg >= esc).reshape(-1)
+            if hub.numel() == 0:
+                return 0
+            return int(torch.unique(torch.cat([hub >> 3, (hub + 1) >> 3])).numel()) * 64
+
+        for shift in ((0, 3) if align_shift is None else (int(align_shift),)):
+            if shift == 0:
+                trow, entries = None, self.n_edges
+            else:
+                pad = (1 << shift) - 1
+                trow = torch.zeros(self.n_vertices + 1, dtype=torch.int64, device=self.device)
+                torch.cumsum((deg + pad) & ~pad, 0, out=trow[1:])
+                entries = int(trow[-1])
+            rb = int(row_bits or max(1, int(entries >> shift).bit_length()))
+            if cb + rb > 62 or (entries >> shift) >= (1 << rb):
+                continue
+            esc = (1 << (64 - cb - rb)) - 1
+            if not force and escape_bytes(esc) > self.HOP8_MAX_ESCAPE_BYTES:
+                continue
+            hops8 = torch.zeros(entries, dtype=torch.int64, device=self.device)
+            with torch.cuda.device(self.device):
+                rc = L.n2v_hops8_build(self.c_struct(), cb, rb, shift, 0 if trow is None else trow.data_ptr(),
+                                       hops8.data_ptr(), _lib.current_stream_ptr())
+            _lib.check(rc, "n2v_hops8_build")
+            self.hops8, self.hops8_bits, self.hops8_rowptr, self.hops8_shift = hops8, (cb, rb), trow, shift
+            return self
         return self
 
     def build_pivots(self) -> "DeviceGraph":

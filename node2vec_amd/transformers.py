@@ -93,7 +93,7 @@ def _build_tables(rowptr: torch.Tensor, ids: torch.Tensor, w64: torch.Tensor) ->
     slots = torch.zeros((max(nnz, 1), 4), dtype=torch.int32, device=dev)
     status = torch.zeros(4, dtype=torch.int32, device=dev)
     g = _lib.Graph(rowptr.numel() - 1, nnz, rowptr.data_ptr(), ids.data_ptr(), 0, w64.data_ptr(),
-                   0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+                   0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
     with torch.cuda.device(dev):
         rc = L.n2v_alias_build(g, slots.data_ptr(), status.data_ptr(), _lib.current_stream_ptr())
     _lib.check(rc, "n2v_alias_build")

@@ -43,10 +43,11 @@ def test_ctypes_structs_match_header_layout():
     """sizeof / field order of the two structs passed by pointer"""
     from node2vec_amd import _lib
 
-    assert ctypes.sizeof(_lib.Graph) == 15 * 8
+    assert ctypes.sizeof(_lib.Graph) == 17 * 8
     assert [f[0] for f in _lib.Graph._fields_] == ["n_vertices", "n_edges", "rowptr", "col", "w", "w64",
                                                     "slots", "pivots", "edge_classes", "hops", "wedge_off", "wedge_pos",
-                                                    "wedge_wide", "reserved", "hops8", "hop8_col_bits", "hop8_row_bits"]
+                                                    "wedge_wide", "reserved", "hops8", "hop8_col_bits", "hop8_row_bits",
+                                                    "hop8_rowptr", "hop8_align_shift", "reserved2"]
     # the header's field order, read from the header itself
     text = open(os.path.join(ROOT, "include", "n2v_hip.h")).read()
     body = text[text.index("typedef struct n2v_graph {"):text.index("} n2v_graph;")]

@@ -188,11 +188,12 @@ def test_hop_table_and_class_counts_change_no_bit(oracle, pq):
     assert torch.equal(fa, fb) and torch.equal(fav, fbv) and torch.equal(fa, fc) and torch.equal(fav, fcv)
 
 
-@pytest.mark.parametrize("bits", [(31, 27), (28, 31), (None, None)])
+@pytest.mark.parametrize("bits", [(31, 30, 0), (29, 31, 0), (None, None, 0), (None, None, 3), (31, 28, 3)])
 def test_hop8_table_changes_no_bit_with_and_without_escapes(oracle, bits):
-    """the 8-byte hop table of the p = q = 1 kernel: with wide id / row fields the degree field is
-    4 or 3 bits and most rows take the escape (degree read from rowptr); same walks as the 16-byte
-    table, the CSR arrays and the oracle -- sinks, hubs, multi-edges, walk length 0 and 1"""
+    """the 8-byte hop table of the p = q = 1 kernel, rows as in the CSR (shift 0) or padded to
+    multiples of 8 entries (shift 3): with wide id / row fields the degree field is 3 to 5 bits and
+    many rows take the escape (degree read from rowptr); same walks as the 16-byte table, the CSR
+    arrays and the oracle -- sinks, hubs, multi-edges, walk length 0 and 1"""
     from node2vec_amd import randomwalk as rw
     from node2vec_amd.graph import DeviceGraph
 
@@ -201,28 +202,32 @@ def test_hop8_table_changes_no_bit_with_and_without_escapes(oracle, bits):
     src = np.concatenate([rng.integers(0, nv - 60, 30000), rng.integers(0, 10, 12000), rng.integers(0, nv - 60, 9000)])
     dst = np.concatenate([rng.integers(0, nv, 30000), rng.integers(0, nv, 12000), rng.integers(0, 10, 9000)])
     g = DeviceGraph.from_edges(src, dst, None, n_vertices=nv, device="cuda")
-    g.build_hops8(force=True, col_bits=bits[0], row_bits=bits[1])
-    assert g.hops8 is not None
+    g.build_hops8(force=True, col_bits=bits[0], row_bits=bits[1], align_shift=bits[2])
+    assert g.hops8 is not None and g.hops8_shift == bits[2]
     cb, rb = g.hops8_bits
     esc = (1 << (64 - cb - rb)) - 1
-    deg = g.degrees()
+    deg = g.degrees().cpu().numpy()
     if bits[0] is not None:
         assert int((deg >= esc).sum()) > 100  # the escape is exercised
     h = g.hops8.cpu().numpy().astype(np.uint64)
-    col = g.col.cpu().numpy()
-    assert np.array_equal((h & np.uint64((1 << cb) - 1)).astype(np.int64), col.astype(np.int64))
-    assert np.array_equal(((h >> np.uint64(cb)) & np.uint64((1 << rb) - 1)).astype(np.int64),
-                          g.rowptr.cpu().numpy()[col])
-    assert np.array_equal((h >> np.uint64(cb + rb)).astype(np.int64),
-                          np.minimum(deg.cpu().numpy()[col], esc))
+    col, rowptr = g.col.cpu().numpy(), g.rowptr.cpu().numpy()
+    trow = rowptr if g.hops8_rowptr is None else g.hops8_rowptr.cpu().numpy()
+    if bits[2]:
+        assert np.all(trow % 8 == 0) and np.all(np.diff(trow) >= deg) and np.all(np.diff(trow) < deg + 8)
+    src_of = np.repeat(np.arange(nv), deg)
+    at = trow[src_of] + (np.arange(col.size) - rowptr[src_of])
+    he = h[at]
+    assert np.array_equal((he & np.uint64((1 << cb) - 1)).astype(np.int64), col.astype(np.int64))
+    assert np.array_equal(((he >> np.uint64(cb)) & np.uint64((1 << rb) - 1)).astype(np.int64),
+                          trow[col] >> bits[2])
+    assert np.array_equal((he >> np.uint64(cb + rb)).astype(np.int64), np.minimum(deg[col], esc))
     start = rw.start_vertices(g)
     for L in (0, 1, 30):
         a, av = rw.walk(g, start, 3, L, 1.0, 1.0, 4)
         b, bv = rw.walk(g, start, 3, L, 1.0, 1.0, 4, use_hops8=False)
         c, cv = rw.walk(g, start, 3, L, 1.0, 1.0, 4, use_hops=False)
         assert torch.equal(a, b) and torch.equal(av, bv) and torch.equal(a, c) and torch.equal(av, cv)
-    want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), col, None, start.cpu().numpy(), 3, 30, 1.0, 1.0, 4,
-                                  n_threads=8)
+    want, wv = oracle.random_walk(rowptr, col, None, start.cpu().numpy(), 3, 30, 1.0, 1.0, 4, n_threads=8)
     assert np.array_equal(av.cpu().numpy(), wv) and np.array_equal(a.cpu().numpy()[wv], want[wv])
     assert not wv.all()
 
