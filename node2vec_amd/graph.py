@@ -296,18 +296,23 @@ class DeviceGraph:
         self.hops_have_classes = self.edge_classes is not None
         return self
 
-    HOP8_MAX_ESCAPE_BYTES = 2 << 20  # rowptr sectors of the rows whose degree does not fit the entry
+    # Measured (profiles/r3x_time_hop8_*.log): with 0 - 11 % of the steps taking the escape the 8-byte
+    # table walks cfg 3 at 51.5 - 51.8 G steps/s against 45.7 G for the 16-byte table; with 26 - 39 %
+    # (cfg 4: 27-bit ids leave 7 - 9 bits for the degree) it LOSES, 37.4 - 38.3 G against 42.7 G --
+    # the second, dependent lookup costs more than the narrower gather saves.
+    HOP8_MAX_ESCAPE_SHARE = 0.12
 
     def build_hops8(self, force: bool = False, col_bits: Optional[int] = None,
                     row_bits: Optional[int] = None, align_shift: Optional[int] = None) -> "DeviceGraph":
         """The 8-byte hop table (n2v_hops8_build) for exact walks with p == q == 1: neighbour id,
         its row start and (a code for) its degree in ONE 8-byte gather -- the chip serves those a
         quarter faster than the 16-byte entries of build_hops.  Field widths follow the graph; a
-        degree that does not fit its field is read from rowptr, which pays as long as the rowptr
-        sectors of those rows stay cached (<= HOP8_MAX_ESCAPE_BYTES).  First choice: rows as in
-        the CSR (cfg 3: 24 + 28 + 12 bits).  When the degree field is then too narrow (cfg 4:
-        27 + 30 + 7 bits, 4 x 10^5 escape rows) the rows of the table are padded to multiples of
-        8 entries, which frees 3 bits of the row field for the degree (27 + 28 + 9)."""
+        degree that does not fit its field is read from rowptr (the "escape"), which pays only
+        while few steps take it (HOP8_MAX_ESCAPE_SHARE).  First choice: rows as in the CSR (cfg 3:
+        24 + 28 + 12 bits); second: rows padded to multiples of 8 entries, which frees 3 bits of
+        the row field for the degree (cfg 3: 24 + 25 + 15, no escape at all).  cfg 4's 27-bit ids
+        leave 7 - 9 bits: a quarter to a third of the steps would escape, and the graph keeps the
+        16-byte table."""
         L = _lib.load()
         _lib.require_gpu()
         self.hops8 = self.hops8_rowptr = None
@@ -319,13 +324,10 @@ class DeviceGraph:
         if cb > 31:                                                           #  more escapes)
             return self
 
-        def escape_bytes(esc):
-            # the escape reads rowptr[x], rowptr[x + 1]: what must stay cached are the 64-byte
-            # sectors of rowptr holding such x (dense when the big vertices have neighbouring ids)
-            hub = torch.nonzero(deg >= esc).reshape(-1)
-            if hub.numel() == 0:
-                return 0
-            return int(torch.unique(torch.cat([hub >> 3, (hub + 1) >> 3])).numel()) * 64
+        def escape_share(esc):
+            # share of the walk steps that would take the escape (a walk on an undirected graph
+            # visits a vertex in proportion to its degree)
+            return float(deg[deg >= esc].sum()) / max(self.n_edges, 1)
 
         for shift in ((0, 3) if align_shift is None else (int(align_shift),)):
             if shift == 0:
@@ -339,7 +341,7 @@ class DeviceGraph:
             if cb + rb > 62 or (entries >> shift) >= (1 << rb):
                 continue
             esc = (1 << (64 - cb - rb)) - 1
-            if not force and escape_bytes(esc) > self.HOP8_MAX_ESCAPE_BYTES:
+            if not force and escape_share(esc) > self.HOP8_MAX_ESCAPE_SHARE:
                 continue
             hops8 = torch.zeros(entries, dtype=torch.int64, device=self.device)
             with torch.cuda.device(self.device):
