@@ -55,4 +55,7 @@ HIP_SGNS_PARAMS: Dict[str, Any] = {
     "sample": 1e-3,
     "min_alpha": 1e-4,
     "ns_exponent": 0.75,
+    # options of the HIP trainer that gensim does not have (all off = gensim's semantics):
+    "batched": False,   # True: negatives shared by the pairs of a centre position (MFMA kernel)
+    "hub_rows": 0,      # > 0: atomic adds on the most frequent rows in hogwild mode
 }

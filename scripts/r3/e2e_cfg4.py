@@ -25,7 +25,17 @@ seed_ids = None
 if frac < 1.0:
     seed_ids = start[: int(frac * start.numel())]
 timings = {}
+import threading
+
+
+def heartbeat():  # gpurun kills a command that is silent for 7 minutes
+    while True:
+        time.sleep(60)
+        print(f"[e2e] {time.perf_counter() - t0:.0f} s", file=sys.stderr, flush=True)
+
+
 t0 = time.perf_counter()
+threading.Thread(target=heartbeat, daemon=True).start()
 model = fit_streaming(g, {"num_walks": 10, "walk_length": 80, "return_param": 1.0, "inout_param": 1.0},
                       {"size": 128, "window": 5, "negative": 5, "iter": 1, "sample": 0, "min_count": 0,
                        "seed": 1, "batched": mode == "batched"},
