@@ -32,6 +32,7 @@
 namespace n2v {
 
 constexpr int kBWaves = 2;        // waves per block (LDS: ~16 KB per wave at dim 128)
+constexpr int kBExpTable = 1000;  // EXP_TABLE_SIZE
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -151,26 +152,18 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
   const int hub_rows = hogwild ? P.hub_rows : 0;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // sigma comes from the caller's 1000-entry table in global memory (4 KB: L1-resident); keeping a
-  // copy per block in LDS cost a block of LDS per CU
-  const float *exp_lds = exp_table_g;
+  float *exp_lds = reinterpret_cast<float *>(smem);
   const int wave_in_block = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int j16 = lane & 15, g4 = lane >> 4;
-  // the 16 x 16 transpose scratch of G lives in rows 6 and 7 of the target tile when those are
-  // free (8-row tile, at most 5 negatives: 4 G rows of 17 floats per plane), else behind the tiles
-  const bool gs_in_tile = TROWS == 8 && K <= 5;
-  const int per_wave_floats = 4 * PR + 4 * PT + (gs_in_tile ? 0 : 16 * 17);
+  constexpr int per_wave_floats = 4 * PR + 4 * PT + 16 * 17;
   const int per_wave_ints = (2 * walk_len + walk_len * PL + 32 + (own_negw ? walk_len * K : 0) + 3) & ~3;
-  unsigned char *mine = smem +
+  unsigned char *mine = smem + kBExpTable * sizeof(float) +
                         (size_t)wave_in_block * ((size_t)per_wave_floats + per_wave_ints) * 4;
   float *ring = reinterpret_cast<float *>(mine);
   float *tgt = ring + 4 * PR;
   float *gs = tgt + 4 * PT;
-  auto gs_at = [&](int m, int n) -> float * {
-    return gs_in_tile ? tgt + (m >> 2) * PT + 6 * RS + (m & 3) * 17 + n : gs + m * 17 + n;
-  };
-  int32_t *sent = reinterpret_cast<int32_t *>(ring + per_wave_floats);
+  int32_t *sent = reinterpret_cast<int32_t *>(gs + 16 * 17);
   int32_t *red = sent + walk_len;
   // the plan of a sentence, per position i: [0 .. K] the target words (centre, then the distinct
   // negatives != centre in draw order), [K + 1 ..] their multiplicities (4 bits each), then one
@@ -181,6 +174,8 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
   // the raw draws are only needed until the plan is built: they borrow the two row tiles (long
   // sentences with many negatives that do not fit there get their own area)
   int32_t *negw = own_negw ? mmultM + 16 : reinterpret_cast<int32_t *>(ring);
+  for (int i = threadIdx.x; i < kBExpTable; i += blockDim.x) exp_lds[i] = exp_table_g[i];
+  __syncthreads();
 
   const uint32_t domain = cum_table[P.n_vocab - 1];
   const int waves_per_block = blockDim.x >> 6;
@@ -469,12 +464,12 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
           const int e = live ? (int)((fv + 6.0f) * 83.0f) : 0;
           const float gg = ((label - exp_lds[e]) * alpha) * (float)mult;
           gv[rI] = live ? gg : 0.0f;
-          *gs_at(m, j16) = gv[rI];
+          gs[m * 17 + j16] = gv[rI];
         }
         wave_sync();
         float ga[KT];  // A operand of Ctx += G . Tgt: G[m = l & 15][column 4 g + s]
 #pragma unroll
-        for (int s = 0; s < KT; ++s) ga[s] = *gs_at(j16, 4 * g4 + s);
+        for (int s = 0; s < KT; ++s) ga[s] = gs[j16 * 17 + 4 * g4 + s];
         int toff[4];  // the same vector of the target row of tile column 4 g4 + r (row 0: none)
 #pragma unroll
         for (int rI = 0; rI < 4; ++rI) {
@@ -633,8 +628,7 @@ extern "C" int n2v_sgns_batched_launch(const int32_t *walks, int64_t n_walks, in
   const int PR = bank_half_stride((rrows + 1) * RS), PT = bank_half_stride(trows * RS);
   const int own_negw = (size_t)walk_len * P->negative > (size_t)4 * (PR + PT);  // else they borrow the tiles
   const int PL = P->negative + 1 + (trows == 8 ? 1 : 2) + 1;
-  const bool gs_in_tile = trows == 8 && P->negative <= 5;
-  const size_t per_wave = ((size_t)(4 * PR + 4 * PT + (gs_in_tile ? 0 : 16 * 17)) +
+  const size_t per_wave = ((size_t)(4 * PR + 4 * PT + 16 * 17) +
                            (size_t)((2 * walk_len + walk_len * PL + 32 + (own_negw ? walk_len * P->negative : 0) + 3) & ~3)) * 4;
   int64_t waves = P->n_vocab / 32;
   if (waves < 1) waves = 1;
@@ -643,7 +637,7 @@ extern "C" int n2v_sgns_batched_launch(const int32_t *walks, int64_t n_walks, in
   int wpb = kBWaves;
   if (P->deterministic || waves < wpb) wpb = 1;
   if (P->deterministic) waves = 1;
-  const size_t lds = (size_t)wpb * per_wave;
+  const size_t lds = kBExpTable * sizeof(float) + (size_t)wpb * per_wave;
   if (lds > 160 * 1024) return N2V_EINVAL;
   int64_t blocks = (waves + wpb - 1) / wpb;
   hipStream_t st = (hipStream_t)stream;
