@@ -191,11 +191,53 @@ class RankState:
         self.walkers = Walkers(head, torch.zeros(rows.numel() + 1, dtype=torch.int64, device=dev),
                                torch.zeros(0, dtype=torch.int32, device=dev))
 
+    # -- the reference's defaults on a unit-weight graph: no table, no travelling row -------------
+    def _advance_uniform(self, n_parts: int) -> List[Walkers]:
+        """p == q == 1 and every weight 1.0: the table of every step is probs == [1.0] * n
+        (randomwalk.py:172-173), sampling_from_alias never takes the alias and returns
+        pick = int(r1 * n) (:95) -- exactly what n2v_walk's p == q == 1 kernel computes.  The
+        previous vertex's row is not needed, so the walker travels as its 32-byte header alone."""
+        from node2vec_amd import _lib
+
+        part, dev, wk = self.part, self.part.device, self.walkers
+        rows, keys, sv, step = wk.head[:, 0], wk.head[:, 1], wk.head[:, 2], wk.head[:, 3]
+        v = sv & 0xffffffff
+        local = v - part.lo
+        b = part.rowptr[local]
+        n = part.rowptr[local + 1] - b
+        k = keys.contiguous()
+        st = step.to(torch.int32).contiguous()
+        r1 = torch.empty(len(wk), dtype=torch.float64, device=dev)
+        r2 = torch.empty(len(wk), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().n2v_walk_uniforms(int(self.seed) & (2 ** 64 - 1), k.data_ptr(),
+                                                     st.data_ptr(), len(wk), r1.data_ptr(),
+                                                     r2.data_ptr(), _lib.current_stream_ptr()),
+                       "n2v_walk_uniforms")
+        pick = (r1 * n.double()).floor().long()  # the reference's fp64 product, then int()
+        nxt = part.col[b + pick].to(torch.int64)
+        self.log.append(torch.stack([rows, step + 1, nxt], 1))
+        keep = step + 1 < self.L
+        head = torch.stack([rows, keys, (v << 32) | nxt, step + 1], 1)[keep]
+        dest = part.owner(nxt[keep])
+        order = torch.argsort(dest, stable=True)
+        counts = torch.bincount(dest, minlength=n_parts).tolist()
+        out, at = [], 0
+        for r in range(n_parts):
+            h = head[order[at:at + counts[r]]]
+            at += counts[r]
+            out.append(Walkers(h, torch.zeros(h.shape[0] + 1, dtype=torch.int64, device=dev),
+                               torch.zeros(0, dtype=torch.int32, device=dev)))
+        return out
+
     # -- one step of every resident walker; returns the migrating walkers per destination -----
     def advance(self, n_parts: int) -> List[Walkers]:
         part, dev, wk = self.part, self.part.device, self.walkers
         if len(wk) == 0:
             return [Walkers.empty(dev) for _ in range(n_parts)]
+        if (part.w is None and self.p == 1.0 and self.q == 1.0 and self.step_fn is hip_step
+                and part.rowptr.is_cuda):
+            return self._advance_uniform(n_parts)
         rows, keys, sv, step = wk.head[:, 0], wk.head[:, 1], wk.head[:, 2], wk.head[:, 3]
         s = (sv >> 32).to(torch.int32)
         v = (sv & 0xffffffff).to(torch.int64)
