@@ -625,27 +625,24 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist)
     # the same launches with atomic adds on the 4096 most frequent rows (n2v_sgns_params.hub_rows):
     # what hogwild loses on hubs at 8192 concurrent waves comes back (cfg 2 link AUC 0.897 -> 0.909,
     # profiles/r3k_hogwild_auc_hub_rows.log) for this much throughput
-    model.hub_rows = 0 if args.no_hub else 4096
-    try:
-        if args.no_hub:
-            raise StopIteration
-        model.train_block(idx, 0.025, 50 * rows)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        p0 = float(model.pairs.item())
-        for k in range(args.steps):
-            model.train_block(idx, 0.025, (60 + k + rank * 1000) * rows)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        res["hub_rows_4096"] = {"value": (float(model.pairs.item()) - p0) / dt,
-                                "unit": "embedding-updates/s on this GPU",
-                                "ms_per_step": 1e3 * dt / args.steps,
-                                "what": "rows [0, 4096) of syn0 / syn1neg updated by atomic adds (hogwild "
-                                        "only); opt-in (w2v_params['hub_rows'])"}
-    except StopIteration:
-        pass
-    finally:
-        model.hub_rows = 0
+    if not args.no_hub:
+        model.hub_rows = 4096
+        try:
+            model.train_block(idx, 0.025, 50 * rows)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            p0 = float(model.pairs.item())
+            for k in range(args.steps):
+                model.train_block(idx, 0.025, (60 + k + rank * 1000) * rows)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res["hub_rows_4096"] = {"value": (float(model.pairs.item()) - p0) / dt,
+                                    "unit": "embedding-updates/s on this GPU",
+                                    "ms_per_step": 1e3 * dt / args.steps,
+                                    "what": "rows [0, 4096) of syn0 / syn1neg updated by atomic adds (hogwild "
+                                            "only); opt-in (w2v_params['hub_rows'])"}
+        finally:
+            model.hub_rows = 0
     if not args.no_batched and dim in (64, 128, 256):
         res["batched"] = bench_sgns_batched(args, torch, dist, model, idx, rows, rank, barrier,
                                             use_dist, dev, dim)
