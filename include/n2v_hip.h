@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define N2V_ABI_VERSION 6
+#define N2V_ABI_VERSION 7
 
 #define N2V_OK 0
 #define N2V_EINVAL (-1)  /* maps to ValueError (randomwalk.py:212-217)      */
@@ -387,6 +387,30 @@ int n2v_corpus_count(const int32_t *walks, const uint8_t *valid, int64_t n_rows,
                      int64_t n_vertices, unsigned long long *counts, void *stream);
 int n2v_corpus_index(const int32_t *walks, const uint8_t *valid, const int32_t *index_of,
                      int64_t n_rows, int32_t len, int64_t n_vertices, int32_t *idx_out, void *stream);
+
+/* Graph-partitioned walking (node2vec_amd/partitioned.py): one step of the k
+ * walkers resident on ONE part of a vertex-range partition -- the reference's per-step join
+ * (fugue.py:146-149: walker row x adjacency row of its current vertex, the row of its previous
+ * vertex carried along) followed by next_step_random_walk (randomwalk.py:300-339), in one launch,
+ * one wave per walker, no table materialised.
+ *   rowptr / col / w / w64   the part's rows [lo, lo + n_local) (rowptr rebased to 0; ids global;
+ *                            at most one of w, w64; both NULL = unit weights)
+ *   head      int64 [k][4] = (output row, RNG key = start * num_walks + ordinal - 1,
+ *             s << 32 | v, step); s = -1 (high word all ones) on the first step (:320-321)
+ *   src_ptr / src_ids        the travelling rows N(s), packed (int64 [k + 1], sorted ids); read
+ *                            only when q != 1 and s >= 0, may be NULL otherwise
+ *   next_out  int32 [k]: the vertex drawn (-1 when status reports an error for that walker)
+ *   status    uint32 [4] as for n2v_walk; [1] is used as the walker counter.
+ * Draws are those of n2v_walk's exact mode (same stream keyed by (seed, key, step)), so walks are
+ * bit-identical to n2v_walk over the unpartitioned graph wherever the walker happens to be.
+ *   n2v_gather_rows  out[out_ptr[j] ..) = ids[ptr[rows[j]] .. ptr[rows[j] + 1]) for j < k: packs
+ *                    the rows that leave with migrating walkers (out_ptr = their prefix sums). */
+int n2v_partition_step(const int64_t *rowptr, const int32_t *col, const float *w, const double *w64,
+                       int64_t lo, int64_t n_local, const int64_t *head, const int64_t *src_ptr,
+                       const int32_t *src_ids, int64_t k, double p, double q, uint64_t seed,
+                       int32_t *next_out, uint32_t *status, void *stream);
+int n2v_gather_rows(const int64_t *ptr, const int32_t *ids, const int64_t *rows,
+                    const int64_t *out_ptr, int64_t k, int32_t *out, void *stream);
 
 /* Measurement aid (bench.py; nothing on the product path calls it): the rate this device
  * sustains for the access shapes of K2 and K3 on the CALLER's buffer, so that the ceilings the

@@ -31,6 +31,34 @@ inline int64_t resident_blocks(const void *kernel, int block_threads, size_t dyn
   return (int64_t)cus * per_cu;
 }
 
+// Work distribution of a short single-step launch (n2v_partition_step): k items, a few per wave.
+// One atomic per item on one counter costs ~12 ns each, serialised (118 k items: 1.4 ms, more than
+// the work), so three quarters of the items are dealt statically, interleaved over the waves, and
+// only the last quarter -- which evens out the differences in cost -- comes from the counter, two
+// at a time.  Wave-uniform; `counter` must be zero at launch.
+struct ItemQueue {
+  int64_t k, n_waves, wave_id, per, j, base;
+  uint32_t left;
+  __device__ __forceinline__ ItemQueue(int64_t items, int waves_per_block)
+      : k(items), n_waves((int64_t)gridDim.x * waves_per_block),
+        wave_id((int64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6)), j(0), base(0), left(0) {
+    per = (k - k / 4) / n_waves;
+  }
+  // next item of this wave, or -1 when there is none left
+  __device__ __forceinline__ int64_t next(uint32_t *counter, int lane) {
+    if (j < per) return wave_id + (j++) * n_waves;
+    if (left == 0) {
+      uint32_t t = 0;
+      if (lane == 0) t = atomicAdd(counter, 2u);
+      base = per * n_waves + (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+      left = 2;
+    }
+    --left;
+    const int64_t i = base++;
+    return i < k ? i : -1;
+  }
+};
+
 // splitmix64 finaliser; the uniform stream of DESIGN.md "RNG".
 __host__ __device__ inline uint64_t mix64(uint64_t z) {
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;

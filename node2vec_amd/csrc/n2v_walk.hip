@@ -561,6 +561,102 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
 #endif
 }
 
+
+// ---- one step of a batch of MIGRATING walkers (graph-partitioned walking) --------
+// The reference joins every walker row with the adjacency row of its current vertex and carries
+// the row of its previous vertex along (fugue.py:146-149), then calls next_step_random_walk on
+// the joined row.  This is that call for the walkers resident on one part of a vertex-range
+// partition: N(v) is read from the part's own CSR (rows [lo, lo + n_local)), N(s) from the
+// packed rows that travelled with the walkers, and the draw is exact_draw above -- the same
+// table, the same uniforms (keyed by walker and step, not by where the walker is), hence the
+// same vertex as n2v_walk on the whole graph.  One wave per walker, taken from a counter.
+// head: int64 [k, 4] = (output row, RNG key, s << 32 | v, step); s == -1 on the first step.
+__global__ __launch_bounds__(kWavesPerBlock * 64) void partition_step_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ w, const double *__restrict__ w64, int64_t lo, int64_t n_local,
+    const int64_t *__restrict__ head, const int64_t *__restrict__ src_ptr,
+    const int32_t *__restrict__ src_ids, int64_t k, double p, double q, uint64_t seed,
+    int32_t *__restrict__ next_out, uint32_t *__restrict__ status) {
+  __shared__ WaveLds lds_all[kWavesPerBlock];
+  const int lane = threadIdx.x & 63;
+  WaveLds &L = lds_all[threadIdx.x >> 6];
+#ifdef N2V_STATS
+  WaveStats WS;
+  for (int i = 0; i < 40; ++i) WS.v[i] = 0;
+#endif
+  StepCtx c;
+  c.p = p;
+  c.q = q;
+  ItemQueue queue(k, kWavesPerBlock);
+  for (;;) {
+    const int64_t i = queue.next(&status[1], lane);
+    if (i < 0) break;
+    const uint64_t key = (uint64_t)readfirstlane_i64(head[4 * i + 1]);
+    const int64_t sv = readfirstlane_i64(head[4 * i + 2]);
+    const uint32_t step = (uint32_t)readfirstlane_i64(head[4 * i + 3]);
+    const int32_t s = (int32_t)(sv >> 32);
+    const int64_t local = (int64_t)(uint32_t)sv - lo;
+    int32_t next = -1;
+    if (local < 0 || local >= n_local) {  // a walker that is not resident here
+      if (lane == 0) atomicOr(status, N2V_ST_RANGE);
+    } else {
+      const int64_t vb = readfirstlane_i64(rowptr[local]);
+      const int n = (int)(readfirstlane_i64(rowptr[local + 1]) - vb);
+      const bool first = s < 0;  // randomwalk.py:320-321: unbiased table
+      c.vcol = col + vb;
+      c.vw = w ? w + vb : nullptr;
+      c.vw64 = w64 ? w64 + vb : nullptr;
+      c.n = n;
+      c.nch = (n + 63) >> 6;
+      c.s = s;
+      c.need_cls = !first && !(p == 1.0 && q == 1.0);
+      c.need_mem = c.need_cls && q != 1.0;
+      c.scol = col;
+      c.m = 1;
+      c.iters = 1;
+      bool ok = n > 0;  // (arrivals at a sink were dropped by the caller, fugue.py:147)
+      if (ok && c.need_mem) {
+        const int64_t sb = readfirstlane_i64(src_ptr[i]);
+        c.m = (int)(readfirstlane_i64(src_ptr[i + 1]) - sb);
+        c.scol = src_ids + sb;
+        c.iters = 32 - __clz(c.m > 0 ? c.m : 1);
+        if (c.m <= 0) {  // the previous vertex had out-edges: its row must have travelled
+          if (lane == 0) atomicOr(status, N2V_ST_RANGE);
+          ok = false;
+        }
+      }
+      if (ok) {
+        const uint64_t bits = step_bits(walker_stream(seed, key), step);
+        const int idx = exact_draw(c, (uint32_t)(bits >> 32), (uint32_t)bits, lane, L N2V_STATS_PASS);
+        if (idx < 0) {
+          if (lane == 0) atomicOr(status, N2V_ST_ZERODIV);
+        } else {
+          next = __builtin_amdgcn_readfirstlane(c.vcol[idx]);
+        }
+      }
+    }
+    if (lane == 0) next_out[i] = next;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// rows[j] of a CSR copied back to back: out[out_ptr[j] ..] = ids[ptr[rows[j]] .. ptr[rows[j] + 1])
+// (the rows that leave with migrating walkers); one wave per row
+__global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t *__restrict__ ptr,
+                                                          const int32_t *__restrict__ ids,
+                                                          const int64_t *__restrict__ rows,
+                                                          const int64_t *__restrict__ out_ptr,
+                                                          int64_t k, int32_t *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  for (int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); j < k; j += n_waves) {
+    const int64_t r = rows[j];
+    const int64_t b = ptr[r], o = out_ptr[j];
+    const int64_t len = out_ptr[j + 1] - o;
+    for (int64_t t = lane; t < len; t += 64) out[o + t] = ids[b + t];
+  }
+}
+
 }  // namespace n2v
 
 extern "C" int n2v_walk_exact_launch(const n2v_graph *g, const int32_t *start_ids,
@@ -579,6 +675,54 @@ extern "C" int n2v_walk_exact_launch(const n2v_graph *g, const int32_t *start_id
   hipLaunchKernelGGL(n2v::walk_exact_kernel, dim3((unsigned)blocks),
                      dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, *g, start_ids,
                      n_start, num_walks, walk_length, p, q, seed, walks_out, valid_out, status);
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}
+
+extern "C" int n2v_partition_step_unit_try(const int64_t *rowptr, const int32_t *col, int64_t lo,
+                                           int64_t n_local, const int64_t *head,
+                                           const int64_t *src_ptr, const int32_t *src_ids, int64_t k,
+                                           double p, double q, uint64_t seed, int32_t *next_out,
+                                           uint32_t *status, void *stream);  // n2v_walk_unit.hip
+
+extern "C" int n2v_partition_step(const int64_t *rowptr, const int32_t *col, const float *w,
+                                  const double *w64, int64_t lo, int64_t n_local,
+                                  const int64_t *head, const int64_t *src_ptr,
+                                  const int32_t *src_ids, int64_t k, double p, double q,
+                                  uint64_t seed, int32_t *next_out, uint32_t *status,
+                                  void *stream) {
+  if (k < 0 || n_local < 0 || k >= 0xfffffff0ll || (w && w64)) return N2V_EINVAL;
+  if (p == 0.0 || q == 0.0) return N2V_EINVAL;  // randomwalk.py:209-212 (ValueError upstream)
+  if (k == 0) return N2V_OK;
+  if (!rowptr || !col || !head || !next_out || !status) return N2V_EINVAL;
+  if (q != 1.0 && !src_ptr) return N2V_EINVAL;
+  int64_t blocks = (k + n2v::kWavesPerBlock - 1) / n2v::kWavesPerBlock;
+  const int64_t cap = n2v::resident_blocks((const void *)n2v::partition_step_kernel,
+                                           n2v::kWavesPerBlock * 64, 0);
+  if (blocks > cap) blocks = cap;
+  if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
+    return N2V_ELAUNCH;
+  if (!w && !w64) {  // unit weights: the closed forms of n2v_walk_unit.hip
+    const int rc = n2v_partition_step_unit_try(rowptr, col, lo, n_local, head, src_ptr, src_ids, k,
+                                               p, q, seed, next_out, status, stream);
+    if (rc != 0) return rc < 0 ? rc : N2V_OK;
+  }
+  hipLaunchKernelGGL(n2v::partition_step_kernel, dim3((unsigned)blocks),
+                     dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, rowptr, col, w, w64,
+                     lo, n_local, head, src_ptr, src_ids, k, p, q, seed, next_out, status);
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}
+
+extern "C" int n2v_gather_rows(const int64_t *ptr, const int32_t *ids, const int64_t *rows,
+                               const int64_t *out_ptr, int64_t k, int32_t *out, void *stream) {
+  if (k < 0) return N2V_EINVAL;
+  if (k == 0) return N2V_OK;
+  if (!ptr || !ids || !rows || !out_ptr || !out) return N2V_EINVAL;
+  int64_t blocks = (k + 3) / 4;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(n2v::gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, ptr, ids, rows, out_ptr, k, out);
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
 }

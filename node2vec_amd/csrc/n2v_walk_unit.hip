@@ -1267,6 +1267,75 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_UNIT_WAVES) void walk_exac
 #endif
 }
 
+// ---- one step of the walkers resident on one part of a partitioned graph -------------------
+// (n2v_partition_step, n2v_walk.hip: the same contract; this is its unit-weight instance.)  N(v)
+// comes from the part's CSR, N(s) from the rows that travelled with the walkers; the draw is
+// unit_draw above, the routine n2v_walk runs on the whole graph, hence the same vertex.
+template <bool kDyadic>
+__global__ __launch_bounds__(kWavesPerBlock * 64, N2V_UNIT_WAVES) void partition_step_unit_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t lo,
+    int64_t n_local, const int64_t *__restrict__ head, const int64_t *__restrict__ src_ptr,
+    const int32_t *__restrict__ src_ids, int64_t k, double p, double q, UnitConsts K, uint64_t seed,
+    int32_t *__restrict__ next_out, uint32_t *__restrict__ status) {
+  __shared__ UnitLds lds_all[kWavesPerBlock];
+  const int lane = threadIdx.x & 63;
+  UnitLds &L = lds_all[threadIdx.x >> 6];
+  const bool biased = !(p == 1.0 && q == 1.0);
+  UnitStep c;
+  c.need_mem = q != 1.0;
+#ifdef N2V_STATS
+  WaveStats WS;
+  for (int i = 0; i < 40; ++i) WS.v[i] = 0;
+#endif
+  ItemQueue queue(k, kWavesPerBlock);
+  for (;;) {
+    const int64_t i = queue.next(&status[1], lane);
+    if (i < 0) break;
+    const uint64_t key = (uint64_t)readfirstlane_i64(head[4 * i + 1]);
+    const int64_t sv = readfirstlane_i64(head[4 * i + 2]);
+    const uint32_t step = (uint32_t)readfirstlane_i64(head[4 * i + 3]);
+    const int32_t s = (int32_t)(sv >> 32);
+    const int64_t local = (int64_t)(uint32_t)sv - lo;
+    int32_t next = -1;
+    if (local < 0 || local >= n_local) {  // a walker that is not resident here
+      if (lane == 0) atomicOr(status, N2V_ST_RANGE);
+    } else {
+      const int64_t vb = readfirstlane_i64(rowptr[local]);
+      const int n = (int)(readfirstlane_i64(rowptr[local + 1]) - vb);
+      if (n > 0) {  // (arrivals at a sink were dropped by the caller, fugue.py:147)
+        const uint64_t bits = step_bits(walker_stream(seed, key), step);
+        int idx = -1;
+        if (s < 0 || !biased) {
+          // uniform row: probs0 == 1.0 everywhere, no underfull slot, alias unused
+          idx = pick_index((uint32_t)(bits >> 32), n);
+        } else {
+          c.vcol = col + vb;
+          c.n = n;
+          c.nch = (n + 63) >> 6;
+          c.s = s;
+          c.scol = col;
+          c.m = 1;
+          c.iters = 1;
+          bool ok = true;
+          if (c.need_mem) {
+            const int64_t sb = readfirstlane_i64(src_ptr[i]);
+            c.m = (int)(readfirstlane_i64(src_ptr[i + 1]) - sb);
+            c.scol = src_ids + sb;
+            c.iters = 32 - __clz(c.m > 0 ? c.m : 1);
+            ok = c.m > 0;  // the previous vertex had out-edges: its row must have travelled
+            if (!ok && lane == 0) atomicOr(status, N2V_ST_RANGE);
+          }
+          if (ok)
+            idx = unit_draw<kDyadic>(c, K, (uint32_t)(bits >> 32), (uint32_t)bits, lane, L N2V_STATS_PASS);
+        }
+        if (idx >= 0) next = __builtin_amdgcn_readfirstlane(col[vb + idx]);
+      }
+    }
+    if (lane == 0) next_out[i] = next;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ---- lanes kernel: one LANE per walker, the wave only for the pairing -------------------
 // With the class counts of every edge at hand (n2v_edge_classes_build) a step (s -> v) needs
 // no classification of N(v) unless the pairing loop (:182-189) has to run for slot `pick`:
@@ -1579,23 +1648,16 @@ static bool scales_exactly(double x, int64_t *t_out) {
   return true;
 }
 
-// returns 1 when the unit-weight kernel applies (and was launched), 0 when the caller
-// must use the generic kernel, < 0 on error
-extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_ids,
-                                       int64_t n_start, int32_t num_walks,
-                                       int32_t walk_length, double p, double q, uint64_t seed,
-                                       int32_t *walks_out, uint8_t *valid_out, uint32_t *status,
-                                       void *stream) {
-  if (g->w != nullptr || g->w64 != nullptr) return 0;
-  n2v::UnitConsts K;
+// the per-(p, q) constants of the unit-weight kernels; false = the pair is outside their range
+static bool unit_consts(double p, double q, n2v::UnitConsts &K, bool &dyadic) {
   K.bR = 1.0 / p;  // the reference's weight / return_param with weight == 1.0
   K.bM = 1.0;
   K.bO = 1.0 / q;
   K.TR = K.TM = K.TO = 0;
   // dyadic 1/p, 1/q: the row sum is an integer combination of three counts; otherwise it is
   // added up in the reference's order, run by run (needs ordinary magnitudes)
-  const bool dyadic = scales_exactly(K.bR, &K.TR) && scales_exactly(K.bM, &K.TM) &&
-                      scales_exactly(K.bO, &K.TO) && K.TR != 0 && K.TO != 0;
+  dyadic = scales_exactly(K.bR, &K.TR) && scales_exactly(K.bM, &K.TM) &&
+           scales_exactly(K.bO, &K.TO) && K.TR != 0 && K.TO != 0;
   K.gR = K.TR;
   K.gM = K.TM;
   K.gO = K.TO;
@@ -1615,7 +1677,20 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
   K.fO = (double)K.gO;
   K.dyadic = dyadic ? 1 : 0;
   const bool ordinary = K.bR >= 0x1p-20 && K.bR <= 0x1p20 && K.bO >= 0x1p-20 && K.bO <= 0x1p20;
-  if (!dyadic && !ordinary) return 0;
+  return dyadic || ordinary;
+}
+
+// returns 1 when the unit-weight kernel applies (and was launched), 0 when the caller
+// must use the generic kernel, < 0 on error
+extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_ids,
+                                       int64_t n_start, int32_t num_walks,
+                                       int32_t walk_length, double p, double q, uint64_t seed,
+                                       int32_t *walks_out, uint8_t *valid_out, uint32_t *status,
+                                       void *stream) {
+  if (g->w != nullptr || g->w64 != nullptr) return 0;
+  n2v::UnitConsts K;
+  bool dyadic = false;
+  if (!unit_consts(p, q, K, dyadic)) return 0;
   const int64_t total = n_start * (int64_t)num_walks;
   if (total == 0) return 1;
   // status[1] is the kernels' walker counter: start it at zero on the same stream
@@ -1676,6 +1751,33 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
                        dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, *g, start_ids,
                        n_start, num_walks, walk_length, p, q, K, seed, walks_out, valid_out,
                        status);
+  if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
+  return 1;
+}
+
+// the unit-weight instance of n2v_partition_step (n2v_walk.hip calls it first): 1 = launched,
+// 0 = (p, q) outside the unit kernels' range, < 0 on error.  status[1] was zeroed by the caller.
+extern "C" int n2v_partition_step_unit_try(const int64_t *rowptr, const int32_t *col, int64_t lo,
+                                           int64_t n_local, const int64_t *head,
+                                           const int64_t *src_ptr, const int32_t *src_ids, int64_t k,
+                                           double p, double q, uint64_t seed, int32_t *next_out,
+                                           uint32_t *status, void *stream) {
+  n2v::UnitConsts K;
+  bool dyadic = false;
+  if (!unit_consts(p, q, K, dyadic)) return 0;
+  int64_t blocks = (k + n2v::kWavesPerBlock - 1) / n2v::kWavesPerBlock;
+  const void *fn = dyadic ? (const void *)n2v::partition_step_unit_kernel<true>
+                          : (const void *)n2v::partition_step_unit_kernel<false>;
+  const int64_t cap = n2v::resident_blocks(fn, n2v::kWavesPerBlock * 64, 0);
+  if (blocks > cap) blocks = cap;
+  if (dyadic)
+    hipLaunchKernelGGL(n2v::partition_step_unit_kernel<true>, dim3((unsigned)blocks),
+                       dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, rowptr, col, lo,
+                       n_local, head, src_ptr, src_ids, k, p, q, K, seed, next_out, status);
+  else
+    hipLaunchKernelGGL(n2v::partition_step_unit_kernel<false>, dim3((unsigned)blocks),
+                       dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, rowptr, col, lo,
+                       n_local, head, src_ptr, src_ids, k, p, q, K, seed, next_out, status);
   if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
   return 1;
 }

@@ -9,12 +9,14 @@ design point on a GPU node:
 * the CSR is partitioned by contiguous VERTEX RANGE; rank r stores the rows of its range only
   (`partition_graph`), so per-GPU memory is E / N instead of E;
 * a walker lives on the rank that stores the row of its CURRENT vertex.  One step there is the
-  reference's transformer on a batch: bias N(v) against the travelling copy of N(s)
-  (n2v_edge_bias), build the tables (K1, n2v_alias_build), draw with the walker's own uniforms
-  (n2v_walk_uniforms + n2v_alias_draw) -- bit-identical to n2v_walk's exact mode, whose RNG is
+  reference's transformer on a batch -- bias N(v) against the travelling copy of N(s), build the
+  table, draw with the walker's own uniforms -- as ONE launch (n2v_partition_step: one wave per
+  walker, the table never materialised; `tables_step` keeps the launch-per-stage form on
+  materialised tables as a cross-check), bit-identical to n2v_walk's exact mode, whose RNG is
   keyed by (seed, start vertex, ordinal, step) and not by where the walker happens to be;
 * then the walker MIGRATES to the owner of the vertex it drew, carrying a 32-byte header
-  (output row, RNG key, previous/current vertex, step) and the row it just left (the
+  (output row, RNG key, previous/current vertex, step) and -- only when q != 1, the one case in
+  which N(s) decides anything (randomwalk.py:226-229) -- the row it just left (the
   `src_neighbors` of its next step): one variable-size all-to-all per step
   (`torch.distributed.all_to_all_single`, RCCL over xGMI on the GPUs, gloo in the CPU tests);
 * every appended vertex is logged as (row, position, vertex) and sent once, at the end, to the
@@ -128,9 +130,11 @@ def _gather_rows(ptr: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor, out_p
 
 
 # ---- the step on one rank ---------------------------------------------------------------------
-def hip_step(dst_ptr, dst_ids, dst_w, src_id, src_ptr, src_ids, keys, steps, p, q, seed):
-    """One step of a batch of walkers on the GPU that stores their current rows: the reference's
-    next_step_random_walk (randomwalk.py:300-339) with n2v_walk's uniforms."""
+def tables_step(dst_ptr, dst_ids, dst_w, src_id, src_ptr, src_ids, keys, steps, p, q, seed):
+    """One step of a batch of walkers on the GPU that stores their current rows, the way the
+    reference does it: next_step_random_walk (randomwalk.py:300-339) on MATERIALISED tables
+    (n2v_edge_bias, n2v_alias_build, n2v_alias_draw) with n2v_walk's uniforms.  ~10 launches and
+    24 bytes of table per neighbour and step; kept as the cross-check of the fused step."""
     from node2vec_amd import _lib
     from node2vec_amd import transformers as T
 
@@ -150,6 +154,13 @@ def hip_step(dst_ptr, dst_ids, dst_w, src_id, src_ptr, src_ids, keys, steps, p, 
     return T._draw_device(dst_ptr, slots, r1, r2)
 
 
+def hip_step(dst_ptr, dst_ids, dst_w, src_id, src_ptr, src_ids, keys, steps, p, q, seed):
+    """The default step.  RankState recognises it and runs the whole step of a rank as ONE launch
+    of n2v_partition_step straight from the part's CSR (`_advance_fused`); called directly, with
+    the joined rows already packed, it is `tables_step`."""
+    return tables_step(dst_ptr, dst_ids, dst_w, src_id, src_ptr, src_ids, keys, steps, p, q, seed)
+
+
 class RankState:
     """what one rank holds between steps"""
 
@@ -163,6 +174,7 @@ class RankState:
         self.log: List[torch.Tensor] = []  # int64 [k, 3]: (output row, position, vertex or -1 = dropped)
         self.n_rows = 0
         self.row_base = 0
+        self.status = None  # uint32 [4] of n2v_partition_step, on the part's device
 
     # -- initiate_random_walk (randomwalk.py:279-296) for the start vertices this rank owns ----
     def initiate(self, start_ids_global: torch.Tensor):
@@ -191,43 +203,66 @@ class RankState:
         self.walkers = Walkers(head, torch.zeros(rows.numel() + 1, dtype=torch.int64, device=dev),
                                torch.zeros(0, dtype=torch.int32, device=dev))
 
-    # -- the reference's defaults on a unit-weight graph: no table, no travelling row -------------
-    def _advance_uniform(self, n_parts: int) -> List[Walkers]:
-        """p == q == 1 and every weight 1.0: the table of every step is probs == [1.0] * n
-        (randomwalk.py:172-173), sampling_from_alias never takes the alias and returns
-        pick = int(r1 * n) (:95) -- exactly what n2v_walk's p == q == 1 kernel computes.  The
-        previous vertex's row is not needed, so the walker travels as its 32-byte header alone."""
+    # -- the step as ONE launch: n2v_partition_step reads N(v) from the part's CSR ---------------
+    def _advance_fused(self, n_parts: int) -> List[Walkers]:
+        """next_step_random_walk (randomwalk.py:300-339) for every resident walker in one launch
+        (one wave per walker, the table never materialised), then the rows that must travel are
+        packed by one more (n2v_gather_rows).  N(s) only decides shared / other
+        (randomwalk.py:226-229): with q == 1 -- the reference's defaults p == q == 1 included, where
+        every table is probs == [1.0] * n and the draw is pick = int(r1 * n) -- the walker travels
+        as its 32-byte header alone."""
         from node2vec_amd import _lib
 
+        L = _lib.load()
         part, dev, wk = self.part, self.part.device, self.walkers
-        rows, keys, sv, step = wk.head[:, 0], wk.head[:, 1], wk.head[:, 2], wk.head[:, 3]
+        k = len(wk)
+        head_in = wk.head.contiguous()
+        rows, keys, sv, step = head_in[:, 0], head_in[:, 1], head_in[:, 2], head_in[:, 3]
         v = sv & 0xffffffff
-        local = v - part.lo
-        b = part.rowptr[local]
-        n = part.rowptr[local + 1] - b
-        k = keys.contiguous()
-        st = step.to(torch.int32).contiguous()
-        r1 = torch.empty(len(wk), dtype=torch.float64, device=dev)
-        r2 = torch.empty(len(wk), dtype=torch.float64, device=dev)
+        carry = self.q != 1.0
+        nxt32 = torch.empty(k, dtype=torch.int32, device=dev)
+        if self.status is None:
+            self.status = torch.zeros(4, dtype=torch.int32, device=dev)
+        w = part.w
+        w32 = w.data_ptr() if (w is not None and w.dtype == torch.float32) else 0
+        w64 = w.data_ptr() if (w is not None and w.dtype == torch.float64) else 0
+        src_ids = wk.ids if wk.ids.numel() else torch.zeros(1, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(_lib.load().n2v_walk_uniforms(int(self.seed) & (2 ** 64 - 1), k.data_ptr(),
-                                                     st.data_ptr(), len(wk), r1.data_ptr(),
-                                                     r2.data_ptr(), _lib.current_stream_ptr()),
-                       "n2v_walk_uniforms")
-        pick = (r1 * n.double()).floor().long()  # the reference's fp64 product, then int()
-        nxt = part.col[b + pick].to(torch.int64)
+            _lib.check(L.n2v_partition_step(part.rowptr.data_ptr(), part.col.data_ptr(), w32, w64,
+                                            part.lo, part.hi - part.lo, head_in.data_ptr(),
+                                            wk.ptr.data_ptr(), src_ids.data_ptr(), k, float(self.p),
+                                            float(self.q), int(self.seed) & (2 ** 64 - 1),
+                                            nxt32.data_ptr(), self.status.data_ptr(),
+                                            _lib.current_stream_ptr()), "n2v_partition_step")
+        nxt = nxt32.to(torch.int64)
         self.log.append(torch.stack([rows, step + 1, nxt], 1))
         keep = step + 1 < self.L
-        head = torch.stack([rows, keys, (v << 32) | nxt, step + 1], 1)[keep]
-        dest = part.owner(nxt[keep])
+        head = torch.stack([rows, keys, (v << 32) | (nxt & 0xffffffff), step + 1], 1)[keep]
+        dest = part.owner(nxt[keep].clamp(min=0))
         order = torch.argsort(dest, stable=True)
-        counts = torch.bincount(dest, minlength=n_parts).tolist()
-        out, at = [], 0
+        head = head[order]
+        cuts = torch.zeros(n_parts + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(torch.bincount(dest, minlength=n_parts), 0, out=cuts[1:])
+        k2 = head.shape[0]
+        ptr = torch.zeros(k2 + 1, dtype=torch.int64, device=dev)
+        if carry:
+            local = (v[keep] - part.lo)[order].contiguous()
+            torch.cumsum(part.rowptr[local + 1] - part.rowptr[local], 0, out=ptr[1:])
+        # one transfer: the status word, the walkers per destination, the row words per destination
+        host = torch.cat([self.status[:1].to(torch.int64), cuts, ptr[cuts]]).tolist()
+        _lib.check_status_word(host[0], "n2v_partition_step")
+        cuts_h, at = host[1:n_parts + 2], host[n_parts + 2:]
+        ids = torch.zeros(0, dtype=torch.int32, device=dev)
+        if carry and at[-1] > 0:
+            ids = torch.empty(at[-1], dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(L.n2v_gather_rows(part.rowptr.data_ptr(), part.col.data_ptr(),
+                                             local.data_ptr(), ptr.data_ptr(), k2, ids.data_ptr(),
+                                             _lib.current_stream_ptr()), "n2v_gather_rows")
+        out = []
         for r in range(n_parts):
-            h = head[order[at:at + counts[r]]]
-            at += counts[r]
-            out.append(Walkers(h, torch.zeros(h.shape[0] + 1, dtype=torch.int64, device=dev),
-                               torch.zeros(0, dtype=torch.int32, device=dev)))
+            a, b = cuts_h[r], cuts_h[r + 1]
+            out.append(Walkers(head[a:b], ptr[a:b + 1] - ptr[a], ids[at[r]:at[r + 1]]))
         return out
 
     # -- one step of every resident walker; returns the migrating walkers per destination -----
@@ -235,9 +270,10 @@ class RankState:
         part, dev, wk = self.part, self.part.device, self.walkers
         if len(wk) == 0:
             return [Walkers.empty(dev) for _ in range(n_parts)]
-        if (part.w is None and self.p == 1.0 and self.q == 1.0 and self.step_fn is hip_step
-                and part.rowptr.is_cuda):
-            return self._advance_uniform(n_parts)
+        if self.step_fn is hip_step and part.rowptr.is_cuda:
+            return self._advance_fused(n_parts)
+        # an injected step function (the tests pass the oracle's; `tables_step` is the reference's
+        # transformer on materialised tables): it takes the joined rows packed
         rows, keys, sv, step = wk.head[:, 0], wk.head[:, 1], wk.head[:, 2], wk.head[:, 3]
         s = (sv >> 32).to(torch.int32)
         v = (sv & 0xffffffff).to(torch.int64)

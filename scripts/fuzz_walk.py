@@ -1,5 +1,7 @@
 """Randomised differential test of the exact walk kernels against the CPU oracle
-(test infrastructure; run on the GPU box):  python scripts/fuzz_walk.py [seconds] [seed]"""
+(test infrastructure; run on the GPU box):  python scripts/fuzz_walk.py [seconds] [seed]
+FUZZ_PARTITIONED=1: the same cases also through graph-partitioned walking (1-6 parts, cut by edges or
+by vertices, n2v_partition_step on every part, walkers migrating) against the same oracle walks."""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,6 +9,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import n2v_oracle
 from node2vec_amd import randomwalk as rw
 from node2vec_amd.graph import DeviceGraph
+from node2vec_amd import partitioned as P
+PARTITIONED = os.environ.get("FUZZ_PARTITIONED") == "1"
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -85,6 +89,13 @@ while time.time() - t0 < budget:
     want, wv = n2v_oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.w.cpu().numpy(),
                                       starts.cpu().numpy(), nw, wl, p, q, seed, n_threads=THREADS)
     ok = np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy(), want)
+    if ok and PARTITIONED:
+        n_parts = int(rng.integers(1, 7))
+        parts = P.partition_graph(g, n_parts, balance=str(rng.choice(["edges", "vertices"])))
+        got, gv = P.walk_partitioned_local(parts, starts, nw, wl, p, q, seed)
+        ok = np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy()[wv], want[wv])
+        if not ok:
+            print("PARTITIONED", n_parts, flush=True)
     n_cases += 1; n_walks += int(wv.sum())
     if not ok:
         bad = np.nonzero((got.cpu().numpy() != want).any(1) | (gv.cpu().numpy() != wv))[0][:5]

@@ -15,7 +15,7 @@ from node2vec_amd import synthetic  # noqa: E402
 g = synthetic.rmat(20, 5_000_000, device="cuda")
 parts = P.partition_graph(g, 8)
 start = rw.start_vertices(g)
-for p, q in ((1.0, 1.0), (0.5, 2.0)):
+for p, q in ((1.0, 1.0), (0.5, 2.0), (0.5, 1.0), (4.0, 0.25)):
     want, wv = rw.walk(g, start, 2, 20, p, q, 42)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -19,7 +19,8 @@ def test_header_declares_the_expected_entry_points():
                  "n2v_edge_classes_build", "n2v_walk", "n2v_trim_mark", "n2v_sgns_train",
                  "n2v_delta_ref_init", "n2v_delta_pack", "n2v_delta_apply", "n2v_edge_bias", "n2v_alias_draw",
                  "n2v_hops_build", "n2v_cum_index_build", "n2v_walk_uniforms", "n2v_wedge_build",
-                 "n2v_mem_probe", "n2v_corpus_count", "n2v_corpus_index", "n2v_hops8_build"):
+                 "n2v_mem_probe", "n2v_corpus_count", "n2v_corpus_index", "n2v_hops8_build",
+                 "n2v_partition_step", "n2v_gather_rows"):
         assert want in names
 
 
@@ -34,7 +35,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert sorted(_lib.SYMBOLS) == _declared()
     lib.n2v_abi_version.restype = ctypes.c_int
-    assert lib.n2v_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.n2v_abi_version() == _lib.ABI_VERSION == 7
     lib.n2v_status_string.restype = ctypes.c_char_p
     assert lib.n2v_status_string(-1) == b"invalid argument"
 

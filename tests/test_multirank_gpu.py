@@ -10,7 +10,11 @@ period autotune -- is the code that runs under RCCL).  Checked:
     matrices, and each rank trained exactly the pairs a single process trains on that shard with
     that rank's sentence ids;
   * pipeline.fit_streaming under the group: identical replicas, the vocabulary of the whole
-    corpus, the pair count of the two shards.
+    corpus, the pair count of the two shards;
+  * partitioned.walk_partitioned under the group: each rank holds HALF of the CSR, steps its
+    resident walkers with n2v_partition_step and exchanges the migrating ones (headers + the
+    travelling rows) through all_to_all_single; the two halves of the output are the rows of
+    n2v_walk on the whole graph, bit for bit.
 """
 import hashlib
 import os
@@ -35,6 +39,9 @@ SCENARIOS = [  # (name, share of the walks on rank 0, wire, sync_every)
     ("empty_shard_fp32_autotune", 1.0, "fp32", None),
     ("empty_shard_bf16", 1.0, "bf16", 1),
 ]
+
+
+PART_PQ = [(0.5, 2.0), (2.0, 1.0)]  # the row of the previous vertex travels / does not
 
 
 def _free_port():
@@ -89,6 +96,15 @@ def _worker(rank, world, port, ret):
                             "syn1neg": _digest(raw.syn1neg), "n_vocab": len(sm.wv),
                             "ids": _digest(raw.vocab.ids), "counts": _digest(raw.vocab.counts),
                             "world": t["world"], "rows": t["rows_this_rank"]}
+        from node2vec_amd import partitioned as P
+        from node2vec_amd import randomwalk as rw
+
+        part = P.partition_graph(g, world)[rank]
+        start = rw.start_vertices(g)
+        for pq in PART_PQ:
+            pw, pv, prow = P.walk_partitioned(part, start, 2, 15, pq[0], pq[1], 31)
+            out["partitioned_%g_%g" % pq] = {"walks": pw.cpu().numpy(), "valid": pv.cpu().numpy(),
+                                             "rows": prow.cpu().numpy(), "edges": int(part.col.numel())}
         ret[rank] = out
     finally:
         dist.destroy_process_group()
@@ -130,6 +146,21 @@ def test_two_ranks_on_one_gpu_fit_and_fit_streaming():
             assert int(m.pairs.item()) == got["pairs"], (name, rank)
         if share0 == 1.0:
             assert b["pairs"] == 0 and a["pairs"] > 0
+
+    from node2vec_amd import randomwalk as rw
+
+    start = rw.start_vertices(g)
+    for pq in PART_PQ:
+        want, wv = rw.walk(g, start, 2, 15, pq[0], pq[1], 31)
+        want, wv = want.cpu().numpy(), wv.cpu().numpy().astype(bool)
+        pa, pb = r0["partitioned_%g_%g" % pq], r1["partitioned_%g_%g" % pq]
+        assert 0 < pa["edges"] < g.n_edges and pa["edges"] + pb["edges"] == g.n_edges
+        rows = np.concatenate([pa["rows"], pb["rows"]])
+        assert np.array_equal(np.sort(rows), np.arange(want.shape[0]))  # every row emitted once
+        for part in (pa, pb):
+            assert len(part["rows"]) > 0
+            assert np.array_equal(part["valid"].astype(bool), wv[part["rows"]]), pq
+            assert np.array_equal(part["walks"], want[part["rows"]]), pq
 
     sa, sb = r0["streaming"], r1["streaming"]
     assert sa["world"] == sb["world"] == 2

@@ -1,7 +1,9 @@
-"""Graph-partitioned walking on the GPU: every rank of a 4-way vertex-range
-partition stepped by the HIP step function (n2v_walk_uniforms + n2v_edge_bias + n2v_alias_build
-+ n2v_alias_draw), walkers migrating between the parts, must reproduce n2v_walk on the whole
-graph bit for bit -- unit and fp64 weights, with sinks, for three (p, q)."""
+"""Graph-partitioned walking on the GPU: every rank of a vertex-range partition
+stepped by the HIP step -- the fused one (n2v_partition_step: one launch per rank and step, N(v)
+from the part's CSR, N(s) travelling only when q != 1) and the launch-per-stage one on
+materialised tables (n2v_walk_uniforms + n2v_edge_bias + n2v_alias_build + n2v_alias_draw) --
+walkers migrating between the parts, must reproduce the oracle and n2v_walk on the whole graph
+bit for bit: unit, fp32 and fp64 weights, with sinks, for (p, q) with q == 1 and q != 1."""
 import numpy as np
 import pytest
 import torch
@@ -9,10 +11,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("step", ["fused", "tables"])
 @pytest.mark.parametrize("weighted", [False, True])
-def test_partitioned_equals_the_oracle_bit_for_bit(oracle, weighted):
+def test_partitioned_equals_the_oracle_bit_for_bit(oracle, weighted, step):
     """the HIP step function on every part, walkers migrating, against the ORACLE's walk over the
-    whole graph (not only against n2v_walk): 3 parts, sinks, three (p, q)"""
+    whole graph (not only against n2v_walk): 3 parts, sinks, four (p, q)"""
     from node2vec_amd import partitioned as P
     from node2vec_amd import randomwalk as rw
     from node2vec_amd.graph import DeviceGraph
@@ -25,17 +28,18 @@ def test_partitioned_equals_the_oracle_bit_for_bit(oracle, weighted):
     g = DeviceGraph.from_edges(src, dst, w, n_vertices=nv, device="cuda")
     parts = P.partition_graph(g, 3)
     start = rw.start_vertices(g)[::3].contiguous()
-    for p, q in ((1.0, 1.0), (0.5, 2.0), (4.0, 0.25)):
+    step_fn = P.hip_step if step == "fused" else P.tables_step
+    for p, q in ((1.0, 1.0), (0.5, 2.0), (4.0, 0.25), (0.3, 1.0)):
         want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(),
                                       None if g.unit_weights else g.w.cpu().numpy(),
                                       start.cpu().numpy(), 2, 12, p, q, 9)
-        walks, valid = P.walk_partitioned_local(parts, start, 2, 12, p, q, 9)
+        walks, valid = P.walk_partitioned_local(parts, start, 2, 12, p, q, 9, step_fn=step_fn)
         got, gv = walks.cpu().numpy(), valid.cpu().numpy().astype(bool)
         assert np.array_equal(gv, wv) and not wv.all()
         assert np.array_equal(got[gv], want[wv])
 
 
-@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("weighted", [False, True, "fp32"])
 def test_partitioned_equals_n2v_walk_bit_for_bit(weighted):
     from node2vec_amd import partitioned as P
     from node2vec_amd import randomwalk as rw
@@ -46,11 +50,13 @@ def test_partitioned_equals_n2v_walk_bit_for_bit(weighted):
     src = np.concatenate([rng.integers(0, nv - 300, ne), rng.integers(0, 12, 30_000)])  # 12 hubs
     dst = np.concatenate([rng.integers(0, nv, ne), rng.integers(0, nv, 30_000)])
     w = (rng.random(len(src)) * 1.7 + 0.3) if weighted else None  # fp64, not fp32-representable
+    if weighted == "fp32":
+        w = w.astype(np.float32)
     g = DeviceGraph.from_edges(src, dst, w, n_vertices=nv, device="cuda")
     parts = P.partition_graph(g, 4)
     assert max(pt.col.numel() for pt in parts) < 0.3 * g.n_edges  # a rank stores ~E / 4
     start = rw.start_vertices(g)[::7].contiguous()
-    for p, q in ((1.0, 1.0), (0.5, 2.0), (4.0, 0.25)):
+    for p, q in ((1.0, 1.0), (0.5, 2.0), (4.0, 0.25), (3.0, 1.0)):
         want, wv = rw.walk(g, start, 3, 15, p, q, 77)
         walks, valid = P.walk_partitioned_local(parts, start, 3, 15, p, q, 77)
         assert torch.equal(valid, wv)
