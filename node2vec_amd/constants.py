@@ -58,4 +58,6 @@ HIP_SGNS_PARAMS: Dict[str, Any] = {
     # options of the HIP trainer that gensim does not have (all off = gensim's semantics):
     "batched": False,   # True: negatives shared by the pairs of a centre position (MFMA kernel)
     "hub_rows": 0,      # > 0: atomic adds on the most frequent rows in hogwild mode
+    "deterministic": False,  # True: one wave, sentences in order -- reproducible bit for bit
+                             # (gensim's workers=1), orders of magnitude slower: for tests
 }

@@ -311,7 +311,8 @@ class Node2VecHIP(Node2VecBase):
                                       rows_max * max(int(p["iter"]), 1))
             sync = sgns.DeltaSync(m, sync_every=p.get("sync_every"), wire=p.get("sync_wire", "fp32"))
         m.train(idx, int(p["iter"]), float(p["alpha"]), float(p["min_alpha"]),
-                sentence_base=sentence_base, sync=sync, rows_global_max=rows_max)
+                sentence_base=sentence_base, sync=sync, rows_global_max=rows_max,
+                deterministic=bool(p.get("deterministic", False)))
         torch.cuda.synchronize(dev)
         p["negative"] = negative
         # the matrices stay in HBM and the tokens stay integer ids (lazy strings): at cfg 4 the

@@ -37,7 +37,8 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
     n2v_params / w2v_params take the reference's keys (NODE2VEC_PARAMS, GENSIM_PARAMS plus
     the pass-through names of HIP_SGNS_PARAMS); missing keys are filled in the caller's
     dicts as the reference does (fugue.py:120-122, embedding.py:105-107).  w2v_params["batched"]
-    selects the opt-in shared-negative trainer; "sync_every" / "sync_wire" the multi-GPU exchange.
+    selects the opt-in shared-negative trainer; "sync_every" / "sync_wire" the multi-GPU exchange;
+    "deterministic" the one-wave reproducible mode (tests).
     `timings` (optional dict) receives the seconds spent walking and training."""
     import time
 
@@ -108,6 +109,7 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
                            device=dev)
     model.batched = bool(p.get("batched", False))
     model.hub_rows = int(p.get("hub_rows", 0) or 0)
+    deterministic = bool(p.get("deterministic", False))
     logging.info("fit_streaming: %d start vertices on this rank, vocabulary %d", n_start, len(vocab))
     sync = None
     if multi:
@@ -131,7 +133,7 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
                 # sentence id = (epoch, rank, row of the rank's virtual corpus): never repeats
                 base = ((ep * world + rank) * rows_rank_max + k * batch_vertices * W) * parts_per_row
                 for j, part in enumerate(torch.split(sgns.split_rows(idx), 1 << 22)):
-                    model.train_block(part, a, base + j * (1 << 22))
+                    model.train_block(part, a, base + j * (1 << 22), deterministic)
             if sync is not None:
                 sync.step()
             t_train += clock() - t1

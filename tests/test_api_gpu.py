@@ -179,6 +179,63 @@ def test_streaming_pipeline_matches_materialised_corpus():
     assert np.isfinite(out.wv.vectors).all()
 
 
+def test_fit_streaming_deterministic_equals_the_oracle_end_to_end(oracle):
+    """walk -> vocabulary -> SGNS through fit_streaming (HIP, "deterministic": True) against the
+    same pipeline made of the ORACLE's walk, a numpy restatement of gensim's vocabulary / negative
+    table / subsampling rule, and the oracle's trainer on the same batches: identical vocabulary,
+    pair count and matrices, bit for bit.  (The initial syn0 is the seeded device draw of
+    sgns.init_syn0 -- gensim's per-word hash seed is not reproducible across processes.)"""
+    from node2vec_amd import sgns
+    from node2vec_amd.graph import DeviceGraph
+    from node2vec_amd.pipeline import fit_streaming
+
+    rng = np.random.default_rng(8)  # directed, 5 hubs, the last 20 vertices have no out-edges
+    src = np.concatenate([rng.integers(0, 580, 3500), rng.integers(0, 5, 500)])
+    g = DeviceGraph.from_edges(src, rng.integers(0, 600, 4000), None, n_vertices=600, device="cuda")
+    W, L, p, q, seed, bv = 3, 12, 0.5, 2.0, 17, 100
+    n2v = {"num_walks": W, "walk_length": L, "return_param": p, "inout_param": q}
+    w2v = {"min_count": 2, "iter": 2, "size": 32, "negative": 5, "sample": 1e-2, "seed": 5, "window": 4,
+           "alpha": 0.025, "min_alpha": 1e-4, "deterministic": True}
+    out, model = fit_streaming(g, dict(n2v), dict(w2v), random_seed=seed, batch_vertices=bv,
+                               return_model=True)
+    # ---- the same with the oracle ------------------------------------------------------------
+    rowptr, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
+    start = np.nonzero(np.diff(rowptr) > 0)[0].astype(np.int32)  # fugue.py:132
+    walks, valid = oracle.random_walk(rowptr, col, None, start, W, L, p, q, seed)
+    assert not valid.all()  # walkers vanished at sinks: their rows are no sentences
+    counts = np.bincount(walks[valid].reshape(-1), minlength=g.n_vertices)
+    ids = np.nonzero(counts >= 2)[0]
+    order = np.argsort(-counts[ids], kind="stable")  # gensim: most frequent first (ties: by id)
+    ids, cnt = ids[order], counts[ids][order]
+    assert np.array_equal(model.vocab.ids.cpu().numpy(), ids)
+    assert np.array_equal(model.vocab.counts.cpu().numpy(), cnt)
+    pw = cnt.astype(np.float64) ** 0.75  # make_cum_table (gensim word2vec.py): domain 2^31 - 1
+    cum = np.round(np.cumsum(pw) / pw.sum() * (2 ** 31 - 1)).astype(np.int64)
+    cum[-1] = 2 ** 31 - 1
+    assert np.array_equal(model.cum_table.cpu().numpy().astype(np.int64), cum)
+    thr = 1e-2 * cnt.sum()  # sample < 1: a fraction of the retained words
+    keep = np.minimum((np.sqrt(cnt / thr) + 1.0) * (thr / cnt), 1.0)
+    sample_int = np.minimum(np.round(keep * 2.0 ** 32), 2.0 ** 32 - 1).astype(np.uint32)
+    assert np.array_equal(model.sample_int.cpu().numpy().view(np.uint32), sample_int)
+    index_of = np.full(g.n_vertices, -1, np.int32)
+    index_of[ids] = np.arange(len(ids), dtype=np.int32)
+    idx = np.where(valid[:, None], index_of[np.clip(walks, 0, None)], -1).astype(np.int32)
+    s0 = sgns.init_syn0(len(ids), 32, 5, "cuda").cpu().numpy()
+    s1 = np.zeros_like(s0)
+    n_batches = -(-len(start) // bv)
+    pairs = 0
+    for ep in range(2):
+        for k in range(n_batches):
+            a = max(1e-4, 0.025 - (0.025 - 1e-4) * ((ep * n_batches + k) / (2 * n_batches)))
+            rows = idx[k * bv * W:(k + 1) * bv * W]
+            pairs += oracle.sgns_train(rows, s0, s1, cum.astype(np.uint32), sample_int, sgns.exp_table(),
+                                       len(ids), ep * len(start) * W + k * bv * W, 5, 32, 4, 5, a)
+    assert pairs == out.pairs_trained > 0
+    assert np.array_equal(model.syn0.cpu().numpy(), s0)
+    assert np.array_equal(model.syn1neg.cpu().numpy(), s1)
+    assert np.array_equal(out.wv.vectors, s0) and np.abs(s1).max() > 0
+
+
 def test_corpus_count_and_index_equal_torch():
     """n2v_corpus_count / n2v_corpus_index (the passes between K2 and K3 of fit_streaming) against
     the framework ops they replace: dropped rows, negative tokens, out-of-range ids"""

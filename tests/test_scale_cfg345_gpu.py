@@ -86,7 +86,7 @@ def test_cfg3_power_law_10m_trimmed(oracle):
     # (4, 0.25): "other" is the overfull class (the mirror closed form and its run-by-run replay);
     # (4, 2) and (0.25, 0.5): the return slot shares a stack with "other" (rows of 10^4 slots)
     for p, q in ((1.0, 1.0), (0.5, 2.0), (4.0, 0.25), (4.0, 2.0), (0.25, 0.5)):
-        _check_config(oracle, g, start, p, q, 42, n_oracle=48, n_hubs=16, oracle_len=40)
+        _check_config(oracle, g, start, p, q, 42, n_oracle=600, n_hubs=64, oracle_len=40)
 
 
 def test_cfg4_power_law_100m(oracle):
@@ -105,7 +105,7 @@ def test_cfg4_power_law_100m(oracle):
     pick = torch.sort(torch.randperm(start_all.numel(), generator=gen)[:100_000]).values
     start = start_all[pick.to("cuda")].contiguous()
     for p, q in ((1.0, 1.0), (0.5, 2.0), (0.25, 0.5)):
-        _check_config(oracle, g, start, p, q, 42, n_oracle=48, n_hubs=16, oracle_len=40)
+        _check_config(oracle, g, start, p, q, 42, n_oracle=600, n_hubs=64, oracle_len=40)
 
 
 def test_cfg5_bipartite_50m_hubs_of_20k(oracle):
@@ -124,7 +124,7 @@ def test_cfg5_bipartite_50m_hubs_of_20k(oracle):
     pick = torch.sort(torch.randperm(start_all.numel(), generator=gen)[:100_000]).values
     start = torch.unique(torch.cat([start_all[pick.to("cuda")],
                                     torch.arange(64, dtype=torch.int32, device="cuda")]))
-    _check_config(oracle, g, start, 4.0, 0.25, 42, n_oracle=40, n_hubs=12, oracle_len=30)
+    _check_config(oracle, g, start, 4.0, 0.25, 42, n_oracle=200, n_hubs=32, oracle_len=30)
     walks, valid = rw.walk(g, start[:4096].contiguous(), W, L, 4.0, 0.25, 42)
     side = walks[valid].long() < n_hubs
     assert bool((side[:, :-1] != side[:, 1:]).all())

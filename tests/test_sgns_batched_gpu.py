@@ -15,6 +15,16 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+# TOLERANCES of the hogwild (racy) tests, from 30 runs on one MI355X (scripts/r3/stat_runs.py ->
+# profiles/r3ad_stat_runs.log), each looser than mean -+ 5 sd:
+#   planted partition AUC: batched hogwild 0.9997 +- 0.0000, batched deterministic 0.9991, default
+#     hogwild 1.0000 -> every AUC > 0.99, differences < 0.01 (measured: 0.0003 and 0.0005)
+#   500-word vocabulary, |syn0| hogwild / serial: 1.148 +- 0.003 (context rows go back as atomic
+#     deltas computed from stale values: a 15 % overshoot on a vocabulary where every row is
+#     contended) -> (1.0, 1.3)
+PLANTED_AUC_MIN, PLANTED_AUC_DIFF_MAX = 0.99, 0.01
+NORM_RATIO = (1.0, 1.3)
+
 
 def _corpus(n_tok, rows, ln, seed, walk_like):
     gen = torch.Generator().manual_seed(seed)
@@ -123,7 +133,7 @@ def test_batched_hogwild_pair_count_and_sanity(oracle):
     # (context rows go back as atomic deltas, so no wave's training of a syn0 row is lost)
     ratio = float(np.linalg.norm(got) / np.linalg.norm(s0))
     print("batched hogwild / serial norm of syn0:", ratio)
-    assert 0.5 < ratio < 2.0
+    assert NORM_RATIO[0] < ratio < NORM_RATIO[1]
 
 
 def _planted(nc=50, sz=40, seed=0):
@@ -142,10 +152,9 @@ def _planted(nc=50, sz=40, seed=0):
     return DeviceGraph.from_edges(src, dst, None, n_vertices=nv, device="cuda"), comm
 
 
-@pytest.mark.statistical
-def test_batched_quality_matches_default_trainer_on_planted_partition():
-    """same walks, same epochs: community AUC of the batched trainer within 0.02 of the default
-    (per-pair negatives) trainer, both > 0.97; deterministic batched run as the reference point"""
+def planted_auc_case():
+    """planted partition: community AUC after 3 epochs of the default or the batched trainer,
+    hogwild or deterministic (shared with scripts/r3/stat_runs.py)"""
     from node2vec_amd import randomwalk as rw
     from node2vec_amd import sgns
 
@@ -158,22 +167,28 @@ def test_batched_quality_matches_default_trainer_on_planted_partition():
     a, b = rng.integers(0, len(ids), 200000), rng.integers(0, len(ids), 200000)
     same = comm[ids[a]] == comm[ids[b]]
 
-    def auc(m):
+    def auc(batched, det):
+        m = sgns.SgnsModel(vocab, 64, 5, 5, seed=7, sample=0.0)
+        m.batched = batched
+        m.train(idx, epochs=3, alpha=0.025, deterministic=det)
+        torch.cuda.synchronize()
         v = m.syn0.cpu().numpy()
         v = v - v.mean(0)
         v /= np.linalg.norm(v, axis=1, keepdims=True)
         s = (v[a] * v[b]).sum(1)
         return float((s[same][:, None] > s[~same][None, :3000]).mean())
 
-    out = {}
-    for name, batched, det in (("default", False, False), ("batched", True, False),
-                               ("batched_det", True, True)):
-        m = sgns.SgnsModel(vocab, 64, 5, 5, seed=7, sample=0.0)
-        m.batched = batched
-        m.train(idx, epochs=3, alpha=0.025, deterministic=det)
-        torch.cuda.synchronize()
-        out[name] = auc(m)
+    return {"auc": auc}
+
+
+@pytest.mark.statistical
+def test_batched_quality_matches_default_trainer_on_planted_partition():
+    """same walks, same epochs: community AUC of the batched trainer against the default
+    (per-pair negatives) trainer and against the deterministic batched run.  Tolerances:
+    TOLERANCES at the top of this file."""
+    auc = planted_auc_case()["auc"]
+    out = {"default": auc(False, False), "batched": auc(True, False), "batched_det": auc(True, True)}
     print("planted partition AUC:", out)
-    assert min(out.values()) > 0.97, out
-    assert abs(out["batched"] - out["default"]) < 0.02, out
-    assert abs(out["batched"] - out["batched_det"]) < 0.02, out
+    assert min(out.values()) > PLANTED_AUC_MIN, out
+    assert abs(out["batched"] - out["default"]) < PLANTED_AUC_DIFF_MAX, out
+    assert abs(out["batched"] - out["batched_det"]) < PLANTED_AUC_DIFF_MAX, out

@@ -12,6 +12,25 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+# TOLERANCES of the hogwild (racy) tests, from 30 runs of every statistic on one MI355X
+# (scripts/r3/stat_runs.py -> profiles/r3ad_stat_runs.log) and a 400-run search for rare outliers
+# (scripts/r3/stat_outliers.py -> profiles/r3ad_stat_outliers.log).  Each bound is looser than
+# mean -+ 5 sd of the sample it comes from:
+#   two cliques: gap 0.8727 in all 30 runs (= the oracle's; 40 words -> one wave), bounds 0.2 / 0.15
+#   planted partition: AUC 1.0000 +- 0.0000 hogwild, 0.9994 deterministic -> > 0.99, |diff| < 0.01
+#   Procrustes cosine of the row directions: hogwild vs hogwild 0.9588 +- 0.0010, deterministic vs
+#     hogwild 0.7764 +- 0.0013 -- BUT one hogwild run in 400 (and one pair in ~8 suite runs) lands
+#     at 0.80 from the others, the distance of the deterministic order, with AUC 1.0000 and
+#     ordinary row norms: a different, equally good solution (sentences are handed out from a
+#     counter, so a scheduling hiccup changes the order at large).  The cosine between two runs is
+#     therefore only held above the level of "another order": 0.6 for both comparisons.
+#   500-word vocabulary, |syn0| hogwild / serial: 0.990 +- 0.009 default, 0.998 +- 0.001 with
+#     hub_rows = 500 -> (0.9, 1.1) and (0.95, 1.05)
+GAP_MIN, GAP_DIFF_MAX = 0.2, 0.15
+PLANTED_AUC_MIN, PLANTED_AUC_DIFF_MAX = 0.99, 0.01
+PLANTED_COS_HH_MIN, PLANTED_COS_DH_MIN = 0.6, 0.6
+NORM_RATIO_DEFAULT, NORM_RATIO_HUB = (0.9, 1.1), (0.95, 1.05)
+
 
 def _setup(n_tok, rows, ln, dim, seed, sample, min_count=1, oov=False):
     from node2vec_amd import sgns
@@ -74,13 +93,12 @@ def test_hogwild_pair_count_equals_oracle(oracle):
     # order; what must hold: finite values, every touched row moved, same scale
     got = m.syn0.cpu().numpy()
     assert np.isfinite(got).all() and np.isfinite(m.syn1neg.cpu().numpy()).all()
-    assert 0.5 < np.linalg.norm(got) / np.linalg.norm(s0) < 2.0
+    ratio = float(np.linalg.norm(got) / np.linalg.norm(s0))
+    assert NORM_RATIO_DEFAULT[0] < ratio < NORM_RATIO_DEFAULT[1], ratio
 
 
-@pytest.mark.statistical
-def test_hogwild_learns_community_structure(oracle):
-    """two 20-vertex cliques joined by one edge: after training, vectors of the
-    same clique are closer than vectors of different cliques (GPU and oracle)."""
+def two_clique_case():
+    """two 20-vertex cliques joined by one edge (shared with scripts/r3/stat_runs.py)"""
     from node2vec_amd import randomwalk as rw
     from node2vec_amd import sgns
     from node2vec_amd.graph import DeviceGraph
@@ -98,38 +116,47 @@ def test_hogwild_learns_community_structure(oracle):
     walks, valid = rw.walk(g, rw.start_vertices(g), 20, 30, 1.0, 1.0, 3)
     vocab = sgns.build_vocab(walks, 1)
     idx = vocab.index_of[walks.long()]
+    ids = vocab.ids.cpu().numpy()
 
-    def gap(vecs, ids):
+    def gap(vecs):
         v = vecs / np.linalg.norm(vecs, axis=1, keepdims=True)
         side = ids < 20
         s = v @ v.T
         intra = (s[np.ix_(side, side)].mean() + s[np.ix_(~side, ~side)].mean()) / 2
-        return intra - s[np.ix_(side, ~side)].mean()
+        return float(intra - s[np.ix_(side, ~side)].mean())
 
-    m = sgns.SgnsModel(vocab, 32, 5, 5, seed=2, sample=0.0)
-    s0, s1 = m.syn0.cpu().numpy().copy(), m.syn1neg.cpu().numpy().copy()
-    m.train(idx, epochs=3, alpha=0.025)
-    torch.cuda.synchronize()
-    ids = vocab.ids.cpu().numpy()
-    g_gpu = gap(m.syn0.cpu().numpy(), ids)
-    rows = idx.shape[0]
-    for ep in range(3):  # same schedule on the oracle (one block per epoch here)
-        a = max(1e-4, 0.025 - (0.025 - 1e-4) * (ep * rows / (3 * rows)))
-        oracle.sgns_train(idx.cpu().numpy(), s0, s1, m.cum_table.cpu().numpy(), None,
-                          sgns.exp_table(), len(vocab), ep * rows, m.seed, 32, 5, 5, a)
-    g_cpu = gap(s0, ids)
-    assert g_gpu > 0.2 and g_cpu > 0.2
-    assert abs(g_gpu - g_cpu) < 0.15
+    def gap_gpu():
+        m = sgns.SgnsModel(vocab, 32, 5, 5, seed=2, sample=0.0)
+        m.train(idx, epochs=3, alpha=0.025)
+        torch.cuda.synchronize()
+        return gap(m.syn0.cpu().numpy())
+
+    def gap_cpu(oracle):
+        m = sgns.SgnsModel(vocab, 32, 5, 5, seed=2, sample=0.0)
+        s0, s1 = m.syn0.cpu().numpy().copy(), m.syn1neg.cpu().numpy().copy()
+        rows = idx.shape[0]
+        for ep in range(3):  # same schedule on the oracle (one block per epoch here)
+            a = max(1e-4, 0.025 - (0.025 - 1e-4) * (ep * rows / (3 * rows)))
+            oracle.sgns_train(idx.cpu().numpy(), s0, s1, m.cum_table.cpu().numpy(), None,
+                              sgns.exp_table(), len(vocab), ep * rows, m.seed, 32, 5, 5, a)
+        return gap(s0)
+
+    return {"gap_gpu": gap_gpu, "gap_cpu": gap_cpu}
 
 
 @pytest.mark.statistical
-def test_hogwild_vs_deterministic_statistical_parity():
-    """Full-speed (hogwild) mode cannot be bit-compared; the claim is statistical
-    (SURVEY.md 8c): on a planted-partition graph (50 communities x 40 vertices) the
-    community-separation AUC of the hogwild embedding equals the deterministic one within
-    0.01 and both exceed 0.99; after Procrustes alignment the mean per-vertex cosine is
-    >= 0.9 between two hogwild runs and >= 0.6 between hogwild and deterministic
-    (measured: 0.99 and 0.78)."""
+def test_hogwild_learns_community_structure(oracle):
+    """two 20-vertex cliques joined by one edge: after training, vectors of the
+    same clique are closer than vectors of different cliques (GPU and oracle).
+    Tolerances: TOLERANCES below."""
+    case = two_clique_case()
+    g_gpu, g_cpu = case["gap_gpu"](), case["gap_cpu"](oracle)
+    assert g_gpu > GAP_MIN and g_cpu > GAP_MIN, (g_gpu, g_cpu)
+    assert abs(g_gpu - g_cpu) < GAP_DIFF_MAX, (g_gpu, g_cpu)
+
+
+def planted_case():
+    """planted partition, 50 communities x 40 vertices (shared with scripts/r3/stat_runs.py)"""
     from node2vec_amd import randomwalk as rw
     from node2vec_amd import sgns
     from node2vec_amd.graph import DeviceGraph
@@ -149,6 +176,9 @@ def test_hogwild_vs_deterministic_statistical_parity():
     vocab = sgns.build_vocab(walks, 1)
     idx = vocab.index_of[walks.long()]
     ids = vocab.ids.cpu().numpy()
+    prng = np.random.default_rng(1)
+    a, b = prng.integers(0, len(ids), 100000), prng.integers(0, len(ids), 100000)
+    same = comm[ids[a]] == comm[ids[b]]
 
     def train(det):
         m = sgns.SgnsModel(vocab, 64, 5, 5, seed=7, sample=0.0)
@@ -159,22 +189,40 @@ def test_hogwild_vs_deterministic_statistical_parity():
     def auc(v):
         v = v - v.mean(0)
         v = v / np.linalg.norm(v, axis=1, keepdims=True)
-        a, b = rng.integers(0, len(v), 100000), rng.integers(0, len(v), 100000)
         s = (v[a] * v[b]).sum(1)
-        same = comm[ids[a]] == comm[ids[b]]
         return float((s[same][:, None] > s[~same][None, :2000]).mean())
 
-    def procrustes_cos(x, y):
+    def procrustes_raw(x, y):
         x, y = x - x.mean(0), y - y.mean(0)
         u, _, vt = np.linalg.svd(x.T @ y)
         xr = x @ (u @ vt)
         return float(np.mean((xr * y).sum(1) / (np.linalg.norm(xr, axis=1) * np.linalg.norm(y, axis=1))))
 
-    det, h1, h2 = train(True), train(False), train(False)
-    a_det, a_h1 = auc(det), auc(h1)
-    assert a_det > 0.99 and a_h1 > 0.99 and abs(a_det - a_h1) < 0.01
-    assert procrustes_cos(h1, h2) > 0.9
-    assert procrustes_cos(det, h1) > 0.6
+    def procrustes(x, y):
+        """rows scaled to unit length first: the rotation is then fitted to directions, and a
+        few long rows (the race amplifies some norms) cannot dominate it"""
+        x, y = x - x.mean(0), y - y.mean(0)
+        x = x / np.linalg.norm(x, axis=1, keepdims=True)
+        y = y / np.linalg.norm(y, axis=1, keepdims=True)
+        return procrustes_raw(x, y)
+
+    return {"train": train, "auc": auc, "procrustes": procrustes, "procrustes_raw": procrustes_raw}
+
+
+@pytest.mark.statistical
+def test_hogwild_vs_deterministic_statistical_parity():
+    """Full-speed (hogwild) mode cannot be bit-compared; the claim is statistical
+    (SURVEY.md 8c): on a planted-partition graph (50 communities x 40 vertices) the
+    community-separation AUC of the hogwild embedding equals the deterministic one and, after
+    Procrustes alignment of the row directions, two hogwild runs agree with each other and with
+    the deterministic run.  Tolerances: TOLERANCES below."""
+    case = planted_case()
+    det, h1, h2 = case["train"](True), case["train"](False), case["train"](False)
+    a_det, a_h1, a_h2 = case["auc"](det), case["auc"](h1), case["auc"](h2)
+    assert a_det > PLANTED_AUC_MIN and min(a_h1, a_h2) > PLANTED_AUC_MIN, (a_det, a_h1, a_h2)
+    assert max(abs(a_det - a_h1), abs(a_det - a_h2)) < PLANTED_AUC_DIFF_MAX, (a_det, a_h1, a_h2)
+    assert case["procrustes"](h1, h2) > PLANTED_COS_HH_MIN
+    assert case["procrustes"](det, h1) > PLANTED_COS_DH_MIN
 
 
 def test_cum_index_is_bisect_left_and_changes_no_draw(oracle):
@@ -287,4 +335,4 @@ def test_hub_rows_atomic_updates(oracle):
     assert np.isfinite(got).all() and np.isfinite(m.syn1neg.cpu().numpy()).all()
     ratio = float(np.linalg.norm(got) / np.linalg.norm(s0))
     print("hub_rows hogwild / serial norm of syn0:", ratio)
-    assert 0.7 < ratio < 1.5
+    assert NORM_RATIO_HUB[0] < ratio < NORM_RATIO_HUB[1], ratio

@@ -156,7 +156,7 @@ def test_rmat_1m_hogwild_quality_is_stable_over_five_seeds():
         hub.append(float((sp[:k, None] > sn[None, :2000]).float().mean()))
         del m, u
     print("rmat-1m: link AUC with hub_rows = 4096", hub)
-    assert 0.9004 <= min(hub) and max(hub) <= 0.9184, hub
+    assert 0.9004 <= min(hub) and max(hub) <= 0.9240, hub  # above: +6 sd at the default trainer's sd
     ov = [_overlap(nbrs[0], nbrs[i]) for i in range(1, 5)]
     print("rmat-1m: link AUC per seed", aucs, "knn@10 overlap vs seed 0", ov)
     assert 0.8826 <= min(aucs) and max(aucs) <= 0.9114, aucs  # mean +- 6 sd of 20 runs
