@@ -45,28 +45,6 @@ __global__ __launch_bounds__(256) void probe_gather_kernel(const T *__restrict__
   if (acc == 0x12345678u) sink[0] = acc;  // keeps the loads alive
 }
 
-// experiment (scripts/r3/probe_hop8.py): a walker step as an 8-byte gather from the big table
-// followed, for a share of the steps, by a dependent 16-byte gather from a small (cache-sized) table
-__global__ __launch_bounds__(256, 8) void probe_hop8_kernel(const uint2 *__restrict__ t, uint64_t n_el,
-                                                            const uint4 *__restrict__ small,
-                                                            uint64_t n_small, int iters,
-                                                            uint32_t escape_share, uint32_t *sink) {
-  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint64_t idx = mix64(gid) % n_el;
-  uint32_t acc = 0;
-  for (int k = 0; k < iters; ++k) {
-    const uint2 r = t[idx];
-    uint64_t h = mix64(((uint64_t)r.x << 32 | r.y) ^ (gid + (uint64_t)k * 0x9E3779B97F4A7C15ULL));
-    if ((uint32_t)h % 100u < escape_share) {
-      const uint4 e = small[(h >> 32) % n_small];
-      h ^= e.x + e.w;
-    }
-    acc += (uint32_t)h;
-    idx = h % n_el;
-  }
-  if (acc == 0x12345678u) sink[0] = acc;
-}
-
 template <bool kWrite>
 __global__ __launch_bounds__(256) void probe_rows_kernel(float *t, uint64_t n_rows, int row_floats,
                                                          int iters, uint32_t *sink) {
@@ -108,18 +86,6 @@ __global__ __launch_bounds__(256) void probe_rows_kernel(float *t, uint64_t n_ro
 }
 
 }  // namespace n2v
-
-extern "C" int n2v_probe_hop8_experiment(const void *big, int64_t big_bytes, const void *small,
-                                         int64_t small_bytes, int32_t iters, int32_t escape_share,
-                                         int64_t *accesses_host, uint32_t *sink, void *stream) {
-  const int64_t blocks = n2v::resident_blocks((const void *)n2v::probe_hop8_kernel, 256, 0);
-  if (accesses_host) *accesses_host = blocks * 256 * (int64_t)iters;
-  hipLaunchKernelGGL(n2v::probe_hop8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     (const uint2 *)big, (uint64_t)(big_bytes / 8), (const uint4 *)small,
-                     (uint64_t)(small_bytes / 16), iters, (uint32_t)escape_share, sink);
-  N2V_HIP_CHECK(hipGetLastError());
-  return N2V_OK;
-}
 
 extern "C" int n2v_mem_probe(void *buffer, int64_t buffer_bytes, int32_t mode, int32_t iters,
                              int32_t row_bytes, int64_t *accesses_host, uint32_t *sink,
