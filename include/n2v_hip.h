@@ -395,22 +395,40 @@ int n2v_corpus_index(const int32_t *walks, const uint8_t *valid, const int32_t *
  * one wave per walker, no table materialised.
  *   rowptr / col / w / w64   the part's rows [lo, lo + n_local) (rowptr rebased to 0; ids global;
  *                            at most one of w, w64; both NULL = unit weights)
- *   head      int64 [k][4] = (output row, RNG key = start * num_walks + ordinal - 1,
- *             s << 32 | v, step); s = -1 (high word all ones) on the first step (:320-321)
- *   src_ptr / src_ids        the travelling rows N(s), packed (int64 [k + 1], sorted ids); read
- *                            only when q != 1 and s >= 0, may be NULL otherwise
+ *   head      int64 [k][head_cols] (head_cols >= 4): (output row, RNG key = start * num_walks +
+ *             ordinal - 1, s << 32 | v, step[, classes]); s = -1 (high word all ones) on the
+ *             first step (:320-321)
+ *   src_ptr / src_ids        what travelled with the walkers, packed (int64 [k + 1] offsets):
+ *     src_kind N2V_SRC_ROWS    the rows N(s), sorted ids; read only when q != 1 and s >= 0 (may
+ *                              be NULL otherwise)
+ *     src_kind N2V_SRC_WEDGES  (unit weights, head_cols >= 5) the WEDGE LIST of the edge (s -> v)
+ *                              walked last -- the positions in N(v) of the neighbours v shares
+ *                              with s, ascending, 32-bit -- cut from the wedge table of the rank
+ *                              that stores that edge (n2v_wedge_build on its part), with
+ *                              head[.][4] = edge_classes[e] | return position << 32: the class of
+ *                              every slot of the step's table is then known by position and
+ *                              neither N(s) nor a pass over N(v) is needed
  *   next_out  int32 [k]: the vertex drawn (-1 when status reports an error for that walker)
+ *   edge_out  int64 [k] or NULL: the index (into the part's col) of the edge drawn
  *   status    uint32 [4] as for n2v_walk; [1] is used as the walker counter.
  * Draws are those of n2v_walk's exact mode (same stream keyed by (seed, key, step)), so walks are
  * bit-identical to n2v_walk over the unpartitioned graph wherever the walker happens to be.
- *   n2v_gather_rows  out[out_ptr[j] ..) = ids[ptr[rows[j]] .. ptr[rows[j] + 1]) for j < k: packs
- *                    the rows that leave with migrating walkers (out_ptr = their prefix sums). */
+ *   n2v_gather_rows    out[out_ptr[j] ..) = ids[ptr[rows[j]] .. ptr[rows[j] + 1]) for j < k: packs
+ *                      the rows that leave with migrating walkers (out_ptr = their prefix sums)
+ *   n2v_gather_wedges  the same for wedge lists: out[out_ptr[j] ..) = the list of edge edges[j]
+ *                      widened to 32 bits, and head[j][4] = edge_classes | return position << 32 */
+#define N2V_SRC_ROWS 0
+#define N2V_SRC_WEDGES 1
 int n2v_partition_step(const int64_t *rowptr, const int32_t *col, const float *w, const double *w64,
-                       int64_t lo, int64_t n_local, const int64_t *head, const int64_t *src_ptr,
-                       const int32_t *src_ids, int64_t k, double p, double q, uint64_t seed,
-                       int32_t *next_out, uint32_t *status, void *stream);
+                       int64_t lo, int64_t n_local, const int64_t *head, int32_t head_cols,
+                       const int64_t *src_ptr, const int32_t *src_ids, int32_t src_kind, int64_t k,
+                       double p, double q, uint64_t seed, int32_t *next_out, int64_t *edge_out,
+                       uint32_t *status, void *stream);
 int n2v_gather_rows(const int64_t *ptr, const int32_t *ids, const int64_t *rows,
                     const int64_t *out_ptr, int64_t k, int32_t *out, void *stream);
+int n2v_gather_wedges(const uint32_t *edge_classes, const uint64_t *wedge_off, const void *wedge_pos,
+                      int32_t wide, const int64_t *edges, const int64_t *out_ptr, int64_t k,
+                      int32_t *out, int64_t *head, int32_t head_cols, void *stream);
 
 /* Measurement aid (bench.py; nothing on the product path calls it): the rate this device
  * sustains for the access shapes of K2 and K3 on the CALLER's buffer, so that the ceilings the

@@ -574,9 +574,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
 __global__ __launch_bounds__(kWavesPerBlock * 64) void partition_step_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ w, const double *__restrict__ w64, int64_t lo, int64_t n_local,
-    const int64_t *__restrict__ head, const int64_t *__restrict__ src_ptr,
+    const int64_t *__restrict__ head, int head_cols, const int64_t *__restrict__ src_ptr,
     const int32_t *__restrict__ src_ids, int64_t k, double p, double q, uint64_t seed,
-    int32_t *__restrict__ next_out, uint32_t *__restrict__ status) {
+    int32_t *__restrict__ next_out, int64_t *__restrict__ edge_out,
+    uint32_t *__restrict__ status) {
   __shared__ WaveLds lds_all[kWavesPerBlock];
   const int lane = threadIdx.x & 63;
   WaveLds &L = lds_all[threadIdx.x >> 6];
@@ -591,12 +592,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void partition_step_kernel(
   for (;;) {
     const int64_t i = queue.next(&status[1], lane);
     if (i < 0) break;
-    const uint64_t key = (uint64_t)readfirstlane_i64(head[4 * i + 1]);
-    const int64_t sv = readfirstlane_i64(head[4 * i + 2]);
-    const uint32_t step = (uint32_t)readfirstlane_i64(head[4 * i + 3]);
+    const int64_t *hd = head + i * head_cols;
+    const uint64_t key = (uint64_t)readfirstlane_i64(hd[1]);
+    const int64_t sv = readfirstlane_i64(hd[2]);
+    const uint32_t step = (uint32_t)readfirstlane_i64(hd[3]);
     const int32_t s = (int32_t)(sv >> 32);
     const int64_t local = (int64_t)(uint32_t)sv - lo;
     int32_t next = -1;
+    int64_t edge = -1;
     if (local < 0 || local >= n_local) {  // a walker that is not resident here
       if (lane == 0) atomicOr(status, N2V_ST_RANGE);
     } else {
@@ -632,10 +635,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void partition_step_kernel(
           if (lane == 0) atomicOr(status, N2V_ST_ZERODIV);
         } else {
           next = __builtin_amdgcn_readfirstlane(c.vcol[idx]);
+          edge = vb + idx;
         }
       }
     }
-    if (lane == 0) next_out[i] = next;
+    if (lane == 0) {
+      next_out[i] = next;
+      if (edge_out) edge_out[i] = edge;
+    }
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -680,22 +687,26 @@ extern "C" int n2v_walk_exact_launch(const n2v_graph *g, const int32_t *start_id
 }
 
 extern "C" int n2v_partition_step_unit_try(const int64_t *rowptr, const int32_t *col, int64_t lo,
-                                           int64_t n_local, const int64_t *head,
-                                           const int64_t *src_ptr, const int32_t *src_ids, int64_t k,
-                                           double p, double q, uint64_t seed, int32_t *next_out,
+                                           int64_t n_local, const int64_t *head, int32_t head_cols,
+                                           const int64_t *src_ptr, const int32_t *src_ids,
+                                           int32_t wedge_lists, int64_t k, double p, double q,
+                                           uint64_t seed, int32_t *next_out, int64_t *edge_out,
                                            uint32_t *status, void *stream);  // n2v_walk_unit.hip
 
 extern "C" int n2v_partition_step(const int64_t *rowptr, const int32_t *col, const float *w,
                                   const double *w64, int64_t lo, int64_t n_local,
-                                  const int64_t *head, const int64_t *src_ptr,
-                                  const int32_t *src_ids, int64_t k, double p, double q,
-                                  uint64_t seed, int32_t *next_out, uint32_t *status,
-                                  void *stream) {
+                                  const int64_t *head, int32_t head_cols, const int64_t *src_ptr,
+                                  const int32_t *src_ids, int32_t src_kind, int64_t k, double p,
+                                  double q, uint64_t seed, int32_t *next_out, int64_t *edge_out,
+                                  uint32_t *status, void *stream) {
   if (k < 0 || n_local < 0 || k >= 0xfffffff0ll || (w && w64)) return N2V_EINVAL;
   if (p == 0.0 || q == 0.0) return N2V_EINVAL;  // randomwalk.py:209-212 (ValueError upstream)
+  if (src_kind != N2V_SRC_ROWS && src_kind != N2V_SRC_WEDGES) return N2V_EINVAL;
+  if (head_cols < (src_kind == N2V_SRC_WEDGES ? 5 : 4)) return N2V_EINVAL;
+  if (src_kind == N2V_SRC_WEDGES && (w || w64)) return N2V_EINVAL;  // unit-weight parts only
   if (k == 0) return N2V_OK;
   if (!rowptr || !col || !head || !next_out || !status) return N2V_EINVAL;
-  if (q != 1.0 && !src_ptr) return N2V_EINVAL;
+  if ((q != 1.0 || src_kind == N2V_SRC_WEDGES) && !src_ptr) return N2V_EINVAL;
   int64_t blocks = (k + n2v::kWavesPerBlock - 1) / n2v::kWavesPerBlock;
   const int64_t cap = n2v::resident_blocks((const void *)n2v::partition_step_kernel,
                                            n2v::kWavesPerBlock * 64, 0);
@@ -703,15 +714,40 @@ extern "C" int n2v_partition_step(const int64_t *rowptr, const int32_t *col, con
   if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
     return N2V_ELAUNCH;
   if (!w && !w64) {  // unit weights: the closed forms of n2v_walk_unit.hip
-    const int rc = n2v_partition_step_unit_try(rowptr, col, lo, n_local, head, src_ptr, src_ids, k,
-                                               p, q, seed, next_out, status, stream);
+    const int rc = n2v_partition_step_unit_try(rowptr, col, lo, n_local, head, head_cols, src_ptr,
+                                               src_ids, src_kind == N2V_SRC_WEDGES, k, p, q, seed,
+                                               next_out, edge_out, status, stream);
     if (rc != 0) return rc < 0 ? rc : N2V_OK;
   }
+  if (src_kind == N2V_SRC_WEDGES) return N2V_EINVAL;  // (p, q) outside the unit kernels' range
   hipLaunchKernelGGL(n2v::partition_step_kernel, dim3((unsigned)blocks),
                      dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, rowptr, col, w, w64,
-                     lo, n_local, head, src_ptr, src_ids, k, p, q, seed, next_out, status);
+                     lo, n_local, head, (int)head_cols, src_ptr, src_ids, k, p, q, seed, next_out,
+                     edge_out, status);
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
+}
+
+// the wedge lists of `edges` (local edge indices of one part) copied back to back as 32-bit
+// positions, and the fifth header word of the walkers that carry them
+__global__ __launch_bounds__(256) void n2v_gather_wedges_kernel(
+    const uint32_t *__restrict__ edge_classes, const uint64_t *__restrict__ wedge_off,
+    const void *__restrict__ wedge_pos, int wide, const int64_t *__restrict__ edges,
+    const int64_t *__restrict__ out_ptr, int64_t k, int32_t *__restrict__ out,
+    int64_t *__restrict__ head, int head_cols) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  for (int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); j < k; j += n_waves) {
+    const int64_t e = edges[j];
+    const uint64_t raw = wedge_off[e];
+    const int64_t b = (int64_t)(raw & N2V_WEDGE_OFF_MASK), o = out_ptr[j];
+    const int64_t len = out_ptr[j + 1] - o;
+    if (lane == 0)
+      head[j * head_cols + 4] = (int64_t)((uint64_t)edge_classes[e] | (raw >> N2V_WEDGE_RPOS_SHIFT) << 32);
+    for (int64_t t = lane; t < len; t += 64)
+      out[o + t] = wide ? (int32_t)reinterpret_cast<const uint32_t *>(wedge_pos)[b + t]
+                        : (int32_t)reinterpret_cast<const uint16_t *>(wedge_pos)[b + t];
+  }
 }
 
 extern "C" int n2v_gather_rows(const int64_t *ptr, const int32_t *ids, const int64_t *rows,
@@ -723,6 +759,23 @@ extern "C" int n2v_gather_rows(const int64_t *ptr, const int32_t *ids, const int
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipLaunchKernelGGL(n2v::gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      (hipStream_t)stream, ptr, ids, rows, out_ptr, k, out);
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}
+
+extern "C" int n2v_gather_wedges(const uint32_t *edge_classes, const uint64_t *wedge_off,
+                                 const void *wedge_pos, int32_t wide, const int64_t *edges,
+                                 const int64_t *out_ptr, int64_t k, int32_t *out, int64_t *head,
+                                 int32_t head_cols, void *stream) {
+  if (k < 0 || head_cols < 5) return N2V_EINVAL;
+  if (k == 0) return N2V_OK;
+  if (!edge_classes || !wedge_off || !wedge_pos || !edges || !out_ptr || !out || !head)
+    return N2V_EINVAL;
+  int64_t blocks = (k + 3) / 4;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(n2v_gather_wedges_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, edge_classes, wedge_off, wedge_pos, (int)wide, edges, out_ptr,
+                     k, out, head, (int)head_cols);
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
 }

@@ -1271,12 +1271,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_UNIT_WAVES) void walk_exac
 // (n2v_partition_step, n2v_walk.hip: the same contract; this is its unit-weight instance.)  N(v)
 // comes from the part's CSR, N(s) from the rows that travelled with the walkers; the draw is
 // unit_draw above, the routine n2v_walk runs on the whole graph, hence the same vertex.
+// (Rows travel here.  When wedge lists travel instead the step is per-lane work:
+// partition_step_wedge_kernel, n2v_walk_wedge.hip.)
 template <bool kDyadic>
 __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_UNIT_WAVES) void partition_step_unit_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t lo,
-    int64_t n_local, const int64_t *__restrict__ head, const int64_t *__restrict__ src_ptr,
-    const int32_t *__restrict__ src_ids, int64_t k, double p, double q, UnitConsts K, uint64_t seed,
-    int32_t *__restrict__ next_out, uint32_t *__restrict__ status) {
+    int64_t n_local, const int64_t *__restrict__ head, int head_cols,
+    const int64_t *__restrict__ src_ptr, const int32_t *__restrict__ src_ids,
+    int64_t k, double p, double q, UnitConsts K, uint64_t seed, int32_t *__restrict__ next_out,
+    int64_t *__restrict__ edge_out, uint32_t *__restrict__ status) {
   __shared__ UnitLds lds_all[kWavesPerBlock];
   const int lane = threadIdx.x & 63;
   UnitLds &L = lds_all[threadIdx.x >> 6];
@@ -1291,12 +1294,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_UNIT_WAVES) void partition
   for (;;) {
     const int64_t i = queue.next(&status[1], lane);
     if (i < 0) break;
-    const uint64_t key = (uint64_t)readfirstlane_i64(head[4 * i + 1]);
-    const int64_t sv = readfirstlane_i64(head[4 * i + 2]);
-    const uint32_t step = (uint32_t)readfirstlane_i64(head[4 * i + 3]);
+    const int64_t *hd = head + i * head_cols;
+    const uint64_t key = (uint64_t)readfirstlane_i64(hd[1]);
+    const int64_t sv = readfirstlane_i64(hd[2]);
+    const uint32_t step = (uint32_t)readfirstlane_i64(hd[3]);
     const int32_t s = (int32_t)(sv >> 32);
     const int64_t local = (int64_t)(uint32_t)sv - lo;
     int32_t next = -1;
+    int64_t edge = -1;
     if (local < 0 || local >= n_local) {  // a walker that is not resident here
       if (lane == 0) atomicOr(status, N2V_ST_RANGE);
     } else {
@@ -1328,10 +1333,16 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_UNIT_WAVES) void partition
           if (ok)
             idx = unit_draw<kDyadic>(c, K, (uint32_t)(bits >> 32), (uint32_t)bits, lane, L N2V_STATS_PASS);
         }
-        if (idx >= 0) next = __builtin_amdgcn_readfirstlane(col[vb + idx]);
+        if (idx >= 0) {
+          next = __builtin_amdgcn_readfirstlane(col[vb + idx]);
+          edge = vb + idx;
+        }
       }
     }
-    if (lane == 0) next_out[i] = next;
+    if (lane == 0) {
+      next_out[i] = next;
+      if (edge_out) edge_out[i] = edge;
+    }
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -1758,26 +1769,34 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
 // the unit-weight instance of n2v_partition_step (n2v_walk.hip calls it first): 1 = launched,
 // 0 = (p, q) outside the unit kernels' range, < 0 on error.  status[1] was zeroed by the caller.
 extern "C" int n2v_partition_step_unit_try(const int64_t *rowptr, const int32_t *col, int64_t lo,
-                                           int64_t n_local, const int64_t *head,
-                                           const int64_t *src_ptr, const int32_t *src_ids, int64_t k,
-                                           double p, double q, uint64_t seed, int32_t *next_out,
+                                           int64_t n_local, const int64_t *head, int32_t head_cols,
+                                           const int64_t *src_ptr, const int32_t *src_ids,
+                                           int32_t wedge_lists, int64_t k, double p, double q,
+                                           uint64_t seed, int32_t *next_out, int64_t *edge_out,
                                            uint32_t *status, void *stream) {
   n2v::UnitConsts K;
   bool dyadic = false;
   if (!unit_consts(p, q, K, dyadic)) return 0;
+  if (wedge_lists)  // one lane per walker, the closed forms of the wedge kernel
+    return n2v_partition_step_wedge_launch(rowptr, col, lo, n_local, head, head_cols, src_ptr,
+                                           src_ids, k, p, q, K, seed, next_out, edge_out, status,
+                                           stream);
   int64_t blocks = (k + n2v::kWavesPerBlock - 1) / n2v::kWavesPerBlock;
-  const void *fn = dyadic ? (const void *)n2v::partition_step_unit_kernel<true>
-                          : (const void *)n2v::partition_step_unit_kernel<false>;
-  const int64_t cap = n2v::resident_blocks(fn, n2v::kWavesPerBlock * 64, 0);
-  if (blocks > cap) blocks = cap;
+#define N2V_PART_LAUNCH(D)                                                                        \
+  do {                                                                                           \
+    const int64_t cap = n2v::resident_blocks((const void *)n2v::partition_step_unit_kernel<D>,   \
+                                             n2v::kWavesPerBlock * 64, 0);                       \
+    if (blocks > cap) blocks = cap;                                                              \
+    hipLaunchKernelGGL(n2v::partition_step_unit_kernel<D>, dim3((unsigned)blocks),               \
+                       dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, rowptr, col, lo,  \
+                       n_local, head, (int)head_cols, src_ptr, src_ids, k, p, q, K, seed,        \
+                       next_out, edge_out, status);                                              \
+  } while (0)
   if (dyadic)
-    hipLaunchKernelGGL(n2v::partition_step_unit_kernel<true>, dim3((unsigned)blocks),
-                       dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, rowptr, col, lo,
-                       n_local, head, src_ptr, src_ids, k, p, q, K, seed, next_out, status);
+    N2V_PART_LAUNCH(true);
   else
-    hipLaunchKernelGGL(n2v::partition_step_unit_kernel<false>, dim3((unsigned)blocks),
-                       dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, rowptr, col, lo,
-                       n_local, head, src_ptr, src_ids, k, p, q, K, seed, next_out, status);
+    N2V_PART_LAUNCH(false);
+#undef N2V_PART_LAUNCH
   if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
   return 1;
 }

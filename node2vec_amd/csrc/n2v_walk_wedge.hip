@@ -304,6 +304,127 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
   }
 }
 
+
+// ---- one step of the walkers resident on one part of a partitioned graph, wedge lists travelling
+// (n2v_partition_step with N2V_SRC_WEDGES, n2v_walk.hip).  A walker that leaves along edge e brings
+// the class counts of e, the return position and the wedge list of e -- exactly what the kernel
+// above reads from hops[e], wedge_off[e] and wedge_pos -- so its step here is the same per-lane
+// work: the row sum from the counts, the class of slot `pick` by one search in the list, the
+// two exits, else the closed form of the arrangement (pair_listed).  One LANE per walker; neither
+// N(s) nor a pass over N(v).  (The step is restated, not shared with the kernel above: that one's
+// registers are the flagship configuration's.)
+template <int kMode>
+__global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void partition_step_wedge_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t lo, int64_t n_local,
+    const int64_t *__restrict__ head, int head_cols, const int64_t *__restrict__ src_ptr,
+    const int32_t *__restrict__ src_ids, int64_t k, double p, double q, UnitConsts K, uint64_t seed,
+    int32_t *__restrict__ next_out, int64_t *__restrict__ edge_out, uint32_t *__restrict__ status) {
+  __shared__ uint32_t stage_all[kWedgeThreads / 64][16 * 32];  // 2 KB per wave (lane_case_a)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  uint32_t *stage = stage_all[tid >> 6];
+  const bool biased = !(p == 1.0 && q == 1.0);
+  const bool need_mem = q != 1.0;
+  const bool merge_r = K.bR == K.bO;
+  constexpr bool kShared = kMode == 1 || kMode == 2;
+#ifdef N2V_CHECK
+  n2v_check_status = status;
+#endif
+  // whole waves stay in the loop (lane_case_a stages through the wave's LDS tile)
+  const int64_t k_up = (k + 63) & ~(int64_t)63;
+  for (int64_t i = (int64_t)blockIdx.x * kWedgeThreads + tid; i < k_up;
+       i += (int64_t)gridDim.x * kWedgeThreads) {
+    const bool have = i < k;
+    const int64_t *hd = head + (have ? i : 0) * head_cols;
+    const uint64_t key = (uint64_t)hd[1];
+    const int64_t sv = hd[2];
+    const uint32_t step = (uint32_t)hd[3];
+    const int32_t s = (int32_t)(sv >> 32);
+    const int64_t local = (int64_t)(uint32_t)sv - lo;
+    int32_t next = -1;
+    int64_t edge = -1;
+    bool ok = have;
+    if (have && (local < 0 || local >= n_local)) {  // a walker that is not resident here
+      atomicOr(status, N2V_ST_RANGE);
+      ok = false;
+    }
+    int64_t vb = 0;
+    int n = 0;
+    if (ok) {
+      vb = rowptr[local];
+      n = (int)(rowptr[local + 1] - vb);
+      ok = n > 0;  // (arrivals at a sink were dropped by the caller, fugue.py:147)
+    }
+    if (ok) {
+      const uint64_t bits = step_bits(walker_stream(seed, key), step);
+      const uint32_t u1 = (uint32_t)(bits >> 32), u2 = (uint32_t)bits;
+      const int pick = pick_index(u1, n);
+      int idx = pick;
+      if (s >= 0 && biased) {
+        const uint64_t extra = (uint64_t)hd[4];
+        const uint32_t ec = (uint32_t)extra;
+        const uint32_t fR = ec >> N2V_EC_RETURN_SHIFT, fM = ec & N2V_EC_SHARED_MASK;
+        const int w_rpos = (int)((extra >> 32) & 0xffffffu);
+        const int64_t sb = src_ptr[i];
+        const uint32_t *list = reinterpret_cast<const uint32_t *>(src_ids) + sb;
+        if (fR == N2V_EC_RETURN_SAT || fM == N2V_EC_SHARED_MASK || src_ptr[i + 1] - sb != (int64_t)fM ||
+            (int64_t)fR + (int64_t)fM > n || w_rpos + (int)fR > n) {
+          atomicOr(status, N2V_ST_RANGE);  // not a wedge list of an edge into this row
+          idx = -1;
+        } else {
+          const int nR = merge_r ? 0 : (int)fR, nM = need_mem ? (int)fM : 0, nO = n - nR - nM;
+          const bool isR = !merge_r && pick >= w_rpos && pick < w_rpos + (int)fR;  // N(v)[pick] == s
+          bool isM = false;
+          int lo_pick = 0;  // entries of the list below `pick`
+          if (need_mem && !isR && nM > 0) lo_pick = wedge_lower_t<uint32_t>(list, 0, nM, pick, isM);
+          double avg;  // :172
+          if constexpr (kMode == 2) {
+            const double b_pick = pick3(isR, isM, K.bR, K.bM, K.bO);
+            const double approx = ((double)nR * K.bR + (double)nM * K.bM + (double)nO * K.bO) / (double)n;
+            const double eps = ((double)n + 8.0) * 4.5e-16;
+            const double r2a = (double)u2 * (1.0 / 4294967296.0);
+            if (b_pick < approx * (1.0 - eps) && r2a < (b_pick / approx) * (1.0 - 2.0 * eps))
+              avg = approx;  // only the (decided) comparison below reads it
+            else
+              avg = lane_row_sum<uint32_t>(n, K, nR, w_rpos, nM, list) / (double)n;
+          } else {
+            const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
+            avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;
+          }
+          const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) / avg;  // :173
+          const double r2 = (double)u2 * (1.0 / 4294967296.0);
+          if (!(p_pick < 1.0 && r2 < p_pick)) {
+            const bool uR = K.bR < avg, uM = K.bM < avg, uO = K.bO < avg;
+            const bool any_under = (nR && uR) || (nM && uM) || (nO && uO);
+            const bool any_over = (nR && !uR) || (nM && !uM) || (nO && !uO);
+            if (!any_under || !any_over) {  // the loop of :182 never runs
+              if (!(r2 < p_pick)) idx = 0;
+            } else {
+              int arr = 0;
+              if (uO && !(nR && uR) && !(nM && uM)) arr = 1;
+              else if (!uO && nO > 0 && (!nR || uR) && (!nM || uM)) arr = 2;
+              else if (kShared && uO && nR && uR && nM && !uM) arr = 3;
+              else if (kShared && !uO && nO > 0 && nR && !uR && nM && uM) arr = 4;
+              else if (kShared && uO && nR && !uR && nM && uM) arr = 5;
+              idx = pair_listed<uint32_t, kMode>(arr, n, pick, r2, K, avg, nR, w_rpos, nM, list, isR,
+                                                 isM, lo_pick, stage, lane);
+              N2V_CHECK_RANGE(2, idx, 0, n);
+            }
+          }
+        }
+      }
+      if (idx >= 0) {
+        next = col[vb + idx];
+        edge = vb + idx;
+      }
+    }
+    if (have) {
+      next_out[i] = next;
+      if (edge_out) edge_out[i] = edge;
+    }
+  }
+}
+
 }  // namespace n2v
 
 // returns 1 when the kernel applies (and was launched), 0 when it does not, < 0 on error
@@ -327,6 +448,29 @@ int n2v_walk_wedge_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_s
   hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(n2v::kWedgeThreads), 0,
                      (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, p, q, K, seed,
                      walks_out, valid_out, status);
+  if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
+  return 1;
+}
+
+// the wedge-list instance of n2v_partition_step: 1 = launched, < 0 on error
+int n2v_partition_step_wedge_launch(const int64_t *rowptr, const int32_t *col, int64_t lo,
+                                    int64_t n_local, const int64_t *head, int32_t head_cols,
+                                    const int64_t *src_ptr, const int32_t *src_ids, int64_t k,
+                                    double p, double q, const n2v::UnitConsts &K, uint64_t seed,
+                                    int32_t *next_out, int64_t *edge_out, uint32_t *status,
+                                    void *stream) {
+  if (head_cols < 5 || !src_ptr || !src_ids) return N2V_EINVAL;
+  const bool alone_under = K.bO <= 1.0 && K.bR >= K.bO, alone_over = K.bO >= 1.0 && K.bR <= K.bO;
+  auto kernel = !K.dyadic    ? n2v::partition_step_wedge_kernel<2>
+                : alone_under ? n2v::partition_step_wedge_kernel<0>
+                : alone_over  ? n2v::partition_step_wedge_kernel<3>
+                              : n2v::partition_step_wedge_kernel<1>;
+  int64_t blocks = (k + n2v::kWedgeThreads - 1) / n2v::kWedgeThreads;
+  const int64_t cap = n2v::resident_blocks((const void *)kernel, n2v::kWedgeThreads, 0);
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(n2v::kWedgeThreads), 0, (hipStream_t)stream,
+                     rowptr, col, lo, n_local, head, (int)head_cols, src_ptr, src_ids, k, p, q, K, seed,
+                     next_out, edge_out, status);
   if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
   return 1;
 }

@@ -14,10 +14,14 @@ design point on a GPU node:
   walker, the table never materialised; `tables_step` keeps the launch-per-stage form on
   materialised tables as a cross-check), bit-identical to n2v_walk's exact mode, whose RNG is
   keyed by (seed, start vertex, ordinal, step) and not by where the walker happens to be;
-* then the walker MIGRATES to the owner of the vertex it drew, carrying a 32-byte header
-  (output row, RNG key, previous/current vertex, step) and -- only when q != 1, the one case in
-  which N(s) decides anything (randomwalk.py:226-229) -- the row it just left (the
-  `src_neighbors` of its next step): one variable-size all-to-all per step
+* then the walker MIGRATES to the owner of the vertex it drew, carrying a 40-byte header
+  (output row, RNG key, previous/current vertex, step, classes) and -- only when q != 1, the one
+  case in which N(s) decides anything (randomwalk.py:226-229) -- either the row it just left (the
+  `src_neighbors` of its next step) or, when the parts hold the per-edge tables of a unit-weight
+  graph, just the WEDGE LIST of the edge it leaves along (the positions, in the row it is going
+  to, of the neighbours that row shares with this one: usually a handful of words instead of a
+  row, and the receiving rank then needs neither a search over N(s) nor a pass over N(v)): one
+  variable-size all-to-all per step
   (`torch.distributed.all_to_all_single`, RCCL over xGMI on the GPUs, gloo in the CPU tests);
 * every appended vertex is logged as (row, position, vertex) and sent once, at the end, to the
   rank that emits the walk (the owner of its start vertex); walkers that reach a vertex without
@@ -36,6 +40,9 @@ import torch
 from node2vec_amd.graph import DeviceGraph
 from node2vec_amd.shard import shard_range
 
+WEDGE_OFF_MASK = (1 << 40) - 1  # include/n2v_hip.h: N2V_WEDGE_OFF_MASK
+HEAD_COLS = 5  # (output row, RNG key, s << 32 | v, step, classes of the step's table)
+
 
 @dataclass
 class GraphPart:
@@ -48,6 +55,12 @@ class GraphPart:
     col: torch.Tensor
     w: Optional[torch.Tensor]
     bounds: torch.Tensor
+    # the part's slice of the per-edge tables of a unit-weight graph (n2v_edge_classes_build,
+    # n2v_wedge_build; list offsets rebased to the slice) or None: with them a walker that
+    # leaves along edge e carries the wedge list of e instead of the whole row of its vertex
+    edge_classes: Optional[torch.Tensor] = None
+    wedge_off: Optional[torch.Tensor] = None
+    wedge_pos: Optional[torch.Tensor] = None
 
     @property
     def device(self):
@@ -57,12 +70,24 @@ class GraphPart:
         return torch.searchsorted(self.bounds, v.to(torch.int64), right=True) - 1
 
     def nbytes(self) -> int:
-        return sum(t.numel() * t.element_size() for t in (self.rowptr, self.col, self.w) if t is not None)
+        return sum(t.numel() * t.element_size() for t in (self.rowptr, self.col, self.w, self.edge_classes,
+                                                         self.wedge_off, self.wedge_pos) if t is not None)
 
 
-def partition_graph(g: DeviceGraph, n_parts: int, balance: str = "edges") -> List[GraphPart]:
+def partition_graph(g: DeviceGraph, n_parts: int, balance: str = "edges",
+                    wedges: bool = True) -> List[GraphPart]:
     """Contiguous vertex ranges with about equal numbers of EDGES (default) or of vertices.
-    A rank of a real run would load only its own part; here they are cut from a whole graph."""
+    A rank of a real run would load only its own part; here they are cut from a whole graph.
+    `wedges`: on a unit-weight graph on the GPU the per-edge tables (class counts and wedge
+    lists) are built once on the whole graph and every part keeps the slice of ITS edges -- part
+    of the partitioned graph's stored form, like the rows themselves."""
+    tables = None
+    if wedges and g.unit_weights and g.rowptr.is_cuda and g.n_edges > 0:
+        if g.wedge_off is None and not g.wedge_tried:
+            g.wedge_tried = True
+            g.build_wedges()
+        if g.wedge_off is not None:
+            tables = (g.edge_classes, g.wedge_off, g.wedge_pos)
     V = g.n_vertices
     if balance == "edges" and g.n_edges > 0:
         targets = torch.arange(1, n_parts, device=g.device, dtype=torch.int64) * g.n_edges // n_parts
@@ -77,24 +102,39 @@ def partition_graph(g: DeviceGraph, n_parts: int, balance: str = "edges") -> Lis
     for r, (lo, hi) in enumerate(zip(los, his)):
         hi = max(hi, lo)
         e0, e1 = int(g.rowptr[lo]), int(g.rowptr[hi])
-        parts.append(GraphPart(r, lo, hi, (g.rowptr[lo:hi + 1] - e0).contiguous(),
-                               g.col[e0:e1].contiguous(),
-                               None if g.unit_weights else g.w[e0:e1].contiguous(), bounds[:-1].contiguous()))
+        part = GraphPart(r, lo, hi, (g.rowptr[lo:hi + 1] - e0).contiguous(),
+                         g.col[e0:e1].contiguous(),
+                         None if g.unit_weights else g.w[e0:e1].contiguous(), bounds[:-1].contiguous())
+        if tables is not None and e1 > e0:
+            ec, off, pos = tables
+            cnt = (ec[e0:e1] & 0xffffff).to(torch.int64)
+            o0 = int(off[e0] & WEDGE_OFF_MASK)
+            o1 = int(off[e1 - 1] & WEDGE_OFF_MASK) + int(cnt[-1])
+            part.edge_classes = ec[e0:e1].contiguous()
+            part.wedge_off = (off[e0:e1] - o0).contiguous()  # the return position (bits 40+) stays
+            part.wedge_pos = pos[o0:o1].contiguous() if o1 > o0 else pos.new_zeros(1)
+        elif tables is not None:  # a part without edges keeps (empty) tables: same mode on every rank
+            part.edge_classes = tables[0][:0].contiguous()
+            part.wedge_off = tables[1][:0].contiguous()
+            part.wedge_pos = tables[2].new_zeros(1)
+        parts.append(part)
     return parts
 
 
 # ---- messages ---------------------------------------------------------------------------------
 @dataclass
 class Walkers:
-    """a batch of walker states: header int64 [k, 4] = (output row, RNG key, s << 32 | v, step)
-    and the travelling rows N(s) as a packed CSR (ptr int64 [k + 1], ids int32 [nnz])"""
+    """a batch of walker states: header int64 [k, 5] = (output row, RNG key, s << 32 | v, step,
+    classes) and what travels with each walker as a packed CSR (ptr int64 [k + 1], ids int32
+    [nnz]): the row N(s), or -- when the parts carry wedge tables -- the wedge list of the edge
+    (s -> v), with classes = edge_classes | return position << 32 (else 0)"""
     head: torch.Tensor
     ptr: torch.Tensor
     ids: torch.Tensor
 
     @classmethod
     def empty(cls, device):
-        return cls(torch.zeros((0, 4), dtype=torch.int64, device=device),
+        return cls(torch.zeros((0, HEAD_COLS), dtype=torch.int64, device=device),
                    torch.zeros(1, dtype=torch.int64, device=device),
                    torch.zeros(0, dtype=torch.int32, device=device))
 
@@ -112,6 +152,8 @@ class Walkers:
         parts = [p for p in parts if len(p)]
         if not parts:
             return cls.empty(device)
+        if len(parts) == 1:
+            return parts[0]
         lens = torch.cat([p.ptr[1:] - p.ptr[:-1] for p in parts])
         ptr = torch.zeros(lens.numel() + 1, dtype=torch.int64, device=device)
         torch.cumsum(lens, 0, out=ptr[1:])
@@ -199,18 +241,28 @@ class RankState:
         if self.L == 0:
             return
         head = torch.stack([rows, keys, (torch.full_like(v, -1) << 32) | (v & 0xffffffff),
-                            torch.zeros_like(rows)], 1)
+                            torch.zeros_like(rows), torch.zeros_like(rows)], 1)
         self.walkers = Walkers(head, torch.zeros(rows.numel() + 1, dtype=torch.int64, device=dev),
                                torch.zeros(0, dtype=torch.int32, device=dev))
 
     # -- the step as ONE launch: n2v_partition_step reads N(v) from the part's CSR ---------------
+    def _wedge_mode(self) -> bool:
+        """the walkers carry wedge lists (not rows): the parts hold the per-edge tables, N(s)
+        matters at all (q != 1), and (p, q) is in the range of the unit-weight kernels"""
+        part = self.part
+        ordinary = all(2.0 ** -20 <= 1.0 / x <= 2.0 ** 20 for x in (self.p, self.q))
+        return part.wedge_off is not None and part.w is None and self.q != 1.0 and ordinary
+
     def _advance_fused(self, n_parts: int) -> List[Walkers]:
         """next_step_random_walk (randomwalk.py:300-339) for every resident walker in one launch
-        (one wave per walker, the table never materialised), then the rows that must travel are
-        packed by one more (n2v_gather_rows).  N(s) only decides shared / other
-        (randomwalk.py:226-229): with q == 1 -- the reference's defaults p == q == 1 included, where
-        every table is probs == [1.0] * n and the draw is pick = int(r1 * n) -- the walker travels
-        as its 32-byte header alone."""
+        (one wave per walker, the table never materialised), then what must travel is packed by
+        one more.  N(s) only decides shared / other (randomwalk.py:226-229): with q == 1 -- the
+        reference's defaults p == q == 1 included, where every table is probs == [1.0] * n and
+        the draw is pick = int(r1 * n) -- the walker travels as its 40-byte header alone.
+        Otherwise it takes the WEDGE LIST of the edge it leaves along (n2v_gather_wedges: the
+        positions in the next row of the neighbours shared with this one, from this part's slice
+        of the wedge table) when the parts carry the per-edge tables, else the whole row it
+        leaves (n2v_gather_rows)."""
         from node2vec_amd import _lib
 
         L = _lib.load()
@@ -219,8 +271,10 @@ class RankState:
         head_in = wk.head.contiguous()
         rows, keys, sv, step = head_in[:, 0], head_in[:, 1], head_in[:, 2], head_in[:, 3]
         v = sv & 0xffffffff
+        wedge = self._wedge_mode()
         carry = self.q != 1.0
         nxt32 = torch.empty(k, dtype=torch.int32, device=dev)
+        edge = torch.empty(k, dtype=torch.int64, device=dev) if wedge else None
         if self.status is None:
             self.status = torch.zeros(4, dtype=torch.int32, device=dev)
         w = part.w
@@ -229,31 +283,45 @@ class RankState:
         src_ids = wk.ids if wk.ids.numel() else torch.zeros(1, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.n2v_partition_step(part.rowptr.data_ptr(), part.col.data_ptr(), w32, w64,
-                                            part.lo, part.hi - part.lo, head_in.data_ptr(),
-                                            wk.ptr.data_ptr(), src_ids.data_ptr(), k, float(self.p),
-                                            float(self.q), int(self.seed) & (2 ** 64 - 1),
-                                            nxt32.data_ptr(), self.status.data_ptr(),
+                                            part.lo, part.hi - part.lo, head_in.data_ptr(), HEAD_COLS,
+                                            wk.ptr.data_ptr(), src_ids.data_ptr(), int(wedge), k,
+                                            float(self.p), float(self.q),
+                                            int(self.seed) & (2 ** 64 - 1), nxt32.data_ptr(),
+                                            edge.data_ptr() if wedge else 0, self.status.data_ptr(),
                                             _lib.current_stream_ptr()), "n2v_partition_step")
         nxt = nxt32.to(torch.int64)
         self.log.append(torch.stack([rows, step + 1, nxt], 1))
         keep = step + 1 < self.L
-        head = torch.stack([rows, keys, (v << 32) | (nxt & 0xffffffff), step + 1], 1)[keep]
+        head = torch.stack([rows, keys, (v << 32) | (nxt & 0xffffffff), step + 1,
+                            torch.zeros_like(rows)], 1)[keep]
         dest = part.owner(nxt[keep].clamp(min=0))
         order = torch.argsort(dest, stable=True)
-        head = head[order]
+        head = head[order].contiguous()
         cuts = torch.zeros(n_parts + 1, dtype=torch.int64, device=dev)
         torch.cumsum(torch.bincount(dest, minlength=n_parts), 0, out=cuts[1:])
         k2 = head.shape[0]
         ptr = torch.zeros(k2 + 1, dtype=torch.int64, device=dev)
-        if carry:
+        if wedge:
+            gone = edge[keep][order].clamp_(min=0).contiguous()  # (-1 only beside a raised status)
+            torch.cumsum((part.edge_classes[gone] & 0xffffff).to(torch.int64), 0, out=ptr[1:])
+        elif carry:
             local = (v[keep] - part.lo)[order].contiguous()
             torch.cumsum(part.rowptr[local + 1] - part.rowptr[local], 0, out=ptr[1:])
-        # one transfer: the status word, the walkers per destination, the row words per destination
+        # one transfer: the status word, the walkers per destination, the words per destination
         host = torch.cat([self.status[:1].to(torch.int64), cuts, ptr[cuts]]).tolist()
         _lib.check_status_word(host[0], "n2v_partition_step")
         cuts_h, at = host[1:n_parts + 2], host[n_parts + 2:]
         ids = torch.zeros(0, dtype=torch.int32, device=dev)
-        if carry and at[-1] > 0:
+        if wedge and k2 > 0:
+            ids = torch.empty(max(at[-1], 1), dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(L.n2v_gather_wedges(part.edge_classes.data_ptr(), part.wedge_off.data_ptr(),
+                                               part.wedge_pos.data_ptr(),
+                                               int(part.wedge_pos.dtype == torch.int32), gone.data_ptr(),
+                                               ptr.data_ptr(), k2, ids.data_ptr(), head.data_ptr(),
+                                               HEAD_COLS, _lib.current_stream_ptr()), "n2v_gather_wedges")
+            ids = ids[:at[-1]]
+        elif carry and at[-1] > 0:
             ids = torch.empty(at[-1], dtype=torch.int32, device=dev)
             with torch.cuda.device(dev):
                 _lib.check(L.n2v_gather_rows(part.rowptr.data_ptr(), part.col.data_ptr(),
@@ -290,7 +358,7 @@ class RankState:
         self.log.append(torch.stack([rows, step + 1, nxt], 1))
         done = step + 1 >= self.L
         keep = ~done
-        head = torch.stack([rows, keys, (v << 32) | nxt, step + 1], 1)[keep]
+        head = torch.stack([rows, keys, (v << 32) | nxt, step + 1, torch.zeros_like(rows)], 1)[keep]
         moving = Walkers(head, *self._subrows(dptr, dids, keep))
         dest = part.owner(nxt[keep])
         return [moving.select(torch.nonzero(dest == r).reshape(-1)) for r in range(n_parts)]
@@ -390,15 +458,28 @@ def _all_to_all_var(tensors: List[torch.Tensor], group, dist) -> List[torch.Tens
 
 
 def _exchange_walkers(out: List[Walkers], group, dist, dev) -> List[Walkers]:
-    heads = _all_to_all_var([w.head for w in out], group, dist)
-    lens = _all_to_all_var([(w.ptr[1:] - w.ptr[:-1]) for w in out], group, dist)
-    ids = _all_to_all_var([w.ids for w in out], group, dist)
-    res = []
-    for h, ln, i in zip(heads, lens, ids):
-        ptr = torch.zeros(ln.numel() + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(ln, 0, out=ptr[1:])
-        res.append(Walkers(h, ptr, i))
-    return res
+    """The migration of one step: three collectives -- the sizes (walkers and row words per
+    destination, one [world, 2] exchange), the headers with the length of what travels with each
+    walker as an extra column, and those words.  Segments arrive in source order in both
+    payloads, so the receiver rebuilds ONE batch: ptr = prefix sums of the extra column."""
+    world = dist.get_world_size(group)
+    cpu = dist.get_backend(group) == "gloo"  # gloo moves host tensors
+    wire = torch.device("cpu") if cpu else dev
+    head5 = torch.cat([torch.cat([w.head, (w.ptr[1:] - w.ptr[:-1])[:, None]], 1) for w in out]).to(wire)
+    ids = torch.cat([w.ids for w in out]).to(wire)
+    sizes = [[len(w), int(w.ids.numel())] for w in out]  # shapes: known on the host, no sync
+    n_send = torch.tensor(sizes, dtype=torch.int64, device=wire)
+    n_recv = torch.empty_like(n_send)
+    dist.all_to_all_single(n_recv, n_send, group=group)
+    got = n_recv.tolist()
+    recv_h = torch.empty((sum(g[0] for g in got), HEAD_COLS + 1), dtype=torch.int64, device=wire)
+    dist.all_to_all_single(recv_h, head5.contiguous(), [g[0] for g in got], [z[0] for z in sizes], group=group)
+    recv_i = torch.empty(sum(g[1] for g in got), dtype=torch.int32, device=wire)
+    dist.all_to_all_single(recv_i, ids.contiguous(), [g[1] for g in got], [z[1] for z in sizes], group=group)
+    recv_h, recv_i = recv_h.to(dev), recv_i.to(dev)
+    ptr = torch.zeros(recv_h.shape[0] + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(recv_h[:, HEAD_COLS], 0, out=ptr[1:])
+    return [Walkers(recv_h[:, :HEAD_COLS].contiguous(), ptr, recv_i)]
 
 
 def walk_partitioned(part: GraphPart, start_ids: torch.Tensor, num_walks: int, walk_length: int,

@@ -91,7 +91,8 @@ while time.time() - t0 < budget:
     ok = np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy(), want)
     if ok and PARTITIONED:
         n_parts = int(rng.integers(1, 7))
-        parts = P.partition_graph(g, n_parts, balance=str(rng.choice(["edges", "vertices"])))
+        parts = P.partition_graph(g, n_parts, balance=str(rng.choice(["edges", "vertices"])),
+                                  wedges=bool(rng.random() < 0.7))  # wedge lists or whole rows travel
         got, gv = P.walk_partitioned_local(parts, starts, nw, wl, p, q, seed)
         ok = np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy()[wv], want[wv])
         if not ok:

@@ -13,15 +13,18 @@ from node2vec_amd import randomwalk as rw  # noqa: E402
 from node2vec_amd import synthetic  # noqa: E402
 
 g = synthetic.rmat(20, 5_000_000, device="cuda")
-parts = P.partition_graph(g, 8)
 start = rw.start_vertices(g)
-for p, q in ((1.0, 1.0), (0.5, 2.0), (0.5, 1.0), (4.0, 0.25)):
-    want, wv = rw.walk(g, start, 2, 20, p, q, 42)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    walks, valid = P.walk_partitioned_local(parts, start, 2, 20, p, q, 42)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ok = torch.equal(valid, wv) and torch.equal(walks, want)
-    print(f"p={p} q={q}: {int(valid.sum())} walkers x 20 steps in {dt:.2f} s = "
-          f"{int(valid.sum()) * 20 / dt / 1e6:.2f} M steps/s, bit-identical to n2v_walk: {ok}", flush=True)
+for wedges in (True, False):
+    parts = P.partition_graph(g, 8, wedges=wedges)
+    print("walkers carry", "wedge lists" if parts[0].wedge_off is not None else "whole rows",
+          "when q != 1; bytes of the largest part:", max(pt.nbytes() for pt in parts), flush=True)
+    for p, q in ((1.0, 1.0), (0.5, 2.0), (0.5, 1.0), (4.0, 0.25), (0.7, 1.3)):
+        want, wv = rw.walk(g, start, 2, 20, p, q, 42)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        walks, valid = P.walk_partitioned_local(parts, start, 2, 20, p, q, 42)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ok = torch.equal(valid, wv) and torch.equal(walks, want)
+        print(f"  p={p} q={q}: {int(valid.sum())} walkers x 20 steps in {dt:.2f} s = "
+              f"{int(valid.sum()) * 20 / dt / 1e6:.2f} M steps/s, bit-identical to n2v_walk: {ok}", flush=True)

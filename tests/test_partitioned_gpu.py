@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("step", ["fused", "tables"])
+@pytest.mark.parametrize("step", ["fused", "fused_rows", "tables"])
 @pytest.mark.parametrize("weighted", [False, True])
 def test_partitioned_equals_the_oracle_bit_for_bit(oracle, weighted, step):
     """the HIP step function on every part, walkers migrating, against the ORACLE's walk over the
@@ -26,9 +26,12 @@ def test_partitioned_equals_the_oracle_bit_for_bit(oracle, weighted, step):
     dst = np.concatenate([rng.integers(0, nv, ne), rng.integers(0, nv, 3000)])
     w = (rng.random(len(src)) * 1.7 + 0.3) if weighted else None
     g = DeviceGraph.from_edges(src, dst, w, n_vertices=nv, device="cuda")
-    parts = P.partition_graph(g, 3)
+    # "fused": walkers carry wedge lists (unit weights; weighted parts have no such tables and
+    # carry rows); "fused_rows": the same launch with whole rows travelling; "tables": launch per stage
+    parts = P.partition_graph(g, 3, wedges=step == "fused")
+    assert (parts[0].wedge_off is not None) == (step == "fused" and not weighted)
     start = rw.start_vertices(g)[::3].contiguous()
-    step_fn = P.hip_step if step == "fused" else P.tables_step
+    step_fn = P.tables_step if step == "tables" else P.hip_step
     for p, q in ((1.0, 1.0), (0.5, 2.0), (4.0, 0.25), (0.3, 1.0)):
         want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(),
                                       None if g.unit_weights else g.w.cpu().numpy(),
@@ -55,8 +58,11 @@ def test_partitioned_equals_n2v_walk_bit_for_bit(weighted):
     g = DeviceGraph.from_edges(src, dst, w, n_vertices=nv, device="cuda")
     parts = P.partition_graph(g, 4)
     assert max(pt.col.numel() for pt in parts) < 0.3 * g.n_edges  # a rank stores ~E / 4
+    if not weighted:  # every part holds the slice of the wedge table of its own edges
+        assert all(pt.wedge_off is not None and pt.wedge_off.numel() == pt.col.numel() for pt in parts)
+        assert sum(pt.wedge_pos.numel() for pt in parts) <= g.wedge_pos.numel() + len(parts)
     start = rw.start_vertices(g)[::7].contiguous()
-    for p, q in ((1.0, 1.0), (0.5, 2.0), (4.0, 0.25), (3.0, 1.0)):
+    for p, q in ((1.0, 1.0), (0.5, 2.0), (4.0, 0.25), (3.0, 1.0), (0.7, 1.3), (4.0, 2.0)):
         want, wv = rw.walk(g, start, 3, 15, p, q, 77)
         walks, valid = P.walk_partitioned_local(parts, start, 3, 15, p, q, 77)
         assert torch.equal(valid, wv)
