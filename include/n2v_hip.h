@@ -407,7 +407,9 @@ int n2v_corpus_index(const int32_t *walks, const uint8_t *valid, const int32_t *
  *                              that stores that edge (n2v_wedge_build on its part), with
  *                              head[.][4] = edge_classes[e] | return position << 32: the class of
  *                              every slot of the step's table is then known by position and
- *                              neither N(s) nor a pass over N(v) is needed
+ *                              neither N(s) nor a pass over N(v) is needed.  With q == 1 the
+ *                              lists are empty (only the return run matters), with p == q == 1
+ *                              nothing is read beyond the first four header words
  *   next_out  int32 [k]: the vertex drawn (-1 when status reports an error for that walker)
  *   edge_out  int64 [k] or NULL: the index (into the part's col) of the edge drawn
  *   status    uint32 [4] as for n2v_walk; [1] is used as the walker counter.
@@ -424,6 +426,21 @@ int n2v_partition_step(const int64_t *rowptr, const int32_t *col, const float *w
                        const int64_t *src_ptr, const int32_t *src_ids, int32_t src_kind, int64_t k,
                        double p, double q, uint64_t seed, int32_t *next_out, int64_t *edge_out,
                        uint32_t *status, void *stream);
+/* The elementwise half of the routing that follows a step: for walker i the path record
+ * log_out[i] = (output row, step + 1, next) -- or (row, -1, -1) when next < 0: the vertex it stood
+ * on has no out-edges, it vanished on arrival (fugue.py:147) --, the header it travels on with,
+ * dest_out[i] = the part that owns `next` (bounds: first vertex of every part, ascending) or
+ * n_parts when the walk is complete or the walker vanished, len_out[i] / src_out[i] = how many
+ * words travel with it and where they come from (carry 0: none; N2V_SRC_ROWS + 1: the row of its
+ * vertex, src = local row; N2V_SRC_WEDGES + 1: the wedge list of edge[i], src = that edge;
+ * N2V_SRC_WEDGES + 2: src = that edge but no words -- q == 1, only the counts and the return
+ * position of the edge travel, in the header).  The caller groups the walkers by a stable sort
+ * of dest_out. */
+int n2v_partition_route(const int64_t *head_in, int32_t head_cols, const int32_t *next,
+                        const int64_t *edge, int64_t k, int32_t walk_length, const int64_t *bounds,
+                        int32_t n_parts, int32_t carry, const int64_t *rowptr, int64_t lo,
+                        const uint32_t *edge_classes, int64_t *log_out, int64_t *head_out,
+                        int32_t *dest_out, int64_t *len_out, int64_t *src_out, void *stream);
 int n2v_gather_rows(const int64_t *ptr, const int32_t *ids, const int64_t *rows,
                     const int64_t *out_ptr, int64_t k, int32_t *out, void *stream);
 int n2v_gather_wedges(const uint32_t *edge_classes, const uint64_t *wedge_off, const void *wedge_pos,

@@ -367,7 +367,8 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void partition_step
         const int w_rpos = (int)((extra >> 32) & 0xffffffu);
         const int64_t sb = src_ptr[i];
         const uint32_t *list = reinterpret_cast<const uint32_t *>(src_ids) + sb;
-        if (fR == N2V_EC_RETURN_SAT || fM == N2V_EC_SHARED_MASK || src_ptr[i + 1] - sb != (int64_t)fM ||
+        if (fR == N2V_EC_RETURN_SAT || fM == N2V_EC_SHARED_MASK ||
+            src_ptr[i + 1] - sb != (need_mem ? (int64_t)fM : 0) ||  // (q == 1: no list travels)
             (int64_t)fR + (int64_t)fM > n || w_rpos + (int)fR > n) {
           atomicOr(status, N2V_ST_RANGE);  // not a wedge list of an edge into this row
           idx = -1;
@@ -459,7 +460,8 @@ int n2v_partition_step_wedge_launch(const int64_t *rowptr, const int32_t *col, i
                                     double p, double q, const n2v::UnitConsts &K, uint64_t seed,
                                     int32_t *next_out, int64_t *edge_out, uint32_t *status,
                                     void *stream) {
-  if (head_cols < 5 || !src_ptr || !src_ids) return N2V_EINVAL;
+  const bool biased = !(p == 1.0 && q == 1.0);  // p == q == 1: the header's first four words do
+  if (biased && (head_cols < 5 || !src_ptr || !src_ids)) return N2V_EINVAL;
   const bool alone_under = K.bO <= 1.0 && K.bR >= K.bO, alone_over = K.bO >= 1.0 && K.bR <= K.bO;
   auto kernel = !K.dyadic    ? n2v::partition_step_wedge_kernel<2>
                 : alone_under ? n2v::partition_step_wedge_kernel<0>

@@ -125,27 +125,37 @@ def partition_graph(g: DeviceGraph, n_parts: int, balance: str = "edges",
 @dataclass
 class Walkers:
     """a batch of walker states: header int64 [k, 5] = (output row, RNG key, s << 32 | v, step,
-    classes) and what travels with each walker as a packed CSR (ptr int64 [k + 1], ids int32
-    [nnz]): the row N(s), or -- when the parts carry wedge tables -- the wedge list of the edge
+    classes) and what travels with each walker, packed (lens int64 [k], ids int32 [nnz]): the
+    row N(s), or -- when the parts carry wedge tables -- the wedge list of the edge
     (s -> v), with classes = edge_classes | return position << 32 (else 0)"""
     head: torch.Tensor
-    ptr: torch.Tensor
+    lens: torch.Tensor
     ids: torch.Tensor
+    _ptr: Optional[torch.Tensor] = None
+
+    @property
+    def ptr(self) -> torch.Tensor:
+        """offsets of every walker's words in `ids` (int64 [k + 1]): built once, on the rank
+        that steps the batch -- on the wire the lengths travel"""
+        if self._ptr is None:
+            self._ptr = torch.zeros(self.lens.numel() + 1, dtype=torch.int64, device=self.lens.device)
+            torch.cumsum(self.lens, 0, out=self._ptr[1:])
+        return self._ptr
 
     @classmethod
     def empty(cls, device):
         return cls(torch.zeros((0, HEAD_COLS), dtype=torch.int64, device=device),
-                   torch.zeros(1, dtype=torch.int64, device=device),
+                   torch.zeros(0, dtype=torch.int64, device=device),
                    torch.zeros(0, dtype=torch.int32, device=device))
 
     def __len__(self):
         return self.head.shape[0]
 
     def select(self, idx: torch.Tensor) -> "Walkers":
-        lens = (self.ptr[1:] - self.ptr[:-1])[idx]
+        lens = self.lens[idx]
         ptr = torch.zeros(idx.numel() + 1, dtype=torch.int64, device=self.head.device)
         torch.cumsum(lens, 0, out=ptr[1:])
-        return Walkers(self.head[idx], ptr, _gather_rows(self.ptr, self.ids, idx, ptr))
+        return Walkers(self.head[idx], lens, _gather_rows(self.ptr, self.ids, idx, ptr), ptr)
 
     @classmethod
     def cat(cls, parts: Sequence["Walkers"], device) -> "Walkers":
@@ -154,10 +164,8 @@ class Walkers:
             return cls.empty(device)
         if len(parts) == 1:
             return parts[0]
-        lens = torch.cat([p.ptr[1:] - p.ptr[:-1] for p in parts])
-        ptr = torch.zeros(lens.numel() + 1, dtype=torch.int64, device=device)
-        torch.cumsum(lens, 0, out=ptr[1:])
-        return cls(torch.cat([p.head for p in parts]), ptr, torch.cat([p.ids for p in parts]))
+        return cls(torch.cat([p.head for p in parts]), torch.cat([p.lens for p in parts]),
+                   torch.cat([p.ids for p in parts]))
 
 
 def _gather_rows(ptr: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor, out_ptr: torch.Tensor):
@@ -217,6 +225,7 @@ class RankState:
         self.n_rows = 0
         self.row_base = 0
         self.status = None  # uint32 [4] of n2v_partition_step, on the part's device
+        self._arange = None
 
     # -- initiate_random_walk (randomwalk.py:279-296) for the start vertices this rank owns ----
     def initiate(self, start_ids_global: torch.Tensor):
@@ -242,36 +251,46 @@ class RankState:
             return
         head = torch.stack([rows, keys, (torch.full_like(v, -1) << 32) | (v & 0xffffffff),
                             torch.zeros_like(rows), torch.zeros_like(rows)], 1)
-        self.walkers = Walkers(head, torch.zeros(rows.numel() + 1, dtype=torch.int64, device=dev),
+        self.walkers = Walkers(head, torch.zeros(rows.numel(), dtype=torch.int64, device=dev),
                                torch.zeros(0, dtype=torch.int32, device=dev))
 
     # -- the step as ONE launch: n2v_partition_step reads N(v) from the part's CSR ---------------
-    def _wedge_mode(self) -> bool:
-        """the walkers carry wedge lists (not rows): the parts hold the per-edge tables, N(s)
-        matters at all (q != 1), and (p, q) is in the range of the unit-weight kernels"""
+    def _lane_mode(self) -> int:
+        """0: one wave per walker (rows travel when q != 1); else the step is per-lane work
+        (partition_step_wedge_kernel) and the value says what travels: 1 nothing (p == q == 1 on
+        unit weights: the draw is `pick`), 2 the wedge list of the edge, 3 only its counts and
+        return position (q == 1).  2 and 3 need the per-edge tables on the parts and (p, q) in
+        the range of the unit-weight kernels."""
         part = self.part
+        if part.w is not None:
+            return 0
+        if self.p == 1.0 and self.q == 1.0:
+            return 1
         ordinary = all(2.0 ** -20 <= 1.0 / x <= 2.0 ** 20 for x in (self.p, self.q))
-        return part.wedge_off is not None and part.w is None and self.q != 1.0 and ordinary
+        if part.wedge_off is None or not ordinary:
+            return 0
+        return 2 if self.q != 1.0 else 3
 
     def _advance_fused(self, n_parts: int) -> List[Walkers]:
         """next_step_random_walk (randomwalk.py:300-339) for every resident walker in one launch
-        (one wave per walker, the table never materialised), then what must travel is packed by
-        one more.  N(s) only decides shared / other (randomwalk.py:226-229): with q == 1 -- the
-        reference's defaults p == q == 1 included, where every table is probs == [1.0] * n and
-        the draw is pick = int(r1 * n) -- the walker travels as its 40-byte header alone.
-        Otherwise it takes the WEDGE LIST of the edge it leaves along (n2v_gather_wedges: the
-        positions in the next row of the neighbours shared with this one, from this part's slice
-        of the wedge table) when the parts carry the per-edge tables, else the whole row it
-        leaves (n2v_gather_rows)."""
+        (the table never materialised), then the routing: one elementwise launch
+        (n2v_partition_route: path record, next header, destination, words to carry), a stable
+        sort by destination, one gather of what travels.  N(s) only decides shared / other
+        (randomwalk.py:226-229): with q == 1 -- the reference's defaults p == q == 1 included,
+        where every table is probs == [1.0] * n and the draw is pick = int(r1 * n) -- the walker
+        travels as its 40-byte header alone.  Otherwise it takes the WEDGE LIST of the edge it
+        leaves along (n2v_gather_wedges: the positions in the next row of the neighbours shared
+        with this one, from this part's slice of the wedge table) when the parts carry the
+        per-edge tables, else the whole row it leaves (n2v_gather_rows).  Walkers that stand on
+        a vertex without out-edges draw nothing and are logged as vanished (fugue.py:147)."""
         from node2vec_amd import _lib
 
         L = _lib.load()
         part, dev, wk = self.part, self.part.device, self.walkers
         k = len(wk)
         head_in = wk.head.contiguous()
-        rows, keys, sv, step = head_in[:, 0], head_in[:, 1], head_in[:, 2], head_in[:, 3]
-        v = sv & 0xffffffff
-        wedge = self._wedge_mode()
+        lanes = self._lane_mode()
+        wedge = lanes >= 2  # the edge drawn is needed: something of it travels
         carry = self.q != 1.0
         nxt32 = torch.empty(k, dtype=torch.int32, device=dev)
         edge = torch.empty(k, dtype=torch.int64, device=dev) if wedge else None
@@ -284,54 +303,61 @@ class RankState:
         with torch.cuda.device(dev):
             _lib.check(L.n2v_partition_step(part.rowptr.data_ptr(), part.col.data_ptr(), w32, w64,
                                             part.lo, part.hi - part.lo, head_in.data_ptr(), HEAD_COLS,
-                                            wk.ptr.data_ptr(), src_ids.data_ptr(), int(wedge), k,
+                                            wk.ptr.data_ptr() if (carry or wedge) else 0,
+                                            src_ids.data_ptr(), int(lanes > 0), k,
                                             float(self.p), float(self.q),
                                             int(self.seed) & (2 ** 64 - 1), nxt32.data_ptr(),
                                             edge.data_ptr() if wedge else 0, self.status.data_ptr(),
                                             _lib.current_stream_ptr()), "n2v_partition_step")
-        nxt = nxt32.to(torch.int64)
-        self.log.append(torch.stack([rows, step + 1, nxt], 1))
-        keep = step + 1 < self.L
-        head = torch.stack([rows, keys, (v << 32) | (nxt & 0xffffffff), step + 1,
-                            torch.zeros_like(rows)], 1)[keep]
-        dest = part.owner(nxt[keep].clamp(min=0))
-        order = torch.argsort(dest, stable=True)
-        head = head[order].contiguous()
-        cuts = torch.zeros(n_parts + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(torch.bincount(dest, minlength=n_parts), 0, out=cuts[1:])
-        k2 = head.shape[0]
-        ptr = torch.zeros(k2 + 1, dtype=torch.int64, device=dev)
-        if wedge:
-            gone = edge[keep][order].clamp_(min=0).contiguous()  # (-1 only beside a raised status)
-            torch.cumsum((part.edge_classes[gone] & 0xffffff).to(torch.int64), 0, out=ptr[1:])
-        elif carry:
-            local = (v[keep] - part.lo)[order].contiguous()
-            torch.cumsum(part.rowptr[local + 1] - part.rowptr[local], 0, out=ptr[1:])
+        # routing: one elementwise kernel (path record, next header, destination, words to carry),
+        # a stable sort by destination, one gather of what travels
+        carry_kind = lanes if wedge else (1 if (carry and not lanes) else 0)
+        log = torch.empty((k, 3), dtype=torch.int64, device=dev)
+        head = torch.empty((k, HEAD_COLS), dtype=torch.int64, device=dev)
+        dest = torch.empty(k, dtype=torch.int32, device=dev)
+        lens = torch.empty(k, dtype=torch.int64, device=dev)
+        src = torch.empty(k, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.n2v_partition_route(head_in.data_ptr(), HEAD_COLS, nxt32.data_ptr(),
+                                             edge.data_ptr() if wedge else 0, k, self.L,
+                                             part.bounds.data_ptr(), n_parts, carry_kind,
+                                             part.rowptr.data_ptr(), part.lo,
+                                             part.edge_classes.data_ptr() if wedge else 0,
+                                             log.data_ptr(), head.data_ptr(), dest.data_ptr(),
+                                             lens.data_ptr(), src.data_ptr(),
+                                             _lib.current_stream_ptr()), "n2v_partition_route")
+        self.log.append(log)
+        dest, order = torch.sort(dest, stable=True)
+        cuts = torch.searchsorted(dest, self._parts_arange(n_parts))  # walkers per destination
+        head, lens, src = head[order], lens[order], src[order]
+        ptr = torch.zeros(k + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(lens, 0, out=ptr[1:])
         # one transfer: the status word, the walkers per destination, the words per destination
         host = torch.cat([self.status[:1].to(torch.int64), cuts, ptr[cuts]]).tolist()
         _lib.check_status_word(host[0], "n2v_partition_step")
-        cuts_h, at = host[1:n_parts + 2], host[n_parts + 2:]
+        cuts_h, at = [0] + host[1:n_parts + 1], [0] + host[n_parts + 1:]
+        k2 = cuts_h[-1]  # forwarded walkers: the first k2 of the sorted batch
         ids = torch.zeros(0, dtype=torch.int32, device=dev)
-        if wedge and k2 > 0:
+        if carry_kind and k2 > 0:
             ids = torch.empty(max(at[-1], 1), dtype=torch.int32, device=dev)
             with torch.cuda.device(dev):
-                _lib.check(L.n2v_gather_wedges(part.edge_classes.data_ptr(), part.wedge_off.data_ptr(),
-                                               part.wedge_pos.data_ptr(),
-                                               int(part.wedge_pos.dtype == torch.int32), gone.data_ptr(),
-                                               ptr.data_ptr(), k2, ids.data_ptr(), head.data_ptr(),
-                                               HEAD_COLS, _lib.current_stream_ptr()), "n2v_gather_wedges")
-            ids = ids[:at[-1]]
-        elif carry and at[-1] > 0:
-            ids = torch.empty(at[-1], dtype=torch.int32, device=dev)
-            with torch.cuda.device(dev):
-                _lib.check(L.n2v_gather_rows(part.rowptr.data_ptr(), part.col.data_ptr(),
-                                             local.data_ptr(), ptr.data_ptr(), k2, ids.data_ptr(),
-                                             _lib.current_stream_ptr()), "n2v_gather_rows")
-        out = []
-        for r in range(n_parts):
-            a, b = cuts_h[r], cuts_h[r + 1]
-            out.append(Walkers(head[a:b], ptr[a:b + 1] - ptr[a], ids[at[r]:at[r + 1]]))
-        return out
+                if wedge:
+                    _lib.check(L.n2v_gather_wedges(part.edge_classes.data_ptr(), part.wedge_off.data_ptr(),
+                                                   part.wedge_pos.data_ptr(),
+                                                   int(part.wedge_pos.dtype == torch.int32), src.data_ptr(),
+                                                   ptr.data_ptr(), k2, ids.data_ptr(), head.data_ptr(),
+                                                   HEAD_COLS, _lib.current_stream_ptr()), "n2v_gather_wedges")
+                else:
+                    _lib.check(L.n2v_gather_rows(part.rowptr.data_ptr(), part.col.data_ptr(),
+                                                 src.data_ptr(), ptr.data_ptr(), k2, ids.data_ptr(),
+                                                 _lib.current_stream_ptr()), "n2v_gather_rows")
+        return [Walkers(head[cuts_h[r]:cuts_h[r + 1]], lens[cuts_h[r]:cuts_h[r + 1]], ids[at[r]:at[r + 1]])
+                for r in range(n_parts)]
+
+    def _parts_arange(self, n_parts: int) -> torch.Tensor:
+        if self._arange is None or self._arange.numel() != n_parts:
+            self._arange = torch.arange(1, n_parts + 1, dtype=torch.int32, device=self.part.device)
+        return self._arange
 
     # -- one step of every resident walker; returns the migrating walkers per destination -----
     def advance(self, n_parts: int) -> List[Walkers]:
@@ -359,7 +385,8 @@ class RankState:
         done = step + 1 >= self.L
         keep = ~done
         head = torch.stack([rows, keys, (v << 32) | nxt, step + 1, torch.zeros_like(rows)], 1)[keep]
-        moving = Walkers(head, *self._subrows(dptr, dids, keep))
+        sub_ptr, sub_ids = self._subrows(dptr, dids, keep)
+        moving = Walkers(head, sub_ptr[1:] - sub_ptr[:-1], sub_ids, sub_ptr)
         dest = part.owner(nxt[keep])
         return [moving.select(torch.nonzero(dest == r).reshape(-1)) for r in range(n_parts)]
 
@@ -375,7 +402,9 @@ class RankState:
     def receive(self, inbox: Sequence[Walkers]):
         part, dev = self.part, self.part.device
         wk = Walkers.cat(inbox, dev)
-        if len(wk):
+        # (the fused step finds the sinks itself: it draws nothing from an empty row and the
+        # routing logs the walker as vanished -- no look at the arrivals, no host sync)
+        if len(wk) and not (self.step_fn is hip_step and part.rowptr.is_cuda):
             v = (wk.head[:, 2] & 0xffffffff) - part.lo
             deg = (part.rowptr[1:] - part.rowptr[:-1])[v]
             dead = deg == 0
@@ -465,7 +494,7 @@ def _exchange_walkers(out: List[Walkers], group, dist, dev) -> List[Walkers]:
     world = dist.get_world_size(group)
     cpu = dist.get_backend(group) == "gloo"  # gloo moves host tensors
     wire = torch.device("cpu") if cpu else dev
-    head5 = torch.cat([torch.cat([w.head, (w.ptr[1:] - w.ptr[:-1])[:, None]], 1) for w in out]).to(wire)
+    head5 = torch.cat([torch.cat([w.head, w.lens[:, None]], 1) for w in out]).to(wire)
     ids = torch.cat([w.ids for w in out]).to(wire)
     sizes = [[len(w), int(w.ids.numel())] for w in out]  # shapes: known on the host, no sync
     n_send = torch.tensor(sizes, dtype=torch.int64, device=wire)
@@ -477,9 +506,7 @@ def _exchange_walkers(out: List[Walkers], group, dist, dev) -> List[Walkers]:
     recv_i = torch.empty(sum(g[1] for g in got), dtype=torch.int32, device=wire)
     dist.all_to_all_single(recv_i, ids.contiguous(), [g[1] for g in got], [z[1] for z in sizes], group=group)
     recv_h, recv_i = recv_h.to(dev), recv_i.to(dev)
-    ptr = torch.zeros(recv_h.shape[0] + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(recv_h[:, HEAD_COLS], 0, out=ptr[1:])
-    return [Walkers(recv_h[:, :HEAD_COLS].contiguous(), ptr, recv_i)]
+    return [Walkers(recv_h[:, :HEAD_COLS].contiguous(), recv_h[:, HEAD_COLS].contiguous(), recv_i)]
 
 
 def walk_partitioned(part: GraphPart, start_ids: torch.Tensor, num_walks: int, walk_length: int,

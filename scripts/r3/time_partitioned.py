@@ -18,6 +18,7 @@ for wedges in (True, False):
     parts = P.partition_graph(g, 8, wedges=wedges)
     print("walkers carry", "wedge lists" if parts[0].wedge_off is not None else "whole rows",
           "when q != 1; bytes of the largest part:", max(pt.nbytes() for pt in parts), flush=True)
+    P.walk_partitioned_local(parts, start[::50].contiguous(), 1, 3, 0.5, 2.0, 1)  # warm-up (first launches)
     for p, q in ((1.0, 1.0), (0.5, 2.0), (0.5, 1.0), (4.0, 0.25), (0.7, 1.3)):
         want, wv = rw.walk(g, start, 2, 20, p, q, 42)
         torch.cuda.synchronize()

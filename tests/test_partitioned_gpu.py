@@ -42,6 +42,33 @@ def test_partitioned_equals_the_oracle_bit_for_bit(oracle, weighted, step):
         assert np.array_equal(got[gv], want[wv])
 
 
+@pytest.mark.parametrize("wedges", [True, False])
+def test_a_part_without_edges_only_sees_walkers_vanish(oracle, wedges):
+    """the last third of the vertices has no out-edges: that part stores no edge (NULL col, NULL
+    per-edge tables), every walker that reaches it vanishes there (fugue.py:147) -- found by the
+    step itself, one step after the arrival -- and the walks still equal the oracle's"""
+    from node2vec_amd import partitioned as P
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+
+    rng = np.random.default_rng(12)
+    g = DeviceGraph.from_edges(rng.integers(0, 200, 3000), rng.integers(0, 300, 3000), None,
+                               n_vertices=300, device="cuda")
+    parts = P.partition_graph(g, 3, balance="vertices", wedges=wedges)
+    assert parts[2].col.numel() == 0 and parts[2].lo == 200
+    start = rw.start_vertices(g)
+    for p, q in ((1.0, 1.0), (0.5, 2.0), (2.0, 1.0)):
+        want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), None,
+                                      start.cpu().numpy(), 3, 9, p, q, 4)
+        walks, valid = P.walk_partitioned_local(parts, start, 3, 9, p, q, 4)
+        got, gv = walks.cpu().numpy(), valid.cpu().numpy().astype(bool)
+        assert np.array_equal(gv, wv) and 0 < wv.sum() < wv.size
+        assert np.array_equal(got[gv], want[wv])
+        # dropped rows: the path up to the sink, then -1 (as n2v_walk emits them)
+        ref, _ = rw.walk(g, start, 3, 9, p, q, 4)
+        assert torch.equal(walks, ref)
+
+
 @pytest.mark.parametrize("weighted", [False, True, "fp32"])
 def test_partitioned_equals_n2v_walk_bit_for_bit(weighted):
     from node2vec_amd import partitioned as P
