@@ -19,7 +19,7 @@ ONE JSON line on rank 0.  Beside the contract's keys:
   roofline      the headline walk kernel: bytes / HIP-event duration against 8 TB/s
   biased        the same graph walked exactly at p = 0.5, q = 2 (at p = q = 1 a step is two
                 gathers; the second-order bias is where the sampler works)
-  fast_mode     rejection sampler at p = 0.5, q = 2 (same distribution, not the same draws)
+  fast_mode     fast mode at p = 0.5, q = 2 (same distribution, not the same draws)
   sgns          K launches of the SGNS kernel on a 10^8 x 128 model (embedding-updates/s)
   cpu_baseline  the CPU oracle (a port of the reference's algorithm) on this box's cores:
                 walks single-thread and all-core, SGNS single-thread and all-core
@@ -315,6 +315,9 @@ def main():
             out["fast_mode"] = {"value": s3 / e3, "unit": "walk-steps/s", "walk_mode": "fast",
                                 "p": bp, "q": bq, "ms_per_step": 1e3 * e3 / args.steps,
                                 "start_vertices_per_step": leg.batch,
+                                "sampler": ("class first (masses from the per-edge counts, slots by index "
+                                            "from the wedge table)" if g.wedge_off is not None and g.unit_weights
+                                            else "rejection (return edge folded out of the envelope)"),
                                 "parity": "same transition distribution as generate_edge_alias_tables, not the "
                                           "same draws (chi-square against the oracle's exact probabilities: "
                                           "weighted tests/test_alias_trim_fast_gpu.py, unit-weight + every "
@@ -364,7 +367,7 @@ def prepare_tables(torch, g, p, q, mode, setup, tag):
             timed("pivots_build", g.build_pivots)
         if biased and g.edge_classes is None and (mode == "fast" or tables_regime(p, q)):
             timed("edge_classes_build", g.build_edge_classes)
-        if biased and mode == "exact" and tables_regime(p, q) and g.wedge_off is None and not g.wedge_tried:
+        if biased and (mode == "fast" or tables_regime(p, q)) and g.wedge_off is None and not g.wedge_tried:
             g.wedge_tried = True
             timed("wedge_table_build", g.build_wedges)
             setup[f"{tag}_wedge_table_GB"] = 0.0 if g.wedge_off is None else (

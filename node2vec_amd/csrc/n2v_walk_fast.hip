@@ -87,7 +87,14 @@ __device__ __forceinline__ int lower_bound_lane(const int32_t *a, int m, int32_t
 // kHops (unit weights): candidates come from the hop table (n2v_hops_build) -- the accepted
 // entry already holds the row pointer and degree of the next vertex and the class counts of the
 // edge, so an accepted step needs no further gather (one sector per trial + the membership test).
-template <bool kUnit, bool kHops>
+// kClassFirst (unit weights, class counts AND wedge table at hand): the table of a step has nR
+// slots of weight 1/p, nM of weight 1 and nO of weight 1/q, and the tables say where the first
+// two kinds are -- so the CLASS is drawn first, from the three exact masses, and then a slot
+// inside it: the return run and the wedge list by index, an "other" slot by a uniform draw over
+// the row that is repeated INSIDE the class while it hits a return or listed slot (redrawing
+// the class as well would skew the class proportions by nO / n).  n / nO trials per step --
+// 1.0x on the BASELINE graphs -- instead of max(1, 1/q) / (mean weight): 1.86 at p = 0.5, q = 2.
+template <bool kUnit, bool kHops, bool kClassFirst>
 __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double p, double q, uint64_t seed, int32_t *__restrict__ walks_out,
@@ -120,6 +127,9 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
   unsigned long long trials = 0;
   double rho = -1.0;   // share of the return branch at this step (< 0: not folded)
   int shared = -1;     // neighbours of v inside N(s) at this step, -1 = unknown
+  int n_ret = 0;       // kClassFirst: return slots of this step's table
+  int cls = -1;        // kClassFirst: class of the step once drawn (0 return, 1 shared, 2 other)
+  double m_ret = 0.0, m_sh = 0.0, m_tot = 0.0;  // kClassFirst: the class masses
 
   // The path is not stored word by word: a 4-byte store into a 324-byte-pitch row costs a
   // 32-byte write request.  Each lane keeps the 16 words of the 64-byte sector of walks_out
@@ -180,6 +190,7 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
       trial = 0;
       rho = -1.0;
       shared = -1;
+      cls = -1;
       emit(0, start);
       h0 = walker_stream(seed, (uint64_t)start * (uint64_t)num_walks + (uint64_t)(ordinal - 1));
       hstep = step_bits(h0, 0);
@@ -197,7 +208,28 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
     const bool plain = s < 0 || !biased;
     const uint64_t bits = plain ? hstep : trial_bits(hstep, trial);
     const uint32_t u1 = (uint32_t)(bits >> 32), u2 = (uint32_t)bits;
-    const int pick = pick_index(u1, n);
+    int pick = pick_index(u1, n);
+    uint64_t wraw = 0;  // kClassFirst: wedge_off of the edge walked last
+    if (kClassFirst && !plain) {
+      if (cls < 0) {  // first trial of the step: the class, then the slot by index
+        const double uc = (double)u2 * (1.0 / 4294967296.0) * m_tot;
+        cls = uc < m_ret ? 0 : (uc < m_ret + m_sh ? 1 : 2);
+        if (cls != 2 || shared > 0) wraw = g.wedge_off[e_prev];
+        if (cls == 0) {
+          int kk = (int)(uc * p);  // uc / (1/p)
+          kk = kk < n_ret ? kk : n_ret - 1;
+          pick = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT) + kk;
+        } else if (cls == 1) {
+          int kk = (int)(uc - m_ret);
+          kk = kk < shared ? (kk < 0 ? 0 : kk) : shared - 1;
+          const int64_t off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK) + kk;
+          pick = w_wide ? (int)reinterpret_cast<const uint32_t *>(g.wedge_pos)[off]
+                        : (int)reinterpret_cast<const uint16_t *>(g.wedge_pos)[off];
+        }
+      } else if (shared > 0) {  // only an "other" draw is ever repeated
+        wraw = g.wedge_off[e_prev];
+      }
+    }
     int32_t x;
     int64_t e = vb + pick;  // kUnit: the edge (v -> x) itself
     n2v_hop h;
@@ -216,7 +248,13 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
     }
     bool accept = true;
     ++trials;
-    if (!plain) {
+    if (kClassFirst && !plain) {
+      if (cls == 2) {  // an "other" slot: not the return run, not a listed position
+        accept = x != s;
+        if (accept && shared > 0)
+          accept = !wedge_has(g.wedge_pos, (int64_t)(wraw & N2V_WEDGE_OFF_MASK), shared, pick, w_wide);
+      }
+    } else if (!plain) {
       const uint64_t b2 = mix64(bits ^ 0xC2B2AE3D27D4EB4FULL);
       const double ua = (double)(uint32_t)(b2 >> 32) * (1.0 / 4294967296.0);
       // accept a non-return candidate x iff u < beta(x), beta = 1 (x in N(s)) or 1/q: the
@@ -264,6 +302,7 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
     v = x;
     ++step;
     trial = 0;
+    cls = -1;
     const bool finished = step == walk_length;
     bool dropped = false;
     if (!finished) {
@@ -278,7 +317,15 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
       hstep = step_bits(h0, (uint32_t)step);
       rho = -1.0;
       shared = -1;
-      if (have_ec && biased && !dropped) {
+      if (kClassFirst) {
+        // (tables that come with a wedge list hold no saturated count: n2v_wedge_build)
+        const uint32_t ec = kHops ? h.classes : g.edge_classes[e];
+        n_ret = (int)(ec >> N2V_EC_RETURN_SHIFT);
+        shared = q != 1.0 ? (int)(ec & N2V_EC_SHARED_MASK) : 0;
+        m_ret = (double)n_ret * inv_p;
+        m_sh = (double)shared;
+        m_tot = m_ret + m_sh + (double)(n - n_ret - shared) * inv_q;
+      } else if (have_ec && biased && !dropped) {
         const uint32_t ec = kHops ? h.classes : g.edge_classes[e];
         const uint32_t fR = ec >> N2V_EC_RETURN_SHIFT, fM = ec & N2V_EC_SHARED_MASK;
         if (fM != N2V_EC_SHARED_MASK) shared = (int)fM;
@@ -312,23 +359,32 @@ extern "C" int n2v_walk_fast_launch(const n2v_graph *g, const int32_t *start_ids
   const int threads = 256;
   int64_t blocks = (total + threads - 1) / threads;
   const bool hops = unit && g->hops != nullptr;
-  const void *fn = hops   ? (const void *)n2v::walk_fast_kernel<true, true>
-                   : unit ? (const void *)n2v::walk_fast_kernel<true, false>
-                          : (const void *)n2v::walk_fast_kernel<false, false>;
+  // class-first sampling: counts, return position and shared positions of every edge at hand
+  const bool cf = unit && (hops || g->edge_classes) && g->wedge_off && g->wedge_pos &&
+                  !(p == 1.0 && q == 1.0);
+  const void *fn = cf     ? (hops ? (const void *)n2v::walk_fast_kernel<true, true, true>
+                                  : (const void *)n2v::walk_fast_kernel<true, false, true>)
+                   : hops ? (const void *)n2v::walk_fast_kernel<true, true, false>
+                   : unit ? (const void *)n2v::walk_fast_kernel<true, false, false>
+                          : (const void *)n2v::walk_fast_kernel<false, false, false>;
   const int64_t cap = n2v::resident_blocks(fn, threads, 0);
   if (blocks > cap) blocks = cap;
   // status[2..3]: 64-bit trial counter (include/n2v_hip.h)
   unsigned long long *trials = reinterpret_cast<unsigned long long *>(status + 2);
-#define N2V_FAST_LAUNCH(U, H)                                                                    \
-  hipLaunchKernelGGL((n2v::walk_fast_kernel<U, H>), dim3((unsigned)blocks), dim3(threads), 0,   \
-                     (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, p, q, \
+#define N2V_FAST_LAUNCH(U, H, C)                                                                  \
+  hipLaunchKernelGGL((n2v::walk_fast_kernel<U, H, C>), dim3((unsigned)blocks), dim3(threads), 0, \
+                     (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, p, q,  \
                      seed, walks_out, valid_out, status, trials)
-  if (hops)
-    N2V_FAST_LAUNCH(true, true);
+  if (cf && hops)
+    N2V_FAST_LAUNCH(true, true, true);
+  else if (cf)
+    N2V_FAST_LAUNCH(true, false, true);
+  else if (hops)
+    N2V_FAST_LAUNCH(true, true, false);
   else if (unit)
-    N2V_FAST_LAUNCH(true, false);
+    N2V_FAST_LAUNCH(true, false, false);
   else
-    N2V_FAST_LAUNCH(false, false);
+    N2V_FAST_LAUNCH(false, false, false);
 #undef N2V_FAST_LAUNCH
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
