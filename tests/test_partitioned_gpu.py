@@ -116,3 +116,87 @@ def test_partitioned_cfg2_sample_equals_n2v_walk():
     dt = time.perf_counter() - t0
     print(f"partitioned walking, 8 parts in one process: {int(valid.sum()) * 80 / dt / 1e6:.2f} M steps/s")
     assert bool(valid.all()) and torch.equal(valid, wv) and torch.equal(walks, want)
+
+
+def test_partition_route_and_gathers_equal_plain_torch():
+    """the C-ABI pieces of the routing on their own (n2v_partition_route, n2v_gather_rows,
+    n2v_gather_wedges) against the index arithmetic they replace: finished walks and walkers that
+    vanished are not forwarded, destinations by the parts' lower bounds (an EMPTY part in the
+    middle owns nothing), lengths and sources by what travels"""
+    from node2vec_amd import _lib
+    from node2vec_amd.graph import DeviceGraph
+
+    L = _lib.load()
+    rng = np.random.default_rng(3)
+    nv = 500
+    g = DeviceGraph.from_edges(rng.integers(0, nv, 6000), rng.integers(0, nv, 6000), None,
+                               n_vertices=nv, device="cuda")
+    g.build_wedges()
+    assert g.wedge_off is not None
+    k, cols, walk_len, lo = 4000, 5, 7, 100
+    bounds = torch.tensor([0, 100, 100, 320], dtype=torch.int64, device="cuda")  # part 1 is empty
+    gen = torch.Generator().manual_seed(1)
+    v = torch.randint(lo, 320, (k,), generator=gen)
+    step = torch.randint(0, walk_len, (k,), generator=gen)
+    nxt = torch.randint(0, nv, (k,), generator=gen).to(torch.int32)
+    nxt[::17] = -1  # stood on a sink
+    head = torch.stack([torch.arange(k), torch.randint(0, 1 << 40, (k,), generator=gen),
+                        (torch.randint(0, nv, (k,), generator=gen) << 32) | v, step,
+                        torch.randint(0, 1 << 30, (k,), generator=gen)], 1).cuda()
+    rowptr = (g.rowptr[lo:321] - g.rowptr[lo]).contiguous()
+    e0 = int(g.rowptr[lo])
+    edge = (rowptr[(v - lo).cuda()] + torch.randint(0, 3, (k,), generator=gen).cuda()).clamp(max=int(rowptr[-1]) - 1)
+    ec = g.edge_classes[e0:e0 + int(rowptr[-1])].contiguous()
+    nxt_d = nxt.cuda()
+    for carry in (0, 1, 2, 3):
+        log = torch.empty((k, 3), dtype=torch.int64, device="cuda")
+        ho = torch.empty((k, cols), dtype=torch.int64, device="cuda")
+        dest = torch.empty(k, dtype=torch.int32, device="cuda")
+        ln = torch.empty(k, dtype=torch.int64, device="cuda")
+        src = torch.empty(k, dtype=torch.int64, device="cuda")
+        _lib.check(L.n2v_partition_route(head.data_ptr(), cols, nxt_d.data_ptr(), edge.data_ptr(), k, walk_len,
+                                         bounds.data_ptr(), 4, carry, rowptr.data_ptr(), lo, ec.data_ptr(),
+                                         log.data_ptr(), ho.data_ptr(), dest.data_ptr(), ln.data_ptr(),
+                                         src.data_ptr(), _lib.current_stream_ptr()), "route")
+        gone = nxt_d < 0
+        fwd = ~gone & (head[:, 3] + 1 < walk_len)
+        assert torch.equal(log[:, 0], head[:, 0])
+        assert torch.equal(log[:, 1], torch.where(gone, -1, head[:, 3] + 1))
+        assert torch.equal(log[:, 2], torch.where(gone, -1, nxt_d.long()))
+        want_dest = torch.searchsorted(bounds, nxt_d.long().clamp(min=0), right=True) - 1
+        assert torch.equal(dest.long(), torch.where(fwd, want_dest, 4)) and not bool((dest == 1).any())
+        assert torch.equal(ho[:, :2], head[:, :2]) and torch.equal(ho[:, 3], head[:, 3] + 1)
+        assert torch.equal(ho[:, 2], ((head[:, 2] & 0xffffffff) << 32) | (nxt_d.long() & 0xffffffff))
+        assert int(ho[:, 4].abs().sum()) == 0
+        local = (head[:, 2] & 0xffffffff) - lo
+        want_len = {0: torch.zeros_like(ln), 1: rowptr[local + 1] - rowptr[local],
+                    2: (ec[edge] & 0xffffff).long(), 3: torch.zeros_like(ln)}[carry]
+        assert torch.equal(ln, torch.where(fwd, want_len, 0))
+        if carry:
+            assert torch.equal(src[fwd], (local if carry == 1 else edge)[fwd])
+        # the gathers over the forwarded walkers, in the given order
+        idx = torch.nonzero(fwd).reshape(-1)
+        ptr = torch.zeros(idx.numel() + 1, dtype=torch.int64, device="cuda")
+        torch.cumsum(ln[idx], 0, out=ptr[1:])
+        out = torch.full((max(int(ptr[-1]), 1),), -7, dtype=torch.int32, device="cuda")
+        s_idx = src[idx].contiguous()
+        if carry == 1:
+            col = g.col[e0:e0 + int(rowptr[-1])].contiguous()
+            _lib.check(L.n2v_gather_rows(rowptr.data_ptr(), col.data_ptr(), s_idx.data_ptr(), ptr.data_ptr(),
+                                         idx.numel(), out.data_ptr(), _lib.current_stream_ptr()), "rows")
+            want = torch.cat([col[rowptr[r]:rowptr[r + 1]] for r in s_idx.tolist()])
+            assert torch.equal(out[:want.numel()], want)
+        elif carry >= 2:
+            off = g.wedge_off[e0:e0 + int(rowptr[-1])].contiguous()
+            hs = ho[idx].contiguous()
+            _lib.check(L.n2v_gather_wedges(ec.data_ptr(), off.data_ptr(), g.wedge_pos.data_ptr(),
+                                           int(g.wedge_pos.dtype == torch.int32), s_idx.data_ptr(), ptr.data_ptr(),
+                                           idx.numel(), out.data_ptr(), hs.data_ptr(), cols,
+                                           _lib.current_stream_ptr()), "wedges")
+            o = off[s_idx]
+            assert torch.equal(hs[:, 4], (ec[s_idx].long() & 0xffffffff) | ((o >> 40) << 32))
+            if carry == 2:
+                want = torch.cat([g.wedge_pos[int(a):int(a) + int(c)].to(torch.int32)
+                                  for a, c in zip((o & ((1 << 40) - 1)).tolist(), ln[idx].tolist())])
+                assert torch.equal(out[:want.numel()], want)
+
