@@ -315,8 +315,8 @@ def main():
             out["fast_mode"] = {"value": s3 / e3, "unit": "walk-steps/s", "walk_mode": "fast",
                                 "p": bp, "q": bq, "ms_per_step": 1e3 * e3 / args.steps,
                                 "start_vertices_per_step": leg.batch,
-                                "sampler": ("class first (masses from the per-edge counts, slots by index "
-                                            "from the wedge table)" if g.wedge_off is not None and g.unit_weights
+                                "sampler": ("layered (layer masses from the per-edge counts, listed slots by "
+                                            "index from the wedge table)" if g.wedge_off is not None and g.unit_weights
                                             else "rejection (return edge folded out of the envelope)"),
                                 "parity": "same transition distribution as generate_edge_alias_tables, not the "
                                           "same draws (chi-square against the oracle's exact probabilities: "

@@ -89,11 +89,19 @@ __device__ __forceinline__ int lower_bound_lane(const int32_t *a, int m, int32_t
 // edge, so an accepted step needs no further gather (one sector per trial + the membership test).
 // kClassFirst (unit weights, class counts AND wedge table at hand): the table of a step has nR
 // slots of weight 1/p, nM of weight 1 and nO of weight 1/q, and the tables say where the first
-// two kinds are -- so the CLASS is drawn first, from the three exact masses, and then a slot
-// inside it: the return run and the wedge list by index, an "other" slot by a uniform draw over
-// the row that is repeated INSIDE the class while it hits a return or listed slot (redrawing
-// the class as well would skew the class proportions by nO / n).  n / nO trials per step --
-// 1.0x on the BASELINE graphs -- instead of max(1, 1/q) / (mean weight): 1.86 at p = 0.5, q = 2.
+// two kinds are.  Sort the three weights, w1 <= w2 <= w3 of classes c1, c2, c3, and cut the table
+// into LAYERS: every slot carries w1 (layer 1: all n slots), the slots of c2 and c3 carry
+// w2 - w1 more (layer 2), those of c3 carry w3 - w2 more (layer 3).  A step draws the layer from
+// the three exact masses and then a slot uniformly inside the layer's set:
+//   * layer 1 is a plain uniform draw -- no rejection, no table access: at q >= 1 with p <= q
+//     (1/q the smallest weight: p = 0.5, q = 2 of the BASELINE configs) that is nearly every
+//     step, one gather like the p == q == 1 kernel;
+//   * a set without "other" slots (return run and / or wedge list) is drawn by index;
+//   * a set with "other" slots is a uniform draw over the row, repeated INSIDE the layer while it
+//     hits a slot outside the set: the return run is recognised by x == s, only the exclusion of
+//     SHARED slots (q < 1) needs the list.
+// P(slot) = sum over the layers that contain it of (layer mass / total) / |set| = weight / total.
+// Trials per step: 1.86 -> 1.00x at p = 0.5, q = 2.
 template <bool kUnit, bool kHops, bool kClassFirst>
 __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
@@ -128,8 +136,27 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
   double rho = -1.0;   // share of the return branch at this step (< 0: not folded)
   int shared = -1;     // neighbours of v inside N(s) at this step, -1 = unknown
   int n_ret = 0;       // kClassFirst: return slots of this step's table
-  int cls = -1;        // kClassFirst: class of the step once drawn (0 return, 1 shared, 2 other)
-  double m_ret = 0.0, m_sh = 0.0, m_tot = 0.0;  // kClassFirst: the class masses
+  int cls = -1;        // kClassFirst: the set of the layer drawn for this step (bits: 1 return,
+                       // 2 shared, 4 other), -1 = not drawn yet
+  double m_l1 = 0.0, m_l12 = 0.0, m_tot = 0.0;  // kClassFirst: masses of layer 1, layers 1 + 2, all
+  // the classes by ascending weight (ties: any order, a layer of mass 0 is never drawn)
+  int c1 = 4, c3 = 1;  // bits of the lightest and of the heaviest class
+  double w1 = 0.0, d2 = 0.0, d3 = 0.0;
+  if (kClassFirst) {
+    double wc[3] = {inv_p, 1.0, inv_q};
+    int bc[3] = {1, 2, 4};
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2 - a; ++b)
+        if (wc[b] > wc[b + 1]) {
+          const double tw = wc[b]; wc[b] = wc[b + 1]; wc[b + 1] = tw;
+          const int tb = bc[b]; bc[b] = bc[b + 1]; bc[b + 1] = tb;
+        }
+    c1 = bc[0];
+    c3 = bc[2];
+    w1 = wc[0];
+    d2 = wc[1] - wc[0];
+    d3 = wc[2] - wc[1];
+  }
 
   // The path is not stored word by word: a 4-byte store into a 324-byte-pitch row costs a
   // 32-byte write request.  Each lane keeps the 16 words of the 64-byte sector of walks_out
@@ -211,24 +238,38 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
     int pick = pick_index(u1, n);
     uint64_t wraw = 0;  // kClassFirst: wedge_off of the edge walked last
     if (kClassFirst && !plain) {
-      if (cls < 0) {  // first trial of the step: the class, then the slot by index
+      if (cls < 0) {  // first trial of the step: the layer, then (sets without "other") the slot
         const double uc = (double)u2 * (1.0 / 4294967296.0) * m_tot;
-        cls = uc < m_ret ? 0 : (uc < m_ret + m_sh ? 1 : 2);
-        if (cls != 2 || shared > 0) wraw = g.wedge_off[e_prev];
-        if (cls == 0) {
-          int kk = (int)(uc * p);  // uc / (1/p)
-          kk = kk < n_ret ? kk : n_ret - 1;
-          pick = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT) + kk;
-        } else if (cls == 1) {
-          int kk = (int)(uc - m_ret);
-          kk = kk < shared ? (kk < 0 ? 0 : kk) : shared - 1;
-          const int64_t off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK) + kk;
-          pick = w_wide ? (int)reinterpret_cast<const uint32_t *>(g.wedge_pos)[off]
-                        : (int)reinterpret_cast<const uint16_t *>(g.wedge_pos)[off];
+        double ul = uc, wl = w1;
+        cls = 7;
+        if (!(uc < m_l1)) {
+          if (uc < m_l12) {
+            cls = 7 & ~c1;
+            ul = uc - m_l1;
+            wl = d2;
+          } else {
+            cls = c3;
+            ul = uc - m_l12;
+            wl = d3;
+          }
         }
-      } else if (shared > 0) {  // only an "other" draw is ever repeated
-        wraw = g.wedge_off[e_prev];
+        if (!(cls & 4)) {  // by index: the return run, then the wedge list
+          wraw = g.wedge_off[e_prev];
+          const int cnt_r = (cls & 1) ? n_ret : 0, cnt_m = (cls & 2) ? shared : 0;
+          int kk = (int)(ul / wl);
+          kk = kk < cnt_r + cnt_m ? kk : cnt_r + cnt_m - 1;
+          kk = kk < 0 ? 0 : kk;
+          if (kk < cnt_r) {
+            pick = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT) + kk;
+          } else {
+            const int64_t off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK) + (kk - cnt_r);
+            pick = w_wide ? (int)reinterpret_cast<const uint32_t *>(g.wedge_pos)[off]
+                          : (int)reinterpret_cast<const uint16_t *>(g.wedge_pos)[off];
+          }
+        }
       }
+      // a uniform draw that must stay clear of the shared slots: the list of the edge
+      if ((cls & 4) && !(cls & 2) && shared > 0) wraw = g.wedge_off[e_prev];
     }
     int32_t x;
     int64_t e = vb + pick;  // kUnit: the edge (v -> x) itself
@@ -249,9 +290,9 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
     bool accept = true;
     ++trials;
     if (kClassFirst && !plain) {
-      if (cls == 2) {  // an "other" slot: not the return run, not a listed position
-        accept = x != s;
-        if (accept && shared > 0)
+      if (cls & 4) {  // drawn over the whole row: outside the layer's set -> again, inside the layer
+        if (!(cls & 1)) accept = x != s;
+        if (accept && !(cls & 2) && shared > 0)
           accept = !wedge_has(g.wedge_pos, (int64_t)(wraw & N2V_WEDGE_OFF_MASK), shared, pick, w_wide);
       }
     } else if (!plain) {
@@ -321,10 +362,13 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
         // (tables that come with a wedge list hold no saturated count: n2v_wedge_build)
         const uint32_t ec = kHops ? h.classes : g.edge_classes[e];
         n_ret = (int)(ec >> N2V_EC_RETURN_SHIFT);
-        shared = q != 1.0 ? (int)(ec & N2V_EC_SHARED_MASK) : 0;
-        m_ret = (double)n_ret * inv_p;
-        m_sh = (double)shared;
-        m_tot = m_ret + m_sh + (double)(n - n_ret - shared) * inv_q;
+        shared = q != 1.0 ? (int)(ec & N2V_EC_SHARED_MASK) : 0;  // q == 1: shared slots ARE other slots
+        const int n_oth = n - n_ret - shared;
+        const int n_c1 = c1 == 1 ? n_ret : (c1 == 2 ? shared : n_oth);
+        const int n_c3 = c3 == 1 ? n_ret : (c3 == 2 ? shared : n_oth);
+        m_l1 = (double)n * w1;
+        m_l12 = m_l1 + (double)(n - n_c1) * d2;
+        m_tot = m_l12 + (double)n_c3 * d3;
       } else if (have_ec && biased && !dropped) {
         const uint32_t ec = kHops ? h.classes : g.edge_classes[e];
         const uint32_t fR = ec >> N2V_EC_RETURN_SHIFT, fM = ec & N2V_EC_SHARED_MASK;

@@ -106,8 +106,9 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
                 graph.build_pivots()
             if use_edge_classes and biased and graph.edge_classes is None:
                 graph.build_edge_classes()
-            # with the wedge table as well the CLASS of a step is drawn first and a slot inside it
-            # by index (n2v_walk_fast.hip, kClassFirst): ~1 trial per step instead of ~2
+            # with the wedge table as well a step is one draw from the layers of its table
+            # (n2v_walk_fast.hip, kClassFirst): 1 trial per step instead of ~2, and at q >= 1 with
+            # p <= q a single gather
             if (use_edge_classes and use_wedges and biased and graph.wedge_off is None
                     and not graph.wedge_tried):
                 graph.wedge_tried = True

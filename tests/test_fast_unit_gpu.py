@@ -68,9 +68,8 @@ GRAPHS = {"low_degree": _low_degree_graph, "multi_edge": _multi_edge_graph,
 TABLES = {"hops+classes": (True, True, False), "classes": (True, False, False),
           "hops+classes+wedges": (True, True, True), "classes+wedges": (True, False, True),
           "bare": (False, False, False)}
-# (with the wedge table the kernel draws the CLASS of a step first and a slot inside it by index
-#  -- n2v_walk_fast.hip, kClassFirst --, without it candidates are rejected: two samplers, one
-#  distribution)
+# (with the wedge table the kernel draws from the LAYERS of a step's table -- n2v_walk_fast.hip,
+#  kClassFirst --, without it candidates are rejected: two samplers, one distribution)
 
 
 def _graph(name):
