@@ -647,23 +647,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void partition_step_kernel(
   }
 }
 
-// rows[j] of a CSR copied back to back: out[out_ptr[j] ..] = ids[ptr[rows[j]] .. ptr[rows[j] + 1])
-// (the rows that leave with migrating walkers); one wave per row
-__global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t *__restrict__ ptr,
-                                                          const int32_t *__restrict__ ids,
-                                                          const int64_t *__restrict__ rows,
-                                                          const int64_t *__restrict__ out_ptr,
-                                                          int64_t k, int32_t *__restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const int64_t n_waves = (int64_t)gridDim.x * 4;
-  for (int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); j < k; j += n_waves) {
-    const int64_t r = rows[j];
-    const int64_t b = ptr[r], o = out_ptr[j];
-    const int64_t len = out_ptr[j + 1] - o;
-    for (int64_t t = lane; t < len; t += 64) out[o + t] = ids[b + t];
-  }
-}
-
 }  // namespace n2v
 
 extern "C" int n2v_walk_exact_launch(const n2v_graph *g, const int32_t *start_ids,
@@ -686,177 +669,23 @@ extern "C" int n2v_walk_exact_launch(const n2v_graph *g, const int32_t *start_id
   return N2V_OK;
 }
 
-extern "C" int n2v_partition_step_unit_try(const int64_t *rowptr, const int32_t *col, int64_t lo,
-                                           int64_t n_local, const int64_t *head, int32_t head_cols,
-                                           const int64_t *src_ptr, const int32_t *src_ids,
-                                           int32_t wedge_lists, int64_t k, double p, double q,
-                                           uint64_t seed, int32_t *next_out, int64_t *edge_out,
-                                           uint32_t *status, void *stream);  // n2v_walk_unit.hip
-
-extern "C" int n2v_partition_step(const int64_t *rowptr, const int32_t *col, const float *w,
-                                  const double *w64, int64_t lo, int64_t n_local,
-                                  const int64_t *head, int32_t head_cols, const int64_t *src_ptr,
-                                  const int32_t *src_ids, int32_t src_kind, int64_t k, double p,
-                                  double q, uint64_t seed, int32_t *next_out, int64_t *edge_out,
-                                  uint32_t *status, void *stream) {
-  if (k < 0 || n_local < 0 || k >= 0xfffffff0ll || (w && w64)) return N2V_EINVAL;
-  if (p == 0.0 || q == 0.0) return N2V_EINVAL;  // randomwalk.py:209-212 (ValueError upstream)
-  if (src_kind != N2V_SRC_ROWS && src_kind != N2V_SRC_WEDGES) return N2V_EINVAL;
-  if (head_cols < 4) return N2V_EINVAL;  // (wedge lists with p or q != 1: 5, checked below)
-  if (src_kind == N2V_SRC_WEDGES && (w || w64)) return N2V_EINVAL;  // unit-weight parts only
-  if (k == 0) return N2V_OK;
-  if (!rowptr || !head || !next_out || !status) return N2V_EINVAL;  // (col: NULL for a part without edges)
-  if (q != 1.0 && !src_ptr) return N2V_EINVAL;
+// the generic (any weights) instance of n2v_partition_step (n2v_partition.hip dispatches):
+// status[1] was zeroed by the caller
+extern "C" int n2v_partition_step_generic_launch(const int64_t *rowptr, const int32_t *col,
+                                                 const float *w, const double *w64, int64_t lo,
+                                                 int64_t n_local, const int64_t *head,
+                                                 int32_t head_cols, const int64_t *src_ptr,
+                                                 const int32_t *src_ids, int64_t k, double p,
+                                                 double q, uint64_t seed, int32_t *next_out,
+                                                 int64_t *edge_out, uint32_t *status, void *stream) {
   int64_t blocks = (k + n2v::kWavesPerBlock - 1) / n2v::kWavesPerBlock;
   const int64_t cap = n2v::resident_blocks((const void *)n2v::partition_step_kernel,
                                            n2v::kWavesPerBlock * 64, 0);
   if (blocks > cap) blocks = cap;
-  if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
-    return N2V_ELAUNCH;
-  if (!w && !w64) {  // unit weights: the closed forms of n2v_walk_unit.hip
-    const int rc = n2v_partition_step_unit_try(rowptr, col, lo, n_local, head, head_cols, src_ptr,
-                                               src_ids, src_kind == N2V_SRC_WEDGES, k, p, q, seed,
-                                               next_out, edge_out, status, stream);
-    if (rc != 0) return rc < 0 ? rc : N2V_OK;
-  }
-  if (src_kind == N2V_SRC_WEDGES) return N2V_EINVAL;  // (p, q) outside the unit kernels' range
   hipLaunchKernelGGL(n2v::partition_step_kernel, dim3((unsigned)blocks),
                      dim3(n2v::kWavesPerBlock * 64), 0, (hipStream_t)stream, rowptr, col, w, w64,
                      lo, n_local, head, (int)head_cols, src_ptr, src_ids, k, p, q, seed, next_out,
                      edge_out, status);
-  N2V_HIP_CHECK(hipGetLastError());
-  return N2V_OK;
-}
-
-// the wedge lists of `edges` (local edge indices of one part) copied back to back as 32-bit
-// positions, and the fifth header word of the walkers that carry them
-__global__ __launch_bounds__(256) void n2v_gather_wedges_kernel(
-    const uint32_t *__restrict__ edge_classes, const uint64_t *__restrict__ wedge_off,
-    const void *__restrict__ wedge_pos, int wide, const int64_t *__restrict__ edges,
-    const int64_t *__restrict__ out_ptr, int64_t k, int32_t *__restrict__ out,
-    int64_t *__restrict__ head, int head_cols) {
-  const int lane = threadIdx.x & 63;
-  const int64_t n_waves = (int64_t)gridDim.x * 4;
-  for (int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); j < k; j += n_waves) {
-    const int64_t e = edges[j];
-    const uint64_t raw = wedge_off[e];
-    const int64_t b = (int64_t)(raw & N2V_WEDGE_OFF_MASK), o = out_ptr[j];
-    const int64_t len = out_ptr[j + 1] - o;
-    if (lane == 0)
-      head[j * head_cols + 4] = (int64_t)((uint64_t)edge_classes[e] | (raw >> N2V_WEDGE_RPOS_SHIFT) << 32);
-    for (int64_t t = lane; t < len; t += 64)
-      out[o + t] = wide ? (int32_t)reinterpret_cast<const uint32_t *>(wedge_pos)[b + t]
-                        : (int32_t)reinterpret_cast<const uint16_t *>(wedge_pos)[b + t];
-  }
-}
-
-extern "C" int n2v_gather_rows(const int64_t *ptr, const int32_t *ids, const int64_t *rows,
-                               const int64_t *out_ptr, int64_t k, int32_t *out, void *stream) {
-  if (k < 0) return N2V_EINVAL;
-  if (k == 0) return N2V_OK;
-  if (!ptr || !ids || !rows || !out_ptr || !out) return N2V_EINVAL;
-  int64_t blocks = (k + 3) / 4;
-  if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(n2v::gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                     (hipStream_t)stream, ptr, ids, rows, out_ptr, k, out);
-  N2V_HIP_CHECK(hipGetLastError());
-  return N2V_OK;
-}
-
-// what happens to every walker after its step (partitioned walking): the path record, the header
-// it travels on with, the rank it goes to and how many words go with it -- the elementwise half of
-// the routing; the grouping by destination is a sort of dest_out by the caller
-__global__ __launch_bounds__(256) void n2v_partition_route_kernel(
-    const int64_t *__restrict__ head_in, int head_cols, const int32_t *__restrict__ next,
-    const int64_t *__restrict__ edge, int64_t k, int walk_length, const int64_t *__restrict__ bounds,
-    int n_parts, int carry, const int64_t *__restrict__ rowptr, int64_t lo,
-    const uint32_t *__restrict__ edge_classes, int64_t *__restrict__ log_out,
-    int64_t *__restrict__ head_out, int32_t *__restrict__ dest_out, int64_t *__restrict__ len_out,
-    int64_t *__restrict__ src_out) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < k;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t *hd = head_in + i * head_cols;
-    const int64_t row = hd[0], key = hd[1], v = (int64_t)(uint32_t)hd[2], step = (int64_t)(uint32_t)hd[3];
-    const int32_t nx = next[i];
-    int32_t dest = n_parts;  // not forwarded
-    int64_t len = 0, src = 0;
-    if (nx < 0) {
-      // the current vertex has no out-edges: the walker vanished on arrival (fugue.py:147)
-      log_out[3 * i] = row;
-      log_out[3 * i + 1] = -1;
-      log_out[3 * i + 2] = -1;
-    } else {
-      log_out[3 * i] = row;
-      log_out[3 * i + 1] = step + 1;
-      log_out[3 * i + 2] = nx;
-      if (step + 1 < walk_length) {
-        int a = 0, b = n_parts;  // last part whose first vertex is <= nx
-        while (b - a > 1) {
-          const int mid = (a + b) >> 1;
-          if (bounds[mid] <= (int64_t)nx)
-            a = mid;
-          else
-            b = mid;
-        }
-        dest = a;
-        if (carry == N2V_SRC_WEDGES + 1) {
-          src = edge[i];
-          len = (int64_t)(edge_classes[src] & N2V_EC_SHARED_MASK);
-        } else if (carry == N2V_SRC_WEDGES + 2) {  // q == 1: counts and return position only
-          src = edge[i];
-        } else if (carry == N2V_SRC_ROWS + 1) {
-          src = v - lo;
-          len = rowptr[src + 1] - rowptr[src];
-        }
-      }
-    }
-    int64_t *ho = head_out + i * head_cols;
-    ho[0] = row;
-    ho[1] = key;
-    ho[2] = (v << 32) | (int64_t)(uint32_t)nx;
-    ho[3] = step + 1;
-    for (int c = 4; c < head_cols; ++c) ho[c] = 0;
-    dest_out[i] = dest;
-    len_out[i] = len;
-    src_out[i] = src;
-  }
-}
-
-extern "C" int n2v_partition_route(const int64_t *head_in, int32_t head_cols, const int32_t *next,
-                                   const int64_t *edge, int64_t k, int32_t walk_length,
-                                   const int64_t *bounds, int32_t n_parts, int32_t carry,
-                                   const int64_t *rowptr, int64_t lo, const uint32_t *edge_classes,
-                                   int64_t *log_out, int64_t *head_out, int32_t *dest_out,
-                                   int64_t *len_out, int64_t *src_out, void *stream) {
-  if (k < 0 || head_cols < 4 || n_parts < 1 || carry < 0 || carry > 3) return N2V_EINVAL;
-  if (k == 0) return N2V_OK;
-  if (!head_in || !next || !bounds || !log_out || !head_out || !dest_out || !len_out || !src_out)
-    return N2V_EINVAL;
-  if (carry == N2V_SRC_ROWS + 1 && !rowptr) return N2V_EINVAL;
-  if (carry >= N2V_SRC_WEDGES + 1 && !edge) return N2V_EINVAL;  // (edge_classes: NULL for a part without edges)
-  int64_t blocks = (k + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(n2v_partition_route_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                     (hipStream_t)stream, head_in, (int)head_cols, next, edge, k, (int)walk_length,
-                     bounds, (int)n_parts, (int)carry, rowptr, lo, edge_classes, log_out, head_out,
-                     dest_out, len_out, src_out);
-  N2V_HIP_CHECK(hipGetLastError());
-  return N2V_OK;
-}
-
-extern "C" int n2v_gather_wedges(const uint32_t *edge_classes, const uint64_t *wedge_off,
-                                 const void *wedge_pos, int32_t wide, const int64_t *edges,
-                                 const int64_t *out_ptr, int64_t k, int32_t *out, int64_t *head,
-                                 int32_t head_cols, void *stream) {
-  if (k < 0 || head_cols < 5) return N2V_EINVAL;
-  if (k == 0) return N2V_OK;
-  if (!edge_classes || !wedge_off || !wedge_pos || !edges || !out_ptr || !out || !head)
-    return N2V_EINVAL;
-  int64_t blocks = (k + 3) / 4;
-  if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(n2v_gather_wedges_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                     (hipStream_t)stream, edge_classes, wedge_off, wedge_pos, (int)wide, edges, out_ptr,
-                     k, out, head, (int)head_cols);
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
 }
