@@ -9,11 +9,12 @@ design point on a GPU node:
 * the CSR is partitioned by contiguous VERTEX RANGE; rank r stores the rows of its range only
   (`partition_graph`), so per-GPU memory is E / N instead of E;
 * a walker lives on the rank that stores the row of its CURRENT vertex.  One step there is the
-  reference's transformer on a batch -- bias N(v) against the travelling copy of N(s), build the
-  table, draw with the walker's own uniforms -- as ONE launch (n2v_partition_step: one wave per
-  walker, the table never materialised; `tables_step` keeps the launch-per-stage form on
-  materialised tables as a cross-check), bit-identical to n2v_walk's exact mode, whose RNG is
-  keyed by (seed, start vertex, ordinal, step) and not by where the walker happens to be;
+  reference's transformer on a batch -- bias N(v) against what travelled with the walker, build
+  the table, draw with the walker's own uniforms -- as ONE launch (n2v_partition_step, the table
+  never materialised; `tables_step` keeps the launch-per-stage form on materialised tables as a
+  cross-check), bit-identical to n2v_walk's exact mode, whose RNG is keyed by (seed, start
+  vertex, ordinal, step) and not by where the walker happens to be; the routing that follows is
+  one more launch (n2v_partition_route), a sort by destination and a gather;
 * then the walker MIGRATES to the owner of the vertex it drew, carrying a 40-byte header
   (output row, RNG key, previous/current vertex, step, classes) and -- only when q != 1, the one
   case in which N(s) decides anything (randomwalk.py:226-229) -- either the row it just left (the
@@ -25,7 +26,8 @@ design point on a GPU node:
   (`torch.distributed.all_to_all_single`, RCCL over xGMI on the GPUs, gloo in the CPU tests);
 * every appended vertex is logged as (row, position, vertex) and sent once, at the end, to the
   rank that emits the walk (the owner of its start vertex); walkers that reach a vertex without
-  out-edges vanish (inner join, fugue.py:147) and their row is marked invalid.
+  out-edges vanish (inner join, fugue.py:147) and their row is marked invalid -- the step finds
+  them itself (nothing to draw from), the arrivals are not inspected.
 
 `walk_partitioned` runs one rank of it; `walk_partitioned_local` runs all ranks of a
 partition in one process (the exchange is a list transpose) and is what the single-GPU tests
