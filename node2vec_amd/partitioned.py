@@ -228,6 +228,7 @@ class RankState:
         self.row_base = 0
         self.status = None  # uint32 [4] of n2v_partition_step, on the part's device
         self._arange = None
+        self.use_tables = True  # walk_partitioned clears it unless every rank holds the tables
 
     # -- initiate_random_walk (randomwalk.py:279-296) for the start vertices this rank owns ----
     def initiate(self, start_ids_global: torch.Tensor):
@@ -269,7 +270,7 @@ class RankState:
         if self.p == 1.0 and self.q == 1.0:
             return 1
         ordinary = all(2.0 ** -20 <= 1.0 / x <= 2.0 ** 20 for x in (self.p, self.q))
-        if part.wedge_off is None or not ordinary:
+        if part.wedge_off is None or not self.use_tables or not ordinary:
             return 0
         return 2 if self.q != 1.0 else 3
 
@@ -519,8 +520,15 @@ def walk_partitioned(part: GraphPart, start_ids: torch.Tensor, num_walks: int, w
     the rows of the start vertices in its range, bit-identical to n2v_walk on the whole graph."""
     import torch.distributed as dist
 
+    from node2vec_amd.shard import all_reduce
+
     world = dist.get_world_size(group)
     st = RankState(part, num_walks, walk_length, p, q, seed, step_fn)
+    # what travels with a walker must mean the same thing on both ends: wedge lists only when
+    # EVERY rank holds the per-edge tables of its part
+    have = torch.tensor([0 if part.wedge_off is None else 1], dtype=torch.int32, device=part.device)
+    all_reduce(have, dist.ReduceOp.MIN, group)
+    st.use_tables = bool(have.item())
     st.initiate(start_ids)
     for _ in range(walk_length):
         st.receive(_exchange_walkers(st.advance(world), group, dist, part.device))

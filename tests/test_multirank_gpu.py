@@ -13,8 +13,9 @@ period autotune -- is the code that runs under RCCL).  Checked:
     corpus, the pair count of the two shards;
   * partitioned.walk_partitioned under the group: each rank holds HALF of the CSR, steps its
     resident walkers with n2v_partition_step and exchanges the migrating ones (headers + the
-    travelling rows) through all_to_all_single; the two halves of the output are the rows of
-    n2v_walk on the whole graph, bit for bit.
+    travelling wedge lists) through all_to_all_single; the two halves of the output are the rows
+    of n2v_walk on the whole graph, bit for bit -- also when one rank lacks the per-edge tables
+    (both then fall back to travelling rows).
 """
 import hashlib
 import os
@@ -105,6 +106,15 @@ def _worker(rank, world, port, ret):
             pw, pv, prow = P.walk_partitioned(part, start, 2, 15, pq[0], pq[1], 31)
             out["partitioned_%g_%g" % pq] = {"walks": pw.cpu().numpy(), "valid": pv.cpu().numpy(),
                                              "rows": prow.cpu().numpy(), "edges": int(part.col.numel())}
+        # one rank WITHOUT the per-edge tables: both must fall back to rows travelling
+        import dataclasses
+
+        assert part.wedge_off is not None
+        bare = part if rank == 0 else dataclasses.replace(part, edge_classes=None, wedge_off=None,
+                                                          wedge_pos=None)
+        pw, pv, prow = P.walk_partitioned(bare, start, 2, 15, 0.5, 2.0, 31)
+        out["partitioned_mixed"] = {"walks": pw.cpu().numpy(), "valid": pv.cpu().numpy(),
+                                    "rows": prow.cpu().numpy(), "edges": int(part.col.numel())}
         ret[rank] = out
     finally:
         dist.destroy_process_group()
@@ -150,10 +160,10 @@ def test_two_ranks_on_one_gpu_fit_and_fit_streaming():
     from node2vec_amd import randomwalk as rw
 
     start = rw.start_vertices(g)
-    for pq in PART_PQ:
+    for pq, key in [(pq, "partitioned_%g_%g" % pq) for pq in PART_PQ] + [((0.5, 2.0), "partitioned_mixed")]:
         want, wv = rw.walk(g, start, 2, 15, pq[0], pq[1], 31)
         want, wv = want.cpu().numpy(), wv.cpu().numpy().astype(bool)
-        pa, pb = r0["partitioned_%g_%g" % pq], r1["partitioned_%g_%g" % pq]
+        pa, pb = r0[key], r1[key]
         assert 0 < pa["edges"] < g.n_edges and pa["edges"] + pb["edges"] == g.n_edges
         rows = np.concatenate([pa["rows"], pb["rows"]])
         assert np.array_equal(np.sort(rows), np.arange(want.shape[0]))  # every row emitted once
