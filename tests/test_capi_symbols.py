@@ -65,6 +65,44 @@ def test_ctypes_structs_match_header_layout():
     assert fields == [f[0] for f in _lib.SgnsParams._fields_]
 
 
+def test_partition_entry_points_validate_their_arguments():
+    """argument errors of the partitioned-walking entry points come back as N2V_EINVAL (-1) before
+    anything is launched (no GPU needed: nothing is launched); an empty batch is N2V_OK"""
+    from node2vec_amd import _lib
+
+    L = _lib.load()
+    buf = (ctypes.c_int64 * 64)()
+    p_ = ctypes.addressof(buf)
+
+    def step(**kw):
+        a = dict(rowptr=p_, col=p_, w=0, w64=0, lo=0, n_local=4, head=p_, head_cols=5, src_ptr=p_,
+                 src_ids=p_, src_kind=0, k=1, p=0.5, q=2.0, seed=1, next_out=p_, edge_out=0, status=p_)
+        a.update(kw)
+        return L.n2v_partition_step(a["rowptr"], a["col"], a["w"], a["w64"], a["lo"], a["n_local"], a["head"],
+                                    a["head_cols"], a["src_ptr"], a["src_ids"], a["src_kind"], a["k"], a["p"],
+                                    a["q"], a["seed"], a["next_out"], a["edge_out"], a["status"], None)
+
+    assert step(k=0) == 0  # nothing to do
+    assert step(p=0.0) == -1 and step(q=0.0) == -1  # randomwalk.py:209-212
+    assert step(k=-1) == -1 and step(n_local=-1) == -1 and step(head_cols=3) == -1
+    assert step(src_kind=2) == -1
+    assert step(w=p_, w64=p_) == -1  # at most one weight array
+    assert step(src_kind=1, w=p_) == -1  # wedge lists: unit-weight parts only
+    assert step(head=0) == -1 and step(next_out=0) == -1 and step(status=0) == -1
+    assert step(src_ptr=0) == -1  # q != 1: something must have travelled
+    assert L.n2v_partition_route(p_, 5, p_, 0, 0, 10, p_, 2, 0, p_, 0, 0, p_, p_, p_, p_, p_, None) == 0
+    assert L.n2v_partition_route(p_, 3, p_, 0, 1, 10, p_, 2, 0, p_, 0, 0, p_, p_, p_, p_, p_, None) == -1
+    assert L.n2v_partition_route(p_, 5, p_, 0, 1, 10, p_, 0, 0, p_, 0, 0, p_, p_, p_, p_, p_, None) == -1
+    assert L.n2v_partition_route(p_, 5, p_, 0, 1, 10, p_, 2, 4, p_, 0, 0, p_, p_, p_, p_, p_, None) == -1
+    assert L.n2v_partition_route(p_, 5, p_, 0, 1, 10, p_, 2, 2, p_, 0, p_, p_, p_, p_, p_, p_, None) == -1  # no edges
+    assert L.n2v_partition_route(p_, 5, p_, 0, 1, 10, p_, 2, 1, 0, 0, 0, p_, p_, p_, p_, p_, None) == -1  # no rowptr
+    assert L.n2v_gather_rows(p_, p_, p_, p_, 0, p_, None) == 0 and L.n2v_gather_rows(p_, p_, p_, p_, -1, p_, None) == -1
+    assert L.n2v_gather_rows(0, p_, p_, p_, 1, p_, None) == -1
+    assert L.n2v_gather_wedges(p_, p_, p_, 0, p_, p_, 0, p_, p_, 5, None) == 0
+    assert L.n2v_gather_wedges(p_, p_, p_, 0, p_, p_, 1, p_, p_, 4, None) == -1
+    assert L.n2v_gather_wedges(0, p_, p_, 0, p_, p_, 1, p_, p_, 5, None) == -1
+
+
 def test_product_package_never_touches_the_oracle():
     """no file of node2vec_amd/ imports, loads or mentions oracle/ code paths"""
     pkg = os.path.join(ROOT, "node2vec_amd")
