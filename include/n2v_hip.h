@@ -435,12 +435,22 @@ int n2v_partition_step(const int64_t *rowptr, const int32_t *col, const float *w
  * vertex, src = local row; N2V_SRC_WEDGES + 1: the wedge list of edge[i], src = that edge;
  * N2V_SRC_WEDGES + 2: src = that edge but no words -- q == 1, only the counts and the return
  * position of the edge travel, in the header).  The caller groups the walkers by a stable sort
- * of dest_out. */
+ * of dest_out, or calls n2v_partition_group. */
 int n2v_partition_route(const int64_t *head_in, int32_t head_cols, const int32_t *next,
                         const int64_t *edge, int64_t k, int32_t walk_length, const int64_t *bounds,
                         int32_t n_parts, int32_t carry, const int64_t *rowptr, int64_t lo,
                         const uint32_t *edge_classes, int64_t *log_out, int64_t *head_out,
                         int32_t *dest_out, int64_t *len_out, int64_t *src_out, void *stream);
+/* Groups what n2v_partition_route wrote by destination, keeping the order inside a destination
+ * (a stable counting sort: per-block counts, one scan, one scatter): head_out / len_out / src_out
+ * = the rows of head / len / src ordered by dest (0 .. n_parts, n_parts = not forwarded, last);
+ * cuts_out int64 [n_parts + 1]: where destination d starts (cuts_out[n_parts] = the number of
+ * forwarded walkers).  n_parts <= 64.  work: int64 scratch of ((k + 255) / 256 + 1) * (n_parts + 1)
+ * words. */
+int n2v_partition_group(const int32_t *dest, const int64_t *head, int32_t head_cols,
+                        const int64_t *len, const int64_t *src, int64_t k, int32_t n_parts,
+                        int64_t *work, int64_t *head_out, int64_t *len_out, int64_t *src_out,
+                        int64_t *cuts_out, void *stream);
 int n2v_gather_rows(const int64_t *ptr, const int32_t *ids, const int64_t *rows,
                     const int64_t *out_ptr, int64_t k, int32_t *out, void *stream);
 int n2v_gather_wedges(const uint32_t *edge_classes, const uint64_t *wedge_off, const void *wedge_pos,

@@ -9,7 +9,9 @@
 //                            of the previous vertex travelled: one wave per walker;
 //                          - partition_step_kernel (n2v_walk.hip): any weights, one wave per walker.
 //   n2v_partition_route  what happens to every walker after its step: path record, next header,
-//                        destination, words to carry (elementwise; the caller sorts by destination)
+//                        destination, words to carry (elementwise)
+//   n2v_partition_group  the walkers grouped by destination: a stable counting sort (per-block
+//                        counts, one scan, one scatter)
 //   n2v_gather_rows / n2v_gather_wedges  pack what travels with the migrating walkers
 #include "n2v_common.h"
 
@@ -188,6 +190,96 @@ extern "C" int n2v_partition_route(const int64_t *head_in, int32_t head_cols, co
                      (hipStream_t)stream, head_in, (int)head_cols, next, edge, k, (int)walk_length,
                      bounds, (int)n_parts, (int)carry, rowptr, lo, edge_classes, log_out, head_out,
                      dest_out, len_out, src_out);
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}
+
+// ---- grouping by destination: a stable counting sort in three launches ---------------------------
+// (a block owns 256 consecutive walkers; destinations 0 .. n_parts, n_parts = "not forwarded")
+constexpr int kGroupMaxParts = 64;
+
+__global__ __launch_bounds__(256) void n2v_group_count_kernel(const int32_t *__restrict__ dest, int64_t k,
+                                                              int p1, int64_t *__restrict__ work) {
+  __shared__ int cnt[kGroupMaxParts + 1];
+  for (int d = threadIdx.x; d < p1; d += 256) cnt[d] = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < k) atomicAdd(&cnt[dest[i]], 1);
+  __syncthreads();
+  for (int d = threadIdx.x; d < p1; d += 256) work[(int64_t)blockIdx.x * p1 + d] = cnt[d];
+}
+
+// work[b][d] := walkers of destination d in the blocks before b; work[nb][d] := where destination d
+// starts in the grouped order; cuts[d] = the same (cuts[n_parts] = forwarded walkers)
+__global__ __launch_bounds__(128) void n2v_group_scan_kernel(int64_t nb, int p1, int64_t *__restrict__ work,
+                                                             int64_t *__restrict__ cuts) {
+  __shared__ int64_t total[kGroupMaxParts + 1];
+  const int d = threadIdx.x;
+  if (d < p1) {
+    int64_t run = 0;
+    for (int64_t b = 0; b < nb; ++b) {
+      const int64_t c = work[b * p1 + d];
+      work[b * p1 + d] = run;
+      run += c;
+    }
+    total[d] = run;
+  }
+  __syncthreads();
+  if (d == 0) {
+    int64_t run = 0;
+    for (int t = 0; t < p1; ++t) {
+      work[nb * p1 + t] = run;
+      cuts[t] = run;
+      run += total[t];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void n2v_group_scatter_kernel(
+    const int32_t *__restrict__ dest, const int64_t *__restrict__ head, int head_cols,
+    const int64_t *__restrict__ len, const int64_t *__restrict__ src, int64_t k, int p1, int64_t nb,
+    const int64_t *__restrict__ work, int64_t *__restrict__ head_out, int64_t *__restrict__ len_out,
+    int64_t *__restrict__ src_out) {
+  __shared__ int wave_cnt[4][kGroupMaxParts + 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int d = i < k ? dest[i] : -1;
+  int rank = 0;
+  for (int t = 0; t < p1; ++t) {  // stable rank among the walkers of the same destination
+    const unsigned long long m = __ballot(d == t);
+    if (d == t) rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wv][t] = __popcll(m);
+  }
+  __syncthreads();
+  if (d >= 0) {
+    for (int w2 = 0; w2 < wv; ++w2) rank += wave_cnt[w2][d];
+    const int64_t pos = work[nb * p1 + d] + work[(int64_t)blockIdx.x * p1 + d] + rank;
+    for (int c = 0; c < head_cols; ++c) head_out[pos * head_cols + c] = head[i * head_cols + c];
+    len_out[pos] = len[i];
+    src_out[pos] = src[i];
+  }
+}
+
+extern "C" int n2v_partition_group(const int32_t *dest, const int64_t *head, int32_t head_cols,
+                                   const int64_t *len, const int64_t *src, int64_t k, int32_t n_parts,
+                                   int64_t *work, int64_t *head_out, int64_t *len_out,
+                                   int64_t *src_out, int64_t *cuts_out, void *stream) {
+  if (k < 0 || head_cols < 1 || n_parts < 1 || n_parts > kGroupMaxParts) return N2V_EINVAL;
+  if (!cuts_out) return N2V_EINVAL;
+  const int p1 = n_parts + 1;
+  if (k == 0) {
+    N2V_HIP_CHECK(hipMemsetAsync(cuts_out, 0, sizeof(int64_t) * p1, (hipStream_t)stream));
+    return N2V_OK;
+  }
+  if (!dest || !head || !len || !src || !work || !head_out || !len_out || !src_out) return N2V_EINVAL;
+  const int64_t nb = (k + 255) / 256;
+  if (nb >= (1ll << 31)) return N2V_EINVAL;
+  hipLaunchKernelGGL(n2v_group_count_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dest,
+                     k, p1, work);
+  hipLaunchKernelGGL(n2v_group_scan_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, nb, p1, work,
+                     cuts_out);
+  hipLaunchKernelGGL(n2v_group_scatter_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dest,
+                     head, (int)head_cols, len, src, k, p1, nb, work, head_out, len_out, src_out);
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
 }

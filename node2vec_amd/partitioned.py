@@ -278,7 +278,7 @@ class RankState:
         """next_step_random_walk (randomwalk.py:300-339) for every resident walker in one launch
         (the table never materialised), then the routing: one elementwise launch
         (n2v_partition_route: path record, next header, destination, words to carry), a stable
-        sort by destination, one gather of what travels.  N(s) only decides shared / other
+        counting sort by destination (n2v_partition_group), one gather of what travels.  N(s) only decides shared / other
         (randomwalk.py:226-229): with q == 1 -- the reference's defaults p == q == 1 included,
         where every table is probs == [1.0] * n and the draw is pick = int(r1 * n) -- the walker
         travels as its 40-byte header alone.  Otherwise it takes the WEDGE LIST of the edge it
@@ -330,15 +330,28 @@ class RankState:
                                              lens.data_ptr(), src.data_ptr(),
                                              _lib.current_stream_ptr()), "n2v_partition_route")
         self.log.append(log)
-        dest, order = torch.sort(dest, stable=True)
-        cuts = torch.searchsorted(dest, self._parts_arange(n_parts))  # walkers per destination
-        head, lens, src = head[order], lens[order], src[order]
+        if n_parts <= 64:  # stable counting sort by destination (three small launches)
+            work = torch.empty(((k + 255) // 256 + 1) * (n_parts + 1), dtype=torch.int64, device=dev)
+            head_s, lens_s, src_s = torch.empty_like(head), torch.empty_like(lens), torch.empty_like(src)
+            cuts = torch.empty(n_parts + 1, dtype=torch.int64, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(L.n2v_partition_group(dest.data_ptr(), head.data_ptr(), HEAD_COLS, lens.data_ptr(),
+                                                 src.data_ptr(), k, n_parts, work.data_ptr(),
+                                                 head_s.data_ptr(), lens_s.data_ptr(), src_s.data_ptr(),
+                                                 cuts.data_ptr(), _lib.current_stream_ptr()),
+                           "n2v_partition_group")
+            head, lens, src = head_s, lens_s, src_s
+        else:
+            dest, order = torch.sort(dest, stable=True)
+            cuts = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev),
+                              torch.searchsorted(dest, self._parts_arange(n_parts))])
+            head, lens, src = head[order], lens[order], src[order]
         ptr = torch.zeros(k + 1, dtype=torch.int64, device=dev)
         torch.cumsum(lens, 0, out=ptr[1:])
         # one transfer: the status word, the walkers per destination, the words per destination
         host = torch.cat([self.status[:1].to(torch.int64), cuts, ptr[cuts]]).tolist()
         _lib.check_status_word(host[0], "n2v_partition_step")
-        cuts_h, at = [0] + host[1:n_parts + 1], [0] + host[n_parts + 1:]
+        cuts_h, at = host[1:n_parts + 2], host[n_parts + 2:]
         k2 = cuts_h[-1]  # forwarded walkers: the first k2 of the sorted batch
         ids = torch.zeros(0, dtype=torch.int32, device=dev)
         if carry_kind and k2 > 0:

@@ -21,7 +21,7 @@ def test_header_declares_the_expected_entry_points():
                  "n2v_hops_build", "n2v_cum_index_build", "n2v_walk_uniforms", "n2v_wedge_build",
                  "n2v_mem_probe", "n2v_corpus_count", "n2v_corpus_index", "n2v_hops8_build",
                  "n2v_partition_step", "n2v_gather_rows", "n2v_gather_wedges",
-                 "n2v_partition_route"):
+                 "n2v_partition_route", "n2v_partition_group"):
         assert want in names
 
 

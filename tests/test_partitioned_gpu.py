@@ -174,6 +174,16 @@ def test_partition_route_and_gathers_equal_plain_torch():
         assert torch.equal(ln, torch.where(fwd, want_len, 0))
         if carry:
             assert torch.equal(src[fwd], (local if carry == 1 else edge)[fwd])
+        # grouping by destination: the stable counting sort against torch's stable sort
+        work = torch.empty(((k + 255) // 256 + 1) * 5, dtype=torch.int64, device="cuda")
+        hg, lg, sg = torch.empty_like(ho), torch.empty_like(ln), torch.empty_like(src)
+        cuts = torch.empty(5, dtype=torch.int64, device="cuda")
+        _lib.check(L.n2v_partition_group(dest.data_ptr(), ho.data_ptr(), cols, ln.data_ptr(), src.data_ptr(), k, 4,
+                                         work.data_ptr(), hg.data_ptr(), lg.data_ptr(), sg.data_ptr(),
+                                         cuts.data_ptr(), _lib.current_stream_ptr()), "group")
+        ds, order = torch.sort(dest, stable=True)
+        assert torch.equal(hg, ho[order]) and torch.equal(lg, ln[order]) and torch.equal(sg, src[order])
+        assert torch.equal(cuts, torch.searchsorted(ds, torch.arange(5, dtype=torch.int32, device="cuda")))
         # the gathers over the forwarded walkers, in the given order
         idx = torch.nonzero(fwd).reshape(-1)
         ptr = torch.zeros(idx.numel() + 1, dtype=torch.int64, device="cuda")
