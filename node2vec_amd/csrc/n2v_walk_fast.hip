@@ -10,6 +10,9 @@
 // unnormalised probability (:223-230).  The first step (s < 0), and every step when
 // p == q == 1, is the unbiased table itself and is draw-for-draw identical to the exact
 // mode (n2v_walk dispatches exact walks with p == q == 1 here when the slots exist).
+// That is the REJECTION sampler (weighted graphs; unit-weight graphs without the wedge table).  On
+// a unit-weight graph with the per-edge tables the step is drawn from the LAYERS of its table
+// instead (kClassFirst below): one trial per step, no rejection at q >= 1 with p <= q.
 //
 // One LANE per walker, walkers resident for all L steps.  Every loop iteration
 // each live lane performs ONE trial for its own current step; a lane whose
