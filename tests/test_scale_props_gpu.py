@@ -119,6 +119,47 @@ def test_exact_and_fast_visit_the_same_distribution():
     assert float((ha - hb).abs().max()) < 5e-3
 
 
+@pytest.mark.parametrize("pq", [(0.5, 2.0), (4.0, 0.25), (0.7, 1.3)])
+def test_layered_fast_sampler_matches_exact_walks_at_scale(pq):
+    """unit-weight R-MAT graph (2.6 x 10^5 vertices), all per-edge tables: the layered sampler of
+    fast mode and the exact sampler are the same Markov chain -- over 6 x 10^6 steps each (fixed
+    seeds: nothing here is random between runs) the share of RETURN moves (x == s: what round 2's
+    fast sampler got wrong) agrees within 5 binomial sd, the degree-bucketed visit frequencies
+    within 5e-3, and the share of moves that close a triangle (x in N(s), x != s) within 5 sd"""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd import synthetic
+
+    p, q = pq
+    g = synthetic.rmat(18, 1_500_000, device="cuda")
+    assert g.unit_weights
+    start = rw.start_vertices(g)
+    a, av = rw.walk(g, start, 1, 30, p, q, 1, mode="exact")
+    b, bv = rw.walk(g, start, 1, 30, p, q, 2, mode="fast")
+    assert g.wedge_off is not None  # fast mode walked the layers of the tables
+    assert bool(av.all()) and bool(bv.all())
+    keys = (torch.repeat_interleave(torch.arange(g.n_vertices, device="cuda"), g.degrees()) * g.n_vertices
+            + g.col.long())  # ascending: rows are sorted
+
+    def shares(w):
+        w = w.long()
+        ret = (w[:, 2:] == w[:, :-2])
+        probe = (w[:, :-2] * g.n_vertices + w[:, 2:]).reshape(-1)  # is (s -> x) an edge?
+        pos = torch.searchsorted(keys, probe).clamp_(max=keys.numel() - 1)
+        tri = (keys[pos] == probe).reshape(ret.shape) & ~ret
+        return float(ret.double().mean()), float(tri.double().mean()), ret.numel()
+
+    (ra, ta, na), (rb, tb, nb) = shares(a), shares(b)
+    for xa, xb in ((ra, rb), (ta, tb)):
+        pbar = (xa * na + xb * nb) / (na + nb)
+        z = (xa - xb) / (pbar * (1 - pbar) * (1 / na + 1 / nb)) ** 0.5
+        assert abs(z) < 5.0, (pq, xa, xb, z)
+    assert ra > 0.01 and ta > 0.001  # both events do occur
+    bucket = torch.log2(g.degrees().clamp(min=1).double()).long()
+    ha = torch.bincount(bucket[a[:, 1:].long()].reshape(-1), minlength=20).double()
+    hb = torch.bincount(bucket[b[:, 1:].long()].reshape(-1), minlength=20).double()
+    assert float((ha / ha.sum() - hb / hb.sum()).abs().max()) < 5e-3
+
+
 def test_weighted_generic_kernel_large_rows(oracle):
     """weighted graph (generic kernel): hubs beyond the 1024-entry weight cache"""
     from node2vec_amd import randomwalk as rw
