@@ -506,8 +506,7 @@ def _exchange_walkers(out: List[Walkers], group, dist, dev) -> List[Walkers]:
     """The migration of one step: three collectives -- the sizes (walkers and row words per
     destination, one [world, 2] exchange), the headers with the length of what travels with each
     walker as an extra column, and those words.  Segments arrive in source order in both
-    payloads, so the receiver rebuilds ONE batch: ptr = prefix sums of the extra column."""
-    world = dist.get_world_size(group)
+    payloads, so the receiver rebuilds ONE batch."""
     cpu = dist.get_backend(group) == "gloo"  # gloo moves host tensors
     wire = torch.device("cpu") if cpu else dev
     head5 = torch.cat([torch.cat([w.head, w.lens[:, None]], 1) for w in out]).to(wire)
