@@ -25,3 +25,15 @@ def test_model_agrees_with_the_reference_loop(name, rows):
     last = res.stdout.strip().splitlines()[-1]
     assert last.startswith("total") and " bad" in last
     assert int(last.split()[1]) > 0  # rows were really drawn
+
+
+def test_layered_sampler_model_gives_every_slot_its_weight():
+    """the layer decomposition of fast mode's sampler (csrc/n2v_walk_fast.hip, kClassFirst) in exact
+    rational arithmetic: P(slot) == weight / sum of weights for every ordering of 1/p, 1, 1/q"""
+    env = dict(os.environ, N2V_MODEL_TRIALS="3000")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "models", "layered_sampler.py")], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    last = res.stdout.strip().splitlines()[-1]
+    assert last.startswith("total") and last.endswith(" 0 bad") and int(last.split()[1]) == 3000
+
