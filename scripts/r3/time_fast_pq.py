@@ -1,5 +1,5 @@
 """fast mode on a BASELINE graph for several (p, q): G steps/s and trials per step, with the wedge
-table (layered sampler) and without it (rejection sampler).  GRAPH=cfg4|cfg3|cfg2, 1 M start
+table (layered sampler) and without it (rejection sampler).  GRAPH=cfg4|cfg3|cfg5|cfg2, 1 M start
 vertices x 10 walks x 80 steps per launch."""
 import os
 import sys
@@ -17,6 +17,8 @@ if cfg == "cfg4":
     g = synthetic.chung_lu(100_000_000, 500_000_000, device="cuda").trimmed(10_000, 42)
 elif cfg == "cfg3":
     g = synthetic.chung_lu(10_000_000, 100_000_000, device="cuda").trimmed(10_000, 42)
+elif cfg == "cfg5":
+    g = synthetic.hub_bipartite(50_000_000, 5000, 10_000, device="cuda")
 else:
     g = synthetic.rmat(20, 5_000_000, device="cuda")
 start = rw.start_vertices(g)
