@@ -261,7 +261,7 @@ def main():
     del leg
     torch.cuda.empty_cache()
 
-    # ---- the second-order bias on the same graph: exact and rejection sampling -------------
+    # ---- the second-order bias on the same graph: exact mode and fast mode (layered or rejection sampler) -------------
     bp, bq = BIASED_PQ
     if not args.no_biased and (bp, bq) != (p, q):
         prepare_tables(torch, g, bp, bq, "exact", setup, "biased")
