@@ -19,7 +19,7 @@
  *    FOUR uint32 words, zeroed by the caller: [0] status bits, [1] scratch (the exact walk
  *    kernels hand out walkers through it; the library resets it on the stream before a launch),
  *    [2..3] a 64-bit counter that N2V_WALK_FAST increments by its number of
- *    rejection trials (for the algorithmic-bytes accounting of DESIGN.md);
+ *    trials (draws, accepted or not; for the algorithmic-bytes accounting of DESIGN.md);
  *  - no global state: re-entrant, any number of streams / devices.
  */
 #ifndef N2V_HIP_H
@@ -44,7 +44,10 @@ extern "C" {
 
 /* walk sampler modes */
 #define N2V_WALK_EXACT 0 /* per-step biased alias rebuild, bit-identical to the reference */
-#define N2V_WALK_FAST 1  /* precomputed first-order tables + rejection (same distribution) */
+#define N2V_WALK_FAST 1  /* same transition distribution, not the same draws: on a unit-weight graph
+                          * with edge_classes + wedge_off / wedge_pos a step is ONE draw from the
+                          * layers of its table (no rejection at q >= 1 with p <= q); otherwise
+                          * candidates from the first-order table are rejected by beta / beta_max */
 
 /* One entry of a first-order Walker alias table, packed so that a draw is ONE
  * 16-byte access: the neighbour id, the neighbour id BEHIND the alias index of
