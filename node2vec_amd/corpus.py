@@ -6,8 +6,13 @@ converting the list column back (embedding.py:125).  The tensor is NOT stored on
 pandas treats DataFrame.attrs as plain metadata (it is deep-copied into every derived frame,
 compared with == by concat / merge, and serialised as JSON by to_parquet).  The frame carries an
 opaque integer token; this module maps token -> (weak reference to the frame, tensor) and hands
-the tensor out only to the very frame object random_walk() returned, with a sampled content check.
-The entry dies with the frame.
+the tensor out only to the very frame object random_walk() returned, after checking that its
+"walk" column still is what the tensor says: every row must still be the very list object
+random_walk() put there (so `df.at[i, "walk"] = ...`, masking, reordering or any other replacement
+of rows is always seen), and 64 sampled rows + the ends are compared element by element (an edit
+INSIDE one of the original list objects is only caught on those; set `corpus.STRICT = True` to
+compare every element, at the cost of the host conversion the device corpus exists to avoid, or
+pass `df.copy()` / drop `df.attrs` to train on the frame's contents).  The entry dies with the frame.
 """
 import itertools
 import weakref
@@ -18,12 +23,17 @@ import torch
 
 ATTR = "n2v_device_walks"
 _tokens = itertools.count(1)
-_registry = {}  # token -> (weakref to the frame, device tensor)
+_registry = {}  # token -> (weakref to the frame, device tensor, ids of the row objects)
+STRICT = False  # True: lookup() compares the whole column with the tensor
+
+
+def _row_ids(col) -> np.ndarray:
+    return np.fromiter(map(id, col.to_numpy()), dtype=np.int64, count=len(col))
 
 
 def attach(frame, walks: torch.Tensor) -> None:
     token = next(_tokens)
-    _registry[token] = (weakref.ref(frame), walks)
+    _registry[token] = (weakref.ref(frame), walks, _row_ids(frame["walk"]))
     weakref.finalize(frame, _registry.pop, token, None)
     frame.attrs[ATTR] = token
 
@@ -39,9 +49,22 @@ def lookup(frame) -> Optional[torch.Tensor]:
     n = walks.shape[0]
     if n != len(frame) or n == 0 or "walk" not in frame.columns:
         return None
+    col = frame["walk"]
+    if not np.array_equal(_row_ids(col), entry[2]):  # some row is no longer the original object
+        return None
+    if STRICT:
+        try:
+            host = np.asarray(col.tolist(), dtype=np.int64)
+        except ValueError:  # ragged rows
+            return None
+        if host.shape != tuple(walks.shape):
+            return None
+        for lo in range(0, n, 1 << 20):
+            if not bool((torch.as_tensor(host[lo:lo + (1 << 20)], device=walks.device) == walks[lo:lo + (1 << 20)]).all()):
+                return None
+        return walks
     rows = np.unique(np.r_[0, n - 1, np.random.default_rng(token).integers(0, n, 64)])
     want = walks[torch.as_tensor(rows, device=walks.device)].cpu().numpy().tolist()
-    col = frame["walk"]
     if [list(col.iloc[int(r)]) for r in rows] != want:
         return None
     return walks

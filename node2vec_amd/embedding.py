@@ -329,7 +329,9 @@ class Node2VecHIP(Node2VecBase):
         wv = self.model.wv
         names = None
         if self.name_id is not None:
-            names = self.name_id.set_index("id")["name"]
+            # embedding.py:139-140 builds a dict: a repeated id keeps its LAST name, and an id
+            # of the vocabulary that name_id does not list is a KeyError
+            names = self.name_id.drop_duplicates("id", keep="last").set_index("id")["name"]
         for lo in range(0, len(wv), chunk_rows):
             hi = min(len(wv), lo + chunk_rows)
             if wv.ids is not None:
@@ -338,6 +340,9 @@ class Node2VecHIP(Node2VecBase):
                 ids = np.array([int(t) for t in wv.index2word[lo:hi]], dtype=np.int64)
             vectors = wv.rows(lo, hi).tolist()
             if names is not None:
+                missing = ~pd.Index(ids).isin(names.index)
+                if missing.any():
+                    raise KeyError(int(np.asarray(ids)[missing][0]))
                 yield pd.DataFrame({"name": names.reindex(ids).to_numpy(), "vector": vectors})
             else:
                 yield pd.DataFrame({"id": ids, "vector": vectors})

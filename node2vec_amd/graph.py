@@ -140,6 +140,8 @@ class DeviceGraph:
                 setattr(g, name, t.to(device))
         g.hops_have_classes = self.hops_have_classes
         g.hops8_bits, g.hops8_shift = self.hops8_bits, self.hops8_shift
+        # a declined build (escape share, memory budget) stays declined on the copy
+        g.hops8_tried, g.wedge_tried = self.hops8_tried, self.wedge_tried
         return g
 
     def c_struct(self) -> _lib.Graph:

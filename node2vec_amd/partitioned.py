@@ -469,7 +469,11 @@ def walk_partitioned_local(parts: Sequence[GraphPart], start_ids: torch.Tensor, 
     (walks, valid) in the row order of n2v_walk over the same start list."""
     n = len(parts)
     ranks = [RankState(pt, num_walks, walk_length, p, q, seed, step_fn) for pt in parts]
+    # what travels with a walker (wedge lists or rows) must be the same on every part: lists only
+    # if EVERY part stores them (walk_partitioned agrees on this with an all-reduce)
+    tables = all(pt.wedge_off is not None for pt in parts)
     for r in ranks:
+        r.use_tables = tables
         r.initiate(start_ids)
     for _ in range(walk_length):
         out = [r.advance(n) for r in ranks]

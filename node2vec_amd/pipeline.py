@@ -77,9 +77,21 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
             torch.cuda.synchronize(dev)
         return time.perf_counter()
 
+    # the walk status word (the reference's ZeroDivisionError on a visited row whose biased weights
+    # sum to 0, randomwalk.py:172-173; an id out of range) is OR-ed on the device over all batches
+    # and raised at the two host synchronisations the function has anyway -- never dropped
+    walk_status = torch.zeros(1, dtype=torch.int32, device=dev)
+
     def walk(k):
-        return rw.walk(graph, start[k * batch_vertices:(k + 1) * batch_vertices].contiguous(), W, L,
-                       pp, qq, seed, mode, check=False)
+        st = {}
+        out = rw.walk(graph, start[k * batch_vertices:(k + 1) * batch_vertices].contiguous(), W, L,
+                      pp, qq, seed, mode, check=False, stats=st)
+        walk_status.bitwise_or_(st["status"][:1])
+        return out
+
+    def raise_walk_status():
+        from node2vec_amd import _lib
+        _lib.check_status_word(int(walk_status.item()), "n2v_walk")
 
     # ---- pass 1: token counts of the virtual corpus (vocabulary, cum_table, subsampling).  No
     # host synchronisation per batch: invalid rows are masked out, not compacted.
@@ -93,6 +105,7 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
     if multi:
         all_reduce(counts, dist.ReduceOp.SUM)
     t_walk += clock() - t0
+    raise_walk_status()  # (the nonzero() below synchronises anyway)
     rows_rank_max = n_start_max * W  # rows of the largest shard: the sentence-id stride of a rank
     ids = torch.nonzero(counts >= max(int(p["min_count"]), 1)).reshape(-1)
     if ids.numel() == 0:
@@ -140,6 +153,7 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
     if sync is not None:
         sync.finish()
     torch.cuda.synchronize(dev)
+    raise_walk_status()
     if timings is not None:
         timings.update(walk_s=t_walk, train_s=t_train, batches=n_batches, epochs=epochs,
                        rows_this_rank=n_start * W, world=world)

@@ -138,7 +138,11 @@ def csr_from_edges(edges, n_vertices=None):
     e = list(edges)
     src = np.array([x[0] for x in e], dtype=np.int64)
     dst = np.array([x[1] for x in e], dtype=np.int64)
-    w = np.array([x[2] for x in e], dtype=np.float32)
+    # the reference carries Python floats (fp64): keep them, and use the 4-byte storage form
+    # only when it holds the very same values (as DeviceGraph.from_edges does on the device)
+    w = np.array([x[2] for x in e], dtype=np.float64)
+    if np.array_equal(w.astype(np.float32).astype(np.float64), w):
+        w = w.astype(np.float32)
     if n_vertices is None:
         n_vertices = int(max(src.max(initial=-1), dst.max(initial=-1)) + 1)
     order = np.lexsort((dst, src))  # stable: last key is primary

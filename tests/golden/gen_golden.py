@@ -335,8 +335,28 @@ def main():
                "p": 3.0, "q": 0.7, "seed": 2025, "walk_seed": None,
                "walks": reference_random_walk(m64, 2, 12, 3.0, 0.7, 2025)})
 
+    # weights whose fp32 rounding CHANGES walks: few decimal values (0.1, 0.3, 0.7 ...) put many
+    # probs[i] within an ulp of 1.0, so underfull / overfull (randomwalk.py:176) depends on the
+    # last bit of the weight.  The reference is run on both forms; the fixture keeps the fp64
+    # walks and records how many differ from the fp32-rounded run, so a test that narrows the
+    # weights on its way to the oracle fails (round-3 review: the *_fp64 cases above survive it).
+    rs = np.random.RandomState(777)
+    for name, p, q, seed in (("decimal_weights_fp64", 1.0, 1.0, 31), ("decimal_weights_pq_fp64", 0.5, 2.0, 32)):
+        dedges = []
+        for a in range(48):
+            for b in sorted(set(int(x) for x in rs.randint(0, 48, size=int(rs.randint(4, 14))))):
+                dedges.append((a, b, float(rs.choice([0.1, 0.2, 0.3, 0.6, 0.7, 1.1, 1.3]))))
+        w64_walks = reference_random_walk(dedges, 4, 14, p, q, seed)
+        w32_walks = reference_random_walk([(a, b, f32(w)) for a, b, w in dedges], 4, 14, p, q, seed)
+        assert len(w64_walks) == len(w32_walks)
+        differ = sum(1 for x, y in zip(w64_walks, w32_walks) if x["walk"] != y["walk"])
+        assert differ >= 8, (name, differ)
+        g4.append({"name": name, "edges": dedges, "num_walks": 4, "walk_length": 14,
+                   "p": p, "q": q, "seed": seed, "walk_seed": None, "walks": w64_walks,
+                   "walks_differing_with_fp32_weights": differ})
+
     # uniform stream itself
-    rng_kat = [{"seed": s, "key": k, "step": t, "u": list(uniform_bits(s, k, t))}
+    rng_kat =[{"seed": s, "key": k, "step": t, "u": list(uniform_bits(s, k, t))}
                for s in (0, 42, 2 ** 63 + 5) for k in (0, 1, 339, 10 ** 9 + 7, 2 ** 40) for t in (0, 1, 79)]
 
     def dump(name, obj):

@@ -236,6 +236,27 @@ def test_fit_streaming_deterministic_equals_the_oracle_end_to_end(oracle):
     assert np.array_equal(out.wv.vectors, s0) and np.abs(s1).max() > 0
 
 
+def test_fit_streaming_raises_the_references_zero_division():
+    """a visited row whose weights are all 0: generate_alias_tables divides by sum / n == 0
+    (randomwalk.py:172-173).  fugue.random_walk raises it; the streaming pipeline walks with
+    check=False (no per-batch host sync) and must still raise it, not train on truncated walks"""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+    from node2vec_amd.pipeline import fit_streaming
+
+    rng = np.random.default_rng(2)
+    src, dst = rng.integers(0, 200, 2400), rng.integers(0, 200, 2400)
+    w = rng.uniform(0.5, 2.0, 2400)
+    w[src == 17] = 0.0  # every out-edge of vertex 17 weighs nothing
+    g = DeviceGraph.from_edges(src, dst, w.astype(np.float32), n_vertices=200, device="cuda")
+    n2v = {"num_walks": 2, "walk_length": 8, "return_param": 0.5, "inout_param": 2.0}
+    w2v = {"min_count": 1, "iter": 1, "size": 32, "negative": 5, "window": 5}
+    with pytest.raises(ZeroDivisionError):
+        rw.walk(g, rw.start_vertices(g), 2, 8, 0.5, 2.0, 3)
+    with pytest.raises(ZeroDivisionError):
+        fit_streaming(g, dict(n2v), dict(w2v), random_seed=3, batch_vertices=64)
+
+
 def test_corpus_count_and_index_equal_torch():
     """n2v_corpus_count / n2v_corpus_index (the passes between K2 and K3 of fit_streaming) against
     the framework ops they replace: dropped rows, negative tokens, out-of-range ids"""

@@ -326,6 +326,21 @@ def test_device_corpus_token_survives_pandas(tmp_path):
     c, wc = frame(3)
     c["walk"] = [[0] * 6] * len(c)
     assert corpus.lookup(c) is None
+    # ONE replaced row (not among the sampled ones) is seen too -- every row must still
+    # be the list object random_walk() put there; STRICT compares every element
+    d, wd = frame(4)
+    assert corpus.lookup(d) is wd
+    d.at[97, "walk"] = list(d.at[97, "walk"])  # same contents, another object: conservative None
+    assert corpus.lookup(d) is None
+    e, we = frame(5)
+    e.at[123, "walk"][2] += 1  # an edit inside an original list object
+    corpus.STRICT = True
+    try:
+        assert corpus.lookup(e) is None
+        f, wf = frame(6)
+        assert corpus.lookup(f) is wf
+    finally:
+        corpus.STRICT = False
     n_before = len(corpus._registry)
     del a, both, merged
     gc.collect()

@@ -118,6 +118,9 @@ def test_next_step_reference_kat(oracle):
 
 def _run_walk_case(oracle, c, n_threads=1):
     rowptr, col, w = oracle.csr_from_edges(c["edges"])
+    if c["name"].endswith("_fp64"):  # weights that are not fp32 values must reach the oracle as fp64
+        assert w.dtype == np.float64
+        assert w.tolist() == [e[2] for e in sorted(c["edges"], key=lambda e: (e[0], e[1]))]
     nv = len(rowptr) - 1
     start = list(range(nv)) if c["walk_seed"] is None else sorted(set(c["walk_seed"]))
     walks, valid = oracle.random_walk(rowptr, col, w, start, c["num_walks"], c["walk_length"],
@@ -143,6 +146,23 @@ def test_whole_walks_match_reference(oracle, threads):
             assert got[k] == want[k], (c["name"], k)
             assert len(got[k]) == c["walk_length"] + 1
             assert got[k][0] == k[0]  # to_path: src = path[0]
+
+
+def test_fp64_weights_are_not_narrowed(oracle):
+    """The decimal_weights_* fixtures were generated so that rounding the weights to fp32 changes
+    walks IN THE REFERENCE (gen_golden.py records how many); the oracle fed fp32-rounded weights
+    must therefore disagree with the fixture, and fed the fp64 weights must not."""
+    cases = [c for c in load_golden("g4_walks.json") if "walks_differing_with_fp32_weights" in c]
+    assert len(cases) == 2
+    for c in cases:
+        assert c["walks_differing_with_fp32_weights"] >= 8
+        want = {(w["start"], w["ordinal"]): w["walk"] for w in c["walks"]}
+        assert _run_walk_case(oracle, c) == want
+        narrowed = dict(c, name="narrowed",
+                        edges=[(a, b, float(np.float32(w))) for a, b, w in c["edges"]])
+        got32 = _run_walk_case(oracle, narrowed)
+        assert got32.keys() == want.keys()
+        assert sum(got32[k] != want[k] for k in want) == c["walks_differing_with_fp32_weights"]
 
 
 def test_sink_semantics(oracle):

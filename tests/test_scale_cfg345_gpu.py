@@ -65,6 +65,33 @@ def _check_config(oracle, g, start, p, q, seed, n_oracle, n_hubs, oracle_len):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+# one (p, q) per code instance of the all-tables kernel (n2v_walk_wedge.hip): <0> "other" alone
+# underfull, <1> the return run shares its stack, <2> not dyadic, <3> "other" alone overfull
+INSTANCE_PQ = ((0.5, 2.0), (4.0, 2.0), (3.0, 0.7), (4.0, 0.25))
+
+
+def full_batch_differential(g, start, pqs=INSTANCE_PQ, seed=42):
+    """A WHOLE bench batch (start x 10 x 80 steps) through three independent implementations of
+    the reference's per-step rebuild (randomwalk.py:182-189, :193-232) -- the all-tables kernel
+    with its closed forms (default), the class-count / wave-per-walker kernels that replay the
+    pairing (use_wedge_kernel=False), and the wave-per-walker kernel that classifies every row
+    itself (no per-edge table at all) -- must give the same bits.  The replay kernels are what the
+    oracle tests pin on small graphs; this extends that to every step of a full-size batch."""
+    from node2vec_amd import randomwalk as rw
+
+    steps = 0
+    for p, q in pqs:
+        walks, valid = rw.walk(g, start, W, L, p, q, seed)
+        replay, rvalid = rw.walk(g, start, W, L, p, q, seed, use_wedge_kernel=False)
+        assert torch.equal(valid, rvalid) and torch.equal(walks, replay), (p, q, "tables, replayed")
+        del replay, rvalid
+        plain, pvalid = rw.walk(g, start, W, L, p, q, seed, use_wedges=False, use_edge_classes=False)
+        assert torch.equal(valid, pvalid) and torch.equal(walks, plain), (p, q, "no tables")
+        steps += int(valid.sum()) * L
+        del plain, pvalid, walks, valid
+    return steps
+
+
 def test_cfg3_power_law_10m_trimmed(oracle):
     """cfg 3: Chung-Lu gamma = 2.1, 10 M vertices, 10^8 undirected draws symmetrised (~1.9 x 10^8
     directed edges), out-degree trimmed at 10 000 (trim_hotspot_vertices); p = q = 1 and (0.5, 2)"""
@@ -87,6 +114,8 @@ def test_cfg3_power_law_10m_trimmed(oracle):
     # (4, 2) and (0.25, 0.5): the return slot shares a stack with "other" (rows of 10^4 slots)
     for p, q in ((1.0, 1.0), (0.5, 2.0), (4.0, 0.25), (4.0, 2.0), (0.25, 0.5)):
         _check_config(oracle, g, start, p, q, 42, n_oracle=600, n_hubs=64, oracle_len=40)
+    # the bench batch (2^20 start vertices x 10 x 80 = 8.4 x 10^8 steps) per kernel instance
+    assert full_batch_differential(g, start_all[: 1 << 20].contiguous()) == 4 * (1 << 20) * W * L
 
 
 def test_cfg4_power_law_100m(oracle):
@@ -106,6 +135,8 @@ def test_cfg4_power_law_100m(oracle):
     start = start_all[pick.to("cuda")].contiguous()
     for p, q in ((1.0, 1.0), (0.5, 2.0), (0.25, 0.5)):
         _check_config(oracle, g, start, p, q, 42, n_oracle=600, n_hubs=64, oracle_len=40)
+    # bench.py's batch: the first 2^20 start vertices x 10 x 80, per kernel instance
+    assert full_batch_differential(g, start_all[: 1 << 20].contiguous()) == 4 * (1 << 20) * W * L
 
 
 def test_cfg5_bipartite_50m_hubs_of_20k(oracle):
@@ -128,3 +159,6 @@ def test_cfg5_bipartite_50m_hubs_of_20k(oracle):
     walks, valid = rw.walk(g, start[:4096].contiguous(), W, L, 4.0, 0.25, 42)
     side = walks[valid].long() < n_hubs
     assert bool((side[:, :-1] != side[:, 1:]).all())
+    del walks, valid, side
+    # a full batch from the hub side and the first leaves (hub rows of 20 000 at every other step)
+    assert full_batch_differential(g, start_all[: 1 << 20].contiguous()) == 4 * (1 << 20) * W * L

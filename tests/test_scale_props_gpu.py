@@ -50,6 +50,20 @@ def test_rmat18_exact_properties_and_oracle_sample(oracle, pq):
 
 
 @pytest.mark.parametrize("pq", [(0.5, 2.0), (4.0, 0.25), (3.0, 0.7), (1.0, 1.0)])
+def test_cfg2_every_walker_three_implementations():
+    """BASELINE cfg 2, EVERY start vertex x 10 x 80: the closed-form kernel, the replay kernels and
+    the table-free kernel give the same walks for one (p, q) per kernel instance"""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd import synthetic
+    from test_scale_cfg345_gpu import full_batch_differential
+
+    g = synthetic.rmat(20, 5_000_000, device="cuda")
+    start = rw.start_vertices(g)
+    assert start.numel() > 500_000
+    assert full_batch_differential(g, start) == 4 * start.numel() * 10 * 80
+
+
+@pytest.mark.parametrize("pq", [(0.5, 2.0), (4.0, 0.25), (3.0, 0.7), (1.0, 1.0)])
 def test_cfg2_full_size_properties_and_oracle_sample(oracle, pq):
     """BASELINE cfg 2 at its full size (R-MAT scale 20, ~9.7 M directed edges, W = 10, L = 80):
     the bench batch is walked once whole and once in 7 uneven shards -- same walks (a checksum of

@@ -54,7 +54,8 @@ def test_exact_walks_equal_reference_golden():
         assert got.keys() == want.keys(), c["name"]
         for k in want:
             assert got[k] == want[k], (c["name"], k)
-    assert {"karate_weighted_fp64", "multigraph_fp64"} <= names
+    assert {"karate_weighted_fp64", "multigraph_fp64", "decimal_weights_fp64",
+            "decimal_weights_pq_fp64"} <= names
 
 
 def _random_graph(rng, nv, ne, weighted, hubs=0, sinks=True):
