@@ -650,7 +650,9 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist)
         res["batched"] = bench_sgns_batched(args, torch, dist, model, idx, rows, rank, barrier,
                                             use_dist, dev, dim)
     if use_dist:  # the exchange step of the multi-GPU path, timed once (blocking, bf16 deltas)
-        sync = sgns.DeltaSync(model, wire="bf16")
+        # (at N = 1 under torch.distributed.run the same calls run on a group of one rank: the
+        # RCCL path is rehearsed, the mean is of one replica)
+        sync = sgns.DeltaSync(model, wire="bf16", rehearse=True)
         barrier()
         t0 = time.perf_counter()
         sync.sync(blocking=True)
@@ -659,6 +661,10 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist)
         step_s = 1e-3 * res["ms_per_step"]
         every = max(1, -(-int(1e6 * dt * 0.9) // max(1, int(1e6 * 0.1 * step_s))))
         res["exchange"] = {"world": dist.get_world_size(), "backend": "nccl (RCCL)",
+                           "path": "n2v_delta_pack -> all_to_all (bytes) -> n2v_delta_reduce (fp32, rank "
+                                   "order) -> all_gather (bytes) -> n2v_delta_apply",
+                           "blocks_exchanged": sync.exchanged_blocks,
+                           "tensors_on_device": bool(sync.on_gpu),
                            "delta_allreduce_s": dt, "wire_dtype": sync.wire_dtype_name,
                            "wire_bytes_per_rank": sync.wire_bytes,
                            "share_of_step_time_if_every_launch": dt / (dt + step_s),

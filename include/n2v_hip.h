@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define N2V_ABI_VERSION 7
+#define N2V_ABI_VERSION 8
 
 #define N2V_OK 0
 #define N2V_EINVAL (-1)  /* maps to ValueError (randomwalk.py:212-217)      */
@@ -104,7 +104,8 @@ typedef struct n2v_graph {
   const uint64_t *wedge_off;    /* [n_edges] or NULL: see n2v_wedge_build */
   const void *wedge_pos;        /* uint16 / uint32 positions, or NULL */
   int32_t wedge_wide;           /* 0: wedge_pos is uint16 (every degree < 65536), 1: uint32 */
-  int32_t reserved;             /* 0 (bit 0 set: do not use the all-tables kernel; diagnostics) */
+  int32_t reserved;             /* 0 (diagnostics: bit 0 set = do not use the all-tables kernel,
+                                   bit 1 set = do not use wedge_slots) */
   const uint64_t *hops8;        /* the 8-byte hop table (n2v_hops8_build) or NULL */
   int32_t hop8_col_bits;        /* field widths of a hops8 entry, see n2v_hops8_build */
   int32_t hop8_row_bits;
@@ -112,6 +113,7 @@ typedef struct n2v_graph {
                                    padded (hop8_align_shift > 0), else NULL (= rowptr) */
   int32_t hop8_align_shift;     /* rows of the hops8 table start at multiples of 2^shift entries */
   int32_t reserved2;            /* 0 */
+  const uint16_t *wedge_slots;  /* [n_edges][16] or NULL: see n2v_wedge_slots_build */
 } n2v_graph;
 
 /* edge_classes[e] for e = (s -> v): bits 0..23 = number of entries x of N(v) with
@@ -197,6 +199,20 @@ int n2v_hops8_build(const n2v_graph *g, int32_t col_bits, int32_t row_bits, int3
 int n2v_wedge_build(const n2v_graph *g, const uint64_t *list_off, uint64_t *wedge_off_out,
                     void *wedge_pos_out, int32_t wide, uint32_t *status, void *stream);
 
+/* Wedge slots: the wedge table laid out so that a biased exact step finds the list of the edge it
+ * came along with ONE gather at a place it knows a step ahead (slot e = edge index), requested
+ * together with the hop entry, instead of wedge_off[e] and then the list behind that offset (two
+ * dependent gathers; random 64-byte sectors per step are what bounds the walk kernels).  32 bytes
+ * = 16 halfwords per edge:
+ *   [0] return position (wedge_off[e] >> 40)   [1] number of list entries below the return position
+ *   n_shared <= 14:  [2 .. 2 + n_shared) the list itself
+ *   n_shared  > 14:  [4 .. 8) the list's offset in wedge_pos as 64 bits, [8 .. 16) eight pivots
+ *                    list[((k + 1) * n_shared) / 9], k = 0 .. 7 (the search enters the right ninth)
+ * 16-bit positions only (wedge_wide == 0); g->edge_classes, g->wedge_off and g->wedge_pos must be
+ * set.  At cfg 4 half of the steps need a list and four fifths of those lists are short.
+ * slots_out: [n_edges * 16] uint16. */
+int n2v_wedge_slots_build(const n2v_graph *g, uint16_t *slots_out, void *stream);
+
 /* Search index for N2V_WALK_FAST: the last id of every aligned block of 32 entries of
  * `col` (one 128-byte line).  Inside a sorted row the block ends ascend, so a
  * membership query is a binary search over (degree / 32) pivots followed by one over a
@@ -228,6 +244,24 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
              double inout_param, uint64_t seed, int32_t mode,
              int32_t *walks_out, uint8_t *valid_out, uint32_t *status,
              void *stream);
+
+/* n2v_walk with a workspace lent by the caller (the library never allocates).  Exact biased walks
+ * on a unit-weight graph that carries the hop and wedge tables, dyadic return_param / inout_param,
+ * then run as passes over 32-byte walker records kept in the workspace: launches that hold the
+ * quick exits and closed forms of the pairing loop (randomwalk.py:182-189) only, each followed by
+ * a launch that replays the steps whose closed form declined -- same walks, bit for bit, as
+ * n2v_walk, faster (csrc/n2v_walk_wedge2.hip).  n2v_walk_workspace_bytes says how many bytes the
+ * call can use (0: this graph / mode / (p, q) has no use for one); workspace == NULL, or fewer
+ * bytes than that, is n2v_walk.  The workspace must be 16-byte aligned; its contents mean nothing
+ * before or after the call, and it may be reused by the next call on the same stream. */
+int64_t n2v_walk_workspace_bytes(const n2v_graph *g, int64_t n_start, int32_t num_walks,
+                                 int32_t walk_length, double return_param, double inout_param,
+                                 int32_t mode);
+int n2v_walk_ws(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
+                int32_t num_walks, int32_t walk_length, double return_param,
+                double inout_param, uint64_t seed, int32_t mode,
+                int32_t *walks_out, uint8_t *valid_out, uint32_t *status,
+                void *workspace, int64_t workspace_bytes, void *stream);
 
 /* The reference's transformer-level protocol on MATERIALISED tables, one partition (a batch of
  * walker rows) per call.  n2v_walk never builds the table of a step; next_step_random_walk
@@ -378,6 +412,14 @@ int n2v_delta_pack(const float *cur, const uint16_t *ref_bf16, int64_t n, float 
                    void *wire_out, int32_t wire_dtype, void *stream);
 int n2v_delta_apply(float *cur, uint16_t *ref_bf16, const float *before, const void *wire_sum,
                     int32_t wire_dtype, int32_t world, int64_t n, void *stream);
+/* The sum itself, when the caller moves bytes instead of calling an all-reduce (so that the result
+ * does not depend on the collective library's reduction order or accumulator type): `parts` holds
+ * `world` contributions of m elements each, rank after rank (what an all-to-all of the ranks' wire
+ * buffers delivers for this rank's shard); out[i] = parts[0][i] + parts[1][i] + ... in fp32, in
+ * rank order, stored in the wire type (bf16: ONE rounding of the fp32 sum).  An all-gather of the
+ * shards then gives every rank the same wire_sum for n2v_delta_apply. */
+int n2v_delta_reduce(const void *parts, int32_t wire_dtype, int32_t world, int64_t m, void *out,
+                     void *stream);
 
 /* The two elementwise passes between K2 and K3 when the corpus is streamed batch by batch
  * (node2vec_amd/pipeline.py; the reference materialises the walks as strings and lets gensim's

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libn2v_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 OK, EINVAL, ELAUNCH, ENOGPU = 0, -1, -2, -3
 ST_ZERODIV, ST_RANGE = 1, 2
@@ -24,7 +24,8 @@ SYMBOLS = ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alia
            "n2v_edge_bias", "n2v_alias_draw", "n2v_hops_build", "n2v_cum_index_build", "n2v_walk_uniforms", "n2v_wedge_build",
            "n2v_mem_probe", "n2v_corpus_count", "n2v_corpus_index", "n2v_hops8_build",
            "n2v_partition_step", "n2v_gather_rows", "n2v_gather_wedges",
-           "n2v_partition_route", "n2v_partition_group")
+           "n2v_partition_route", "n2v_partition_group", "n2v_walk_ws", "n2v_walk_workspace_bytes",
+           "n2v_delta_reduce", "n2v_wedge_slots_build")
 
 
 class Graph(C.Structure):
@@ -36,7 +37,8 @@ class Graph(C.Structure):
                 ("wedge_off", C.c_void_p), ("wedge_pos", C.c_void_p), ("wedge_wide", C.c_int32),
                 ("reserved", C.c_int32), ("hops8", C.c_void_p), ("hop8_col_bits", C.c_int32),
                 ("hop8_row_bits", C.c_int32), ("hop8_rowptr", C.c_void_p),
-                ("hop8_align_shift", C.c_int32), ("reserved2", C.c_int32)]
+                ("hop8_align_shift", C.c_int32), ("reserved2", C.c_int32),
+                ("wedge_slots", C.c_void_p)]
 
 
 class SgnsParams(C.Structure):
@@ -82,6 +84,8 @@ def load():
     L.n2v_wedge_build.restype = C.c_int
     L.n2v_wedge_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                   C.c_void_p, C.c_void_p]
+    L.n2v_wedge_slots_build.restype = C.c_int
+    L.n2v_wedge_slots_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p]
     L.n2v_hops_build.restype = C.c_int
     L.n2v_hops_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p]
     L.n2v_hops8_build.restype = C.c_int
@@ -93,6 +97,11 @@ def load():
     L.n2v_walk.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                            C.c_double, C.c_double, C.c_uint64, C.c_int32, C.c_void_p,
                            C.c_void_p, C.c_void_p, C.c_void_p]
+    L.n2v_walk_ws.restype = C.c_int
+    L.n2v_walk_ws.argtypes = L.n2v_walk.argtypes[:-1] + [C.c_void_p, C.c_int64, C.c_void_p]
+    L.n2v_walk_workspace_bytes.restype = C.c_int64
+    L.n2v_walk_workspace_bytes.argtypes = [C.POINTER(Graph), C.c_int64, C.c_int32, C.c_int32,
+                                           C.c_double, C.c_double, C.c_int32]
     L.n2v_trim_mark.restype = C.c_int
     L.n2v_trim_mark.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p,
                                 C.c_void_p]
@@ -105,6 +114,8 @@ def load():
     L.n2v_delta_pack.restype = C.c_int
     L.n2v_delta_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_int32, C.c_void_p]
+    L.n2v_delta_reduce.restype = C.c_int
+    L.n2v_delta_reduce.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
     L.n2v_delta_apply.restype = C.c_int
     L.n2v_delta_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                   C.c_int32, C.c_int64, C.c_void_p]

@@ -9,7 +9,10 @@ int n2v_walk_exact_launch(const n2v_graph *g, const int32_t *start_ids, int64_t 
 int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
                             int32_t num_walks, int32_t walk_length, double p, double q,
                             uint64_t seed, int32_t *walks_out, uint8_t *valid_out,
-                            uint32_t *status, void *stream);
+                            uint32_t *status, void *workspace, int64_t workspace_bytes,
+                            void *stream);
+int64_t n2v_walk_exact_unit_workspace(const n2v_graph *g, int64_t total, int32_t walk_length,
+                                      double p, double q);
 int n2v_walk_uniform_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
                          int32_t num_walks, int32_t walk_length, double p, double q,
                          uint64_t seed, int32_t *walks_out, uint8_t *valid_out,
@@ -37,10 +40,27 @@ int n2v_device_count(void) {
   return n;
 }
 
+int64_t n2v_walk_workspace_bytes(const n2v_graph *g, int64_t n_start, int32_t num_walks,
+                                 int32_t walk_length, double return_param, double inout_param,
+                                 int32_t mode) {
+  if (!g || n_start <= 0 || num_walks <= 0 || walk_length < 0 || mode != N2V_WALK_EXACT) return 0;
+  if (return_param == 0.0 || inout_param == 0.0) return 0;
+  return n2v_walk_exact_unit_workspace(g, n_start * (int64_t)num_walks, walk_length, return_param,
+                                       inout_param);
+}
+
 int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start, int32_t num_walks,
              int32_t walk_length, double return_param, double inout_param, uint64_t seed,
              int32_t mode, int32_t *walks_out, uint8_t *valid_out, uint32_t *status,
              void *stream) {
+  return n2v_walk_ws(g, start_ids, n_start, num_walks, walk_length, return_param, inout_param, seed,
+                     mode, walks_out, valid_out, status, nullptr, 0, stream);
+}
+
+int n2v_walk_ws(const n2v_graph *g, const int32_t *start_ids, int64_t n_start, int32_t num_walks,
+                int32_t walk_length, double return_param, double inout_param, uint64_t seed,
+                int32_t mode, int32_t *walks_out, uint8_t *valid_out, uint32_t *status,
+                void *workspace, int64_t workspace_bytes, void *stream) {
   if (!g || !g->rowptr || !g->col || n_start < 0 || num_walks < 0 || walk_length < 0)
     return N2V_EINVAL;
   // buffers are only required when there is at least one walker
@@ -59,7 +79,7 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start, int3
     if (ru != 0) return ru < 0 ? ru : N2V_OK;
     const int rc = n2v_walk_exact_unit_try(g, start_ids, n_start, num_walks, walk_length,
                                            return_param, inout_param, seed, walks_out,
-                                           valid_out, status, stream);
+                                           valid_out, status, workspace, workspace_bytes, stream);
     if (rc != 0) return rc < 0 ? rc : N2V_OK;
     // p == q == 1 (the reference's defaults, constants.py:22,26): w/p == w/q == w exactly, so
     // the table generate_edge_alias_tables builds at (s, v) IS generate_alias_tables(row v) --

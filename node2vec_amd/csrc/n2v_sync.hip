@@ -77,6 +77,27 @@ __global__ __launch_bounds__(256) void delta_apply_kernel(float *__restrict__ cu
   }
 }
 
+// out[i] = sum over ranks of parts[r * m + i], accumulated in fp32 in rank order
+template <bool kBf16>
+__global__ __launch_bounds__(256) void delta_reduce_kernel(const void *__restrict__ parts, int world,
+                                                          int64_t m, void *__restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+    float acc;
+    if constexpr (kBf16) {
+      const uint16_t *p = reinterpret_cast<const uint16_t *>(parts);
+      acc = bf16_bits_to_float(p[i]);
+      for (int r = 1; r < world; ++r) acc = acc + bf16_bits_to_float(p[(int64_t)r * m + i]);
+      reinterpret_cast<uint16_t *>(out)[i] = float_to_bf16_bits(acc);
+    } else {
+      const float *p = reinterpret_cast<const float *>(parts);
+      acc = p[i];
+      for (int r = 1; r < world; ++r) acc = acc + p[(int64_t)r * m + i];
+      reinterpret_cast<float *>(out)[i] = acc;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void ref_init_kernel(const float *__restrict__ cur, int64_t n,
                                                       uint16_t *__restrict__ ref) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -145,6 +166,26 @@ extern "C" int n2v_delta_apply(float *cur, uint16_t *ref_bf16, const float *befo
     const int64_t blocks = n2v::stream_blocks(n, (const void *)n2v::delta_apply_kernel<false>);
     hipLaunchKernelGGL(n2v::delta_apply_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st,
                        cur, ref_bf16, before, wire_sum, inv, n);
+  }
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}
+
+extern "C" int n2v_delta_reduce(const void *parts, int32_t wire_dtype, int32_t world, int64_t m,
+                                void *out, void *stream) {
+  if (m < 0 || world < 1 || (wire_dtype != N2V_WIRE_F32 && wire_dtype != N2V_WIRE_BF16))
+    return N2V_EINVAL;
+  if (m == 0) return N2V_OK;
+  if (!parts || !out) return N2V_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (wire_dtype == N2V_WIRE_BF16) {
+    const int64_t blocks = n2v::stream_blocks(m, (const void *)n2v::delta_reduce_kernel<true>);
+    hipLaunchKernelGGL(n2v::delta_reduce_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st,
+                       parts, (int)world, m, out);
+  } else {
+    const int64_t blocks = n2v::stream_blocks(m, (const void *)n2v::delta_reduce_kernel<false>);
+    hipLaunchKernelGGL(n2v::delta_reduce_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st,
+                       parts, (int)world, m, out);
   }
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;

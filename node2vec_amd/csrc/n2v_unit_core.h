@@ -1265,6 +1265,15 @@ int n2v_walk_wedge_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_s
                        const n2v::UnitConsts &K, uint64_t seed, int32_t *walks_out,
                        uint8_t *valid_out, uint32_t *status, void *stream);
 
+// the same walk in passes over a caller-lent workspace (n2v_walk_wedge2.hip): closed forms in the
+// main launches, declined steps replayed out of line.  1 = enqueued, 0 = does not apply
+int64_t n2v_walk_wedge2_workspace(int64_t total);
+int n2v_walk_wedge2_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
+                        int32_t num_walks, int32_t walk_length, double p, double q,
+                        const n2v::UnitConsts &K, uint64_t seed, int32_t *walks_out,
+                        uint8_t *valid_out, uint32_t *status, void *workspace,
+                        int64_t workspace_bytes, int32_t rounds, void *stream);
+
 // the wedge-list instance of n2v_partition_step (n2v_walk_wedge.hip): 1 = launched, < 0 on error
 int n2v_partition_step_wedge_launch(const int64_t *rowptr, const int32_t *col, int64_t lo,
                                     int64_t n_local, const int64_t *head, int32_t head_cols,

@@ -1693,11 +1693,23 @@ static bool unit_consts(double p, double q, n2v::UnitConsts &K, bool &dyadic) {
 
 // returns 1 when the unit-weight kernel applies (and was launched), 0 when the caller
 // must use the generic kernel, < 0 on error
+// workspace n2v_walk_ws can use for (g, p, q): the record lists of n2v_walk_wedge2.hip, 0 = none
+extern "C" int64_t n2v_walk_exact_unit_workspace(const n2v_graph *g, int64_t total,
+                                                 int32_t walk_length, double p, double q) {
+  if (g->w != nullptr || g->w64 != nullptr || (p == 1.0 && q == 1.0)) return 0;
+  if (!g->hops || !g->wedge_off || !g->wedge_pos || (g->reserved & 1)) return 0;
+  n2v::UnitConsts K;
+  bool dyadic = false;
+  if (!unit_consts(p, q, K, dyadic) || !dyadic) return 0;
+  if (total <= 0 || total >= 0xffffff00ll || walk_length >= 0xfffff0) return 0;
+  return n2v_walk_wedge2_workspace(total);
+}
+
 extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_ids,
                                        int64_t n_start, int32_t num_walks,
                                        int32_t walk_length, double p, double q, uint64_t seed,
                                        int32_t *walks_out, uint8_t *valid_out, uint32_t *status,
-                                       void *stream) {
+                                       void *workspace, int64_t workspace_bytes, void *stream) {
   if (g->w != nullptr || g->w64 != nullptr) return 0;
   n2v::UnitConsts K;
   bool dyadic = false;
@@ -1721,6 +1733,16 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
   // (values that are not dyadic: the same kernel adds the row up in the reference's order and
   // replays every pairing run by run)
   if (!(p == 1.0 && q == 1.0) && !(g->reserved & 1)) {
+    // every per-edge table is at hand and the caller lent a workspace: closed forms in the main
+    // launches, declined steps replayed out of line (n2v_walk_wedge2.hip)
+    if (workspace) {
+      int rounds = 4;
+      if (const char *e = getenv("N2V_WEDGE2_ROUNDS")) rounds = atoi(e);
+      const int r2 = n2v_walk_wedge2_try(g, start_ids, n_start, num_walks, walk_length, p, q, K, seed,
+                                         walks_out, valid_out, status, workspace, workspace_bytes,
+                                         rounds, stream);
+      if (r2 != 0) return r2;
+    }
     // every per-edge table is at hand: the kernel in which no step needs the wave
     const int rw = n2v_walk_wedge_try(g, start_ids, n_start, num_walks, walk_length, p, q, K, seed,
                                       walks_out, valid_out, status, stream);

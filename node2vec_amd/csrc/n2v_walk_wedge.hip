@@ -21,7 +21,7 @@
 // 324-byte-pitch row costs a 32-byte write request each: 12x write amplification measured on the
 // lanes kernel).  Any dyadic p, q (the row sum is then an exact integer combination of the class
 // counts); graphs without the tables keep the kernels of n2v_walk_unit.hip.
-#include "n2v_unit_core.h"
+#include "n2v_wedge_step.h"
 
 namespace n2v {
 
@@ -29,55 +29,6 @@ constexpr int kWedgeThreads = 256;
 #ifndef N2V_WEDGE_WAVES
 #define N2V_WEDGE_WAVES 6
 #endif
-
-// the pairing loop for slot `pick` by one lane: closed form by arrangement `arr` (see the kernel),
-// else -- fp64 rounding decides the draw: a tie or a thin margin -- the replays.
-// kMode 0 / 3: the (p, q) that leave "other" alone on its stack on ordinary rows, underfull (0) or
-// overfull (3: the mirror closed form then runs at every step and finds the next slot without a
-// search -- code instance 0 does without: its registers are the flagship configuration's); 1: those for which
-// the return run shares a stack with it (arrangements 3-5: compiled out of instance 0, whose
-// registers they would cost); 2: 1/p or 1/q not dyadic -- no exact integer arithmetic, so no
-// closed form: every pairing is replayed run by run in fp64.
-template <typename P, int kMode>
-__device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, const UnitConsts &K,
-                                           double avg, int nR, int rpos, int nM, const P *list,
-                                           bool isR, bool isM, int lo_pick, P *stage, int lane) {
-  constexpr bool kShared = kMode == 1 || kMode == 2;
-  int res = -1;
-  if constexpr (kMode != 2) {
-    if (arr == 1)
-      res = lane_case_a_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
-    else if (arr == 2)
-      res = lane_case_b_jump<P, kMode != 0>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
-  }
-  if constexpr (kMode == 1) {
-    if (arr == 3)
-      res = lane_case_a2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
-    else if (arr == 4)
-      res = lane_case_b2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
-    else if (arr == 5)
-      res = lane_case_a3_jump<P>(n, pick, r2, K, nR, rpos, nM, isR, isM, lo_pick);
-  }
-#ifdef N2V_ABLATE_W
-  if (N2V_ABLATE_W == 1 && arr == 2) res = pick;  // timing-only: no closed form at all
-#endif
-  if (res >= 0) return res;
-  const double vR = K.bR / avg, vM = K.bM / avg, vO = K.bO / avg;
-  if (n <= 64) {  // a short row: the two stacks as bit masks
-    uint64_t Rm = 0ull;
-    if (nR) Rm = ((nR >= 64) ? ~0ull : ((1ull << nR) - 1ull)) << rpos;
-    const uint64_t Mm = wedge_mask_t<P>(list, 0, nM);
-    return lane_pairing(n, Rm, Mm, pick, r2, vR, vM, vO);
-  }
-  if (arr == 1) return lane_case_a<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM, stage, lane);
-  if (arr == 2) return lane_case_b<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM);
-  if constexpr (kShared) {
-    if (arr == 3) return lane_case_a2<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM, stage, lane);
-    if (arr == 4) return lane_case_b2<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM);
-    if (arr == 5) return lane_case_a3<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM);
-  }
-  return lane_pairing_list<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list);
-}
 
 template <int kMode>
 __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wedge_kernel(
@@ -305,6 +256,118 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
 }
 
 
+// ---- the same walk with the per-edge wedge SLOTS (n2v_wedge_slots_build): one lane per walker,
+// replays inline, the step itself in wedge_step (n2v_wedge_step.h).  The slot of the edge walked
+// is requested together with the hop entry and holds the return position and a short list itself,
+// so a step that needs its list is two INDEPENDENT gathers instead of hop + offset -> list.
+// kMode 0, 1, 3: dyadic p, q (values that are not keep the kernel above); 16-bit positions.
+template <int kMode>
+__global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wedge_slots_kernel(
+    n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
+    int32_t walk_length, double q, UnitConsts K, uint64_t seed, int32_t *__restrict__ walks_out,
+    uint8_t *__restrict__ valid_out, uint32_t *__restrict__ status) {
+  __shared__ int32_t path_tile[16][kWedgeThreads];             // word k of thread t at [k][t]
+  __shared__ uint32_t stage_all[kWedgeThreads / 64][16 * 32];  // 2 KB per wave (lane_case_a)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  uint32_t *stage = stage_all[tid >> 6];
+  const int64_t total = n_start * (int64_t)num_walks;
+  const int L1 = walk_length + 1;
+  const StepFlags F = step_flags(g, K, q);
+  const bool base_aligned = (reinterpret_cast<uintptr_t>(walks_out) & 63u) == 0;
+
+  int64_t w0 = 0;  // absolute word index of path position 0 of the current walker
+  int lo = 0;      // first word of the current sector that belongs to this row
+  auto flush = [&](int64_t a) {  // words [sector(a) + lo, a] are complete: store them
+    const int k = (int)(a & 15);
+    int32_t *sec = walks_out + (a & ~(int64_t)15);
+    if (lo == 0 && k == 15 && base_aligned) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        reinterpret_cast<int4 *>(sec)[u] =
+            make_int4(path_tile[4 * u][tid], path_tile[4 * u + 1][tid], path_tile[4 * u + 2][tid],
+                      path_tile[4 * u + 3][tid]);
+    } else {
+      for (int kk = lo; kk <= k; ++kk) sec[kk] = path_tile[kk][tid];
+    }
+    lo = 0;
+  };
+  auto emit = [&](int pos, int32_t x) {  // path position pos of the current walker
+    const int64_t a = w0 + pos;
+    path_tile[(int)(a & 15)][tid] = x;
+    if ((a & 15) == 15 || pos == walk_length) flush(a);
+  };
+
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&status[1], 64u);
+    const int64_t base = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (base >= total) break;
+    const int64_t r = base + lane;
+    const bool have = r < total;
+    int32_t start = -1;
+    uint64_t h0 = 0;
+    bool alive = have;
+    if (have) {
+      start = start_ids[r / num_walks];
+      const int32_t ordinal = (int32_t)(r % num_walks) + 1;
+      h0 = walker_stream(seed, (uint64_t)start * (uint64_t)num_walks + (uint64_t)(ordinal - 1));
+      if (start < 0 || (int64_t)start >= g.n_vertices) {
+        atomicOr(status, N2V_ST_RANGE);
+        alive = false;
+      }
+    }
+    int64_t vb = 0, e_prev = 0;
+    uint32_t ec_prev = 0;  // class counts of the edge (s -> v), from the hop that walked it
+    int n = 0;
+    if (alive) {
+      vb = g.rowptr[start];
+      n = (int)(g.rowptr[start + 1] - vb);
+      alive = n > 0;  // fugue.py:132
+    }
+    w0 = r * (int64_t)L1;
+    lo = (int)(w0 & 15);
+    if (have) {
+      emit(0, alive ? start : -1);
+      if (!alive)  // no such vertex / no out-edges: the row is all -1, like the other kernels
+        for (int tt = 1; tt < L1; ++tt) emit(tt, -1);
+    }
+    int32_t s = -1, v = start;
+    bool walking = alive;
+    for (int step = 0; step < walk_length; ++step) {
+      if (ballot64(walking) == 0ull) break;
+      if (!walking) continue;
+      const uint64_t bits = step_bits(h0, (uint32_t)step);
+      const uint32_t u1 = (uint32_t)(bits >> 32), u2 = (uint32_t)bits;
+      n2v_hop h;
+      int idx;
+      if (s >= 0) {
+        idx = wedge_step<kMode, false, true>(g, K, F, u1, u2, s, vb, n, e_prev, ec_prev, h, stage, lane,
+                                             status);
+      } else {  // first step: generate_alias_tables of unit weights is the uniform draw (:320-321)
+        idx = pick_index(u1, n);
+        h = load_hop(g.hops + vb + idx);
+      }
+      const int32_t x = h.col;
+      emit(step + 1, x);
+      e_prev = vb + idx;
+      ec_prev = h.classes;
+      s = v;
+      v = x;
+      if (step + 1 < walk_length) {
+        vb = hop_row(h);
+        n = hop_deg(h);
+        if (n == 0) {  // fugue.py:147: the walker vanishes at a sink, the rest of its row is -1
+          walking = false;
+          alive = false;
+          for (int tt = step + 2; tt < L1; ++tt) emit(tt, -1);
+        }
+      }
+    }
+    if (have) valid_out[r] = alive ? 1 : 0;
+  }
+}
+
 // ---- one step of the walkers resident on one part of a partitioned graph, wedge lists travelling
 // (n2v_partition_step with N2V_SRC_WEDGES, n2v_walk.hip).  A walker that leaves along edge e brings
 // the class counts of e, the return position and the wedge list of e -- exactly what the kernel
@@ -439,6 +502,20 @@ int n2v_walk_wedge_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_s
   if (total == 0) return 1;
   // the return run shares a stack with "other" on ordinary rows: q > 1 with p > q, q < 1 with p < q
   const bool alone_under = K.bO <= 1.0 && K.bR >= K.bO, alone_over = K.bO >= 1.0 && K.bR <= K.bO;
+  if (K.dyadic && g->wedge_slots && !g->wedge_wide && !(g->reserved & 2)) {
+    // the wedge slots are at hand: the list of a step arrives with its hop entry
+    auto sk = alone_under ? n2v::walk_exact_wedge_slots_kernel<0>
+              : alone_over ? n2v::walk_exact_wedge_slots_kernel<3>
+                           : n2v::walk_exact_wedge_slots_kernel<1>;
+    int64_t sblocks = (total + n2v::kWedgeThreads - 1) / n2v::kWedgeThreads;
+    const int64_t scap = n2v::resident_blocks((const void *)sk, n2v::kWedgeThreads, 0);
+    if (sblocks > scap) sblocks = scap;
+    hipLaunchKernelGGL(sk, dim3((unsigned)sblocks), dim3(n2v::kWedgeThreads), 0, (hipStream_t)stream,
+                       *g, start_ids, n_start, num_walks, walk_length, q, K, seed, walks_out,
+                       valid_out, status);
+    if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
+    return 1;
+  }
   auto kernel = !K.dyadic    ? n2v::walk_exact_wedge_kernel<2>
                 : alone_under ? n2v::walk_exact_wedge_kernel<0>
                 : alone_over  ? n2v::walk_exact_wedge_kernel<3>

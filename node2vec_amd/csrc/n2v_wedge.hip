@@ -253,3 +253,77 @@ extern "C" int n2v_wedge_build(const n2v_graph *g, const uint64_t *list_off, uin
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
 }
+
+namespace n2v {
+// one thread per edge: copy a short list into its slot, or leave its offset and eight pivots
+__global__ __launch_bounds__(256) void wedge_slots_kernel(n2v_graph g, uint16_t *__restrict__ slots) {
+  const uint16_t *pos = reinterpret_cast<const uint16_t *>(g.wedge_pos);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < g.n_edges;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t ec = g.edge_classes[e];
+    const uint64_t wraw = g.wedge_off[e];
+    const uint64_t off = wraw & N2V_WEDGE_OFF_MASK;
+    const int rpos = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
+    int nM = (int)(ec & N2V_EC_SHARED_MASK);
+    if ((uint32_t)nM == N2V_EC_SHARED_MASK) nM = 0;  // saturated: the walk kernels flag it
+    const uint16_t *list = pos + off;
+    uint32_t hw[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hw[k] = 0;
+    hw[0] = (uint32_t)rpos & 0xffffu;
+    int below = 0;  // list entries below the return position
+    if (nM <= 14) {
+      for (int k = 0; k < nM; ++k) {
+        const uint32_t v = list[k];
+        below += (int)v < rpos ? 1 : 0;
+#pragma unroll
+        for (int u = 0; u < 14; ++u)
+          if (u == k) hw[2 + u] = v;
+      }
+    } else {
+      int lo = 0, hi = nM;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((int)list[mid] < rpos)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      below = lo;
+      hw[4] = (uint32_t)(off & 0xffffu);
+      hw[5] = (uint32_t)((off >> 16) & 0xffffu);
+      hw[6] = (uint32_t)((off >> 32) & 0xffffu);
+      hw[7] = (uint32_t)((off >> 48) & 0xffffu);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) hw[8 + k] = list[((int64_t)(k + 1) * nM) / 9];
+    }
+    hw[1] = (uint32_t)below & 0xffffu;
+    int4 a, b;
+    a.x = (int)(hw[0] | (hw[1] << 16));
+    a.y = (int)(hw[2] | (hw[3] << 16));
+    a.z = (int)(hw[4] | (hw[5] << 16));
+    a.w = (int)(hw[6] | (hw[7] << 16));
+    b.x = (int)(hw[8] | (hw[9] << 16));
+    b.y = (int)(hw[10] | (hw[11] << 16));
+    b.z = (int)(hw[12] | (hw[13] << 16));
+    b.w = (int)(hw[14] | (hw[15] << 16));
+    reinterpret_cast<int4 *>(slots + e * 16)[0] = a;
+    reinterpret_cast<int4 *>(slots + e * 16)[1] = b;
+  }
+}
+}  // namespace n2v
+
+extern "C" int n2v_wedge_slots_build(const n2v_graph *g, uint16_t *slots_out, void *stream) {
+  if (!g || g->n_edges < 0) return N2V_EINVAL;
+  if (g->n_edges == 0) return N2V_OK;
+  if (!g->edge_classes || !g->wedge_off || !g->wedge_pos || g->wedge_wide || !slots_out)
+    return N2V_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(slots_out) & 31u) != 0) return N2V_EINVAL;
+  int64_t blocks = (g->n_edges + 255) / 256;
+  const int64_t cap = 8 * n2v::resident_blocks((const void *)n2v::wedge_slots_kernel, 256, 0);
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(n2v::wedge_slots_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, *g, slots_out);
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}

@@ -1,0 +1,281 @@
+// n2v_wedge_step.h -- one step of an exact biased walk on a unit-weight graph from the per-edge
+// tables (hop table with class counts + wedge table, include/n2v_hip.h), by one lane: shared by the
+// kernels of n2v_walk_wedge.hip (one launch, replays inline) and n2v_walk_wedge2.hip (closed
+// forms in the main launches, declined steps replayed out of line).  Reference: the table
+// generate_edge_alias_tables builds at (s, v) and sampling_from_alias on it, randomwalk.py:86-99,
+// :157-232.
+#pragma once
+#include "n2v_unit_core.h"
+
+namespace n2v {
+
+// the pairing loop for slot `pick` by one lane: closed form by arrangement `arr` (see the kernel),
+// else -- fp64 rounding decides the draw: a tie or a thin margin -- the replays.
+// kMode 0 / 3: the (p, q) that leave "other" alone on its stack on ordinary rows, underfull (0) or
+// overfull (3: the mirror closed form then runs at every step and finds the next slot without a
+// search -- code instance 0 does without: its registers are the flagship configuration's); 1: those for which
+// the return run shares a stack with it (arrangements 3-5: compiled out of instance 0, whose
+// registers they would cost); 2: 1/p or 1/q not dyadic -- no exact integer arithmetic, so no
+// closed form: every pairing is replayed run by run in fp64.
+template <typename P, int kMode>
+__device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, const UnitConsts &K,
+                                           double avg, int nR, int rpos, int nM, const P *list,
+                                           bool isR, bool isM, int lo_pick, P *stage, int lane) {
+  constexpr bool kShared = kMode == 1 || kMode == 2;
+  int res = -1;
+  if constexpr (kMode != 2) {
+    if (arr == 1)
+      res = lane_case_a_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+    else if (arr == 2)
+      res = lane_case_b_jump<P, kMode != 0>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+  }
+  if constexpr (kMode == 1) {
+    if (arr == 3)
+      res = lane_case_a2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+    else if (arr == 4)
+      res = lane_case_b2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+    else if (arr == 5)
+      res = lane_case_a3_jump<P>(n, pick, r2, K, nR, rpos, nM, isR, isM, lo_pick);
+  }
+#ifdef N2V_ABLATE_W
+  if (N2V_ABLATE_W == 1 && arr == 2) res = pick;  // timing-only: no closed form at all
+#endif
+  if (res >= 0) return res;
+  const double vR = K.bR / avg, vM = K.bM / avg, vO = K.bO / avg;
+  if (n <= 64) {  // a short row: the two stacks as bit masks
+    uint64_t Rm = 0ull;
+    if (nR) Rm = ((nR >= 64) ? ~0ull : ((1ull << nR) - 1ull)) << rpos;
+    const uint64_t Mm = wedge_mask_t<P>(list, 0, nM);
+    return lane_pairing(n, Rm, Mm, pick, r2, vR, vM, vO);
+  }
+  if (arr == 1) return lane_case_a<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM, stage, lane);
+  if (arr == 2) return lane_case_b<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM);
+  if constexpr (kShared) {
+    if (arr == 3) return lane_case_a2<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM, stage, lane);
+    if (arr == 4) return lane_case_b2<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM);
+    if (arr == 5) return lane_case_a3<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM);
+  }
+  return lane_pairing_list<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list);
+}
+
+
+// the closed-form half of pair_listed alone: the slot the draw returns, or -1 when fp64 rounding
+// decides it (a tie, a thin margin, an arrangement without a closed form) -- the caller then has
+// the step replayed (pair_listed) somewhere else.  kMode 0, 1, 3 (dyadic p, q).
+template <typename P, int kMode>
+__device__ __forceinline__ int jump_listed(int arr, int n, int pick, double r2, const UnitConsts &K,
+                                           int nR, int rpos, int nM, const P *list, bool isR,
+                                           bool isM, int lo_pick) {
+  static_assert(kMode != 2, "values that are not dyadic have no closed form");
+  if (arr == 1) return lane_case_a_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+  if (arr == 2)
+    return lane_case_b_jump<P, kMode != 0>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+  if constexpr (kMode == 1) {
+    if (arr == 3) return lane_case_a2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+    if (arr == 4) return lane_case_b2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+    if (arr == 5) return lane_case_a3_jump<P>(n, pick, r2, K, nR, rpos, nM, isR, isM, lo_pick);
+  }
+  return -1;
+}
+
+// ---- per-edge wedge slots (n2v_wedge_slots_build, include/n2v_hip.h): 16 halfwords per edge ----
+// A biased step reads the return position and the shared-position list of the edge it came along.
+// Through wedge_off that is two DEPENDENT gathers (offset, then list); the slot of edge e sits at
+// a fixed place, is requested together with the hop, and holds for a list of n <= kSlotShort
+// entries the list itself:  [0] return position  [1] entries below the return position
+//   n <= 14:  [2 .. 2 + n) the positions           n > 14:  [4 .. 8) offset of the list in wedge_pos
+//                                                           (64 bits), [8 .. 16) eight pivots,
+//                                                           list[((k + 1) n) / 9], k = 0 .. 7
+// so that ~80 % of the steps that need a list (cfg 4: 39 % of all steps) take one sector instead
+// of two, and a long list is entered at the right ninth (one more sector up to ~290 entries).
+constexpr int kSlotShort = 14;
+constexpr int kSlotPivots = 8;
+
+__device__ __forceinline__ int slot_half(const int4 &a, const int4 &b, int k) {  // halfword k, k constant
+  const int w = k >> 1;
+  const uint32_t d = (uint32_t)(w == 0 ? a.x : w == 1 ? a.y : w == 2 ? a.z : w == 3 ? a.w
+                              : w == 4 ? b.x : w == 5 ? b.y : w == 6 ? b.z : b.w);
+  return (int)((k & 1) ? (d >> 16) : (d & 0xffffu));
+}
+
+// lower bound of `pick` in the list of a slot (entries below it; found = it is in the list)
+__device__ __forceinline__ int slot_lower(const int4 &sa, const int4 &sb, int nM, int pick,
+                                          const uint16_t *wedge_pos, bool &found) {
+  found = false;
+  if (nM <= kSlotShort) {
+    int lo = 0;
+#pragma unroll
+    for (int k = 0; k < kSlotShort; ++k) {
+      const int e = slot_half(sa, sb, k + 2);
+      const bool in = k < nM;
+      lo += (in && e < pick) ? 1 : 0;
+      found = found || (in && e == pick);
+    }
+    return lo;
+  }
+  const uint64_t off = (uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32);
+  const uint16_t *list = wedge_pos + off;
+  int j = 0;  // pivots below pick
+#pragma unroll
+  for (int k = 0; k < kSlotPivots; ++k) j += (slot_half(sa, sb, 8 + k) < pick) ? 1 : 0;
+  // list[idx(j - 1)] < pick <= list[idx(j)], idx(k) = ((k + 1) nM) / 9, idx(-1) = -1, idx(8) = nM
+  int lo = j == 0 ? 0 : (int)(((int64_t)j * nM) / 9) + 1;
+  int hi = j == kSlotPivots ? nM : (int)(((int64_t)(j + 1) * nM) / 9);
+  const int top = hi;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)list[mid] < pick)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  if (lo < nM) {
+    int e = 0;  // list[lo]: the pivot itself when the search ran to the end of its ninth
+    if (lo == top && j < kSlotPivots) {
+#pragma unroll
+      for (int k = 0; k < kSlotPivots; ++k)
+        if (k == j) e = slot_half(sa, sb, 8 + k);
+    } else {
+      e = (int)list[lo];
+    }
+    found = e == pick;
+  }
+  return lo;
+}
+
+// what a kernel needs of (p, q) beyond UnitConsts, computed once
+struct StepFlags {
+  bool need_mem, always_pair, merge_r, w_wide;
+};
+__device__ __forceinline__ StepFlags step_flags(const n2v_graph &g, const UnitConsts &K, double q) {
+  StepFlags f;
+  f.need_mem = q != 1.0;
+  f.always_pair = K.bO > 1.0;  // 1/q > 1: "other" overfull, an overfull `pick` has no quick exit
+  f.merge_r = K.bR == K.bO;    // p == q: the return slot IS an "other" slot (:223-230)
+  f.w_wide = g.wedge_wide != 0;
+  return f;
+}
+
+// One biased step (s >= 0) of a walker standing on v (row vb, n slots) that came along edge e_prev
+// with class counts ec_prev: the slot sampling_from_alias returns, and in `h` the hop entry of that
+// slot.  kJumpOnly: closed forms only; returns -1 when the step has to be replayed (h is then the
+// entry of `pick`).  Otherwise the replays run here (pair_listed) and the result is always >= 0.
+// kSlots: the edge's list comes from g.wedge_slots (16-bit positions only) instead of wedge_off.
+// A saturated class count (tables that do not belong to this graph) flags N2V_ST_RANGE and keeps
+// `pick`, as the one-launch kernel does.  kMode 0, 1, 3 (dyadic p, q).
+template <int kMode, bool kJumpOnly, bool kSlots>
+__device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &K, const StepFlags &F,
+                                          uint32_t u1, uint32_t u2, int32_t s, int64_t vb, int n,
+                                          int64_t e_prev, uint32_t ec_prev, n2v_hop &h,
+                                          uint32_t *stage, int lane, uint32_t *status) {
+  constexpr bool kShared = kMode == 1;
+  const int pick = pick_index(u1, n);
+  int idx = pick;
+  const uint32_t fR = ec_prev >> N2V_EC_RETURN_SHIFT, fM = ec_prev & N2V_EC_SHARED_MASK;
+  const bool counts_ok = fR != N2V_EC_RETURN_SAT && fM != N2V_EC_SHARED_MASK;
+  // this step's wedge list: its offset (its slot) is requested before the hop so both loads
+  // overlap; steps whose edge has no shared neighbour need it only if the pairing runs (lazy)
+  uint64_t wraw = 0;
+  int4 sa = make_int4(0, 0, 0, 0), sb = make_int4(0, 0, 0, 0);
+  bool w_loaded = false;
+  const uint16_t *slot = nullptr;
+  if constexpr (kSlots) slot = reinterpret_cast<const uint16_t *>(g.wedge_slots) + e_prev * 16;
+  if (counts_ok && ((F.need_mem && fM > 0) || (F.always_pair && (fM > 0 || fR > 0)))) {
+    if constexpr (kSlots) {
+      sa = reinterpret_cast<const int4 *>(slot)[0];
+      sb = reinterpret_cast<const int4 *>(slot)[1];
+    } else {
+      wraw = g.wedge_off[e_prev];
+    }
+    w_loaded = true;
+  }
+  h = load_hop(g.hops + vb + pick);
+  if (!counts_ok) {
+    atomicOr(status, N2V_ST_RANGE);
+    return idx;
+  }
+  const int32_t x = h.col;
+  const int nR = F.merge_r ? 0 : (int)fR, nM = F.need_mem ? (int)fM : 0, nO = n - nR - nM;
+  int64_t w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
+  const bool isR = !F.merge_r && x == s;
+  bool isM = false;
+  int lo_pick = 0;  // entries of the edge's list below `pick`
+  if (F.need_mem && !isR && nM > 0) {  // :226
+    if constexpr (kSlots)
+      lo_pick = slot_lower(sa, sb, nM, pick, reinterpret_cast<const uint16_t *>(g.wedge_pos), isM);
+    else
+      lo_pick = wedge_lower(g.wedge_pos, w_off, nM, pick, F.w_wide, isM);
+  }
+  const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
+  const double avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;  // :172
+  const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) / avg;       // :173
+  const double r2 = (double)u2 * (1.0 / 4294967296.0);
+  if (p_pick < 1.0 && r2 < p_pick) return idx;  // an accepted underfull slot is final
+  // underfull / overfull by class without dividing: fl(b / avg) < 1.0 <=> b < avg
+  const bool uR = K.bR < avg, uM = K.bM < avg, uO = K.bO < avg;
+  const bool any_under = (nR && uR) || (nM && uM) || (nO && uO);
+  const bool any_over = (nR && !uR) || (nM && !uM) || (nO && !uO);
+  if (!any_under || !any_over) {  // the loop of :182 never runs
+    if (!(r2 < p_pick)) idx = 0;
+  } else {
+    if (!w_loaded) {  // the return position (and an empty list)
+      if constexpr (kSlots) {
+        sa = reinterpret_cast<const int4 *>(slot)[0];
+      } else {
+        wraw = g.wedge_off[e_prev];
+        w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
+      }
+    }
+    int w_rpos;
+    if constexpr (kSlots)
+      w_rpos = (int)((uint32_t)sa.x & 0xffffu);
+    else
+      w_rpos = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
+    // the stacks: 1 = "other" alone underfull, 2 = "other" alone overfull, 3 = return + "other"
+    // underfull, 4 = return + "other" overfull, 5 = return alone overfull, 0 = else
+    int arr = 0;
+    if (uO && !(nR && uR) && !(nM && uM)) arr = 1;
+    else if (!uO && nO > 0 && (!nR || uR) && (!nM || uM)) arr = 2;
+    else if (kShared && uO && nR && uR && nM && !uM) arr = 3;
+    else if (kShared && !uO && nO > 0 && nR && !uR && nM && uM) arr = 4;
+    else if (kShared && uO && nR && !uR && nM && uM) arr = 5;
+    if constexpr (kSlots) {
+      // the list as the pairing routines read it: inside the slot, or in wedge_pos
+      const uint16_t *list = slot + 2;
+      if (nM > kSlotShort)
+        list = reinterpret_cast<const uint16_t *>(g.wedge_pos) +
+               ((uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32));
+      if constexpr (kJumpOnly) {
+        idx = jump_listed<uint16_t, kMode>(arr, n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
+        if (idx < 0) return -1;
+      } else {
+        idx = pair_listed<uint16_t, kMode>(arr, n, pick, r2, K, avg, nR, w_rpos, nM, list, isR, isM,
+                                           lo_pick, reinterpret_cast<uint16_t *>(stage), lane);
+      }
+    } else if constexpr (kJumpOnly) {
+      // a plain branch on the (uniform) list width: never a select between two loads
+      if (F.w_wide)
+        idx = jump_listed<uint32_t, kMode>(arr, n, pick, r2, K, nR, w_rpos, nM,
+                                           reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off,
+                                           isR, isM, lo_pick);
+      else
+        idx = jump_listed<uint16_t, kMode>(arr, n, pick, r2, K, nR, w_rpos, nM,
+                                           reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off,
+                                           isR, isM, lo_pick);
+      if (idx < 0) return -1;
+    } else {
+      if (F.w_wide)
+        idx = pair_listed<uint32_t, kMode>(arr, n, pick, r2, K, avg, nR, w_rpos, nM,
+                                           reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off,
+                                           isR, isM, lo_pick, stage, lane);
+      else
+        idx = pair_listed<uint16_t, kMode>(arr, n, pick, r2, K, avg, nR, w_rpos, nM,
+                                           reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off,
+                                           isR, isM, lo_pick, reinterpret_cast<uint16_t *>(stage), lane);
+    }
+  }
+  if (idx != pick) h = load_hop(g.hops + vb + idx);
+  return idx;
+}
+
+}  // namespace n2v

@@ -45,6 +45,7 @@ class DeviceGraph:
         self.wedge_off: Optional[torch.Tensor] = None  # int64 [E]: list offset | return position << 40
         self.wedge_pos: Optional[torch.Tensor] = None  # int16 / int32 [sum of shared counts]
         self.wedge_tried = False  # randomwalk.walk tries to build the table once
+        self.wedge_slots: Optional[torch.Tensor] = None  # int16 [E, 16]: n2v_wedge_slots_build
 
     @property
     def w(self) -> torch.Tensor:
@@ -134,7 +135,7 @@ class DeviceGraph:
         g = DeviceGraph(self.rowptr.to(device), self.col.to(device),
                         None if self._w is None else self._w.to(device))
         for name in ("slots", "pivots", "edge_classes", "hops", "hops8", "hops8_rowptr", "wedge_off",
-                     "wedge_pos"):
+                     "wedge_pos", "wedge_slots"):
             t = getattr(self, name)
             if t is not None:
                 setattr(g, name, t.to(device))
@@ -160,7 +161,8 @@ class DeviceGraph:
                           0 if self.hops8 is None else self.hops8.data_ptr(),
                           self.hops8_bits[0], self.hops8_bits[1],
                           0 if self.hops8_rowptr is None else self.hops8_rowptr.data_ptr(),
-                          self.hops8_shift, 0)
+                          self.hops8_shift, 0,
+                          0 if self.wedge_slots is None else self.wedge_slots.data_ptr())
 
     # -- a9 -----------------------------------------------------------------------
     def trimmed(self, max_out_degree: int, seed: int) -> "DeviceGraph":
@@ -227,20 +229,23 @@ class DeviceGraph:
         self.edge_classes = ec
         return self
 
-    def build_wedges(self, max_bytes: Optional[int] = None, wide: Optional[bool] = None) -> "DeviceGraph":
+    def build_wedges(self, max_bytes: Optional[int] = None, wide: Optional[bool] = None,
+                     slots: bool = True) -> "DeviceGraph":
         """Shared-position lists (n2v_wedge_build): for every edge (s -> v) the positions in
         N(v) of the neighbours v shares with s -- what generate_edge_alias_tables recomputes by a
         set intersection at every step (randomwalk.py:226), stored once.  8 bytes per edge + 2
         (4 when some degree >= 65536) per (edge, common neighbour) pair; `max_bytes` (default:
         half of the free device memory) bounds it -- a graph with more triangles than that
-        walks without the lists (same bits, slower on the steps that need the pairing)."""
+        walks without the lists (same bits, slower on the steps that need the pairing).  With
+        16-bit positions and room for 32 more bytes per edge the wedge slots are built as well
+        (build_wedge_slots)."""
         L = _lib.load()
         _lib.require_gpu()
         if not self.unit_weights:
             raise ValueError("the wedge table exists for unit-weight graphs only")
         if self.edge_classes is None:
             self.build_edge_classes()
-        self.wedge_off = self.wedge_pos = None
+        self.wedge_off = self.wedge_pos = self.wedge_slots = None
         if self.n_edges == 0 or int(self.degrees().max()) >= self.HOP_MAX_DEGREE:
             return self
         counts = (self.edge_classes & 0xffffff).to(torch.int64)
@@ -264,6 +269,25 @@ class DeviceGraph:
         if int(status[0].item()) & _lib.ST_RANGE:
             raise RuntimeError("n2v_wedge_build: list lengths disagree with edge_classes")
         self.wedge_off, self.wedge_pos = off, pos
+        if slots and not wide and need + 32 * self.n_edges <= max_bytes:
+            self.build_wedge_slots()
+        return self
+
+    def build_wedge_slots(self) -> "DeviceGraph":
+        """Wedge slots (n2v_wedge_slots_build): 32 bytes per edge at a place the walker knows a
+        step ahead -- the return position and, for the four fifths of the lists that have at most
+        14 entries, the list itself; offset + eight pivots for longer ones.  The exact biased
+        kernel then fetches hop entry and list in two independent gathers instead of hop, offset
+        and list (DESIGN.md "K2 exact, biased").  Needs the wedge table with 16-bit positions."""
+        L = _lib.load()
+        self.wedge_slots = None
+        if self.wedge_off is None or self.wedge_pos is None or self.wedge_pos.dtype != torch.int16:
+            return self
+        slots = torch.empty((self.n_edges, 16), dtype=torch.int16, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = L.n2v_wedge_slots_build(self.c_struct(), slots.data_ptr(), _lib.current_stream_ptr())
+        _lib.check(rc, "n2v_wedge_slots_build")
+        self.wedge_slots = slots
         return self
 
     HOP_MAX_DEGREE = 1 << 24  # n2v_hop packs the degree into 24 bits

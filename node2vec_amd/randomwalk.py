@@ -69,7 +69,8 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
          return_param: float, inout_param: float, seed: int, mode: str = "exact",
          out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, check: bool = True,
          stats: Optional[dict] = None, use_edge_classes: bool = True, use_hops: bool = True,
-         use_wedges: bool = True, use_wedge_kernel: bool = True, use_hops8: bool = True):
+         use_wedges: bool = True, use_wedge_kernel: bool = True, use_hops8: bool = True,
+         use_workspace: bool = False, use_wedge_slots: bool = True):
     """Launch K2.  Returns (walks int32 [n_start*num_walks, walk_length+1], valid bool).
 
     mode "fast", and on weighted graphs mode "exact" with return_param == inout_param == 1
@@ -84,7 +85,11 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     every edge by position, 8 bytes per edge + 2 per entry, skipped when it would not fit;
     use_wedges=False walks without it: same bits, searches at the steps that need the pairing).
     With all three tables the walk runs in the kernel where no step needs the wave
-    (n2v_walk_wedge.hip); use_wedge_kernel=False keeps the class-count kernel: same bits."""
+    (n2v_walk_wedge.hip); use_wedge_kernel=False keeps the class-count kernel: same bits.  For
+    dyadic p, q that walk then runs in passes over a workspace lent to the library (n2v_walk_ws:
+    closed forms in the main launches, the ~1 % of steps they decline replayed out of line;
+    64 bytes per walker, allocated here); use_workspace=False keeps the one-launch kernel: same
+    bits."""
     L = _lib.load()
     _lib.require_gpu()
     if mode not in MODES:
@@ -165,11 +170,21 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
         g.wedge_pos = 0
     if not use_wedge_kernel:  # keep the tables but walk with the lanes kernel (tests: same bits)
         g.reserved = 1
+    if not use_wedge_slots:  # the all-tables kernel through wedge_off (tests: same bits)
+        g.wedge_slots = 0
     with torch.cuda.device(graph.device):
-        rc = L.n2v_walk(g, start_ids.data_ptr(), n_start, num_walks, walk_length,
-                        float(return_param), float(inout_param), seed & (2 ** 64 - 1),
-                        MODES[mode], walks.data_ptr(), valid.data_ptr(), status.data_ptr(),
-                        _lib.current_stream_ptr())
+        ws_bytes = 0
+        if use_workspace and n_start > 0:
+            ws_bytes = int(L.n2v_walk_workspace_bytes(g, n_start, num_walks, walk_length,
+                                                      float(return_param), float(inout_param),
+                                                      MODES[mode]))
+        # (torch's caching allocator: the block is reused by the next launch on this stream)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=graph.device) if ws_bytes else None
+        rc = L.n2v_walk_ws(g, start_ids.data_ptr(), n_start, num_walks, walk_length,
+                           float(return_param), float(inout_param), seed & (2 ** 64 - 1),
+                           MODES[mode], walks.data_ptr(), valid.data_ptr(), status.data_ptr(),
+                           ws.data_ptr() if ws is not None else None, ws_bytes,
+                           _lib.current_stream_ptr())
     _lib.check(rc, "n2v_walk")
     if check:
         _lib.check_status_word(int(status[0].item()), "n2v_walk")

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from node2vec_amd import _lib
-from node2vec_amd.shard import all_reduce
+from node2vec_amd.shard import all_reduce, ordered_sum
 
 EXP_TABLE_SIZE = 1000
 MAX_EXP = 6
@@ -306,7 +306,7 @@ class DeltaSync:
 
     def __init__(self, model_or_tensors, group=None, sync_every: Optional[int] = None,
                  wire: str = "fp32", block_rows: int = 1 << 20, overlap: bool = True,
-                 comm_share: float = 0.10):
+                 comm_share: float = 0.10, rehearse: bool = False):
         import torch.distributed as dist
 
         if wire not in ("fp32", "bf16"):
@@ -331,8 +331,13 @@ class DeltaSync:
         self._t_sync = None
         self._t_mark = None
         self._before = self._wire = None
+        self._scratch = {}
+        # rehearse: a group of ONE rank still runs pack -> collectives -> apply (a mean of one);
+        # `exchanged_blocks` counts the blocks that went through them
+        self.rehearse = bool(rehearse) and self.active
+        self.exchanged_blocks = 0
         self.refs = None
-        if wire == "bf16" and self.world > 1:
+        if wire == "bf16" and (self.world > 1 or self.rehearse):
             self.refs = [self._ref_init(t) for t in self.tensors]
 
     # -- sizes reported by bench.py ------------------------------------------------------
@@ -410,12 +415,15 @@ class DeltaSync:
                 n = cur.numel()
                 snap = None if exact else before[:n]
                 self._pack(cur, None if ref is None else ref[lo:hi], snap, wire[:n])
-                all_reduce(wire[:n], self.dist.ReduceOp.SUM, self.group, self.dist)
+                # the sum over the ranks: bytes through the collective library, the additions here,
+                # in fp32 and in rank order (shard.ordered_sum) -- the same bits under RCCL and gloo
+                ordered_sum(wire[:n], self.group, self.dist, self._scratch, force=self.rehearse)
+                self.exchanged_blocks += 1
                 self._apply(cur, None if ref is None else ref[lo:hi], snap, wire[:n])
 
     # -- the protocol -------------------------------------------------------------------------
     def sync(self, blocking: bool = False):
-        if not self.active or self.world == 1:
+        if not self.active or (self.world == 1 and not self.rehearse):
             return
         self.syncs += 1
         if self.side is None or blocking:

@@ -85,7 +85,11 @@ while time.time() - t0 < budget:
     # unit weights, dyadic p, q: the lanes kernel (per-edge class counts) by default, the
     # wave-per-walker kernel without them -- both must match
     uec = bool(rng.random() < 0.7)
-    got, gv = rw.walk(g, starts, nw, wl, p, q, seed, use_edge_classes=uec)
+    # the passes of n2v_walk_ws (dyadic p, q with all tables): any number of main / resolve rounds
+    # before the finishing launch must give the same walks
+    os.environ["N2V_WEDGE2_ROUNDS"] = str(int(rng.choice([0, 1, 2, 4, 9])))
+    got, gv = rw.walk(g, starts, nw, wl, p, q, seed, use_edge_classes=uec,
+                      use_workspace=bool(rng.random() < 0.3), use_wedge_slots=bool(rng.random() < 0.7))
     want, wv = n2v_oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.w.cpu().numpy(),
                                       starts.cpu().numpy(), nw, wl, p, q, seed, n_threads=THREADS)
     ok = np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy(), want)

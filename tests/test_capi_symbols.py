@@ -21,7 +21,8 @@ def test_header_declares_the_expected_entry_points():
                  "n2v_hops_build", "n2v_cum_index_build", "n2v_walk_uniforms", "n2v_wedge_build",
                  "n2v_mem_probe", "n2v_corpus_count", "n2v_corpus_index", "n2v_hops8_build",
                  "n2v_partition_step", "n2v_gather_rows", "n2v_gather_wedges",
-                 "n2v_partition_route", "n2v_partition_group"):
+                 "n2v_partition_route", "n2v_partition_group", "n2v_walk_ws",
+                 "n2v_walk_workspace_bytes", "n2v_delta_reduce", "n2v_wedge_slots_build"):
         assert want in names
 
 
@@ -36,7 +37,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert sorted(_lib.SYMBOLS) == _declared()
     lib.n2v_abi_version.restype = ctypes.c_int
-    assert lib.n2v_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.n2v_abi_version() == _lib.ABI_VERSION == 8
     lib.n2v_status_string.restype = ctypes.c_char_p
     assert lib.n2v_status_string(-1) == b"invalid argument"
 
@@ -45,11 +46,11 @@ def test_ctypes_structs_match_header_layout():
     """sizeof / field order of the two structs passed by pointer"""
     from node2vec_amd import _lib
 
-    assert ctypes.sizeof(_lib.Graph) == 17 * 8
+    assert ctypes.sizeof(_lib.Graph) == 18 * 8
     assert [f[0] for f in _lib.Graph._fields_] == ["n_vertices", "n_edges", "rowptr", "col", "w", "w64",
                                                     "slots", "pivots", "edge_classes", "hops", "wedge_off", "wedge_pos",
                                                     "wedge_wide", "reserved", "hops8", "hop8_col_bits", "hop8_row_bits",
-                                                    "hop8_rowptr", "hop8_align_shift", "reserved2"]
+                                                    "hop8_rowptr", "hop8_align_shift", "reserved2", "wedge_slots"]
     # the header's field order, read from the header itself
     text = open(os.path.join(ROOT, "include", "n2v_hip.h")).read()
     body = text[text.index("typedef struct n2v_graph {"):text.index("} n2v_graph;")]

@@ -102,3 +102,20 @@ def test_overlapped_exchange_keeps_what_was_trained_meanwhile():
     s._exchange(exact=False)
     torch.cuda.synchronize()
     assert torch.allclose(t, before_all, atol=1e-6)
+
+
+def test_delta_reduce_is_the_rank_ordered_fp32_sum():
+    """n2v_delta_reduce (the local half of shard.ordered_sum) against the same additions spelled
+    out with torch on the host: fp32 accumulation in rank order, one rounding to the wire type --
+    so RCCL (device tensors), gloo (host tensors) and gloo with staged device tensors agree"""
+    from node2vec_amd.shard import _rank_ordered_reduce
+
+    gen = torch.Generator().manual_seed(9)
+    for dtype in (torch.float32, torch.bfloat16):
+        for world, m in ((2, 1000), (8, 4099), (5, 1)):
+            scale = torch.logspace(-3, 3, world).repeat_interleave(m)
+            parts = (torch.randn(world * m, generator=gen) * scale).to(dtype)
+            want = _rank_ordered_reduce(parts, world, m, torch.empty(m, dtype=dtype))
+            got = _rank_ordered_reduce(parts.cuda(), world, m, torch.empty(m, dtype=dtype, device="cuda"))
+            torch.cuda.synchronize()
+            assert torch.equal(got.cpu().view(torch.uint8), want.view(torch.uint8)), (dtype, world, m)

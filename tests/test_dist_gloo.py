@@ -47,6 +47,24 @@ def _worker(rank, world, port, ret):
             ok = ok and torch.allclose(syn0, want0 + 2.0, atol=2 * tol)
             sync.finish()
             ok = ok and sync.syncs == 3
+        # the sum itself (shard.ordered_sum): bytes through the backend, additions in fp32 in rank
+        # order -- bit-equal to that sum spelled out locally, for both wire types, with a length
+        # that does not divide by the world size; identical on every rank
+        from node2vec_amd.shard import ordered_sum
+
+        for dtype in (torch.float32, torch.bfloat16):
+            parts = [(torch.randn(1001, generator=torch.Generator().manual_seed(7 + r)) * 3.0 ** r).to(dtype)
+                     for r in range(world)]
+            acc = parts[0].float().clone()
+            for r in range(1, world):
+                acc += parts[r].float()
+            want = acc.to(dtype)
+            mine, scratch = parts[rank].clone(), {}
+            ordered_sum(mine, None, dist, scratch)
+            ok = ok and torch.equal(mine.view(torch.uint8), want.view(torch.uint8))
+            again = parts[rank].clone()
+            ordered_sum(again, None, dist, scratch)  # the buffers are reused
+            ok = ok and torch.equal(again, mine)
         # period logic: 7 launches at sync_every=3 -> exchanges after launches 3 and 6 + finish()
         t = torch.zeros(4, 2) + rank
         sync = DeltaSync([t], sync_every=3)

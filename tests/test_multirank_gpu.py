@@ -188,3 +188,32 @@ def test_two_ranks_on_one_gpu_fit_and_fit_streaming():
     tot = sa["pairs"] + sb["pairs"]
     assert abs(tot - single.pairs_trained) / single.pairs_trained < 0.01, (tot, single.pairs_trained)
     assert np.isfinite(single.wv.vectors).all()
+
+
+def test_bench_under_torchrun_rehearses_the_rccl_exchange():
+    """`bench.py --gpus 1` launched as the driver launches the N > 1 case (torch.distributed.run,
+    one rank): the process group is RCCL ("nccl"), and the exchange step of the SGNS path -- pack,
+    all_to_all / all_gather of bytes over RCCL, the rank-ordered fp32 sum, apply -- runs on device
+    tensors on a group of one rank.  The N = 8 run on the 8-GPU node is the driver's; this is the
+    same code with world = 1."""
+    import json
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "cfg2", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--no-fast", "--no-regimes", "--no-biased",
+           "--no-batched", "--no-hub"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    run = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    ex = out["sgns"]["exchange"]
+    assert ex["world"] == 1 and ex["backend"] == "nccl (RCCL)" and ex["wire_dtype"] == "bf16"
+    assert ex["tensors_on_device"] is True and ex["blocks_exchanged"] >= 2  # syn0 and syn1neg
+    assert ex["delta_allreduce_s"] > 0

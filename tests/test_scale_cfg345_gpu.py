@@ -71,7 +71,7 @@ INSTANCE_PQ = ((0.5, 2.0), (4.0, 2.0), (3.0, 0.7), (4.0, 0.25))
 
 
 def full_batch_differential(g, start, pqs=INSTANCE_PQ, seed=42):
-    """A WHOLE bench batch (start x 10 x 80 steps) through three independent implementations of
+    """A WHOLE bench batch (start x 10 x 80 steps) through independent implementations of
     the reference's per-step rebuild (randomwalk.py:182-189, :193-232) -- the all-tables kernel
     with its closed forms (default), the class-count / wave-per-walker kernels that replay the
     pairing (use_wedge_kernel=False), and the wave-per-walker kernel that classifies every row
@@ -82,6 +82,10 @@ def full_batch_differential(g, start, pqs=INSTANCE_PQ, seed=42):
     steps = 0
     for p, q in pqs:
         walks, valid = rw.walk(g, start, W, L, p, q, seed)
+        if g.wedge_slots is not None:  # the same kernel family reading wedge_off instead of the slots
+            other, ovalid = rw.walk(g, start, W, L, p, q, seed, use_wedge_slots=False)
+            assert torch.equal(valid, ovalid) and torch.equal(walks, other), (p, q, "wedge_off, no slots")
+            del other, ovalid
         replay, rvalid = rw.walk(g, start, W, L, p, q, seed, use_wedge_kernel=False)
         assert torch.equal(valid, rvalid) and torch.equal(walks, replay), (p, q, "tables, replayed")
         del replay, rvalid

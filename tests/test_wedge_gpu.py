@@ -55,6 +55,26 @@ def test_wedge_lists_equal_the_per_step_set_intersection(wide):
         big += n_shared > 24
     assert big > 50  # the wave path was exercised
     assert int(off[-1] & np.uint64(0xffffffffff)) + int(ec[-1] & 0xffffff) == sum(len(p) for p in want_pos)
+    if wide:
+        assert g.wedge_slots is None  # the slots hold 16-bit positions
+        return
+    # the wedge slots (n2v_wedge_slots_build) restate the same lists: return position, entries below
+    # it, and the list itself (<= 14 entries) or its offset and eight pivots
+    slots = g.wedge_slots.cpu().numpy().astype(np.uint16).astype(np.int64)
+    assert slots.shape == (g.n_edges, 16)
+    n_long = 0
+    for e in range(g.n_edges):
+        lst, n_ret = want_pos[e], int(ec[e] >> 24)
+        rp = want_rpos[e] if n_ret else int(off[e] >> np.uint64(40))
+        assert slots[e, 0] == rp and slots[e, 1] == sum(1 for x in lst if x < rp), e
+        if len(lst) <= 14:
+            assert slots[e, 2:2 + len(lst)].tolist() == lst, e
+        else:
+            o = int(slots[e, 4] | (slots[e, 5] << 16) | (slots[e, 6] << 32) | (slots[e, 7] << 48))
+            assert o == int(off[e] & np.uint64(0xffffffffff))
+            assert slots[e, 8:16].tolist() == [lst[((k + 1) * len(lst)) // 9] for k in range(8)], e
+            n_long += 1
+    assert n_long > 100
 
 
 def test_wedge_table_respects_its_memory_bound():
@@ -63,5 +83,9 @@ def test_wedge_table_respects_its_memory_bound():
     g = synthetic.rmat(14, 200_000, device="cuda")
     g.build_wedges(max_bytes=1000)
     assert g.wedge_off is None and g.wedge_pos is None and g.edge_classes is not None
+    assert g.wedge_slots is None
     g.build_wedges()
-    assert g.wedge_off is not None
+    assert g.wedge_off is not None and g.wedge_slots is not None
+    need = 8 * g.n_edges + 2 * g.wedge_pos.numel()
+    g.build_wedges(max_bytes=need + 8)  # room for the lists but not for 32 more bytes per edge
+    assert g.wedge_off is not None and g.wedge_slots is None
