@@ -57,7 +57,10 @@ HIP_SGNS_PARAMS: Dict[str, Any] = {
     "ns_exponent": 0.75,
     # options of the HIP trainer that gensim does not have (all off = gensim's semantics):
     "batched": False,   # True: negatives shared by the pairs of a centre position (MFMA kernel)
-    "hub_rows": 0,      # > 0: atomic adds on the most frequent rows in hogwild mode
+    "hub_rows": None,   # hogwild mode: rows [0, hub_rows) -- the most frequent words -- are updated by
+                        # atomic adds.  None = as many as are held by >= 1 wave at a time on average
+                        # (SgnsModel.auto_hub_rows: gensim's <= 16 threads never share a row, 8 192
+                        # waves do); 0 = plain stores everywhere, gensim's code as written
     "deterministic": False,  # True: one wave, sentences in order -- reproducible bit for bit
                              # (gensim's workers=1), orders of magnitude slower: for tests
 }

@@ -294,7 +294,7 @@ class Node2VecHIP(Node2VecBase):
         # centre position among its pairs (csrc/n2v_sgns_batched.hip; dim 64 / 128 / 256,
         # window <= 7, negative <= 15)
         m.batched = bool(p.get("batched", False))
-        m.hub_rows = int(p.get("hub_rows", 0) or 0)  # hogwild: atomic adds on the top rows
+        m.hub_rows = None if p.get("hub_rows") is None else int(p["hub_rows"])  # hogwild: atomic adds on the top rows
         # tokens < 0 (rows of dropped walkers in an on-device corpus, fugue.random_walk_tensors)
         # stay outside the vocabulary; a negative index must not wrap around
         idx = torch.where(walks >= 0, vocab.index_of[walks.clamp(min=0).long()],

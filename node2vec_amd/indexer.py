@@ -55,7 +55,8 @@ def index_graph_pandas(df_graph: pd.DataFrame, directed: bool,
 
 
 def index_graph_tensors(src: torch.Tensor, dst: torch.Tensor, weight: Optional[torch.Tensor] = None,
-                        directed: bool = True, device=None, id_rule: str = "sorted"):
+                        directed: bool = True, device=None, id_rule: str = "sorted",
+                        weight_dtype: torch.dtype = torch.float32):
     """The same indexing for integer-named edge lists that already live in (or fit) device
     memory: sort/unique on the GPU instead of pandas merges, for graphs of 10^8-10^9 edges.
 
@@ -64,17 +65,28 @@ def index_graph_tensors(src: torch.Tensor, dst: torch.Tensor, weight: Optional[t
     id_rule ("sorted": dense, sorted-name order; "first_appearance": position of the first
     appearance in [src..., dst...], names[id] = -1 for the unused ids in between); undirected
     graphs are symmetrised and de-duplicated on (src, dst, weight) like indexer.py:45-48.  The
-    edge order is by (src, dst, weight)."""
+    edge order is by (src, dst, weight).
+
+    Weights: the reference's two twins differ here as well -- index_graph_spark casts the column
+    with cast("float") (indexer.py:65, 32 bits), index_graph_pandas with astype(float) (:24, 64
+    bits).  `weight_dtype` selects the twin: torch.float32 (default, the Spark twin and the 4-byte
+    storage form of the kernels) or torch.float64 (the pandas twin: weights like 0.1 keep all
+    their bits, and DeviceGraph.from_edges stores them as fp64); de-duplication compares the
+    weights in that type."""
     if id_rule not in ID_RULES:
         raise ValueError(f"unknown id_rule {id_rule!r}")
+    if weight_dtype not in (torch.float32, torch.float64):
+        raise ValueError("weight_dtype is torch.float32 (Spark twin) or torch.float64 (pandas twin)")
     src = torch.as_tensor(src).to(device=device, dtype=torch.int64).reshape(-1)
     dst = torch.as_tensor(dst).to(device=device, dtype=torch.int64).reshape(-1)
     if src.numel() != dst.numel():
         raise ValueError("src and dst differ in length")
     if weight is None:
-        w = torch.ones(src.numel(), dtype=torch.float32, device=src.device)  # indexer.py:20-21
+        w = torch.ones(src.numel(), dtype=weight_dtype, device=src.device)  # indexer.py:20-21
     else:
-        w = torch.as_tensor(weight).to(device=src.device, dtype=torch.float32).reshape(-1)
+        if not torch.is_tensor(weight):  # (torch would read a list of Python floats as fp32)
+            weight = np.asarray(weight.to_numpy() if hasattr(weight, "to_numpy") else weight, dtype=np.float64)
+        w = torch.as_tensor(weight).to(device=src.device, dtype=weight_dtype).reshape(-1)
         if w.numel() != src.numel():
             raise ValueError("weight differs in length from src")
     names, inverse = torch.unique(torch.cat([src, dst]), sorted=True, return_inverse=True)
@@ -99,4 +111,52 @@ def index_graph_tensors(src: torch.Tensor, dst: torch.Tensor, weight: Optional[t
         if s_id.numel() > 1:
             head[1:] = (s_id[1:] != s_id[:-1]) | (d_id[1:] != d_id[:-1]) | (w[1:] != w[:-1])
         s_id, d_id, w = s_id[head], d_id[head], w[head]
+    return s_id, d_id, w, names
+
+
+def index_graph_names(src, dst, weight=None, directed: bool = True, device=None,
+                      id_rule: str = "sorted", weight_dtype: torch.dtype = torch.float32,
+                      chunk_rows: int = 1 << 24):
+    """index_graph_tensors for vertex NAMES of any type -- strings as in the reference's own test
+    input ('a1', 'a2', ...: tests/test_indexer.py:14-16) -- at sizes where the pandas twin's
+    merges (indexer.py:36-41) do not finish.  The names are dictionary-encoded on the host by
+    pyarrow's hash table, `chunk_rows` at a time with one unified dictionary (an exact code per
+    distinct name: nothing is hashed down to a key that could collide); everything per EDGE -- id
+    lookup, symmetrising, de-duplication -- then runs on the device on the integer codes.
+
+    Returns (src_id int64, dst_id int64, weight, names) with names a numpy object array,
+    names[id] = the vertex name (id_rule "first_appearance": None at the unused ids in between),
+    ids numbered exactly like index_graph_pandas with the same id_rule."""
+    import pyarrow as pa
+
+    if id_rule not in ID_RULES:
+        raise ValueError(f"unknown id_rule {id_rule!r}")
+
+    def chunks(col):
+        col = col.to_numpy() if hasattr(col, "to_numpy") else np.asarray(col)
+        return [pa.array(col[lo:lo + chunk_rows]) for lo in range(0, max(len(col), 1), chunk_rows)]
+
+    n_src = len(src)
+    if n_src != len(dst):
+        raise ValueError("src and dst differ in length")
+    enc = pa.chunked_array(chunks(src) + chunks(dst)).dictionary_encode().unify_dictionaries()
+    dictionary = enc.chunk(0).dictionary.to_numpy(zero_copy_only=False)
+    codes = np.concatenate([c.indices.to_numpy(zero_copy_only=False) for c in enc.chunks]).astype(np.int64)
+    if id_rule == "sorted":
+        # dense ids in sorted-name order (index_graph_pandas above / the Spark twin): rank of every
+        # distinct name, on the host -- V names, not 2 E
+        order = np.argsort(dictionary, kind="stable")
+        rank = np.empty(len(order), dtype=np.int64)
+        rank[order] = np.arange(len(order), dtype=np.int64)
+        codes = rank[codes]
+        by_id = dictionary[order]
+    codes = torch.from_numpy(codes).to(device)
+    s_id, d_id, w, code_of_id = index_graph_tensors(codes[:n_src], codes[n_src:], weight, directed,
+                                                    device, id_rule, weight_dtype)
+    if id_rule == "sorted":
+        names = by_id  # code_of_id is 0 .. V-1
+    else:
+        c = code_of_id.cpu().numpy()
+        names = np.full(len(c), None, dtype=object)
+        names[c >= 0] = dictionary[c[c >= 0]]
     return s_id, d_id, w, names

@@ -121,7 +121,7 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
                            sample=float(p["sample"] or 0.0), ns_exponent=float(p["ns_exponent"]),
                            device=dev)
     model.batched = bool(p.get("batched", False))
-    model.hub_rows = int(p.get("hub_rows", 0) or 0)
+    model.hub_rows = None if p.get("hub_rows") is None else int(p["hub_rows"])
     deterministic = bool(p.get("deterministic", False))
     logging.info("fit_streaming: %d start vertices on this rank, vocabulary %d", n_start, len(vocab))
     sync = None

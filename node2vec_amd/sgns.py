@@ -140,10 +140,42 @@ class SgnsModel:
         self.max_waves = 0  # hogwild concurrency cap (0 = the library's rule, n2v_sgns_params)
         self.batched = False  # opt-in: negatives shared by the pairs of a centre position
         self.window_cache = 0  # default kernel: syn0 rows of the window in LDS (measured slower: off)
-        self.hub_rows = 0  # hogwild: atomic adds on rows [0, hub_rows) (the most frequent words)
+        # hogwild: atomic adds instead of stores on rows [0, hub_rows), the most frequent words.
+        # None = chosen from the corpus (auto_hub_rows); 0 = plain stores everywhere (gensim's code)
+        self.hub_rows: Optional[int] = None
+        self.ns_exponent = float(ns_exponent)
         self._counters = torch.zeros(2, dtype=torch.int64, device=device)
         self.pairs = self._counters[:1]
         self.sentences_seen = 0
+
+    HOGWILD_WAVES = 8192  # what the chip keeps resident (n2v_sgns_train's cap: 256 CUs x 32 waves)
+
+    def auto_hub_rows(self) -> int:
+        """How many of the most frequent rows to update by atomic adds so that the trainer's
+        concurrency regime is the reference's.  gensim runs <= 16 unsynchronised threads
+        (constants.py:67 `workers`, embedding.py:126): a row is practically never held by two of
+        them.  The GPU runs up to 8 192 waves; each holds one syn0 row (its context word) and
+        1 + k syn1neg rows (centre word and negatives), so row i is held by
+            lambda_i = waves x (f_i + k n_i)        f_i token share, n_i negative-draw share
+        waves at a time on average.  Rows with lambda_i >= 1 are where read-modify-write stores
+        overwrite what other waves learned (measured on cfg 2: link AUC 0.897 against 0.908 - 0.914
+        at <= 64 waves, profiles/r3a_hogwild_auc_runs.log); they get atomic adds.  The vocabulary is
+        in descending count order, so they are a prefix [0, H).  Opt-in kernels (batched) keep 0."""
+        if self.batched:
+            return 0
+        n = len(self.vocab)
+        waves = min(self.HOGWILD_WAVES, max(1, n // 32))
+        if self.max_waves > 0:
+            waves = min(waves, int(self.max_waves))
+        c = self.vocab.counts.to(torch.float64)
+        pw = c.pow(self.ns_exponent)
+        lam = waves * (c / c.sum() + self.negative * pw / pw.sum())
+        return int((lam >= 1.0).sum().item())
+
+    def _hub_rows(self) -> int:
+        if self.hub_rows is None:
+            self.hub_rows = self.auto_hub_rows()
+        return int(self.hub_rows)
 
     # -- one kernel launch ----------------------------------------------------
     def train_block(self, walks_idx: torch.Tensor, alpha: float, sentence_base: int,
@@ -159,7 +191,7 @@ class SgnsModel:
         P = _lib.SgnsParams(len(self.vocab), int(sentence_base), self.seed, self.dim, self.window,
                             self.negative, float(alpha), int(bool(deterministic)),
                             self.cum_index_bits, 0 if self.cum_index is None else self.cum_index.data_ptr(),
-                            int(self.max_waves), int(bool(self.batched)), int(self.window_cache), int(self.hub_rows))
+                            int(self.max_waves), int(bool(self.batched)), int(self.window_cache), self._hub_rows())
         with torch.cuda.device(walks_idx.device):
             rc = L.n2v_sgns_train(walks_idx.data_ptr(), walks_idx.shape[0], walks_idx.shape[1],
                                   self.syn0.data_ptr(), self.syn1neg.data_ptr(),

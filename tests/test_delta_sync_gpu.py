@@ -10,16 +10,38 @@ pytestmark = pytest.mark.gpu
 
 
 class _TwoRanks:
-    """stands in for torch.distributed inside DeltaSync._exchange: `other` holds what the second
-    rank would contribute to each all-reduce, in call order"""
+    """stands in for torch.distributed inside shard.ordered_sum as rank 0 of two: `other` holds
+    what rank 1 would put on the wire at each exchange, in call order.  The two collectives only
+    move bytes: all_to_all_single hands rank 0 the first shard of both ranks' buffers,
+    all_gather_into_tensor returns rank 0's summed shard and -- rank 1's work, done here with the
+    same rank-ordered fp32 additions -- the sum of the second shards."""
 
     def __init__(self, other):
         self.other = list(other)
         self.ReduceOp = torch.distributed.ReduceOp
 
-    def all_reduce(self, t, op=None, group=None):
-        o = self.other.pop(0).to(t.device)
-        t.copy_((t.float() + o.float()).to(t.dtype))  # fp32 accumulate, one rounding
+    def get_world_size(self, group=None):
+        return 2
+
+    def get_backend(self, group=None):
+        return "stand-in"
+
+    def all_to_all_single(self, recv, send, group=None):
+        o = self.other.pop(0)
+        m = send.numel() // 2  # bytes per shard
+        theirs = torch.zeros(send.numel(), dtype=torch.uint8, device=send.device)
+        ob = o.contiguous().view(torch.uint8).to(send.device)
+        theirs[: ob.numel()] = ob
+        recv[:m].copy_(send[:m])
+        recv[m:].copy_(theirs[:m])
+        self._second = (send[m:].clone(), theirs[m:].clone(), o.dtype)
+
+    def all_gather_into_tensor(self, full, shard, group=None):
+        mine, theirs, dtype = self._second
+        total = (mine.view(dtype).float() + theirs.view(dtype).float()).to(dtype)
+        m = shard.numel()
+        full[:m].copy_(shard)
+        full[m:].copy_(total.view(torch.uint8))
 
 
 def _replicas(device, shapes, seed):
@@ -92,13 +114,12 @@ def test_overlapped_exchange_keeps_what_was_trained_meanwhile():
     s = DeltaSync([t], wire="fp32", block_rows=128, overlap=False)
     s.active, s.world = True, 2
 
-    class _Same:  # the other rank holds the same rows: the mean is the tensor itself
-        ReduceOp = torch.distributed.ReduceOp
+    class _Same(_TwoRanks):  # the other rank holds the same rows: the mean is the tensor itself
+        def all_to_all_single(self, recv, send, group=None):
+            self.other = [send.clone().view(torch.float32)]
+            super().all_to_all_single(recv, send, group)
 
-        def all_reduce(self, w, op=None, group=None):
-            w.mul_(2.0)
-
-    s.dist = _Same()
+    s.dist = _Same([])
     s._exchange(exact=False)
     torch.cuda.synchronize()
     assert torch.allclose(t, before_all, atol=1e-6)

@@ -386,3 +386,37 @@ def test_keyed_vectors_from_ids_is_lazy_and_reference_shaped(tmp_path):
     named = n2v.embedding()
     assert list(named.columns) == ["name", "vector"] and named["name"].tolist() == ["d", "b", "e", "a", "c"]
     assert n2v.get_vector(7) == vec[1].tolist()
+
+
+def test_index_graph_names_on_the_references_own_input():
+    """reference tests/test_indexer.py:14-20: string names 'a1' .. 'b2', undirected -> 6 vertices
+    and 2 x the edges; the device indexer's string front end (pyarrow dictionary codes, then
+    index_graph_tensors on the codes; here on CPU tensors) numbers them like index_graph_pandas
+    under both id rules, in chunks smaller than the input"""
+    import pandas as pd
+    import torch
+
+    from node2vec_amd.indexer import index_graph_names, index_graph_pandas
+
+    df = pd.DataFrame.from_dict({"src": ["a1", "a2", "a3", "a4"], "dst": ["a2", "b1", "b2", "a1"]})
+    for rule in ("sorted", "first_appearance"):
+        e, vid = index_graph_pandas(df.copy(), False, id_rule=rule)
+        s, d, w, names = index_graph_names(df["src"], df["dst"], None, False, "cpu", rule, chunk_rows=3)
+        assert len(s) == 2 * len(df) and sum(x is not None for x in names) == 6
+        assert sorted(zip(s.tolist(), d.tolist())) == sorted(zip(e["src"], e["dst"]))
+        assert bool((w == 1.0).all())
+        if rule == "sorted":
+            assert names.tolist() == vid["name"].tolist()
+        else:
+            assert [names[i] for i in vid["vertex_id"]] == vid["vertex_name"].tolist()
+    with pytest.raises(ValueError):
+        index_graph_names(["a"], ["b", "c"])
+    # the two weight rules of the reference's twins: fp32 (Spark twin) merges weights that differ
+    # below fp32 precision when de-duplicating, fp64 (pandas twin) keeps them apart
+    src, dst = ["x", "y"], ["y", "x"]
+    wt = [0.1, 0.1 + 1e-12]
+    _, _, w32, _ = index_graph_names(src, dst, wt, False, "cpu", weight_dtype=torch.float32)
+    _, _, w64, _ = index_graph_names(src, dst, wt, False, "cpu", weight_dtype=torch.float64)
+    assert w32.dtype == torch.float32 and len(w32) == 2 and w64.dtype == torch.float64 and len(w64) == 4
+    e64, _ = index_graph_pandas(pd.DataFrame({"src": src, "dst": dst, "weight": wt}), False)
+    assert len(e64) == 4

@@ -49,3 +49,26 @@ def test_indexed_tensors_feed_the_csr_and_the_walk(oracle):
                                   2, 20, 0.5, 2.0, 1, n_threads=8)
     assert np.array_equal(valid.cpu().numpy(), wv) and np.array_equal(walks.cpu().numpy(), want)
     assert bool((names[walks[valid].long()] % 1000003 == 0).all())  # ids map back to the names
+
+
+@pytest.mark.parametrize("id_rule", ["sorted", "first_appearance"])
+def test_index_graph_names_strings_on_the_gpu_equal_the_pandas_indexer(id_rule):
+    """string vertex names (the reference's own input type, tests/test_indexer.py:14-16) through
+    the device indexer: 300 k edges over 40 k names, chunked dictionary encoding, undirected"""
+    from node2vec_amd.indexer import index_graph_names, index_graph_pandas
+
+    rng = np.random.default_rng(5)
+    pool = np.array([f"v{int(x):09d}" if x % 3 else f"user/{int(x)}" for x in rng.choice(10 ** 9, 40_000, replace=False)],
+                    dtype=object)
+    src, dst = pool[rng.integers(0, len(pool), 300_000)], pool[rng.integers(0, len(pool), 300_000)]
+    w = rng.choice([0.5, 1.0, 2.0], 300_000)
+    e, vid = index_graph_pandas(pd.DataFrame({"src": src, "dst": dst, "weight": w}), False, id_rule=id_rule)
+    s_id, d_id, ww, names = index_graph_names(src, dst, w, False, "cuda", id_rule, chunk_rows=70_000)
+    assert s_id.is_cuda
+    got = torch.stack([s_id, d_id, (ww * 4).long()], 1).cpu().numpy()
+    want = np.stack([e["src"].to_numpy(), e["dst"].to_numpy(), (e["weight"].to_numpy() * 4).astype(np.int64)], 1)
+    assert np.array_equal(got[np.lexsort(got.T[::-1])], want[np.lexsort(want.T[::-1])])
+    if id_rule == "sorted":
+        assert names.tolist() == vid["name"].tolist()
+    else:
+        assert [names[i] for i in vid["vertex_id"]] == vid["vertex_name"].tolist()
