@@ -243,16 +243,19 @@ def main():
     nv = min(cfg["sgns_vertices"], leg.batch)
     sg_walks = leg.walks[: nv * W][leg.valid[: nv * W].bool()].clone()
     ref_bytes = reference_algorithmic_bytes(torch, g, leg.walks, leg.valid)
-    workload = (f"{cfg['label']}: {g.n_vertices} vertices, {g.n_edges} directed edges, "
-                f"{int(start_all.numel())} start vertices; p={p} q={q}, {W} walks x length {L}, "
-                f"{leg.batch} start vertices per step per GPU, seed 42")
+    # (short: the driver's record keeps 160 characters of it; the details are separate keys)
+    workload = (f"{args.config} {cfg['gen']} {g.n_vertices} vertices / {g.n_edges} directed edges, "
+                f"p={p} q={q}, {W} walks x {L} steps, {leg.batch} start vertices per step")
+    assert len(workload) <= 160, workload
     out = {
         "metric": "walk-steps/sec + embedding-updates/sec on 100M-node synthetic; 1/2/4/8 GPU",
         "value": value, "unit": "walk-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": workload, "walk_mode": "exact", "n_vertices": g.n_vertices,
+        "config": {"workload": workload, "graph": cfg["label"], "seed": 42, "num_walks": W,
+                   "walk_length": L, "start_vertices_per_step_per_gpu": leg.batch,
+                   "walk_mode": "exact", "n_vertices": g.n_vertices,
                    "n_edges": g.n_edges, "start_vertices": int(start_all.numel()),
                    "parallelism": f"graph replicated, start vertices range-sharded x{world}"},
     }
@@ -372,6 +375,8 @@ def prepare_tables(torch, g, p, q, mode, setup, tag):
             timed("wedge_table_build", g.build_wedges)
             setup[f"{tag}_wedge_table_GB"] = 0.0 if g.wedge_off is None else (
                 g.wedge_off.numel() * 8 + g.wedge_pos.numel() * g.wedge_pos.element_size()) / 1e9
+            setup[f"{tag}_wedge_slots_GB"] = 0.0 if g.wedge_slots is None else g.wedge_slots.numel() * 2 / 1e9
+
         if not biased and mode == "exact" and g.hops8 is None and not g.hops8_tried:
             timed("hop8_table_build", g.build_hops8)  # 8 bytes per edge; p = q = 1 only
         if (biased or mode != "exact" or g.hops8 is None) and (
@@ -389,6 +394,10 @@ def kernel_name(g, p, q):
         if p == 1.0 and q == 1.0:
             return "walk_uniform_kernel"
         if tables_regime(p, q) and g.hops is not None and g.wedge_off is not None:
+            from node2vec_amd.randomwalk import _dyadic
+
+            if g.wedge_slots is not None and _dyadic(p) and _dyadic(q):
+                return "walk_exact_wedge_slots_kernel"
             return "walk_exact_wedge_kernel"
         if lanes_regime(p, q) and g.edge_classes is not None:
             return "walk_exact_unit_lanes_kernel"
@@ -432,20 +441,27 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
     else:
         alg = (16 + 4) if hops else (16 + 4 + 4 + 4)
         wedges = leg.g.wedge_off is not None
+        slots = wedges and getattr(leg.g, "wedge_slots", None) is not None and "slots" in kernel
         formula = (("16 (hop entry) + 4 (path write)" if hops else
                     "16 (rowptr pair) + 4 (edge class word) + 4 (col[pick]) + 4 (path write)") +
                    " per step" +
-                   (", + 8 (wedge offset) + 2 per probe of the edge's shared-position list on steps "
+                   (", + 32 (the edge's wedge slot: return position + the list itself up to 14 entries, "
+                    "else its offset and eight pivots) on steps whose edge has shared neighbours or that "
+                    "run the pairing, + 2 per probe of a longer list" if slots else
+                    ", + 8 (wedge offset) + 2 per probe of the edge's shared-position list on steps "
                     "whose edge has shared neighbours; the steps that run the pairing read 2 bytes per "
                     "shared neighbour at most" if wedges else
                     ", + 4 per probe of the membership search; steps that run the pairing read both rows"))
     kernel_key = kernel + (":hop8" if hop8 else (":hops" if hops else "")) + (
         ":wedges" if (leg.g.wedge_off is not None and mode == "exact" and not (p == 1.0 and q == 1.0)) else "")
+    # bytes past L2 per launch from the COMMITTED rocprofv3 --pmc passes of this command: not
+    # observed in this run, so it is reported as `traffic_committed`; `traffic` (the contract's
+    # live PMC figure) stays null -- bench.py does not run under the profiler
     traffic = pmc_traffic(config, kernel_key, p, q, leg.batch)
     alg_launch = alg * per_launch_steps
     ach = alg_launch / res["kernel_s"]
     r = {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-         "frac": ach / HBM_PEAK, "traffic": traffic, "kernel": kernel,
+         "frac": ach / HBM_PEAK, "traffic": None, "traffic_committed": traffic, "kernel": kernel,
          "hop_table": "8-byte" if hop8 else hops,
          "wedge_table": ":wedges" in kernel_key,
          "kernel_ms": 1e3 * res["kernel_s"],
@@ -454,7 +470,7 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
          "frac_algorithmic": ach / HBM_PEAK,
          "algorithmic_bytes_per_launch": alg_launch, "algorithmic_bytes_per_walk_step": alg,
          "algorithmic_formula": formula,
-         "traffic_source": None if not traffic else
+         "traffic_committed_source": None if not traffic else
          "profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
          "command on an earlier box (a committed measurement, not observed in this run)"}
     if traffic:
@@ -611,8 +627,8 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist)
                                       "n_vocab": g.n_vertices, "sample": 0, "min_count": 0,
                                       "model_bytes": 2 * g.n_vertices * dim * 4},
            "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
-                        "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic,
-                        "kernel": "sgns_kernel", "kernel_ms": 1e3 * kernel_s,
+                        "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": None,
+                        "traffic_committed": traffic, "kernel": "sgns_kernel", "kernel_ms": 1e3 * kernel_s,
                         "achieved_from": "algorithmic bytes (SURVEY 8d: 8*D*(2+k) per pair).  `traffic` = "
                                          "2 * FETCH_SIZE + WRITE_SIZE of a committed rocprofv3 pass (the "
                                          "counter tallies half of this kernel's row reads: calibrated in "
@@ -625,11 +641,15 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist)
                         "measured_row_ceiling_GBps": row_ceiling,
                         "algorithmic_bytes_per_pair": bytes_per_pair,
                         "fma_utilisation": pairs / args.steps * flops_per_pair / kernel_s / FP32_PEAK}}
-    # the same launches with atomic adds on the 4096 most frequent rows (n2v_sgns_params.hub_rows):
-    # what hogwild loses on hubs at 8192 concurrent waves comes back (cfg 2 link AUC 0.897 -> 0.909,
-    # profiles/r3k_hogwild_auc_hub_rows.log) for this much throughput
+    # The launches above ran the DEFAULT: atomic adds on the rows that more than one wave holds at
+    # a time on average (SgnsModel.auto_hub_rows), the reference's concurrency regime (gensim: <= 16
+    # threads) at 8192 waves.  The same launches with plain stores everywhere (hub_rows = 0, gensim's
+    # code as written; cfg 2 link AUC 0.897 instead of 0.909) for comparison:
+    res["hub_rows_auto"] = {"rows": int(model.hub_rows or 0), "n_vocab": len(model.vocab),
+                            "rule": "rows with waves x (token share + k x negative-draw share) >= 1"}
     if not args.no_hub:
-        model.hub_rows = 4096
+        auto_rows = model.hub_rows
+        model.hub_rows = 0
         try:
             model.train_block(idx, 0.025, 50 * rows)
             torch.cuda.synchronize()
@@ -639,13 +659,14 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist)
                 model.train_block(idx, 0.025, (60 + k + rank * 1000) * rows)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            res["hub_rows_4096"] = {"value": (float(model.pairs.item()) - p0) / dt,
-                                    "unit": "embedding-updates/s on this GPU",
-                                    "ms_per_step": 1e3 * dt / args.steps,
-                                    "what": "rows [0, 4096) of syn0 / syn1neg updated by atomic adds (hogwild "
-                                            "only); opt-in (w2v_params['hub_rows'])"}
+            res["plain_stores"] = {"value": (float(model.pairs.item()) - p0) / dt,
+                                   "unit": "embedding-updates/s on this GPU",
+                                   "ms_per_step": 1e3 * dt / args.steps,
+                                   "what": "hub_rows = 0: every row updated by read-modify-write stores "
+                                           "(w2v_params['hub_rows'] = 0)"}
+            res["hub_rows_auto"]["throughput_vs_plain_stores"] = res["value"] / max(res["plain_stores"]["value"], 1.0)
         finally:
-            model.hub_rows = 0
+            model.hub_rows = auto_rows
     if not args.no_batched and dim in (64, 128, 256):
         res["batched"] = bench_sgns_batched(args, torch, dist, model, idx, rows, rank, barrier,
                                             use_dist, dev, dim)
@@ -680,6 +701,7 @@ def bench_sgns_batched(args, torch, dist, model, idx, rows, rank, barrier, use_d
     corpus: K launches.  A position is three small dense products on v_mfma_f32_16x16x4_f32 and
     moves 8*D*(2+k) bytes of HBM per POSITION instead of per pair."""
     model.batched = True
+    keep_hub, model.hub_rows = model.hub_rows, 0  # the opt-in kernel runs with plain stores (DESIGN.md)
     try:
         for k in range(args.warmup):
             model.train_block(idx, 0.025, (100 + k) * rows)
@@ -697,6 +719,7 @@ def bench_sgns_batched(args, torch, dist, model, idx, rows, rank, barrier, use_d
         pairs = float(model.pairs.item())
     finally:
         model.batched = False
+        model.hub_rows = keep_hub
     elapsed, pairs_total = reduce_job(torch, dist, use_dist, dev, elapsed, pairs)
     kernel_s = 1e-3 * sum(a.elapsed_time(b) for a, b in ev) / args.steps
     positions = float((idx >= 0).sum().item())  # per launch: every token is a centre position
@@ -712,7 +735,8 @@ def bench_sgns_batched(args, torch, dist, model, idx, rows, rank, barrier, use_d
             "pairs_per_position": pairs / args.steps / max(positions, 1.0),
             "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach / HBM_PEAK,
-                         "traffic": pmc_traffic(args.config, "sgns_batched_kernel", 0, 0, rows),
+                         "traffic": None,
+                         "traffic_committed": pmc_traffic(args.config, "sgns_batched_kernel", 0, 0, rows),
                          "kernel": "sgns_batched_kernel",
                          "kernel_ms": 1e3 * kernel_s,
                          "achieved_from": "algorithmic bytes 8*D*(2+k) per centre POSITION (centre + k "

@@ -329,7 +329,7 @@ __device__ __forceinline__ double floor_div(double a, double b) {  // 0 <= a, 0 
 template <typename P>
 __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, const UnitConsts &K,
                                                 int nR, int rpos, int nM, const P *list,
-                                                bool pickR, bool pickM, int lo_pick) {
+                                                bool pickR, bool pickM, int lo_pick, int below = -1) {
   const int nO = n - nR - nM;
   const double dn = (double)n;
   const double isum = (double)nR * K.fR + (double)nM * K.fM + (double)nO * K.fO;
@@ -339,13 +339,17 @@ __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, cons
   if (dn * isum > 2.0e14 || dn * dn * fmax(K.fR, K.fM) > 4.0e15) return -1;
   int mA = nM;  // shared slots above the return run come first in descending order
   if (nR > 0 && nM > 0) {
-    int lo = 0, hi = nM;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if ((int)list[mid] < rpos)
-        lo = mid + 1;
-      else
-        hi = mid;
+    int lo = below;  // entries of the list below the return position: stored with the wedge slot,
+    if (lo < 0) {    // else searched (probes of the list are requests the kernel is bound by)
+      lo = 0;
+      int hi = nM;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((int)list[mid] < rpos)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
     }
     mA = nM - lo;
   }
@@ -418,7 +422,7 @@ __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, cons
 template <typename P, bool kNextSlot>
 __device__ __forceinline__ int lane_case_b_jump(int n, int pick, double r2, const UnitConsts &K,
                                                 int nR, int rpos, int nM, const P *list,
-                                                bool pickR, bool pickM, int lo_pick) {
+                                                bool pickR, bool pickM, int lo_pick, int below = -1) {
   const int nO = n - nR - nM;
   const double dn = (double)n;
   const double isum = (double)nR * K.fR + (double)nM * K.fM + (double)nO * K.fO;
@@ -437,7 +441,7 @@ __device__ __forceinline__ int lane_case_b_jump(int n, int pick, double r2, cons
     return lo;
   };
   int mA = nM;  // shared slots above the return run come first in descending order
-  if (nR > 0 && nM > 0) mA = nM - list_lower(rpos);
+  if (nR > 0 && nM > 0) mA = nM - (below >= 0 ? below : list_lower(rpos));
   const int S = nM + nR;
   const double dmA = (double)mA, dnR = (double)nR;
   auto Y_of = [&](double j) -> double {

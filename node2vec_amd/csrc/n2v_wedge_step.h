@@ -20,14 +20,15 @@ namespace n2v {
 template <typename P, int kMode>
 __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, const UnitConsts &K,
                                            double avg, int nR, int rpos, int nM, const P *list,
-                                           bool isR, bool isM, int lo_pick, P *stage, int lane) {
+                                           bool isR, bool isM, int lo_pick, P *stage, int lane,
+                                           int below = -1) {
   constexpr bool kShared = kMode == 1 || kMode == 2;
   int res = -1;
   if constexpr (kMode != 2) {
     if (arr == 1)
-      res = lane_case_a_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+      res = lane_case_a_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick, below);
     else if (arr == 2)
-      res = lane_case_b_jump<P, kMode != 0>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+      res = lane_case_b_jump<P, kMode != 0>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick, below);
   }
   if constexpr (kMode == 1) {
     if (arr == 3)
@@ -65,11 +66,11 @@ __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, 
 template <typename P, int kMode>
 __device__ __forceinline__ int jump_listed(int arr, int n, int pick, double r2, const UnitConsts &K,
                                            int nR, int rpos, int nM, const P *list, bool isR,
-                                           bool isM, int lo_pick) {
+                                           bool isM, int lo_pick, int below = -1) {
   static_assert(kMode != 2, "values that are not dyadic have no closed form");
-  if (arr == 1) return lane_case_a_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+  if (arr == 1) return lane_case_a_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick, below);
   if (arr == 2)
-    return lane_case_b_jump<P, kMode != 0>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+    return lane_case_b_jump<P, kMode != 0>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick, below);
   if constexpr (kMode == 1) {
     if (arr == 3) return lane_case_a2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
     if (arr == 4) return lane_case_b2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
@@ -182,6 +183,8 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
   if constexpr (kSlots) slot = reinterpret_cast<const uint16_t *>(g.wedge_slots) + e_prev * 16;
   if (counts_ok && ((F.need_mem && fM > 0) || (F.always_pair && (fM > 0 || fR > 0)))) {
     if constexpr (kSlots) {
+      // (asking for the second half only when the list has more than six entries was measured
+      // and changes nothing: -3 .. +4 % by (p, q), profiles/r4i_time_slots_on_demand.log)
       sa = reinterpret_cast<const int4 *>(slot)[0];
       sb = reinterpret_cast<const int4 *>(slot)[1];
     } else {
@@ -240,17 +243,20 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
     else if (kShared && !uO && nO > 0 && nR && !uR && nM && uM) arr = 4;
     else if (kShared && uO && nR && !uR && nM && uM) arr = 5;
     if constexpr (kSlots) {
+      // entries of the list below the return position (stored: saves the routines a search)
+      const int w_below = (int)((uint32_t)sa.x >> 16);
       // the list as the pairing routines read it: inside the slot, or in wedge_pos
       const uint16_t *list = slot + 2;
       if (nM > kSlotShort)
         list = reinterpret_cast<const uint16_t *>(g.wedge_pos) +
                ((uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32));
       if constexpr (kJumpOnly) {
-        idx = jump_listed<uint16_t, kMode>(arr, n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick);
+        idx = jump_listed<uint16_t, kMode>(arr, n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick,
+                                           w_below);
         if (idx < 0) return -1;
       } else {
         idx = pair_listed<uint16_t, kMode>(arr, n, pick, r2, K, avg, nR, w_rpos, nM, list, isR, isM,
-                                           lo_pick, reinterpret_cast<uint16_t *>(stage), lane);
+                                           lo_pick, reinterpret_cast<uint16_t *>(stage), lane, w_below);
       }
     } else if constexpr (kJumpOnly) {
       // a plain branch on the (uniform) list width: never a select between two loads

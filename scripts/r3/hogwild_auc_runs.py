@@ -42,7 +42,8 @@ def run(seed, max_waves=0):
     m = sgns.SgnsModel(vocab, 128, 5, 5, seed=seed, sample=1e-3)
     m.max_waves = max_waves
     m.batched = BATCHED
-    m.hub_rows = int(os.environ.get('HUB_ROWS', '0'))
+    hr = os.environ.get('HUB_ROWS', '0')
+    m.hub_rows = None if hr == 'auto' else int(hr)  # auto: SgnsModel.auto_hub_rows (the default)
     t0 = time.perf_counter()
     m.train(idx, epochs=1, alpha=0.025, min_alpha=1e-4)
     torch.cuda.synchronize()
@@ -58,6 +59,8 @@ def run(seed, max_waves=0):
     # hub rows: norms of the 100 most frequent words (where concurrent writers collide)
     hub = float(m.syn0[:100].norm(dim=1).mean())
     hub1 = float(m.syn1neg[:100].norm(dim=1).mean())
+    global LAST_HUB_ROWS
+    LAST_HUB_ROWS = m.hub_rows
     return auc, nbrs, dt, hub, hub1, int(m.pairs.item())
 
 
@@ -75,7 +78,8 @@ for waves in WAVES:
         ov = overlap(first, nbrs) if seed else 1.0
         aucs.append(auc)
         print(f"max_waves={waves} seed={seed} auc={auc:.4f} knn10_overlap_vs_seed0={ov:.3f} "
-              f"train_s={dt:.2f} pairs={pairs} hub_norm_syn0={hub:.3f} hub_norm_syn1neg={hub1:.3f}",
+              f"train_s={dt:.2f} pairs={pairs} hub_norm_syn0={hub:.3f} hub_norm_syn1neg={hub1:.3f} "
+              f"hub_rows={LAST_HUB_ROWS}",
               flush=True)
     a = np.array(aucs)
     print(f"max_waves={waves}: n={len(a)} mean={a.mean():.4f} sd={a.std(ddof=1):.4f} "

@@ -12,6 +12,7 @@ from node2vec_amd import partitioned as P  # noqa: E402
 from node2vec_amd import randomwalk as rw  # noqa: E402
 from node2vec_amd import synthetic  # noqa: E402
 
+W = int(os.environ.get("WALKS", "2"))  # walks per start vertex: 2 -> 9.4e5 walkers, 10 -> 4.7e6
 g = synthetic.rmat(20, 5_000_000, device="cuda")
 start = rw.start_vertices(g)
 for wedges in (True, False):
@@ -20,10 +21,10 @@ for wedges in (True, False):
           "when q != 1; bytes of the largest part:", max(pt.nbytes() for pt in parts), flush=True)
     P.walk_partitioned_local(parts, start[::50].contiguous(), 1, 3, 0.5, 2.0, 1)  # warm-up (first launches)
     for p, q in ((1.0, 1.0), (0.5, 2.0), (0.5, 1.0), (4.0, 0.25), (0.7, 1.3)):
-        want, wv = rw.walk(g, start, 2, 20, p, q, 42)
+        want, wv = rw.walk(g, start, W, 20, p, q, 42)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        walks, valid = P.walk_partitioned_local(parts, start, 2, 20, p, q, 42)
+        walks, valid = P.walk_partitioned_local(parts, start, W, 20, p, q, 42)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         ok = torch.equal(valid, wv) and torch.equal(walks, want)

@@ -58,7 +58,7 @@ def test_cfg2_every_walker_three_implementations():
 
     g = synthetic.rmat(20, 5_000_000, device="cuda")
     start = rw.start_vertices(g)
-    assert start.numel() > 500_000
+    assert start.numel() > 400_000
     assert full_batch_differential(g, start) == 4 * start.numel() * 10 * 80
 
 
