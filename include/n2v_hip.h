@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define N2V_ABI_VERSION 8
+#define N2V_ABI_VERSION 9
 
 #define N2V_OK 0
 #define N2V_EINVAL (-1)  /* maps to ValueError (randomwalk.py:212-217)      */
@@ -368,6 +368,22 @@ typedef struct n2v_sgns_params {
                            trainer always returns its context rows as atomic deltas; hub_rows
                            adds the same for its target rows (8 adds per lane and row: measured
                            -34 % at 4096 on cfg 3, link AUC 0.886 -> 0.899 on cfg 2) */
+  /* gensim's learning-rate schedule.  gensim.models.Word2Vec (embedding.py:126) lowers the rate
+   * per JOB -- a batch of consecutive sentences of at most batch_words raw words
+   * (constants.py:58: 1000) -- to  max(end, start - (start - end) * (epoch + pushed / total) /
+   * epochs),  pushed = sentences queued before the job (word2vec.py _job_producer,
+   * _get_next_alpha; Python doubles, then cast to fp32).  sched_job_rows > 0 makes the kernel do
+   * the same per row: row r of this launch is sentence sched_row0 + r of its epoch, its job is
+   * that index / sched_job_rows, and `alpha` is ignored.  sched_job_rows == 0: `alpha` for every
+   * row of the launch (what rounds 1 - 3 did: one rate per launch). */
+  int32_t sched_job_rows; /* sentences per job = max(1, batch_words / sentence length); 0 = off */
+  int32_t sched_epoch;    /* cur_epoch */
+  int32_t sched_epochs;   /* epochs (`iter`) */
+  int32_t reserved;       /* 0 */
+  int64_t sched_row0;     /* index of row 0 of this launch among the sentences of its epoch */
+  int64_t sched_rows;     /* total_examples: sentences per epoch */
+  double sched_alpha0;    /* start alpha */
+  double sched_alpha_min; /* end alpha (min_alpha) */
 } n2v_sgns_params;
 
 #define N2V_SGNS_MAX_SENTENCE 256 /* longer walks: split rows on the host */

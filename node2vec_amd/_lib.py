@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libn2v_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 OK, EINVAL, ELAUNCH, ENOGPU = 0, -1, -2, -3
 ST_ZERODIV, ST_RANGE = 1, 2
@@ -47,7 +47,10 @@ class SgnsParams(C.Structure):
                 ("dim", C.c_int32), ("window", C.c_int32), ("negative", C.c_int32),
                 ("alpha", C.c_float), ("deterministic", C.c_int32), ("cum_index_bits", C.c_int32),
                 ("cum_index", C.c_void_p), ("max_waves", C.c_int32), ("batched", C.c_int32),
-                ("window_cache", C.c_int32), ("hub_rows", C.c_int32)]
+                ("window_cache", C.c_int32), ("hub_rows", C.c_int32),
+                ("sched_job_rows", C.c_int32), ("sched_epoch", C.c_int32), ("sched_epochs", C.c_int32),
+                ("reserved", C.c_int32), ("sched_row0", C.c_int64), ("sched_rows", C.c_int64),
+                ("sched_alpha0", C.c_double), ("sched_alpha_min", C.c_double)]
 
 
 _lib = None

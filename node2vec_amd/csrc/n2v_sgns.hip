@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (kRingRows ? (VEC <= 2 ? 4 : 1) : 
   const int hub_rows = P.deterministic ? 0 : P.hub_rows;
   const int64_t hub_span = (int64_t)hub_rows * dim;
   const bool full = dim == 64 * VEC;
-  const float alpha = P.alpha;
+  float alpha = P.alpha;  // per launch, or per job of sentences (sched_alpha) inside the row loop
   const uint32_t domain = cum_table[P.n_vocab - 1];
   const int waves_per_block = blockDim.x >> 6;
   const int64_t n_waves = (int64_t)gridDim.x * waves_per_block;
@@ -204,6 +204,7 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (kRingRows ? (VEC <= 2 ? 4 : 1) : 
     const int64_t r = readfirstlane_i64(rr);
     if (!dynamic) rr += n_waves;
     const uint64_t hs = sentence_stream(P.seed, (uint64_t)(P.sentence_base + r));
+    if (P.sched_job_rows > 0) alpha = sched_alpha(P, r);  // gensim: the rate of this sentence's job
     // ---- sentence preparation (lane-parallel, order-preserving compaction) ----
     int nf = 0;
     for (int base = 0; base < walk_len; base += 64) {
@@ -615,6 +616,10 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   if (P->window_cache != 0 && P->window_cache != 1) return N2V_EINVAL;
   if (P->window_cache == 1 && !ring_fits) return N2V_EINVAL;
   if (P->hub_rows < 0) return N2V_EINVAL;
+  if (P->sched_job_rows < 0 ||
+      (P->sched_job_rows > 0 && (P->sched_rows < 1 || P->sched_epochs < 1 || P->sched_epoch < 0 ||
+                                 P->sched_row0 < 0)))
+    return N2V_EINVAL;
   const bool use_ring = P->window_cache == 1;
   const int sent_cap = (walk_len + 3) & ~3;
   const int ints_per_wave = (2 * sent_cap + (2 * P->window + 1) * P->negative + 3) & ~3;

@@ -741,9 +741,11 @@ struct TwoOnStack {
     }
     return lo;
   }
-  __device__ __forceinline__ TwoOnStack(int n_, int nR_, int rpos_, int nM_, const P *list_)
+  // `below`: the number of listed slots below the return position when the caller has it stored
+  // (wedge slots), else -1 and the list is searched
+  __device__ __forceinline__ TwoOnStack(int n_, int nR_, int rpos_, int nM_, const P *list_, int below = -1)
       : n(n_), nR(nR_), rpos(rpos_), nM(nM_), nO(n_ - nR_ - nM_), list(list_) {
-    const int mA = nM - list_lower(rpos);  // shared slots above the return run
+    const int mA = nM - (below >= 0 ? below : list_lower(rpos));  // shared slots above the return run
     rho = (n - rpos - nR) - mA;            // "other" slots above the return run
     nS = nO + nR;
   }
@@ -782,14 +784,14 @@ struct TwoOnStack {
 template <typename P>
 __device__ __forceinline__ int lane_case_a2_jump(int n, int pick, double r2, const UnitConsts &K,
                                                  int nR, int rpos, int nM, const P *list,
-                                                 bool pickR, bool pickM, int lo_pick) {
+                                                 bool pickR, bool pickM, int lo_pick, int below = -1) {
   const int nO = n - nR - nM;
   const double dn = (double)n;
   const double isum = (double)nR * K.fR + (double)nM * K.fM + (double)nO * K.fO;
   const double EM = K.fM * dn - isum, D = isum - K.fO * dn, DR = isum - K.fR * dn;
   if (nR <= 0 || nM <= 0 || !(D > 0.0) || !(DR > 0.0) || !(EM > 0.0)) return -1;
   if (dn * isum > 2.0e14 || dn * dn * K.fM > 4.0e15) return -1;
-  const TwoOnStack<P> G(n, nR, rpos, nM, list);
+  const TwoOnStack<P> G(n, nR, rpos, nM, list, below);
   const double drho = (double)G.rho, dnR = (double)nR;
   auto Def = [&](double k) -> double {
     if (k <= drho) return k * D;
@@ -924,14 +926,14 @@ __device__ __forceinline__ int lane_case_a2(int n, int pick, double r2, double v
 template <typename P>
 __device__ __forceinline__ int lane_case_b2_jump(int n, int pick, double r2, const UnitConsts &K,
                                                  int nR, int rpos, int nM, const P *list,
-                                                 bool pickR, bool pickM, int lo_pick) {
+                                                 bool pickR, bool pickM, int lo_pick, int below = -1) {
   const int nO = n - nR - nM;
   const double dn = (double)n;
   const double isum = (double)nR * K.fR + (double)nM * K.fM + (double)nO * K.fO;
   const double e = K.fO * dn - isum, eR = K.fR * dn - isum, dM = isum - K.fM * dn;
   if (nR <= 0 || nM <= 0 || nO <= 0 || !(e > 0.0) || !(eR > 0.0) || !(dM > 0.0)) return -1;
   if (dn * isum > 2.0e14 || dn * dn * fmax(K.fR, K.fO) > 4.0e15) return -1;
-  const TwoOnStack<P> G(n, nR, rpos, nM, list);
+  const TwoOnStack<P> G(n, nR, rpos, nM, list, below);
   const double drho = (double)G.rho, dnR = (double)nR;
   auto Xo = [&](double t) -> double {
     if (t <= drho) return t * e;

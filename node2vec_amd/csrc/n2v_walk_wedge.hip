@@ -261,8 +261,11 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
 // is requested together with the hop entry and holds the return position and a short list itself,
 // so a step that needs its list is two INDEPENDENT gathers instead of hop + offset -> list.
 // kMode 0, 1, 3: dyadic p, q (values that are not keep the kernel above); 16-bit positions.
+#ifndef N2V_SLOTS_WAVES
+#define N2V_SLOTS_WAVES 6
+#endif
 template <int kMode>
-__global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wedge_slots_kernel(
+__global__ __launch_bounds__(kWedgeThreads, N2V_SLOTS_WAVES) void walk_exact_wedge_slots_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double q, UnitConsts K, uint64_t seed, int32_t *__restrict__ walks_out,
     uint8_t *__restrict__ valid_out, uint32_t *__restrict__ status) {
@@ -502,11 +505,12 @@ int n2v_walk_wedge_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_s
   if (total == 0) return 1;
   // the return run shares a stack with "other" on ordinary rows: q > 1 with p > q, q < 1 with p < q
   const bool alone_under = K.bO <= 1.0 && K.bR >= K.bO, alone_over = K.bO >= 1.0 && K.bR <= K.bO;
-  if (K.dyadic && g->wedge_slots && !g->wedge_wide && !(g->reserved & 2)) {
+  if (g->wedge_slots && !g->wedge_wide && !(g->reserved & 2)) {
     // the wedge slots are at hand: the list of a step arrives with its hop entry
-    auto sk = alone_under ? n2v::walk_exact_wedge_slots_kernel<0>
-              : alone_over ? n2v::walk_exact_wedge_slots_kernel<3>
-                           : n2v::walk_exact_wedge_slots_kernel<1>;
+    auto sk = !K.dyadic    ? n2v::walk_exact_wedge_slots_kernel<2>
+              : alone_under ? n2v::walk_exact_wedge_slots_kernel<0>
+              : alone_over  ? n2v::walk_exact_wedge_slots_kernel<3>
+                            : n2v::walk_exact_wedge_slots_kernel<1>;
     int64_t sblocks = (total + n2v::kWedgeThreads - 1) / n2v::kWedgeThreads;
     const int64_t scap = n2v::resident_blocks((const void *)sk, n2v::kWedgeThreads, 0);
     if (sblocks > scap) sblocks = scap;

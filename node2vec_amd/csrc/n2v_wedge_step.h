@@ -32,9 +32,9 @@ __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, 
   }
   if constexpr (kMode == 1) {
     if (arr == 3)
-      res = lane_case_a2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+      res = lane_case_a2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick, below);
     else if (arr == 4)
-      res = lane_case_b2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+      res = lane_case_b2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick, below);
     else if (arr == 5)
       res = lane_case_a3_jump<P>(n, pick, r2, K, nR, rpos, nM, isR, isM, lo_pick);
   }
@@ -72,8 +72,8 @@ __device__ __forceinline__ int jump_listed(int arr, int n, int pick, double r2, 
   if (arr == 2)
     return lane_case_b_jump<P, kMode != 0>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick, below);
   if constexpr (kMode == 1) {
-    if (arr == 3) return lane_case_a2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
-    if (arr == 4) return lane_case_b2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick);
+    if (arr == 3) return lane_case_a2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick, below);
+    if (arr == 4) return lane_case_b2_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick, below);
     if (arr == 5) return lane_case_a3_jump<P>(n, pick, r2, K, nR, rpos, nM, isR, isM, lo_pick);
   }
   return -1;
@@ -163,13 +163,15 @@ __device__ __forceinline__ StepFlags step_flags(const n2v_graph &g, const UnitCo
 // entry of `pick`).  Otherwise the replays run here (pair_listed) and the result is always >= 0.
 // kSlots: the edge's list comes from g.wedge_slots (16-bit positions only) instead of wedge_off.
 // A saturated class count (tables that do not belong to this graph) flags N2V_ST_RANGE and keeps
-// `pick`, as the one-launch kernel does.  kMode 0, 1, 3 (dyadic p, q).
+// `pick`, as the one-launch kernel does.  kMode 0, 1, 3 (dyadic p, q); with kSlots also 2 (values
+// that are not dyadic: reference-order row sum, every pairing replayed).
 template <int kMode, bool kJumpOnly, bool kSlots>
 __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &K, const StepFlags &F,
                                           uint32_t u1, uint32_t u2, int32_t s, int64_t vb, int n,
                                           int64_t e_prev, uint32_t ec_prev, n2v_hop &h,
-                                          uint32_t *stage, int lane, uint32_t *status) {
-  constexpr bool kShared = kMode == 1;
+                                          uint32_t *stage, int lane, uint32_t *status,
+                                          uint16_t *lds_list = nullptr) {
+  constexpr bool kShared = kMode == 1 || kMode == 2;
   const int pick = pick_index(u1, n);
   int idx = pick;
   const uint32_t fR = ec_prev >> N2V_EC_RETURN_SHIFT, fM = ec_prev & N2V_EC_SHARED_MASK;
@@ -181,7 +183,8 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
   bool w_loaded = false;
   const uint16_t *slot = nullptr;
   if constexpr (kSlots) slot = reinterpret_cast<const uint16_t *>(g.wedge_slots) + e_prev * 16;
-  if (counts_ok && ((F.need_mem && fM > 0) || (F.always_pair && (fM > 0 || fR > 0)))) {
+  // (not dyadic: the row sum needs the list and the return position at every step)
+  if (counts_ok && ((F.need_mem && fM > 0) || ((kMode == 2 || F.always_pair) && (fM > 0 || fR > 0)))) {
     if constexpr (kSlots) {
       // (asking for the second half only when the list has more than six entries was measured
       // and changes nothing: -3 .. +4 % by (p, q), profiles/r4i_time_slots_on_demand.log)
@@ -209,10 +212,42 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
     else
       lo_pick = wedge_lower(g.wedge_pos, w_off, nM, pick, F.w_wide, isM);
   }
-  const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
-  const double avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;  // :172
-  const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) / avg;       // :173
   const double r2 = (double)u2 * (1.0 / 4294967296.0);
+  double avg;  // :172
+  if constexpr (kMode == 2) {
+    static_assert(kSlots && !kJumpOnly, "values that are not dyadic: the slots kernel, replays inline");
+    // the reference's sum is rounded at every addition; any order of the same positive addends
+    // agrees with it to (n - 1) 2^-53 relatively, so an underfull `pick` whose acceptance clears
+    // that margin is decided from the counts alone; otherwise the row is added up in the
+    // reference's order, run by run (lane_row_sum), the short list read from this lane's LDS row
+    const double b_pick = pick3(isR, isM, K.bR, K.bM, K.bO);
+    const double approx = ((double)nR * K.bR + (double)nM * K.bM + (double)nO * K.bO) / (double)n;
+    const double eps = ((double)n + 8.0) * 4.5e-16;
+    if (b_pick < approx * (1.0 - eps) && r2 < (b_pick / approx) * (1.0 - 2.0 * eps)) {
+      avg = approx;  // only the (decided) comparison below reads it
+    } else {
+      const uint16_t *sum_list = slot + 2;
+      if (nM > kSlotShort) {
+        sum_list = reinterpret_cast<const uint16_t *>(g.wedge_pos) +
+                   ((uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32));
+      } else if (lds_list != nullptr) {
+        uint32_t *row = reinterpret_cast<uint32_t *>(lds_list);
+        row[0] = (uint32_t)sa.y;
+        row[1] = (uint32_t)sa.z;
+        row[2] = (uint32_t)sa.w;
+        row[3] = (uint32_t)sb.x;
+        row[4] = (uint32_t)sb.y;
+        row[5] = (uint32_t)sb.z;
+        row[6] = (uint32_t)sb.w;
+        sum_list = lds_list;
+      }
+      avg = lane_row_sum<uint16_t>(n, K, nR, (int)((uint32_t)sa.x & 0xffffu), nM, sum_list) / (double)n;
+    }
+  } else {
+    const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
+    avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;
+  }
+  const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) / avg;  // :173
   if (p_pick < 1.0 && r2 < p_pick) return idx;  // an accepted underfull slot is final
   // underfull / overfull by class without dividing: fl(b / avg) < 1.0 <=> b < avg
   const bool uR = K.bR < avg, uM = K.bM < avg, uO = K.bO < avg;
@@ -255,8 +290,29 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
                                            w_below);
         if (idx < 0) return -1;
       } else {
-        idx = pair_listed<uint16_t, kMode>(arr, n, pick, r2, K, avg, nR, w_rpos, nM, list, isR, isM,
-                                           lo_pick, reinterpret_cast<uint16_t *>(stage), lane, w_below);
+        bool done = false;
+        if (kMode != 2 && lds_list != nullptr && nM <= kSlotShort) {
+          // (optional, measured and NOT used by the kernels: a short list copied from the slot's
+          // registers to 32 bytes of LDS per lane for the closed forms to read -- 20.3 against
+          // 23.2 G steps/s at (0.5, 2), 16.4 against 18.6 G at (4, 0.25): the flat loads and the
+          // LDS it takes (5 waves per SIMD instead of 6) cost more than probes of a sector that
+          // is still cached, profiles/r4k_time_lds_list_cfg4.log)
+          uint32_t *row = reinterpret_cast<uint32_t *>(lds_list);
+          row[0] = (uint32_t)sa.y;
+          row[1] = (uint32_t)sa.z;
+          row[2] = (uint32_t)sa.w;
+          row[3] = (uint32_t)sb.x;
+          row[4] = (uint32_t)sb.y;
+          row[5] = (uint32_t)sb.z;
+          row[6] = (uint32_t)sb.w;
+          if constexpr (kMode != 2)
+            idx = jump_listed<uint16_t, kMode>(arr, n, pick, r2, K, nR, w_rpos, nM, lds_list, isR, isM,
+                                               lo_pick, w_below);
+          done = idx >= 0;
+        }
+        if (!done)  // long lists; a tie or a thin margin: the replays read the list in memory
+          idx = pair_listed<uint16_t, kMode>(arr, n, pick, r2, K, avg, nR, w_rpos, nM, list, isR, isM,
+                                             lo_pick, reinterpret_cast<uint16_t *>(stage), lane, w_below);
       }
     } else if constexpr (kJumpOnly) {
       // a plain branch on the (uniform) list width: never a select between two loads

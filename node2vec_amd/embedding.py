@@ -310,9 +310,13 @@ class Node2VecHIP(Node2VecBase):
             sentence_base = rank_base(dist.get_rank(), dist.get_world_size(),
                                       rows_max * max(int(p["iter"]), 1))
             sync = sgns.DeltaSync(m, sync_every=p.get("sync_every"), wire=p.get("sync_wire", "fp32"))
+        # the rate falls per job of batch_words words as in gensim (constants.py:58; a corpus whose
+        # walks had to be split into sentences keeps one rate per launch)
+        split = idx.shape[0] != walks.shape[0]
         m.train(idx, int(p["iter"]), float(p["alpha"]), float(p["min_alpha"]),
                 sentence_base=sentence_base, sync=sync, rows_global_max=rows_max,
-                deterministic=bool(p.get("deterministic", False)))
+                deterministic=bool(p.get("deterministic", False)),
+                batch_words=None if split else int(p.get("batch_words") or 0) or None)
         torch.cuda.synchronize(dev)
         p["negative"] = negative
         # the matrices stay in HBM and the tokens stay integer ids (lazy strings): at cfg 4 the

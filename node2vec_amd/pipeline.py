@@ -133,7 +133,13 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
     epochs = max(int(p["iter"]), 1)
     alpha, min_alpha = float(p["alpha"]), float(p["min_alpha"])
     parts_per_row = -(-(L + 1) // sgns.MAX_SENTENCE)
+    batch_words = int(p.get("batch_words") or 0)
     for ep in range(epochs):
+        # gensim's schedule: the rate of a job of batch_words words (constants.py:58); rows of the
+        # virtual corpus are sentences in order (dropped walkers keep their row: they train nothing)
+        sched = None
+        if batch_words and parts_per_row == 1:
+            sched = sgns.JobSchedule.for_corpus(batch_words, L + 1, rows_rank_max, ep, epochs, alpha, min_alpha)
         for k in range(n_batches):
             t0 = clock()
             walks, valid = walk(k)
@@ -146,7 +152,8 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
                 # sentence id = (epoch, rank, row of the rank's virtual corpus): never repeats
                 base = ((ep * world + rank) * rows_rank_max + k * batch_vertices * W) * parts_per_row
                 for j, part in enumerate(torch.split(sgns.split_rows(idx), 1 << 22)):
-                    model.train_block(part, a, base + j * (1 << 22), deterministic)
+                    model.train_block(part, a, base + j * (1 << 22), deterministic, sched,
+                                      k * batch_vertices * W + j * (1 << 22))
             if sync is not None:
                 sync.step()
             t_train += clock() - t1

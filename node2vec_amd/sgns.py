@@ -107,6 +107,35 @@ def init_syn0(n_vocab: int, dim: int, seed: int, device) -> torch.Tensor:
     return out.sub_(0.5).div_(dim)
 
 
+class JobSchedule:
+    """gensim's learning-rate schedule (word2vec.py `_job_producer`, `_get_next_alpha`, called from
+    embedding.py:126): sentences are queued in jobs of at most `batch_words` raw words, and the rate
+    of a job is  max(end, start - (start - end) * (epoch + pushed / total) / epochs)  with `pushed`
+    the sentences queued before it.  For the equal-length sentences of a walk corpus a job is
+    `job_rows` = max(1, batch_words // sentence length) consecutive rows; the kernels evaluate the
+    expression per row (n2v_sgns_params.sched_*), `alpha_of_rows` is the same on the host."""
+
+    def __init__(self, job_rows: int, rows: int, epoch: int, epochs: int, alpha0: float, alpha_min: float):
+        self.job_rows, self.rows = max(1, int(job_rows)), max(1, int(rows))
+        self.epoch, self.epochs = int(epoch), max(1, int(epochs))
+        self.alpha0, self.alpha_min = float(alpha0), float(alpha_min)
+
+    @classmethod
+    def for_corpus(cls, batch_words: int, sentence_len: int, rows: int, epoch: int, epochs: int,
+                   alpha0: float, alpha_min: float) -> "JobSchedule":
+        return cls(max(1, int(batch_words) // max(1, int(sentence_len))), rows, epoch, epochs,
+                   alpha0, alpha_min)
+
+    def alpha_of_rows(self, row0: int, n: int) -> np.ndarray:
+        """fp32 rate of rows row0 .. row0 + n - 1 (numpy float64 arithmetic, as Python's)"""
+        job = (row0 + np.arange(n, dtype=np.int64)) // self.job_rows
+        pushed = (job * self.job_rows).astype(np.float64)
+        epoch_progress = 1.0 * pushed / float(self.rows)
+        progress = (float(self.epoch) + epoch_progress) / float(self.epochs)
+        nxt = self.alpha0 - (self.alpha0 - self.alpha_min) * progress
+        return np.maximum(self.alpha_min, nxt).astype(np.float32)
+
+
 class SgnsModel:
     """The trained state: what gensim keeps in model.wv.vectors / trainables.syn1neg."""
 
@@ -179,8 +208,10 @@ class SgnsModel:
 
     # -- one kernel launch ----------------------------------------------------
     def train_block(self, walks_idx: torch.Tensor, alpha: float, sentence_base: int,
-                    deterministic: bool = False):
-        """walks_idx: int32 [rows, len] vocabulary indices (-1 = out of vocabulary)."""
+                    deterministic: bool = False, sched: Optional["JobSchedule"] = None, row0: int = 0):
+        """walks_idx: int32 [rows, len] vocabulary indices (-1 = out of vocabulary).  `alpha` is
+        the rate of every row of the launch unless `sched` (gensim's per-job schedule) is given;
+        row 0 of the block is then sentence `row0` of the schedule's epoch."""
         L = _lib.load()
         _lib.require_gpu()
         if walks_idx.dtype != torch.int32 or walks_idx.dim() != 2 or not walks_idx.is_cuda:
@@ -191,7 +222,10 @@ class SgnsModel:
         P = _lib.SgnsParams(len(self.vocab), int(sentence_base), self.seed, self.dim, self.window,
                             self.negative, float(alpha), int(bool(deterministic)),
                             self.cum_index_bits, 0 if self.cum_index is None else self.cum_index.data_ptr(),
-                            int(self.max_waves), int(bool(self.batched)), int(self.window_cache), self._hub_rows())
+                            int(self.max_waves), int(bool(self.batched)), int(self.window_cache), self._hub_rows(),
+                            *((0, 0, 0, 0, 0, 0, 0.0, 0.0) if sched is None else
+                              (sched.job_rows, sched.epoch, sched.epochs, 0, int(row0), sched.rows,
+                               sched.alpha0, sched.alpha_min)))
         with torch.cuda.device(walks_idx.device):
             rc = L.n2v_sgns_train(walks_idx.data_ptr(), walks_idx.shape[0], walks_idx.shape[1],
                                   self.syn0.data_ptr(), self.syn1neg.data_ptr(),
@@ -205,9 +239,12 @@ class SgnsModel:
     def train(self, walks_idx: torch.Tensor, epochs: int, alpha: float = 0.025,
               min_alpha: float = 1e-4, block_rows: Optional[int] = None,
               sentence_base: int = 0, deterministic: bool = False, sync=None,
-              rows_global_max: Optional[int] = None):
-        """`epochs` passes over walks_idx; the learning rate falls linearly from alpha
-        to min_alpha with the fraction of rows trained (gensim: by words, per job).
+              rows_global_max: Optional[int] = None, batch_words: Optional[int] = None):
+        """`epochs` passes over walks_idx; the learning rate falls linearly from alpha to
+        min_alpha.  With `batch_words` (gensim's parameter; the reference passes 1000,
+        constants.py:58) it falls exactly as gensim lowers it: per job of
+        max(1, batch_words // sentence length) consecutive sentences (JobSchedule); without, once
+        per launch with the fraction of rows trained.
 
         `sync`: the multi-GPU exchange (DeltaSync, or any object with step()/finish()).
         Every rank must then make the SAME number of calls to it, whatever its own row
@@ -225,12 +262,16 @@ class SgnsModel:
         if sync is not None and getattr(sync, "max_every", 0) is None:
             sync.max_every = max(1, math.ceil(max(grid_rows, 1) / block_rows))  # launches per epoch
         for ep in range(epochs):
+            sched = None
+            if batch_words:
+                sched = JobSchedule.for_corpus(batch_words, walks_idx.shape[1], grid_rows, ep, epochs,
+                                               alpha, min_alpha)
             for lo in range(0, max(grid_rows, 1), block_rows):
                 hi = min(grid_rows, lo + block_rows)
                 a = max(min_alpha, alpha - (alpha - min_alpha) * (done / total))
                 if lo < rows:
                     self.train_block(walks_idx[lo:min(hi, rows)], a,
-                                     sentence_base + ep * grid_rows + lo, deterministic)
+                                     sentence_base + ep * grid_rows + lo, deterministic, sched, lo)
                 done += hi - lo
                 if sync is not None:
                     sync.step()

@@ -224,12 +224,23 @@ def test_fit_streaming_deterministic_equals_the_oracle_end_to_end(oracle):
     s1 = np.zeros_like(s0)
     n_batches = -(-len(start) // bv)
     pairs = 0
+    # the learning rate falls per JOB as in gensim (word2vec.py _job_producer / _get_next_alpha with
+    # the reference's batch_words = 1000, constants.py:58): restated here in plain Python floats
+    total, job_rows = len(start) * W, 1000 // (L + 1)
+
+    def job_alpha(row, ep):
+        pushed = (row // job_rows) * job_rows
+        progress = (ep + 1.0 * pushed / total) / 2
+        return float(np.float32(max(1e-4, 0.025 - (0.025 - 1e-4) * progress)))
+
     for ep in range(2):
         for k in range(n_batches):
-            a = max(1e-4, 0.025 - (0.025 - 1e-4) * ((ep * n_batches + k) / (2 * n_batches)))
-            rows = idx[k * bv * W:(k + 1) * bv * W]
-            pairs += oracle.sgns_train(rows, s0, s1, cum.astype(np.uint32), sample_int, sgns.exp_table(),
-                                       len(ids), ep * len(start) * W + k * bv * W, 5, 32, 4, 5, a)
+            lo, hi = k * bv * W, min((k + 1) * bv * W, total)
+            for j0 in range(lo - lo % job_rows, hi, job_rows):  # the jobs that overlap this batch
+                a, b = max(j0, lo), min(j0 + job_rows, hi)
+                pairs += oracle.sgns_train(idx[a:b], s0, s1, cum.astype(np.uint32), sample_int,
+                                           sgns.exp_table(), len(ids), ep * total + a, 5, 32, 4, 5,
+                                           job_alpha(a, ep))
     assert pairs == out.pairs_trained > 0
     assert np.array_equal(model.syn0.cpu().numpy(), s0)
     assert np.array_equal(model.syn1neg.cpu().numpy(), s1)

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert sorted(_lib.SYMBOLS) == _declared()
     lib.n2v_abi_version.restype = ctypes.c_int
-    assert lib.n2v_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.n2v_abi_version() == _lib.ABI_VERSION == 9
     lib.n2v_status_string.restype = ctypes.c_char_p
     assert lib.n2v_status_string(-1) == b"invalid argument"
 
@@ -56,11 +56,12 @@ def test_ctypes_structs_match_header_layout():
     body = text[text.index("typedef struct n2v_graph {"):text.index("} n2v_graph;")]
     fields = re.findall(r"\*?\s*\b(\w+);", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
     assert fields == [f[0] for f in _lib.Graph._fields_]
-    assert ctypes.sizeof(_lib.SgnsParams) == 3 * 8 + 6 * 4 + 8 + 4 * 4
+    assert ctypes.sizeof(_lib.SgnsParams) == 3 * 8 + 6 * 4 + 8 + 4 * 4 + 4 * 4 + 4 * 8
     assert [f[0] for f in _lib.SgnsParams._fields_] == [
         "n_vocab", "sentence_base", "seed", "dim", "window", "negative", "alpha",
         "deterministic", "cum_index_bits", "cum_index", "max_waves", "batched", "window_cache",
-        "hub_rows"]
+        "hub_rows", "sched_job_rows", "sched_epoch", "sched_epochs", "reserved", "sched_row0",
+        "sched_rows", "sched_alpha0", "sched_alpha_min"]
     body = text[text.index("typedef struct n2v_sgns_params {"):text.index("} n2v_sgns_params;")]
     fields = re.findall(r"\*?\s*\b(\w+);", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
     assert fields == [f[0] for f in _lib.SgnsParams._fields_]

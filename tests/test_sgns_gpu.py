@@ -336,3 +336,45 @@ def test_hub_rows_atomic_updates(oracle):
     ratio = float(np.linalg.norm(got) / np.linalg.norm(s0))
     print("hub_rows hogwild / serial norm of syn0:", ratio)
     assert NORM_RATIO_HUB[0] < ratio < NORM_RATIO_HUB[1], ratio
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_gensim_job_schedule_in_the_kernel_equals_the_oracle_job_by_job(oracle, batched):
+    """n2v_sgns_params.sched_*: the learning rate of a row is that of its gensim JOB (word2vec.py
+    _job_producer / _get_next_alpha: max(end, start - (start - end) * (epoch + pushed / total) /
+    epochs) per batch of batch_words words).  Deterministic mode with the schedule == the oracle
+    called job by job with the rate restated in plain Python floats, bit for bit -- both kernels,
+    launches that start in the middle of a job, two epochs."""
+    from node2vec_amd import sgns
+
+    rng = np.random.default_rng(11)
+    n_vocab, rows, length, dim = 300, 230, 21, 64
+    walks = rng.integers(0, n_vocab, (rows, length)).astype(np.int32)
+    walks[rng.random((rows, length)) < 0.05] = -1
+    counts = np.maximum(np.bincount(walks[walks >= 0], minlength=n_vocab), 1)
+    order = np.argsort(-counts, kind="stable")
+    vocab = sgns.Vocab(torch.arange(n_vocab).cuda(), torch.from_numpy(counts[order]).cuda(),
+                       torch.arange(n_vocab, dtype=torch.int32).cuda())
+    m = sgns.SgnsModel(vocab, dim, 5, 5, seed=3, sample=0.0)
+    m.batched = batched
+    s0, s1 = m.syn0.cpu().numpy().copy(), m.syn1neg.cpu().numpy().copy()
+    idx = torch.from_numpy(walks).cuda()
+    batch_words, epochs, a0, amin = 100, 2, 0.025, 1e-4
+    job_rows = batch_words // length  # 4 sentences per job
+    m.train(idx, epochs, a0, amin, block_rows=70, deterministic=True, batch_words=batch_words)
+    torch.cuda.synchronize()
+    cum = m.cum_table.cpu().numpy().astype(np.uint32)
+    pairs = 0
+    for ep in range(epochs):
+        for j0 in range(0, rows, job_rows):
+            progress = (ep + 1.0 * j0 / rows) / epochs
+            alpha = float(np.float32(max(amin, a0 - (a0 - amin) * progress)))
+            pairs += oracle.sgns_train(walks[j0:j0 + job_rows], s0, s1, cum, None, sgns.exp_table(), n_vocab,
+                                       ep * rows + j0, 3, dim, 5, 5, alpha, batched=batched)
+    assert pairs == int(m.pairs.item()) > 0
+    assert np.array_equal(m.syn0.cpu().numpy(), s0) and np.array_equal(m.syn1neg.cpu().numpy(), s1)
+    # and the host restatement the tests of other modules use
+    sch = sgns.JobSchedule.for_corpus(batch_words, length, rows, 1, epochs, a0, amin)
+    want = [np.float32(max(amin, a0 - (a0 - amin) * ((1 + 1.0 * ((r // job_rows) * job_rows) / rows) / epochs)))
+            for r in range(rows)]
+    assert sch.job_rows == job_rows and np.array_equal(sch.alpha_of_rows(0, rows), np.array(want, np.float32))

@@ -1,7 +1,9 @@
-"""The one scheduling deviation from gensim, quantified on the oracle (CPU, no GPU): gensim
-lowers the learning rate once per JOB (batch_words = 10 000 words of the corpus), the HIP
-trainer once per LAUNCH (sgns.SgnsModel.train: max(65 536 rows, rows / 64) per launch).  Both are
-the same linear ramp sampled at different granularity.  On a planted-partition corpus trained
+"""gensim lowers the learning rate once per JOB (batch_words words of the corpus).  Since round 4
+the HIP trainer does the same when it is given batch_words (n2v_sgns_params.sched_*,
+sgns.JobSchedule: Node2VecHIP.fit and fit_streaming pass the reference's value, constants.py:58);
+called without it (SgnsModel.train(batch_words=None), a corpus of split rows) the rate falls once
+per LAUNCH (max(65 536 rows, rows / 64) per launch), which is what this file quantifies on the
+oracle (CPU, no GPU).  Both are the same linear ramp sampled at different granularity.  On a planted-partition corpus trained
 with the oracle under (a) a per-launch ramp of 8 launches per epoch -- coarser than any real
 run -- and (b) a per-job ramp (10 000 words), the two embeddings agree: Procrustes cosine >= 0.97,
 community AUC equal within 0.01."""
@@ -66,3 +68,23 @@ def test_per_launch_and_per_job_learning_rate_ramps_agree(oracle):
     print("procrustes cosine", cos, "AUC per-launch", a_l, "per-job", a_j)
     assert cos >= 0.97
     assert a_l > 0.9 and a_j > 0.9 and abs(a_l - a_j) <= 0.01
+
+
+def test_job_schedule_is_gensims_expression():
+    """sgns.JobSchedule.alpha_of_rows == word2vec.py _get_next_alpha evaluated at the sentences
+    pushed before each job, in plain Python floats; jobs of batch_words // sentence length rows"""
+    from node2vec_amd.sgns import JobSchedule
+
+    for batch_words, length, rows, epochs in ((1000, 81, 5000, 10), (10_000, 21, 777, 1), (50, 81, 40, 3)):
+        k = max(1, batch_words // length)
+        for ep in range(epochs):
+            sch = JobSchedule.for_corpus(batch_words, length, rows, ep, epochs, 0.025, 1e-4)
+            got = sch.alpha_of_rows(3, rows - 3)
+            for r in (3, 4, k - 1, k, k + 1, rows // 2, rows - 1):
+                if r < 3 or r >= rows:
+                    continue
+                pushed = (r // k) * k
+                progress = (ep + 1.0 * pushed / rows) / epochs
+                want = np.float32(max(1e-4, 0.025 - (0.025 - 1e-4) * progress))
+                assert got[r - 3] == want, (batch_words, length, ep, r)
+            assert (np.diff(got.astype(np.float64)) <= 0).all()  # never rises inside an epoch
