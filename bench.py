@@ -442,12 +442,19 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
         alg = (16 + 4) if hops else (16 + 4 + 4 + 4)
         wedges = leg.g.wedge_off is not None
         slots = wedges and getattr(leg.g, "wedge_slots", None) is not None and "slots" in kernel
+        if slots and leg.g.edge_classes is not None:
+            # a walk visits directed edges ~uniformly, and a step reads the 32-byte slot of the edge
+            # it came along when that edge has shared neighbours (the steps that pair without a list
+            # and read the slot for the return position alone are not counted)
+            share = float(((leg.g.edge_classes & 0xffffff) != 0).float().mean())
+            alg = 16 + 4 + 32 * share
         formula = (("16 (hop entry) + 4 (path write)" if hops else
                     "16 (rowptr pair) + 4 (edge class word) + 4 (col[pick]) + 4 (path write)") +
                    " per step" +
                    (", + 32 (the edge's wedge slot: return position + the list itself up to 14 entries, "
-                    "else its offset and eight pivots) on steps whose edge has shared neighbours or that "
-                    "run the pairing, + 2 per probe of a longer list" if slots else
+                    "else its offset and eight pivots) x the share of edges with shared neighbours (counted "
+                    "in the figure above; probes of longer lists and slots read for the return position "
+                    "alone are not)" if slots else
                     ", + 8 (wedge offset) + 2 per probe of the edge's shared-position list on steps "
                     "whose edge has shared neighbours; the steps that run the pairing read 2 bytes per "
                     "shared neighbour at most" if wedges else
