@@ -58,7 +58,7 @@ HIP_SGNS_PARAMS: Dict[str, Any] = {
     # options of the HIP trainer that gensim does not have (all off = gensim's semantics):
     "batched": False,   # True: negatives shared by the pairs of a centre position (MFMA kernel)
     "hub_rows": None,   # hogwild mode: rows [0, hub_rows) -- the most frequent words -- are updated by
-                        # atomic adds.  None = as many as are held by >= 1 wave at a time on average
+                        # atomic adds.  None = as many as are held by >= 1.5 waves at a time on average
                         # (SgnsModel.auto_hub_rows: gensim's <= 16 threads never share a row, 8 192
                         # waves do); 0 = plain stores everywhere, gensim's code as written
     "deterministic": False,  # True: one wave, sentences in order -- reproducible bit for bit

@@ -178,6 +178,7 @@ class SgnsModel:
         self.sentences_seen = 0
 
     HOGWILD_WAVES = 8192  # what the chip keeps resident (n2v_sgns_train's cap: 256 CUs x 32 waves)
+    HUB_LAMBDA = 1.5      # rows held by at least this many waves on average are updated atomically
 
     def auto_hub_rows(self) -> int:
         """How many of the most frequent rows to update by atomic adds so that the trainer's
@@ -186,10 +187,15 @@ class SgnsModel:
         them.  The GPU runs up to 8 192 waves; each holds one syn0 row (its context word) and
         1 + k syn1neg rows (centre word and negatives), so row i is held by
             lambda_i = waves x (f_i + k n_i)        f_i token share, n_i negative-draw share
-        waves at a time on average.  Rows with lambda_i >= 1 are where read-modify-write stores
-        overwrite what other waves learned (measured on cfg 2: link AUC 0.897 against 0.908 - 0.914
-        at <= 64 waves, profiles/r3a_hogwild_auc_runs.log); they get atomic adds.  The vocabulary is
-        in descending count order, so they are a prefix [0, H).  Opt-in kernels (batched) keep 0."""
+        waves at a time on average.  Rows held by more than one wave more often than not are where
+        read-modify-write stores overwrite what other waves learned (measured on cfg 2: link AUC
+        0.897 against 0.908 - 0.914 at <= 64 waves, profiles/r3a_hogwild_auc_runs.log); they get
+        atomic adds.  The vocabulary is in descending count order, so they are a prefix [0, H).
+        The threshold lambda_i >= 1.5 is the knee of the measured curve on cfg 2
+        (profiles/r4n_hogwild_auc_hub_rows_knee.log, r4l_*: H = 512 / 1024 / 2048 / 4096 / 6196 ->
+        AUC 0.9015 / 0.9041 / 0.9093 / 0.9094 / 0.9119 at +9 / +12 / +17 / +30 / +56 % of the epoch
+        time): the level of the <= 64-wave runs is reached around 2 000 - 3 000 rows, more rows only
+        cost.  Opt-in kernels (batched) keep 0."""
         if self.batched:
             return 0
         n = len(self.vocab)
@@ -199,7 +205,7 @@ class SgnsModel:
         c = self.vocab.counts.to(torch.float64)
         pw = c.pow(self.ns_exponent)
         lam = waves * (c / c.sum() + self.negative * pw / pw.sum())
-        return int((lam >= 1.0).sum().item())
+        return int((lam >= self.HUB_LAMBDA).sum().item())
 
     def _hub_rows(self) -> int:
         if self.hub_rows is None:

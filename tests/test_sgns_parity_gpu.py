@@ -144,17 +144,18 @@ def test_rmat_1m_hogwild_quality_is_stable_over_five_seeds():
     # hub_rows = 4096 (atomic adds on the most frequent rows): no wave overwrites what another
     # learned on a hub; measured 0.9094 +- 0.0015 over 5 seeds (profiles/r3k_hogwild_auc_hub_rows.log),
     # the level of the same trainer capped at 64 waves (0.908 .. 0.914) -- asserted at +- 6 sd
-    # the DEFAULT (hub_rows None -> SgnsModel.auto_hub_rows: the rows held by >= 1 of the 8 192 waves
-    # at a time, 6 196 on this corpus): measured 0.9119 +- 0.0024 over 5 seeds
-    # (profiles/r4l_hogwild_auc_hub_rows_auto.log) -- gensim's <= 16-thread regime, at 3.58 s per
-    # epoch instead of 2.28 s; asserted in the same band as the explicit 4096 below
+    # the DEFAULT (hub_rows None -> SgnsModel.auto_hub_rows: the rows held by >= 1.5 of the 8 192
+    # waves at a time, 2 000 - 4 100 on this corpus): measured 0.9093 +- 0.0025 at 2 048 rows and
+    # 0.9094 +- 0.0015 at 4 096 (profiles/r4n_hogwild_auc_hub_rows_knee.log, r3k_*) -- the level of
+    # gensim's <= 16-thread regime -- for +17 .. +30 % of the epoch time; asserted in the same band
+    # as the explicit 4096 below
     auto = []
     for seed in range(2):
         m = sgns.SgnsModel(vocab, 128, 5, 5, seed=seed, sample=1e-3)
         assert m.hub_rows is None
         m.train(idx, epochs=1, alpha=0.025, min_alpha=1e-4)
         torch.cuda.synchronize()
-        assert 3000 <= m.hub_rows <= 12000, m.hub_rows
+        assert 1300 <= m.hub_rows <= 4200, m.hub_rows
         u = m.syn0 - m.syn0.mean(0)
         u = u / (u.norm(dim=1, keepdim=True) + 1e-30)
         sp, sn = (u[pa] * u[pb]).sum(1), (u[na] * u[nb]).sum(1)
