@@ -276,8 +276,9 @@ class SgnsModel:
                 hi = min(grid_rows, lo + block_rows)
                 a = max(min_alpha, alpha - (alpha - min_alpha) * (done / total))
                 if lo < rows:
+                    extra = {} if sched is None else {"sched": sched, "row0": lo}
                     self.train_block(walks_idx[lo:min(hi, rows)], a,
-                                     sentence_base + ep * grid_rows + lo, deterministic, sched, lo)
+                                     sentence_base + ep * grid_rows + lo, deterministic, **extra)
                 done += hi - lo
                 if sync is not None:
                     sync.step()
