@@ -332,6 +332,7 @@ def main():
         torch.cuda.empty_cache()
     # the walk tables are not needed any more (the CPU baseline reads rowptr / col only)
     g.slots = g.pivots = g.hops = g.hops8 = g.edge_classes = g.wedge_off = g.wedge_pos = None
+    g.wedge_slots = None
     torch.cuda.empty_cache()
 
     # ---- SGNS on the config's model ------------------------------------------------------------
@@ -381,7 +382,8 @@ def prepare_tables(torch, g, p, q, mode, setup, tag):
             timed("hop8_table_build", g.build_hops8)  # 8 bytes per edge; p = q = 1 only
         if (biased or mode != "exact" or g.hops8 is None) and (
                 g.hops is None or (g.edge_classes is not None and not g.hops_have_classes)):
-            timed("hop_table_build", g.build_hops)
+            # (exact biased walks: class words with inline return positions, the slots kernel's form)
+            timed("hop_table_build", lambda: g.build_hops(inline_rpos=(mode == "exact" and biased)))
     elif g.slots is None and (mode == "fast" or not biased):
         timed("alias_tables_build", g.build_alias)
 

@@ -112,7 +112,8 @@ typedef struct n2v_graph {
   const int64_t *hop8_rowptr;   /* [n_vertices + 1] row starts of the hops8 table when its rows are
                                    padded (hop8_align_shift > 0), else NULL (= rowptr) */
   int32_t hop8_align_shift;     /* rows of the hops8 table start at multiples of 2^shift entries */
-  int32_t reserved2;            /* 0 */
+  int32_t reserved2;            /* bit 0 (N2V_HOPS_INLINE_RPOS): the class words of `hops` carry inline
+                                   return positions, see n2v_hops_build; else 0 */
   const uint16_t *wedge_slots;  /* [n_edges][16] or NULL: see n2v_wedge_slots_build */
 } n2v_graph;
 
@@ -123,6 +124,12 @@ typedef struct n2v_graph {
 #define N2V_EC_SHARED_MASK 0x00ffffffu
 #define N2V_EC_RETURN_SHIFT 24
 #define N2V_EC_RETURN_SAT 0xffu
+/* Inside a hop table built with N2V_HOPS_INLINE_RPOS (never in edge_classes[]): an edge WITHOUT
+ * shared neighbours stores  N2V_EC_INLINE | return count (7 bits) << 24 | return position (24
+ * bits)  -- the one thing a step that runs the pairing loop still needs of such an edge, so that it
+ * does not fetch the edge's wedge slot for it (half of the edges of cfg 4, all of cfg 5). */
+#define N2V_EC_INLINE 0x80000000u
+#define N2V_HOPS_INLINE_RPOS 1
 
 int n2v_abi_version(void);
 const char *n2v_status_string(int code);
@@ -157,6 +164,11 @@ int n2v_edge_classes_build(const n2v_graph *g, uint32_t *classes_out, uint32_t *
 
 /* Hop table of a unit-weight graph (struct n2v_hop above): hops_out[e] = {col[e],
  * g->edge_classes ? g->edge_classes[e] : all ones, rowptr[col[e]] | degree(col[e]) << 40}.
+ * With g->wedge_off set and g->reserved2 & N2V_HOPS_INLINE_RPOS the class word of an edge whose
+ * shared count is 0 is written in the N2V_EC_INLINE form (every return count must be below 128,
+ * else N2V_ST_RANGE); such a table serves the wedge-slots kernel of N2V_WALK_EXACT only, and
+ * n2v_walk returns N2V_EINVAL when it would have to hand it to another kernel -- build the plain
+ * form for those (the table takes milliseconds).
  * N2V_EINVAL when the graph has weights or 2^40 edges or more; a row of 2^24 entries or more
  * sets N2V_ST_RANGE in status[0] (read after synchronising): the table must then be discarded
  * (walk without it). */

@@ -17,6 +17,7 @@ namespace n2v {
 __global__ __launch_bounds__(256) void hops_build_kernel(n2v_graph g, n2v_hop *__restrict__ out,
                                                          uint32_t *__restrict__ overflow) {
   bool bad = false;
+  const bool inline_rpos = g.edge_classes && g.wedge_off && (g.reserved2 & N2V_HOPS_INLINE_RPOS);
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < g.n_edges;
        e += (int64_t)gridDim.x * blockDim.x) {
     const int32_t x = g.col[e];
@@ -24,7 +25,16 @@ __global__ __launch_bounds__(256) void hops_build_kernel(n2v_graph g, n2v_hop *_
     const int64_t d = g.rowptr[x + 1] - b;
     bad = bad || d >= (1ll << (64 - N2V_HOP_DEG_SHIFT));
     const uint64_t row = (uint64_t)b | ((uint64_t)d << N2V_HOP_DEG_SHIFT);
-    const uint32_t cls = g.edge_classes ? g.edge_classes[e] : 0xffffffffu;
+    uint32_t cls = g.edge_classes ? g.edge_classes[e] : 0xffffffffu;
+    if (inline_rpos && cls != 0xffffffffu) {
+      // an edge without shared neighbours carries its return position instead of the zero count
+      const uint32_t fR = cls >> N2V_EC_RETURN_SHIFT;
+      bad = bad || fR >= 0x80u;  // (the caller checked: every return count is below 128)
+      if ((cls & N2V_EC_SHARED_MASK) == 0u) {
+        const uint64_t rpos = g.wedge_off[e] >> N2V_WEDGE_RPOS_SHIFT;
+        cls = N2V_EC_INLINE | ((fR & 0x7fu) << N2V_EC_RETURN_SHIFT) | (uint32_t)(rpos & N2V_EC_SHARED_MASK);
+      }
+    }
     int4 v;
     v.x = x;
     v.y = (int)cls;

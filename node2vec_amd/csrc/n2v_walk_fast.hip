@@ -406,6 +406,8 @@ extern "C" int n2v_walk_fast_launch(const n2v_graph *g, const int32_t *start_ids
   const int threads = 256;
   int64_t blocks = (total + threads - 1) / threads;
   const bool hops = unit && g->hops != nullptr;
+  // (a hop table with inline return positions is read by the exact slots kernel alone)
+  if (hops && (g->reserved2 & N2V_HOPS_INLINE_RPOS) && !(p == 1.0 && q == 1.0)) return N2V_EINVAL;
   // class-first sampling: counts, return position and shared positions of every edge at hand
   const bool cf = unit && (hops || g->edge_classes) && g->wedge_off && g->wedge_pos &&
                   !(p == 1.0 && q == 1.0);

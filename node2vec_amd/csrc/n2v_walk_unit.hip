@@ -1748,6 +1748,8 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
                                       walks_out, valid_out, status, stream);
     if (rw != 0) return rw;
   }
+  // (a hop table with inline return positions is read by the slots kernel alone)
+  if (g->hops && (g->reserved2 & N2V_HOPS_INLINE_RPOS) && !(p == 1.0 && q == 1.0)) return N2V_EINVAL;
   if (dyadic && lanes_regime && total < 0xffffff00ll &&
       (g->edge_classes || g->hops || (p == 1.0 && q == 1.0))) {
     int64_t blocks = (total + 255) / 256;

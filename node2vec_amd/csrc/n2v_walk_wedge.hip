@@ -520,6 +520,7 @@ int n2v_walk_wedge_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_s
     if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
     return 1;
   }
+  if (g->reserved2 & N2V_HOPS_INLINE_RPOS) return N2V_EINVAL;  // that hop table is the slots kernel's
   auto kernel = !K.dyadic    ? n2v::walk_exact_wedge_kernel<2>
                 : alone_under ? n2v::walk_exact_wedge_kernel<0>
                 : alone_over  ? n2v::walk_exact_wedge_kernel<3>

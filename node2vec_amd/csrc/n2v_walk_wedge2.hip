@@ -482,6 +482,7 @@ int n2v_walk_wedge2_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_
   using namespace n2v;
   if (!g->hops || !g->wedge_off || !g->wedge_pos || g->w || g->w64 || !K.dyadic) return 0;
   if (p == 1.0 && q == 1.0) return 0;
+  if (g->reserved2 & N2V_HOPS_INLINE_RPOS) return 0;  // that hop table is the slots kernel's
   const int64_t total = n_start * (int64_t)num_walks;
   if (total >= 0xffffff00ll || walk_length >= (int32_t)kRecDone - 1) return 0;
   if (!workspace || workspace_bytes < n2v_walk_wedge2_workspace(total)) return 0;

@@ -146,7 +146,7 @@ __device__ __forceinline__ int slot_lower(const int4 &sa, const int4 &sb, int nM
 
 // what a kernel needs of (p, q) beyond UnitConsts, computed once
 struct StepFlags {
-  bool need_mem, always_pair, merge_r, w_wide;
+  bool need_mem, always_pair, merge_r, w_wide, inline_rpos;
 };
 __device__ __forceinline__ StepFlags step_flags(const n2v_graph &g, const UnitConsts &K, double q) {
   StepFlags f;
@@ -154,6 +154,7 @@ __device__ __forceinline__ StepFlags step_flags(const n2v_graph &g, const UnitCo
   f.always_pair = K.bO > 1.0;  // 1/q > 1: "other" overfull, an overfull `pick` has no quick exit
   f.merge_r = K.bR == K.bO;    // p == q: the return slot IS an "other" slot (:223-230)
   f.w_wide = g.wedge_wide != 0;
+  f.inline_rpos = (g.reserved2 & N2V_HOPS_INLINE_RPOS) != 0;  // (the slots kernel's hop table only)
   return f;
 }
 
@@ -174,17 +175,23 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
   constexpr bool kShared = kMode == 1 || kMode == 2;
   const int pick = pick_index(u1, n);
   int idx = pick;
-  const uint32_t fR = ec_prev >> N2V_EC_RETURN_SHIFT, fM = ec_prev & N2V_EC_SHARED_MASK;
-  const bool counts_ok = fR != N2V_EC_RETURN_SAT && fM != N2V_EC_SHARED_MASK;
+  // an edge without shared neighbours may carry its return position in the class word itself
+  // (N2V_EC_INLINE, slots kernel only): its slot is then never fetched
+  const bool inl = kSlots && F.inline_rpos && ec_prev != 0xffffffffu && (ec_prev & N2V_EC_INLINE) != 0u;
+  const uint32_t fR = inl ? ((ec_prev >> N2V_EC_RETURN_SHIFT) & 0x7fu) : (ec_prev >> N2V_EC_RETURN_SHIFT);
+  const uint32_t fM = inl ? 0u : (ec_prev & N2V_EC_SHARED_MASK);
+  const bool counts_ok = inl || (fR != N2V_EC_RETURN_SAT && fM != N2V_EC_SHARED_MASK);
   // this step's wedge list: its offset (its slot) is requested before the hop so both loads
   // overlap; steps whose edge has no shared neighbour need it only if the pairing runs (lazy)
   uint64_t wraw = 0;
   int4 sa = make_int4(0, 0, 0, 0), sb = make_int4(0, 0, 0, 0);
-  bool w_loaded = false;
+  bool w_loaded = inl;
+  if (inl) sa.x = (int)(ec_prev & 0xffffu);  // halfword 0: the return position (16-bit positions), 1: below = 0
   const uint16_t *slot = nullptr;
   if constexpr (kSlots) slot = reinterpret_cast<const uint16_t *>(g.wedge_slots) + e_prev * 16;
   // (not dyadic: the row sum needs the list and the return position at every step)
-  if (counts_ok && ((F.need_mem && fM > 0) || ((kMode == 2 || F.always_pair) && (fM > 0 || fR > 0)))) {
+  if (!inl && counts_ok &&
+      ((F.need_mem && fM > 0) || ((kMode == 2 || F.always_pair) && (fM > 0 || fR > 0)))) {
     if constexpr (kSlots) {
       // (asking for the second half only when the list has more than six entries was measured
       // and changes nothing: -3 .. +4 % by (p, q), profiles/r4i_time_slots_on_demand.log)

@@ -46,6 +46,7 @@ class DeviceGraph:
         self.wedge_pos: Optional[torch.Tensor] = None  # int16 / int32 [sum of shared counts]
         self.wedge_tried = False  # randomwalk.walk tries to build the table once
         self.wedge_slots: Optional[torch.Tensor] = None  # int16 [E, 16]: n2v_wedge_slots_build
+        self.hops_inline_rpos = False  # the hop table's class words carry return positions (slots kernel)
 
     @property
     def w(self) -> torch.Tensor:
@@ -143,6 +144,7 @@ class DeviceGraph:
         g.hops8_bits, g.hops8_shift = self.hops8_bits, self.hops8_shift
         # a declined build (escape share, memory budget) stays declined on the copy
         g.hops8_tried, g.wedge_tried = self.hops8_tried, self.wedge_tried
+        g.hops_inline_rpos = self.hops_inline_rpos
         return g
 
     def c_struct(self) -> _lib.Graph:
@@ -161,7 +163,7 @@ class DeviceGraph:
                           0 if self.hops8 is None else self.hops8.data_ptr(),
                           self.hops8_bits[0], self.hops8_bits[1],
                           0 if self.hops8_rowptr is None else self.hops8_rowptr.data_ptr(),
-                          self.hops8_shift, 0,
+                          self.hops8_shift, int(self.hops_inline_rpos and self.hops is not None),
                           0 if self.wedge_slots is None else self.wedge_slots.data_ptr())
 
     # -- a9 -----------------------------------------------------------------------
@@ -292,7 +294,16 @@ class DeviceGraph:
 
     HOP_MAX_DEGREE = 1 << 24  # n2v_hop packs the degree into 24 bits
 
-    def build_hops(self, with_classes: bool = False) -> "DeviceGraph":
+    def can_inline_rpos(self) -> bool:
+        """the hop table may carry return positions in its class words (N2V_EC_INLINE): wedge table
+        with 16-bit positions and wedge slots at hand, every return count below 128"""
+        if self.edge_classes is None or self.wedge_off is None or self.wedge_slots is None:
+            return False
+        if self.wedge_pos is None or self.wedge_pos.dtype != torch.int16:
+            return False
+        return self.n_edges == 0 or int((self.edge_classes >> 24 & 0xff).max()) < 128
+
+    def build_hops(self, with_classes: bool = False, inline_rpos: bool = False) -> "DeviceGraph":
         """Hop table (n2v_hops_build): per edge {neighbour id, class counts of the edge, row
         pointer and degree of the neighbour} in 16 bytes, so that a walk step is one gather.
         `with_classes` builds the per-edge class counts first (biased walks need them inside
@@ -310,15 +321,19 @@ class DeviceGraph:
             self.hops = None
             return self
         self.hops = None  # the kernel must not read a half-written table through c_struct()
+        inline_rpos = bool(inline_rpos) and self.can_inline_rpos()
         hops = torch.empty((self.n_edges, 4), dtype=torch.int32, device=self.device)
         status = torch.zeros(4, dtype=torch.int32, device=self.device)
+        cs = self.c_struct()
+        cs.reserved2 = 1 if inline_rpos else 0  # N2V_HOPS_INLINE_RPOS
         with torch.cuda.device(self.device):
-            rc = L.n2v_hops_build(self.c_struct(), hops.data_ptr(), status.data_ptr(),
-                                  _lib.current_stream_ptr())
+            rc = L.n2v_hops_build(cs, hops.data_ptr(), status.data_ptr(), _lib.current_stream_ptr())
         _lib.check(rc, "n2v_hops_build")
         if int(status[0].item()) & _lib.ST_RANGE:
+            self.hops_inline_rpos = False
             return self
         self.hops = hops
+        self.hops_inline_rpos = inline_rpos
         self.hops_have_classes = self.edge_classes is not None
         return self
 

@@ -147,8 +147,14 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
         # hop table (16 bytes per edge): one gather per step instead of two or three.  It embeds
         # the class counts, so it is (re)built after them when a biased walk first needs them.
         want_classes = graph.edge_classes is not None
-        if graph.hops is None or (want_classes and not graph.hops_have_classes):
-            graph.build_hops()
+        # the exact slots kernel reads return positions out of the hop table's class words; every
+        # other kernel needs the plain form (the table is rebuilt in milliseconds when it changes hands)
+        want_inline = (mode == "exact" and biased and use_edge_classes and use_wedges and use_wedge_kernel
+                       and use_wedge_slots and not use_workspace and graph.wedge_slots is not None
+                       and tables_regime(return_param, inout_param) and graph.can_inline_rpos())
+        if (graph.hops is None or (want_classes and not graph.hops_have_classes)
+                or (biased and graph.hops_inline_rpos != want_inline)):
+            graph.build_hops(inline_rpos=want_inline)
     start_ids = start_ids.to(device=graph.device, dtype=torch.int32).contiguous()
     n_start = start_ids.numel()
     total = n_start * num_walks

@@ -77,6 +77,51 @@ def test_wedge_lists_equal_the_per_step_set_intersection(wide):
     assert n_long > 100
 
 
+def test_hop_table_with_inline_return_positions():
+    """n2v_hops_build with N2V_HOPS_INLINE_RPOS: the class word of an edge WITHOUT shared neighbours
+    is N2V_EC_INLINE | return count << 24 | return position, every other entry is edge_classes[e];
+    exact biased walks through that table (slots kernel) equal those through the plain one"""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+
+    rng = np.random.default_rng(23)
+    nv = 900
+    src = np.concatenate([rng.integers(0, nv, 7000), rng.integers(0, 5, 1500), rng.integers(0, nv, 1500)])
+    dst = np.concatenate([rng.integers(0, nv, 7000), rng.integers(0, nv, 1500), rng.integers(0, 5, 1500)])
+    g = DeviceGraph.from_edges(np.concatenate([src, dst]), np.concatenate([dst, src]), None, n_vertices=nv,
+                               device="cuda")
+    g.build_wedges()
+    assert g.can_inline_rpos()
+    g.build_hops(inline_rpos=True)
+    assert g.hops_inline_rpos and g.c_struct().reserved2 == 1
+    ec = g.edge_classes.cpu().numpy().astype(np.uint32)
+    off = g.wedge_off.cpu().numpy().astype(np.uint64)
+    cls = g.hops.cpu().numpy()[:, 1].astype(np.uint32)
+    plain = (ec & 0xffffff) != 0
+    assert 100 < plain.sum() < len(ec) - 100  # both kinds of edges
+    assert np.array_equal(cls[plain], ec[plain])
+    want = np.uint32(0x80000000) | (ec[~plain] & np.uint32(0x7f000000)) | (off[~plain] >> np.uint64(40)).astype(np.uint32)
+    assert np.array_equal(cls[~plain], want)
+    start = rw.start_vertices(g)
+    for p, q in ((0.5, 2.0), (4.0, 0.25), (4.0, 2.0), (3.0, 0.7)):
+        a, av = rw.walk(g, start, 3, 30, p, q, 5)
+        assert g.hops_inline_rpos  # the default path keeps the inline form
+        b, bv = rw.walk(g, start, 3, 30, p, q, 5, use_wedge_slots=False)
+        assert not g.hops_inline_rpos  # another kernel: the table was rebuilt in the plain form
+        assert torch.equal(a, b) and torch.equal(av, bv)
+    # a caller that hands the inline form to another kernel is told so
+    g.build_hops(inline_rpos=True)
+    from node2vec_amd import _lib
+    cs = g.c_struct()
+    cs.wedge_slots = 0
+    walks = torch.empty((start.numel(), 5), dtype=torch.int32, device="cuda")
+    valid = torch.empty(start.numel(), dtype=torch.uint8, device="cuda")
+    status = torch.zeros(4, dtype=torch.int32, device="cuda")
+    rc = _lib.load().n2v_walk(cs, start.data_ptr(), start.numel(), 1, 4, 0.5, 2.0, 1, 0, walks.data_ptr(),
+                              valid.data_ptr(), status.data_ptr(), None)
+    assert rc == _lib.EINVAL
+
+
 def test_wedge_table_respects_its_memory_bound():
     from node2vec_amd import synthetic
 
