@@ -207,6 +207,76 @@ __device__ __forceinline__ bool wedge_has(const void *base, int64_t off, int cnt
   return wedge_has_t<uint16_t>(base, off, cnt, pos);
 }
 
+// ---- wedge slots (n2v_wedge_slots_build, include/n2v_hip.h): 16 halfwords per edge, loaded as two
+// 16-byte words.  [0] return position, [1] list entries below it, then the list itself (<= 14
+// entries) or, for a longer one, its 64-bit offset in wedge_pos at [4 .. 8) and eight pivots
+// list[((k + 1) n) / 9] at [8 .. 16).
+constexpr int kSlotShort = 14;
+constexpr int kSlotPivots = 8;
+
+__device__ __forceinline__ int slot_half(const int4 &a, const int4 &b, int k) {  // halfword k, k constant
+  const int w = k >> 1;
+  const uint32_t d = (uint32_t)(w == 0 ? a.x : w == 1 ? a.y : w == 2 ? a.z : w == 3 ? a.w
+                              : w == 4 ? b.x : w == 5 ? b.y : w == 6 ? b.z : b.w);
+  return (int)((k & 1) ? (d >> 16) : (d & 0xffffu));
+}
+
+// lower bound of `pick` in the list of a slot (entries below it; found = it is in the list)
+__device__ __forceinline__ int slot_lower(const int4 &sa, const int4 &sb, int nM, int pick,
+                                          const uint16_t *wedge_pos, bool &found) {
+  found = false;
+  if (nM <= kSlotShort) {
+    int lo = 0;
+#pragma unroll
+    for (int k = 0; k < kSlotShort; ++k) {
+      const int e = slot_half(sa, sb, k + 2);
+      const bool in = k < nM;
+      lo += (in && e < pick) ? 1 : 0;
+      found = found || (in && e == pick);
+    }
+    return lo;
+  }
+  const uint64_t off = (uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32);
+  const uint16_t *list = wedge_pos + off;
+  int j = 0;  // pivots below pick
+#pragma unroll
+  for (int k = 0; k < kSlotPivots; ++k) j += (slot_half(sa, sb, 8 + k) < pick) ? 1 : 0;
+  // list[idx(j - 1)] < pick <= list[idx(j)], idx(k) = ((k + 1) nM) / 9, idx(-1) = -1, idx(8) = nM
+  int lo = j == 0 ? 0 : (int)(((int64_t)j * nM) / 9) + 1;
+  int hi = j == kSlotPivots ? nM : (int)(((int64_t)(j + 1) * nM) / 9);
+  const int top = hi;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)list[mid] < pick)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  if (lo < nM) {
+    int e = 0;  // list[lo]: the pivot itself when the search ran to the end of its ninth
+    if (lo == top && j < kSlotPivots) {
+#pragma unroll
+      for (int k = 0; k < kSlotPivots; ++k)
+        if (k == j) e = slot_half(sa, sb, 8 + k);
+    } else {
+      e = (int)list[lo];
+    }
+    found = e == pick;
+  }
+  return lo;
+}
+
+// entry i of the list of a slot (i < n), i not a compile-time constant
+__device__ __forceinline__ int slot_entry(const int4 &sa, const int4 &sb, int n, int i,
+                                          const uint16_t *wedge_pos) {
+  if (n > kSlotShort)
+    return (int)wedge_pos[((uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32)) + (uint64_t)i];
+  const int w = (i + 2) >> 1;  // dword 1 .. 7 of the slot
+  const uint32_t d = (uint32_t)(w < 4 ? (w == 1 ? sa.y : (w == 2 ? sa.z : sa.w))
+                                      : (w < 6 ? (w == 4 ? sb.x : sb.y) : (w == 6 ? sb.z : sb.w)));
+  return (int)((i & 1) ? (d >> 16) : (d & 0xffffu));
+}
+
 __device__ inline int64_t wave_sum_i64(int64_t v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

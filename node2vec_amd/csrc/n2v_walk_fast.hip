@@ -123,6 +123,8 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
   // "pick is in the list of the edge (s -> v)": one offset gather + a search in a short list
   const bool have_w = have_ec && g.wedge_off != nullptr && g.wedge_pos != nullptr;
   const bool w_wide = g.wedge_wide != 0;
+  // wedge slots (n2v_wedge_slots_build): return position and list of an edge with ONE gather
+  const bool have_slots = have_w && !w_wide && g.wedge_slots != nullptr;
   int64_t e_prev = 0;  // the edge (s -> v) walked last
   const bool fold_return = have_ec && inv_p > b_hi;
   const bool base_aligned = (reinterpret_cast<uintptr_t>(walks_out) & 63u) == 0;
@@ -240,6 +242,7 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
     const uint32_t u1 = (uint32_t)(bits >> 32), u2 = (uint32_t)bits;
     int pick = pick_index(u1, n);
     uint64_t wraw = 0;  // kClassFirst: wedge_off of the edge walked last
+    int4 ws_a = make_int4(0, 0, 0, 0), ws_b = make_int4(0, 0, 0, 0);  // ... or its wedge slot
     if (kClassFirst && !plain) {
       if (cls < 0) {  // first trial of the step: the layer, then (sets without "other") the slot
         const double uc = (double)u2 * (1.0 / 4294967296.0) * m_tot;
@@ -257,22 +260,39 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
           }
         }
         if (!(cls & 4)) {  // by index: the return run, then the wedge list
-          wraw = g.wedge_off[e_prev];
           const int cnt_r = (cls & 1) ? n_ret : 0, cnt_m = (cls & 2) ? shared : 0;
           int kk = (int)(ul / wl);
           kk = kk < cnt_r + cnt_m ? kk : cnt_r + cnt_m - 1;
           kk = kk < 0 ? 0 : kk;
-          if (kk < cnt_r) {
-            pick = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT) + kk;
+          if (have_slots) {
+            const int4 *slot = reinterpret_cast<const int4 *>(g.wedge_slots + e_prev * 16);
+            ws_a = slot[0];
+            ws_b = slot[1];
+            pick = kk < cnt_r ? (int)((uint32_t)ws_a.x & 0xffffu) + kk
+                              : slot_entry(ws_a, ws_b, shared, kk - cnt_r,
+                                           reinterpret_cast<const uint16_t *>(g.wedge_pos));
           } else {
-            const int64_t off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK) + (kk - cnt_r);
-            pick = w_wide ? (int)reinterpret_cast<const uint32_t *>(g.wedge_pos)[off]
-                          : (int)reinterpret_cast<const uint16_t *>(g.wedge_pos)[off];
+            wraw = g.wedge_off[e_prev];
+            if (kk < cnt_r) {
+              pick = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT) + kk;
+            } else {
+              const int64_t off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK) + (kk - cnt_r);
+              pick = w_wide ? (int)reinterpret_cast<const uint32_t *>(g.wedge_pos)[off]
+                            : (int)reinterpret_cast<const uint16_t *>(g.wedge_pos)[off];
+            }
           }
         }
       }
       // a uniform draw that must stay clear of the shared slots: the list of the edge
-      if ((cls & 4) && !(cls & 2) && shared > 0) wraw = g.wedge_off[e_prev];
+      if ((cls & 4) && !(cls & 2) && shared > 0) {
+        if (have_slots) {
+          const int4 *slot = reinterpret_cast<const int4 *>(g.wedge_slots + e_prev * 16);
+          ws_a = slot[0];
+          ws_b = slot[1];
+        } else {
+          wraw = g.wedge_off[e_prev];
+        }
+      }
     }
     int32_t x;
     int64_t e = vb + pick;  // kUnit: the edge (v -> x) itself
@@ -295,8 +315,15 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
     if (kClassFirst && !plain) {
       if (cls & 4) {  // drawn over the whole row: outside the layer's set -> again, inside the layer
         if (!(cls & 1)) accept = x != s;
-        if (accept && !(cls & 2) && shared > 0)
-          accept = !wedge_has(g.wedge_pos, (int64_t)(wraw & N2V_WEDGE_OFF_MASK), shared, pick, w_wide);
+        if (accept && !(cls & 2) && shared > 0) {
+          if (have_slots) {
+            bool found = false;
+            slot_lower(ws_a, ws_b, shared, pick, reinterpret_cast<const uint16_t *>(g.wedge_pos), found);
+            accept = !found;
+          } else {
+            accept = !wedge_has(g.wedge_pos, (int64_t)(wraw & N2V_WEDGE_OFF_MASK), shared, pick, w_wide);
+          }
+        }
       }
     } else if (!plain) {
       const uint64_t b2 = mix64(bits ^ 0xC2B2AE3D27D4EB4FULL);

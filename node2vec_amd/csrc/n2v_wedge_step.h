@@ -89,60 +89,7 @@ __device__ __forceinline__ int jump_listed(int arr, int n, int pick, double r2, 
 //                                                           list[((k + 1) n) / 9], k = 0 .. 7
 // so that ~80 % of the steps that need a list (cfg 4: 39 % of all steps) take one sector instead
 // of two, and a long list is entered at the right ninth (one more sector up to ~290 entries).
-constexpr int kSlotShort = 14;
-constexpr int kSlotPivots = 8;
-
-__device__ __forceinline__ int slot_half(const int4 &a, const int4 &b, int k) {  // halfword k, k constant
-  const int w = k >> 1;
-  const uint32_t d = (uint32_t)(w == 0 ? a.x : w == 1 ? a.y : w == 2 ? a.z : w == 3 ? a.w
-                              : w == 4 ? b.x : w == 5 ? b.y : w == 6 ? b.z : b.w);
-  return (int)((k & 1) ? (d >> 16) : (d & 0xffffu));
-}
-
-// lower bound of `pick` in the list of a slot (entries below it; found = it is in the list)
-__device__ __forceinline__ int slot_lower(const int4 &sa, const int4 &sb, int nM, int pick,
-                                          const uint16_t *wedge_pos, bool &found) {
-  found = false;
-  if (nM <= kSlotShort) {
-    int lo = 0;
-#pragma unroll
-    for (int k = 0; k < kSlotShort; ++k) {
-      const int e = slot_half(sa, sb, k + 2);
-      const bool in = k < nM;
-      lo += (in && e < pick) ? 1 : 0;
-      found = found || (in && e == pick);
-    }
-    return lo;
-  }
-  const uint64_t off = (uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32);
-  const uint16_t *list = wedge_pos + off;
-  int j = 0;  // pivots below pick
-#pragma unroll
-  for (int k = 0; k < kSlotPivots; ++k) j += (slot_half(sa, sb, 8 + k) < pick) ? 1 : 0;
-  // list[idx(j - 1)] < pick <= list[idx(j)], idx(k) = ((k + 1) nM) / 9, idx(-1) = -1, idx(8) = nM
-  int lo = j == 0 ? 0 : (int)(((int64_t)j * nM) / 9) + 1;
-  int hi = j == kSlotPivots ? nM : (int)(((int64_t)(j + 1) * nM) / 9);
-  const int top = hi;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if ((int)list[mid] < pick)
-      lo = mid + 1;
-    else
-      hi = mid;
-  }
-  if (lo < nM) {
-    int e = 0;  // list[lo]: the pivot itself when the search ran to the end of its ninth
-    if (lo == top && j < kSlotPivots) {
-#pragma unroll
-      for (int k = 0; k < kSlotPivots; ++k)
-        if (k == j) e = slot_half(sa, sb, 8 + k);
-    } else {
-      e = (int)list[lo];
-    }
-    found = e == pick;
-  }
-  return lo;
-}
+// (kSlotShort, kSlotPivots, slot_half, slot_lower: n2v_common.h -- the fast kernel reads slots too)
 
 // what a kernel needs of (p, q) beyond UnitConsts, computed once
 struct StepFlags {

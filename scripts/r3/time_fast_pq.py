@@ -26,14 +26,17 @@ b = min(1 << 20, start.numel())
 walks = torch.empty((b * 10, 81), dtype=torch.int32, device="cuda")
 valid = torch.empty(b * 10, dtype=torch.uint8, device="cuda")
 PQ = [(0.5, 2.0), (0.25, 4.0), (1.0, 2.0), (2.0, 2.0), (4.0, 2.0), (2.0, 1.0), (4.0, 0.25), (0.5, 0.25), (3.0, 0.7), (0.7, 1.3)]
-for wedges in (True, False):
+if os.environ.get("PQ"):
+    PQ = [tuple(float(x) for x in pq.split(",")) for pq in os.environ["PQ"].split(";")]
+# layered sampler reading the wedge slots, reading wedge_off + lists, rejection sampler
+for wedges, slots in ((True, True), (True, False), (False, False)):
     for p, q in PQ:
         st = {}
 
         def run(k):
             lo = (k * b) % max(1, start.numel() - b + 1)
             rw.walk(g, start[lo:lo + b], 10, 80, p, q, 42, mode="fast", out=(walks, valid), check=False,
-                    use_wedges=wedges, stats=st)
+                    use_wedges=wedges, use_wedge_slots=slots, stats=st)
 
         run(0)
         torch.cuda.synchronize()
@@ -43,6 +46,6 @@ for wedges in (True, False):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 5
         steps = int(valid.sum()) * 80
-        print(f"{cfg} fast p={p} q={q} {'layered' if wedges and g.wedge_off is not None else 'rejection'}: "
+        print(f"{cfg} fast p={p} q={q} {('layered, slots' if slots else 'layered, wedge_off') if wedges and g.wedge_off is not None else 'rejection'}: "
               f"{b * 800 / dt / 1e9:6.2f} G steps/s ({dt * 1e3:6.2f} ms per launch), "
               f"{int(st['trials'].item()) / max(steps, 1):.3f} trials per step", flush=True)

@@ -193,6 +193,10 @@ def test_hop_table_and_class_counts_change_no_bit(oracle, pq):
     fd, fdv = rw.walk(g, start, 3, 25, p, q, 9, mode="fast", use_wedges=False, use_hops=False)
     assert torch.equal(fa, fb) and torch.equal(fav, fbv)
     assert torch.equal(fc, fd) and torch.equal(fcv, fdv)
+    # the layered sampler reads an edge's list from its wedge slot or through wedge_off: same draws
+    fe, fev = rw.walk(g, start, 3, 25, p, q, 9, mode="fast", use_wedge_slots=False)
+    assert (p == q == 1.0) or g.wedge_slots is not None
+    assert torch.equal(fa, fe) and torch.equal(fav, fev)
     assert torch.equal(fa[:, :2], a[:, :2]) and torch.equal(fc[:, :2], a[:, :2])
     if p == q == 1.0:
         assert torch.equal(fa, a) and torch.equal(fc, a)
