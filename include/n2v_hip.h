@@ -166,9 +166,9 @@ int n2v_edge_classes_build(const n2v_graph *g, uint32_t *classes_out, uint32_t *
  * g->edge_classes ? g->edge_classes[e] : all ones, rowptr[col[e]] | degree(col[e]) << 40}.
  * With g->wedge_off set and g->reserved2 & N2V_HOPS_INLINE_RPOS the class word of an edge whose
  * shared count is 0 is written in the N2V_EC_INLINE form (every return count must be below 128,
- * else N2V_ST_RANGE); such a table serves the wedge-slots kernel of N2V_WALK_EXACT only, and
- * n2v_walk returns N2V_EINVAL when it would have to hand it to another kernel -- build the plain
- * form for those (the table takes milliseconds).
+ * else N2V_ST_RANGE); such a table serves the wedge-slots kernel of N2V_WALK_EXACT and
+ * N2V_WALK_FAST, and n2v_walk returns N2V_EINVAL when it would have to hand it to another exact
+ * kernel -- build the plain form for those (the table takes milliseconds).
  * N2V_EINVAL when the graph has weights or 2^40 edges or more; a row of 2^24 entries or more
  * sets N2V_ST_RANGE in status[0] (read after synchronising): the table must then be discarded
  * (walk without it). */

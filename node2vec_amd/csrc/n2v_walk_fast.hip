@@ -105,7 +105,7 @@ __device__ __forceinline__ int lower_bound_lane(const int32_t *a, int m, int32_t
 //     SHARED slots (q < 1) needs the list.
 // P(slot) = sum over the layers that contain it of (layer mass / total) / |set| = weight / total.
 // Trials per step: 1.86 -> 1.00x at p = 0.5, q = 2.
-template <bool kUnit, bool kHops, bool kClassFirst>
+template <bool kUnit, bool kHops, bool kClassFirst, bool kSlots = false>
 __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double p, double q, uint64_t seed, int32_t *__restrict__ walks_out,
@@ -124,7 +124,14 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
   const bool have_w = have_ec && g.wedge_off != nullptr && g.wedge_pos != nullptr;
   const bool w_wide = g.wedge_wide != 0;
   // wedge slots (n2v_wedge_slots_build): return position and list of an edge with ONE gather
-  const bool have_slots = have_w && !w_wide && g.wedge_slots != nullptr;
+  // (its own code instance, launched at q < 1 only -- where every "other" draw is tested against the
+  // list: there the slots win 9 - 10 %; at q >= 1 nearly every step is a plain uniform draw and the
+  // eight registers of a slot cost 9 - 10 %, profiles/r4r_time_fast_slots_cfg4.log)
+  const bool have_slots = kSlots && have_w && !w_wide && g.wedge_slots != nullptr;
+  // hop table with inline return positions (N2V_HOPS_INLINE_RPOS): an edge without shared
+  // neighbours says where its return run starts in the class word itself
+  const bool inl_tab = kHops && (g.reserved2 & N2V_HOPS_INLINE_RPOS) != 0;
+  int rpos_inl = -1;
   int64_t e_prev = 0;  // the edge (s -> v) walked last
   const bool fold_return = have_ec && inv_p > b_hi;
   const bool base_aligned = (reinterpret_cast<uintptr_t>(walks_out) & 63u) == 0;
@@ -264,7 +271,9 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
           int kk = (int)(ul / wl);
           kk = kk < cnt_r + cnt_m ? kk : cnt_r + cnt_m - 1;
           kk = kk < 0 ? 0 : kk;
-          if (have_slots) {
+          if (rpos_inl >= 0 && cnt_m == 0) {
+            pick = rpos_inl + kk;  // the return run of an edge without shared neighbours: no gather
+          } else if (have_slots) {
             const int4 *slot = reinterpret_cast<const int4 *>(g.wedge_slots + e_prev * 16);
             ws_a = slot[0];
             ws_b = slot[1];
@@ -390,7 +399,12 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
       shared = -1;
       if (kClassFirst) {
         // (tables that come with a wedge list hold no saturated count: n2v_wedge_build)
-        const uint32_t ec = kHops ? h.classes : g.edge_classes[e];
+        uint32_t ec = kHops ? h.classes : g.edge_classes[e];
+        rpos_inl = -1;
+        if (inl_tab && ec != 0xffffffffu && (ec & N2V_EC_INLINE) != 0u) {
+          rpos_inl = (int)(ec & N2V_EC_SHARED_MASK);
+          ec = ((ec >> N2V_EC_RETURN_SHIFT) & 0x7fu) << N2V_EC_RETURN_SHIFT;  // no shared neighbours
+        }
         n_ret = (int)(ec >> N2V_EC_RETURN_SHIFT);
         shared = q != 1.0 ? (int)(ec & N2V_EC_SHARED_MASK) : 0;  // q == 1: shared slots ARE other slots
         const int n_oth = n - n_ret - shared;
@@ -400,7 +414,9 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
         m_l12 = m_l1 + (double)(n - n_c1) * d2;
         m_tot = m_l12 + (double)n_c3 * d3;
       } else if (have_ec && biased && !dropped) {
-        const uint32_t ec = kHops ? h.classes : g.edge_classes[e];
+        uint32_t ec = kHops ? h.classes : g.edge_classes[e];
+        if (inl_tab && ec != 0xffffffffu && (ec & N2V_EC_INLINE) != 0u)
+          ec = ((ec >> N2V_EC_RETURN_SHIFT) & 0x7fu) << N2V_EC_RETURN_SHIFT;  // the plain form
         const uint32_t fR = ec >> N2V_EC_RETURN_SHIFT, fM = ec & N2V_EC_SHARED_MASK;
         if (fM != N2V_EC_SHARED_MASK) shared = (int)fM;
         if (fold_return && fR != N2V_EC_RETURN_SAT) {
@@ -433,12 +449,12 @@ extern "C" int n2v_walk_fast_launch(const n2v_graph *g, const int32_t *start_ids
   const int threads = 256;
   int64_t blocks = (total + threads - 1) / threads;
   const bool hops = unit && g->hops != nullptr;
-  // (a hop table with inline return positions is read by the exact slots kernel alone)
-  if (hops && (g->reserved2 & N2V_HOPS_INLINE_RPOS) && !(p == 1.0 && q == 1.0)) return N2V_EINVAL;
   // class-first sampling: counts, return position and shared positions of every edge at hand
   const bool cf = unit && (hops || g->edge_classes) && g->wedge_off && g->wedge_pos &&
                   !(p == 1.0 && q == 1.0);
-  const void *fn = cf     ? (hops ? (const void *)n2v::walk_fast_kernel<true, true, true>
+  const bool slots = cf && hops && q < 1.0 && g->wedge_slots && !g->wedge_wide;
+  const void *fn = slots  ? (const void *)n2v::walk_fast_kernel<true, true, true, true>
+                   : cf   ? (hops ? (const void *)n2v::walk_fast_kernel<true, true, true>
                                   : (const void *)n2v::walk_fast_kernel<true, false, true>)
                    : hops ? (const void *)n2v::walk_fast_kernel<true, true, false>
                    : unit ? (const void *)n2v::walk_fast_kernel<true, false, false>
@@ -451,7 +467,11 @@ extern "C" int n2v_walk_fast_launch(const n2v_graph *g, const int32_t *start_ids
   hipLaunchKernelGGL((n2v::walk_fast_kernel<U, H, C>), dim3((unsigned)blocks), dim3(threads), 0, \
                      (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, p, q,  \
                      seed, walks_out, valid_out, status, trials)
-  if (cf && hops)
+  if (slots)
+    hipLaunchKernelGGL((n2v::walk_fast_kernel<true, true, true, true>), dim3((unsigned)blocks),
+                       dim3(threads), 0, (hipStream_t)stream, *g, start_ids, n_start, num_walks,
+                       walk_length, p, q, seed, walks_out, valid_out, status, trials);
+  else if (cf && hops)
     N2V_FAST_LAUNCH(true, true, true);
   else if (cf)
     N2V_FAST_LAUNCH(true, false, true);

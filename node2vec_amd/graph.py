@@ -47,6 +47,7 @@ class DeviceGraph:
         self.wedge_tried = False  # randomwalk.walk tries to build the table once
         self.wedge_slots: Optional[torch.Tensor] = None  # int16 [E, 16]: n2v_wedge_slots_build
         self.hops_inline_rpos = False  # the hop table's class words carry return positions (slots kernel)
+        self._inline_ok = None  # (edge_classes tensor, every return count < 128): can_inline_rpos()
 
     @property
     def w(self) -> torch.Tensor:
@@ -301,7 +302,11 @@ class DeviceGraph:
             return False
         if self.wedge_pos is None or self.wedge_pos.dtype != torch.int16:
             return False
-        return self.n_edges == 0 or int((self.edge_classes >> 24 & 0xff).max()) < 128
+        if self._inline_ok is None or self._inline_ok[0] is not self.edge_classes:
+            # one pass over the class words and a host sync: once per table, not per walk() call
+            ok = self.n_edges == 0 or int((self.edge_classes >> 24 & 0xff).max()) < 128
+            self._inline_ok = (self.edge_classes, ok)
+        return self._inline_ok[1]
 
     def build_hops(self, with_classes: bool = False, inline_rpos: bool = False) -> "DeviceGraph":
         """Hop table (n2v_hops_build): per edge {neighbour id, class counts of the edge, row

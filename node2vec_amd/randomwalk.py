@@ -149,11 +149,13 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
         want_classes = graph.edge_classes is not None
         # the exact slots kernel reads return positions out of the hop table's class words; every
         # other kernel needs the plain form (the table is rebuilt in milliseconds when it changes hands)
-        want_inline = (mode == "exact" and biased and use_edge_classes and use_wedges and use_wedge_kernel
+        # (fast mode reads either form)
+        want_inline = (biased and use_edge_classes and use_wedges and use_wedge_kernel
                        and use_wedge_slots and not use_workspace and graph.wedge_slots is not None
-                       and tables_regime(return_param, inout_param) and graph.can_inline_rpos())
+                       and (mode == "fast" or tables_regime(return_param, inout_param))
+                       and graph.can_inline_rpos())
         if (graph.hops is None or (want_classes and not graph.hops_have_classes)
-                or (biased and graph.hops_inline_rpos != want_inline)):
+                or (biased and mode == "exact" and graph.hops_inline_rpos != want_inline)):
             graph.build_hops(inline_rpos=want_inline)
     start_ids = start_ids.to(device=graph.device, dtype=torch.int32).contiguous()
     n_start = start_ids.numel()
@@ -174,6 +176,7 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     if not use_wedges or not use_edge_classes:
         g.wedge_off = 0
         g.wedge_pos = 0
+        g.wedge_slots = 0
     if not use_wedge_kernel:  # keep the tables but walk with the lanes kernel (tests: same bits)
         g.reserved = 1
     if not use_wedge_slots:  # the all-tables kernel through wedge_off (tests: same bits)
