@@ -672,7 +672,10 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist)
                                    "unit": "embedding-updates/s on this GPU",
                                    "ms_per_step": 1e3 * dt / args.steps,
                                    "what": "hub_rows = 0: every row updated by read-modify-write stores "
-                                           "(w2v_params['hub_rows'] = 0)"}
+                                           "(w2v_params['hub_rows'] = 0).  This leg runs AFTER the default "
+                                           "one on the same rows: the model has seen them K + W times more, "
+                                           "more targets reach |f| >= 6 and are skipped, so its launches are "
+                                           "a few per cent shorter whatever hub_rows is"}
             if auto_rows:
                 res["hub_rows_auto"]["throughput_vs_plain_stores"] = res["value"] / max(res["plain_stores"]["value"], 1.0)
             else:

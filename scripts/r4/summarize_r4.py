@@ -64,7 +64,8 @@ kernels = {"walk_uniform_kernel": "exact p=q=1", "walk_exact_wedge_kernel": "exa
            "sgns_batched_kernel": "sgns, batched (negatives shared per centre position)"}
 ROW_KERNELS = ("sgns_kernel", "sgns_batched_kernel")  # FETCH_SIZE counts half of their read bytes
 out = {"tag": tag, "config": config, "kernels": {}}
-stats_files = glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True)
+stats_files = sorted(glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime,
+                     reverse=True)  # the newest run of the tag
 trace = {}
 if stats_files:
     rows = list(csv.DictReader(open(stats_files[0])))
