@@ -229,6 +229,8 @@ class RankState:
         self.status = None  # uint32 [4] of n2v_partition_step, on the part's device
         self._arange = None
         self.use_tables = True  # walk_partitioned clears it unless every rank holds the tables
+        self.last_status = 0       # status bits of n2v_partition_step seen so far
+        self.defer_status = False  # True: collected in last_status instead of raised at once
 
     # -- initiate_random_walk (randomwalk.py:279-296) for the start vertices this rank owns ----
     def initiate(self, start_ids_global: torch.Tensor):
@@ -350,7 +352,11 @@ class RankState:
         torch.cumsum(lens, 0, out=ptr[1:])
         # one transfer: the status word, the walkers per destination, the words per destination
         host = torch.cat([self.status[:1].to(torch.int64), cuts, ptr[cuts]]).tolist()
-        _lib.check_status_word(host[0], "n2v_partition_step")
+        # one rank of several must not raise alone (the others would wait for it in the exchange):
+        # walk_partitioned sets defer_status and raises on every rank after the size exchange
+        self.last_status |= int(host[0])
+        if not self.defer_status:
+            _lib.check_status_word(host[0], "n2v_partition_step")
         cuts_h, at = host[1:n_parts + 2], host[n_parts + 2:]
         k2 = cuts_h[-1]  # forwarded walkers: the first k2 of the sorted batch
         ids = torch.zeros(0, dtype=torch.int32, device=dev)
@@ -506,7 +512,7 @@ def _all_to_all_var(tensors: List[torch.Tensor], group, dist) -> List[torch.Tens
     return [t.to(dev) for t in torch.split(recv, n_recv.tolist())]
 
 
-def _exchange_walkers(out: List[Walkers], group, dist, dev) -> List[Walkers]:
+def _exchange_walkers(out: List[Walkers], group, dist, dev, status: int = 0) -> List[Walkers]:
     """The migration of one step: three collectives -- the sizes (walkers and row words per
     destination, one [world, 2] exchange), the headers with the length of what travels with each
     walker as an extra column, and those words.  Segments arrive in source order in both
@@ -516,10 +522,18 @@ def _exchange_walkers(out: List[Walkers], group, dist, dev) -> List[Walkers]:
     head5 = torch.cat([torch.cat([w.head, w.lens[:, None]], 1) for w in out]).to(wire)
     ids = torch.cat([w.ids for w in out]).to(wire)
     sizes = [[len(w), int(w.ids.numel())] for w in out]  # shapes: known on the host, no sync
-    n_send = torch.tensor(sizes, dtype=torch.int64, device=wire)
+    # (the third column: this rank's status word, so that an error of one rank is every rank's)
+    n_send = torch.tensor([z + [int(status)] for z in sizes], dtype=torch.int64, device=wire)
     n_recv = torch.empty_like(n_send)
     dist.all_to_all_single(n_recv, n_send, group=group)
     got = n_recv.tolist()
+    bad = 0
+    for g3 in got:
+        bad |= int(g3[2])
+    if bad:
+        from node2vec_amd import _lib
+
+        _lib.check_status_word(bad, "n2v_partition_step (on some rank)")
     recv_h = torch.empty((sum(g[0] for g in got), HEAD_COLS + 1), dtype=torch.int64, device=wire)
     dist.all_to_all_single(recv_h, head5.contiguous(), [g[0] for g in got], [z[0] for z in sizes], group=group)
     recv_i = torch.empty(sum(g[1] for g in got), dtype=torch.int32, device=wire)
@@ -545,8 +559,10 @@ def walk_partitioned(part: GraphPart, start_ids: torch.Tensor, num_walks: int, w
     have = torch.tensor([0 if part.wedge_off is None else 1], dtype=torch.int32, device=part.device)
     all_reduce(have, dist.ReduceOp.MIN, group)
     st.use_tables = bool(have.item())
+    st.defer_status = True
     st.initiate(start_ids)
     for _ in range(walk_length):
-        st.receive(_exchange_walkers(st.advance(world), group, dist, part.device))
+        out = st.advance(world)
+        st.receive(_exchange_walkers(out, group, dist, part.device, st.last_status))
     records = _all_to_all_var(st.log_by_home(start_ids, world), group, dist)
     return st.assemble(records, start_ids)
