@@ -380,22 +380,9 @@ typedef struct n2v_sgns_params {
                            trainer always returns its context rows as atomic deltas; hub_rows
                            adds the same for its target rows (8 adds per lane and row: measured
                            -34 % at 4096 on cfg 3, link AUC 0.886 -> 0.899 on cfg 2) */
-  /* gensim's learning-rate schedule.  gensim.models.Word2Vec (embedding.py:126) lowers the rate
-   * per JOB -- a batch of consecutive sentences of at most batch_words raw words
-   * (constants.py:58: 1000) -- to  max(end, start - (start - end) * (epoch + pushed / total) /
-   * epochs),  pushed = sentences queued before the job (word2vec.py _job_producer,
-   * _get_next_alpha; Python doubles, then cast to fp32).  sched_job_rows > 0 makes the kernel do
-   * the same per row: row r of this launch is sentence sched_row0 + r of its epoch, its job is
-   * that index / sched_job_rows, and `alpha` is ignored.  sched_job_rows == 0: `alpha` for every
-   * row of the launch (what rounds 1 - 3 did: one rate per launch). */
-  int32_t sched_job_rows; /* sentences per job = max(1, batch_words / sentence length); 0 = off */
-  int32_t sched_epoch;    /* cur_epoch */
-  int32_t sched_epochs;   /* epochs (`iter`) */
-  int32_t reserved;       /* 0 */
-  int64_t sched_row0;     /* index of row 0 of this launch among the sentences of its epoch */
-  int64_t sched_rows;     /* total_examples: sentences per epoch */
-  double sched_alpha0;    /* start alpha */
-  double sched_alpha_min; /* end alpha (min_alpha) */
+  const float *row_alpha; /* [n_walks] or NULL: the learning rate of every row of the launch (gensim
+                             lowers it per job of sentences: n2v_sgns_job_alpha writes such an
+                             array); NULL = `alpha` for every row */
 } n2v_sgns_params;
 
 #define N2V_SGNS_MAX_SENTENCE 256 /* longer walks: split rows on the host */
@@ -408,6 +395,17 @@ typedef struct n2v_sgns_params {
  * sectors).  index_out: [2^bits + 1] int32. */
 int n2v_cum_index_build(const uint32_t *cum_table, int64_t n_vocab, int32_t bits,
                         int32_t *index_out, void *stream);
+
+/* gensim's learning-rate schedule, per row of a launch.  gensim.models.Word2Vec (embedding.py:126)
+ * lowers the rate per JOB -- a batch of consecutive sentences of at most batch_words raw words
+ * (constants.py:58: 1000) -- to  max(end, start - (start - end) * (epoch + pushed / total) / epochs),
+ * pushed = sentences queued before the job (word2vec.py _job_producer, _get_next_alpha; Python
+ * doubles, then cast to fp32).  out[i] = that rate for sentence row0 + i of epoch `epoch`, whose job
+ * is (row0 + i) / job_rows (job_rows = max(1, batch_words / sentence length) for the equal-length
+ * sentences of a walk corpus): the same double operations in the same order.  Pass `out` as
+ * n2v_sgns_params.row_alpha.  out: [n] fp32. */
+int n2v_sgns_job_alpha(int32_t job_rows, int32_t epoch, int32_t epochs, int64_t row0, int64_t rows,
+                       double alpha0, double alpha_min, int64_t n, float *out, void *stream);
 
 int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t walk_len,
                    float *syn0, float *syn1neg, const uint32_t *cum_table,

@@ -25,7 +25,7 @@ SYMBOLS = ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alia
            "n2v_mem_probe", "n2v_corpus_count", "n2v_corpus_index", "n2v_hops8_build",
            "n2v_partition_step", "n2v_gather_rows", "n2v_gather_wedges",
            "n2v_partition_route", "n2v_partition_group", "n2v_walk_ws", "n2v_walk_workspace_bytes",
-           "n2v_delta_reduce", "n2v_wedge_slots_build")
+           "n2v_delta_reduce", "n2v_wedge_slots_build", "n2v_sgns_job_alpha")
 
 
 class Graph(C.Structure):
@@ -47,10 +47,7 @@ class SgnsParams(C.Structure):
                 ("dim", C.c_int32), ("window", C.c_int32), ("negative", C.c_int32),
                 ("alpha", C.c_float), ("deterministic", C.c_int32), ("cum_index_bits", C.c_int32),
                 ("cum_index", C.c_void_p), ("max_waves", C.c_int32), ("batched", C.c_int32),
-                ("window_cache", C.c_int32), ("hub_rows", C.c_int32),
-                ("sched_job_rows", C.c_int32), ("sched_epoch", C.c_int32), ("sched_epochs", C.c_int32),
-                ("reserved", C.c_int32), ("sched_row0", C.c_int64), ("sched_rows", C.c_int64),
-                ("sched_alpha0", C.c_double), ("sched_alpha_min", C.c_double)]
+                ("window_cache", C.c_int32), ("hub_rows", C.c_int32), ("row_alpha", C.c_void_p)]
 
 
 _lib = None
@@ -108,6 +105,9 @@ def load():
     L.n2v_trim_mark.restype = C.c_int
     L.n2v_trim_mark.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p,
                                 C.c_void_p]
+    L.n2v_sgns_job_alpha.restype = C.c_int
+    L.n2v_sgns_job_alpha.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_double,
+                                     C.c_double, C.c_int64, C.c_void_p, C.c_void_p]
     L.n2v_sgns_train.restype = C.c_int
     L.n2v_sgns_train.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SgnsParams),

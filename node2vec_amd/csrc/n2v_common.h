@@ -101,17 +101,6 @@ __device__ __forceinline__ n2v_hop load_hop(const n2v_hop *p) {
 __device__ __forceinline__ int64_t hop_row(const n2v_hop &h) { return (int64_t)(h.row & N2V_HOP_ROW_MASK); }
 __device__ __forceinline__ int hop_deg(const n2v_hop &h) { return (int)(h.row >> N2V_HOP_DEG_SHIFT); }
 
-// the learning rate of row r of a launch under gensim's per-job schedule (n2v_sgns_params.sched_*):
-// word2vec.py _job_producer / _get_next_alpha, the same double operations in the same order
-__device__ __forceinline__ float sched_alpha(const n2v_sgns_params &P, int64_t r) {
-  const int64_t job = (P.sched_row0 + r) / (int64_t)P.sched_job_rows;
-  const double pushed = (double)(job * (int64_t)P.sched_job_rows);
-  const double epoch_progress = 1.0 * pushed / (double)P.sched_rows;
-  const double progress = ((double)P.sched_epoch + epoch_progress) / (double)P.sched_epochs;
-  const double next_alpha = P.sched_alpha0 - (P.sched_alpha0 - P.sched_alpha_min) * progress;
-  return (float)(P.sched_alpha_min > next_alpha ? P.sched_alpha_min : next_alpha);  // max(end, next)
-}
-
 __device__ inline int lane_id() { return __lane_id(); }
 
 __device__ inline double readlane_f64(double v, int lane) {

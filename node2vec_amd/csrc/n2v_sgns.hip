@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (kRingRows ? (VEC <= 2 ? 4 : 1) : 
   const int hub_rows = P.deterministic ? 0 : P.hub_rows;
   const int64_t hub_span = (int64_t)hub_rows * dim;
   const bool full = dim == 64 * VEC;
-  float alpha = P.alpha;  // per launch, or per job of sentences (sched_alpha) inside the row loop
+  float alpha = P.alpha;  // per launch, or per row (P.row_alpha: the rate of the row's gensim job)
   const uint32_t domain = cum_table[P.n_vocab - 1];
   const int waves_per_block = blockDim.x >> 6;
   const int64_t n_waves = (int64_t)gridDim.x * waves_per_block;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kSgnsWaves * 64, (kRingRows ? (VEC <= 2 ? 4 : 1) : 
     const int64_t r = readfirstlane_i64(rr);
     if (!dynamic) rr += n_waves;
     const uint64_t hs = sentence_stream(P.seed, (uint64_t)(P.sentence_base + r));
-    if (P.sched_job_rows > 0) alpha = sched_alpha(P, r);  // gensim: the rate of this sentence's job
+    if (P.row_alpha) alpha = P.row_alpha[r];  // gensim: the rate of this sentence's job (a scalar load)
     // ---- sentence preparation (lane-parallel, order-preserving compaction) ----
     int nf = 0;
     for (int base = 0; base < walk_len; base += 64) {
@@ -616,10 +616,6 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   if (P->window_cache != 0 && P->window_cache != 1) return N2V_EINVAL;
   if (P->window_cache == 1 && !ring_fits) return N2V_EINVAL;
   if (P->hub_rows < 0) return N2V_EINVAL;
-  if (P->sched_job_rows < 0 ||
-      (P->sched_job_rows > 0 && (P->sched_rows < 1 || P->sched_epochs < 1 || P->sched_epoch < 0 ||
-                                 P->sched_row0 < 0)))
-    return N2V_EINVAL;
   const bool use_ring = P->window_cache == 1;
   const int sent_cap = (walk_len + 3) & ~3;
   const int ints_per_wave = (2 * sent_cap + (2 * P->window + 1) * P->negative + 3) & ~3;
@@ -686,6 +682,38 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   }
 #undef N2V_LAUNCH_RING
 #undef N2V_LAUNCH_R
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}
+
+namespace n2v {
+// gensim's rate of the job of each row (word2vec.py _job_producer / _get_next_alpha): the same
+// double operations in the same order, then the cast to fp32
+__global__ __launch_bounds__(256) void job_alpha_kernel(int job_rows, int epoch, int epochs, int64_t row0,
+                                                       int64_t rows, double alpha0, double alpha_min,
+                                                       int64_t n, float *__restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t job = (row0 + i) / (int64_t)job_rows;
+    const double pushed = (double)(job * (int64_t)job_rows);
+    const double epoch_progress = 1.0 * pushed / (double)rows;
+    const double progress = ((double)epoch + epoch_progress) / (double)epochs;
+    const double next_alpha = alpha0 - (alpha0 - alpha_min) * progress;
+    out[i] = (float)(alpha_min > next_alpha ? alpha_min : next_alpha);  // max(end_alpha, next_alpha)
+  }
+}
+}  // namespace n2v
+
+extern "C" int n2v_sgns_job_alpha(int32_t job_rows, int32_t epoch, int32_t epochs, int64_t row0,
+                                  int64_t rows, double alpha0, double alpha_min, int64_t n, float *out,
+                                  void *stream) {
+  if (job_rows < 1 || epoch < 0 || epochs < 1 || row0 < 0 || rows < 1 || n < 0) return N2V_EINVAL;
+  if (n == 0) return N2V_OK;
+  if (!out) return N2V_EINVAL;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(n2v::job_alpha_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (int)job_rows, (int)epoch, (int)epochs, row0, rows, alpha0, alpha_min, n, out);
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
 }

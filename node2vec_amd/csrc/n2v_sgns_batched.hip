@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
   constexpr int TM_WORDS = TROWS == 8 ? 1 : 2;      // packed multiplicities: 4 bits per target
   const int window = P.window, K = P.negative;
   const int PL = K + 1 + TM_WORDS + 1;              // plan ints per position (below)
-  float alpha = P.alpha;  // per launch, or per job of sentences (sched_alpha) inside the row loop
+  float alpha = P.alpha;  // per launch, or per row (P.row_alpha: the rate of the row's gensim job)
   const bool hogwild = P.deterministic == 0;
   const int hub_rows = hogwild ? P.hub_rows : 0;
 
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kBWaves * 64) void sgns_batched_kernel(
     const int64_t r = readfirstlane_i64(rr);
     if (!dynamic) rr += n_waves;
     const uint64_t hs = b_sentence_stream(P.seed, (uint64_t)(P.sentence_base + r));
-    if (P.sched_job_rows > 0) alpha = sched_alpha(P, r);  // gensim: the rate of this sentence's job
+    if (P.row_alpha) alpha = P.row_alpha[r];  // gensim: the rate of this sentence's job (a scalar load)
     // ---- sentence preparation: vocabulary filter, subsampling, reduced windows ----
     int nf = 0;
     for (int base = 0; base < walk_len; base += 64) {

@@ -112,8 +112,9 @@ class JobSchedule:
     embedding.py:126): sentences are queued in jobs of at most `batch_words` raw words, and the rate
     of a job is  max(end, start - (start - end) * (epoch + pushed / total) / epochs)  with `pushed`
     the sentences queued before it.  For the equal-length sentences of a walk corpus a job is
-    `job_rows` = max(1, batch_words // sentence length) consecutive rows; the kernels evaluate the
-    expression per row (n2v_sgns_params.sched_*), `alpha_of_rows` is the same on the host."""
+    `job_rows` = max(1, batch_words // sentence length) consecutive rows; n2v_sgns_job_alpha writes
+    the rate of every row of a launch (n2v_sgns_params.row_alpha), `alpha_of_rows` is the same on the
+    host."""
 
     def __init__(self, job_rows: int, rows: int, epoch: int, epochs: int, alpha0: float, alpha_min: float):
         self.job_rows, self.rows = max(1, int(job_rows)), max(1, int(rows))
@@ -225,13 +226,19 @@ class SgnsModel:
         if walks_idx.shape[1] > MAX_SENTENCE:
             raise ValueError(f"walks longer than {MAX_SENTENCE}: split rows first (split_rows)")
         walks_idx = walks_idx.contiguous()
+        row_alpha = None
+        if sched is not None and walks_idx.shape[0] > 0:  # the rate of every row: that of its gensim job
+            row_alpha = torch.empty(walks_idx.shape[0], dtype=torch.float32, device=walks_idx.device)
+            with torch.cuda.device(walks_idx.device):
+                _lib.check(L.n2v_sgns_job_alpha(sched.job_rows, sched.epoch, sched.epochs, int(row0),
+                                                sched.rows, sched.alpha0, sched.alpha_min,
+                                                row_alpha.numel(), row_alpha.data_ptr(),
+                                                _lib.current_stream_ptr()), "n2v_sgns_job_alpha")
         P = _lib.SgnsParams(len(self.vocab), int(sentence_base), self.seed, self.dim, self.window,
                             self.negative, float(alpha), int(bool(deterministic)),
                             self.cum_index_bits, 0 if self.cum_index is None else self.cum_index.data_ptr(),
                             int(self.max_waves), int(bool(self.batched)), int(self.window_cache), self._hub_rows(),
-                            *((0, 0, 0, 0, 0, 0, 0.0, 0.0) if sched is None else
-                              (sched.job_rows, sched.epoch, sched.epochs, 0, int(row0), sched.rows,
-                               sched.alpha0, sched.alpha_min)))
+                            0 if row_alpha is None else row_alpha.data_ptr())
         with torch.cuda.device(walks_idx.device):
             rc = L.n2v_sgns_train(walks_idx.data_ptr(), walks_idx.shape[0], walks_idx.shape[1],
                                   self.syn0.data_ptr(), self.syn1neg.data_ptr(),

@@ -22,7 +22,7 @@ def test_header_declares_the_expected_entry_points():
                  "n2v_mem_probe", "n2v_corpus_count", "n2v_corpus_index", "n2v_hops8_build",
                  "n2v_partition_step", "n2v_gather_rows", "n2v_gather_wedges",
                  "n2v_partition_route", "n2v_partition_group", "n2v_walk_ws",
-                 "n2v_walk_workspace_bytes", "n2v_delta_reduce", "n2v_wedge_slots_build"):
+                 "n2v_walk_workspace_bytes", "n2v_delta_reduce", "n2v_wedge_slots_build", "n2v_sgns_job_alpha"):
         assert want in names
 
 
@@ -56,12 +56,11 @@ def test_ctypes_structs_match_header_layout():
     body = text[text.index("typedef struct n2v_graph {"):text.index("} n2v_graph;")]
     fields = re.findall(r"\*?\s*\b(\w+);", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
     assert fields == [f[0] for f in _lib.Graph._fields_]
-    assert ctypes.sizeof(_lib.SgnsParams) == 3 * 8 + 6 * 4 + 8 + 4 * 4 + 4 * 4 + 4 * 8
+    assert ctypes.sizeof(_lib.SgnsParams) == 3 * 8 + 6 * 4 + 8 + 4 * 4 + 8
     assert [f[0] for f in _lib.SgnsParams._fields_] == [
         "n_vocab", "sentence_base", "seed", "dim", "window", "negative", "alpha",
         "deterministic", "cum_index_bits", "cum_index", "max_waves", "batched", "window_cache",
-        "hub_rows", "sched_job_rows", "sched_epoch", "sched_epochs", "reserved", "sched_row0",
-        "sched_rows", "sched_alpha0", "sched_alpha_min"]
+        "hub_rows", "row_alpha"]
     body = text[text.index("typedef struct n2v_sgns_params {"):text.index("} n2v_sgns_params;")]
     fields = re.findall(r"\*?\s*\b(\w+);", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
     assert fields == [f[0] for f in _lib.SgnsParams._fields_]

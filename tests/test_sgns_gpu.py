@@ -340,7 +340,7 @@ def test_hub_rows_atomic_updates(oracle):
 
 @pytest.mark.parametrize("batched", [False, True])
 def test_gensim_job_schedule_in_the_kernel_equals_the_oracle_job_by_job(oracle, batched):
-    """n2v_sgns_params.sched_*: the learning rate of a row is that of its gensim JOB (word2vec.py
+    """n2v_sgns_params.row_alpha / n2v_sgns_job_alpha: the learning rate of a row is that of its gensim JOB (word2vec.py
     _job_producer / _get_next_alpha: max(end, start - (start - end) * (epoch + pushed / total) /
     epochs) per batch of batch_words words).  Deterministic mode with the schedule == the oracle
     called job by job with the rate restated in plain Python floats, bit for bit -- both kernels,
@@ -378,3 +378,30 @@ def test_gensim_job_schedule_in_the_kernel_equals_the_oracle_job_by_job(oracle, 
     want = [np.float32(max(amin, a0 - (a0 - amin) * ((1 + 1.0 * ((r // job_rows) * job_rows) / rows) / epochs)))
             for r in range(rows)]
     assert sch.job_rows == job_rows and np.array_equal(sch.alpha_of_rows(0, rows), np.array(want, np.float32))
+
+
+def test_job_alpha_entry_point_equals_python_floats():
+    """n2v_sgns_job_alpha == gensim's expression in Python floats, bit for bit, at the row counts of
+    configuration 4 (jobs of 12 sentences in a 1.13e9-sentence corpus, launches starting mid-job)
+    and at the clamp to min_alpha; bad arguments are refused."""
+    from node2vec_amd import _lib, sgns
+
+    L = _lib.load()
+    for job_rows, epoch, epochs, row0, rows, a0, amin, n in (
+            (12, 0, 1, 1_130_000_000 - 70_001, 1_130_000_000, 0.025, 1e-4, 70_001),
+            (12, 2, 5, 999_999_937, 1_130_000_000, 0.025, 1e-4, 4099),
+            (1, 0, 1, 0, 7, 0.025, 0.025, 7),
+            (47, 0, 3, 5, 100_000, 0.05, 0.04, 99_995)):
+        out = torch.empty(n, dtype=torch.float32, device="cuda")
+        _lib.check(L.n2v_sgns_job_alpha(job_rows, epoch, epochs, row0, rows, a0, amin, n, out.data_ptr(),
+                                        _lib.current_stream_ptr()), "n2v_sgns_job_alpha")
+        got = out.cpu().numpy()
+        assert np.array_equal(got, sgns.JobSchedule(job_rows, rows, epoch, epochs, a0, amin).alpha_of_rows(row0, n))
+        for i in (0, 1, n // 2, n - 1):  # plain Python floats, as gensim computes them
+            pushed = ((row0 + i) // job_rows) * job_rows
+            want = max(amin, a0 - (a0 - amin) * ((epoch + 1.0 * pushed / rows) / epochs))
+            assert got[i] == np.float32(want)
+    out = torch.empty(4, dtype=torch.float32, device="cuda")
+    for bad in ((0, 0, 1, 0, 4, 0.1, 0.01, 4), (1, 0, 0, 0, 4, 0.1, 0.01, 4), (1, 0, 1, -1, 4, 0.1, 0.01, 4),
+                (1, 0, 1, 0, 0, 0.1, 0.01, 4)):
+        assert L.n2v_sgns_job_alpha(*bad, out.data_ptr(), _lib.current_stream_ptr()) == _lib.EINVAL

@@ -1,5 +1,5 @@
 """gensim lowers the learning rate once per JOB (batch_words words of the corpus).  Since round 4
-the HIP trainer does the same when it is given batch_words (n2v_sgns_params.sched_*,
+the HIP trainer does the same when it is given batch_words (n2v_sgns_job_alpha,
 sgns.JobSchedule: Node2VecHIP.fit and fit_streaming pass the reference's value, constants.py:58);
 called without it (SgnsModel.train(batch_words=None), a corpus of split rows) the rate falls once
 per LAUNCH (max(65 536 rows, rows / 64) per launch), which is what this file quantifies on the
