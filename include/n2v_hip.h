@@ -115,6 +115,30 @@ typedef struct n2v_graph {
   int32_t reserved2;            /* bit 0 (N2V_HOPS_INLINE_RPOS): the class words of `hops` carry inline
                                    return positions, see n2v_hops_build; else 0 */
   const uint16_t *wedge_slots;  /* [n_edges][16] or NULL: see n2v_wedge_slots_build */
+  /* The degree-ranked form of a unit-weight graph (p == q == 1 walks; n2v_rank_hops_build), or all
+   * NULL / 0.  Vertices are numbered again by descending degree (`rank`), rows are laid out in rank
+   * order, so the row of a rank follows from the DEGREE CLASS the rank falls in and an entry of the
+   * table is the 4-byte rank of the neighbour alone: a step is one 4-byte gather. */
+  const uint32_t *rank_hops;        /* [n_edges]: rank of every neighbour; rows in rank order, the entries
+                                       of a row in the CSR's order (so pick = int(r1 * n) is unchanged) */
+  const int32_t *rank_of;           /* [n_vertices]: vertex id -> rank */
+  const int32_t *rank_vertex;       /* [n_vertices]: rank -> vertex id */
+  const uint64_t *rank_head;        /* [rank_head_n]: row offset | degree << 40 of ranks below rank_head_n
+                                       (the few top vertices whose degrees are all different) */
+  const uint32_t *rank_class_first; /* [rank_classes]: first rank of every degree class of the ranks from
+                                       rank_head_n on, ascending, [0] == rank_head_n; then n_vertices in
+                                       the entry after the last class and in the padding */
+  const uint32_t *rank_class_off;   /* [rank_classes]: offset in rank_hops of the row of that first rank
+                                       (n_edges after the last class; the form needs n_edges < 2^32).
+                                       The degree of class c is (off[c+1] - off[c]) / (first[c+1] - first[c]) */
+  int32_t rank_head_n;              /* 0 .. 2^22 */
+  int32_t rank_classes;             /* a power of two, 2 .. 8192, > the number of classes (the walk kernel
+                                       keeps both arrays in LDS: 8 bytes per class) */
+  int32_t rank_emit;                /* what the ranked kernel writes to walks_out: 0 = vertex ids (one more
+                                       gather per token through rank_vertex), 1 = ranks (the caller
+                                       composes rank_vertex into its own per-token lookup, as
+                                       n2v_corpus_index's index_of) */
+  int32_t reserved3;                /* 0 */
 } n2v_graph;
 
 /* edge_classes[e] for e = (s -> v): bits 0..23 = number of entries x of N(v) with
@@ -528,6 +552,18 @@ int n2v_gather_wedges(const uint32_t *edge_classes, const uint64_t *wedge_off, c
                       int32_t wide, const int64_t *edges, const int64_t *out_ptr, int64_t k,
                       int32_t *out, int64_t *head, int32_t head_cols, void *stream);
 
+/* Fills the entry table of the degree-ranked form (n2v_graph.rank_hops) of a unit-weight graph.
+ * The caller ranks the vertices -- any STABLE sort by descending degree: rank_vertex[r] = the vertex
+ * of rank r, rank_of its inverse -- and passes rank_rowptr[r] = the sum of the degrees of ranks
+ * below r ([n_vertices + 1], int64).  out[rank_rowptr[r] + k] = rank_of[col[rowptr[v] + k]] for
+ * v = rank_vertex[r].  The head and class tables of n2v_graph are a few thousand words the caller
+ * derives from the sorted degrees (node2vec_amd/graph.py build_ranked shows how).  Replaces nothing
+ * in the reference (its adjacency rows are Python lists, fugue.py:130); it is the layout that lets
+ * a p == q == 1 step (randomwalk.py:86-99 with probs == 1.0) be one 4-byte gather.
+ * out: [g->n_edges] uint32. */
+int n2v_rank_hops_build(const n2v_graph *g, const int32_t *rank_of, const int32_t *rank_vertex,
+                        const int64_t *rank_rowptr, uint32_t *out, void *stream);
+
 /* Measurement aid (bench.py; nothing on the product path calls it): the rate this device
  * sustains for the access shapes of K2 and K3 on the CALLER's buffer, so that the ceilings the
  * kernels are compared with are observed on the box the bench runs on.  One launch; the caller
@@ -537,6 +573,9 @@ int n2v_gather_wedges(const uint32_t *edge_classes, const uint64_t *wedge_off, c
  *   mode 1  one dependent chain of such reads per lane (a walker)
  *   mode 2  random rows of row_bytes (512 | 1024 | 2048) read by one wave each (a syn0 row)
  *   mode 3  the same rows read, modified and written back (a trained row)
+ *   mode 4  one dependent chain of random 4-byte reads per lane with a binary search over an LDS
+ *           table of row_bytes degree classes (a power of two, 64 .. 8192) between them: a walker on
+ *           a graph numbered by descending degree whose entries are the neighbour id alone
  * iters: accesses per lane (modes 0, 1) / rows per wave (modes 2, 3), a multiple of 4.
  * *accesses_host (host pointer, optional) receives the number of accesses the launch makes.
  * buffer: 16-byte aligned device memory, overwritten in mode 3.  sink: one device word. */

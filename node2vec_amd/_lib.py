@@ -25,7 +25,7 @@ SYMBOLS = ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alia
            "n2v_mem_probe", "n2v_corpus_count", "n2v_corpus_index", "n2v_hops8_build",
            "n2v_partition_step", "n2v_gather_rows", "n2v_gather_wedges",
            "n2v_partition_route", "n2v_partition_group", "n2v_walk_ws", "n2v_walk_workspace_bytes",
-           "n2v_delta_reduce", "n2v_wedge_slots_build", "n2v_sgns_job_alpha")
+           "n2v_delta_reduce", "n2v_wedge_slots_build", "n2v_sgns_job_alpha", "n2v_rank_hops_build")
 
 
 class Graph(C.Structure):
@@ -38,7 +38,10 @@ class Graph(C.Structure):
                 ("reserved", C.c_int32), ("hops8", C.c_void_p), ("hop8_col_bits", C.c_int32),
                 ("hop8_row_bits", C.c_int32), ("hop8_rowptr", C.c_void_p),
                 ("hop8_align_shift", C.c_int32), ("reserved2", C.c_int32),
-                ("wedge_slots", C.c_void_p)]
+                ("wedge_slots", C.c_void_p), ("rank_hops", C.c_void_p), ("rank_of", C.c_void_p),
+                ("rank_vertex", C.c_void_p), ("rank_head", C.c_void_p), ("rank_class_first", C.c_void_p),
+                ("rank_class_off", C.c_void_p), ("rank_head_n", C.c_int32), ("rank_classes", C.c_int32),
+                ("rank_emit", C.c_int32), ("reserved3", C.c_int32)]
 
 
 class SgnsParams(C.Structure):
@@ -91,6 +94,9 @@ def load():
     L.n2v_hops8_build.restype = C.c_int
     L.n2v_hops8_build.argtypes = [C.POINTER(Graph), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                   C.c_void_p, C.c_void_p]
+    L.n2v_rank_hops_build.restype = C.c_int
+    L.n2v_rank_hops_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]
     L.n2v_pivots_build.restype = C.c_int
     L.n2v_pivots_build.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.n2v_walk.restype = C.c_int

@@ -114,3 +114,53 @@ extern "C" int n2v_hops_build(const n2v_graph *g, n2v_hop *hops_out, uint32_t *s
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
 }
+
+namespace n2v {
+// One wave per 64 consecutive ranks (neighbouring ranks have neighbouring degrees): rows of 64
+// entries or more are copied by the whole wave one after the other, shorter ones lane per row.
+__global__ __launch_bounds__(256) void rank_hops_build_kernel(n2v_graph g, const int32_t *__restrict__ rank_of,
+                                                              const int32_t *__restrict__ rank_vertex,
+                                                              const int64_t *__restrict__ rank_rowptr,
+                                                              uint32_t *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int64_t groups = (g.n_vertices + 63) >> 6;
+  for (int64_t grp = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); grp < groups; grp += n_waves) {
+    const int64_t r = grp * 64 + lane;
+    int64_t src = 0, dst = 0;
+    int d = 0;
+    if (r < g.n_vertices) {
+      const int32_t v = rank_vertex[r];
+      src = g.rowptr[v];
+      d = (int)(g.rowptr[v + 1] - src);
+      dst = rank_rowptr[r];
+    }
+    uint64_t big = ballot64(d >= 64);
+    while (big) {
+      const int l = __builtin_ctzll(big);
+      big &= big - 1;
+      const int64_t s_src = __shfl(src, l, 64), s_dst = __shfl(dst, l, 64);
+      const int s_d = __shfl(d, l, 64);
+      for (int k = lane; k < s_d; k += 64) out[s_dst + k] = (uint32_t)rank_of[g.col[s_src + k]];
+    }
+    if (d < 64)
+      for (int k = 0; k < d; ++k) out[dst + k] = (uint32_t)rank_of[g.col[src + k]];
+  }
+}
+}  // namespace n2v
+
+extern "C" int n2v_rank_hops_build(const n2v_graph *g, const int32_t *rank_of, const int32_t *rank_vertex,
+                                   const int64_t *rank_rowptr, uint32_t *out, void *stream) {
+  if (!g || !g->rowptr || g->n_vertices < 0 || g->n_edges < 0) return N2V_EINVAL;
+  if (g->w || g->w64) return N2V_EINVAL;  // unit-weight graphs only
+  if (g->n_edges >= (1ll << N2V_HOP_DEG_SHIFT) || g->n_vertices >= (1ll << 31)) return N2V_EINVAL;
+  if (g->n_edges == 0) return N2V_OK;
+  if (!g->col || !rank_of || !rank_vertex || !rank_rowptr || !out) return N2V_EINVAL;
+  int64_t blocks = ((g->n_vertices + 63) / 64 + 3) / 4;
+  const int64_t cap = n2v::resident_blocks((const void *)n2v::rank_hops_build_kernel, 256, 0) * 4;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(n2v::rank_hops_build_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     *g, rank_of, rank_vertex, rank_rowptr, out);
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}

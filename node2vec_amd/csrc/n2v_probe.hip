@@ -7,6 +7,10 @@
 //   mode 2  random rows of `row_bytes` read by one wave, 8 bytes per lane at 512 bytes, four rows
 //           in flight                                              -- a syn0 / syn1neg row (K3)
 //   mode 3  the same rows read, changed and written back           -- a trained row (K3)
+//   mode 4  one dependent chain of random 4-byte reads per lane with a binary search over an LDS
+//           table of `row_bytes` degree classes between them        -- a walker on a graph whose
+//           vertices are numbered by descending degree (entry = the id alone; row start and degree
+//           follow from the id's class)
 //
 // Addresses come from the counter-based mixer of the walk RNG: uniform over the buffer, so with
 // a buffer much larger than the 256 MB Infinity Cache every access is a miss.
@@ -43,6 +47,41 @@ __global__ __launch_bounds__(256) void probe_gather_kernel(const T *__restrict__
     }
   }
   if (acc == 0x12345678u) sink[0] = acc;  // keeps the loads alive
+}
+
+// mode 4: what a step costs when the 4-byte entry names the next vertex and its row is found
+// through the class table (first id of the class, row offset of that id, degree of the class)
+__global__ __launch_bounds__(1024) void probe_class_chain_kernel(const uint32_t *__restrict__ t, uint64_t n_el,
+                                                                 int classes, int iters, uint32_t *sink) {
+  extern __shared__ uint32_t lds_probe[];
+  uint32_t *first = lds_probe;                                          // [classes] ascending ids
+  uint64_t *where = reinterpret_cast<uint64_t *>(lds_probe + classes);  // [classes] offset | degree << 40
+  const uint64_t n_v = n_el / 8 > 2 ? n_el / 8 : 2;
+  for (int c = threadIdx.x; c < classes; c += blockDim.x) {
+    // class c holds the ids [n_v (c / classes)^3, ...): one vertex per class at the head, millions at
+    // the tail, degrees falling from `classes` to 1
+    const double f = (double)c / (double)classes;
+    first[c] = (uint32_t)((double)n_v * f * f * f);
+    where[c] = ((uint64_t)((double)n_el * f * f) & ((1ull << 40) - 1)) | (uint64_t)(classes - c) << 40;
+  }
+  __syncthreads();
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t acc = 0;
+  uint64_t idx = mix64(gid) % n_el;
+  for (int k = 0; k < iters; ++k) {
+    const uint32_t r = t[idx];
+    acc += r;
+    const uint64_t bits = mix64((uint64_t)r ^ (gid + (uint64_t)k * 0x9E3779B97F4A7C15ULL));
+    const uint32_t v = (uint32_t)(((bits >> 32) * n_v) >> 32);  // stands for the id the entry names
+    int c = 0;
+    for (int half = classes >> 1; half > 0; half >>= 1)  // largest c with first[c] <= v
+      if (first[c + half] <= v) c += half;
+    const uint64_t wv = where[c];
+    const uint32_t deg = (uint32_t)(wv >> 40);
+    const uint64_t row = (wv & ((1ull << 40) - 1)) + (uint64_t)(v - first[c]) * deg;
+    idx = (row + (uint32_t)(((uint64_t)(uint32_t)bits * deg) >> 32)) % n_el;
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
 }
 
 template <bool kWrite>
@@ -90,11 +129,22 @@ __global__ __launch_bounds__(256) void probe_rows_kernel(float *t, uint64_t n_ro
 extern "C" int n2v_mem_probe(void *buffer, int64_t buffer_bytes, int32_t mode, int32_t iters,
                              int32_t row_bytes, int64_t *accesses_host, uint32_t *sink,
                              void *stream) {
-  if (!buffer || !sink || buffer_bytes < 4096 || iters < 4 || (iters & 3) || mode < 0 || mode > 3)
+  if (!buffer || !sink || buffer_bytes < 4096 || iters < 4 || (iters & 3) || mode < 0 || mode > 4)
     return N2V_EINVAL;
   if ((reinterpret_cast<uintptr_t>(buffer) & 15u) != 0) return N2V_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int threads = 256;
+  if (mode == 4) {
+    const int classes = row_bytes;  // a power of two
+    if (classes < 64 || classes > 8192 || (classes & (classes - 1))) return N2V_EINVAL;
+    const size_t lds = (size_t)classes * 12;
+    const int64_t blocks = n2v::resident_blocks((const void *)n2v::probe_class_chain_kernel, 1024, lds);
+    if (accesses_host) *accesses_host = blocks * 1024 * (int64_t)iters;
+    hipLaunchKernelGGL(n2v::probe_class_chain_kernel, dim3((unsigned)blocks), dim3(1024), lds, st,
+                       (const uint32_t *)buffer, (uint64_t)(buffer_bytes / 4), classes, iters, sink);
+    N2V_HIP_CHECK(hipGetLastError());
+    return N2V_OK;
+  }
   if (mode <= 1) {
     // row_bytes selects the element width of the gathers here: 0 / 16 = 16-byte, 8, 4
     const int width = row_bytes == 0 ? 16 : row_bytes;

@@ -21,15 +21,45 @@
 //     64-byte sector reads per second whatever the kernel does (profiles/r02_gather_ceiling.log),
 //     so halving the sectors per step is the only lever left; it costs 16 B/edge of HBM
 //     (12 GB at cfg 4 of 288 GB).
+//   * round 4, the degree-ranked form (n2v_graph.rank_hops): the chip serves random 4-byte reads of
+//     a 3 GB table at 52 G/s against 40 G/s for 16-byte reads of a 12 GB one (n2v_mem_probe modes
+//     1 / 4, profiles/r4x_probe_classes.log), and an entry can be the neighbour's id alone once
+//     vertices are numbered by descending degree: rows lie in rank order, so the row of a rank is
+//     offset(class) + (rank - first(class)) * degree(class), the class found by a 13-step search of
+//     an LDS table (the probe shows the search is free: 51.6 - 53.2 G/s).  The few top ranks whose
+//     degrees are all different are looked up in a small cached table instead.
 // Same uniform stream as every other kernel (step_bits, n2v_common.h): bit-identical walks.
 #include "n2v_common.h"
 
 namespace n2v {
 
+// row start and degree of rank x (degree-ranked form): the head table for the top ranks, else the
+// degree class of x by a fixed-depth search of the LDS table (first[0] == head_n <= x; the entry
+// after the last class and the padding hold n_vertices / n_edges, never <= x).  8 bytes per class:
+// its degree is (offset of the next class - its own) / (its number of ranks).
+__device__ __forceinline__ void rank_row(const n2v_graph &g, const uint32_t *first, const uint32_t *off,
+                                         uint32_t x, int64_t &vb, int &n) {
+  if (x < (uint32_t)g.rank_head_n) {
+    const uint64_t e = g.rank_head[x];
+    vb = (int64_t)(e & N2V_HOP_ROW_MASK);
+    n = (int)(e >> N2V_HOP_DEG_SHIFT);
+    return;
+  }
+  int c = 0;
+  for (int half = g.rank_classes >> 1; half > 0; half >>= 1)
+    if (first[c + half] <= x) c += half;
+  const uint32_t f0 = first[c], o0 = off[c];
+  const uint32_t d = (off[c + 1] - o0) / (first[c + 1] - f0);
+  n = (int)d;
+  vb = (int64_t)(o0 + (x - f0) * d);  // < n_edges < 2^32
+}
+
 // kHops: 0 = CSR arrays (two gathers per step), 1 = the 16-byte hop table, 2 = the 8-byte hop
-// table (round 3: the chip serves 8-byte gathers over a table half the size a quarter faster)
-template <int kHops>
-__global__ __launch_bounds__(256, 8) void walk_uniform_kernel(
+// table (round 3: the chip serves 8-byte gathers over a table half the size a quarter faster),
+// 3 = the degree-ranked 4-byte table (blocks of 1024 threads, the class table in LDS: up to 8191
+// classes in 64 KB, two blocks per CU)
+template <int kHops, int kThreads>
+__global__ __launch_bounds__(kThreads, 8) void walk_uniform_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, uint64_t seed, int32_t *__restrict__ walks_out,
     uint8_t *__restrict__ valid_out, uint32_t *__restrict__ status) {
@@ -38,6 +68,17 @@ __global__ __launch_bounds__(256, 8) void walk_uniform_kernel(
   const int L1 = walk_length + 1;
   // whole sectors need a 64-byte aligned output base (torch / hipMalloc give >= 256)
   const bool base_aligned = (reinterpret_cast<uintptr_t>(walks_out) & 63u) == 0;
+  extern __shared__ uint32_t rank_lds[];
+  const uint32_t *cls_first = rank_lds;
+  const uint32_t *cls_where = rank_lds + (kHops == 3 ? g.rank_classes : 0);
+  if (kHops == 3) {
+    for (int c = threadIdx.x; c < g.rank_classes; c += kThreads) {
+      rank_lds[c] = g.rank_class_first[c];
+      rank_lds[g.rank_classes + c] = g.rank_class_off[c];
+    }
+    __syncthreads();
+  }
+  const bool emit_rank = kHops == 3 && g.rank_emit != 0;
   for (;;) {
     uint32_t t = 0;
     if (lane == 0) t = atomicAdd(&status[1], 64u);
@@ -59,7 +100,15 @@ __global__ __launch_bounds__(256, 8) void walk_uniform_kernel(
     }
     int64_t vb = 0;
     int n = 0;
-    if (alive) {
+    int32_t v_emit = v;
+    if (kHops == 3) {
+      if (alive) {
+        const int32_t rk = g.rank_of[v];
+        if (emit_rank) v_emit = rk;
+        rank_row(g, cls_first, cls_where, (uint32_t)rk, vb, n);
+        alive = n > 0;  // fugue.py:132
+      }
+    } else if (alive) {
       vb = g.rowptr[v];
       n = (int)(g.rowptr[v + 1] - vb);
       alive = n > 0;  // fugue.py:132
@@ -93,7 +142,7 @@ __global__ __launch_bounds__(256, 8) void walk_uniform_kernel(
       lo = 0;
     };
     if (have) {
-      put(w0, alive ? v : -1);
+      put(w0, alive ? v_emit : -1);
       if ((w0 & 15) == 15 || walk_length == 0) flush(w0);
     }
     for (int step = 0; step < walk_length; ++step) {
@@ -102,7 +151,11 @@ __global__ __launch_bounds__(256, 8) void walk_uniform_kernel(
       if (walking) {
         const uint64_t bits = step_bits(h0, (uint32_t)step);
         const int pick = pick_index((uint32_t)(bits >> 32), n);  // int(r1 * n); r2 is irrelevant
-        if (kHops == 2) {
+        if (kHops == 3) {
+          const uint32_t xr = g.rank_hops[vb + pick];
+          x = emit_rank ? (int32_t)xr : g.rank_vertex[xr];
+          if (step + 1 < walk_length) rank_row(g, cls_first, cls_where, xr, vb, n);
+        } else if (kHops == 2) {
           const uint64_t h = g.hops8[vb + pick];
           const int cb = g.hop8_col_bits, rb = g.hop8_row_bits;
           x = (int32_t)(h & ((1ull << cb) - 1ull));
@@ -154,18 +207,35 @@ extern "C" int n2v_walk_uniform_try(const n2v_graph *g, const int32_t *start_ids
   if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
     return N2V_ELAUNCH;
   int64_t blocks = (total + 255) / 256;
-  const int form = g->hops8 ? 2 : (g->hops ? 1 : 0);
+  const int form = g->rank_hops ? 3 : g->hops8 ? 2 : (g->hops ? 1 : 0);
+  if (form == 3) {
+    const int P = g->rank_classes;
+    if (P < 2 || P > 8192 || (P & (P - 1)) || !g->rank_of || !g->rank_class_first || !g->rank_class_off ||
+        g->n_edges >= (1ll << 32) ||
+        g->rank_head_n < 0 || g->rank_head_n > (1 << 22) || (g->rank_head_n > 0 && !g->rank_head) ||
+        (g->rank_emit == 0 && !g->rank_vertex) || (g->rank_emit & ~1))
+      return N2V_EINVAL;
+    const size_t lds = (size_t)P * 8;
+    blocks = (total + 1023) / 1024;
+    const int64_t cap3 = n2v::resident_blocks((const void *)n2v::walk_uniform_kernel<3, 1024>, 1024, lds);
+    if (blocks > cap3) blocks = cap3;
+    hipLaunchKernelGGL((n2v::walk_uniform_kernel<3, 1024>), dim3((unsigned)blocks), dim3(1024), lds,
+                       (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, seed, walks_out,
+                       valid_out, status);
+    if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
+    return 1;
+  }
   if (form == 2 && (g->hop8_col_bits < 1 || g->hop8_row_bits < 1 ||
                     g->hop8_col_bits + g->hop8_row_bits > 62 || g->hop8_align_shift < 0 ||
                     g->hop8_align_shift > 6 || (g->hop8_align_shift > 0 && !g->hop8_rowptr)))
     return N2V_EINVAL;
-  const void *fn = form == 2   ? (const void *)n2v::walk_uniform_kernel<2>
-                   : form == 1 ? (const void *)n2v::walk_uniform_kernel<1>
-                               : (const void *)n2v::walk_uniform_kernel<0>;
+  const void *fn = form == 2   ? (const void *)n2v::walk_uniform_kernel<2, 256>
+                   : form == 1 ? (const void *)n2v::walk_uniform_kernel<1, 256>
+                               : (const void *)n2v::walk_uniform_kernel<0, 256>;
   const int64_t cap = n2v::resident_blocks(fn, 256, 0);
   if (blocks > cap) blocks = cap;
 #define N2V_UNIFORM_LAUNCH(F)                                                                     \
-  hipLaunchKernelGGL(n2v::walk_uniform_kernel<F>, dim3((unsigned)blocks), dim3(256), 0,          \
+  hipLaunchKernelGGL((n2v::walk_uniform_kernel<F, 256>), dim3((unsigned)blocks), dim3(256), 0,   \
                      (hipStream_t)stream, *g, start_ids, n_start, num_walks, walk_length, seed,  \
                      walks_out, valid_out, status)
   if (form == 2)

@@ -48,6 +48,14 @@ class DeviceGraph:
         self.wedge_slots: Optional[torch.Tensor] = None  # int16 [E, 16]: n2v_wedge_slots_build
         self.hops_inline_rpos = False  # the hop table's class words carry return positions (slots kernel)
         self._inline_ok = None  # (edge_classes tensor, every return count < 128): can_inline_rpos()
+        # the degree-ranked form (build_ranked): 4-byte entries for p = q = 1 walks
+        self.rank_hops: Optional[torch.Tensor] = None  # int32 [E] (uint32 ranks)
+        self.rank_of: Optional[torch.Tensor] = None  # int32 [V] vertex id -> rank
+        self.rank_vertex: Optional[torch.Tensor] = None  # int32 [V] rank -> vertex id
+        self.rank_head: Optional[torch.Tensor] = None  # int64 [H]
+        self.rank_class_first: Optional[torch.Tensor] = None  # int32 [P] (uint32)
+        self.rank_class_off: Optional[torch.Tensor] = None  # int32 [P] (uint32)
+        self.rank_tried = False
 
     @property
     def w(self) -> torch.Tensor:
@@ -137,14 +145,15 @@ class DeviceGraph:
         g = DeviceGraph(self.rowptr.to(device), self.col.to(device),
                         None if self._w is None else self._w.to(device))
         for name in ("slots", "pivots", "edge_classes", "hops", "hops8", "hops8_rowptr", "wedge_off",
-                     "wedge_pos", "wedge_slots"):
+                     "wedge_pos", "wedge_slots", "rank_hops", "rank_of", "rank_vertex", "rank_head",
+                     "rank_class_first", "rank_class_off"):
             t = getattr(self, name)
             if t is not None:
                 setattr(g, name, t.to(device))
         g.hops_have_classes = self.hops_have_classes
         g.hops8_bits, g.hops8_shift = self.hops8_bits, self.hops8_shift
         # a declined build (escape share, memory budget) stays declined on the copy
-        g.hops8_tried, g.wedge_tried = self.hops8_tried, self.wedge_tried
+        g.hops8_tried, g.wedge_tried, g.rank_tried = self.hops8_tried, self.wedge_tried, self.rank_tried
         g.hops_inline_rpos = self.hops_inline_rpos
         return g
 
@@ -165,7 +174,16 @@ class DeviceGraph:
                           self.hops8_bits[0], self.hops8_bits[1],
                           0 if self.hops8_rowptr is None else self.hops8_rowptr.data_ptr(),
                           self.hops8_shift, int(self.hops_inline_rpos and self.hops is not None),
-                          0 if self.wedge_slots is None else self.wedge_slots.data_ptr())
+                          0 if self.wedge_slots is None else self.wedge_slots.data_ptr(),
+                          *self._rank_fields())
+
+    def _rank_fields(self):
+        if self.rank_hops is None:
+            return (0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+        return (self.rank_hops.data_ptr(), self.rank_of.data_ptr(), self.rank_vertex.data_ptr(),
+                0 if self.rank_head is None else self.rank_head.data_ptr(),
+                self.rank_class_first.data_ptr(), self.rank_class_off.data_ptr(),
+                0 if self.rank_head is None else self.rank_head.numel(), self.rank_class_first.numel(), 0, 0)
 
     # -- a9 -----------------------------------------------------------------------
     def trimmed(self, max_out_degree: int, seed: int) -> "DeviceGraph":
@@ -396,6 +414,69 @@ class DeviceGraph:
             _lib.check(rc, "n2v_hops8_build")
             self.hops8, self.hops8_bits, self.hops8_rowptr, self.hops8_shift = hops8, (cb, rb), trow, shift
             return self
+        return self
+
+    # The degree-ranked form keeps its class table in LDS (8 bytes per class, 64 KB for each of the
+    # two blocks of 1024 threads of a CU); should a graph have more distinct degrees, its top ranks
+    # go to a small table in HBM that stays cached.
+    RANK_MAX_CLASSES = 8191
+    RANK_MAX_HEAD = 1 << 22
+
+    def build_ranked(self) -> "DeviceGraph":
+        """The degree-ranked form for p = q = 1 walks on unit weights (n2v_graph.rank_*,
+        n2v_rank_hops_build): vertices numbered by descending degree (stable: ties by ascending
+        id), rows laid out in rank order, an entry = the 4-byte rank of the neighbour.  The row of a
+        rank follows from its degree class: offset(class) + (rank - first(class)) * degree(class).
+        4 bytes per edge + 8 per vertex; declined (rank_hops stays None) when the graph is
+        weighted, has 2^32 edges or more, a degree needs more than 24 bits, or more than
+        RANK_MAX_HEAD top vertices would have to be listed one by one."""
+        L = _lib.load()
+        _lib.require_gpu()
+        self.rank_tried = True
+        self.rank_hops = None
+        if not self.unit_weights or not self.rowptr.is_cuda:
+            return self
+        n, dev = self.n_vertices, self.device
+        deg = self.degrees()
+        if (self.n_edges == 0 or self.n_edges >= (1 << 32) or n >= (1 << 31)
+                or int(deg.max()) >= self.HOP_MAX_DEGREE):
+            return self
+        order = torch.sort(deg, descending=True, stable=True).indices
+        deg_r = deg[order]
+        rank_vertex = order.to(torch.int32)
+        rank_of = torch.empty(n, dtype=torch.int32, device=dev)
+        rank_of[order] = torch.arange(n, dtype=torch.int32, device=dev)
+        del order
+        rank_rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(deg_r, 0, out=rank_rowptr[1:])
+        cls_deg, cls_count = torch.unique_consecutive(deg_r, return_counts=True)
+        cls_first = torch.cumsum(cls_count, 0) - cls_count
+        n_cls = int(cls_deg.numel())
+        keep = min(n_cls, self.RANK_MAX_CLASSES)
+        head_n = int(cls_first[n_cls - keep].item())  # ranks below it are looked up one by one
+        if head_n > self.RANK_MAX_HEAD:
+            return self
+        P = 2
+        while P < keep + 1:  # one entry after the last class closes it
+            P *= 2
+        first = torch.full((P,), n, dtype=torch.int64, device=dev)
+        off = torch.full((P,), self.n_edges, dtype=torch.int64, device=dev)
+        kept_first = cls_first[n_cls - keep:]
+        first[:keep] = kept_first
+        off[:keep] = rank_rowptr[kept_first]
+        head = None
+        if head_n:
+            head = (rank_rowptr[:head_n] | (deg_r[:head_n] << 40)).contiguous()
+        del deg_r, cls_deg, cls_count, cls_first
+        hops = torch.empty(self.n_edges, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.n2v_rank_hops_build(self.c_struct(), rank_of.data_ptr(), rank_vertex.data_ptr(),
+                                             rank_rowptr.data_ptr(), hops.data_ptr(),
+                                             _lib.current_stream_ptr()), "n2v_rank_hops_build")
+        self.rank_of, self.rank_vertex, self.rank_head = rank_of, rank_vertex, head
+        self.rank_class_first = first.to(torch.int32)
+        self.rank_class_off = torch.where(off >= (1 << 31), off - (1 << 32), off).to(torch.int32)  # uint32 bits
+        self.rank_hops = hops
         return self
 
     def build_pivots(self) -> "DeviceGraph":

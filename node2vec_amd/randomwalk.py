@@ -70,7 +70,8 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
          out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, check: bool = True,
          stats: Optional[dict] = None, use_edge_classes: bool = True, use_hops: bool = True,
          use_wedges: bool = True, use_wedge_kernel: bool = True, use_hops8: bool = True,
-         use_workspace: bool = False, use_wedge_slots: bool = True):
+         use_workspace: bool = False, use_wedge_slots: bool = True, use_ranked: Optional[bool] = None,
+         rank_ids: bool = False):
     """Launch K2.  Returns (walks int32 [n_start*num_walks, walk_length+1], valid bool).
 
     mode "fast", and on weighted graphs mode "exact" with return_param == inout_param == 1
@@ -89,7 +90,13 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     dyadic p, q that walk then runs in passes over a workspace lent to the library (n2v_walk_ws:
     closed forms in the main launches, the ~1 % of steps they decline replayed out of line;
     64 bytes per walker, allocated here); use_workspace=False keeps the one-launch kernel: same
-    bits."""
+    bits.
+    Exact p = q = 1 walks on unit weights can run on the degree-ranked form (graph.build_ranked():
+    4-byte entries, the neighbour's RANK by descending degree).  rank_ids=True returns the walks in
+    ranks (map with graph.rank_vertex, or compose it into the per-token lookup that follows, as
+    fit_streaming does): the form is built on first use and one step is one 4-byte gather.  With
+    rank_ids=False the kernel translates every token back (one more gather): use_ranked=True asks
+    for that, the default (None) keeps the hop tables for vertex-id output."""
     L = _lib.load()
     _lib.require_gpu()
     if mode not in MODES:
@@ -136,14 +143,24 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
             graph.build_alias()
         except ZeroDivisionError:
             pass  # some row sums to 0: keep the per-step path, which raises only if it is visited
+    ranked = False
+    if graph.unit_weights and not biased and mode == "exact" and (rank_ids or use_ranked):
+        if graph.rank_hops is None and not graph.rank_tried:
+            graph.build_ranked()
+        ranked = graph.rank_hops is not None
+    if rank_ids and not ranked:
+        raise ValueError("rank_ids: exact p = q = 1 walks on a unit-weight graph that has a degree-ranked "
+                         "form (graph.build_ranked()) only")
     uniform8 = False
-    if graph.unit_weights and use_hops and use_hops8 and not biased and mode == "exact":
+    if ranked:
+        pass
+    elif graph.unit_weights and use_hops and use_hops8 and not biased and mode == "exact":
         # p == q == 1: the 8-byte hop table (built once, when the graph's field widths allow it and
         # its high-degree rows are few enough to stay cached) -- one 8-byte gather per step
         if graph.hops8 is None and not graph.hops8_tried:
             graph.build_hops8()
         uniform8 = graph.hops8 is not None
-    if graph.unit_weights and use_hops and not uniform8:
+    if graph.unit_weights and use_hops and not uniform8 and not ranked:
         # hop table (16 bytes per edge): one gather per step instead of two or three.  It embeds
         # the class counts, so it is (re)built after them when a biased walk first needs them.
         want_classes = graph.edge_classes is not None
@@ -173,6 +190,9 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
         g.hops = 0
     if not uniform8:
         g.hops8 = 0
+    if not ranked:
+        g.rank_hops = 0
+    g.rank_emit = 1 if rank_ids else 0
     if not use_wedges or not use_edge_classes:
         g.wedge_off = 0
         g.wedge_pos = 0
