@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
+    ap.add_argument("--no-ranked", action="store_true",
+                    help="p = q = 1: keep vertex-id output as the headline (no degree-ranked form)")
     ap.add_argument("--num-walks", type=int, default=10)
     ap.add_argument("--walk-length", type=int, default=80)
     ap.add_argument("--batch", type=int, default=0, help="start vertices per step per GPU (0 = config)")
@@ -116,7 +118,8 @@ def reference_algorithmic_bytes(torch, g, walks, valid, rows=65536):
 class WalkLeg:
     """K timed launches of n2v_walk over batches of start vertices."""
 
-    def __init__(self, torch, rw, g, start_all, W, L, p, q, mode, batch, rank, world):
+    def __init__(self, torch, rw, g, start_all, W, L, p, q, mode, batch, rank, world, rank_ids=False):
+        self.rank_ids = rank_ids  # the walks come out in degree ranks (fit_streaming's form at p = q = 1)
         self.torch, self.rw, self.g, self.start_all = torch, rw, g, start_all
         self.W, self.L, self.p, self.q, self.mode = W, L, p, q, mode
         self.batch = int(min(batch, start_all.numel()))
@@ -133,7 +136,7 @@ class WalkLeg:
 
     def step(self, k):
         self.rw.walk(self.g, self.starts(k), self.W, self.L, self.p, self.q, 42, mode=self.mode,
-                     out=(self.walks, self.valid), check=False, stats=self.stats)
+                     out=(self.walks, self.valid), check=False, stats=self.stats, rank_ids=self.rank_ids)
 
     def run(self, steps, warmup, barrier):
         torch = self.torch
@@ -234,11 +237,40 @@ def main():
             c = measure_ceilings(torch, table, gather_width=width)
             setup["measured_gather_ceiling"] = dict(c, table_GB=table.numel() * table.element_size() / 1e9,
                                                     gather_bytes=width)
-    leg = WalkLeg(torch, rw, g, start_all, W, L, p, q, "exact", batch, rank, world)
+    # p = q = 1 on unit weights: fit_streaming walks the degree-ranked form (4-byte entries) and
+    # takes the walks in RANKS -- the same walks, vertex for vertex, under the graph's other
+    # numbering; rank -> vertex id is folded into the per-token vocabulary lookup that follows.
+    # That launch is the headline; the launch that writes vertex ids (what random_walk() puts in
+    # its DataFrame: the hop-table kernel) is timed first and reported beside it.
+    in_ranks = False
+    if p == 1.0 and q == 1.0 and g.unit_weights and not args.no_ranked:
+        t0 = time.perf_counter()
+        g.build_ranked()
+        torch.cuda.synchronize()
+        setup["headline_rank_table_build_s"] = time.perf_counter() - t0
+        in_ranks = g.rank_hops is not None
+    vertex_leg = None
+    if in_ranks:
+        leg = WalkLeg(torch, rw, g, start_all, W, L, p, q, "exact", batch, rank, world)
+        rv = leg.run(args.steps, args.warmup, barrier)
+        ev, sv = reduce_job(torch, dist, use_dist, dev, rv["elapsed"], rv["steps_done"])
+        if rank == 0:
+            vertex_leg = {"value": sv / ev, "unit": "walk-steps/s", "ms_per_step": 1e3 * ev / args.steps,
+                          "what": "the same walks written as vertex ids (randomwalk.walk's default, the "
+                                  "random_walk() DataFrame): hop-table kernel, 16- or 8-byte entries",
+                          "roofline": roofline(kernel_name(g, p, q), rv, leg, args.config, p, q, "exact", None)}
+            c4 = measure_ceilings(torch, g.rank_hops, gather_width=4, classes=g.rank_class_first.numel())
+            setup["measured_gather_ceiling_ranked"] = dict(c4, table_GB=g.rank_hops.numel() * 4 / 1e9,
+                                                           gather_bytes=4)
+        del leg
+        torch.cuda.empty_cache()
+    leg = WalkLeg(torch, rw, g, start_all, W, L, p, q, "exact", batch, rank, world, rank_ids=in_ranks)
     res = leg.run(args.steps, args.warmup, barrier)
     elapsed, steps_total = reduce_job(torch, dist, use_dist, dev, res["elapsed"], res["steps_done"])
     value = steps_total / elapsed
     head_kernel = kernel_name(g, p, q)
+    if in_ranks:  # everything below reads vertex ids (outside the timed region)
+        leg.walks = torch.where(leg.walks >= 0, g.rank_vertex[leg.walks.clamp(min=0).long()], leg.walks)
     # the SGNS legs train on walks of this leg (rows of the last batch walked)
     nv = min(cfg["sgns_vertices"], leg.batch)
     sg_walks = leg.walks[: nv * W][leg.valid[: nv * W].bool()].clone()
@@ -256,11 +288,16 @@ def main():
         "config": {"workload": workload, "graph": cfg["label"], "seed": 42, "num_walks": W,
                    "walk_length": L, "start_vertices_per_step_per_gpu": leg.batch,
                    "walk_mode": "exact", "n_vertices": g.n_vertices,
+                   "walk_ids": ("degree ranks (the graph numbered by descending degree; the same walks; "
+                                "fit_streaming composes rank -> vertex id into its per-token vocabulary "
+                                "lookup); vertex-id output: see vertex_id_output") if in_ranks else "vertex ids",
                    "n_edges": g.n_edges, "start_vertices": int(start_all.numel()),
                    "parallelism": f"graph replicated, start vertices range-sharded x{world}"},
     }
     if rank == 0:
         out["roofline"] = roofline(head_kernel, res, leg, args.config, p, q, "exact", ref_bytes)
+        if vertex_leg is not None:
+            out["vertex_id_output"] = vertex_leg
     del leg
     torch.cuda.empty_cache()
 
@@ -332,7 +369,7 @@ def main():
         torch.cuda.empty_cache()
     # the walk tables are not needed any more (the CPU baseline reads rowptr / col only)
     g.slots = g.pivots = g.hops = g.hops8 = g.edge_classes = g.wedge_off = g.wedge_pos = None
-    g.wedge_slots = None
+    g.wedge_slots = g.rank_hops = g.rank_of = g.rank_vertex = None
     torch.cuda.empty_cache()
 
     # ---- SGNS on the config's model ------------------------------------------------------------
@@ -419,8 +456,15 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
     algorithm's bytes are reported beside it, never as the roofline."""
     per_launch_steps = leg.batch * leg.W * leg.L
     hops = leg.g.hops is not None
-    hop8 = leg.g.hops8 is not None and mode == "exact" and p == 1.0 and q == 1.0
-    if mode == "fast":
+    ranked = bool(getattr(leg, "rank_ids", False))
+    hop8 = leg.g.hops8 is not None and mode == "exact" and p == 1.0 and q == 1.0 and not ranked
+    if ranked:
+        head = 0 if leg.g.rank_head is None else leg.g.rank_head.numel()
+        alg = 4 + 4
+        formula = ("4 (table entry: the neighbour's degree rank; its row follows from its degree class, "
+                   f"{leg.g.rank_class_first.numel()}-entry table in LDS"
+                   f"{f', the first {head} ranks from a cached table' if head else ''}) + 4 (path write) per step")
+    elif mode == "fast":
         t = res["trials"] / max(res["steps_done"], 1)
         alg = (t * 16 + 4) if hops else (16 + t * 16 + 4)
         formula = ("trials * 16 (hop entry: neighbour, its row and degree, edge classes) + 4 (path)"
@@ -461,7 +505,7 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
                     "whose edge has shared neighbours; the steps that run the pairing read 2 bytes per "
                     "shared neighbour at most" if wedges else
                     ", + 4 per probe of the membership search; steps that run the pairing read both rows"))
-    kernel_key = kernel + (":hop8" if hop8 else (":hops" if hops else "")) + (
+    kernel_key = kernel + (":ranked" if ranked else ":hop8" if hop8 else (":hops" if hops else "")) + (
         ":wedges" if (leg.g.wedge_off is not None and mode == "exact" and not (p == 1.0 and q == 1.0)) else "")
     # bytes past L2 per launch from the COMMITTED rocprofv3 --pmc passes of this command: not
     # observed in this run, so it is reported as `traffic_committed`; `traffic` (the contract's
@@ -471,7 +515,7 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
     ach = alg_launch / res["kernel_s"]
     r = {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
          "frac": ach / HBM_PEAK, "traffic": None, "traffic_committed": traffic, "kernel": kernel,
-         "hop_table": "8-byte" if hop8 else hops,
+         "hop_table": "4-byte degree-ranked" if ranked else "8-byte" if hop8 else hops,
          "wedge_table": ":wedges" in kernel_key,
          "kernel_ms": 1e3 * res["kernel_s"],
          "achieved_from": "ALGORITHMIC bytes of the kernel (formula below) x walk-steps per launch / "
@@ -492,7 +536,16 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
         r["counter_over_algorithmic"] = traffic / alg_launch
         r["sectors_per_walk_step"] = sectors / per_launch_steps
     g_meas = MEASURED.get("gather_independent")
-    if g_meas:
+    if ranked and MEASURED.get("ranked_chain"):
+        gathers = res["steps_done"] / max(res["launches"], 1) / res["kernel_s"]
+        r["gather_ceiling"] = {
+            "gathers_per_walk_step_min": 1.0, "gather_bytes": 4, "kernel_Ggathers_per_s": gathers / 1e9,
+            "measured_Ggathers_per_s_dependent_chain": MEASURED["ranked_chain"] / 1e9,
+            "measured_Ggathers_per_s_chain_with_class_search": MEASURED.get("ranked_chain_class_search", 0.0) / 1e9,
+            "frac": gathers / MEASURED["ranked_chain"],
+            "source": "n2v_mem_probe modes 1 (4-byte) / 4 over the ranked table of this graph, in this "
+                      "process (untimed): what one dependent chain of random 4-byte reads per lane sustains"}
+    elif g_meas:
         # the binding resource, observed on this box: random 16-byte gathers per second
         gathers = (res["trials"] if mode == "fast" and res.get("trials") else res["steps_done"]) / \
             max(res["launches"], 1) / res["kernel_s"]
@@ -522,7 +575,7 @@ def escape_share(leg):
     return float((deg[w] >= esc).float().mean()) if w.numel() else 0.0
 
 
-def measure_ceilings(torch, buffer, tag_rows=None, gather_width=16):
+def measure_ceilings(torch, buffer, tag_rows=None, gather_width=16, classes=None):
     """n2v_mem_probe on `buffer` (a device tensor >> Infinity Cache): random 16-byte gathers,
     and -- when tag_rows names a row size -- random row reads / read-modify-writes.  Untimed
     with respect to the bench's K steps; HIP events around each probe launch."""
@@ -550,6 +603,11 @@ def measure_ceilings(torch, buffer, tag_rows=None, gather_width=16):
                 best = dt if best is None else min(best, dt)
         return n.value / best
 
+    if classes is not None:  # the ranked walk's shape; kept apart from the hop table's figures
+        out["ranked_chain"] = run(1, 256, gather_width)
+        out["ranked_chain_class_search"] = run(4, 256, int(min(max(classes, 64), 8192)))
+        MEASURED.update(out)
+        return out
     if tag_rows is None:
         out["gather_independent"] = run(0, 256, gather_width)
         out["gather_chain"] = run(1, 256, gather_width)

@@ -81,11 +81,19 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
     # sum to 0, randomwalk.py:172-173; an id out of range) is OR-ed on the device over all batches
     # and raised at the two host synchronisations the function has anyway -- never dropped
     walk_status = torch.zeros(1, dtype=torch.int32, device=dev)
+    # p = q = 1 on unit weights: the walks come out in degree RANKS (4-byte table entries, the
+    # fastest walk there is: graph.build_ranked) -- nothing downstream needs vertex ids per token,
+    # only counts per vertex (permuted once) and the per-token vocabulary lookup (composed once)
+    in_ranks = False
+    if graph.unit_weights and pp == 1.0 and qq == 1.0 and mode == "exact" and graph.rowptr.is_cuda:
+        if graph.rank_hops is None and not graph.rank_tried:
+            graph.build_ranked()
+        in_ranks = graph.rank_hops is not None
 
     def walk(k):
         st = {}
         out = rw.walk(graph, start[k * batch_vertices:(k + 1) * batch_vertices].contiguous(), W, L,
-                      pp, qq, seed, mode, check=False, stats=st)
+                      pp, qq, seed, mode, check=False, stats=st, rank_ids=in_ranks)
         walk_status.bitwise_or_(st["status"][:1])
         return out
 
@@ -102,6 +110,8 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
         if walks.numel() == 0:
             continue
         sgns.corpus_count(walks, valid, counts)  # one pass, no widening / clamping / scatter ops
+    if in_ranks:
+        counts = counts[graph.rank_of.long()]  # counted per rank: back to vertex ids
     if multi:
         all_reduce(counts, dist.ReduceOp.SUM)
     t_walk += clock() - t0
@@ -117,6 +127,7 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
     index_of = torch.full((graph.n_vertices,), -1, dtype=torch.int32, device=dev)
     index_of[ids] = torch.arange(ids.numel(), dtype=torch.int32, device=dev)
     vocab = sgns.Vocab(ids, cnt, index_of)
+    token_index = index_of[graph.rank_vertex.long()].contiguous() if in_ranks else index_of
     model = sgns.SgnsModel(vocab, int(p["size"]), int(p["window"]), negative, int(p["seed"] or seed),
                            sample=float(p["sample"] or 0.0), ns_exponent=float(p["ns_exponent"]),
                            device=dev)
@@ -146,7 +157,7 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
             t1 = clock()
             t_walk += t1 - t0
             if walks.numel():
-                idx = sgns.corpus_index(walks, valid, index_of)
+                idx = sgns.corpus_index(walks, valid, token_index)
                 done = (ep * n_batches + k) / (epochs * n_batches)
                 a = max(min_alpha, alpha - (alpha - min_alpha) * done)
                 # sentence id = (epoch, rank, row of the rank's virtual corpus): never repeats

@@ -179,8 +179,11 @@ def test_streaming_pipeline_matches_materialised_corpus():
     assert np.isfinite(out.wv.vectors).all()
 
 
-def test_fit_streaming_deterministic_equals_the_oracle_end_to_end(oracle):
-    """walk -> vocabulary -> SGNS through fit_streaming (HIP, "deterministic": True) against the
+@pytest.mark.parametrize("pq", [(0.5, 2.0), (1.0, 1.0)])
+def test_fit_streaming_deterministic_equals_the_oracle_end_to_end(oracle, pq):
+    """(at p = q = 1 the walks run on the degree-ranked form and come out in ranks: counts and the
+    per-token lookup are translated once, nothing else changes)
+    walk -> vocabulary -> SGNS through fit_streaming (HIP, "deterministic": True) against the
     same pipeline made of the ORACLE's walk, a numpy restatement of gensim's vocabulary / negative
     table / subsampling rule, and the oracle's trainer on the same batches: identical vocabulary,
     pair count and matrices, bit for bit.  (The initial syn0 is the seeded device draw of
@@ -192,12 +195,13 @@ def test_fit_streaming_deterministic_equals_the_oracle_end_to_end(oracle):
     rng = np.random.default_rng(8)  # directed, 5 hubs, the last 20 vertices have no out-edges
     src = np.concatenate([rng.integers(0, 580, 3500), rng.integers(0, 5, 500)])
     g = DeviceGraph.from_edges(src, rng.integers(0, 600, 4000), None, n_vertices=600, device="cuda")
-    W, L, p, q, seed, bv = 3, 12, 0.5, 2.0, 17, 100
+    W, L, (p, q), seed, bv = 3, 12, pq, 17, 100
     n2v = {"num_walks": W, "walk_length": L, "return_param": p, "inout_param": q}
     w2v = {"min_count": 2, "iter": 2, "size": 32, "negative": 5, "sample": 1e-2, "seed": 5, "window": 4,
            "alpha": 0.025, "min_alpha": 1e-4, "deterministic": True}
     out, model = fit_streaming(g, dict(n2v), dict(w2v), random_seed=seed, batch_vertices=bv,
                                return_model=True)
+    assert (g.rank_hops is not None) == (pq == (1.0, 1.0))
     # ---- the same with the oracle ------------------------------------------------------------
     rowptr, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
     start = np.nonzero(np.diff(rowptr) > 0)[0].astype(np.int32)  # fugue.py:132
