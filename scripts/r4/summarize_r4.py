@@ -56,7 +56,11 @@ for line in open(os.path.join(src, "trace.log")):
     if line.startswith("{") and '"metric"' in line:
         bench = json.loads(line)
 
-kernels = {"walk_uniform_kernel": "exact p=q=1", "walk_exact_wedge_kernel": "exact biased (all tables)",
+kernels = {"walk_uniform_kernel<3, 1024>": "exact p=q=1, degree-ranked 4-byte table (ranks out): the headline",
+           "walk_uniform_kernel<1, 256>": "exact p=q=1, 16-byte hop table (vertex ids out)",
+           "walk_uniform_kernel<2, 256>": "exact p=q=1, 8-byte hop table (vertex ids out)",
+           "walk_uniform_kernel<0, 256>": "exact p=q=1, CSR arrays",
+           "walk_exact_wedge_kernel": "exact biased (all tables)",
            "walk_exact_wedge_slots_kernel": "exact biased (all tables, wedge slots)",
            "walk_exact_unit_lanes_kernel": "exact biased",
            "walk_exact_unit_kernel": "exact biased (wave per walker)",
@@ -77,7 +81,7 @@ if stats_files:
             w.writerow(r)
     for r in rows:
         for k in kernels:
-            if "::" + k + "(" in r["Name"] or "::" + k + "<" in r["Name"]:
+            if "::" + k + "(" in r["Name"] or "::" + k + "<" in r["Name"] or ("<" in k and "::" + k in r["Name"]):
                 trace[k] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                             "max_ms": float(r["MaxNs"]) / 1e6, "min_ms": float(r["MinNs"]) / 1e6}
 for k, what in kernels.items():
@@ -119,9 +123,13 @@ tpath = "profiles/pmc_traffic.json"
 table = json.load(open(tpath)) if os.path.exists(tpath) else {}
 if bench:
     def put(kernel, p, q, batch, hops=False, wedges=False):
-        e = out["kernels"].get(kernel)
+        if kernel == "walk_uniform_kernel":  # one entry per instance of the template
+            inst = {"4-byte degree-ranked": "<3, 1024>", "8-byte": "<2, 256>"}.get(hops, "<1, 256>" if hops else "<0, 256>")
+            e = out["kernels"].get(kernel + inst)
+        else:
+            e = out["kernels"].get(kernel)
         if e:
-            tab = ":hop8" if hops == "8-byte" else (":hops" if hops else "")
+            tab = ":ranked" if hops == "4-byte degree-ranked" else ":hop8" if hops == "8-byte" else (":hops" if hops else "")
             table[f"{config}:{kernel}{tab}{':wedges' if wedges else ''}:p{p}:q{q}:batch{batch}"] = {
                 "hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "source": f"profiles/{tag}_summary.json",
                 "FETCH_SIZE_KB": e["FETCH_SIZE_KB"], "WRITE_SIZE_KB": e["WRITE_SIZE_KB"],
@@ -130,6 +138,9 @@ if bench:
     hb = int(bench["config"]["workload"].split(" start vertices per step")[0].split(",")[-1].strip())
     pq = bench["config"]["workload"].split("p=")[1].split(",")[0].split()
     put(head, float(pq[0]), float(pq[1].replace("q=", "")), hb, bench["roofline"].get("hop_table", False))
+    if "vertex_id_output" in bench:
+        put(head, float(pq[0]), float(pq[1].replace("q=", "")), hb,
+            bench["vertex_id_output"]["roofline"].get("hop_table", False))
     if "biased" in bench:
         b = bench["biased"]
         put(b["roofline"]["kernel"], b["p"], b["q"], b["start_vertices_per_step"],
