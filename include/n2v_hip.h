@@ -41,6 +41,7 @@ extern "C" {
 /* bits of the device status word */
 #define N2V_ST_ZERODIV 1u /* sum(weights) == 0: ZeroDivisionError, randomwalk.py:172-173 */
 #define N2V_ST_RANGE 2u   /* a start id outside [0, n_vertices)                          */
+#define N2V_ST_OVERFLOW 4u /* n2v_partition_forward: a mailbox or the word pool was too small */
 
 /* walk sampler modes */
 #define N2V_WALK_EXACT 0 /* per-step biased alias rebuild, bit-identical to the reference */
@@ -516,6 +517,9 @@ int n2v_corpus_index(const int32_t *walks, const uint8_t *valid, const int32_t *
  *                      widened to 32 bits, and head[j][4] = edge_classes | return position << 32 */
 #define N2V_SRC_ROWS 0
 #define N2V_SRC_WEDGES 1
+#define N2V_SRC_WEDGES_AT 2 /* as N2V_SRC_WEDGES, but src_ptr is int64 [k]: where the list of walker i
+                               STARTS in src_ids (its length is the shared count in head[i][4]) -- the
+                               form n2v_partition_forward leaves the lists in */
 int n2v_partition_step(const int64_t *rowptr, const int32_t *col, const float *w, const double *w64,
                        int64_t lo, int64_t n_local, const int64_t *head, int32_t head_cols,
                        const int64_t *src_ptr, const int32_t *src_ids, int32_t src_kind, int64_t k,
@@ -546,6 +550,34 @@ int n2v_partition_group(const int32_t *dest, const int64_t *head, int32_t head_c
                         const int64_t *len, const int64_t *src, int64_t k, int32_t n_parts,
                         int64_t *work, int64_t *head_out, int64_t *len_out, int64_t *src_out,
                         int64_t *cuts_out, void *stream);
+/* Route, group and gather in ONE launch, no size known to the host (round 4).  For walker i: the
+ * path record -- log_out[i] as n2v_partition_route writes it, or, when log_out is NULL, straight
+ * into walks_out[row][step + 1] (valid_out[row] = 0 for a walker that vanished): the single-process
+ * form, where the emitting rank's arrays are at hand --; then, if the walk goes on, the walker is
+ * APPENDED to the mailbox of the part that owns `next`:
+ *   box_head  int64 [n_parts][cap][head_cols]   headers (head[.][4] = edge_classes | return position
+ *                                               << 32 of the edge drawn when carry != 0)
+ *   box_off   int64 [n_parts][cap]              where its list starts in box_words
+ *   box_words int32 [wcap]                      the wedge lists (carry N2V_SRC_WEDGES + 1), one pool
+ *                                               for all destinations
+ *   box_count uint64 [n_parts + 1]              walkers appended per destination; [n_parts] = words
+ *                                               used.  The caller zeroes it before the first launch
+ *                                               of a step; several source parts may append to the
+ *                                               same boxes (wave-aggregated atomic adds).
+ * A full mailbox or pool sets N2V_ST_OVERFLOW in status[0] (the step must be repeated with larger
+ * ones; nothing is written out of bounds).  carry: 0 (headers only: p == q == 1), N2V_SRC_WEDGES + 1
+ * (the list of edge[i]), N2V_SRC_WEDGES + 2 (q == 1: counts and return position only); rows do not
+ * travel this way.  The next n2v_partition_step takes a mailbox as head / src_ptr = box_off /
+ * src_ids = box_words with src_kind N2V_SRC_WEDGES_AT.  Replaces n2v_partition_route +
+ * n2v_partition_group + a prefix sum + n2v_gather_wedges and the host read between them; the order
+ * of the walkers in a mailbox is not defined, the walks are (the RNG is keyed by walker and step). */
+int n2v_partition_forward(const int64_t *head_in, int32_t head_cols, const int32_t *next,
+                          const int64_t *edge, int64_t k, int32_t walk_length, const int64_t *bounds,
+                          int32_t n_parts, int32_t carry, const uint32_t *edge_classes,
+                          const uint64_t *wedge_off, const void *wedge_pos, int32_t wide,
+                          int64_t *box_head, int64_t *box_off, int32_t *box_words,
+                          unsigned long long *box_count, int64_t cap, int64_t wcap, int64_t *log_out,
+                          int32_t *walks_out, uint8_t *valid_out, uint32_t *status, void *stream);
 int n2v_gather_rows(const int64_t *ptr, const int32_t *ids, const int64_t *rows,
                     const int64_t *out_ptr, int64_t k, int32_t *out, void *stream);
 int n2v_gather_wedges(const uint32_t *edge_classes, const uint64_t *wedge_off, const void *wedge_pos,

@@ -13,6 +13,9 @@
 //   n2v_partition_group  the walkers grouped by destination: a stable counting sort (per-block
 //                        counts, one scan, one scatter)
 //   n2v_gather_rows / n2v_gather_wedges  pack what travels with the migrating walkers
+//   n2v_partition_forward  route + group + gather in ONE launch and without a size known to the
+//                        host: every walker is appended to the mailbox of its destination
+//                        (wave-aggregated atomics), its wedge list copied behind it
 #include "n2v_common.h"
 
 extern "C" int n2v_partition_step_generic_launch(const int64_t *rowptr, const int32_t *col,
@@ -38,9 +41,10 @@ extern "C" int n2v_partition_step(const int64_t *rowptr, const int32_t *col, con
                                   uint32_t *status, void *stream) {
   if (k < 0 || n_local < 0 || k >= 0xfffffff0ll || (w && w64)) return N2V_EINVAL;
   if (p == 0.0 || q == 0.0) return N2V_EINVAL;  // randomwalk.py:209-212 (ValueError upstream)
-  if (src_kind != N2V_SRC_ROWS && src_kind != N2V_SRC_WEDGES) return N2V_EINVAL;
+  if (src_kind != N2V_SRC_ROWS && src_kind != N2V_SRC_WEDGES && src_kind != N2V_SRC_WEDGES_AT)
+    return N2V_EINVAL;
   if (head_cols < 4) return N2V_EINVAL;  // (wedge lists with p or q != 1: 5, checked below)
-  if (src_kind == N2V_SRC_WEDGES && (w || w64)) return N2V_EINVAL;  // unit-weight parts only
+  if (src_kind != N2V_SRC_ROWS && (w || w64)) return N2V_EINVAL;  // unit-weight parts only
   if (k == 0) return N2V_OK;
   if (!rowptr || !head || !next_out || !status) return N2V_EINVAL;  // (col: NULL for a part without edges)
   if (q != 1.0 && !src_ptr) return N2V_EINVAL;
@@ -48,11 +52,11 @@ extern "C" int n2v_partition_step(const int64_t *rowptr, const int32_t *col, con
     return N2V_ELAUNCH;
   if (!w && !w64) {  // unit weights: the closed forms of n2v_walk_unit.hip
     const int rc = n2v_partition_step_unit_try(rowptr, col, lo, n_local, head, head_cols, src_ptr,
-                                               src_ids, src_kind == N2V_SRC_WEDGES, k, p, q, seed,
-                                               next_out, edge_out, status, stream);
+                                               src_ids, src_kind == N2V_SRC_ROWS ? 0 : src_kind, k, p,
+                                               q, seed, next_out, edge_out, status, stream);
     if (rc != 0) return rc < 0 ? rc : N2V_OK;
   }
-  if (src_kind == N2V_SRC_WEDGES) return N2V_EINVAL;  // (p, q) outside the unit kernels' range
+  if (src_kind != N2V_SRC_ROWS) return N2V_EINVAL;  // (p, q) outside the unit kernels' range
   return n2v_partition_step_generic_launch(rowptr, col, w, w64, lo, n_local, head, head_cols, src_ptr,
                                            src_ids, k, p, q, seed, next_out, edge_out, status, stream);
 }
@@ -301,3 +305,167 @@ extern "C" int n2v_gather_wedges(const uint32_t *edge_classes, const uint64_t *w
   return N2V_OK;
 }
 
+// ---- route + group + gather in one launch (round 4) ------------------------------------------------
+// One LANE per walker.  What n2v_partition_route computes per walker, then instead of a sort by
+// destination and a prefix sum over the list lengths (three launches, a scan, a host read of the
+// cuts, a gather): the lanes of a wave that go to the same part reserve consecutive places in that
+// part's mailbox with ONE atomic add, the wave reserves the words of its lists with one more, and
+// every lane writes its header and copies its list (lists of 32 words or more by the whole wave).
+// The order inside a mailbox is whatever the atomics gave -- a walk depends on its key and step
+// alone (counter-based RNG), never on its place in a batch.
+constexpr int kFwdThreads = 1024;  // a block reserves mailbox places ONCE per destination and pass
+constexpr int kFwdMaxParts = 256;
+
+__global__ __launch_bounds__(kFwdThreads) void n2v_partition_forward_kernel(
+    const int64_t *__restrict__ head_in, int head_cols, const int32_t *__restrict__ next,
+    const int64_t *__restrict__ edge, int64_t k, int walk_length, const int64_t *__restrict__ bounds,
+    int n_parts, int carry, const uint32_t *__restrict__ edge_classes,
+    const uint64_t *__restrict__ wedge_off, const void *__restrict__ wedge_pos, int wide,
+    int64_t *__restrict__ box_head, int64_t *__restrict__ box_off, int32_t *__restrict__ box_words,
+    unsigned long long *__restrict__ box_count, int64_t cap, int64_t wcap, int64_t *__restrict__ log_out,
+    int32_t *__restrict__ walks_out, uint8_t *__restrict__ valid_out, uint32_t *__restrict__ status) {
+  // Same-address atomics serialise in L2 (~0.1 us each): one per wave and destination made this
+  // kernel take 0.85 ms for 6 x 10^5 walkers.  So the block counts first -- per wave and destination
+  // in LDS --, ONE thread per destination reserves the block's places (and one the block's words),
+  // and every wave takes its share of them.
+  __shared__ uint32_t cnt[kFwdThreads / 64][kFwdMaxParts + 1];   // [wave][dest]; [.][n_parts] = words
+  __shared__ unsigned long long base[kFwdMaxParts + 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t k_up = (k + kFwdThreads - 1) / kFwdThreads * kFwdThreads;  // whole blocks stay in the loop
+  for (int64_t i = (int64_t)blockIdx.x * kFwdThreads + threadIdx.x; i < k_up;
+       i += (int64_t)gridDim.x * kFwdThreads) {
+    const bool have = i < k;
+    int64_t row = 0, key = 0, v = 0, step = 0, src = 0;
+    int32_t nx = -1;
+    int dest = -1;  // -1: not forwarded
+    uint32_t len = 0;
+    uint64_t extra = 0;
+    for (int d = lane; d <= n_parts; d += 64) cnt[wv][d] = 0;
+    if (have) {
+      const int64_t *hd = head_in + i * head_cols;
+      row = hd[0], key = hd[1], v = (int64_t)(uint32_t)hd[2], step = (int64_t)(uint32_t)hd[3];
+      nx = next[i];
+      if (log_out) {  // (row, step + 1, next), or (row, -1, -1): vanished on arrival (fugue.py:147)
+        log_out[3 * i] = row;
+        log_out[3 * i + 1] = nx < 0 ? -1 : step + 1;
+        log_out[3 * i + 2] = nx < 0 ? -1 : (int64_t)nx;
+      } else if (nx < 0) {
+        valid_out[row] = 0;
+      } else {
+        walks_out[row * (int64_t)(walk_length + 1) + step + 1] = nx;
+      }
+      if (nx >= 0 && step + 1 < walk_length) {
+        int a = 0, b = n_parts;  // last part whose first vertex is <= nx
+        while (b - a > 1) {
+          const int mid = (a + b) >> 1;
+          if (bounds[mid] <= (int64_t)nx)
+            a = mid;
+          else
+            b = mid;
+        }
+        dest = a;
+        if (carry >= N2V_SRC_WEDGES + 1 && (!edge_classes || !wedge_off)) {
+          atomicOr(status, N2V_ST_RANGE);  // a part without edges (NULL tables) forwards nobody
+          dest = -1;
+        } else if (carry >= N2V_SRC_WEDGES + 1) {
+          src = edge[i];
+          const uint32_t ec = edge_classes[src];
+          const uint64_t raw = wedge_off[src];
+          extra = (uint64_t)ec | (raw >> N2V_WEDGE_RPOS_SHIFT) << 32;
+          if (carry == N2V_SRC_WEDGES + 1) len = ec & N2V_EC_SHARED_MASK;
+          src = (int64_t)(raw & N2V_WEDGE_OFF_MASK);  // from here on: where the list starts
+        }
+      }
+    }
+    // rank inside the wave among the lanes of the same destination; words: exclusive scan
+    int rank = 0;
+    uint64_t todo = n2v::ballot64(dest >= 0);
+    while (todo) {
+      const int d = __shfl(dest, __builtin_ctzll(todo), 64);
+      const uint64_t m = n2v::ballot64(dest == d);
+      if (dest == d) rank = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) cnt[wv][d] = (uint32_t)__popcll(m);
+      todo &= ~m;
+    }
+    uint32_t incl = len;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) cnt[wv][n_parts] = incl;
+    __syncthreads();
+    // one thread per destination (and one for the words): the block's reservation; cnt[w][d] becomes
+    // the offset of wave w inside it
+    for (int d = threadIdx.x; d <= n_parts; d += kFwdThreads) {
+      uint32_t run = 0;
+      for (int w2 = 0; w2 < kFwdThreads / 64; ++w2) {
+        const uint32_t c = cnt[w2][d];
+        cnt[w2][d] = run;
+        run += c;
+      }
+      base[d] = run ? atomicAdd(&box_count[d], (unsigned long long)run) : 0ull;
+    }
+    __syncthreads();
+    int64_t pos = -1, woff = 0;
+    if (dest >= 0) pos = (int64_t)base[dest] + cnt[wv][dest] + rank;
+    if (len) woff = (int64_t)base[n_parts] + cnt[wv][n_parts] + (int64_t)(incl - len);
+    __syncthreads();  // (cnt is cleared at the top of the next pass)
+    bool fits = dest >= 0 && pos < cap && woff + (int64_t)len <= wcap;
+    if (dest >= 0 && !fits) atomicOr(status, N2V_ST_OVERFLOW);
+    if (fits) {
+      int64_t *ho = box_head + ((int64_t)dest * cap + pos) * head_cols;
+      ho[0] = row;
+      ho[1] = key;
+      ho[2] = (v << 32) | (int64_t)(uint32_t)nx;
+      ho[3] = step + 1;
+      if (head_cols > 4) ho[4] = (int64_t)extra;
+      for (int c = 5; c < head_cols; ++c) ho[c] = 0;
+      box_off[(int64_t)dest * cap + pos] = woff;
+    }
+    if (!fits) len = 0;
+    // lists: short ones lane by lane, long ones by the whole wave
+    uint64_t big = n2v::ballot64(len >= 32u);
+    while (big) {
+      const int l = __builtin_ctzll(big);
+      big &= big - 1;
+      const int64_t b = __shfl(src, l, 64), o = __shfl(woff, l, 64);
+      const int n = (int)__shfl(len, l, 64);
+      for (int t = lane; t < n; t += 64)
+        box_words[o + t] = wide ? (int32_t)reinterpret_cast<const uint32_t *>(wedge_pos)[b + t]
+                                : (int32_t)reinterpret_cast<const uint16_t *>(wedge_pos)[b + t];
+    }
+    if (len < 32u)
+      for (uint32_t t = 0; t < len; ++t)
+        box_words[woff + t] = wide ? (int32_t)reinterpret_cast<const uint32_t *>(wedge_pos)[src + t]
+                                   : (int32_t)reinterpret_cast<const uint16_t *>(wedge_pos)[src + t];
+  }
+}
+
+extern "C" int n2v_partition_forward(const int64_t *head_in, int32_t head_cols, const int32_t *next,
+                                     const int64_t *edge, int64_t k, int32_t walk_length,
+                                     const int64_t *bounds, int32_t n_parts, int32_t carry,
+                                     const uint32_t *edge_classes, const uint64_t *wedge_off,
+                                     const void *wedge_pos, int32_t wide, int64_t *box_head,
+                                     int64_t *box_off, int32_t *box_words, unsigned long long *box_count,
+                                     int64_t cap, int64_t wcap, int64_t *log_out, int32_t *walks_out,
+                                     uint8_t *valid_out, uint32_t *status, void *stream) {
+  if (k < 0 || head_cols < 4 || n_parts < 1 || n_parts > kFwdMaxParts || cap < 0 || wcap < 0 ||
+      walk_length < 0)
+    return N2V_EINVAL;
+  if (carry != 0 && carry != N2V_SRC_WEDGES + 1 && carry != N2V_SRC_WEDGES + 2) return N2V_EINVAL;
+  if (carry != 0 && head_cols < 5) return N2V_EINVAL;
+  if (k == 0) return N2V_OK;
+  if (!head_in || !next || !bounds || !box_head || !box_off || !box_count || !status) return N2V_EINVAL;
+  if (!log_out && (!walks_out || !valid_out)) return N2V_EINVAL;
+  if (carry != 0 && !edge) return N2V_EINVAL;  // (edge_classes, wedge_off: NULL for a part without edges)
+  if (carry == N2V_SRC_WEDGES + 1 && !box_words) return N2V_EINVAL;
+  int64_t blocks = (k + kFwdThreads - 1) / kFwdThreads;
+  const int64_t cap_blocks = n2v::resident_blocks((const void *)n2v_partition_forward_kernel, kFwdThreads, 0);
+  if (blocks > cap_blocks) blocks = cap_blocks;
+  hipLaunchKernelGGL(n2v_partition_forward_kernel, dim3((unsigned)blocks), dim3(kFwdThreads), 0, (hipStream_t)stream,
+                     head_in, (int)head_cols, next, edge, k, (int)walk_length, bounds, (int)n_parts, (int)carry,
+                     edge_classes, wedge_off, wedge_pos, (int)wide, box_head, box_off, box_words, box_count, cap,
+                     wcap, log_out, walks_out, valid_out, status);
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}

@@ -1283,7 +1283,7 @@ int n2v_walk_wedge2_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_
 // the wedge-list instance of n2v_partition_step (n2v_walk_wedge.hip): 1 = launched, < 0 on error
 int n2v_partition_step_wedge_launch(const int64_t *rowptr, const int32_t *col, int64_t lo,
                                     int64_t n_local, const int64_t *head, int32_t head_cols,
-                                    const int64_t *src_ptr, const int32_t *src_ids, int64_t k,
-                                    double p, double q, const n2v::UnitConsts &K, uint64_t seed,
+                                    const int64_t *src_ptr, const int32_t *src_ids, int32_t src_at,
+                                    int64_t k, double p, double q, const n2v::UnitConsts &K, uint64_t seed,
                                     int32_t *next_out, int64_t *edge_out, uint32_t *status,
                                     void *stream);

@@ -1803,8 +1803,8 @@ extern "C" int n2v_partition_step_unit_try(const int64_t *rowptr, const int32_t 
   if (!unit_consts(p, q, K, dyadic)) return 0;
   if (wedge_lists)  // one lane per walker, the closed forms of the wedge kernel
     return n2v_partition_step_wedge_launch(rowptr, col, lo, n_local, head, head_cols, src_ptr,
-                                           src_ids, k, p, q, K, seed, next_out, edge_out, status,
-                                           stream);
+                                           src_ids, wedge_lists == 2, k, p, q, K, seed, next_out,
+                                           edge_out, status, stream);
   int64_t blocks = (k + n2v::kWavesPerBlock - 1) / n2v::kWavesPerBlock;
 #define N2V_PART_LAUNCH(D)                                                                        \
   do {                                                                                           \

@@ -383,8 +383,11 @@ template <int kMode>
 __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void partition_step_wedge_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t lo, int64_t n_local,
     const int64_t *__restrict__ head, int head_cols, const int64_t *__restrict__ src_ptr,
-    const int32_t *__restrict__ src_ids, int64_t k, double p, double q, UnitConsts K, uint64_t seed,
-    int32_t *__restrict__ next_out, int64_t *__restrict__ edge_out, uint32_t *__restrict__ status) {
+    const int32_t *__restrict__ src_ids, int src_at, int64_t k, double p, double q, UnitConsts K,
+    uint64_t seed, int32_t *__restrict__ next_out, int64_t *__restrict__ edge_out,
+    uint32_t *__restrict__ status) {
+  // src_at: src_ptr[i] is where walker i's list starts (N2V_SRC_WEDGES_AT: lists appended in any
+  // order by n2v_partition_forward), its length is the shared count in the header
   __shared__ uint32_t stage_all[kWedgeThreads / 64][16 * 32];  // 2 KB per wave (lane_case_a)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void partition_step
         const int64_t sb = src_ptr[i];
         const uint32_t *list = reinterpret_cast<const uint32_t *>(src_ids) + sb;
         if (fR == N2V_EC_RETURN_SAT || fM == N2V_EC_SHARED_MASK ||
-            src_ptr[i + 1] - sb != (need_mem ? (int64_t)fM : 0) ||  // (q == 1: no list travels)
+            (!src_at && src_ptr[i + 1] - sb != (need_mem ? (int64_t)fM : 0)) ||  // (q == 1: no list travels)
             (int64_t)fR + (int64_t)fM > n || w_rpos + (int)fR > n) {
           atomicOr(status, N2V_ST_RANGE);  // not a wedge list of an edge into this row
           idx = -1;
@@ -538,8 +541,8 @@ int n2v_walk_wedge_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_s
 // the wedge-list instance of n2v_partition_step: 1 = launched, < 0 on error
 int n2v_partition_step_wedge_launch(const int64_t *rowptr, const int32_t *col, int64_t lo,
                                     int64_t n_local, const int64_t *head, int32_t head_cols,
-                                    const int64_t *src_ptr, const int32_t *src_ids, int64_t k,
-                                    double p, double q, const n2v::UnitConsts &K, uint64_t seed,
+                                    const int64_t *src_ptr, const int32_t *src_ids, int32_t src_at,
+                                    int64_t k, double p, double q, const n2v::UnitConsts &K, uint64_t seed,
                                     int32_t *next_out, int64_t *edge_out, uint32_t *status,
                                     void *stream) {
   const bool biased = !(p == 1.0 && q == 1.0);  // p == q == 1: the header's first four words do
@@ -553,8 +556,8 @@ int n2v_partition_step_wedge_launch(const int64_t *rowptr, const int32_t *col, i
   const int64_t cap = n2v::resident_blocks((const void *)kernel, n2v::kWedgeThreads, 0);
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(n2v::kWedgeThreads), 0, (hipStream_t)stream,
-                     rowptr, col, lo, n_local, head, (int)head_cols, src_ptr, src_ids, k, p, q, K, seed,
-                     next_out, edge_out, status);
+                     rowptr, col, lo, n_local, head, (int)head_cols, src_ptr, src_ids, (int)src_at, k, p, q, K,
+                     seed, next_out, edge_out, status);
   if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
   return 1;
 }

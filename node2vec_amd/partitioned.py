@@ -468,11 +468,165 @@ class RankState:
 
 
 # ---- drivers ----------------------------------------------------------------------------------
+# first size of the pool the wedge lists of a step are appended to (_walk_local_forwarding): a step
+# that needs more reports how much, the pool is enlarged and the step repeated
+FORWARD_WORDS_PER_WALKER = 8
+FORWARD_STREAMS = True  # step the parts of a step on separate streams
+FORWARD_MIN_WORDS = 1 << 16
+
+
+def _forward_mode(parts: Sequence[GraphPart], p: float, q: float, step_fn: Callable) -> int:
+    """the lane mode (RankState._lane_mode) when every part can run the step as per-lane work and
+    forward its walkers with n2v_partition_forward -- unit weights, all parts on one GPU, the
+    per-edge tables on every part unless p == q == 1 --, else 0"""
+    if step_fn is not hip_step or not parts or not all(pt.rowptr.is_cuda for pt in parts):
+        return 0
+    if len({pt.device for pt in parts}) != 1 or any(pt.w is not None for pt in parts):
+        return 0
+    tables = all(pt.wedge_off is not None for pt in parts)
+    modes = set()
+    for pt in parts:
+        st = RankState(pt, 1, 1, p, q, 0)
+        st.use_tables = tables
+        modes.add(st._lane_mode())
+    return modes.pop() if len(modes) == 1 else 0
+
+
+def _walk_local_forwarding(parts: Sequence[GraphPart], start_ids: torch.Tensor, num_walks: int,
+                           walk_length: int, p: float, q: float, seed: int, lanes: int,
+                           timings: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """walk_partitioned_local with TWO launches per part and step and one host read per step:
+    n2v_partition_step on the part's mailbox, then n2v_partition_forward, which writes the path
+    straight into the output rows and appends every walker (and the wedge list of the edge it
+    leaves along) to the mailbox of the part it goes to -- no sort, no prefix sum, no size on the
+    host.  The host reads the mailbox counts once per step (they are the next step's launch
+    sizes) together with the status word; a word pool that turns out too small is enlarged to
+    the size the step reported and the step repeated (its writes are idempotent)."""
+    from node2vec_amd import _lib
+
+    L = _lib.load()
+    _lib.require_gpu()
+    n, dev, W, Lw = len(parts), parts[0].device, int(num_walks), int(walk_length)
+    if p == 0 or q == 0:
+        raise ValueError(f"Zero return ({p}) or inout ({q}) parameter!")
+    s = start_ids.to(device=dev, dtype=torch.int64)
+    total = int(s.numel()) * W
+    walks = torch.full((total, Lw + 1), -1, dtype=torch.int32, device=dev)
+    valid = torch.ones(total, dtype=torch.uint8, device=dev)
+    # initiate_random_walk (randomwalk.py:279-296): the walkers of every part's start vertices
+    ords = torch.arange(W, device=dev, dtype=torch.int64)
+    heads = []
+    for pt in parts:
+        idx = torch.nonzero((s >= pt.lo) & (s < pt.hi)).reshape(-1)
+        mine = s[idx]
+        live = ((pt.rowptr[1:] - pt.rowptr[:-1])[mine - pt.lo] > 0).repeat_interleave(W)  # fugue.py:132
+        rows = (idx[:, None] * W + ords[None, :]).reshape(-1)
+        keys = (mine[:, None] * W + ords[None, :]).reshape(-1)
+        v = mine.repeat_interleave(W)
+        walks[rows, 0] = torch.where(live, v, torch.full_like(v, -1)).to(torch.int32)
+        valid[rows[~live]] = 0
+        rows, keys, v = rows[live], keys[live], v[live]
+        heads.append(torch.stack([rows, keys, (torch.full_like(v, -1) << 32) | (v & 0xffffffff),
+                                  torch.zeros_like(rows), torch.zeros_like(rows)], 1))
+    counts = [int(h.shape[0]) for h in heads]
+    cap = max(sum(counts), 1)
+    if Lw == 0 or sum(counts) == 0:
+        return walks, valid.bool()
+    wedge = lanes >= 2          # the edge drawn is needed: something of it travels
+    carry = lanes if wedge else 0  # N2V_SRC_WEDGES + 1 (the list) / + 2 (counts only) / nothing
+    wcap = max(FORWARD_WORDS_PER_WALKER * cap, FORWARD_MIN_WORDS, 1) if lanes == 2 else 1
+
+    class Boxes:
+        def __init__(self):
+            self.head = torch.empty((n, cap, HEAD_COLS), dtype=torch.int64, device=dev)
+            self.off = torch.zeros((n, cap), dtype=torch.int64, device=dev)
+            self.words = torch.zeros(wcap, dtype=torch.int32, device=dev)
+            self.count = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+
+    cur, nxt = Boxes(), Boxes()
+    for r, h in enumerate(heads):
+        cur.head[r, :counts[r]] = h
+    del heads
+    nxt32 = torch.empty(cap, dtype=torch.int32, device=dev)
+    edge = torch.empty(cap, dtype=torch.int64, device=dev) if wedge else None
+    status = torch.zeros((n, 4), dtype=torch.int32, device=dev)  # one word set per part
+    seed64 = int(seed) & (2 ** 64 - 1)
+    # The parts of a step are independent (in a real run they are different GPUs): each is stepped
+    # on its own stream, so that the launch of one part does not wait for the slowest lane of the
+    # previous one (a launch is one or two generations of waves: its time is its longest walker).
+    main = torch.cuda.current_stream(dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in parts] if FORWARD_STREAMS else [main] * n
+    for _ in range(Lw):
+        while True:
+            nxt.count.zero_()
+            at = 0
+            if FORWARD_STREAMS:
+                for st in streams:
+                    st.wait_stream(main)
+            for r, pt in enumerate(parts):
+                k = counts[r]
+                if k == 0:
+                    continue
+                nx_r = nxt32[at:at + k]
+                ed_r = edge[at:at + k] if wedge else None
+                at += k
+                with torch.cuda.device(dev), torch.cuda.stream(streams[r]):
+                    stream = _lib.current_stream_ptr()
+                    _lib.check(L.n2v_partition_step(pt.rowptr.data_ptr(), pt.col.data_ptr(), 0, 0, pt.lo,
+                                                    pt.hi - pt.lo, cur.head[r].data_ptr(), HEAD_COLS,
+                                                    cur.off[r].data_ptr(), cur.words.data_ptr(),
+                                                    2,  # N2V_SRC_WEDGES_AT
+                                                    k, float(p), float(q), seed64, nx_r.data_ptr(),
+                                                    ed_r.data_ptr() if wedge else 0, status[r].data_ptr(), stream),
+                               "n2v_partition_step")
+                    _lib.check(L.n2v_partition_forward(
+                        cur.head[r].data_ptr(), HEAD_COLS, nx_r.data_ptr(), ed_r.data_ptr() if wedge else 0, k,
+                        Lw, pt.bounds.data_ptr(), n, carry,
+                        pt.edge_classes.data_ptr() if wedge else 0, pt.wedge_off.data_ptr() if wedge else 0,
+                        pt.wedge_pos.data_ptr() if wedge else 0,
+                        int(wedge and pt.wedge_pos.dtype == torch.int32), nxt.head.data_ptr(),
+                        nxt.off.data_ptr(), nxt.words.data_ptr(), nxt.count.data_ptr(), cap,
+                        nxt.words.numel(), 0, walks.data_ptr(), valid.data_ptr(), status[r].data_ptr(), stream),
+                        "n2v_partition_forward")
+            if FORWARD_STREAMS:
+                for st in streams:
+                    main.wait_stream(st)
+            word = status[0, 0]
+            for r in range(1, n):
+                word = word | status[r, 0]
+            host = torch.cat([nxt.count, word.reshape(1).to(torch.int64)]).tolist()  # the step's one host read
+            word = int(host[-1])
+            if word & ~_lib.ST_OVERFLOW:
+                _lib.check_status_word(word & ~_lib.ST_OVERFLOW, "n2v_partition_step")
+            if not (word & _lib.ST_OVERFLOW):
+                break
+            # the pool was too small: the step says how many words it needs
+            nxt.words = torch.zeros(int(host[n]) + FORWARD_MIN_WORDS, dtype=torch.int32, device=dev)
+            if timings is not None:
+                timings["pool_enlarged"] = timings.get("pool_enlarged", 0) + 1
+            status.zero_()
+        if timings is not None:
+            timings.setdefault("walkers_per_step", []).append(host[:n])
+        counts = [int(c) for c in host[:n]]
+        cur, nxt = nxt, cur
+        if sum(counts) == 0:
+            break
+    return walks, valid.bool()
+
+
 def walk_partitioned_local(parts: Sequence[GraphPart], start_ids: torch.Tensor, num_walks: int,
                            walk_length: int, p: float, q: float, seed: int,
-                           step_fn: Callable = hip_step) -> Tuple[torch.Tensor, torch.Tensor]:
+                           step_fn: Callable = hip_step,
+                           forwarding: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Every rank of the partition in ONE process (the all-to-all is a list transpose): returns
-    (walks, valid) in the row order of n2v_walk over the same start list."""
+    (walks, valid) in the row order of n2v_walk over the same start list.  `forwarding`: None =
+    the two-launch form (_walk_local_forwarding) wherever it applies, False = always the
+    launch-per-stage form that walk_partitioned's ranks run, True = insist."""
+    lanes = _forward_mode(parts, p, q, step_fn) if forwarding is not False else 0
+    if forwarding and not lanes:
+        raise ValueError("forwarding: unit-weight parts on one GPU with the per-edge tables (or p == q == 1) only")
+    if lanes:
+        return _walk_local_forwarding(parts, start_ids, num_walks, walk_length, p, q, seed, lanes)
     n = len(parts)
     ranks = [RankState(pt, num_walks, walk_length, p, q, seed, step_fn) for pt in parts]
     # what travels with a walker (wedge lists or rows) must be the same on every part: lists only

@@ -22,7 +22,7 @@ def test_header_declares_the_expected_entry_points():
                  "n2v_mem_probe", "n2v_corpus_count", "n2v_corpus_index", "n2v_hops8_build",
                  "n2v_partition_step", "n2v_gather_rows", "n2v_gather_wedges",
                  "n2v_partition_route", "n2v_partition_group", "n2v_walk_ws",
-                 "n2v_walk_workspace_bytes", "n2v_delta_reduce", "n2v_wedge_slots_build", "n2v_sgns_job_alpha", "n2v_rank_hops_build"):
+                 "n2v_walk_workspace_bytes", "n2v_delta_reduce", "n2v_wedge_slots_build", "n2v_sgns_job_alpha", "n2v_rank_hops_build", "n2v_partition_forward"):
         assert want in names
 
 
@@ -89,11 +89,27 @@ def test_partition_entry_points_validate_their_arguments():
     assert step(k=0) == 0  # nothing to do
     assert step(p=0.0) == -1 and step(q=0.0) == -1  # randomwalk.py:209-212
     assert step(k=-1) == -1 and step(n_local=-1) == -1 and step(head_cols=3) == -1
-    assert step(src_kind=2) == -1
+    assert step(src_kind=3) == -1 and step(src_kind=-1) == -1
+    assert step(src_kind=2, w=p_) == -1  # N2V_SRC_WEDGES_AT: unit-weight parts only
     assert step(w=p_, w64=p_) == -1  # at most one weight array
     assert step(src_kind=1, w=p_) == -1  # wedge lists: unit-weight parts only
     assert step(head=0) == -1 and step(next_out=0) == -1 and step(status=0) == -1
     assert step(src_ptr=0) == -1  # q != 1: something must have travelled
+    def forward(**kw):
+        a = dict(head=p_, head_cols=5, next=p_, edge=p_, k=1, walk_length=10, bounds=p_, n_parts=2, carry=2,
+                 ec=p_, off=p_, pos=p_, wide=0, box_head=p_, box_off=p_, box_words=p_, box_count=p_, cap=4,
+                 wcap=4, log=p_, walks=0, valid=0, status=p_)
+        a.update(kw)
+        return L.n2v_partition_forward(a["head"], a["head_cols"], a["next"], a["edge"], a["k"], a["walk_length"],
+                                       a["bounds"], a["n_parts"], a["carry"], a["ec"], a["off"], a["pos"],
+                                       a["wide"], a["box_head"], a["box_off"], a["box_words"], a["box_count"],
+                                       a["cap"], a["wcap"], a["log"], a["walks"], a["valid"], a["status"], None)
+
+    assert forward(k=0) == 0
+    assert forward(carry=1) == -1  # rows do not travel this way
+    assert forward(carry=2, head_cols=4) == -1 and forward(k=-1) == -1 and forward(n_parts=0) == -1
+    assert forward(log=0) == -1  # neither a log nor the output rows
+    assert forward(carry=2, edge=0) == -1 and forward(carry=2, box_words=0) == -1 and forward(box_count=0) == -1
     assert L.n2v_partition_route(p_, 5, p_, 0, 0, 10, p_, 2, 0, p_, 0, 0, p_, p_, p_, p_, p_, None) == 0
     assert L.n2v_partition_route(p_, 3, p_, 0, 1, 10, p_, 2, 0, p_, 0, 0, p_, p_, p_, p_, p_, None) == -1
     assert L.n2v_partition_route(p_, 5, p_, 0, 1, 10, p_, 0, 0, p_, 0, 0, p_, p_, p_, p_, p_, None) == -1

@@ -95,6 +95,41 @@ def test_partitioned_equals_n2v_walk_bit_for_bit(weighted):
         assert torch.equal(valid, wv)
         assert not bool(wv.all())  # walkers did vanish at sinks
         assert torch.equal(walks, want)  # dropped rows included: path up to the sink, then -1
+        if not weighted:
+            # unit weights: the call above forwarded the walkers with n2v_partition_forward (two
+            # launches per part and step); the launch-per-stage routing that walk_partitioned's ranks
+            # run must give the same rows
+            assert P._forward_mode(parts, p, q, P.hip_step) == (1 if p == q == 1.0 else 3 if q == 1.0 else 2)
+            w2, v2 = P.walk_partitioned_local(parts, start, 3, 15, p, q, 77, forwarding=False)
+            assert torch.equal(v2, wv) and torch.equal(w2, want)
+        else:
+            assert P._forward_mode(parts, p, q, P.hip_step) == 0
+
+
+def test_forwarding_repeats_a_step_whose_word_pool_was_too_small(monkeypatch):
+    """the pool the wedge lists are appended to starts at 0 words: every step with lists overflows
+    (N2V_ST_OVERFLOW), reports what it needs, and is repeated -- same walks"""
+    from node2vec_amd import partitioned as P
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+
+    rng = np.random.default_rng(3)
+    nv = 4000
+    src = np.concatenate([rng.integers(0, nv, 60_000), rng.integers(0, 8, 8000)])
+    dst = np.concatenate([rng.integers(0, nv, 60_000), rng.integers(0, nv, 8000)])
+    g = DeviceGraph.from_edges(np.concatenate([src, dst]), np.concatenate([dst, src]), None, n_vertices=nv,
+                               device="cuda")
+    parts = P.partition_graph(g, 5)
+    start = rw.start_vertices(g)
+    want, wv = rw.walk(g, start, 2, 20, 0.5, 2.0, 8)
+    monkeypatch.setattr(P, "FORWARD_WORDS_PER_WALKER", 0)
+    monkeypatch.setattr(P, "FORWARD_MIN_WORDS", 0)
+    t = {}
+    walks, valid = P._walk_local_forwarding(parts, start, 2, 20, 0.5, 2.0, 8, 2, timings=t)
+    assert t.get("pool_enlarged", 0) >= 1 and len(t["walkers_per_step"]) == 20
+    assert torch.equal(valid, wv) and torch.equal(walks, want)
+    with pytest.raises(ValueError):
+        P.walk_partitioned_local(P.partition_graph(g, 5, wedges=False), start, 2, 20, 0.5, 2.0, 8, forwarding=True)
 
 
 def test_partitioned_cfg2_sample_equals_n2v_walk():
