@@ -167,7 +167,10 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
                                       k * batch_vertices * W + j * (1 << 22))
             if sync is not None:
                 sync.step()
-            t_train += clock() - t1
+            t2 = clock()
+            t_train += t2 - t1
+            if timings is not None:  # (per batch: walking, training)
+                timings.setdefault("batch_s", []).append((t1 - t0, t2 - t1))
     if sync is not None:
         sync.finish()
     torch.cuda.synchronize(dev)

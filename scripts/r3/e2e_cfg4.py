@@ -49,5 +49,6 @@ out = {"config": f"cfg4 chung_lu {g.n_vertices} vertices / {g.n_edges} edges, fr
        "train_s": timings["train_s"], "other_s": total - timings["walk_s"] - timings["train_s"],
        "pairs": model.pairs_trained, "pairs_per_s_train_only": model.pairs_trained / timings["train_s"],
        "walk_steps": timings["rows_this_rank"] * 80 * 2,  # counting pass + training pass
-       "vocabulary": len(model.wv), "hbm_peak_GB": torch.cuda.max_memory_allocated() / 1e9}
+       "vocabulary": len(model.wv), "hbm_peak_GB": torch.cuda.max_memory_allocated() / 1e9,
+       "train_s_per_batch": [round(b[1], 3) for b in timings.get("batch_s", [])]}
 print(json.dumps(out), flush=True)
