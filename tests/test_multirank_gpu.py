@@ -97,6 +97,13 @@ def _worker(rank, world, port, ret):
                             "syn1neg": _digest(raw.syn1neg), "n_vocab": len(sm.wv),
                             "ids": _digest(raw.vocab.ids), "counts": _digest(raw.vocab.counts),
                             "world": t["world"], "rows": t["rows_this_rank"]}
+        # p = q = 1: the walks run on the degree-ranked form and come out in ranks on every rank
+        n11 = dict(N2V, return_param=1.0, inout_param=1.0)
+        sm1, raw1 = fit_streaming(g, n11, dict(W2V, sync_wire="fp32", sync_every=3), random_seed=17,
+                                  batch_vertices=200, return_model=True)
+        out["streaming_ranks"] = {"pairs": int(sm1.pairs_trained), "syn0": _digest(raw1.syn0),
+                                  "syn1neg": _digest(raw1.syn1neg), "ids": _digest(raw1.vocab.ids),
+                                  "counts": _digest(raw1.vocab.counts), "ranked": g.rank_hops is not None}
         from node2vec_amd import partitioned as P
         from node2vec_amd import randomwalk as rw
 
@@ -184,6 +191,13 @@ def test_two_ranks_on_one_gpu_fit_and_fit_streaming():
     assert sa["rows"] == (hi0 - lo0) * N2V["num_walks"] and sa["rows"] + sb["rows"] == n_start * N2V["num_walks"]
     # a single process streaming the whole graph trains a different schedule (other sentence
     # ids), but the same corpus: pair counts agree to a fraction of a per cent
+    # the same at p = q = 1 (walks in degree ranks): the vocabulary of the whole corpus in vertex ids
+    ra, rb = r0["streaming_ranks"], r1["streaming_ranks"]
+    assert ra["ranked"] and rb["ranked"]
+    assert ra["syn0"] == rb["syn0"] and ra["syn1neg"] == rb["syn1neg"]
+    w11, v11 = rw.walk(g, rw.start_vertices(g), N2V["num_walks"], N2V["walk_length"], 1.0, 1.0, 17)
+    vocab11 = sgns.build_vocab(w11[v11], 1)
+    assert ra["ids"] == rb["ids"] == _digest(vocab11.ids) and ra["counts"] == rb["counts"] == _digest(vocab11.counts)
     single = fit_streaming(g, dict(N2V), dict(W2V), random_seed=17, batch_vertices=200)
     tot = sa["pairs"] + sb["pairs"]
     assert abs(tot - single.pairs_trained) / single.pairs_trained < 0.01, (tot, single.pairs_trained)
