@@ -75,6 +75,8 @@ while time.time() - t0 < budget:
     else:
         p = float(rng.choice([0.25, 0.5, 1.0, 2.0, 4.0, 3.0, 0.7]))
         q = float(rng.choice([0.25, 0.5, 1.0, 2.0, 4.0, 1.3, 0.1]))
+    if rng.random() < 0.12:
+        p = q = 1.0  # the reference's defaults: the hop-table kernels and the degree-ranked form
     nw, wl = int(rng.integers(1, 5)), int(rng.choice([1, 5, 20, 60, 130]))
     seed = int(rng.integers(0, 2 ** 62))
     deg = g.degrees()
@@ -93,14 +95,30 @@ while time.time() - t0 < budget:
     want, wv = n2v_oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.w.cpu().numpy(),
                                       starts.cpu().numpy(), nw, wl, p, q, seed, n_threads=THREADS)
     ok = np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy(), want)
+    if ok and p == 1.0 and q == 1.0 and g.unit_weights:
+        # the degree-ranked form (few classes: most ranks go through the head table), walks out in ranks
+        g.RANK_MAX_CLASSES = int(rng.choice([8191, 64, 4, 1]))
+        rk, rv = rw.walk(g, starts, nw, wl, p, q, seed, rank_ids=True)
+        back = torch.where(rk >= 0, g.rank_vertex[rk.clamp(min=0).long()], rk)
+        got2, gv2 = rw.walk(g, starts, nw, wl, p, q, seed, use_ranked=True)
+        ok = (np.array_equal(rv.cpu().numpy(), wv) and np.array_equal(back.cpu().numpy(), want)
+              and np.array_equal(gv2.cpu().numpy(), wv) and np.array_equal(got2.cpu().numpy(), want))
+        if not ok:
+            print("RANKED", g.RANK_MAX_CLASSES, flush=True)
     if ok and PARTITIONED:
         n_parts = int(rng.integers(1, 7))
         parts = P.partition_graph(g, n_parts, balance=str(rng.choice(["edges", "vertices"])),
                                   wedges=bool(rng.random() < 0.7))  # wedge lists or whole rows travel
-        got, gv = P.walk_partitioned_local(parts, starts, nw, wl, p, q, seed)
+        # forwarding (n2v_partition_forward, where it applies) or the launch-per-stage routing; a word
+        # pool that starts too small makes steps repeat; parts on separate streams or one
+        fw = [None, False][int(rng.random() < 0.3)]
+        P.FORWARD_WORDS_PER_WALKER = int(rng.choice([8, 1, 0]))
+        P.FORWARD_MIN_WORDS = int(rng.choice([1 << 16, 64, 0]))
+        P.FORWARD_STREAMS = bool(rng.random() < 0.5)
+        got, gv = P.walk_partitioned_local(parts, starts, nw, wl, p, q, seed, forwarding=fw)
         ok = np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy()[wv], want[wv])
         if not ok:
-            print("PARTITIONED", n_parts, flush=True)
+            print("PARTITIONED", n_parts, fw, P.FORWARD_WORDS_PER_WALKER, P.FORWARD_MIN_WORDS, P.FORWARD_STREAMS, flush=True)
     n_cases += 1; n_walks += int(wv.sum())
     if not ok:
         bad = np.nonzero((got.cpu().numpy() != want).any(1) | (gv.cpu().numpy() != wv))[0][:5]
