@@ -338,7 +338,8 @@ def main():
     if not args.no_biased and not args.no_regimes:
         regimes = []
         for rp, rq, what in ((4.0, 0.25, "other alone overfull"), (4.0, 2.0, "return + other underfull"),
-                             (0.25, 0.5, "return + other overfull / return alone overfull")):
+                             (0.25, 0.5, "return + other overfull / return alone overfull"),
+                             (3.0, 0.7, "1/p, 1/q not dyadic: closed forms with margins, the rest replayed")):
             leg = WalkLeg(torch, rw, g, start_all, W, L, rp, rq, "exact", cfg["biased_batch"], rank, world)
             rr = leg.run(args.steps, args.warmup, barrier)
             er, sr = reduce_job(torch, dist, use_dist, dev, rr["elapsed"], rr["steps_done"])

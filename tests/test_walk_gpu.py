@@ -256,3 +256,32 @@ def test_hop_table_is_refused_for_rows_it_cannot_pack():
     g = DeviceGraph(rowptr, col, None)
     g.build_hops()
     assert g.hops is None
+
+
+@pytest.mark.parametrize("pq", [(3.0, 0.7), (0.7, 3.0), (1.3, 1.3), (5.0, 3.0), (0.2, 0.6), (0.6, 0.2), (7.0, 1.0),
+                                (0.3, 1.7), (10.0, 0.1), (0.001, 37.5)])
+def test_values_that_are_not_dyadic_closed_forms_with_margins(oracle, pq):
+    """1/p or 1/q not a power of two: the slots kernel decides most pairings by the closed forms on
+    the values the counts give, with a margin that covers the reference loop's rounding
+    (n2v_unit_near.h), and replays the rest.  Every arrangement of the three classes on the two
+    stacks, hubs of a few thousand neighbours, multi-edges, sinks: the oracle's walks, bit for bit;
+    and the same walks from the kernel that replays every pairing (no wedge slots)."""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+
+    rng = np.random.default_rng(int(pq[0] * 1000 + pq[1] * 10))
+    nv = 6000
+    src = np.concatenate([rng.integers(0, nv - 50, 60000), rng.integers(0, 8, 16000), rng.integers(0, nv - 50, 9000)])
+    dst = np.concatenate([rng.integers(0, nv, 60000), rng.integers(0, nv, 16000), rng.integers(0, 8, 9000)])
+    g = DeviceGraph.from_edges(np.concatenate([src, dst[:70000]]), np.concatenate([dst, src[:70000]]), None,
+                               n_vertices=nv, device="cuda")
+    start = torch.unique(torch.cat([torch.arange(0, 40), torch.arange(0, nv, 7)])).to(torch.int32)
+    p, q = pq
+    got, gv = rw.walk(g, start, 3, 40, p, q, 99)
+    assert g.wedge_slots is not None
+    other, ov = rw.walk(g, start, 3, 40, p, q, 99, use_wedge_slots=False)
+    assert torch.equal(got, other) and torch.equal(gv, ov)
+    want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), None, start.cpu().numpy(), 3, 40,
+                                  p, q, 99, n_threads=8)
+    assert np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy()[wv], want[wv])
+    assert wv.sum() > 1000
