@@ -360,4 +360,43 @@ __device__ __forceinline__ int near_listed(int arr, int n, int pick, double r2, 
   return -1;
 }
 
+// One step whose class values are not dyadic, before the row is added up in the reference's order:
+// taken when every decision on the way clears the margin -- which side of the average every class is
+// on, that `pick` was not accepted (the caller's quick exit accepts with its own margin), and the
+// decisions inside the closed form.  Returns the slot of the draw, or -1: the exact row sum and the
+// replays decide.  `below`: listed slots below the return position, or -1 (searched).
+template <typename P>
+__device__ __forceinline__ int near_step(int n, int pick, double r2, const UnitConsts &K, int nR, int rpos,
+                                         int nM, const P *list, bool isR, bool isM, int lo_pick, int below) {
+  const int nO = n - nR - nM;
+  const double b_pick = pick3(isR, isM, K.bR, K.bM, K.bO);
+  const double approx = ((double)nR * K.bR + (double)nM * K.bM + (double)nO * K.bO) / (double)n;
+  const double eps = ((double)n + 8.0) * 4.5e-16;  // any order of the addends against the reference's
+  const double lo_f = 1.0 - 2.0 * eps, hi_f = 1.0 + 2.0 * eps;
+  const bool decR = nR == 0 || K.bR < approx * lo_f || K.bR > approx * hi_f;
+  const bool decM = nM == 0 || K.bM < approx * lo_f || K.bM > approx * hi_f;
+  const bool decO = nO == 0 || K.bO < approx * lo_f || K.bO > approx * hi_f;
+  const double pp = b_pick / approx;
+  const bool not_accepted = b_pick > approx * hi_f || (b_pick < approx * lo_f && r2 > pp * hi_f);
+  if (!(decR && decM && decO && not_accepted)) return -1;
+  const bool uR = K.bR < approx, uM = K.bM < approx, uO = K.bO < approx;
+  const bool any_under = (nR && uR) || (nM && uM) || (nO && uO);
+  const bool any_over = (nR && !uR) || (nM && !uM) || (nO && !uO);
+  if (!any_under || !any_over) return -1;
+  // the stacks, as the kernels number them
+  int arr = 0;
+  if (uO && !(nR && uR) && !(nM && uM)) arr = 1;
+  else if (!uO && nO > 0 && (!nR || uR) && (!nM || uM)) arr = 2;
+  else if (uO && nR && uR && nM && !uM) arr = 3;
+  else if (!uO && nO > 0 && nR && !uR && nM && uM) arr = 4;
+  else if (uO && nR && !uR && nM && uM) arr = 5;
+  NearVals V;
+  V.vR = K.bR / approx, V.vM = K.bM / approx, V.vO = K.bO / approx;
+  double vmax = nO ? V.vO : 0.0;
+  if (nR) vmax = fmax(vmax, V.vR);
+  if (nM) vmax = fmax(vmax, V.vM);
+  V.mg = 5e-15 * (double)n * ((double)n + 8.0) * vmax;
+  return near_listed<P>(arr, n, pick, r2, V, nR, rpos, nM, list, isR, isM, lo_pick, below);
+}
+
 }  // namespace n2v

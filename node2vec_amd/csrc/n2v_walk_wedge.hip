@@ -448,22 +448,31 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void partition_step
           int lo_pick = 0;  // entries of the list below `pick`
           if (need_mem && !isR && nM > 0) lo_pick = wedge_lower_t<uint32_t>(list, 0, nM, pick, isM);
           double avg;  // :172
+          int near_idx = -1;
           if constexpr (kMode == 2) {
             const double b_pick = pick3(isR, isM, K.bR, K.bM, K.bO);
             const double approx = ((double)nR * K.bR + (double)nM * K.bM + (double)nO * K.bO) / (double)n;
             const double eps = ((double)n + 8.0) * 4.5e-16;
             const double r2a = (double)u2 * (1.0 / 4294967296.0);
-            if (b_pick < approx * (1.0 - eps) && r2a < (b_pick / approx) * (1.0 - 2.0 * eps))
+            if (b_pick < approx * (1.0 - eps) && r2a < (b_pick / approx) * (1.0 - 2.0 * eps)) {
               avg = approx;  // only the (decided) comparison below reads it
-            else
-              avg = lane_row_sum<uint32_t>(n, K, nR, w_rpos, nM, list) / (double)n;
+            } else {
+              // the closed forms on the values the counts give, with margins (n2v_unit_near.h), before
+              // the row is added up in the reference's order
+              near_idx = N2V_NEAR_FORMS ? near_step<uint32_t>(n, pick, r2a, K, nR, w_rpos, nM, list, isR, isM,
+                                                              lo_pick, -1)
+                                        : -1;
+              avg = near_idx >= 0 ? approx : lane_row_sum<uint32_t>(n, K, nR, w_rpos, nM, list) / (double)n;
+            }
           } else {
             const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
             avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;
           }
           const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) / avg;  // :173
           const double r2 = (double)u2 * (1.0 / 4294967296.0);
-          if (!(p_pick < 1.0 && r2 < p_pick)) {
+          if (near_idx >= 0) {
+            idx = near_idx;
+          } else if (!(p_pick < 1.0 && r2 < p_pick)) {
             const bool uR = K.bR < avg, uM = K.bM < avg, uO = K.bO < avg;
             const bool any_under = (nR && uR) || (nM && uM) || (nO && uO);
             const bool any_over = (nR && !uR) || (nM && !uM) || (nO && !uO);

@@ -186,45 +186,18 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
       avg = approx;  // only the (decided) comparison below reads it
     } else {
       // (round 4) Before the row is added up in the reference's order: the closed forms on the values
-      // the COUNTS give (n2v_unit_near.h).  Taken when every decision on the way clears the margin
-      // that covers the difference between those values and the reference's, and its loop's rounding:
-      // which side of the average every class is on, that `pick` was not accepted, and the decisions
-      // inside the closed form.  Anything closer goes on to the exact row sum and the replays below.
+      // the COUNTS give, with margins (near_step, n2v_unit_near.h).  Anything closer than the margin
+      // goes on to the exact row sum and the replays below.
       if (w_loaded && N2V_NEAR_FORMS) {
-        const double lo_f = 1.0 - 2.0 * eps, hi_f = 1.0 + 2.0 * eps;
-        const bool decR = nR == 0 || K.bR < approx * lo_f || K.bR > approx * hi_f;
-        const bool decM = nM == 0 || K.bM < approx * lo_f || K.bM > approx * hi_f;
-        const bool decO = nO == 0 || K.bO < approx * lo_f || K.bO > approx * hi_f;
-        const double pp = b_pick / approx;
-        const bool not_accepted = b_pick > approx * hi_f || (b_pick < approx * lo_f && r2 > pp * hi_f);
-        if (decR && decM && decO && not_accepted) {
-          const bool uR = K.bR < approx, uM = K.bM < approx, uO = K.bO < approx;
-          const bool any_under = (nR && uR) || (nM && uM) || (nO && uO);
-          const bool any_over = (nR && !uR) || (nM && !uM) || (nO && !uO);
-          if (any_under && any_over) {
-            int arr = 0;
-            if (uO && !(nR && uR) && !(nM && uM)) arr = 1;
-            else if (!uO && nO > 0 && (!nR || uR) && (!nM || uM)) arr = 2;
-            else if (uO && nR && uR && nM && !uM) arr = 3;
-            else if (!uO && nO > 0 && nR && !uR && nM && uM) arr = 4;
-            else if (uO && nR && !uR && nM && uM) arr = 5;
-            NearVals V;
-            V.vR = K.bR / approx, V.vM = K.bM / approx, V.vO = K.bO / approx;
-            double vmax = nO ? V.vO : 0.0;
-            if (nR) vmax = fmax(vmax, V.vR);
-            if (nM) vmax = fmax(vmax, V.vM);
-            V.mg = 5e-15 * (double)n * ((double)n + 8.0) * vmax;
-            const uint16_t *nlist = slot + 2;
-            if (nM > kSlotShort)
-              nlist = reinterpret_cast<const uint16_t *>(g.wedge_pos) +
-                      ((uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32));
-            const int res = near_listed<uint16_t>(arr, n, pick, r2, V, nR, (int)((uint32_t)sa.x & 0xffffu), nM,
-                                                  nlist, isR, isM, lo_pick, (int)((uint32_t)sa.x >> 16));
-            if (res >= 0) {
-              if (res != pick) h = load_hop(g.hops + vb + res);
-              return res;
-            }
-          }
+        const uint16_t *nlist = slot + 2;
+        if (nM > kSlotShort)
+          nlist = reinterpret_cast<const uint16_t *>(g.wedge_pos) +
+                  ((uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32));
+        const int res = near_step<uint16_t>(n, pick, r2, K, nR, (int)((uint32_t)sa.x & 0xffffu), nM, nlist, isR,
+                                            isM, lo_pick, (int)((uint32_t)sa.x >> 16));
+        if (res >= 0) {
+          if (res != pick) h = load_hop(g.hops + vb + res);
+          return res;
         }
       }
       const uint16_t *sum_list = slot + 2;
