@@ -438,9 +438,7 @@ def kernel_name(g, p, q):
         if p == 1.0 and q == 1.0:
             return "walk_uniform_kernel"
         if tables_regime(p, q) and g.hops is not None and g.wedge_off is not None:
-            from node2vec_amd.randomwalk import _dyadic
-
-            if g.wedge_slots is not None and _dyadic(p) and _dyadic(q):
+            if g.wedge_slots is not None:  # (all four instances: dyadic p, q or not)
                 return "walk_exact_wedge_slots_kernel"
             return "walk_exact_wedge_kernel"
         if lanes_regime(p, q) and g.edge_classes is not None:
