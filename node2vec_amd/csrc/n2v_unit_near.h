@@ -218,6 +218,22 @@ __device__ __forceinline__ int lane_case_b_near(int n, int pick, double r2, cons
   const double prob = 1.0 + (T - Y_of(j));
   if (fabs(prob - r2) < 1e-9 + mg) return -1;
   if (r2 < prob) return pick;
+  // the "other" slot of rank t + 1 is the next one below pick: usually pick - 1, found from the
+  // rank of pick in the list (no search); other_pos() if the row runs out (it cannot: t < nO)
+  int cpos = pick - 1, k = lo_pick - 1;
+  while (cpos >= 0) {
+    if (nR > 0 && cpos >= rpos && cpos < rpos + nR) {
+      cpos = rpos - 1;
+      continue;
+    }
+    while (k >= 0 && (int)list[k] > cpos) --k;
+    if (k >= 0 && (int)list[k] == cpos) {
+      --cpos;
+      --k;
+      continue;
+    }
+    return cpos;
+  }
   return other_pos(t + 1);
 }
 
@@ -322,6 +338,18 @@ __device__ __forceinline__ int lane_case_b2_near(int n, int pick, double r2, con
   const double prob = 1.0 + (T - j * dM);
   if (fabs(prob - r2) < 1e-9 + mg) return -1;
   if (r2 < prob) return pick;
+  if (!pickR) {  // the next slot of the stack is the next position below pick that is not listed
+    int cpos = pick - 1, k = lo_pick - 1;
+    while (cpos >= 0) {
+      while (k >= 0 && (int)list[k] > cpos) --k;
+      if (k >= 0 && (int)list[k] == cpos) {
+        --cpos;
+        --k;
+        continue;
+      }
+      return cpos;
+    }
+  }
   return G.stack_pos(t + 1);
 }
 
@@ -369,6 +397,10 @@ template <typename P>
 __device__ __forceinline__ int near_step(int n, int pick, double r2, const UnitConsts &K, int nR, int rpos,
                                          int nM, const P *list, bool isR, bool isM, int lo_pick, int below) {
   const int nO = n - nR - nM;
+  // one class only (a leaf's single return edge; a row without shared neighbours when p == q): every
+  // value is b / avg = 1 within n 2^-53, and sampling_from_alias returns `pick` on either side of 1.0
+  // -- below it is accepted (r2 <= 1 - 2^-32 is smaller), at or above it the loop of :182 never runs
+  if ((nR == n || nM == n || nO == n) && n < (1 << 20)) return pick;
   const double b_pick = pick3(isR, isM, K.bR, K.bM, K.bO);
   const double approx = ((double)nR * K.bR + (double)nM * K.bM + (double)nO * K.bO) / (double)n;
   const double eps = ((double)n + 8.0) * 4.5e-16;  // any order of the addends against the reference's

@@ -141,9 +141,10 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
   if (inl) sa.x = (int)(ec_prev & 0xffffu);  // halfword 0: the return position (16-bit positions), 1: below = 0
   const uint16_t *slot = nullptr;
   if constexpr (kSlots) slot = reinterpret_cast<const uint16_t *>(g.wedge_slots) + e_prev * 16;
-  // (not dyadic: the row sum needs the list and the return position at every step)
+  // (not dyadic: the steps past the quick accept need the return position and the list -- for the
+  // closed forms with margins, else for the row sum --: fetched there if not here)
   if (!inl && counts_ok &&
-      ((F.need_mem && fM > 0) || ((kMode == 2 || F.always_pair) && (fM > 0 || fR > 0)))) {
+      ((F.need_mem && fM > 0) || (F.always_pair && (fM > 0 || fR > 0)))) {
     if constexpr (kSlots) {
       // (asking for the second half only when the list has more than six entries was measured
       // and changes nothing: -3 .. +4 % by (p, q), profiles/r4i_time_slots_on_demand.log)
@@ -188,7 +189,15 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
       // (round 4) Before the row is added up in the reference's order: the closed forms on the values
       // the COUNTS give, with margins (near_step, n2v_unit_near.h).  Anything closer than the margin
       // goes on to the exact row sum and the replays below.
-      if (w_loaded && N2V_NEAR_FORMS) {
+#ifdef N2V_NEAR_COUNT
+      atomicAdd(status + 2, 1u);
+#endif
+      if (!w_loaded) {  // an edge without shared neighbours whose step got here: its return position
+        sa = reinterpret_cast<const int4 *>(slot)[0];
+        sb = reinterpret_cast<const int4 *>(slot)[1];
+        w_loaded = true;
+      }
+      if (N2V_NEAR_FORMS) {
         const uint16_t *nlist = slot + 2;
         if (nM > kSlotShort)
           nlist = reinterpret_cast<const uint16_t *>(g.wedge_pos) +
@@ -199,6 +208,9 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
           if (res != pick) h = load_hop(g.hops + vb + res);
           return res;
         }
+#ifdef N2V_NEAR_COUNT  // diagnostic build: steps past the quick accept ([2]) / declined by the closed forms ([3])
+        atomicAdd(status + 3, 1u);
+#endif
       }
       const uint16_t *sum_list = slot + 2;
       if (nM > kSlotShort) {
