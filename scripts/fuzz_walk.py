@@ -73,8 +73,9 @@ while time.time() - t0 < budget:
                  (0.125, 0.25), (0.0625, 0.5)]
         p, q = pairs[int(rng.integers(len(pairs)))]
     else:
-        p = float(rng.choice([0.25, 0.5, 1.0, 2.0, 4.0, 3.0, 0.7]))
-        q = float(rng.choice([0.25, 0.5, 1.0, 2.0, 4.0, 1.3, 0.1]))
+        # (3, 1.5, 6, 0.75: class values in small rational ratios -- cumulative sums that meet within a few ulp)
+        p = float(rng.choice([0.25, 0.5, 1.0, 2.0, 4.0, 3.0, 0.7, 1.5, 6.0]))
+        q = float(rng.choice([0.25, 0.5, 1.0, 2.0, 4.0, 1.3, 0.1, 3.0, 0.75]))
     if rng.random() < 0.12:
         p = q = 1.0  # the reference's defaults: the hop-table kernels and the degree-ranked form
     nw, wl = int(rng.integers(1, 5)), int(rng.choice([1, 5, 20, 60, 130]))

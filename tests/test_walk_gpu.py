@@ -285,3 +285,39 @@ def test_values_that_are_not_dyadic_closed_forms_with_margins(oracle, pq):
                                   p, q, 99, n_threads=8)
     assert np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy()[wv], want[wv])
     assert wv.sum() > 1000
+
+
+@pytest.mark.parametrize("pq", [(3.0, 3.0), (1.5, 3.0), (3.0, 1.5), (0.75, 0.375), (6.0, 3.0), (0.3, 0.9), (1.2, 0.6)])
+def test_values_that_are_not_dyadic_on_rows_full_of_near_ties(oracle, pq):
+    """Class values in small rational ratios (1/3, 2/3, 1 ...) on overlapping cliques: the cumulative
+    sums of the pairing loop meet EXACTLY in real arithmetic on many rows (n_shared = n_other, an
+    excess that is twice a deficit ...) and within a few ulp in fp64 -- the decisions the closed forms
+    with margins must NOT make.  The oracle's walks, bit for bit."""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+
+    rng = np.random.default_rng(5)
+    src, dst = [], []
+    nv = 0
+    for size in [4, 5, 6, 7, 8, 9, 10, 12, 16, 24, 33, 48, 64, 65, 100] * 3:
+        ids = np.arange(nv, nv + size)
+        a, b = np.meshgrid(ids, ids)
+        keep = a != b
+        src.append(a[keep]); dst.append(b[keep])
+        nv += size
+    src, dst = np.concatenate(src), np.concatenate(dst)
+    # bridges between cliques (symmetric), pendant vertices, a few duplicated edges
+    extra = rng.integers(0, nv, (1500, 2))
+    extra = extra[extra[:, 0] != extra[:, 1]]
+    src = np.concatenate([src, extra[:, 0], extra[:, 1], extra[:40, 0]])
+    dst = np.concatenate([dst, extra[:, 1], extra[:, 0], extra[:40, 1]])
+    g = DeviceGraph.from_edges(src, dst, None, n_vertices=nv, device="cuda")
+    start = rw.start_vertices(g)
+    p, q = pq
+    got, gv = rw.walk(g, start, 6, 60, p, q, 7)
+    assert g.wedge_slots is not None
+    want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), None, start.cpu().numpy(), 6, 60,
+                                  p, q, 7, n_threads=8)
+    assert np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy()[wv], want[wv])
+    other, ov = rw.walk(g, start, 6, 60, p, q, 7, use_wedge_slots=False)
+    assert torch.equal(got, other) and torch.equal(gv, ov)
