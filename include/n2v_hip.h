@@ -557,18 +557,20 @@ int n2v_partition_group(const int32_t *dest, const int64_t *head, int32_t head_c
  * APPENDED to the mailbox of the part that owns `next`:
  *   box_head  int64 [n_parts][cap][head_cols]   headers (head[.][4] = edge_classes | return position
  *                                               << 32 of the edge drawn when carry != 0)
- *   box_off   int64 [n_parts][cap]              where its list starts in box_words
- *   box_words int32 [wcap]                      the wedge lists (carry N2V_SRC_WEDGES + 1), one pool
- *                                               for all destinations
- *   box_count uint64 [n_parts + 1]              walkers appended per destination; [n_parts] = words
- *                                               used.  The caller zeroes it before the first launch
- *                                               of a step; several source parts may append to the
- *                                               same boxes (wave-aggregated atomic adds).
+ *   box_off   int64 [n_parts][cap]              where its list starts in the destination's pool
+ *   box_words int32 [n_parts][wcap]             the wedge lists (carry N2V_SRC_WEDGES + 1): one pool per
+ *                                               destination, so that what goes to one part is
+ *                                               contiguous (an exchange sends pool d to rank d)
+ *   box_count uint64 [2 n_parts]                walkers appended per destination, then words used per
+ *                                               destination.  The caller zeroes it before the first
+ *                                               launch of a step; several source parts may append to
+ *                                               the same boxes (one atomic add per block and
+ *                                               destination).
  * A full mailbox or pool sets N2V_ST_OVERFLOW in status[0] (the step must be repeated with larger
  * ones; nothing is written out of bounds).  carry: 0 (headers only: p == q == 1), N2V_SRC_WEDGES + 1
  * (the list of edge[i]), N2V_SRC_WEDGES + 2 (q == 1: counts and return position only); rows do not
- * travel this way.  The next n2v_partition_step takes a mailbox as head / src_ptr = box_off /
- * src_ids = box_words with src_kind N2V_SRC_WEDGES_AT.  Replaces n2v_partition_route +
+ * travel this way.  The next n2v_partition_step takes mailbox d as head = box_head[d] / src_ptr =
+ * box_off[d] / src_ids = box_words[d] with src_kind N2V_SRC_WEDGES_AT.  Replaces n2v_partition_route +
  * n2v_partition_group + a prefix sum + n2v_gather_wedges and the host read between them; the order
  * of the walkers in a mailbox is not defined, the walks are (the RNG is keyed by walker and step). */
 int n2v_partition_forward(const int64_t *head_in, int32_t head_cols, const int32_t *next,

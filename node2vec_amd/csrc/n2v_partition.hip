@@ -325,11 +325,12 @@ __global__ __launch_bounds__(kFwdThreads) void n2v_partition_forward_kernel(
     unsigned long long *__restrict__ box_count, int64_t cap, int64_t wcap, int64_t *__restrict__ log_out,
     int32_t *__restrict__ walks_out, uint8_t *__restrict__ valid_out, uint32_t *__restrict__ status) {
   // Same-address atomics serialise in L2 (~0.1 us each): one per wave and destination made this
-  // kernel take 0.85 ms for 6 x 10^5 walkers.  So the block counts first -- per wave and destination
-  // in LDS --, ONE thread per destination reserves the block's places (and one the block's words),
-  // and every wave takes its share of them.
-  __shared__ uint32_t cnt[kFwdThreads / 64][kFwdMaxParts + 1];   // [wave][dest]; [.][n_parts] = words
-  __shared__ unsigned long long base[kFwdMaxParts + 1];
+  // kernel take 0.85 ms for 6 x 10^5 walkers.  So the block counts first -- walkers and words per
+  // wave and destination in LDS --, ONE thread per destination reserves the block's places and
+  // words in that part's mailbox, and every wave takes its share of them.
+  __shared__ uint32_t cnt[kFwdThreads / 64][kFwdMaxParts];   // [wave][dest] walkers
+  __shared__ uint32_t cntw[kFwdThreads / 64][kFwdMaxParts];  // [wave][dest] words
+  __shared__ unsigned long long base[kFwdMaxParts], basew[kFwdMaxParts];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t k_up = (k + kFwdThreads - 1) / kFwdThreads * kFwdThreads;  // whole blocks stay in the loop
   for (int64_t i = (int64_t)blockIdx.x * kFwdThreads + threadIdx.x; i < k_up;
@@ -340,7 +341,10 @@ __global__ __launch_bounds__(kFwdThreads) void n2v_partition_forward_kernel(
     int dest = -1;  // -1: not forwarded
     uint32_t len = 0;
     uint64_t extra = 0;
-    for (int d = lane; d <= n_parts; d += 64) cnt[wv][d] = 0;
+    for (int d = lane; d < n_parts; d += 64) {
+      cnt[wv][d] = 0;
+      cntw[wv][d] = 0;
+    }
     if (have) {
       const int64_t *hd = head_in + i * head_cols;
       row = hd[0], key = hd[1], v = (int64_t)(uint32_t)hd[2], step = (int64_t)(uint32_t)hd[3];
@@ -377,38 +381,51 @@ __global__ __launch_bounds__(kFwdThreads) void n2v_partition_forward_kernel(
         }
       }
     }
-    // rank inside the wave among the lanes of the same destination; words: exclusive scan
+    // inside the wave, per destination: the rank of every lane among the lanes that go there and
+    // the words of the lanes before it (a masked scan)
     int rank = 0;
+    uint32_t wrank = 0;
     uint64_t todo = n2v::ballot64(dest >= 0);
     while (todo) {
       const int d = __shfl(dest, __builtin_ctzll(todo), 64);
       const uint64_t m = n2v::ballot64(dest == d);
-      if (dest == d) rank = __popcll(m & ((1ull << lane) - 1ull));
-      if (lane == 0) cnt[wv][d] = (uint32_t)__popcll(m);
+      const uint32_t x = dest == d ? len : 0u;
+      uint32_t incl = x;
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      if (dest == d) {
+        rank = __popcll(m & ((1ull << lane) - 1ull));
+        wrank = incl - x;
+      }
+      if (lane == 63) {
+        cnt[wv][d] = (uint32_t)__popcll(m);
+        cntw[wv][d] = incl;
+      }
       todo &= ~m;
     }
-    uint32_t incl = len;
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) cnt[wv][n_parts] = incl;
     __syncthreads();
-    // one thread per destination (and one for the words): the block's reservation; cnt[w][d] becomes
-    // the offset of wave w inside it
-    for (int d = threadIdx.x; d <= n_parts; d += kFwdThreads) {
-      uint32_t run = 0;
+    // one thread per destination: the block's reservation of places and of words in that part's
+    // mailbox; cnt / cntw[w][d] become the offset of wave w inside it
+    for (int d = threadIdx.x; d < n_parts; d += kFwdThreads) {
+      uint32_t run = 0, runw = 0;
       for (int w2 = 0; w2 < kFwdThreads / 64; ++w2) {
-        const uint32_t c = cnt[w2][d];
+        const uint32_t c = cnt[w2][d], cw = cntw[w2][d];
         cnt[w2][d] = run;
+        cntw[w2][d] = runw;
         run += c;
+        runw += cw;
       }
       base[d] = run ? atomicAdd(&box_count[d], (unsigned long long)run) : 0ull;
+      basew[d] = runw ? atomicAdd(&box_count[n_parts + d], (unsigned long long)runw) : 0ull;
     }
     __syncthreads();
     int64_t pos = -1, woff = 0;
-    if (dest >= 0) pos = (int64_t)base[dest] + cnt[wv][dest] + rank;
-    if (len) woff = (int64_t)base[n_parts] + cnt[wv][n_parts] + (int64_t)(incl - len);
+    if (dest >= 0) {
+      pos = (int64_t)base[dest] + cnt[wv][dest] + rank;
+      woff = (int64_t)basew[dest] + cntw[wv][dest] + (int64_t)wrank;  // inside the pool of `dest`
+    }
     __syncthreads();  // (cnt is cleared at the top of the next pass)
     bool fits = dest >= 0 && pos < cap && woff + (int64_t)len <= wcap;
     if (dest >= 0 && !fits) atomicOr(status, N2V_ST_OVERFLOW);
@@ -423,12 +440,13 @@ __global__ __launch_bounds__(kFwdThreads) void n2v_partition_forward_kernel(
       box_off[(int64_t)dest * cap + pos] = woff;
     }
     if (!fits) len = 0;
+    const int64_t wabs = (int64_t)(dest < 0 ? 0 : dest) * wcap + woff;  // in box_words
     // lists: short ones lane by lane, long ones by the whole wave
     uint64_t big = n2v::ballot64(len >= 32u);
     while (big) {
       const int l = __builtin_ctzll(big);
       big &= big - 1;
-      const int64_t b = __shfl(src, l, 64), o = __shfl(woff, l, 64);
+      const int64_t b = __shfl(src, l, 64), o = __shfl(wabs, l, 64);
       const int n = (int)__shfl(len, l, 64);
       for (int t = lane; t < n; t += 64)
         box_words[o + t] = wide ? (int32_t)reinterpret_cast<const uint32_t *>(wedge_pos)[b + t]
@@ -436,7 +454,7 @@ __global__ __launch_bounds__(kFwdThreads) void n2v_partition_forward_kernel(
     }
     if (len < 32u)
       for (uint32_t t = 0; t < len; ++t)
-        box_words[woff + t] = wide ? (int32_t)reinterpret_cast<const uint32_t *>(wedge_pos)[src + t]
+        box_words[wabs + t] = wide ? (int32_t)reinterpret_cast<const uint32_t *>(wedge_pos)[src + t]
                                    : (int32_t)reinterpret_cast<const uint16_t *>(wedge_pos)[src + t];
   }
 }

@@ -170,6 +170,39 @@ class Walkers:
                    torch.cat([p.ids for p in parts]))
 
 
+@dataclass
+class Mail:
+    """walkers as n2v_partition_forward leaves them in a mailbox: headers int64 [k, 5], where every
+    walker's wedge list starts in `words` (int64 [k]: no prefix array -- the order in a mailbox is
+    whatever the atomics gave), the lists int32 [w]"""
+    head: torch.Tensor
+    off: torch.Tensor
+    words: torch.Tensor
+
+    def __len__(self):
+        return self.head.shape[0]
+
+    @classmethod
+    def empty(cls, device):
+        return cls(torch.zeros((0, HEAD_COLS), dtype=torch.int64, device=device),
+                   torch.zeros(0, dtype=torch.int64, device=device),
+                   torch.zeros(0, dtype=torch.int32, device=device))
+
+    @classmethod
+    def cat(cls, parts: Sequence["Mail"], device) -> "Mail":
+        """one batch out of the mail of several sources: list starts rebased to the joined pool"""
+        parts = [p for p in parts if len(p)]
+        if not parts:
+            return cls.empty(device)
+        if len(parts) == 1:
+            return parts[0]
+        base, offs = 0, []
+        for p in parts:
+            offs.append(p.off + base)
+            base += int(p.words.numel())
+        return cls(torch.cat([p.head for p in parts]), torch.cat(offs), torch.cat([p.words for p in parts]))
+
+
 def _gather_rows(ptr: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor, out_ptr: torch.Tensor):
     """concatenation of ids[ptr[r] : ptr[r + 1]] for r in rows (out_ptr = the new offsets)"""
     total = int(out_ptr[-1])
@@ -231,6 +264,10 @@ class RankState:
         self.use_tables = True  # walk_partitioned clears it unless every rank holds the tables
         self.last_status = 0       # status bits of n2v_partition_step seen so far
         self.defer_status = False  # True: collected in last_status instead of raised at once
+        # route with n2v_partition_forward (one launch; walkers travel as Mail) where the step is
+        # per-lane work, instead of route + group + prefix sum + gather (walkers travel as Walkers)
+        self.forward = False
+        self.mail = Mail.empty(part.device)
 
     # -- initiate_random_walk (randomwalk.py:279-296) for the start vertices this rank owns ----
     def initiate(self, start_ids_global: torch.Tensor):
@@ -258,6 +295,8 @@ class RankState:
                             torch.zeros_like(rows), torch.zeros_like(rows)], 1)
         self.walkers = Walkers(head, torch.zeros(rows.numel(), dtype=torch.int64, device=dev),
                                torch.zeros(0, dtype=torch.int32, device=dev))
+        self.mail = Mail(head, torch.zeros(rows.numel(), dtype=torch.int64, device=dev),
+                         torch.zeros(0, dtype=torch.int32, device=dev))
 
     # -- the step as ONE launch: n2v_partition_step reads N(v) from the part's CSR ---------------
     def _lane_mode(self) -> int:
@@ -382,8 +421,75 @@ class RankState:
         return self._arange
 
     # -- one step of every resident walker; returns the migrating walkers per destination -----
+    def forwarding(self) -> bool:
+        """this rank's walkers travel as Mail (n2v_partition_forward)"""
+        return (self.forward and self.step_fn is hip_step and self.part.rowptr.is_cuda
+                and self._lane_mode() >= 1)
+
+    def _advance_forward(self, n_parts: int) -> List[Mail]:
+        """_advance_fused with the routing in ONE launch: n2v_partition_step on the resident mail,
+        then n2v_partition_forward into one outbox per destination (headers, list starts, a word
+        pool per destination: what goes to a rank is contiguous).  One host read: the counts (the
+        sizes of the exchange that follows) and the status word; a pool that was too small is
+        enlarged to what the launch reported and the launch repeated."""
+        from node2vec_amd import _lib
+
+        L = _lib.load()
+        part, dev, ml = self.part, self.part.device, self.mail
+        k = len(ml)
+        lanes = self._lane_mode()
+        wedge = lanes >= 2
+        carry = lanes if wedge else 0
+        head_in = ml.head.contiguous()
+        off_in = ml.off.contiguous()
+        words_in = ml.words if ml.words.numel() else torch.zeros(1, dtype=torch.int32, device=dev)
+        nxt32 = torch.empty(k, dtype=torch.int32, device=dev)
+        edge = torch.empty(k, dtype=torch.int64, device=dev) if wedge else None
+        if self.status is None:
+            self.status = torch.zeros(4, dtype=torch.int32, device=dev)
+        stream = _lib.current_stream_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(L.n2v_partition_step(part.rowptr.data_ptr(), part.col.data_ptr(), 0, 0, part.lo,
+                                            part.hi - part.lo, head_in.data_ptr(), HEAD_COLS, off_in.data_ptr(),
+                                            words_in.data_ptr(), 2,  # N2V_SRC_WEDGES_AT
+                                            k, float(self.p), float(self.q), int(self.seed) & (2 ** 64 - 1),
+                                            nxt32.data_ptr(), edge.data_ptr() if wedge else 0,
+                                            self.status.data_ptr(), stream), "n2v_partition_step")
+        log = torch.empty((k, 3), dtype=torch.int64, device=dev)
+        box_head = torch.empty((n_parts, k, HEAD_COLS), dtype=torch.int64, device=dev)
+        box_off = torch.zeros((n_parts, k), dtype=torch.int64, device=dev)
+        count = torch.zeros(2 * n_parts, dtype=torch.int64, device=dev)
+        wcap = max(FORWARD_WORDS_PER_WALKER * k // n_parts, FORWARD_MIN_WORDS, 1) if lanes == 2 else 1
+        while True:
+            box_words = torch.empty((n_parts, wcap), dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(L.n2v_partition_forward(
+                    head_in.data_ptr(), HEAD_COLS, nxt32.data_ptr(), edge.data_ptr() if wedge else 0, k, self.L,
+                    part.bounds.data_ptr(), n_parts, carry,
+                    part.edge_classes.data_ptr() if wedge else 0, part.wedge_off.data_ptr() if wedge else 0,
+                    part.wedge_pos.data_ptr() if wedge else 0, int(wedge and part.wedge_pos.dtype == torch.int32),
+                    box_head.data_ptr(), box_off.data_ptr(), box_words.data_ptr(), count.data_ptr(), k, wcap,
+                    log.data_ptr(), 0, 0, self.status.data_ptr(), stream), "n2v_partition_forward")
+            host = torch.cat([count, self.status[:1].to(torch.int64)]).tolist()  # the step's one host read
+            word = int(host[-1])
+            if not (word & _lib.ST_OVERFLOW):
+                break
+            wcap = int(max(host[n_parts:2 * n_parts])) + max(FORWARD_MIN_WORDS, 1)
+            count.zero_()
+            self.status[0] = word & ~_lib.ST_OVERFLOW
+        self.log.append(log)
+        self.last_status |= word
+        if not self.defer_status:
+            _lib.check_status_word(word, "n2v_partition_step")
+        return [Mail(box_head[d, :host[d]], box_off[d, :host[d]], box_words[d, :host[n_parts + d]])
+                for d in range(n_parts)]
+
     def advance(self, n_parts: int) -> List[Walkers]:
         part, dev, wk = self.part, self.part.device, self.walkers
+        if self.forwarding():
+            if len(self.mail) == 0:
+                return [Mail.empty(dev) for _ in range(n_parts)]
+            return self._advance_forward(n_parts)
         if len(wk) == 0:
             return [Walkers.empty(dev) for _ in range(n_parts)]
         if self.step_fn is hip_step and part.rowptr.is_cuda:
@@ -423,6 +529,9 @@ class RankState:
     # -- arrivals: walkers whose new current vertex has no out-edges vanish (fugue.py:147) -----
     def receive(self, inbox: Sequence[Walkers]):
         part, dev = self.part, self.part.device
+        if self.forwarding():
+            self.mail = Mail.cat(inbox, dev)
+            return
         wk = Walkers.cat(inbox, dev)
         # (the fused step finds the sinks itself: it draws nothing from an empty row and the
         # routing logs the walker as vanished -- no look at the arrivals, no host sync)
@@ -534,14 +643,14 @@ def _walk_local_forwarding(parts: Sequence[GraphPart], start_ids: torch.Tensor, 
         return walks, valid.bool()
     wedge = lanes >= 2          # the edge drawn is needed: something of it travels
     carry = lanes if wedge else 0  # N2V_SRC_WEDGES + 1 (the list) / + 2 (counts only) / nothing
-    wcap = max(FORWARD_WORDS_PER_WALKER * cap, FORWARD_MIN_WORDS, 1) if lanes == 2 else 1
+    wcap = max(FORWARD_WORDS_PER_WALKER * cap // n, FORWARD_MIN_WORDS, 1) if lanes == 2 else 1
 
     class Boxes:
         def __init__(self):
             self.head = torch.empty((n, cap, HEAD_COLS), dtype=torch.int64, device=dev)
             self.off = torch.zeros((n, cap), dtype=torch.int64, device=dev)
-            self.words = torch.zeros(wcap, dtype=torch.int32, device=dev)
-            self.count = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+            self.words = torch.zeros((n, wcap), dtype=torch.int32, device=dev)  # one pool per destination
+            self.count = torch.zeros(2 * n, dtype=torch.int64, device=dev)     # walkers, then words
 
     cur, nxt = Boxes(), Boxes()
     for r, h in enumerate(heads):
@@ -574,7 +683,7 @@ def _walk_local_forwarding(parts: Sequence[GraphPart], start_ids: torch.Tensor, 
                     stream = _lib.current_stream_ptr()
                     _lib.check(L.n2v_partition_step(pt.rowptr.data_ptr(), pt.col.data_ptr(), 0, 0, pt.lo,
                                                     pt.hi - pt.lo, cur.head[r].data_ptr(), HEAD_COLS,
-                                                    cur.off[r].data_ptr(), cur.words.data_ptr(),
+                                                    cur.off[r].data_ptr(), cur.words[r].data_ptr(),
                                                     2,  # N2V_SRC_WEDGES_AT
                                                     k, float(p), float(q), seed64, nx_r.data_ptr(),
                                                     ed_r.data_ptr() if wedge else 0, status[r].data_ptr(), stream),
@@ -586,7 +695,7 @@ def _walk_local_forwarding(parts: Sequence[GraphPart], start_ids: torch.Tensor, 
                         pt.wedge_pos.data_ptr() if wedge else 0,
                         int(wedge and pt.wedge_pos.dtype == torch.int32), nxt.head.data_ptr(),
                         nxt.off.data_ptr(), nxt.words.data_ptr(), nxt.count.data_ptr(), cap,
-                        nxt.words.numel(), 0, walks.data_ptr(), valid.data_ptr(), status[r].data_ptr(), stream),
+                        nxt.words.shape[1], 0, walks.data_ptr(), valid.data_ptr(), status[r].data_ptr(), stream),
                         "n2v_partition_forward")
             if FORWARD_STREAMS:
                 for st in streams:
@@ -600,8 +709,9 @@ def _walk_local_forwarding(parts: Sequence[GraphPart], start_ids: torch.Tensor, 
                 _lib.check_status_word(word & ~_lib.ST_OVERFLOW, "n2v_partition_step")
             if not (word & _lib.ST_OVERFLOW):
                 break
-            # the pool was too small: the step says how many words it needs
-            nxt.words = torch.zeros(int(host[n]) + FORWARD_MIN_WORDS, dtype=torch.int32, device=dev)
+            # a pool was too small: the step says how many words every destination needs
+            nxt.words = torch.zeros((n, int(max(host[n:2 * n])) + max(FORWARD_MIN_WORDS, 1)), dtype=torch.int32,
+                                    device=dev)
             if timings is not None:
                 timings["pool_enlarged"] = timings.get("pool_enlarged", 0) + 1
             status.zero_()
@@ -621,11 +731,15 @@ def walk_partitioned_local(parts: Sequence[GraphPart], start_ids: torch.Tensor, 
     """Every rank of the partition in ONE process (the all-to-all is a list transpose): returns
     (walks, valid) in the row order of n2v_walk over the same start list.  `forwarding`: None =
     the two-launch form (_walk_local_forwarding) wherever it applies, False = always the
-    launch-per-stage form that walk_partitioned's ranks run, True = insist."""
+    launch-per-stage routing (route, group, prefix sum, gather), True = insist, "ranks" = every
+    part as a rank of walk_partitioned steps it (n2v_partition_forward into per-destination
+    outboxes, walkers travelling as Mail), the exchange being a list transpose."""
     lanes = _forward_mode(parts, p, q, step_fn) if forwarding is not False else 0
-    if forwarding and not lanes:
+    if forwarding is True and not lanes:
         raise ValueError("forwarding: unit-weight parts on one GPU with the per-edge tables (or p == q == 1) only")
-    if lanes:
+    if not lanes:
+        forwarding = False  # ("ranks": the ranks then route launch by stage, as walk_partitioned's would)
+    if lanes and forwarding != "ranks":
         return _walk_local_forwarding(parts, start_ids, num_walks, walk_length, p, q, seed, lanes)
     n = len(parts)
     ranks = [RankState(pt, num_walks, walk_length, p, q, seed, step_fn) for pt in parts]
@@ -634,6 +748,7 @@ def walk_partitioned_local(parts: Sequence[GraphPart], start_ids: torch.Tensor, 
     tables = all(pt.wedge_off is not None for pt in parts)
     for r in ranks:
         r.use_tables = tables
+        r.forward = forwarding == "ranks"  # what walk_partitioned's ranks do, the exchange a list transpose
         r.initiate(start_ids)
     for _ in range(walk_length):
         out = [r.advance(n) for r in ranks]
@@ -696,6 +811,41 @@ def _exchange_walkers(out: List[Walkers], group, dist, dev, status: int = 0) -> 
     return [Walkers(recv_h[:, :HEAD_COLS].contiguous(), recv_h[:, HEAD_COLS].contiguous(), recv_i)]
 
 
+def _exchange_mail(out: List[Mail], group, dist, dev, status: int = 0) -> List[Mail]:
+    """_exchange_walkers for walkers that travel as Mail: the sizes, the headers with the list
+    start as a sixth column, the word pools.  Pool d of this rank is what rank d gets, so the
+    payloads are the outboxes as they lie; the receiver rebases the list starts of every source
+    to where that source's words landed."""
+    cpu = dist.get_backend(group) == "gloo"  # gloo moves host tensors
+    wire = torch.device("cpu") if cpu else dev
+    head6 = torch.cat([torch.cat([m.head, m.off[:, None]], 1) for m in out]).to(wire)
+    words = torch.cat([m.words for m in out]).to(wire)
+    sizes = [[len(m), int(m.words.numel())] for m in out]  # shapes: known on the host, no sync
+    n_send = torch.tensor([z + [int(status)] for z in sizes], dtype=torch.int64, device=wire)
+    n_recv = torch.empty_like(n_send)
+    dist.all_to_all_single(n_recv, n_send, group=group)
+    got = n_recv.tolist()
+    bad = 0
+    for g3 in got:
+        bad |= int(g3[2])
+    if bad:
+        from node2vec_amd import _lib
+
+        _lib.check_status_word(bad, "n2v_partition_step (on some rank)")
+    recv_h = torch.empty((sum(g[0] for g in got), HEAD_COLS + 1), dtype=torch.int64, device=wire)
+    dist.all_to_all_single(recv_h, head6.contiguous(), [g[0] for g in got], [z[0] for z in sizes], group=group)
+    recv_w = torch.empty(sum(g[1] for g in got), dtype=torch.int32, device=wire)
+    dist.all_to_all_single(recv_w, words.contiguous(), [g[1] for g in got], [z[1] for z in sizes], group=group)
+    recv_h, recv_w = recv_h.to(dev), recv_w.to(dev)
+    bases, run = [], 0
+    for g3 in got:  # where the words of every source start in recv_w
+        bases.append(run)
+        run += int(g3[1])
+    add = torch.repeat_interleave(torch.tensor(bases, dtype=torch.int64, device=dev),
+                                  torch.tensor([int(g3[0]) for g3 in got], dtype=torch.int64, device=dev))
+    return [Mail(recv_h[:, :HEAD_COLS].contiguous(), recv_h[:, HEAD_COLS] + add, recv_w)]
+
+
 def walk_partitioned(part: GraphPart, start_ids: torch.Tensor, num_walks: int, walk_length: int,
                      p: float, q: float, seed: int, group=None, step_fn: Callable = hip_step):
     """One rank of the partitioned walk under torch.distributed (one process per GPU; backend
@@ -714,9 +864,13 @@ def walk_partitioned(part: GraphPart, start_ids: torch.Tensor, num_walks: int, w
     all_reduce(have, dist.ReduceOp.MIN, group)
     st.use_tables = bool(have.item())
     st.defer_status = True
+    # per-lane steps (unit weights; the tables on every rank, or p == q == 1): route with
+    # n2v_partition_forward, one launch; every rank takes the same branch (use_tables is agreed)
+    st.forward = True
     st.initiate(start_ids)
     for _ in range(walk_length):
         out = st.advance(world)
-        st.receive(_exchange_walkers(out, group, dist, part.device, st.last_status))
+        exchange = _exchange_mail if st.forwarding() else _exchange_walkers
+        st.receive(exchange(out, group, dist, part.device, st.last_status))
     records = _all_to_all_var(st.log_by_home(start_ids, world), group, dist)
     return st.assemble(records, start_ids)

@@ -112,7 +112,7 @@ while time.time() - t0 < budget:
                                   wedges=bool(rng.random() < 0.7))  # wedge lists or whole rows travel
         # forwarding (n2v_partition_forward, where it applies) or the launch-per-stage routing; a word
         # pool that starts too small makes steps repeat; parts on separate streams or one
-        fw = [None, False][int(rng.random() < 0.3)]
+        fw = [None, False, "ranks"][int(rng.integers(0, 3))]
         P.FORWARD_WORDS_PER_WALKER = int(rng.choice([8, 1, 0]))
         P.FORWARD_MIN_WORDS = int(rng.choice([1 << 16, 64, 0]))
         P.FORWARD_STREAMS = bool(rng.random() < 0.5)

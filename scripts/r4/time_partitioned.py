@@ -23,7 +23,7 @@ for fw in (True, False):
     P.walk_partitioned_local(parts, start[::50].contiguous(), 1, 3, 0.5, 2.0, 1, forwarding=fw)  # warm-up
 PQS = [tuple(float(x) for x in pq.split(",")) for pq in os.environ["PQ"].split(";")] if os.environ.get("PQ") else \
     [(1.0, 1.0), (0.5, 2.0), (0.5, 1.0), (4.0, 0.25), (0.7, 1.3)]
-FORMS = {"1": (True,), "0": (False,)}.get(os.environ.get("FORWARD", ""), (True, False))
+FORMS = {"1": (True,), "0": (False,), "ranks": ("ranks",)}.get(os.environ.get("FORWARD", ""), (True, "ranks", False))
 for p, q in PQS:
     want, wv = rw.walk(g, start, W, STEPS, p, q, 42)
     for fw in FORMS:
@@ -36,6 +36,6 @@ for p, q in PQS:
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         ok = torch.equal(valid, wv) and torch.equal(walks, want)
-        print(f"  p={p} q={q} {'forwarding' if fw else 'launch per stage'}: {int(valid.sum())} walkers x {STEPS} steps in "
+        print(f"  p={p} q={q} {'forwarding' if fw is True else 'ranks, forward launch' if fw else 'launch per stage'}: {int(valid.sum())} walkers x {STEPS} steps in "
               f"{best * 1e3:.1f} ms = {int(valid.sum()) * STEPS / best / 1e9:.3f} G steps/s, bit-identical to n2v_walk: {ok}",
               flush=True)

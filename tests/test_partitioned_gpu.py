@@ -102,6 +102,10 @@ def test_partitioned_equals_n2v_walk_bit_for_bit(weighted):
             assert P._forward_mode(parts, p, q, P.hip_step) == (1 if p == q == 1.0 else 3 if q == 1.0 else 2)
             w2, v2 = P.walk_partitioned_local(parts, start, 3, 15, p, q, 77, forwarding=False)
             assert torch.equal(v2, wv) and torch.equal(w2, want)
+            # and every part stepped as a rank of walk_partitioned steps it: one forward launch into
+            # per-destination outboxes, the walkers travelling as Mail
+            w3, v3 = P.walk_partitioned_local(parts, start, 3, 15, p, q, 77, forwarding="ranks")
+            assert torch.equal(v3, wv) and torch.equal(w3, want)
         else:
             assert P._forward_mode(parts, p, q, P.hip_step) == 0
 
@@ -127,6 +131,8 @@ def test_forwarding_repeats_a_step_whose_word_pool_was_too_small(monkeypatch):
     t = {}
     walks, valid = P._walk_local_forwarding(parts, start, 2, 20, 0.5, 2.0, 8, 2, timings=t)
     assert t.get("pool_enlarged", 0) >= 1 and len(t["walkers_per_step"]) == 20
+    assert torch.equal(valid, wv) and torch.equal(walks, want)
+    walks, valid = P.walk_partitioned_local(parts, start, 2, 20, 0.5, 2.0, 8, forwarding="ranks")  # the ranks' form
     assert torch.equal(valid, wv) and torch.equal(walks, want)
     with pytest.raises(ValueError):
         P.walk_partitioned_local(P.partition_graph(g, 5, wedges=False), start, 2, 20, 0.5, 2.0, 8, forwarding=True)
