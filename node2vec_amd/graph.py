@@ -15,6 +15,46 @@ import torch
 from node2vec_amd import _lib
 
 
+def rank_tables(deg: torch.Tensor, max_classes: int, max_head: int):
+    """The host half of the degree-ranked form (DeviceGraph.build_ranked; plain torch, any device):
+    from the out-degrees int64 [V] -- rank_vertex / rank_of int32 [V] (stable sort by descending
+    degree), rank_rowptr int64 [V + 1] (row starts in rank order), the head table int64 [H] or None
+    (row offset | degree << 40 of the ranks that are looked up one by one) and the class table
+    first / off int32 [P] as n2v_graph wants them (P a power of two > the classes kept; the entry
+    after the last class and the padding hold V / E; uint32 bits).  None when more than `max_head`
+    top vertices would have to be listed."""
+    n, dev = int(deg.numel()), deg.device
+    n_edges = int(deg.sum())
+    order = torch.sort(deg, descending=True, stable=True).indices
+    deg_r = deg[order]
+    rank_vertex = order.to(torch.int32)
+    rank_of = torch.empty(n, dtype=torch.int32, device=dev)
+    rank_of[order] = torch.arange(n, dtype=torch.int32, device=dev)
+    del order
+    rank_rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(deg_r, 0, out=rank_rowptr[1:])
+    cls_deg, cls_count = torch.unique_consecutive(deg_r, return_counts=True)
+    cls_first = torch.cumsum(cls_count, 0) - cls_count
+    n_cls = int(cls_deg.numel())
+    keep = min(n_cls, int(max_classes))
+    head_n = int(cls_first[n_cls - keep].item())  # ranks below it are looked up one by one
+    if head_n > max_head:
+        return None
+    P = 2
+    while P < keep + 1:  # one entry after the last class closes it
+        P *= 2
+    first = torch.full((P,), n, dtype=torch.int64, device=dev)
+    off = torch.full((P,), n_edges, dtype=torch.int64, device=dev)
+    kept_first = cls_first[n_cls - keep:]
+    first[:keep] = kept_first
+    off[:keep] = rank_rowptr[kept_first]
+    head = None
+    if head_n:
+        head = (rank_rowptr[:head_n] | (deg_r[:head_n] << 40)).contiguous()
+    as_u32 = lambda t: torch.where(t >= (1 << 31), t - (1 << 32), t).to(torch.int32)  # noqa: E731  (uint32 bits)
+    return rank_vertex, rank_of, rank_rowptr, head, as_u32(first), as_u32(off)
+
+
 class DeviceGraph:
     def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, w: Optional[torch.Tensor]):
         """`w` None = every weight is 1.0 (what index_graph_* produces, indexer.py:20-21):
@@ -441,41 +481,17 @@ class DeviceGraph:
         if (self.n_edges == 0 or self.n_edges >= (1 << 32) or n >= (1 << 31)
                 or int(deg.max()) >= self.HOP_MAX_DEGREE):
             return self
-        order = torch.sort(deg, descending=True, stable=True).indices
-        deg_r = deg[order]
-        rank_vertex = order.to(torch.int32)
-        rank_of = torch.empty(n, dtype=torch.int32, device=dev)
-        rank_of[order] = torch.arange(n, dtype=torch.int32, device=dev)
-        del order
-        rank_rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(deg_r, 0, out=rank_rowptr[1:])
-        cls_deg, cls_count = torch.unique_consecutive(deg_r, return_counts=True)
-        cls_first = torch.cumsum(cls_count, 0) - cls_count
-        n_cls = int(cls_deg.numel())
-        keep = min(n_cls, self.RANK_MAX_CLASSES)
-        head_n = int(cls_first[n_cls - keep].item())  # ranks below it are looked up one by one
-        if head_n > self.RANK_MAX_HEAD:
+        tables = rank_tables(deg, self.RANK_MAX_CLASSES, self.RANK_MAX_HEAD)
+        if tables is None:
             return self
-        P = 2
-        while P < keep + 1:  # one entry after the last class closes it
-            P *= 2
-        first = torch.full((P,), n, dtype=torch.int64, device=dev)
-        off = torch.full((P,), self.n_edges, dtype=torch.int64, device=dev)
-        kept_first = cls_first[n_cls - keep:]
-        first[:keep] = kept_first
-        off[:keep] = rank_rowptr[kept_first]
-        head = None
-        if head_n:
-            head = (rank_rowptr[:head_n] | (deg_r[:head_n] << 40)).contiguous()
-        del deg_r, cls_deg, cls_count, cls_first
+        rank_vertex, rank_of, rank_rowptr, head, first, off = tables
         hops = torch.empty(self.n_edges, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.n2v_rank_hops_build(self.c_struct(), rank_of.data_ptr(), rank_vertex.data_ptr(),
                                              rank_rowptr.data_ptr(), hops.data_ptr(),
                                              _lib.current_stream_ptr()), "n2v_rank_hops_build")
         self.rank_of, self.rank_vertex, self.rank_head = rank_of, rank_vertex, head
-        self.rank_class_first = first.to(torch.int32)
-        self.rank_class_off = torch.where(off >= (1 << 31), off - (1 << 32), off).to(torch.int32)  # uint32 bits
+        self.rank_class_first, self.rank_class_off = first, off
         self.rank_hops = hops
         return self
 
