@@ -391,10 +391,11 @@ __global__ __launch_bounds__(kFwdThreads) void n2v_partition_forward_kernel(
       const uint64_t m = n2v::ballot64(dest == d);
       const uint32_t x = dest == d ? len : 0u;
       uint32_t incl = x;
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-      }
+      if (carry == N2V_SRC_WEDGES + 1)  // (only then do words travel)
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t t = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += t;
+        }
       if (dest == d) {
         rank = __popcll(m & ((1ull << lane) - 1ull));
         wrank = incl - x;
