@@ -277,6 +277,9 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_SLOTS_WAVES) void walk_exact_wed
   const int64_t total = n_start * (int64_t)num_walks;
   const int L1 = walk_length + 1;
   const StepFlags F = step_flags(g, K, q);
+#ifdef N2V_NEAR_COUNT
+  n2v_count_words = status;
+#endif
   const bool base_aligned = (reinterpret_cast<uintptr_t>(walks_out) & 63u) == 0;
 
   int64_t w0 = 0;  // absolute word index of path position 0 of the current walker

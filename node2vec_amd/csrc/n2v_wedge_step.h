@@ -14,6 +14,10 @@
 
 namespace n2v {
 
+#ifdef N2V_NEAR_COUNT
+__device__ uint32_t *n2v_count_words;  // = status of the launch (set by the kernel's first lines)
+#endif
+
 // the pairing loop for slot `pick` by one lane: closed form by arrangement `arr` (see the kernel),
 // else -- fp64 rounding decides the draw: a tie or a thin margin -- the replays.
 // kMode 0 / 3: the (p, q) that leave "other" alone on its stack on ordinary rows, underfull (0) or
@@ -45,6 +49,12 @@ __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, 
   }
 #ifdef N2V_ABLATE_W
   if (N2V_ABLATE_W == 1 && arr == 2) res = pick;  // timing-only: no closed form at all
+#endif
+#ifdef N2V_NEAR_COUNT  // diagnostic build: pairings ([2]) / pairings the closed forms declined ([3])
+  if (kMode != 2) {
+    atomicAdd(n2v_count_words + 2, 1u);
+    if (res < 0) atomicAdd(n2v_count_words + 3, 1u);
+  }
 #endif
   if (res >= 0) return res;
   const double vR = K.bR / avg, vM = K.bM / avg, vO = K.bO / avg;

@@ -8,11 +8,12 @@ _lib.LIB_PATH = os.path.join(ROOT, "build_variants", "libn2v_wedge_nearcount.so"
 from node2vec_amd import synthetic, randomwalk as rw
 g = synthetic.chung_lu(100_000_000, 500_000_000, device="cuda").trimmed(10_000, 42)
 start = rw.start_vertices(g)[:1 << 18].contiguous()
-for p, q in ((0.7, 3.0), (1.3, 1.3), (3.0, 0.7), (0.3, 0.7)):
+for p, q in ((0.5, 2.0), (4.0, 0.25), (4.0, 2.0), (0.25, 0.5), (0.7, 3.0), (1.3, 1.3), (3.0, 0.7), (0.3, 0.7)):
     st = {}
     walks, valid = rw.walk(g, start, 10, 80, p, q, 42, stats=st)
     torch.cuda.synchronize()
     steps = int(valid.sum()) * 80
     s = st["status"].cpu().numpy().astype("uint32")
-    print(f"p={p} q={q}: steps {steps}; past the quick accept {int(s[2])} ({s[2] / steps:.3f}); "
+    what = "pairings" if all((1.0 / x) == 2.0 ** round(__import__("math").log2(1.0 / x)) for x in (p, q)) else "past the quick accept"
+    print(f"p={p} q={q}: steps {steps}; {what} {int(s[2])} ({s[2] / steps:.3f}); "
           f"declined by the closed forms {int(s[3])} ({s[3] / max(int(s[2]), 1):.4f} of those)", flush=True)
