@@ -1,5 +1,7 @@
 """Randomised differential test of the exact walk kernels against the CPU oracle
 (test infrastructure; run on the GPU box):  python scripts/fuzz_walk.py [seconds] [seed]
+FUZZ_PQ=extreme | two | rational: very small / large p, q; the shared-stack arrangements; class values
+in small rational ratios on clique-heavy graphs (near-ties of the pairing loop).
 FUZZ_PARTITIONED=1: the same cases also through graph-partitioned walking (1-6 parts, cut by edges or
 by vertices, n2v_partition_step on every part, walkers migrating) against the same oracle walks."""
 import os, sys, time
@@ -36,6 +38,13 @@ def graph(kind):
             nb = rng.integers(0, nv, k)
             src += [h] * k + list(nb); dst += list(nb) + [h] * k
         src, dst = np.array(src), np.array(dst)
+    elif kind == "cliques":  # overlapping cliques + bridges: rows whose class counts stand in small ratios
+        src, dst, nv = [], [], 0
+        for size in rng.integers(3, 70, int(rng.integers(8, 40))):
+            ids = np.arange(nv, nv + int(size)); a, b = np.meshgrid(ids, ids); keep = a != b
+            src.append(a[keep]); dst.append(b[keep]); nv += int(size)
+        extra = rng.integers(0, nv, (int(nv * rng.choice([0.2, 1, 4])), 2)); extra = extra[extra[:, 0] != extra[:, 1]]
+        src = np.concatenate(src + [extra[:, 0], extra[:, 1]]); dst = np.concatenate(dst + [extra[:, 1], extra[:, 0]])
     else:  # bipartite
         nh = int(rng.integers(2, 12)); nv = max(nv, 2000)
         leaves = rng.integers(nh, nv, nh * int(rng.choice([100, 3000, 12000])))
@@ -58,7 +67,8 @@ def graph(kind):
 
 t0 = time.time(); n_cases = 0; n_walks = 0
 while time.time() - t0 < budget:
-    kind = rng.choice(["er", "powerlaw", "hubs", "bipartite"])
+    kind = rng.choice(["er", "powerlaw", "hubs", "bipartite", "cliques"] if os.environ.get("FUZZ_PQ") != "rational"
+                      else ["cliques", "cliques", "powerlaw", "hubs"])
     nv, src, dst, w, wk = graph(kind)
     if len(src) == 0:
         continue
@@ -66,6 +76,11 @@ while time.time() - t0 < budget:
     # FUZZ_PQ=extreme: very small / very large and non-dyadic parameters
     if os.environ.get("FUZZ_PQ") == "extreme":
         vals = [0.001, 0.01, 0.03125, 0.03, 1.0 / 3.0, 0.999, 1.001, 16.0, 37.5, 100.0, 1000.0, 1024.0]
+        p, q = float(rng.choice(vals)), float(rng.choice(vals))
+    elif os.environ.get("FUZZ_PQ") == "rational":
+        # class values in small rational ratios: the cumulative sums of the pairing loop meet exactly in
+        # real arithmetic and within a few ulp in fp64 -- what the closed forms with margins must decline
+        vals = [1.0 / 3.0, 2.0 / 3.0, 1.5, 3.0, 6.0, 0.75, 1.25, 5.0, 0.2, 0.6, 1.2, 2.5, 7.0, 1.0 / 7.0, 9.0, 12.0]
         p, q = float(rng.choice(vals)), float(rng.choice(vals))
     elif os.environ.get("FUZZ_PQ") == "two":
         # the return slot shares a stack with "other": q > 1 with p > q, q < 1 with p < q
