@@ -931,7 +931,15 @@ __device__ __forceinline__ int lane_case_b2_jump(int n, int pick, double r2, con
   const double dn = (double)n;
   const double isum = (double)nR * K.fR + (double)nM * K.fM + (double)nO * K.fO;
   const double e = K.fO * dn - isum, eR = K.fR * dn - isum, dM = isum - K.fM * dn;
-  if (nR <= 0 || nM <= 0 || nO <= 0 || !(e > 0.0) || !(eR > 0.0) || !(dM > 0.0)) return -1;
+  // "other" exactly ON the average (p = 1/4, q = 1/2 with two shared neighbours per return edge:
+  // 10 % of that regime's pairings): its slots are overfull with excess 0.  The average then IS the
+  // "other" weight, a power of two, so every value of the table is one and the reference's loop is
+  // exact arithmetic -- no rounding decides anything: a slot that reaches exactly 1.0 stays
+  // overfull (:187), the zero-excess slots above the return run pass the first deficit on, those
+  // below it are never reached.  The formulas below hold with the ties taken that way (checked
+  // against the reference loop in Python: 4.7 M draws, 0 mismatches).
+  const bool flat = e == 0.0;
+  if (nR <= 0 || nM <= 0 || nO <= 0 || !(e > 0.0 || flat) || !(eR > 0.0) || !(dM > 0.0)) return -1;
   if (dn * isum > 2.0e14 || dn * dn * fmax(K.fR, K.fO) > 4.0e15) return -1;
   const TwoOnStack<P> G(n, nR, rpos, nM, list, below);
   const double drho = (double)G.rho, dnR = (double)nR;
@@ -946,16 +954,18 @@ __device__ __forceinline__ int lane_case_b2_jump(int n, int pick, double r2, con
     double t = 1.0;
     if (j > 1) {
       const double Yp = (double)(j - 1) * dM;  // smallest t with Xo(t) >= Yp
-      if (drho * e >= Yp) {
+      if (!flat && drho * e >= Yp) {
         t = floor_div(Yp + e - 1.0, e);
       } else {
         const double X1 = drho * e;
         if (X1 + dnR * eR >= Yp)
           t = drho + floor_div(Yp - X1 + eR - 1.0, eR);
-        else
+        else if (!flat)
           t = drho + dnR + floor_div(Yp - X1 - dnR * eR + e - 1.0, e);
+        else
+          return -1;  // (mass balance: the return run covers every listed slot)
       }
-      if (Xo(t) == Yp) return -1;  // that slot holds exactly 1.0: fp64 decides
+      if (!flat && Xo(t) == Yp) return -1;  // that slot holds exactly 1.0: fp64 decides
     }
     if (!(t >= 1.0) || t > (double)G.nS) return -1;
     return G.stack_pos((int)t);
@@ -965,8 +975,9 @@ __device__ __forceinline__ int lane_case_b2_jump(int n, int pick, double r2, con
   if (t == G.nS) return pick;  // the last overfull slot: 1.0 within rounding, or never reached
   const double T = Xo((double)t);
   const double j = floor_div(T, dM) + 1.0;
+  if (flat && j > (double)nM) return pick;  // never demoted: the end of the return run, "other" below it
   if (!(j >= 1.0) || j > (double)nM) return -1;
-  if (j > 1.0 && (j - 1.0) * dM == T) return -1;
+  if (!flat && j > 1.0 && (j - 1.0) * dM == T) return -1;
   const double prob = 1.0 + (T - j * dM) / isum;
   if (fabs(prob - r2) < 1e-9) return -1;
   if (r2 < prob) return pick;

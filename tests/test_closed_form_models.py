@@ -28,6 +28,16 @@ def test_model_agrees_with_the_reference_loop(name, rows):
     assert int(last.split()[1]) > 0  # rows were really drawn
 
 
+def test_a_class_exactly_on_the_average_model():
+    """lane_case_b2_jump on rows whose "other" slots have excess 0 (scripts/models/flat_b2.py)"""
+    env = dict(os.environ, N2V_MODEL_TRIALS="4000")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "models", "flat_b2.py")], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    last = res.stdout.strip().splitlines()[-1]
+    assert last.startswith("total") and last.endswith("bad 0") and int(last.split()[1]) > 10000
+
+
 def test_layered_sampler_model_gives_every_slot_its_weight():
     """the layer decomposition of fast mode's sampler (csrc/n2v_walk_fast.hip, kClassFirst) in exact
     rational arithmetic: P(slot) == weight / sum of weights for every ordering of 1/p, 1, 1/q"""

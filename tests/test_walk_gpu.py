@@ -321,3 +321,37 @@ def test_values_that_are_not_dyadic_on_rows_full_of_near_ties(oracle, pq):
     assert np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy()[wv], want[wv])
     other, ov = rw.walk(g, start, 6, 60, p, q, 7, use_wedge_slots=False)
     assert torch.equal(got, other) and torch.equal(gv, ov)
+
+
+@pytest.mark.parametrize("pq", [(0.25, 0.5), (0.125, 0.25), (0.0625, 0.125), (0.5, 2.0), (4.0, 2.0)])
+def test_a_class_exactly_on_the_average(oracle, pq):
+    """Dyadic p, q on rows where one class sits exactly on the row average (p = 1/4, q = 1/2 with two
+    shared neighbours per return edge: "other" = 2 = avg): its slots are overfull with excess 0, the
+    table's values are powers of two and the reference's loop is exact arithmetic -- the closed form of
+    the shared-stack arrangement decides those rows with the ties taken as the loop takes them (a slot
+    at exactly 1.0 stays overfull).  Cliques of every size with bridges and duplicated edges: the oracle's
+    walks and the table-free kernel's, bit for bit."""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+
+    rng = np.random.default_rng(11)
+    src, dst, nv = [], [], 0
+    for size in list(range(3, 40)) * 2 + [64, 65, 130]:
+        ids = np.arange(nv, nv + size)
+        a, b = np.meshgrid(ids, ids)
+        keep = a != b
+        src.append(a[keep]); dst.append(b[keep])
+        nv += size
+    extra = rng.integers(0, nv, (4000, 2))
+    extra = extra[extra[:, 0] != extra[:, 1]]
+    src = np.concatenate(src + [extra[:, 0], extra[:, 1], extra[:60, 0], extra[:60, 1]])
+    dst = np.concatenate(dst + [extra[:, 1], extra[:, 0], extra[:60, 1], extra[:60, 0]])
+    g = DeviceGraph.from_edges(src, dst, None, n_vertices=nv, device="cuda")
+    start = rw.start_vertices(g)
+    p, q = pq
+    got, gv = rw.walk(g, start, 8, 50, p, q, 3)
+    want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), None, start.cpu().numpy(), 8, 50,
+                                  p, q, 3, n_threads=8)
+    assert np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy()[wv], want[wv])
+    other, ov = rw.walk(g, start, 8, 50, p, q, 3, use_wedges=False, use_edge_classes=False)
+    assert torch.equal(got, other) and torch.equal(gv, ov)
