@@ -334,6 +334,11 @@ __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, cons
   const double dn = (double)n;
   const double isum = (double)nR * K.fR + (double)nM * K.fM + (double)nO * K.fO;
   const double EM = K.fM * dn - isum, ER = K.fR * dn - isum, D = isum - K.fO * dn;
+  // (A shared class exactly on the average -- p = 1/2, q = 2 with two "other" slots per return edge,
+  // 5 % of that regime's pairings -- could be decided here as lane_case_b2_jump decides its
+  // zero-excess rows (scripts/models/flat_a.py: 4.7 M draws, 0 mismatches).  Built and measured in
+  // round 4: same walks, no gain -- such rows are short and their replay is the bit-mask loop --
+  // so this instance, whose registers are the flagship configuration's, was left as it was.)
   if (!(D > 0.0) || (nM > 0 && !(EM > 0.0)) || (nR > 0 && !(ER > 0.0))) return -1;
   // exactness of the arithmetic (products < 2^52) and of the decisions (4 n 1e-15 < 1 / isum)
   if (dn * isum > 2.0e14 || dn * dn * fmax(K.fR, K.fM) > 4.0e15) return -1;
