@@ -58,7 +58,7 @@ CONFIGS = {
 BIASED_PQ = (0.5, 2.0)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -78,10 +78,57 @@ def parse():
     ap.add_argument("--no-biased", action="store_true")
     ap.add_argument("--no-regimes", action="store_true", help="skip the other (p, q) regimes of the exact sampler")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU time budget per baseline leg")
-    return ap.parse_args()
+    ap.add_argument("--trim", type=int, default=-1,
+                    help="out-degree cap of trim_hotspot_vertices (-1 = the config's, 10000; 100000 = the "
+                         "reference's default cap, constants.py:6; 0 = no trim)")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks through torch.distributed.run also at --gpus 1 (at --gpus N > 1 "
+                         "this is what happens anyway when RANK is not in the environment)")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the spawned ranks (0 = a free one)")
+    return ap.parse_args(argv)
 
 
-def build_graph(cfg, torch, dev, setup):
+def spawn_command(argv, n, port):
+    """The command `bench.py --gpus N` re-launches itself as when it was started as ONE process
+    (no RANK in the environment): N ranks under torch.distributed.run, the driver's own form."""
+    rest = [a for a in argv if a != "--spawn"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + rest
+
+
+def spawn_ranks(args, argv):
+    """Parent of a self-launched run: NO GPU call is made here (a process that has touched the
+    GPU must not start the ranks by exec, and this one does not need the GPU at all).  The
+    ranks run as a CHILD process; its one JSON line is relayed, its exit code is ours."""
+    import socket
+    import subprocess
+
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    child = subprocess.Popen(spawn_command(argv, args.gpus, port), env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for ln in child.stdout:  # stderr goes straight through; stdout carries the JSON line
+        if ln.startswith("{"):
+            lines.append(ln)
+        else:
+            sys.stderr.write(ln)
+    code = child.wait()
+    for ln in lines:
+        sys.stdout.write(ln)
+    sys.stdout.flush()
+    if code == 0 and len(lines) != 1:
+        sys.stderr.write(f"bench.py: the spawned ranks printed {len(lines)} JSON lines, expected 1\n")
+        code = 1
+    return code
+
+
+def build_graph(cfg, torch, dev, setup, trim=-1):
     from node2vec_amd import synthetic
 
     t0 = time.perf_counter()
@@ -92,9 +139,11 @@ def build_graph(cfg, torch, dev, setup):
     torch.cuda.synchronize()
     setup["graph_generate_s"] = time.perf_counter() - t0
     setup["edges_before_trim"] = g.n_edges
-    if cfg["trim"]:
+    cap = cfg["trim"] if trim < 0 else trim
+    setup["trim_cap"] = cap
+    if cap:
         t0 = time.perf_counter()
-        g = g.trimmed(cfg["trim"], 42)  # trim_hotspot_vertices, randomwalk.py:238-262
+        g = g.trimmed(cap, 42)  # trim_hotspot_vertices, randomwalk.py:238-262
         torch.cuda.synchronize()
         setup["trim_s"] = time.perf_counter() - t0
     torch.cuda.empty_cache()
@@ -178,13 +227,22 @@ def reduce_job(torch, dist, use_dist, dev, elapsed, units):
 
 
 def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
-
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "RANK" not in os.environ and (args.gpus > 1 or args.spawn):
+        # started as one process: --gpus N means N ranks, so start them (before any GPU call)
+        raise SystemExit(spawn_ranks(args, argv))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                         f"(python bench.py --gpus {args.gpus} does it itself)")
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
     torch.cuda.set_device(local)
@@ -219,7 +277,8 @@ def main():
     cfg = CONFIGS[args.config]
     W, L = args.num_walks, args.walk_length
     setup = {}
-    g = build_graph(cfg, torch, dev, setup)
+    g = build_graph(cfg, torch, dev, setup, args.trim)
+    setup["max_out_degree"] = int(g.degrees().max())
     start_all = rw.start_vertices(g)
     batch = args.batch or cfg["batch"]
 
@@ -269,6 +328,24 @@ def main():
     elapsed, steps_total = reduce_job(torch, dist, use_dist, dev, res["elapsed"], res["steps_done"])
     value = steps_total / elapsed
     head_kernel = kernel_name(g, p, q)
+    # the SGNS leg's vocabulary, built as fit_streaming builds it (pipeline.corpus_vocabulary: pass 1
+    # over EVERY batch of the virtual corpus, descending token counts) -- untimed setup; the walks
+    # are the headline's (ranks at p = q = 1), regenerated batch by batch into the leg's buffers
+    sg_vocab = None
+    if not args.no_sgns:
+        from node2vec_amd.pipeline import corpus_vocabulary
+
+        def count_walk(k):
+            st = start_all[k * leg.batch:(k + 1) * leg.batch]
+            full = st.numel() == leg.batch
+            return rw.walk(g, st, W, L, p, q, 42, mode="exact", out=(leg.walks, leg.valid) if full else None,
+                           check=False, rank_ids=in_ranks)
+
+        t0 = time.perf_counter()
+        sg_vocab, _ = corpus_vocabulary(g, count_walk, -(-start_all.numel() // leg.batch), 0, in_ranks)
+        torch.cuda.synchronize()
+        setup["sgns_vocabulary_pass_s"] = time.perf_counter() - t0
+        leg.step(args.warmup + args.steps - 1)  # the buffers hold the last timed batch again
     if in_ranks:  # everything below reads vertex ids (outside the timed region)
         leg.walks = torch.where(leg.walks >= 0, g.rank_vertex[leg.walks.clamp(min=0).long()], leg.walks)
     # the SGNS legs train on walks of this leg (rows of the last batch walked)
@@ -278,23 +355,24 @@ def main():
     sg_blocks = max(1, min(args.steps + args.warmup, leg.batch // nv))
     sg_walks = leg.walks[: nv * W * sg_blocks][leg.valid[: nv * W * sg_blocks].bool()].clone()
     ref_bytes = reference_algorithmic_bytes(torch, g, leg.walks, leg.valid)
-    # (short: the driver's record keeps 160 characters of it; the details are separate keys)
-    workload = (f"{args.config} {cfg['gen']} {g.n_vertices} vertices / {g.n_edges} directed edges, "
-                f"p={p} q={q}, {W} walks x {L} steps, {leg.batch} start vertices per step")
-    assert len(workload) <= 160, workload
+    # (short: the driver's record keeps 120 characters of a string; the details are separate keys)
+    workload = (f"{args.config} {cfg['gen']} {g.n_vertices} vertices / {g.n_edges} edges, p={p:g} q={q:g}, "
+                f"{W} walks x {L} steps, batch {leg.batch}")
+    assert len(workload) <= 120, workload
     out = {
         "metric": "walk-steps/sec + embedding-updates/sec on 100M-node synthetic; 1/2/4/8 GPU",
         "value": value, "unit": "walk-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": workload, "graph": cfg["label"], "seed": 42, "num_walks": W,
+        "config": {"workload": workload, "graph": cfg["label"].replace("trimmed at 10000", f"trimmed at {setup['trim_cap']}"),
+                   "seed": 42, "num_walks": W,
                    "walk_length": L, "start_vertices_per_step_per_gpu": leg.batch,
                    "walk_mode": "exact", "n_vertices": g.n_vertices,
-                   "walk_ids": ("degree ranks (the graph numbered by descending degree; the same walks; "
-                                "fit_streaming composes rank -> vertex id into its per-token vocabulary "
-                                "lookup); vertex-id output: see vertex_id_output") if in_ranks else "vertex ids",
+                   "walk_ids": ("degree ranks (fit_streaming's launch); vertex ids out: value_vertex_ids"
+                                if in_ranks else "vertex ids"),
                    "n_edges": g.n_edges, "start_vertices": int(start_all.numel()),
+                   "trim_cap": setup["trim_cap"], "max_out_degree": setup["max_out_degree"],
                    "parallelism": f"graph replicated, start vertices range-sharded x{world}"},
     }
     if rank == 0:
@@ -379,7 +457,8 @@ def main():
     # ---- SGNS on the config's model ------------------------------------------------------------
     model = None
     if not args.no_sgns:
-        sg, model = bench_sgns(args, cfg, torch, dist, g, sg_walks, rank, world, barrier, use_dist, sg_blocks)
+        sg, model = bench_sgns(args, cfg, torch, dist, g, sg_walks, rank, world, barrier, use_dist, sg_blocks,
+                               sg_vocab)
         if rank == 0:
             out["sgns"] = sg
     if rank == 0 and not args.no_cpu_baseline and world == 1:
@@ -389,10 +468,56 @@ def main():
     if rank == 0:
         setup["hbm_peak_allocated_GB"] = torch.cuda.max_memory_allocated() / 1e9
         out["setup"] = setup
-        print(json.dumps(out), flush=True)
+        print(json.dumps(ordered_line(out)), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def ordered_line(out):
+    """The ONE line, ordered for its readers: the contract's keys first; the bulky sub-objects
+    (setup, sgns, fast_mode, the regimes) in the middle; at the END -- the part of a long line
+    that a record keeping only a tail of stdout retains -- the exact biased leg, the two rooflines
+    of the headline (ranks out = what fit_streaming launches; vertex ids out = what random_walk()
+    returns, reference fugue.py:153-155), the CPU baseline and a compact summary of every leg."""
+    head = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "config"]
+    tail = ["biased", "cpu_baseline", "roofline", "value_vertex_ids", "ms_per_step_vertex_ids",
+            "roofline_vertex_ids", "summary"]
+    vleg = out.pop("vertex_id_output", None)
+    if vleg is not None:
+        out["value_vertex_ids"] = vleg["value"]
+        out["ms_per_step_vertex_ids"] = vleg["ms_per_step"]
+        out["roofline_vertex_ids"] = vleg["roofline"]
+    elif "roofline" in out:  # the headline launch itself writes vertex ids
+        out["value_vertex_ids"] = out["value"]
+        out["ms_per_step_vertex_ids"] = out["ms_per_step"]
+
+    def frac(o):
+        return None if not o or "roofline" not in o else round(o["roofline"]["frac"], 4)
+
+    sg = out.get("sgns") or {}
+    cpu = out.get("cpu_baseline") or {}
+    out["summary"] = {
+        "walk_steps_per_s": {
+            "exact_pq1_ranks_out": out["value"], "exact_pq1_vertex_ids_out": out.get("value_vertex_ids"),
+            "exact_biased_0.5_2": (out.get("biased") or {}).get("value"),
+            **{"exact_%g_%g" % (r["p"], r["q"]): r["value"] for r in out.get("biased_other_regimes", [])},
+            "fast_0.5_2": (out.get("fast_mode") or {}).get("value")},
+        "walk_roofline_frac": {"exact_pq1_ranks_out": frac(out),
+                               "exact_pq1_vertex_ids_out": None if "roofline_vertex_ids" not in out
+                               else round(out["roofline_vertex_ids"]["frac"], 4),
+                               "exact_biased_0.5_2": frac(out.get("biased")), "fast_0.5_2": frac(out.get("fast_mode"))},
+        "sgns_pairs_per_s": {"per_pair_default": sg.get("value"),
+                             "per_pair_plain_stores": (sg.get("plain_stores") or {}).get("value"),
+                             "batched_opt_in": (sg.get("batched") or {}).get("value")},
+        "sgns_roofline_frac": {"per_pair_default": frac(sg), "batched_opt_in": frac(sg.get("batched"))},
+        "sgns_exchange_world": (sg.get("exchange") or {}).get("world"),
+        "cpu_port": {"walk_steps_per_s": cpu.get("value"), "sgns_pairs_per_s": (cpu.get("sgns") or {}).get("value"),
+                     "cores": cpu.get("cores")},
+        "hbm_peak_allocated_GB": (out.get("setup") or {}).get("hbm_peak_allocated_GB")}
+    keys = head + [k for k in out if k not in head and k not in tail] + [k for k in tail if k in out]
+    return {k: out[k] for k in keys if k in out}
 
 
 def prepare_tables(torch, g, p, q, mode, setup, tag):
@@ -635,23 +760,20 @@ def pmc_traffic(config, kernel, p, q, batch):
     return float(ent["hbm_bytes_per_launch"]) if ent else None
 
 
-def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist, n_blocks=1):
+def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist, n_blocks=1, vocab=None):
     """K launches of the SGNS kernel (embedding-updates/s).  One step = one launch over the
-    walks of `sgns_vertices` start vertices (x W rows of L+1 tokens), vocabulary = every
-    vertex (min_count=0, sample=0: deterministic unit counts; index order = descending
-    degree), dim from the config, window 5, k=5.  Unit: one positive (centre, context) pair
+    walks of `sgns_vertices` start vertices (x W rows of L+1 tokens), vocabulary = the one
+    fit_streaming builds for this corpus (pipeline.corpus_vocabulary: every vertex the walks
+    visit, min_count=0, sample=0, index order = descending token count over the WHOLE virtual
+    corpus), dim from the config, window 5, k=5.  Unit: one positive (centre, context) pair
     with its k negative targets.  With N GPUs every rank trains its own walks on a full
     replica; the exchange step (bf16 delta all-reduce, sgns.DeltaSync) is timed beside it."""
     from node2vec_amd import sgns
 
     dev = walks.device
     dim = cfg["dim"]
-    deg = g.degrees().clamp(min=1)
-    order = torch.sort(deg, descending=True, stable=True).indices
-    index_of = torch.empty(g.n_vertices, dtype=torch.int32, device=dev)
-    index_of[order] = torch.arange(g.n_vertices, dtype=torch.int32, device=dev)
-    vocab = sgns.Vocab(order, deg[order], index_of)
-    del deg
+    assert vocab is not None
+    index_of = vocab.index_of
     model = sgns.SgnsModel(vocab, dim, 5, 5, seed=1, sample=0.0, device=dev)
     idx_all = index_of[walks.long()].contiguous()
     rows = idx_all.shape[0] // n_blocks
@@ -703,8 +825,10 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist,
            "row_updates_per_s": pairs_total / elapsed * 6, "ms_per_step": 1e3 * elapsed / args.steps,
            "dtype": "f32", "config": {"dim": dim, "window": 5, "negative": 5, "rows_per_step": rows,
                                       "distinct_blocks_of_rows": n_blocks,
-                                      "n_vocab": g.n_vertices, "sample": 0, "min_count": 0,
-                                      "model_bytes": 2 * g.n_vertices * dim * 4},
+                                      "n_vocab": len(vocab), "sample": 0, "min_count": 0,
+                                      "vocabulary": "pipeline.corpus_vocabulary: token counts of the whole "
+                                                    "virtual corpus, descending (fit_streaming's pass 1)",
+                                      "model_bytes": 2 * len(vocab) * dim * 4},
            "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
                         "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": None,
                         "traffic_committed": traffic, "kernel": "sgns_kernel", "kernel_ms": 1e3 * kernel_s,
@@ -760,12 +884,15 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist,
     if use_dist:  # the exchange step of the multi-GPU path, timed once (blocking, bf16 deltas)
         # (at N = 1 under torch.distributed.run the same calls run on a group of one rank: the
         # RCCL path is rehearsed, the mean is of one replica)
+        torch.cuda.reset_peak_memory_stats()
         sync = sgns.DeltaSync(model, wire="bf16", rehearse=True)
         barrier()
         t0 = time.perf_counter()
         sync.sync(blocking=True)
         barrier()
         dt = time.perf_counter() - t0
+        peak_live = torch.tensor([float(torch.cuda.max_memory_allocated())], dtype=torch.float64, device=dev)
+        dist.all_reduce(peak_live, op=dist.ReduceOp.MAX)
         step_s = 1e-3 * res["ms_per_step"]
         every = max(1, -(-int(1e6 * dt * 0.9) // max(1, int(1e6 * 0.1 * step_s))))
         res["exchange"] = {"world": dist.get_world_size(), "backend": "nccl (RCCL)",
@@ -773,6 +900,7 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist,
                                    "order) -> all_gather (bytes) -> n2v_delta_apply",
                            "blocks_exchanged": sync.exchanged_blocks,
                            "tensors_on_device": bool(sync.on_gpu),
+                           "hbm_peak_allocated_GB_with_exchange_live": float(peak_live.item()) / 1e9,
                            "delta_allreduce_s": dt, "wire_dtype": sync.wire_dtype_name,
                            "wire_bytes_per_rank": sync.wire_bytes,
                            "share_of_step_time_if_every_launch": dt / (dt + step_s),

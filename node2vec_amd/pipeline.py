@@ -29,6 +29,45 @@ from node2vec_amd.embedding import HipW2V, KeyedVectors
 from node2vec_amd.graph import DeviceGraph
 
 
+def corpus_vocabulary(graph: DeviceGraph, walk, n_batches: int, min_count: int, in_ranks: bool,
+                      multi: bool = False, after_count=None):
+    """Pass 1 of fit_streaming: the vocabulary of the virtual corpus `walk(0) ... walk(n_batches - 1)`
+    -- what gensim's vocabulary scan does with the token strings of embedding.py:125: token counts,
+    min_count, descending-count order (ties: ascending id).  No host synchronisation per batch:
+    invalid rows are masked out, not compacted.  Returns (Vocab, per-token lookup): the lookup takes
+    the tokens as the walks carry them (degree ranks when `in_ranks`) to vocabulary indices.
+    bench.py builds its SGNS leg's vocabulary with this same function."""
+    import torch.distributed as dist
+
+    from node2vec_amd.shard import all_reduce
+
+    dev = graph.device
+    counts = torch.zeros(graph.n_vertices, dtype=torch.int64, device=dev)
+    for k in range(n_batches):
+        walks, valid = walk(k)
+        if walks.numel() == 0:
+            continue
+        sgns.corpus_count(walks, valid, counts)  # one pass, no widening / clamping / scatter ops
+    if in_ranks:
+        counts = counts[graph.rank_of.long()]  # counted per rank: back to vertex ids
+    if multi:
+        all_reduce(counts, dist.ReduceOp.SUM)
+    if after_count is not None:
+        after_count()  # (the nonzero() below synchronises anyway)
+    ids = torch.nonzero(counts >= max(int(min_count), 1)).reshape(-1)
+    if ids.numel() == 0:
+        raise RuntimeError("you must first build vocabulary before training the model")
+    cnt = counts[ids]
+    order = torch.sort(cnt, descending=True, stable=True).indices  # ties: ascending id
+    ids, cnt = ids[order], cnt[order]
+    del counts, order
+    index_of = torch.full((graph.n_vertices,), -1, dtype=torch.int32, device=dev)
+    index_of[ids] = torch.arange(ids.numel(), dtype=torch.int32, device=dev)
+    vocab = sgns.Vocab(ids, cnt, index_of)
+    token_index = index_of[graph.rank_vertex.long()].contiguous() if in_ranks else index_of
+    return vocab, token_index
+
+
 def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Dict[str, Any],
                   random_seed: int, batch_vertices: int = 65536, walk_seed_ids=None,
                   mode: str = "exact", return_model: bool = False, timings: Optional[dict] = None):
@@ -44,7 +83,7 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
 
     import torch.distributed as dist
 
-    from node2vec_amd.shard import all_reduce, shard_range
+    from node2vec_amd.shard import shard_range
 
     for k, v in NODE2VEC_PARAMS.items():
         n2v_params.setdefault(k, v)
@@ -101,33 +140,12 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
         from node2vec_amd import _lib
         _lib.check_status_word(int(walk_status.item()), "n2v_walk")
 
-    # ---- pass 1: token counts of the virtual corpus (vocabulary, cum_table, subsampling).  No
-    # host synchronisation per batch: invalid rows are masked out, not compacted.
-    counts = torch.zeros(graph.n_vertices, dtype=torch.int64, device=dev)
+    # ---- pass 1: token counts of the virtual corpus (vocabulary, cum_table, subsampling)
     t0 = clock()
-    for k in range(n_batches):
-        walks, valid = walk(k)
-        if walks.numel() == 0:
-            continue
-        sgns.corpus_count(walks, valid, counts)  # one pass, no widening / clamping / scatter ops
-    if in_ranks:
-        counts = counts[graph.rank_of.long()]  # counted per rank: back to vertex ids
-    if multi:
-        all_reduce(counts, dist.ReduceOp.SUM)
+    vocab, token_index = corpus_vocabulary(graph, walk, n_batches, int(p["min_count"]), in_ranks, multi,
+                                           raise_walk_status)
     t_walk += clock() - t0
-    raise_walk_status()  # (the nonzero() below synchronises anyway)
     rows_rank_max = n_start_max * W  # rows of the largest shard: the sentence-id stride of a rank
-    ids = torch.nonzero(counts >= max(int(p["min_count"]), 1)).reshape(-1)
-    if ids.numel() == 0:
-        raise RuntimeError("you must first build vocabulary before training the model")
-    cnt = counts[ids]
-    order = torch.sort(cnt, descending=True, stable=True).indices  # ties: ascending id
-    ids, cnt = ids[order], cnt[order]
-    del counts, order
-    index_of = torch.full((graph.n_vertices,), -1, dtype=torch.int32, device=dev)
-    index_of[ids] = torch.arange(ids.numel(), dtype=torch.int32, device=dev)
-    vocab = sgns.Vocab(ids, cnt, index_of)
-    token_index = index_of[graph.rank_vertex.long()].contiguous() if in_ranks else index_of
     model = sgns.SgnsModel(vocab, int(p["size"]), int(p["window"]), negative, int(p["seed"] or seed),
                            sample=float(p["sample"] or 0.0), ns_exponent=float(p["ns_exponent"]),
                            device=dev)

@@ -420,3 +420,43 @@ def test_index_graph_names_on_the_references_own_input():
     assert w32.dtype == torch.float32 and len(w32) == 2 and w64.dtype == torch.float64 and len(w64) == 4
     e64, _ = index_graph_pandas(pd.DataFrame({"src": src, "dst": dst, "weight": wt}), False)
     assert len(e64) == 4
+
+
+def test_bench_gpus_n_spawns_n_ranks(monkeypatch):
+    """bench.py --gpus N, started as one process, launches N ranks under torch.distributed.run as a
+    child process: the command line it would run at N = 2, and the refusal of a
+    WORLD_SIZE that contradicts --gpus.  (No GPU here: nothing is started.)"""
+    import importlib.util
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("n2v_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    argv = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "cfg2"]
+    cmd = bench.spawn_command(argv, 2, 29517)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[3:10] == ["--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29517"]
+    assert cmd[10] == os.path.join(root, "bench.py") and cmd[11:] == argv
+    assert "--spawn" not in bench.spawn_command(argv + ["--spawn"], 2, 1)
+    # main(): one process + --gpus 2 -> the spawn path, with the parsed arguments; no torch import needed
+    seen = {}
+
+    def fake_spawn(args, av):
+        seen["gpus"], seen["argv"] = args.gpus, list(av)
+        return 0
+
+    monkeypatch.setattr(bench, "spawn_ranks", fake_spawn)
+    monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and seen == {"gpus": 2, "argv": argv}
+    # a rank of a world of 1 claiming --gpus 2 is refused
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=1" in str(e.value.code)

@@ -231,3 +231,36 @@ def test_bench_under_torchrun_rehearses_the_rccl_exchange():
     assert ex["world"] == 1 and ex["backend"] == "nccl (RCCL)" and ex["wire_dtype"] == "bf16"
     assert ex["tensors_on_device"] is True and ex["blocks_exchanged"] >= 2  # syn0 and syn1neg
     assert ex["delta_allreduce_s"] > 0
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus N` started as ONE process (no RANK in the environment) starts the N
+    ranks itself: a child `python -m torch.distributed.run --nproc-per-node N bench.py ...` (never an
+    exec; the parent makes no GPU call), relays the one JSON line and returns the child's exit code.
+    One GPU here, so N = 1 through the same path (`--spawn` forces it at N = 1; at N > 1 it is what
+    `--gpus N` does): `n_gpus` == --gpus and the exchange ran on a group of that size."""
+    import json
+    import subprocess
+
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--config", "cfg2",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-fast", "--no-regimes", "--no-biased",
+           "--no-batched", "--no-hub"]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    run = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    ex = out["sgns"]["exchange"]  # only a run under torch.distributed has it: the ranks were spawned
+    assert ex["world"] == 1 and ex["backend"] == "nccl (RCCL)"
+    assert ex["hbm_peak_allocated_GB_with_exchange_live"] > 0
+    assert out["summary"]["sgns_exchange_world"] == 1
+    assert list(out)[-1] == "summary" and "value_vertex_ids" in out
+    # a rank count that contradicts --gpus is refused before anything touches the GPU
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT,
+                         env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), capture_output=True,
+                         text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
