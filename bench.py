@@ -849,6 +849,7 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist,
     # threads) at 8192 waves.  The same launches with plain stores everywhere (hub_rows = 0, gensim's
     # code as written; cfg 2 link AUC 0.897 instead of 0.909) for comparison:
     res["hub_rows_auto"] = {"rows": int(model.hub_rows or 0), "n_vocab": len(model.vocab),
+                            "waves_in_flight": model.hub_waves,
                             "rule": "rows with waves x (token share + k x negative-draw share) >= 1.5"}
     if not args.no_hub:
         auto_rows = model.hub_rows

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define N2V_ABI_VERSION 9
+#define N2V_ABI_VERSION 10
 
 #define N2V_OK 0
 #define N2V_EINVAL (-1)  /* maps to ValueError (randomwalk.py:212-217)      */
@@ -104,7 +104,10 @@ typedef struct n2v_graph {
   const struct n2v_hop *hops;   /* [n_edges] or NULL (unit-weight graphs) */
   const uint64_t *wedge_off;    /* [n_edges] or NULL: see n2v_wedge_build */
   const void *wedge_pos;        /* uint16 / uint32 positions, or NULL */
-  int32_t wedge_wide;           /* 0: wedge_pos is uint16 (every degree < 65536), 1: uint32 */
+  int32_t wedge_wide;           /* 0: wedge_pos is uint16 (every degree < 65536), 1: uint32,
+                                   T >= 2 (mixed; 65536 in production): the lists of the edges INTO a row
+                                   of T entries or more are uint32 and lie behind the uint16 lists of all
+                                   other edges -- see n2v_wedge_build */
   int32_t reserved;             /* 0 (diagnostics: bit 0 set = do not use the all-tables kernel,
                                    bit 1 set = do not use wedge_slots) */
   const uint64_t *hops8;        /* the 8-byte hop table (n2v_hops8_build) or NULL */
@@ -227,8 +230,15 @@ int n2v_hops8_build(const n2v_graph *g, int32_t col_bits, int32_t row_bits, int3
  * slot off the list.  One entry per (edge, common neighbour) pair: six per triangle.
  *   list_off      [n_edges] exclusive prefix sum of the shared counts (the caller's cumsum over
  *                 edge_classes & N2V_EC_SHARED_MASK); may be the same buffer as wedge_off_out
- *   wedge_pos_out [sum of the counts] uint16 when wide == 0 (every out-degree < 65536) else
- *                 uint32
+ *   wedge_pos_out [sum of the counts] uint16 when wide == 0 (every out-degree < 65536), uint32
+ *                 when wide == 1.  wide == T >= 2 (T <= 65536; "mixed"): the list of an edge into a
+ *                 row of fewer than T entries is uint16, offsets in uint16 units; the list of an
+ *                 edge into a row of T entries or more ("wide row": its positions need more than 16
+ *                 bits) is uint32, offsets in uint32 units from the same base, and the caller lays
+ *                 those lists behind all the uint16 ones (list_off says where, per edge).  A walker
+ *                 knows the degree of the row it stands on, so it knows the width of the list it
+ *                 reads: a few hubs (the reference caps rows at 100 000, constants.py:6) cost the
+ *                 other rows nothing.  The same value goes into n2v_graph.wedge_wide.
  * g->edge_classes must be set.  A list whose length disagrees with its count sets
  * N2V_ST_RANGE in status[0] (the tables must then be discarded). */
 #define N2V_WEDGE_RPOS_SHIFT 40
@@ -245,7 +255,8 @@ int n2v_wedge_build(const n2v_graph *g, const uint64_t *list_off, uint64_t *wedg
  *   n_shared <= 14:  [2 .. 2 + n_shared) the list itself
  *   n_shared  > 14:  [4 .. 8) the list's offset in wedge_pos as 64 bits, [8 .. 16) eight pivots
  *                    list[((k + 1) * n_shared) / 9], k = 0 .. 7 (the search enters the right ninth)
- * 16-bit positions only (wedge_wide == 0); g->edge_classes, g->wedge_off and g->wedge_pos must be
+ * 16-bit positions only (wedge_wide == 0, or mixed: the slots of the edges into wide rows are left
+ * zero and never read -- those steps go through wedge_off); g->edge_classes, g->wedge_off and g->wedge_pos must be
  * set.  At cfg 4 half of the steps need a list and four fifths of those lists are short.
  * slots_out: [n_edges * 16] uint16. */
 int n2v_wedge_slots_build(const n2v_graph *g, uint16_t *slots_out, void *stream);
@@ -434,6 +445,13 @@ int n2v_cum_index_build(const uint32_t *cum_table, int64_t n_vocab, int32_t bits
  * n2v_sgns_params.row_alpha.  out: [n] fp32. */
 int n2v_sgns_job_alpha(int32_t job_rows, int32_t epoch, int32_t epochs, int64_t row0, int64_t rows,
                        double alpha0, double alpha_min, int64_t n, float *out, void *stream);
+
+/* How many waves n2v_sgns_train(P, n_walks, walk_len) keeps in flight on this device (its hogwild
+ * concurrency rule, max_waves and the occupancy of the kernel instance it picks, all applied) --
+ * nothing is launched.  The host chooses n2v_sgns_params.hub_rows from it (node2vec_amd/sgns.py
+ * auto_hub_rows: a row held by more than one wave at a time on average gets atomic adds).  0 for the
+ * batched trainer; a negative status for parameters n2v_sgns_train would refuse. */
+int64_t n2v_sgns_hogwild_waves(const n2v_sgns_params *P, int64_t n_walks, int32_t walk_len);
 
 int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t walk_len,
                    float *syn0, float *syn1neg, const uint32_t *cum_table,

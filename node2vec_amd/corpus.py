@@ -8,8 +8,10 @@ compared with == by concat / merge, and serialised as JSON by to_parquet).  The 
 opaque integer token; this module maps token -> (weak reference to the frame, tensor) and hands
 the tensor out only to the very frame object random_walk() returned, after checking that its
 "walk" column still is what the tensor says: every row must still be the very list object
-random_walk() put there (so `df.at[i, "walk"] = ...`, masking, reordering or any other replacement
-of rows is always seen), and 64 sampled rows + the ends are compared element by element (an edit
+random_walk() put there -- the registry keeps a reference to each of them, so an address can never
+be reused by another object while the entry lives, and `df.at[i, "walk"] = ...`, masking,
+reordering or any other replacement of rows is always seen --, and 64 sampled rows + the ends are
+compared element by element (an edit
 INSIDE one of the original list objects is only caught on those; set `corpus.STRICT = True` to
 compare every element, at the cost of the host conversion the device corpus exists to avoid, or
 pass `df.copy()` / drop `df.attrs` to train on the frame's contents).  The entry dies with the frame.
@@ -23,7 +25,7 @@ import torch
 
 ATTR = "n2v_device_walks"
 _tokens = itertools.count(1)
-_registry = {}  # token -> (weakref to the frame, device tensor, ids of the row objects)
+_registry = {}  # token -> (weakref to the frame, device tensor, ids of the row objects, the row objects)
 STRICT = False  # True: lookup() compares the whole column with the tensor
 
 
@@ -33,7 +35,10 @@ def _row_ids(col) -> np.ndarray:
 
 def attach(frame, walks: torch.Tensor) -> None:
     token = next(_tokens)
-    _registry[token] = (weakref.ref(frame), walks, _row_ids(frame["walk"]))
+    rows = frame["walk"].to_numpy()
+    # (the row objects themselves are kept: CPython reuses the address of a freed list, so bare ids
+    # could match a row that was dropped and replaced)
+    _registry[token] = (weakref.ref(frame), walks, _row_ids(frame["walk"]), list(rows))
     weakref.finalize(frame, _registry.pop, token, None)
     frame.attrs[ATTR] = token
 

@@ -185,6 +185,12 @@ __device__ __forceinline__ int wedge_lower_t(const void *base, int64_t off, int 
   return lo;
 }
 
+// width of the wedge list a walker reads while it stands on a row of n entries (n2v_graph.wedge_wide:
+// 0 uint16 everywhere, 1 uint32 everywhere, T >= 2 mixed -- uint32 for the rows of T entries or more)
+__host__ __device__ __forceinline__ bool wedge_row_wide(int32_t wedge_wide, int64_t n) {
+  return wedge_wide == 1 || (wedge_wide >= 2 && n >= (int64_t)wedge_wide);
+}
+
 __device__ __forceinline__ int wedge_lower(const void *base, int64_t off, int cnt, int pos, bool wide,
                                            bool &found) {
   if (wide) return wedge_lower_t<uint32_t>(base, off, cnt, pos, found);

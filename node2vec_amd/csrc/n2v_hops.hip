@@ -30,7 +30,9 @@ __global__ __launch_bounds__(256) void hops_build_kernel(n2v_graph g, n2v_hop *_
       // an edge without shared neighbours carries its return position instead of the zero count
       const uint32_t fR = cls >> N2V_EC_RETURN_SHIFT;
       bad = bad || fR >= 0x80u;  // (the caller checked: every return count is below 128)
-      if ((cls & N2V_EC_SHARED_MASK) == 0u) {
+      // (an edge into a wide row of a mixed wedge table keeps its plain class word: its return
+      // position needs more than the 16 bits the slots kernel reads back)
+      if ((cls & N2V_EC_SHARED_MASK) == 0u && !(g.wedge_wide >= 2 && d >= (int64_t)g.wedge_wide)) {
         const uint64_t rpos = g.wedge_off[e] >> N2V_WEDGE_RPOS_SHIFT;
         cls = N2V_EC_INLINE | ((fR & 0x7fu) << N2V_EC_RETURN_SHIFT) | (uint32_t)(rpos & N2V_EC_SHARED_MASK);
       }

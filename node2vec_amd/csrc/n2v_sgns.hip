@@ -592,20 +592,26 @@ extern "C" int n2v_sgns_batched_launch(const int32_t *walks, int64_t n_walks, in
                                        const n2v_sgns_params *P, unsigned long long *pairs_out,
                                        void *stream);
 
-extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t walk_len,
-                              float *syn0, float *syn1neg, const uint32_t *cum_table,
-                              const uint32_t *sample_int, const float *exp_table,
-                              const n2v_sgns_params *P, unsigned long long *pairs_out,
-                              void *stream) {
-  if (!P || !walks || !syn0 || !syn1neg || !cum_table || !exp_table) return N2V_EINVAL;
+// n2v_sgns_train, or (dry_waves != NULL) only its launch geometry: the waves it would keep in flight
+static int sgns_train_impl(const int32_t *walks, int64_t n_walks, int32_t walk_len,
+                           float *syn0, float *syn1neg, const uint32_t *cum_table,
+                           const uint32_t *sample_int, const float *exp_table,
+                           const n2v_sgns_params *P, unsigned long long *pairs_out,
+                           void *stream, int64_t *dry_waves) {
+  if (!P) return N2V_EINVAL;
+  if (!dry_waves && (!walks || !syn0 || !syn1neg || !cum_table || !exp_table)) return N2V_EINVAL;
   if (n_walks < 0 || walk_len < 1 || walk_len > N2V_SGNS_MAX_SENTENCE) return N2V_EINVAL;
   if (P->n_vocab < 1 || P->dim < 1 || P->dim > 1024 || P->window < 1 || P->window > 32 ||
       P->negative < 1 || P->negative > 32)
     return N2V_EINVAL;
   if (P->batched != 0 && P->batched != 1) return N2V_EINVAL;
+  if (dry_waves) *dry_waves = 0;
   if (n_walks == 0) return N2V_OK;
-  if (P->batched) return n2v_sgns_batched_launch(walks, n_walks, walk_len, syn0, syn1neg, cum_table,
-                                                 sample_int, exp_table, P, pairs_out, stream);
+  if (P->batched) {
+    if (dry_waves) return N2V_OK;  // (the batched trainer runs plain stores: nobody asks)
+    return n2v_sgns_batched_launch(walks, n_walks, walk_len, syn0, syn1neg, cum_table,
+                                   sample_int, exp_table, P, pairs_out, stream);
+  }
   using namespace n2v;
   int V = 1;
   while (64 * V < P->dim) V *= 2;
@@ -642,7 +648,7 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   }
   hipStream_t st = (hipStream_t)stream;
   // pairs_out[1] is the kernel's row counter: start it at zero on the same stream
-  if (pairs_out && hipMemsetAsync(pairs_out + 1, 0, sizeof(unsigned long long), st) != hipSuccess)
+  if (!dry_waves && pairs_out && hipMemsetAsync(pairs_out + 1, 0, sizeof(unsigned long long), st) != hipSuccess)
     return N2V_ELAUNCH;
   // lookahead depth: 1 pair for dim <= 512, none above (registers).  Depth 2 was measured
   // in rounds 2 and 3 (ring variant) and lost every time.
@@ -659,6 +665,10 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
     if (!P->deterministic) {                                                                 \
       const int64_t cap = resident_blocks(fn, (int)block.x, lds);                            \
       if (blocks > cap) blocks = cap;                                                        \
+    }                                                                                        \
+    if (dry_waves) {                                                                         \
+      *dry_waves = blocks * (int64_t)(block.x / 64);                                         \
+      break;                                                                                 \
     }                                                                                        \
     hipLaunchKernelGGL((sgns_kernel<VV, kD, RR>), dim3((unsigned)blocks), block, lds, st,     \
                        walks, n_walks, walk_len, syn0, syn1neg, cum_table, sample_int,        \
@@ -682,8 +692,25 @@ extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t wal
   }
 #undef N2V_LAUNCH_RING
 #undef N2V_LAUNCH_R
+  if (dry_waves) return N2V_OK;
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
+}
+
+extern "C" int n2v_sgns_train(const int32_t *walks, int64_t n_walks, int32_t walk_len,
+                              float *syn0, float *syn1neg, const uint32_t *cum_table,
+                              const uint32_t *sample_int, const float *exp_table,
+                              const n2v_sgns_params *P, unsigned long long *pairs_out,
+                              void *stream) {
+  return sgns_train_impl(walks, n_walks, walk_len, syn0, syn1neg, cum_table, sample_int, exp_table, P,
+                         pairs_out, stream, nullptr);
+}
+
+extern "C" int64_t n2v_sgns_hogwild_waves(const n2v_sgns_params *P, int64_t n_walks, int32_t walk_len) {
+  int64_t waves = 0;
+  const int rc = sgns_train_impl(nullptr, n_walks, walk_len, nullptr, nullptr, nullptr, nullptr, nullptr, P,
+                                 nullptr, nullptr, &waves);
+  return rc == N2V_OK ? waves : (int64_t)rc;
 }
 
 namespace n2v {

@@ -122,12 +122,12 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
   // wedge table (n2v_wedge_build): "x in N(s)" for the candidate at position `pick` of N(v) is
   // "pick is in the list of the edge (s -> v)": one offset gather + a search in a short list
   const bool have_w = have_ec && g.wedge_off != nullptr && g.wedge_pos != nullptr;
-  const bool w_wide = g.wedge_wide != 0;
   // wedge slots (n2v_wedge_slots_build): return position and list of an edge with ONE gather
   // (its own code instance, launched at q < 1 only -- where every "other" draw is tested against the
   // list: there the slots win 9 - 10 %; at q >= 1 nearly every step is a plain uniform draw and the
   // eight registers of a slot cost 9 - 10 %, profiles/r4r_time_fast_slots_cfg4.log)
-  const bool have_slots = kSlots && have_w && !w_wide && g.wedge_slots != nullptr;
+  // (a mixed wedge table: the steps of walkers standing on a wide row go through wedge_off)
+  const bool slots_tab = kSlots && have_w && g.wedge_wide != 1 && g.wedge_slots != nullptr;
   // hop table with inline return positions (N2V_HOPS_INLINE_RPOS): an edge without shared
   // neighbours says where its return run starts in the class word itself
   const bool inl_tab = kHops && (g.reserved2 & N2V_HOPS_INLINE_RPOS) != 0;
@@ -248,6 +248,8 @@ __global__ __launch_bounds__(256, 6) void walk_fast_kernel(
     const uint64_t bits = plain ? hstep : trial_bits(hstep, trial);
     const uint32_t u1 = (uint32_t)(bits >> 32), u2 = (uint32_t)bits;
     int pick = pick_index(u1, n);
+    const bool w_wide = wedge_row_wide(g.wedge_wide, n);  // width of the list of the edge walked last
+    const bool have_slots = slots_tab && !w_wide;
     uint64_t wraw = 0;  // kClassFirst: wedge_off of the edge walked last
     int4 ws_a = make_int4(0, 0, 0, 0), ws_b = make_int4(0, 0, 0, 0);  // ... or its wedge slot
     if (kClassFirst && !plain) {
@@ -452,7 +454,7 @@ extern "C" int n2v_walk_fast_launch(const n2v_graph *g, const int32_t *start_ids
   // class-first sampling: counts, return position and shared positions of every edge at hand
   const bool cf = unit && (hops || g->edge_classes) && g->wedge_off && g->wedge_pos &&
                   !(p == 1.0 && q == 1.0);
-  const bool slots = cf && hops && q < 1.0 && g->wedge_slots && !g->wedge_wide;
+  const bool slots = cf && hops && q < 1.0 && g->wedge_slots && g->wedge_wide != 1;
   const void *fn = slots  ? (const void *)n2v::walk_fast_kernel<true, true, true, true>
                    : cf   ? (hops ? (const void *)n2v::walk_fast_kernel<true, true, true>
                                   : (const void *)n2v::walk_fast_kernel<true, false, true>)

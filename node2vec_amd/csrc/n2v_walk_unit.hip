@@ -1382,7 +1382,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
   const bool need_mem = q != 1.0;
   // wedge table (n2v_wedge_build): the class of every slot of a step's table by position
   const bool have_w = g.wedge_off != nullptr && g.wedge_pos != nullptr;
-  const bool w_wide = g.wedge_wide != 0;
 #ifdef N2V_CHECK
   n2v_check_status = status;
   const int dbg = g.reserved;  // bit 0: no per-lane pairing, 1: no list classification, 2: no list membership
@@ -1450,6 +1449,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
         u2 = (uint32_t)bits;
         const int pick = pick_index(u1, n);
         idx = pick;
+        const bool w_wide = wedge_row_wide(g.wedge_wide, n);  // (a mixed table: by the row stood on)
         // the class counts of this step's table are known before any load (they came with the
         // hop that walked the edge), so the offset of the edge's wedge list is requested FIRST and
         // travels together with the hop gather: two independent loads, one latency
@@ -1573,13 +1573,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, N2V_LANES_WAVES) void walk_exa
         c.iters = 32 - __clz(c.m);
         c.s = __builtin_amdgcn_readlane(s, l);
         c.w_have = __builtin_amdgcn_readlane((int)w_ok, l) != 0;
-        c.w_wide = w_wide;
+        c.w_wide = wedge_row_wide(g.wedge_wide, c.n);
         c.w_nR = __builtin_amdgcn_readlane(w_nR, l);
         c.w_nM = __builtin_amdgcn_readlane(w_nM, l);
         c.w_rpos = __builtin_amdgcn_readlane(w_rpos, l);
         {
           const int64_t wo = readfirstlane_i64(__shfl(w_off, l, 64));
-          c.w_pos = w_wide ? (const void *)(reinterpret_cast<const uint32_t *>(g.wedge_pos) + wo)
+          c.w_pos = c.w_wide ? (const void *)(reinterpret_cast<const uint32_t *>(g.wedge_pos) + wo)
                            : (const void *)(reinterpret_cast<const uint16_t *>(g.wedge_pos) + wo);
         }
         const uint32_t u1_l = (uint32_t)__builtin_amdgcn_readlane((int)u1, l);

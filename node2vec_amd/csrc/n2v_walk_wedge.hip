@@ -45,7 +45,6 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
   const int L1 = walk_length + 1;
   const bool biased = !(p == 1.0 && q == 1.0);
   const bool need_mem = q != 1.0;
-  const bool w_wide = g.wedge_wide != 0;
   // 1/q > 1: "other" is overfull, an overfull `pick` has no quick exit, so nearly every step runs
   // the pairing and needs the return position: request the wedge offset with the hop, always
   const bool always_pair = K.bO > 1.0;
@@ -121,6 +120,7 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
       const uint32_t u1 = (uint32_t)(bits >> 32), u2 = (uint32_t)bits;
       const int pick = pick_index(u1, n);
       int idx = pick;
+      const bool w_wide = wedge_row_wide(g.wedge_wide, n);  // (mixed table: by the row stood on)
       const bool step_biased = s >= 0 && biased;
       uint32_t fR = 0, fM = 0;
       if (step_biased) {
@@ -520,7 +520,8 @@ int n2v_walk_wedge_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_s
   if (total == 0) return 1;
   // the return run shares a stack with "other" on ordinary rows: q > 1 with p > q, q < 1 with p < q
   const bool alone_under = K.bO <= 1.0 && K.bR >= K.bO, alone_over = K.bO >= 1.0 && K.bR <= K.bO;
-  if (g->wedge_slots && !g->wedge_wide && !(g->reserved & 2)) {
+  if (g->wedge_wide < 0 || g->wedge_wide > 65536) return N2V_EINVAL;
+  if (g->wedge_slots && g->wedge_wide != 1 && !(g->reserved & 2)) {
     // the wedge slots are at hand: the list of a step arrives with its hop entry
     auto sk = !K.dyadic    ? n2v::walk_exact_wedge_slots_kernel<2>
               : alone_under ? n2v::walk_exact_wedge_slots_kernel<0>

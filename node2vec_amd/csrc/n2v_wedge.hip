@@ -154,13 +154,18 @@ __device__ __forceinline__ int wedge_wave(const int32_t *scol, int ds, const int
   return __builtin_amdgcn_readfirstlane(cnt);
 }
 
-template <typename P>
+// kWide 0: uint16 lists, 1: uint32 lists, 2: mixed -- uint32 for the edges into rows of `wide_from`
+// entries or more (offsets in units of the list's own width from the one base)
+template <int kWide>
 __global__ __launch_bounds__(256) void wedge_fill_kernel(n2v_graph g,
                                                         const uint64_t *list_off,  // may alias wedge_off (in-place use is allowed)
                                                         uint64_t *wedge_off,
-                                                        P *__restrict__ wedge_pos,
+                                                        void *__restrict__ wedge_pos_v,
+                                                        int wide_from,
                                                         uint32_t *__restrict__ status,
                                                         uint32_t *__restrict__ counter) {
+  uint16_t *pos16 = reinterpret_cast<uint16_t *>(wedge_pos_v);
+  uint32_t *pos32 = reinterpret_cast<uint32_t *>(wedge_pos_v);
   const int lane = threadIdx.x & 63;
   const int64_t n_edges = g.n_edges;
   const int64_t n_batches = (n_edges + kWEdgeBatch - 1) / kWEdgeBatch;
@@ -196,7 +201,13 @@ __global__ __launch_bounds__(256) void wedge_fill_kernel(n2v_graph g,
       }
       int got = 0, rpos = 0;
       const bool small = act && min(ds, dv) <= kWLaneMax;
-      if (small) got = wedge_lane<P>(g.col + sb, ds, g.col + vb, dv, s, wedge_pos + off, want, rpos);
+      const bool wide_e = kWide == 1 || (kWide == 2 && dv >= wide_from);
+      if (small) {
+        if (wide_e)
+          got = wedge_lane<uint32_t>(g.col + sb, ds, g.col + vb, dv, s, pos32 + off, want, rpos);
+        else
+          got = wedge_lane<uint16_t>(g.col + sb, ds, g.col + vb, dv, s, pos16 + off, want, rpos);
+      }
       uint64_t big = ballot64(act && !small);
       while (big != 0ull) {
         const int l = (int)__builtin_ctzll(big);
@@ -209,8 +220,11 @@ __global__ __launch_bounds__(256) void wedge_fill_kernel(n2v_graph g,
         const int want_l = __builtin_amdgcn_readlane(want, l);
         const int32_t s_l = __builtin_amdgcn_readlane(s, l);
         int rp = 0;
-        const int k = wedge_wave<P>(g.col + sb_l, ds_l, g.col + vb_l, dv_l, s_l, lane,
-                                    wedge_pos + off_l, want_l, rp);
+        int k;
+        if (kWide == 1 || (kWide == 2 && dv_l >= wide_from))  // (wave-uniform)
+          k = wedge_wave<uint32_t>(g.col + sb_l, ds_l, g.col + vb_l, dv_l, s_l, lane, pos32 + off_l, want_l, rp);
+        else
+          k = wedge_wave<uint16_t>(g.col + sb_l, ds_l, g.col + vb_l, dv_l, s_l, lane, pos16 + off_l, want_l, rp);
         if (lane == l) {
           got = k;
           rpos = rp;
@@ -240,16 +254,13 @@ extern "C" int n2v_wedge_build(const n2v_graph *g, const uint64_t *list_off, uin
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), st) != hipSuccess) return N2V_ELAUNCH;
   int64_t blocks = (n_batches + 3) / 4;
-  const void *fn = wide ? (const void *)n2v::wedge_fill_kernel<uint32_t>
-                        : (const void *)n2v::wedge_fill_kernel<uint16_t>;
-  const int64_t cap = n2v::resident_blocks(fn, 256, 0);
+  if (wide < 0 || wide > 65536) return N2V_EINVAL;
+  if (wide >= 2 && (reinterpret_cast<uintptr_t>(wedge_pos_out) & 3u) != 0) return N2V_EINVAL;
+  auto fn = wide == 0 ? n2v::wedge_fill_kernel<0> : wide == 1 ? n2v::wedge_fill_kernel<1> : n2v::wedge_fill_kernel<2>;
+  const int64_t cap = n2v::resident_blocks((const void *)fn, 256, 0);
   if (blocks > cap) blocks = cap;
-  if (wide)
-    hipLaunchKernelGGL(n2v::wedge_fill_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, st, *g,
-                       list_off, wedge_off_out, (uint32_t *)wedge_pos_out, status, status + 1);
-  else
-    hipLaunchKernelGGL(n2v::wedge_fill_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, st, *g,
-                       list_off, wedge_off_out, (uint16_t *)wedge_pos_out, status, status + 1);
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), 0, st, *g, list_off, wedge_off_out, wedge_pos_out,
+                     (int)wide, status, status + 1);
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
 }
@@ -260,6 +271,14 @@ __global__ __launch_bounds__(256) void wedge_slots_kernel(n2v_graph g, uint16_t 
   const uint16_t *pos = reinterpret_cast<const uint16_t *>(g.wedge_pos);
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < g.n_edges;
        e += (int64_t)gridDim.x * blockDim.x) {
+    if (g.wedge_wide >= 2) {  // mixed: an edge into a wide row has a uint32 list and no slot
+      const int32_t x = g.col[e];
+      if (g.rowptr[x + 1] - g.rowptr[x] >= (int64_t)g.wedge_wide) {
+        reinterpret_cast<int4 *>(slots + e * 16)[0] = make_int4(0, 0, 0, 0);
+        reinterpret_cast<int4 *>(slots + e * 16)[1] = make_int4(0, 0, 0, 0);
+        continue;
+      }
+    }
     const uint32_t ec = g.edge_classes[e];
     const uint64_t wraw = g.wedge_off[e];
     const uint64_t off = wraw & N2V_WEDGE_OFF_MASK;
@@ -316,8 +335,9 @@ __global__ __launch_bounds__(256) void wedge_slots_kernel(n2v_graph g, uint16_t 
 extern "C" int n2v_wedge_slots_build(const n2v_graph *g, uint16_t *slots_out, void *stream) {
   if (!g || g->n_edges < 0) return N2V_EINVAL;
   if (g->n_edges == 0) return N2V_OK;
-  if (!g->edge_classes || !g->wedge_off || !g->wedge_pos || g->wedge_wide || !slots_out)
+  if (!g->edge_classes || !g->wedge_off || !g->wedge_pos || g->wedge_wide == 1 || !slots_out)
     return N2V_EINVAL;
+  if (g->wedge_wide >= 2 && (!g->rowptr || !g->col || g->wedge_wide > 65536)) return N2V_EINVAL;
   if ((reinterpret_cast<uintptr_t>(slots_out) & 31u) != 0) return N2V_EINVAL;
   int64_t blocks = (g->n_edges + 255) / 256;
   const int64_t cap = 8 * n2v::resident_blocks((const void *)n2v::wedge_slots_kernel, 256, 0);

@@ -115,7 +115,7 @@ __device__ __forceinline__ StepFlags step_flags(const n2v_graph &g, const UnitCo
   f.need_mem = q != 1.0;
   f.always_pair = K.bO > 1.0;  // 1/q > 1: "other" overfull, an overfull `pick` has no quick exit
   f.merge_r = K.bR == K.bO;    // p == q: the return slot IS an "other" slot (:223-230)
-  f.w_wide = g.wedge_wide != 0;
+  f.w_wide = g.wedge_wide == 1;  // (a mixed table, wedge_wide >= 2: by the row, in wedge_step)
   f.inline_rpos = (g.reserved2 & N2V_HOPS_INLINE_RPOS) != 0;  // (the slots kernel's hop table only)
   return f;
 }
@@ -135,8 +135,25 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
                                           uint32_t *stage, int lane, uint32_t *status,
                                           uint16_t *lds_list = nullptr) {
   constexpr bool kShared = kMode == 1 || kMode == 2;
+  if constexpr (kSlots) {
+    // mixed wedge table (g.wedge_wide = T >= 2): the edges into a row of T entries or more have
+    // uint32 lists and no slot -- the step of a walker standing on such a row goes through wedge_off
+    // (a per-lane branch: the other lanes of the wave keep their slots)
+    if (g.wedge_wide >= 2 && n >= g.wedge_wide) {
+#if defined(N2V_ABLATE_WIDE) && N2V_ABLATE_WIDE == 1  // timing only: a wide step is a plain uniform draw
+      const int pk = pick_index(u1, n);
+      h = load_hop(g.hops + vb + pk);
+      return pk;
+#endif
+      StepFlags Fw = F;
+      Fw.w_wide = true;
+      return wedge_step<kMode, kJumpOnly, false>(g, K, Fw, u1, u2, s, vb, n, e_prev, ec_prev, h, stage, lane,
+                                                 status, nullptr);
+    }
+  }
   const int pick = pick_index(u1, n);
   int idx = pick;
+  const bool w_wide = F.w_wide || wedge_row_wide(g.wedge_wide, n);  // width of this step's list (!kSlots)
   // an edge without shared neighbours may carry its return position in the class word itself
   // (N2V_EC_INLINE, slots kernel only): its slot is then never fetched
   const bool inl = kSlots && F.inline_rpos && ec_prev != 0xffffffffu && (ec_prev & N2V_EC_INLINE) != 0u;
@@ -180,12 +197,12 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
     if constexpr (kSlots)
       lo_pick = slot_lower(sa, sb, nM, pick, reinterpret_cast<const uint16_t *>(g.wedge_pos), isM);
     else
-      lo_pick = wedge_lower(g.wedge_pos, w_off, nM, pick, F.w_wide, isM);
+      lo_pick = wedge_lower(g.wedge_pos, w_off, nM, pick, w_wide, isM);
   }
   const double r2 = (double)u2 * (1.0 / 4294967296.0);
   double avg;  // :172
   if constexpr (kMode == 2) {
-    static_assert(kSlots && !kJumpOnly, "values that are not dyadic: the slots kernel, replays inline");
+    static_assert(!kJumpOnly, "values that are not dyadic: replays inline");
     // the reference's sum is rounded at every addition; any order of the same positive addends
     // agrees with it to (n - 1) 2^-53 relatively, so an underfull `pick` whose acceptance clears
     // that margin is decided from the counts alone; otherwise the row is added up in the
@@ -202,42 +219,71 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
 #ifdef N2V_NEAR_COUNT
       atomicAdd(status + 2, 1u);
 #endif
-      if (!w_loaded) {  // an edge without shared neighbours whose step got here: its return position
-        sa = reinterpret_cast<const int4 *>(slot)[0];
-        sb = reinterpret_cast<const int4 *>(slot)[1];
-        w_loaded = true;
-      }
-      if (N2V_NEAR_FORMS) {
-        const uint16_t *nlist = slot + 2;
-        if (nM > kSlotShort)
-          nlist = reinterpret_cast<const uint16_t *>(g.wedge_pos) +
-                  ((uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32));
-        const int res = near_step<uint16_t>(n, pick, r2, K, nR, (int)((uint32_t)sa.x & 0xffffu), nM, nlist, isR,
-                                            isM, lo_pick, (int)((uint32_t)sa.x >> 16));
-        if (res >= 0) {
-          if (res != pick) h = load_hop(g.hops + vb + res);
-          return res;
+      if constexpr (kSlots) {
+        if (!w_loaded) {  // an edge without shared neighbours whose step got here: its return position
+          sa = reinterpret_cast<const int4 *>(slot)[0];
+          sb = reinterpret_cast<const int4 *>(slot)[1];
+          w_loaded = true;
         }
+        if (N2V_NEAR_FORMS) {
+          const uint16_t *nlist = slot + 2;
+          if (nM > kSlotShort)
+            nlist = reinterpret_cast<const uint16_t *>(g.wedge_pos) +
+                    ((uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32));
+          const int res = near_step<uint16_t>(n, pick, r2, K, nR, (int)((uint32_t)sa.x & 0xffffu), nM, nlist, isR,
+                                              isM, lo_pick, (int)((uint32_t)sa.x >> 16));
+          if (res >= 0) {
+            if (res != pick) h = load_hop(g.hops + vb + res);
+            return res;
+          }
 #ifdef N2V_NEAR_COUNT  // diagnostic build: steps past the quick accept ([2]) / declined by the closed forms ([3])
-        atomicAdd(status + 3, 1u);
+          atomicAdd(status + 3, 1u);
 #endif
+        }
+        const uint16_t *sum_list = slot + 2;
+        if (nM > kSlotShort) {
+          sum_list = reinterpret_cast<const uint16_t *>(g.wedge_pos) +
+                     ((uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32));
+        } else if (lds_list != nullptr) {
+          uint32_t *row = reinterpret_cast<uint32_t *>(lds_list);
+          row[0] = (uint32_t)sa.y;
+          row[1] = (uint32_t)sa.z;
+          row[2] = (uint32_t)sa.w;
+          row[3] = (uint32_t)sb.x;
+          row[4] = (uint32_t)sb.y;
+          row[5] = (uint32_t)sb.z;
+          row[6] = (uint32_t)sb.w;
+          sum_list = lds_list;
+        }
+        avg = lane_row_sum<uint16_t>(n, K, nR, (int)((uint32_t)sa.x & 0xffffu), nM, sum_list) / (double)n;
+      } else {
+        // through wedge_off (the wide rows of a mixed table): the same two stages on the list in memory
+        if (!w_loaded) {
+          wraw = g.wedge_off[e_prev];
+          w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
+          w_loaded = true;
+        }
+        const int rp = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
+        int res = -1;
+        if (N2V_NEAR_FORMS) {
+          if (w_wide)
+            res = near_step<uint32_t>(n, pick, r2, K, nR, rp, nM,
+                                      reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off, isR, isM, lo_pick, -1);
+          else
+            res = near_step<uint16_t>(n, pick, r2, K, nR, rp, nM,
+                                      reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off, isR, isM, lo_pick, -1);
+          if (res >= 0) {
+            if (res != pick) h = load_hop(g.hops + vb + res);
+            return res;
+          }
+        }
+        double sum;
+        if (w_wide)
+          sum = lane_row_sum<uint32_t>(n, K, nR, rp, nM, reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off);
+        else
+          sum = lane_row_sum<uint16_t>(n, K, nR, rp, nM, reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off);
+        avg = sum / (double)n;
       }
-      const uint16_t *sum_list = slot + 2;
-      if (nM > kSlotShort) {
-        sum_list = reinterpret_cast<const uint16_t *>(g.wedge_pos) +
-                   ((uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32));
-      } else if (lds_list != nullptr) {
-        uint32_t *row = reinterpret_cast<uint32_t *>(lds_list);
-        row[0] = (uint32_t)sa.y;
-        row[1] = (uint32_t)sa.z;
-        row[2] = (uint32_t)sa.w;
-        row[3] = (uint32_t)sb.x;
-        row[4] = (uint32_t)sb.y;
-        row[5] = (uint32_t)sb.z;
-        row[6] = (uint32_t)sb.w;
-        sum_list = lds_list;
-      }
-      avg = lane_row_sum<uint16_t>(n, K, nR, (int)((uint32_t)sa.x & 0xffffu), nM, sum_list) / (double)n;
     }
   } else {
     const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
@@ -245,6 +291,9 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
   }
   const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) / avg;  // :173
   if (p_pick < 1.0 && r2 < p_pick) return idx;  // an accepted underfull slot is final
+#if defined(N2V_ABLATE_WIDE) && N2V_ABLATE_WIDE == 2  // timing only: a wide step never pairs
+  if (!kSlots) return idx;
+#endif
   // underfull / overfull by class without dividing: fl(b / avg) < 1.0 <=> b < avg
   const bool uR = K.bR < avg, uM = K.bM < avg, uO = K.bO < avg;
   const bool any_under = (nR && uR) || (nM && uM) || (nO && uO);
@@ -312,7 +361,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
       }
     } else if constexpr (kJumpOnly) {
       // a plain branch on the (uniform) list width: never a select between two loads
-      if (F.w_wide)
+      if (w_wide)
         idx = jump_listed<uint32_t, kMode>(arr, n, pick, r2, K, nR, w_rpos, nM,
                                            reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off,
                                            isR, isM, lo_pick);
@@ -322,7 +371,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
                                            isR, isM, lo_pick);
       if (idx < 0) return -1;
     } else {
-      if (F.w_wide)
+      if (w_wide)
         idx = pair_listed<uint32_t, kMode>(arr, n, pick, r2, K, avg, nR, w_rpos, nM,
                                            reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off,
                                            isR, isM, lo_pick, stage, lane);

@@ -319,6 +319,9 @@ class Node2VecHIP(Node2VecBase):
                 batch_words=None if split else int(p.get("batch_words") or 0) or None)
         torch.cuda.synchronize(dev)
         p["negative"] = negative
+        # what the trainer really ran with (hub_rows None = chosen from the corpus: recorded, so that a
+        # parity run can pin it -- hub_rows = 0 is gensim's code as written)
+        p["hub_rows"], p["hub_rows_auto"], p["hub_waves"] = m.hub_rows, m.hub_rows_auto, m.hub_waves
         # the matrices stay in HBM and the tokens stay integer ids (lazy strings): at cfg 4 the
         # host copies would be 2 x 51 GB + 10^8 Python strings that most callers never read
         self.model = HipW2V(KeyedVectors(vocab.ids, m.syn0), m.syn1neg, p, int(m.pairs.item()))

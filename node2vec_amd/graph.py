@@ -84,6 +84,7 @@ class DeviceGraph:
         self.hops8_tried = False
         self.wedge_off: Optional[torch.Tensor] = None  # int64 [E]: list offset | return position << 40
         self.wedge_pos: Optional[torch.Tensor] = None  # int16 / int32 [sum of shared counts]
+        self.wedge_mode = 0  # n2v_graph.wedge_wide: 0 16-bit lists, 1 32-bit, T >= 2 mixed (build_wedges)
         self.wedge_tried = False  # randomwalk.walk tries to build the table once
         self.wedge_slots: Optional[torch.Tensor] = None  # int16 [E, 16]: n2v_wedge_slots_build
         self.hops_inline_rpos = False  # the hop table's class words carry return positions (slots kernel)
@@ -195,6 +196,7 @@ class DeviceGraph:
         # a declined build (escape share, memory budget) stays declined on the copy
         g.hops8_tried, g.wedge_tried, g.rank_tried = self.hops8_tried, self.wedge_tried, self.rank_tried
         g.hops_inline_rpos = self.hops_inline_rpos
+        g.wedge_mode = self.wedge_mode
         return g
 
     def c_struct(self) -> _lib.Graph:
@@ -209,7 +211,7 @@ class DeviceGraph:
                           0 if self.hops is None else self.hops.data_ptr(),
                           0 if self.wedge_off is None else self.wedge_off.data_ptr(),
                           0 if self.wedge_pos is None else self.wedge_pos.data_ptr(),
-                          0 if self.wedge_pos is None else int(self.wedge_pos.dtype == torch.int32), 0,
+                          0 if self.wedge_pos is None else self.wedge_mode, 0,
                           0 if self.hops8 is None else self.hops8.data_ptr(),
                           self.hops8_bits[0], self.hops8_bits[1],
                           0 if self.hops8_rowptr is None else self.hops8_rowptr.data_ptr(),
@@ -290,16 +292,25 @@ class DeviceGraph:
         self.edge_classes = ec
         return self
 
+    WEDGE_WIDE_FROM = 65536  # rows of this many entries or more need 32-bit positions
+
     def build_wedges(self, max_bytes: Optional[int] = None, wide: Optional[bool] = None,
-                     slots: bool = True) -> "DeviceGraph":
+                     slots: bool = True, wide_from: Optional[int] = None) -> "DeviceGraph":
         """Shared-position lists (n2v_wedge_build): for every edge (s -> v) the positions in
         N(v) of the neighbours v shares with s -- what generate_edge_alias_tables recomputes by a
         set intersection at every step (randomwalk.py:226), stored once.  8 bytes per edge + 2
-        (4 when some degree >= 65536) per (edge, common neighbour) pair; `max_bytes` (default:
-        half of the free device memory) bounds it -- a graph with more triangles than that
-        walks without the lists (same bits, slower on the steps that need the pairing).  With
-        16-bit positions and room for 32 more bytes per edge the wedge slots are built as well
-        (build_wedge_slots)."""
+        per (edge, common neighbour) pair; `max_bytes` (default: half of the free device memory)
+        bounds it -- a graph with more triangles than that walks without the lists (same bits,
+        slower on the steps that need the pairing).  With room for 32 more bytes per edge the
+        wedge slots are built as well (build_wedge_slots).
+
+        Rows of 65 536 entries or more (the reference's own trim cap is 100 000, constants.py:6) need
+        32-bit positions.  Only the lists of the edges INTO such a row are widened ("mixed" table,
+        n2v_graph.wedge_wide = 65536): they lie, 4 bytes per entry, behind the 16-bit lists of all
+        other edges, and a walker standing on a wide row reads them through wedge_off -- every
+        other step keeps the 16-bit lists and the wedge slots.  `wide=True` forces 32-bit positions
+        for every list (no slots: what partitioned walking slices); `wide_from` (tests) lowers
+        the row length from which lists are widened."""
         L = _lib.load()
         _lib.require_gpu()
         if not self.unit_weights:
@@ -307,30 +318,52 @@ class DeviceGraph:
         if self.edge_classes is None:
             self.build_edge_classes()
         self.wedge_off = self.wedge_pos = self.wedge_slots = None
+        self.wedge_mode = 0
         if self.n_edges == 0 or int(self.degrees().max()) >= self.HOP_MAX_DEGREE:
             return self
         counts = (self.edge_classes & 0xffffff).to(torch.int64)
         if bool((counts == 0xffffff).any()) or bool((((self.edge_classes >> 24) & 0xff) == 0xff).any()):
             return self  # a saturated count (16 M shared or 255 parallel return edges): no lists
         total = int(counts.sum())
-        wide = bool(wide) or int(self.degrees().max()) >= 65536  # `wide=True` forces 32-bit positions
-        need = 8 * self.n_edges + total * (4 if wide else 2)
+        deg = self.degrees()
+        t_from = int(wide_from) if wide_from else self.WEDGE_WIDE_FROM
+        if not 2 <= t_from <= 65536:
+            raise ValueError("wide_from: 2 .. 65536")
+        mode = 1 if wide else (t_from if int(deg.max()) >= t_from else 0)
+        total_wide = 0
+        wide_e = None
+        if mode >= 2:
+            wide_e = (deg >= t_from)[self.col.long()]  # edges into a wide row
+            total_wide = int(counts[wide_e].sum())
+        need = 8 * self.n_edges + (total * 4 if mode == 1 else (total - total_wide) * 2 + total_wide * 4 + 4)
         if max_bytes is None:
             max_bytes = torch.cuda.mem_get_info(self.device)[0] // 2
         if need > max_bytes or total >= (1 << 40):
             return self
-        off = torch.cumsum(counts, 0) - counts  # exclusive prefix sum; becomes wedge_off in place
-        del counts
-        pos = torch.empty(max(total, 1), dtype=torch.int32 if wide else torch.int16, device=self.device)
+        if mode >= 2:
+            # the 16-bit lists first (offsets in 2-byte units), then the 32-bit lists of the edges into
+            # wide rows (offsets in 4-byte units from the same base)
+            c16 = torch.where(wide_e, torch.zeros_like(counts), counts)
+            off = torch.cumsum(c16, 0) - c16
+            base32 = (total - total_wide + 1) // 2
+            c32 = counts - c16
+            off32 = torch.cumsum(c32, 0) - c32 + base32
+            off = torch.where(wide_e, off32, off)
+            del c16, c32, off32
+            pos = torch.empty(2 * (base32 + max(total_wide, 1)), dtype=torch.int16, device=self.device)
+        else:
+            off = torch.cumsum(counts, 0) - counts  # exclusive prefix sum; becomes wedge_off in place
+            pos = torch.empty(max(total, 1), dtype=torch.int32 if mode == 1 else torch.int16, device=self.device)
+        del counts, wide_e
         status = torch.zeros(4, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             rc = L.n2v_wedge_build(self.c_struct(), off.data_ptr(), off.data_ptr(), pos.data_ptr(),
-                                   int(wide), status.data_ptr(), _lib.current_stream_ptr())
+                                   mode, status.data_ptr(), _lib.current_stream_ptr())
         _lib.check(rc, "n2v_wedge_build")
         if int(status[0].item()) & _lib.ST_RANGE:
             raise RuntimeError("n2v_wedge_build: list lengths disagree with edge_classes")
-        self.wedge_off, self.wedge_pos = off, pos
-        if slots and not wide and need + 32 * self.n_edges <= max_bytes:
+        self.wedge_off, self.wedge_pos, self.wedge_mode = off, pos, mode
+        if slots and mode != 1 and need + 32 * self.n_edges <= max_bytes:
             self.build_wedge_slots()
         return self
 
@@ -342,7 +375,7 @@ class DeviceGraph:
         and list (DESIGN.md "K2 exact, biased").  Needs the wedge table with 16-bit positions."""
         L = _lib.load()
         self.wedge_slots = None
-        if self.wedge_off is None or self.wedge_pos is None or self.wedge_pos.dtype != torch.int16:
+        if self.wedge_off is None or self.wedge_pos is None or self.wedge_mode == 1:
             return self
         slots = torch.empty((self.n_edges, 16), dtype=torch.int16, device=self.device)
         with torch.cuda.device(self.device):
@@ -358,7 +391,7 @@ class DeviceGraph:
         with 16-bit positions and wedge slots at hand, every return count below 128"""
         if self.edge_classes is None or self.wedge_off is None or self.wedge_slots is None:
             return False
-        if self.wedge_pos is None or self.wedge_pos.dtype != torch.int16:
+        if self.wedge_pos is None or self.wedge_mode == 1:
             return False
         if self._inline_ok is None or self._inline_ok[0] is not self.edge_classes:
             # one pass over the class words and a host sync: once per table, not per walk() call

@@ -88,7 +88,15 @@ def partition_graph(g: DeviceGraph, n_parts: int, balance: str = "edges",
         if g.wedge_off is None and not g.wedge_tried:
             g.wedge_tried = True
             g.build_wedges()
-        if g.wedge_off is not None:
+        if g.wedge_off is not None and g.wedge_mode >= 2:
+            # a mixed table (16-bit lists, then the 32-bit lists of the edges into wide rows) cannot be
+            # cut by edge ranges: the parts of a graph with such rows keep 32-bit lists throughout
+            gw = DeviceGraph(g.rowptr, g.col, None)
+            gw.edge_classes = g.edge_classes
+            gw.build_wedges(wide=True, slots=False)
+            if gw.wedge_off is not None:
+                tables = (gw.edge_classes, gw.wedge_off, gw.wedge_pos)
+        elif g.wedge_off is not None:
             tables = (g.edge_classes, g.wedge_off, g.wedge_pos)
     V = g.n_vertices
     if balance == "edges" and g.n_edges > 0:

@@ -165,7 +165,11 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
     batch_words = int(p.get("batch_words") or 0)
     for ep in range(epochs):
         # gensim's schedule: the rate of a job of batch_words words (constants.py:58); rows of the
-        # virtual corpus are sentences in order (dropped walkers keep their row: they train nothing)
+        # virtual corpus are sentences in order.  A dropped walker (a sink was reached: valid = 0) keeps
+        # its row and trains nothing, where gensim's corpus would not contain it at all: on a graph WITH
+        # sinks the job boundaries and `pushed / total` therefore count those empty rows and the rates
+        # drift from gensim's by the share of dropped rows; on graphs without sinks (every symmetrised
+        # graph: all BASELINE configs) the schedule is gensim's exactly.
         sched = None
         if batch_words and parts_per_row == 1:
             sched = sgns.JobSchedule.for_corpus(batch_words, L + 1, rows_rank_max, ep, epochs, alpha, min_alpha)
@@ -197,6 +201,10 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
         timings.update(walk_s=t_walk, train_s=t_train, batches=n_batches, epochs=epochs,
                        rows_this_rank=n_start * W, world=world)
     p["negative"] = negative
+    # what the trainer really ran with (hub_rows None = chosen from the corpus: recorded)
+    p["hub_rows"], p["hub_rows_auto"], p["hub_waves"] = model.hub_rows, model.hub_rows_auto, model.hub_waves
+    if timings is not None:
+        timings.update(hub_rows=model.hub_rows, hub_rows_auto=model.hub_rows_auto, hub_waves=model.hub_waves)
     # device-backed result: no host copy of the matrices, integer ids instead of token strings
     out = HipW2V(KeyedVectors(vocab.ids, model.syn0), model.syn1neg, p, int(model.pairs.item()))
     return (out, model) if return_model else out

@@ -173,15 +173,31 @@ class SgnsModel:
         # hogwild: atomic adds instead of stores on rows [0, hub_rows), the most frequent words.
         # None = chosen from the corpus (auto_hub_rows); 0 = plain stores everywhere (gensim's code)
         self.hub_rows: Optional[int] = None
+        self.hub_rows_auto = False  # True once auto_hub_rows chose hub_rows (with hub_waves waves in flight)
+        self.hub_waves: Optional[int] = None
         self.ns_exponent = float(ns_exponent)
         self._counters = torch.zeros(2, dtype=torch.int64, device=device)
         self.pairs = self._counters[:1]
         self.sentences_seen = 0
 
-    HOGWILD_WAVES = 8192  # what the chip keeps resident (n2v_sgns_train's cap: 256 CUs x 32 waves)
     HUB_LAMBDA = 1.5      # rows held by at least this many waves on average are updated atomically
 
-    def auto_hub_rows(self) -> int:
+    def hogwild_waves(self, rows: int, length: int) -> int:
+        """the waves n2v_sgns_train keeps in flight for a launch of `rows` sentences of `length`
+        tokens on THIS device with this model's parameters -- asked of the library
+        (n2v_sgns_hogwild_waves: its concurrency rule, max_waves and the kernel's occupancy), not
+        assumed (8 192 on an MI355X at dim 128)"""
+        L = _lib.load()
+        P = _lib.SgnsParams(len(self.vocab), 0, self.seed, self.dim, self.window, self.negative, 0.025, 0,
+                            self.cum_index_bits, 0 if self.cum_index is None else self.cum_index.data_ptr(),
+                            int(self.max_waves), 0, int(self.window_cache), 0, 0)
+        with torch.cuda.device(self.syn0.device):
+            w = int(L.n2v_sgns_hogwild_waves(P, int(rows), int(length)))
+        if w < 0:
+            _lib.check(w, "n2v_sgns_hogwild_waves")
+        return max(w, 1)
+
+    def auto_hub_rows(self, rows: int = 1 << 30, length: int = 81) -> int:
         """How many of the most frequent rows to update by atomic adds so that the trainer's
         concurrency regime is the reference's.  gensim runs <= 16 unsynchronised threads
         (constants.py:67 `workers`, embedding.py:126): a row is practically never held by two of
@@ -199,18 +215,17 @@ class SgnsModel:
         cost.  Opt-in kernels (batched) keep 0."""
         if self.batched:
             return 0
-        n = len(self.vocab)
-        waves = min(self.HOGWILD_WAVES, max(1, n // 32))
-        if self.max_waves > 0:
-            waves = min(waves, int(self.max_waves))
+        waves = self.hogwild_waves(rows, length)  # (of the launch the rule is applied to: the first)
+        self.hub_waves = waves
         c = self.vocab.counts.to(torch.float64)
         pw = c.pow(self.ns_exponent)
         lam = waves * (c / c.sum() + self.negative * pw / pw.sum())
         return int((lam >= self.HUB_LAMBDA).sum().item())
 
-    def _hub_rows(self) -> int:
+    def _hub_rows(self, rows: int, length: int) -> int:
         if self.hub_rows is None:
-            self.hub_rows = self.auto_hub_rows()
+            self.hub_rows = self.auto_hub_rows(rows, length)
+            self.hub_rows_auto = True
         return int(self.hub_rows)
 
     # -- one kernel launch ----------------------------------------------------
@@ -237,7 +252,8 @@ class SgnsModel:
         P = _lib.SgnsParams(len(self.vocab), int(sentence_base), self.seed, self.dim, self.window,
                             self.negative, float(alpha), int(bool(deterministic)),
                             self.cum_index_bits, 0 if self.cum_index is None else self.cum_index.data_ptr(),
-                            int(self.max_waves), int(bool(self.batched)), int(self.window_cache), self._hub_rows(),
+                            int(self.max_waves), int(bool(self.batched)), int(self.window_cache),
+                            self._hub_rows(walks_idx.shape[0], walks_idx.shape[1]),
                             0 if row_alpha is None else row_alpha.data_ptr())
         with torch.cuda.device(walks_idx.device):
             rc = L.n2v_sgns_train(walks_idx.data_ptr(), walks_idx.shape[0], walks_idx.shape[1],
@@ -255,7 +271,8 @@ class SgnsModel:
               rows_global_max: Optional[int] = None, batch_words: Optional[int] = None):
         """`epochs` passes over walks_idx; the learning rate falls linearly from alpha to
         min_alpha.  With `batch_words` (gensim's parameter; the reference passes 1000,
-        constants.py:58) it falls exactly as gensim lowers it: per job of
+        constants.py:58) it falls as gensim lowers it (exactly so when every row is a sentence; rows
+        of dropped walkers count as empty sentences here, gensim's corpus would not hold them): per job of
         max(1, batch_words // sentence length) consecutive sentences (JobSchedule); without, once
         per launch with the fraction of rows trained.
 

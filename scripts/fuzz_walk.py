@@ -73,6 +73,9 @@ while time.time() - t0 < budget:
     if len(src) == 0:
         continue
     g = DeviceGraph.from_edges(src, dst, w, n_vertices=nv, device="cuda")
+    # mixed wedge table: the lists of the edges into rows of this many entries or more are 32-bit and
+    # have no slot (production: 65536) -- lowered here so that small graphs have such rows
+    g.WEDGE_WIDE_FROM = int(rng.choice([65536, 65536, 2, 8, 64, 700]))
     # FUZZ_PQ=extreme: very small / very large and non-dyadic parameters
     if os.environ.get("FUZZ_PQ") == "extreme":
         vals = [0.001, 0.01, 0.03125, 0.03, 1.0 / 3.0, 0.999, 1.001, 16.0, 37.5, 100.0, 1000.0, 1024.0]
@@ -139,7 +142,8 @@ while time.time() - t0 < budget:
     if not ok:
         bad = np.nonzero((got.cpu().numpy() != want).any(1) | (gv.cpu().numpy() != wv))[0][:5]
         print("MISMATCH", dict(kind=kind, nv=nv, ne=len(src), weights=wk, p=p, q=q, nw=nw, wl=wl, seed=seed,
-                               maxdeg=int(deg.max()), unit=g.unit_weights, edge_classes=uec), "rows", bad.tolist(), flush=True)
+                               maxdeg=int(deg.max()), unit=g.unit_weights, edge_classes=uec,
+                               wide_from=g.WEDGE_WIDE_FROM, wedge_mode=g.wedge_mode), "rows", bad.tolist(), flush=True)
         for r in bad[:2]:
             print(" got ", got[r].tolist()[:12], "\n want", want[r].tolist()[:12])
         sys.exit(1)

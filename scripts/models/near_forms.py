@@ -3,7 +3,9 @@
 loop of generate_alias_tables (reference randomwalk.py:157-190, restated in ref_tables: Python floats,
 left-to-right sum) on random rows of the three class values: `python near_forms.py` (short rows),
 `python near_forms.py big` (long rows); N2V_MODEL_TRIALS overrides the number of rows.  Every slot of every
-row is asked for with a random r2.  Prints how many draws the forms decided, how many they left to the replay
+row is asked for with a random r2.  `python near_forms.py adversarial`: EVERY (return run, shared subset)
+composition of the rows of n <= N2V_MODEL_NMAX (default 6) slots x twelve (p, q), then random rows of up to
+120 slots, every slot, with r2 on the nine u / 2^32 grid points around the reference's own probs[pick].  Prints how many draws the forms decided, how many they left to the replay
 ("ambiguous") and the mismatch count (must be 0)."""
 import math
 import os
@@ -283,17 +285,36 @@ def near_step(n, cls, pick, r2, b):
     return None if f is None else f(G, pick, r2, V, mg, pickR, pickM, lo_pick)
 
 
-random.seed(int(os.environ.get("N2V_MODEL_SEED", 7)))
-big = len(sys.argv) > 1 and sys.argv[1] == "big"
-VALS = [0.7, 1.3, 3.0, 0.3, 1.5, 6.0, 0.75, 1.0 / 3.0, 2.0 / 3.0, 5.0, 0.2, 0.6, 1.2, 2.5, 7.0, 1.0 / 7.0, 10.0, 0.1, 37.5, 1.0]
-rows = draws = amb = bad = 0
-by_arr = {}
-trials = int(os.environ.get("N2V_MODEL_TRIALS", 3000 if not big else 150))
-while rows < trials:
-    n = random.randint(200, 2500) if big else random.randint(1, 70)
-    p, q = random.choice(VALS), random.choice(VALS)
-    if all((1.0 / x) == 2.0 ** round(math.log2(1.0 / x)) for x in (p, q)): continue  # (dyadic: the other forms)
-    b = {'R': 1.0 / p, 'M': 1.0, 'O': 1.0 / q}
+def check_row(n, cls, b, picks, adversarial, stats):
+    """every slot of `picks` of one row against the reference's loop.  adversarial: r2 on the nine
+    u / 2^32 grid points around the reference's own probs[pick] -- the draws a random r2 never
+    hits, where the decision  r2 < probs[pick]  is as close as the uniform stream allows"""
+    w = [b[c] for c in cls]
+    alias, probs = ref_tables(w)
+    avg = sum(w) / n
+    for pick in picks:
+        if adversarial:
+            u0 = int(math.floor(probs[pick] * 2.0 ** 32))
+            r2s = [min(max(u0 + d, 0), 2 ** 32 - 1) / 2 ** 32 for d in range(-4, 5)]
+        else:
+            r2s = [random.getrandbits(32) / 2 ** 32]
+        for r2 in r2s:
+            p0 = w[pick] / avg
+            if p0 < 1.0 and r2 < p0: continue  # the quick accept (the kernel's own margin test comes first)
+            want = pick if r2 < probs[pick] else alias[pick]
+            got = near_step(n, cls, pick, r2, b)
+            stats[0] += 1
+            if got is None: stats[1] += 1
+            elif got != want:
+                stats[2] += 1
+                if stats[2] < 6: print("MISMATCH", n, b, ''.join(cls) if n < 100 else "", pick, r2, want, got)
+
+
+def dyadic_pq(p, q):
+    return all((1.0 / x) == 2.0 ** round(math.log2(1.0 / x)) for x in (p, q))
+
+
+def random_row(n, p, q):
     cls = ['O'] * n
     nR = random.choice([0, 1, 1, 1, 2, 3]) if n > 3 else random.choice([0, 1])
     rp = random.randint(0, n - nR)
@@ -303,20 +324,60 @@ while rows < trials:
         if cls[i] == 'O' and random.random() < dens: cls[i] = 'M'
     if q == 1.0: cls = [c if c != 'M' else 'O' for c in cls]  # need_mem false: no listed slots
     if p == q: cls = [c if c != 'R' else 'O' for c in cls]    # merge_r: the return slot IS an "other" slot
-    w = [b[c] for c in cls]
-    alias, probs = ref_tables(w)
-    avg = sum(w) / n
-    rows += 1
-    for pick in (range(n) if not big else random.sample(range(n), 60)):
-        r2 = random.getrandbits(32) / 2 ** 32
-        p0 = w[pick] / avg
-        if p0 < 1.0 and r2 < p0: continue  # the quick accept (the kernel's own margin test comes first)
-        want = pick if r2 < probs[pick] else alias[pick]
-        got = near_step(n, cls, pick, r2, b)
-        draws += 1
-        if got is None: amb += 1
-        elif got != want:
-            bad += 1
-            if bad < 6: print("MISMATCH", n, p, q, ''.join(cls) if n < 100 else "", pick, r2, want, got)
-print("total", draws, "ambiguous", amb, "bad", bad)
-sys.exit(1 if bad else 0)
+    return cls
+
+
+def compositions(n):
+    """every row of n slots: a return run (0 .. n consecutive slots anywhere) and any subset of the
+    remaining slots shared"""
+    runs = [(0, 0)] + [(rp, k) for k in range(1, n + 1) for rp in range(0, n - k + 1)]
+    for rp, k in runs:
+        rest = [i for i in range(n) if not (rp <= i < rp + k)]
+        for mask in range(1 << len(rest)):
+            cls = ['O'] * n
+            for i in range(rp, rp + k): cls[i] = 'R'
+            for j, i in enumerate(rest):
+                if mask >> j & 1: cls[i] = 'M'
+            yield cls
+
+
+random.seed(int(os.environ.get("N2V_MODEL_SEED", 7)))
+mode = sys.argv[1] if len(sys.argv) > 1 else "short"
+big = mode == "big"
+VALS = [0.7, 1.3, 3.0, 0.3, 1.5, 6.0, 0.75, 1.0 / 3.0, 2.0 / 3.0, 5.0, 0.2, 0.6, 1.2, 2.5, 7.0, 1.0 / 7.0, 10.0, 0.1, 37.5, 1.0]
+stats = [0, 0, 0]  # draws, left to the replay, wrong
+rows = 0
+if mode == "adversarial":
+    # (VERDICT r4, item 7b) every (return run, shared subset) composition of the rows of n <= NMAX slots x
+    # twelve (p, q) that are not dyadic, then random rows of up to 120 slots, every slot, adversarial r2
+    PQ = [(0.7, 3.0), (3.0, 0.7), (1.3, 1.3), (0.3, 0.7), (3.0, 1.0), (1.0 / 3.0, 2.0 / 3.0), (1.5, 6.0), (6.0, 1.5),
+          (0.75, 1.2), (5.0, 0.2), (7.0, 1.0 / 7.0), (37.5, 0.6)]
+    nmax = int(os.environ.get("N2V_MODEL_NMAX", 6))
+    for n in range(1, nmax + 1):
+        for cls0 in compositions(n):
+            for p, q in PQ:
+                cls = list(cls0)
+                if q == 1.0: cls = [c if c != 'M' else 'O' for c in cls]
+                check_row(n, cls, {'R': 1.0 / p, 'M': 1.0, 'O': 1.0 / q}, range(n), True, stats)
+                rows += 1
+    trials = int(os.environ.get("N2V_MODEL_TRIALS", 600))
+    k = 0
+    while k < trials:
+        n = random.randint(1, 120)
+        p, q = random.choice(VALS), random.choice(VALS)
+        if dyadic_pq(p, q): continue
+        check_row(n, random_row(n, p, q), {'R': 1.0 / p, 'M': 1.0, 'O': 1.0 / q}, range(n), True, stats)
+        k += 1; rows += 1
+else:
+    trials = int(os.environ.get("N2V_MODEL_TRIALS", 3000 if not big else 150))
+    while rows < trials:
+        n = random.randint(200, 2500) if big else random.randint(1, 70)
+        p, q = random.choice(VALS), random.choice(VALS)
+        if dyadic_pq(p, q): continue  # (dyadic: the other forms)
+        cls = random_row(n, p, q)
+        check_row(n, cls, {'R': 1.0 / p, 'M': 1.0, 'O': 1.0 / q},
+                  range(n) if not big else random.sample(range(n), 60), False, stats)
+        rows += 1
+print("rows", rows)
+print("total", stats[0], "ambiguous", stats[1], "bad", stats[2])
+sys.exit(1 if stats[2] else 0)

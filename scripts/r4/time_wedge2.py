@@ -10,15 +10,17 @@ if os.environ.get("N2V_VARIANT_LIB"):
 from node2vec_amd import synthetic, randomwalk as rw
 label = sys.argv[1] if len(sys.argv) > 1 else ""
 cfg = os.environ.get("GRAPH", "cfg4")
+TRIM = int(os.environ.get("TRIM", 10_000))  # 100000 = the reference's default cap (constants.py:6)
 if cfg == "cfg4":
-    g = synthetic.chung_lu(100_000_000, 500_000_000, device="cuda").trimmed(10_000, 42)
+    g = synthetic.chung_lu(100_000_000, 500_000_000, device="cuda").trimmed(TRIM, 42)
 elif cfg == "cfg3":
-    g = synthetic.chung_lu(10_000_000, 100_000_000, device="cuda").trimmed(10_000, 42)
+    g = synthetic.chung_lu(10_000_000, 100_000_000, device="cuda").trimmed(TRIM, 42)
 elif cfg == "cfg5":
     g = synthetic.hub_bipartite(50_000_000, 5000, 10_000, device="cuda")
 else:
     g = synthetic.rmat(20, 5_000_000, device="cuda")
 start = rw.start_vertices(g)
+print(f"{label}: {cfg} trim {TRIM}: {g.n_edges} edges, max degree {int(g.degrees().max())}", flush=True)
 b = min(int(os.environ.get("BATCH", 1 << 20)), start.numel())
 nb = max(1, start.numel() // b)
 walks = torch.empty((b * 10, 81), dtype=torch.int32, device="cuda")
@@ -39,6 +41,10 @@ for pq in os.environ.get("PQ", "0.5,2.0").split(";"):
         return (time.perf_counter() - t0) / reps
 
     dt = timed(False)
+    if pq == os.environ.get("PQ", "0.5,2.0").split(";")[0]:
+        deg = g.degrees()
+        print(f"{label}: wedge_mode {g.wedge_mode}, slots {g.wedge_slots is not None}, share of edges into rows >= 65536: "
+              f"{float(deg[deg >= 65536].sum()) / g.n_edges:.4f}", flush=True)
     print(f"{label}: {cfg} p={P_} q={Q_} batch {b} one-launch {b * 800 / dt / 1e9:.2f} G steps/s ({dt * 1e3:.2f} ms)", flush=True)
     run(3, False, ref); torch.cuda.synchronize()
     if g.wedge_slots is not None:

@@ -28,6 +28,21 @@ def test_model_agrees_with_the_reference_loop(name, rows):
     assert int(last.split()[1]) > 0  # rows were really drawn
 
 
+def test_closed_forms_with_margins_on_adversarial_draws():
+    """near_forms.py adversarial: every (return run, shared subset) composition of
+    the rows of n <= 6 slots x twelve (p, q) that are not dyadic + random rows of up to 120 slots, every
+    slot, r2 on the nine u / 2^32 grid points around the reference's own probs[pick] -- the draws where
+    r2 < probs[pick] is as close as the uniform stream allows.  The forms may decline; they must never
+    be wrong.  (n <= 7 and 3 000 rows: profiles/r7_near_model_adversarial.log, 1.96 M draws.)"""
+    env = dict(os.environ, N2V_MODEL_NMAX="6", N2V_MODEL_TRIALS="600")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "models", "near_forms.py"), "adversarial"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    last = res.stdout.strip().splitlines()[-1].split()
+    assert last[0] == "total" and last[-2:] == ["bad", "0"]
+    assert int(last[1]) > 400_000 and int(last[3]) < int(last[1])  # many draws, not all declined
+
+
 def test_a_class_exactly_on_the_average_model():
     """lane_case_b2_jump on rows whose "other" slots have excess 0 (scripts/models/flat_b2.py)"""
     env = dict(os.environ, N2V_MODEL_TRIALS="4000")

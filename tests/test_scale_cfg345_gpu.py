@@ -65,6 +65,18 @@ def _check_config(oracle, g, start, p, q, seed, n_oracle, n_hubs, oracle_len):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+def _oracle_sample(oracle, g, start, p, q, seed, n_oracle, n_hubs, oracle_len):
+    """the oracle sample alone (the biggest hubs included), for one (p, q)"""
+    from node2vec_amd import randomwalk as rw
+
+    sample = _sample_with_hubs(g, start, n_oracle, n_hubs, seed)
+    got, gv = rw.walk(g, sample, W, oracle_len, p, q, seed)
+    want, wv = oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), None,
+                                  sample.cpu().numpy(), W, oracle_len, p, q, seed, n_threads=16)
+    assert np.array_equal(gv.cpu().numpy(), wv), (p, q)
+    assert np.array_equal(got.cpu().numpy(), want), (p, q)
+
+
 # one (p, q) per code instance of the all-tables kernel (n2v_walk_wedge.hip): <0> "other" alone
 # underfull, <1> the return run shares its stack, <2> not dyadic, <3> "other" alone overfull
 INSTANCE_PQ = ((0.5, 2.0), (4.0, 2.0), (3.0, 0.7), (4.0, 0.25))
@@ -122,6 +134,35 @@ def test_cfg3_power_law_10m_trimmed(oracle):
     assert full_batch_differential(g, start_all[: 1 << 20].contiguous()) == 4 * (1 << 20) * W * L
 
 
+def test_cfg3_trimmed_at_the_reference_default_cap(oracle):
+    """cfg 3 trimmed at 100 000 -- the reference's own default cap (constants.py:6, randomwalk.py:252-253)
+    where every other test and the bench trim at 10 000 (examples/fugue_spark.py:47).  Rows of 65 536
+    entries or more need 32-bit positions: the wedge table is MIXED (only the lists of the edges into
+    those rows are widened), the wedge slots and the closed-form kernel stay.  A full
+    bench batch through the slots kernel == the same through wedge_off == the replay kernels == the
+    table-free kernel, and a sample that includes the widest rows == the oracle."""
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd import synthetic
+
+    g = synthetic.chung_lu(10_000_000, 100_000_000, seed=42, device="cuda").trimmed(0, 42)  # 0 -> 100 000
+    deg = g.degrees()
+    assert int(deg.max()) == 100_000 and int((deg >= 65536).sum()) >= 2
+    start_all = rw.start_vertices(g)
+    batch = start_all[: 1 << 20].contiguous()
+    assert full_batch_differential(g, batch, pqs=((0.5, 2.0), (3.0, 0.7))) == 2 * (1 << 20) * W * L
+    assert g.wedge_mode == 65536 and g.wedge_slots is not None  # mixed table, slots kept
+    gen = torch.Generator().manual_seed(6)
+    pick = torch.sort(torch.randperm(start_all.numel(), generator=gen)[:50_000]).values
+    start = start_all[pick.to("cuda")].contiguous()
+    for p, q in ((0.5, 2.0), (3.0, 0.7), (4.0, 0.25), (4.0, 2.0)):
+        _oracle_sample(oracle, g, start, p, q, 42, n_oracle=300, n_hubs=24, oracle_len=16)
+    # the widest rows are really walked: the sample's walks stand on them
+    wide = torch.nonzero(deg >= 65536).reshape(-1)
+    sample = _sample_with_hubs(g, start, 300, 24, 42)
+    got, _ = rw.walk(g, sample, W, 16, 0.5, 2.0, 42)
+    assert int(torch.isin(got[:, 1:-1].long(), wide).sum()) > 200
+
+
 def test_cfg4_power_law_100m(oracle):
     """cfg 4 (the configuration BASELINE.json's metric is quoted on): 10^8 vertices, 5 x 10^8
     undirected draws (~0.9 x 10^9 directed edges), trimmed at 10 000; 100 k start vertices"""
@@ -139,6 +180,10 @@ def test_cfg4_power_law_100m(oracle):
     start = start_all[pick.to("cuda")].contiguous()
     for p, q in ((1.0, 1.0), (0.5, 2.0), (0.25, 0.5)):
         _check_config(oracle, g, start, p, q, 42, n_oracle=600, n_hubs=64, oracle_len=40)
+    # the other code instances against the ORACLE at full size too (not only against sibling kernels):
+    # the closed forms with margins (3, 0.7), "other" overfull (4, 0.25), the shared stack (4, 2)
+    for p, q in ((3.0, 0.7), (4.0, 0.25), (4.0, 2.0)):
+        _oracle_sample(oracle, g, start, p, q, 42, n_oracle=600, n_hubs=64, oracle_len=40)
     # bench.py's batch: the first 2^20 start vertices x 10 x 80, per kernel instance
     assert full_batch_differential(g, start_all[: 1 << 20].contiguous()) == 4 * (1 << 20) * W * L
 

@@ -77,6 +77,152 @@ def test_wedge_lists_equal_the_per_step_set_intersection(wide):
     assert n_long > 100
 
 
+def test_mixed_wedge_table_widens_only_the_lists_into_wide_rows():
+    """n2v_wedge_build with wide = T >= 2 (production 65536: the reference's own trim cap is 100 000,
+    constants.py:6): the list of an edge into a row of fewer than T entries is uint16 as ever, the
+    list of an edge into a row of T entries or more is uint32 and lies behind all the 16-bit ones;
+    the wedge slots exist for the first kind only; the hop table inlines return positions for the
+    first kind only.  Same lists, edge by edge, as the reference's per-step set intersection."""
+    from node2vec_amd.graph import DeviceGraph
+
+    rng = np.random.default_rng(19)
+    nv = 700
+    src = np.concatenate([rng.integers(0, nv - 20, 9000), rng.integers(0, 6, 2500), rng.integers(0, nv - 20, 2500),
+                          rng.integers(0, 40, 300)])
+    dst = np.concatenate([rng.integers(0, nv, 9000), rng.integers(0, nv, 2500), rng.integers(0, 6, 2500),
+                          rng.integers(0, 40, 300)])
+    g = DeviceGraph.from_edges(src, dst, None, n_vertices=nv, device="cuda")
+    T = 40
+    g.build_wedges(wide_from=T)
+    assert g.wedge_mode == T and g.c_struct().wedge_wide == T and g.wedge_pos.dtype == torch.int16
+    rowptr, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
+    deg = np.diff(rowptr)
+    want_pos, want_rpos, want_nr = _expected(rowptr, col)
+    ec = g.edge_classes.cpu().numpy().astype(np.uint32)
+    off = g.wedge_off.cpu().numpy().astype(np.uint64)
+    pos16 = g.wedge_pos.cpu().numpy().astype(np.uint16)
+    pos32 = pos16.view(np.uint32).astype(np.int64)
+    pos16 = pos16.astype(np.int64)
+    wide_e = deg[col] >= T
+    assert 500 < wide_e.sum() < g.n_edges - 500
+    n16 = sum(len(want_pos[e]) for e in range(g.n_edges) if not wide_e[e])
+    lo32 = (n16 + 1) // 2
+    for e in range(g.n_edges):
+        n_shared, n_ret = int(ec[e] & 0xffffff), int(ec[e] >> 24)
+        o, rp = int(off[e] & np.uint64(0xffffffffff)), int(off[e] >> np.uint64(40))
+        assert n_shared == len(want_pos[e])
+        if wide_e[e]:
+            assert o >= lo32 and pos32[o:o + n_shared].tolist() == want_pos[e], e
+        else:
+            assert o + n_shared <= n16 and pos16[o:o + n_shared].tolist() == want_pos[e], e
+        if n_ret:
+            assert rp == want_rpos[e], e
+    slots = g.wedge_slots.cpu().numpy().astype(np.uint16).astype(np.int64)
+    assert not slots[wide_e].any()  # no slot for an edge into a wide row
+    for e in np.nonzero(~wide_e)[0][::7]:
+        lst, n_ret = want_pos[e], int(ec[e] >> 24)
+        rp = want_rpos[e] if n_ret else int(off[e] >> np.uint64(40))
+        assert slots[e, 0] == rp and slots[e, 1] == sum(1 for x in lst if x < rp), e
+        if len(lst) <= 14:
+            assert slots[e, 2:2 + len(lst)].tolist() == lst, e
+    assert g.can_inline_rpos()
+    g.build_hops(inline_rpos=True)
+    cls = g.hops.cpu().numpy()[:, 1].astype(np.uint32)
+    inl = (cls & np.uint32(0x80000000)) != 0
+    assert inl.any() and not inl[wide_e].any()
+    assert np.array_equal(cls[wide_e], ec[wide_e])
+    assert np.array_equal(inl[~wide_e], (ec[~wide_e] & 0xffffff) == 0)
+
+
+PQ_MIXED = [(0.5, 2.0), (4.0, 0.25), (4.0, 2.0), (0.25, 0.5), (3.0, 0.7), (0.7, 3.0), (2.0, 1.0), (0.5, 0.5)]
+
+
+@pytest.mark.parametrize("wide_from", [2, 24, 200])
+def test_walks_over_a_mixed_wedge_table_equal_the_oracle(wide_from):
+    """Exact biased walks on a graph whose wedge table is mixed (some rows "wide"): the slots kernel
+    (steps on wide rows go through wedge_off with 32-bit lists, per lane), the kernel without slots,
+    the class-count kernel and the passes over a workspace all give the oracle's walks, for every
+    arrangement of the closed forms and for values that are not dyadic."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import n2v_oracle
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+
+    rng = np.random.default_rng(100 + wide_from)
+    nv = 1500
+    src = np.concatenate([rng.integers(0, nv, 9000), rng.integers(0, 8, 4000), rng.integers(0, 60, 2000)])
+    dst = np.concatenate([rng.integers(0, nv, 9000), rng.integers(0, nv, 4000), rng.integers(0, 60, 2000)])
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    g = DeviceGraph.from_edges(np.concatenate([src, dst]), np.concatenate([dst, src]), None, n_vertices=nv,
+                               device="cuda")
+    g.build_wedges(wide_from=wide_from)
+    g.wedge_tried = True
+    assert g.wedge_mode == wide_from and g.wedge_slots is not None
+    start = rw.start_vertices(g)
+    rowptr, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
+    for p, q in PQ_MIXED:
+        want, wv = n2v_oracle.random_walk(rowptr, col, None, start.cpu().numpy(), 2, 25, p, q, 77, n_threads=8)
+        for kw in ({}, {"use_wedge_slots": False}, {"use_wedge_kernel": False}, {"use_workspace": True}):
+            got, gv = rw.walk(g, start, 2, 25, p, q, 77, **kw)
+            assert g.wedge_mode == wide_from  # (the table was not rebuilt)
+            assert np.array_equal(gv.cpu().numpy(), wv), (p, q, kw)
+            assert np.array_equal(got.cpu().numpy(), want), (p, q, kw)
+
+
+def test_a_row_of_more_than_65535_entries_keeps_the_slots_kernel():
+    """The reference's default trim cap is 100 000 (constants.py:6, randomwalk.py:252-253): ONE row of
+    65 536 entries or more used to switch the wedge slots off for the whole graph.
+    Now only the steps standing on such a row read 32-bit lists.  A hub of 70 000 neighbours inside a
+    graph with triangles: the table is mixed, the slots exist, and the walks equal the table-free
+    kernel's over all start vertices and the oracle's on a sample that starts on and next to the hub."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import n2v_oracle
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+
+    rng = np.random.default_rng(5)
+    nv = 90_000
+    leaves = rng.choice(np.arange(2, nv), 70_000, replace=False)
+    a, b = rng.integers(0, nv, 300_000), rng.integers(0, nv, 300_000)
+    second = rng.choice(np.arange(2, nv), 66_000, replace=False)  # a second wide row: hub-hub wedges are long
+    src = np.concatenate([np.zeros_like(leaves), a, np.ones_like(second), [0]])
+    dst = np.concatenate([leaves, b, second, [1]])
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    key = np.unique(np.concatenate([src * nv + dst, dst * nv + src]))
+    g = DeviceGraph.from_edges(key // nv, key % nv, None, n_vertices=nv, device="cuda")
+    assert int(g.degrees().max()) >= 70_000
+    g.build_wedges()
+    g.wedge_tried = True
+    assert g.wedge_mode == 65536 and g.wedge_slots is not None and g.wedge_pos.dtype == torch.int16
+    start_all = rw.start_vertices(g)
+    rowptr, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
+    hub_nbrs = col[rowptr[0]:rowptr[0] + 40]
+    sample = torch.tensor(np.unique(np.concatenate([[0, 1], hub_nbrs, col[rowptr[1]:rowptr[1] + 20]])),
+                          dtype=torch.int32, device="cuda")
+    for p, q in ((0.5, 2.0), (4.0, 0.25), (3.0, 0.7), (4.0, 2.0)):
+        a1, v1 = rw.walk(g, start_all, 1, 12, p, q, 9)
+        a2, v2 = rw.walk(g, start_all, 1, 12, p, q, 9, use_edge_classes=False)  # table-free, wave per walker
+        assert torch.equal(v1, v2) and torch.equal(a1, a2), (p, q)
+        a3, v3 = rw.walk(g, start_all, 1, 12, p, q, 9, use_wedge_slots=False)
+        assert torch.equal(v1, v3) and torch.equal(a1, a3), (p, q)
+        got, gv = rw.walk(g, sample, 2, 6, p, q, 9)
+        want, wv = n2v_oracle.random_walk(rowptr, col, None, sample.cpu().numpy(), 2, 6, p, q, 9, n_threads=8)
+        assert np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy(), want), (p, q)
+        hub_steps = int(((got[:, :-1] == 0) | (got[:, :-1] == 1)).sum())
+        assert hub_steps > 50  # the wide path was taken
+    # fast mode reads the same table: walks start, stay in range and follow edges
+    f, fv = rw.walk(g, sample, 2, 10, 4.0, 0.25, 9, mode="fast")
+    assert bool(fv.all()) and int(f.min()) >= 0 and int(f.max()) < nv
+
+
 def test_hop_table_with_inline_return_positions():
     """n2v_hops_build with N2V_HOPS_INLINE_RPOS: the class word of an edge WITHOUT shared neighbours
     is N2V_EC_INLINE | return count << 24 | return position, every other entry is edge_classes[e];
