@@ -81,6 +81,8 @@ def parse(argv=None):
     ap.add_argument("--trim", type=int, default=-1,
                     help="out-degree cap of trim_hotspot_vertices (-1 = the config's, 10000; 100000 = the "
                          "reference's default cap, constants.py:6; 0 = no trim)")
+    ap.add_argument("--no-audition", action="store_true",
+                    help="take the first output buffer the allocator hands out (no placement audition)")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks through torch.distributed.run also at --gpus 1 (at --gpus N > 1 "
                          "this is what happens anyway when RANK is not in the environment)")
@@ -167,7 +169,8 @@ def reference_algorithmic_bytes(torch, g, walks, valid, rows=65536):
 class WalkLeg:
     """K timed launches of n2v_walk over batches of start vertices."""
 
-    def __init__(self, torch, rw, g, start_all, W, L, p, q, mode, batch, rank, world, rank_ids=False):
+    def __init__(self, torch, rw, g, start_all, W, L, p, q, mode, batch, rank, world, rank_ids=False,
+                 audition=True):
         self.rank_ids = rank_ids  # the walks come out in degree ranks (fit_streaming's form at p = q = 1)
         self.torch, self.rw, self.g, self.start_all = torch, rw, g, start_all
         self.W, self.L, self.p, self.q, self.mode = W, L, p, q, mode
@@ -175,9 +178,17 @@ class WalkLeg:
         self.rank, self.world = rank, world
         self.n_batches = max(1, start_all.numel() // self.batch)
         dev = g.device
-        self.walks = torch.empty((self.batch * W, L + 1), dtype=torch.int32, device=dev)
-        self.valid = torch.empty(self.batch * W, dtype=torch.uint8, device=dev)
         self.stats = {}
+        self.audition = {}
+        if audition:
+            # where the output buffer lies decides up to 7 % of the launch time (DESIGN.md 5 "Placement"):
+            # a few candidate buffers take a short launch each, the fastest is kept -- what
+            # fit_streaming does for the buffers it walks its batches into (randomwalk.audition_buffers)
+            self.walks, self.valid = rw.audition_buffers(g, self.starts(0), W, L, p, q, 42, mode,
+                                                         report=self.audition, rank_ids=rank_ids)
+        else:
+            self.walks = torch.empty((self.batch * W, L + 1), dtype=torch.int32, device=dev)
+            self.valid = torch.empty(self.batch * W, dtype=torch.uint8, device=dev)
 
     def starts(self, k):
         i = (k * self.world + self.rank) % self.n_batches
@@ -310,7 +321,7 @@ def main():
         in_ranks = g.rank_hops is not None
     vertex_leg = None
     if in_ranks:
-        leg = WalkLeg(torch, rw, g, start_all, W, L, p, q, "exact", batch, rank, world)
+        leg = WalkLeg(torch, rw, g, start_all, W, L, p, q, "exact", batch, rank, world, audition=not args.no_audition)
         rv = leg.run(args.steps, args.warmup, barrier)
         ev, sv = reduce_job(torch, dist, use_dist, dev, rv["elapsed"], rv["steps_done"])
         if rank == 0:
@@ -323,7 +334,7 @@ def main():
                                                            gather_bytes=4)
         del leg
         torch.cuda.empty_cache()
-    leg = WalkLeg(torch, rw, g, start_all, W, L, p, q, "exact", batch, rank, world, rank_ids=in_ranks)
+    leg = WalkLeg(torch, rw, g, start_all, W, L, p, q, "exact", batch, rank, world, rank_ids=in_ranks, audition=not args.no_audition)
     res = leg.run(args.steps, args.warmup, barrier)
     elapsed, steps_total = reduce_job(torch, dist, use_dist, dev, res["elapsed"], res["steps_done"])
     value = steps_total / elapsed
@@ -386,7 +397,7 @@ def main():
     bp, bq = BIASED_PQ
     if not args.no_biased and (bp, bq) != (p, q):
         prepare_tables(torch, g, bp, bq, "exact", setup, "biased")
-        leg = WalkLeg(torch, rw, g, start_all, W, L, bp, bq, "exact", cfg["biased_batch"], rank, world)
+        leg = WalkLeg(torch, rw, g, start_all, W, L, bp, bq, "exact", cfg["biased_batch"], rank, world, audition=not args.no_audition)
         r2 = leg.run(args.steps, args.warmup, barrier)
         e2, s2 = reduce_job(torch, dist, use_dist, dev, r2["elapsed"], r2["steps_done"])
         if rank == 0:
@@ -418,7 +429,7 @@ def main():
         for rp, rq, what in ((4.0, 0.25, "other alone overfull"), (4.0, 2.0, "return + other underfull"),
                              (0.25, 0.5, "return + other overfull / return alone overfull"),
                              (3.0, 0.7, "1/p, 1/q not dyadic: closed forms with margins, the rest replayed")):
-            leg = WalkLeg(torch, rw, g, start_all, W, L, rp, rq, "exact", cfg["biased_batch"], rank, world)
+            leg = WalkLeg(torch, rw, g, start_all, W, L, rp, rq, "exact", cfg["biased_batch"], rank, world, audition=not args.no_audition)
             rr = leg.run(args.steps, args.warmup, barrier)
             er, sr = reduce_job(torch, dist, use_dist, dev, rr["elapsed"], rr["steps_done"])
             regimes.append({"p": rp, "q": rq, "arrangement": what, "value": sr / er,
@@ -430,7 +441,7 @@ def main():
             out["biased_other_regimes"] = regimes
     if not args.no_fast:
         prepare_tables(torch, g, bp, bq, "fast", setup, "fast")
-        leg = WalkLeg(torch, rw, g, start_all, W, L, bp, bq, "fast", batch, rank, world)
+        leg = WalkLeg(torch, rw, g, start_all, W, L, bp, bq, "fast", batch, rank, world, audition=not args.no_audition)
         r3 = leg.run(args.steps, args.warmup, barrier)
         e3, s3 = reduce_job(torch, dist, use_dist, dev, r3["elapsed"], r3["steps_done"])
         if rank == 0:
@@ -646,6 +657,7 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
          "hop_table": "4-byte degree-ranked" if ranked else "8-byte" if hop8 else hops,
          "wedge_table": ":wedges" in kernel_key,
          "kernel_ms": 1e3 * res["kernel_s"],
+         "output_buffer_audition": getattr(leg, "audition", None) or None,
          "achieved_from": "ALGORITHMIC bytes of the kernel (formula below) x walk-steps per launch / "
                           "HIP-event duration of the launch",
          "frac_algorithmic": ach / HBM_PEAK,

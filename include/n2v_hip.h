@@ -217,7 +217,7 @@ int n2v_hops_build(const n2v_graph *g, struct n2v_hop *hops_out, uint32_t *statu
 int n2v_hops8_build(const n2v_graph *g, int32_t col_bits, int32_t row_bits, int32_t align_shift,
                     const int64_t *hop8_rowptr, uint64_t *hops8_out, void *stream);
 
-/* Shared-position lists ("wedge table") of a unit-weight graph.  For edge e = (s -> v) the list
+/* Shared-position lists ("wedge table") of a graph (weights play no part).  For edge e = (s -> v) the list
  *   wedge_pos[off .. off + n_shared)   off = wedge_off[e] & (2^40 - 1), n_shared = low 24 bits
  *                                      of edge_classes[e]
  * holds, ascending, the positions j with N(v)[j] in N_out(s) and N(v)[j] != s -- WHICH slots of
@@ -292,6 +292,33 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
              double inout_param, uint64_t seed, int32_t mode,
              int32_t *walks_out, uint8_t *valid_out, uint32_t *status,
              void *stream);
+
+/* ONE STEP of exact walks on a WEIGHTED graph (g->w or g->w64), one lane per walker
+ * (csrc/n2v_walk_wlanes.hip) -- the step-synchronous form of n2v_walk for the graphs whose tables have
+ * no closed form: every value of the table generate_edge_alias_tables builds (randomwalk.py:193-232)
+ * is different, so a step is O(row) with two serial parts, the left-to-right row sum (:172) and the
+ * pairing loop (:182-189).  n2v_walk gives a walker a wave and runs those on one lane of it; here 64
+ * walkers share a wave and their serial chains run side by side -- which pays when the lanes of a
+ * wave stand on rows of similar length, hence `order`.  The caller keeps the state and loops:
+ *     walks  [n_rows, walk_length + 1] int32, row r = start r / num_walks, ordinal r % num_walks + 1;
+ *            before step 0: walks[r][0] = the start vertex, or -1 (and valid[r] = 0) for a start
+ *            vertex out of range or without out-edges (fugue.py:132); everything else -1
+ *     valid  [n_rows] 1 while the walker walks; the step clears it when the walker reaches a vertex
+ *            without out-edges before the last step (fugue.py:147) or its row sums to 0
+ *            (N2V_ST_ZERODIV)
+ *     edge_state [n_rows] the edge (index into col) every walker walked last; the step writes it
+ *     order  [n_rows] the rows in the order lanes take them -- sorted by the out-degree of
+ *            walks[r][step], descending -- or NULL (row order)
+ *   for step = 0 .. walk_length - 1:  n2v_walk_weighted_step(..., step, ...)
+ * and the result is n2v_walk's, bit for bit (same uniform stream, keyed by start vertex, ordinal and
+ * step).  For return_param or inout_param != 1 the steps after the first read the classes of the
+ * slots from g->edge_classes, g->wedge_off and g->wedge_pos (n2v_edge_classes_build, n2v_wedge_build:
+ * they depend on the ids alone and are built for a weighted graph as for a unit one). */
+int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_ids, int32_t num_walks,
+                           const int64_t *order, int64_t n_rows, int32_t step, int32_t walk_length,
+                           double return_param, double inout_param, uint64_t seed,
+                           int64_t *edge_state, int32_t *walks, uint8_t *valid, uint32_t *status,
+                           void *stream);
 
 /* n2v_walk with a workspace lent by the caller (the library never allocates).  Exact biased walks
  * on a unit-weight graph that carries the hop and wedge tables, dyadic return_param / inout_param,

@@ -26,7 +26,7 @@ SYMBOLS = ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alia
            "n2v_partition_step", "n2v_gather_rows", "n2v_gather_wedges",
            "n2v_partition_route", "n2v_partition_group", "n2v_walk_ws", "n2v_walk_workspace_bytes",
            "n2v_delta_reduce", "n2v_wedge_slots_build", "n2v_sgns_job_alpha", "n2v_rank_hops_build", "n2v_partition_forward",
-           "n2v_sgns_hogwild_waves")
+           "n2v_sgns_hogwild_waves", "n2v_walk_weighted_step")
 
 
 class Graph(C.Structure):
@@ -117,6 +117,10 @@ def load():
     L.n2v_trim_mark.restype = C.c_int
     L.n2v_trim_mark.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p,
                                 C.c_void_p]
+    L.n2v_walk_weighted_step.restype = C.c_int
+    L.n2v_walk_weighted_step.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
+                                         C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint64,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.n2v_sgns_hogwild_waves.restype = C.c_int64
     L.n2v_sgns_hogwild_waves.argtypes = [C.POINTER(SgnsParams), C.c_int64, C.c_int32]
     L.n2v_sgns_job_alpha.restype = C.c_int

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void edge_classes_kernel(n2v_graph g,
 extern "C" int n2v_edge_classes_build(const n2v_graph *g, uint32_t *classes_out,
                                       uint32_t *status, void *stream) {
   if (!g || !g->rowptr || g->n_vertices < 0 || g->n_edges < 0) return N2V_EINVAL;
-  if (g->w || g->w64) return N2V_EINVAL;  // unit-weight graphs only
+  // (weights play no part: which slots are return / shared / other depends on the ids alone)
   if (g->n_edges == 0) return N2V_OK;
   if (!g->col || !classes_out || !status) return N2V_EINVAL;
   const int64_t n_batches = (g->n_edges + n2v::kEdgeBatch - 1) / n2v::kEdgeBatch;

@@ -388,6 +388,32 @@ __device__ __forceinline__ int near_listed(int arr, int n, int pick, double r2, 
   return -1;
 }
 
+// The closed forms once more, AFTER the row has been added up in the reference's order (round 5).  near_step
+// works on values from the class counts and must allow for the order of the row sum: its margin grows with
+// n^2 (5e-15 n (n + 8) vmax: 5e-5 at n = 10^5, the size of an excess or a deficit there), so on the long rows
+// of a graph trimmed at the reference's own cap (100 000, constants.py:6) it declines several per cent of
+// the pairings and every one of those is an O(list) replay.  Given the reference's `avg` bit for bit
+// (lane_row_sum) the values v = fl(b / avg) ARE the reference's, which side of 1.0 each class lies on and
+// whether `pick` was accepted are exact comparisons the caller has made, and what is left is
+//   * the reference's loop: two roundings per iteration, fewer than n iterations, values <= vmax + 1:
+//     <= 2.2e-16 n (vmax + 1) at any lattice point of the staircase ("Why a margin ...");
+//   * the formulas: products and sums of up to n values, a handful of operations: <= 1e-15 n vmax;
+// so a margin of 2e-14 n (vmax + 1) -- LINEAR in n, twelve times the sum -- decides.  -1: replay.
+template <typename P>
+__device__ __forceinline__ int near_listed_exact(int arr, int n, int pick, double r2, const UnitConsts &K,
+                                                 double avg, int nR, int rpos, int nM, const P *list, bool isR,
+                                                 bool isM, int lo_pick, int below) {
+  const int nO = n - nR - nM;
+  NearVals V;
+  V.vR = K.bR / avg, V.vM = K.bM / avg, V.vO = K.bO / avg;
+  double vmax = nO ? V.vO : 0.0;
+  if (nR) vmax = fmax(vmax, V.vR);
+  if (nM) vmax = fmax(vmax, V.vM);
+  V.mg = 2e-14 * (double)n * (vmax + 1.0);
+  return near_listed<P>(arr, n, pick, r2, V, nR, rpos, nM, list, isR, isM, lo_pick, below);
+}
+constexpr int kNearExactMin = 256;  // rows from this length on try the forms again with the exact average
+
 // One step whose class values are not dyadic, before the row is added up in the reference's order:
 // taken when every decision on the way clears the margin -- which side of the average every class is
 // on, that `pick` was not accepted (the caller's quick exit accepts with its own margin), and the

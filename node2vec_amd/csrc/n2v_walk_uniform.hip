@@ -129,6 +129,9 @@ __global__ __launch_bounds__(kThreads, 8) void walk_uniform_kernel(
     auto flush = [&](int64_t a) {  // words [sector(a) + lo, a] are complete: store them
       const int k = (int)(a & 15);
       int32_t *sec = walks_out + (a & ~(int64_t)15);
+#if defined(N2V_ABLATE_UNIFORM) && N2V_ABLATE_UNIFORM == 1  // timing only: no path stores (placement diagnosis)
+      if (buf[k] == 0x7fffffff) sec[k] = 0;
+#else
       if (lo == 0 && k == 15 && base_aligned) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(kThreads, 8) void walk_uniform_kernel(
         for (int kk = 0; kk < 16; ++kk)
           if (kk >= lo && kk <= k) sec[kk] = buf[kk];
       }
+#endif
       lo = 0;
     };
     if (have) {
@@ -152,7 +156,11 @@ __global__ __launch_bounds__(kThreads, 8) void walk_uniform_kernel(
         const uint64_t bits = step_bits(h0, (uint32_t)step);
         const int pick = pick_index((uint32_t)(bits >> 32), n);  // int(r1 * n); r2 is irrelevant
         if (kHops == 3) {
+#if defined(N2V_ABLATE_UNIFORM) && N2V_ABLATE_UNIFORM == 2  // timing only: no table read (placement diagnosis)
+          const uint32_t xr = (uint32_t)((bits >> 7) % (uint64_t)g.n_vertices);
+#else
           const uint32_t xr = g.rank_hops[vb + pick];
+#endif
           x = emit_rank ? (int32_t)xr : g.rank_vertex[xr];
           if (step + 1 < walk_length) rank_row(g, cls_first, cls_where, xr, vb, n);
         } else if (kHops == 2) {

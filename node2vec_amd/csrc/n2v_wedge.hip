@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void wedge_fill_kernel(n2v_graph g,
 extern "C" int n2v_wedge_build(const n2v_graph *g, const uint64_t *list_off, uint64_t *wedge_off_out,
                                void *wedge_pos_out, int32_t wide, uint32_t *status, void *stream) {
   if (!g || !g->rowptr || g->n_vertices < 0 || g->n_edges < 0) return N2V_EINVAL;
-  if (g->w || g->w64) return N2V_EINVAL;  // unit-weight graphs only
+  // (weights play no part: which slots are return / shared / other depends on the ids alone)
   if (g->n_edges == 0) return N2V_OK;
   if (!g->col || !g->edge_classes || !list_off || !wedge_off_out || !wedge_pos_out || !status)
     return N2V_EINVAL;

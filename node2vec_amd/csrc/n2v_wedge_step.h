@@ -57,6 +57,14 @@ __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, 
   }
 #endif
   if (res >= 0) return res;
+  if constexpr (kMode == 2) {
+    // a long row whose values are not dyadic: the closed forms on the reference's own values (the exact
+    // row sum has been taken), with a margin that grows with n instead of n^2
+    if (N2V_NEAR_FORMS && n >= kNearExactMin && arr >= 1) {
+      res = near_listed_exact<P>(arr, n, pick, r2, K, avg, nR, rpos, nM, list, isR, isM, lo_pick, below);
+      if (res >= 0) return res;
+    }
+  }
   const double vR = K.bR / avg, vM = K.bM / avg, vO = K.bO / avg;
   if (n <= 64) {  // a short row: the two stacks as bit masks
     uint64_t Rm = 0ull;
@@ -301,6 +309,9 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
   if (!any_under || !any_over) {  // the loop of :182 never runs
     if (!(r2 < p_pick)) idx = 0;
   } else {
+#ifdef N2V_BIG_STATS  // diagnostic build: pairings on rows of >= N2V_BIG_STATS slots ([2]) and the cycles / 256 they take ([3])
+    const unsigned long long big_t0 = __builtin_readcyclecounter();
+#endif
     if (!w_loaded) {  // the return position (and an empty list)
       if constexpr (kSlots) {
         sa = reinterpret_cast<const int4 *>(slot)[0];
@@ -380,6 +391,12 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
                                            reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off,
                                            isR, isM, lo_pick, reinterpret_cast<uint16_t *>(stage), lane);
     }
+#ifdef N2V_BIG_STATS
+    if (n >= N2V_BIG_STATS && idx >= 0) {
+      atomicAdd(status + 2, 1u);
+      atomicAdd(status + 3, (uint32_t)((__builtin_readcyclecounter() - big_t0) >> 8));
+    }
+#endif
   }
   if (idx != pick) h = load_hop(g.hops + vb + idx);
   return idx;

@@ -274,12 +274,12 @@ class DeviceGraph:
         return self.build_pivots()
 
     def build_edge_classes(self) -> "DeviceGraph":
-        """Per-edge class counts (n2v_edge_classes_build) for exact walks on a unit-weight
-        graph: 4 bytes per edge, computed once, kept on the graph."""
+        """Per-edge class counts (n2v_edge_classes_build) for exact walks: 4 bytes per edge,
+        computed once, kept on the graph.  They depend on the ids alone (which slots of the table of
+        step (s -> v) are return / shared / other), so weighted graphs have them too: the
+        lane-per-walker kernel of weighted exact walks reads them (n2v_walk_weighted_step)."""
         L = _lib.load()
         _lib.require_gpu()
-        if not self.unit_weights:
-            raise ValueError("edge classes exist for unit-weight graphs only")
         if not self.rowptr.is_cuda:
             raise RuntimeError("build_edge_classes: graph is not on the GPU")
         ec = torch.zeros(self.n_edges, dtype=torch.int32, device=self.device)
@@ -313,8 +313,6 @@ class DeviceGraph:
         the row length from which lists are widened."""
         L = _lib.load()
         _lib.require_gpu()
-        if not self.unit_weights:
-            raise ValueError("the wedge table exists for unit-weight graphs only")
         if self.edge_classes is None:
             self.build_edge_classes()
         self.wedge_off = self.wedge_pos = self.wedge_slots = None

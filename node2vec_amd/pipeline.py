@@ -129,12 +129,26 @@ def fit_streaming(graph: DeviceGraph, n2v_params: Dict[str, Any], w2v_params: Di
             graph.build_ranked()
         in_ranks = graph.rank_hops is not None
 
+    # every batch is walked into the same pair of buffers, chosen once by audition (where an output
+    # buffer lies decides up to 7 % of the walk kernel's time: randomwalk.audition_buffers)
+    buffers = [None]
+
     def walk(k):
         st = {}
-        out = rw.walk(graph, start[k * batch_vertices:(k + 1) * batch_vertices].contiguous(), W, L,
-                      pp, qq, seed, mode, check=False, stats=st, rank_ids=in_ranks)
+        sk = start[k * batch_vertices:(k + 1) * batch_vertices].contiguous()
+        if buffers[0] is None and sk.numel() == batch_vertices and n_batches > 2 and p.get("audition", True):
+            rep = {}
+            buffers[0] = rw.audition_buffers(graph, sk, W, L, pp, qq, seed, mode, report=rep, rank_ids=in_ranks)
+            if timings is not None:
+                timings["audition"] = rep
+        out = None
+        if buffers[0] is not None:
+            rows = sk.numel() * W
+            out = (buffers[0][0][:rows], buffers[0][1][:rows])
+        walks, valid = rw.walk(graph, sk, W, L, pp, qq, seed, mode, out=out, check=False, stats=st,
+                               rank_ids=in_ranks)
         walk_status.bitwise_or_(st["status"][:1])
-        return out
+        return walks, valid.bool()
 
     def raise_walk_status():
         from node2vec_amd import _lib

@@ -71,7 +71,7 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
          stats: Optional[dict] = None, use_edge_classes: bool = True, use_hops: bool = True,
          use_wedges: bool = True, use_wedge_kernel: bool = True, use_hops8: bool = True,
          use_workspace: bool = False, use_wedge_slots: bool = True, use_ranked: Optional[bool] = None,
-         rank_ids: bool = False):
+         rank_ids: bool = False, use_weighted_lanes: Optional[bool] = None):
     """Launch K2.  Returns (walks int32 [n_start*num_walks, walk_length+1], valid bool).
 
     mode "fast", and on weighted graphs mode "exact" with return_param == inout_param == 1
@@ -96,7 +96,11 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     ranks (map with graph.rank_vertex, or compose it into the per-token lookup that follows, as
     fit_streaming does): the form is built on first use and one step is one 4-byte gather.  With
     rank_ids=False the kernel translates every token back (one more gather): use_ranked=True asks
-    for that, the default (None) keeps the hop tables for vertex-id output."""
+    for that, the default (None) keeps the hop tables for vertex-id output.
+    Exact biased walks on a WEIGHTED graph run step-synchronously, one lane per walker, the walkers
+    of every step ordered by the degree of the vertex they stand on (n2v_walk_weighted_step; the
+    per-edge class counts and wedge lists are built on first use -- they depend on the ids alone):
+    the same walks as the wave-per-walker kernel of n2v_walk, which use_weighted_lanes=False keeps."""
     L = _lib.load()
     _lib.require_gpu()
     if mode not in MODES:
@@ -177,6 +181,12 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     start_ids = start_ids.to(device=graph.device, dtype=torch.int32).contiguous()
     n_start = start_ids.numel()
     total = n_start * num_walks
+    if (mode == "exact" and biased and not graph.unit_weights and use_weighted_lanes is not False
+            and total > 0 and walk_length > 0
+            and (use_weighted_lanes or total >= WEIGHTED_LANES_MIN_WALKERS)
+            and weighted_lanes_tables(graph, bool(use_weighted_lanes))):
+        return _walk_weighted_lanes(graph, start_ids, num_walks, walk_length, return_param, inout_param,
+                                    seed, out, check, stats)
     if out is None:
         walks = torch.empty((total, walk_length + 1), dtype=torch.int32, device=graph.device)
         valid = torch.empty(total, dtype=torch.uint8, device=graph.device)
@@ -221,6 +231,114 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
         stats["trials"] = status[2:4].view(torch.int64)
         stats["status"] = status
     return walks, valid.bool() if out is None else valid
+
+
+# Below this many walkers a launch per step cannot win over the one-launch wave-per-walker kernel
+WEIGHTED_LANES_MIN_WALKERS = 4096
+
+
+def weighted_lanes_tables(graph: DeviceGraph, insist: bool = False) -> bool:
+    """the per-edge class counts and wedge lists of a WEIGHTED graph, built on first use (they depend
+    on the ids alone): what n2v_walk_weighted_step reads.  False when they do not fit (or were
+    declined before)."""
+    if graph.edge_classes is None:
+        graph.build_edge_classes()
+    if graph.wedge_off is None and (insist or not graph.wedge_tried):
+        graph.wedge_tried = True
+        graph.build_wedges(slots=False)
+    return graph.wedge_off is not None
+
+
+def _walk_weighted_lanes(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_length: int,
+                         p: float, q: float, seed: int, out, check: bool, stats: Optional[dict]):
+    """Exact biased walks on a weighted graph, step by step (n2v_walk_weighted_step): per step one
+    sort of the walkers by the degree of the vertex they stand on, one launch with a lane per
+    walker.  Initialisation = initiate_random_walk (randomwalk.py:279-296), the loop = fugue.py:137-153."""
+    L = _lib.load()
+    dev = graph.device
+    n_start, W, Lw = start_ids.numel(), int(num_walks), int(walk_length)
+    total = n_start * W
+    if out is None:
+        walks = torch.empty((total, Lw + 1), dtype=torch.int32, device=dev)
+        valid = torch.empty(total, dtype=torch.uint8, device=dev)
+    else:
+        walks, valid = out
+    status = torch.zeros(4, dtype=torch.int32, device=dev)
+    deg = graph.degrees().to(torch.int32)
+    s64 = start_ids.long()
+    in_range = (s64 >= 0) & (s64 < graph.n_vertices)
+    alive = in_range & (deg[s64.clamp(0, max(graph.n_vertices - 1, 0))] > 0)  # fugue.py:132
+    status[0] = torch.where(in_range.all(), 0, int(_lib.ST_RANGE)).to(torch.int32)
+    walks.fill_(-1)
+    walks[:, 0] = torch.where(alive, start_ids, torch.full_like(start_ids, -1)).repeat_interleave(W)
+    valid.copy_(alive.repeat_interleave(W).to(torch.uint8))
+    edge_state = torch.full((total,), -1, dtype=torch.int64, device=dev)
+    g = graph.c_struct()
+    with torch.cuda.device(dev):
+        stream = _lib.current_stream_ptr()
+        for step in range(Lw):
+            cur = walks[:, step]
+            # the lanes of a wave should stand on rows of about the same length: order the walkers of
+            # this step by the degree of their vertex (vanished walkers last; they are skipped)
+            key = torch.where(valid.bool() & (cur >= 0), deg[cur.clamp(min=0).long()], torch.full_like(cur, -1))
+            order = torch.sort(key, descending=True).indices
+            _lib.check(L.n2v_walk_weighted_step(g, start_ids.data_ptr(), W, order.data_ptr(), total, step, Lw,
+                                                float(p), float(q), seed & (2 ** 64 - 1),
+                                                edge_state.data_ptr(), walks.data_ptr(), valid.data_ptr(),
+                                                status.data_ptr(), stream), "n2v_walk_weighted_step")
+    if check:
+        _lib.check_status_word(int(status[0].item()), "n2v_walk")
+    if stats is not None:
+        stats["trials"] = status[2:4].view(torch.int64)
+        stats["status"] = status
+    return walks, valid.bool() if out is None else valid
+
+
+def audition_buffers(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_length: int,
+                     return_param: float, inout_param: float, seed: int, mode: str = "exact",
+                     candidates: int = 4, probe_vertices: int = 1 << 17, report: Optional[dict] = None,
+                     **walk_kw) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Output buffers (walks int32 [n_start * num_walks, walk_length + 1], valid uint8) for REPEATED
+    launches of `walk(..., out=...)` over batches of start_ids.numel() start vertices, chosen by
+    audition: the same walk kernel on the same tables runs up to 7 % faster or slower depending on
+    WHICH allocation it writes to (DESIGN.md 5 "Placement": the reads alone and the stores alone do not
+    care where the buffers are, their mix does, for every pair of table and output differently; no
+    counter up to the L2 shows why), and a launch over 2^17 start vertices ranks the candidates the way
+    the full launches do (profiles/r7d_placement_parts.log).  So `candidates` buffers are allocated,
+    each takes a short launch (untimed warm-up + one timed by HIP events on the current stream), the
+    fastest is kept and the others are freed.  Costs candidates x the buffer transiently and
+    ~5 ms per candidate; callers that launch once (random_walk()) do not bother."""
+    n_start = int(start_ids.numel())
+    total = n_start * int(num_walks)
+    dev = graph.device
+
+    def alloc():
+        return (torch.empty((total, walk_length + 1), dtype=torch.int32, device=dev),
+                torch.empty(total, dtype=torch.uint8, device=dev))
+
+    free = torch.cuda.mem_get_info(dev)[0]
+    need = total * (walk_length + 2) * 4
+    k = int(max(1, min(candidates, (free // 2) // max(need, 1))))
+    probe = start_ids[: min(n_start, int(probe_vertices))]
+    if k <= 1 or probe.numel() == 0 or walk_length == 0:
+        return alloc()
+    bufs = [alloc() for _ in range(k)]
+    rows = probe.numel() * int(num_walks)
+    times = []
+    for w, v in bufs:
+        for rep in range(2):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            walk(graph, probe, num_walks, walk_length, return_param, inout_param, seed, mode,
+                 out=(w[:rows], v[:rows]), check=False, **walk_kw)
+            b.record()
+        torch.cuda.synchronize(dev)
+        times.append(a.elapsed_time(b))
+    best = min(range(k), key=times.__getitem__)
+    if report is not None:
+        report.update(candidates=k, probe_ms=[round(t, 3) for t in times], chosen=best,
+                      probe_start_vertices=int(probe.numel()))
+    return bufs[best]
 
 
 # the reference's row-level surface of this module (Neighbors, AliasProb, RandomPath,

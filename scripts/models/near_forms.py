@@ -5,7 +5,9 @@ left-to-right sum) on random rows of the three class values: `python near_forms.
 `python near_forms.py big` (long rows); N2V_MODEL_TRIALS overrides the number of rows.  Every slot of every
 row is asked for with a random r2.  `python near_forms.py adversarial`: EVERY (return run, shared subset)
 composition of the rows of n <= N2V_MODEL_NMAX (default 6) slots x twelve (p, q), then random rows of up to
-120 slots, every slot, with r2 on the nine u / 2^32 grid points around the reference's own probs[pick].  Prints how many draws the forms decided, how many they left to the replay
+120 slots, every slot, with r2 on the nine u / 2^32 grid points around the reference's own probs[pick].
+`python near_forms.py exactavg`: the second stage (near_listed_exact: the forms on the reference's own
+values after the exact row sum, margin linear in n) on rows of 256 .. 20 000 slots.  Prints how many draws the forms decided, how many they left to the replay
 ("ambiguous") and the mismatch count (must be 0)."""
 import math
 import os
@@ -285,6 +287,32 @@ def near_step(n, cls, pick, r2, b):
     return None if f is None else f(G, pick, r2, V, mg, pickR, pickM, lo_pick)
 
 
+def near_step_exact(n, cls, pick, r2, b):
+    """near_listed_exact of n2v_unit_near.h: the forms on the reference's OWN values (avg = the
+    left-to-right sum / n, v = b / avg) with the margin that is linear in n; None = replay"""
+    G = Row(n, cls); nR, nM, nO = G.nR, G.nM, G.nO
+    w = [b[c] for c in cls]
+    avg = sum(w) / n
+    uR, uM, uO = b['R'] < avg, b['M'] < avg, b['O'] < avg
+    any_under = (nR and uR) or (nM and uM) or (nO and uO)
+    any_over = (nR and not uR) or (nM and not uM) or (nO and not uO)
+    if not any_under or not any_over: return None
+    arr = 0
+    if uO and not (nR and uR) and not (nM and uM): arr = 1
+    elif not uO and nO > 0 and (not nR or uR) and (not nM or uM): arr = 2
+    elif uO and nR and uR and nM and not uM: arr = 3
+    elif not uO and nO > 0 and nR and not uR and nM and uM: arr = 4
+    elif uO and nR and not uR and nM and uM: arr = 5
+    V = {c: b[c] / avg for c in 'RMO'}
+    vmax = max([V['O']] * (nO > 0) + [V['R']] * (nR > 0) + [V['M']] * (nM > 0))
+    mg = 2e-14 * float(n) * (vmax + 1.0)
+    f = {1: case_a, 2: case_b, 3: case_a2, 4: case_b2, 5: case_a3}.get(arr)
+    return None if f is None else f(G, pick, r2, V, mg, cls[pick] == 'R', cls[pick] == 'M', G.lower(pick))
+
+
+STEP = [None]  # the step function under test (near_step; near_step_exact in mode "exactavg")
+
+
 def check_row(n, cls, b, picks, adversarial, stats):
     """every slot of `picks` of one row against the reference's loop.  adversarial: r2 on the nine
     u / 2^32 grid points around the reference's own probs[pick] -- the draws a random r2 never
@@ -302,7 +330,7 @@ def check_row(n, cls, b, picks, adversarial, stats):
             p0 = w[pick] / avg
             if p0 < 1.0 and r2 < p0: continue  # the quick accept (the kernel's own margin test comes first)
             want = pick if r2 < probs[pick] else alias[pick]
-            got = near_step(n, cls, pick, r2, b)
+            got = (STEP[0] or near_step)(n, cls, pick, r2, b)
             stats[0] += 1
             if got is None: stats[1] += 1
             elif got != want:
@@ -368,6 +396,36 @@ if mode == "adversarial":
         if dyadic_pq(p, q): continue
         check_row(n, random_row(n, p, q), {'R': 1.0 / p, 'M': 1.0, 'O': 1.0 / q}, range(n), True, stats)
         k += 1; rows += 1
+elif mode == "exactavg":
+    # the second stage (round 5): rows of 256 .. N2V_MODEL_NMAX slots (default 20 000), the forms on the
+    # reference's own values with the LINEAR margin, r2 random and adversarial, 48 slots per row + every
+    # return / shared slot of the row's first 200
+    STEP[0] = near_step_exact
+    trials = int(os.environ.get("N2V_MODEL_TRIALS", 60))
+    nmax = int(os.environ.get("N2V_MODEL_NMAX", 20000))
+    k = 0
+    while k < trials:
+        n = int(math.exp(random.uniform(math.log(256), math.log(nmax))))
+        p, q = random.choice(VALS), random.choice(VALS)
+        if dyadic_pq(p, q): continue
+        cls = random_row(n, p, q)
+        if random.random() < 0.5:  # a sparse list, as the rows of a hub have
+            cls = [c if c != 'M' or random.random() < 0.05 else 'O' for c in cls]
+        special = [i for i in range(n) if cls[i] != 'O'][:200]
+        picks = sorted(set(random.sample(range(n), 48) + special))
+        bb = {'R': 1.0 / p, 'M': 1.0, 'O': 1.0 / q}
+        check_row(n, cls, bb, picks, True, stats)
+        rnd = [0, 0, 0]
+        check_row(n, cls, bb, picks, False, rnd)
+        STEP[0] = near_step  # the first stage on the same draws, for comparison
+        first = [0, 0, 0]
+        check_row(n, cls, bb, picks, False, first)
+        STEP[0] = near_step_exact
+        for i in range(3): stats[i] += rnd[i]
+        random_draws = [a + b for a, b in zip(globals().get("random_draws", [0, 0, 0, 0]), rnd + [first[1]])]
+        k += 1; rows += 1
+    print("random r2 only: draws", random_draws[0], "left to the replay by the second stage", random_draws[1],
+          "(by the first stage, counts + n^2 margin:", random_draws[3], ") bad", random_draws[2])
 else:
     trials = int(os.environ.get("N2V_MODEL_TRIALS", 3000 if not big else 150))
     while rows < trials:

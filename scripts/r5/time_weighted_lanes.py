@@ -1,0 +1,36 @@
+"""weighted exact walks at p, q != 1: the lane-per-walker step kernel (n2v_walk_weighted_step) against the
+wave-per-walker kernel (walk_exact_kernel), weighted cfg 2 (R-MAT 1 M / 10 M, fp32 weights U[0.1, 2]):
+  BATCH=47104 PQ="0.5,2.0;3.0,0.7" OLD=1 python scripts/r5/time_weighted_lanes.py"""
+import os, sys, time, torch
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, ROOT)
+from node2vec_amd import synthetic, randomwalk as rw
+from node2vec_amd.graph import DeviceGraph
+base = synthetic.rmat(20, 5_000_000, device="cuda")
+gen = torch.Generator(device="cuda").manual_seed(1)
+kinds = {"fp32": (torch.rand(base.n_edges, generator=gen, device="cuda") * 1.9 + 0.1),
+         "fp64": (torch.rand(base.n_edges, generator=gen, device="cuda", dtype=torch.float64) * 1.9 + 0.1)}
+B = int(os.environ.get("BATCH", 47104))
+for kind in os.environ.get("KINDS", "fp32").split(","):
+    g = DeviceGraph(base.rowptr, base.col, kinds[kind])
+    start_all = rw.start_vertices(g)
+    t0 = time.time(); rw.weighted_lanes_tables(g); torch.cuda.synchronize()
+    print(f"{kind}: per-edge tables of the weighted graph built in {time.time() - t0:.2f} s "
+          f"(wedge lists {g.wedge_pos.numel() * 2 / 1e6:.0f} MB)", flush=True)
+    for pq in os.environ.get("PQ", "0.5,2.0").split(";"):
+        p, q = (float(x) for x in pq.split(","))
+        for batch in sorted({B, min(start_all.numel(), int(os.environ.get("BIG", start_all.numel())))}):
+            start = start_all[:batch].contiguous()
+            best = 1e9
+            for it in range(2):
+                torch.cuda.synchronize(); t = time.time()
+                walks, valid = rw.walk(g, start, 10, 80, p, q, 42, use_weighted_lanes=True)
+                torch.cuda.synchronize(); best = min(best, time.time() - t)
+            steps = int(valid.sum()) * 80
+            print(f"{kind} p={p} q={q} {batch} start vertices: lanes {best * 1e3:8.1f} ms = {steps / best / 1e6:8.1f} M steps/s", flush=True)
+            if os.environ.get("OLD", "1") == "1" and batch == B:
+                torch.cuda.synchronize(); t = time.time()
+                w2, v2 = rw.walk(g, start, 10, 80, p, q, 42, use_weighted_lanes=False)
+                torch.cuda.synchronize(); dt = time.time() - t
+                print(f"{kind} p={p} q={q} {batch} start vertices: wave  {dt * 1e3:8.1f} ms = {steps / dt / 1e6:8.1f} M steps/s "
+                      f"identical={bool(torch.equal(walks, w2) and torch.equal(valid, v2))}", flush=True)

@@ -43,6 +43,18 @@ def test_closed_forms_with_margins_on_adversarial_draws():
     assert int(last[1]) > 400_000 and int(last[3]) < int(last[1])  # many draws, not all declined
 
 
+def test_closed_forms_on_the_exact_average_of_long_rows():
+    """near_forms.py exactavg (round 5): the second stage of the closed forms with margins -- after the row has
+    been added up in the reference's order the forms run on the reference's OWN values with a margin that is
+    linear in n (near_listed_exact) -- on rows of 256 .. 20 000 slots, random and adversarial r2: never wrong."""
+    env = dict(os.environ, N2V_MODEL_TRIALS="24", N2V_MODEL_NMAX="20000")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "models", "near_forms.py"), "exactavg"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    last = res.stdout.strip().splitlines()[-1].split()
+    assert last[0] == "total" and last[-2:] == ["bad", "0"] and int(last[1]) > 5000
+
+
 def test_a_class_exactly_on_the_average_model():
     """lane_case_b2_jump on rows whose "other" slots have excess 0 (scripts/models/flat_b2.py)"""
     env = dict(os.environ, N2V_MODEL_TRIALS="4000")
