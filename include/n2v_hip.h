@@ -658,6 +658,10 @@ int n2v_rank_hops_build(const n2v_graph *g, const int32_t *rank_of, const int32_
  *   mode 4  one dependent chain of random 4-byte reads per lane with a binary search over an LDS
  *           table of row_bytes degree classes (a power of two, 64 .. 8192) between them: a walker on
  *           a graph numbered by descending degree whose entries are the neighbour id alone
+ *   mode 5  the shape of a biased exact step: a dependent chain of hop entries of row_bytes (16 | 8)
+ *           bytes, and with 49 % of the steps an independent 32-byte read of a wedge slot; the buffer
+ *           is cut into E hop entries followed by E slots (E = buffer_bytes / (row_bytes + 32)); six
+ *           waves per SIMD as the walk kernel runs
  * iters: accesses per lane (modes 0, 1) / rows per wave (modes 2, 3), a multiple of 4.
  * *accesses_host (host pointer, optional) receives the number of accesses the launch makes.
  * buffer: 16-byte aligned device memory, overwritten in mode 3.  sink: one device word. */

@@ -12,6 +12,12 @@
 //           vertices are numbered by descending degree (entry = the id alone; row start and degree
 //           follow from the id's class)
 //
+//   mode 5  the shape of a BIASED exact step (n2v_walk_wedge.hip): one dependent chain per lane of hop
+//           entries (`row_bytes` = 16: today's table; 8: the {rank, classes} entry a degree-ranked
+//           table would have), and with every step, for 49 % of the steps (cfg 4's share of edges
+//           with shared neighbours), an independent 32-byte read of the wedge slot of the edge walked
+//           last; buffer = [E hop entries | E slots]; 6 waves per SIMD like the kernel (LDS-limited)
+//
 // Addresses come from the counter-based mixer of the walk RNG: uniform over the buffer, so with
 // a buffer much larger than the 256 MB Infinity Cache every access is a miss.
 #include "n2v_common.h"
@@ -84,6 +90,33 @@ __global__ __launch_bounds__(1024) void probe_class_chain_kernel(const uint32_t 
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// mode 5: hop chain + slot reads, the go / no-go of 8-byte hop entries for the biased kernels
+template <typename T>
+__global__ __launch_bounds__(256) void probe_biased_step_kernel(const T *__restrict__ hops, const uint4 *__restrict__ slots,
+                                                                uint64_t n_el, int iters, uint32_t *sink) {
+  extern __shared__ uint32_t lds_hold[];  // 24 KB per block: six blocks per CU, as the walk kernel has
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (iters < 0) lds_hold[threadIdx.x] = (uint32_t)gid;
+  uint32_t acc = 0;
+  uint64_t idx = mix64(gid) % n_el, prev = mix64(gid + 1) % n_el;
+  for (int k = 0; k < iters; ++k) {
+    const uint64_t bits = mix64(idx ^ (gid + (uint64_t)k * 0x9E3779B97F4A7C15ULL));
+    const bool need_slot = (uint32_t)(bits & 0xff) < 125u;  // 49 %
+    uint4 sa = make_uint4(0, 0, 0, 0), sb = make_uint4(0, 0, 0, 0);
+    if (need_slot) {
+      sa = slots[2 * prev];
+      sb = slots[2 * prev + 1];
+    }
+    const T r = hops[idx];
+    uint32_t lo, hi;
+    if constexpr (sizeof(T) == 8) { lo = r.x; hi = r.y; } else { lo = r.x; hi = r.w; }
+    acc += hi + sa.x + sb.w;
+    prev = idx;
+    idx = mix64(((uint64_t)lo << 32 | hi) ^ (uint64_t)sa.y ^ bits) % n_el;
+  }
+  if (acc == 0x12345678u) sink[0] = acc + lds_hold[0];
+}
+
 template <bool kWrite>
 __global__ __launch_bounds__(256) void probe_rows_kernel(float *t, uint64_t n_rows, int row_floats,
                                                          int iters, uint32_t *sink) {
@@ -129,11 +162,30 @@ __global__ __launch_bounds__(256) void probe_rows_kernel(float *t, uint64_t n_ro
 extern "C" int n2v_mem_probe(void *buffer, int64_t buffer_bytes, int32_t mode, int32_t iters,
                              int32_t row_bytes, int64_t *accesses_host, uint32_t *sink,
                              void *stream) {
-  if (!buffer || !sink || buffer_bytes < 4096 || iters < 4 || (iters & 3) || mode < 0 || mode > 4)
+  if (!buffer || !sink || buffer_bytes < 4096 || iters < 4 || (iters & 3) || mode < 0 || mode > 5)
     return N2V_EINVAL;
   if ((reinterpret_cast<uintptr_t>(buffer) & 15u) != 0) return N2V_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int threads = 256;
+  if (mode == 5) {
+    if (row_bytes != 8 && row_bytes != 16) return N2V_EINVAL;
+    const uint64_t n_el = (uint64_t)(buffer_bytes / (row_bytes + 32)) & ~(uint64_t)1;  // (slots 32-byte aligned)
+    if (n_el < 2) return N2V_EINVAL;
+    const size_t lds = 24 * 1024;
+    const void *fn = row_bytes == 8 ? (const void *)n2v::probe_biased_step_kernel<uint2>
+                                    : (const void *)n2v::probe_biased_step_kernel<uint4>;
+    const int64_t blocks = n2v::resident_blocks(fn, threads, lds);
+    if (accesses_host) *accesses_host = blocks * threads * (int64_t)iters;
+    const uint4 *slots = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(buffer) + n_el * row_bytes);
+    if (row_bytes == 8)
+      hipLaunchKernelGGL(n2v::probe_biased_step_kernel<uint2>, dim3((unsigned)blocks), dim3(threads), lds, st,
+                         (const uint2 *)buffer, slots, n_el, iters, sink);
+    else
+      hipLaunchKernelGGL(n2v::probe_biased_step_kernel<uint4>, dim3((unsigned)blocks), dim3(threads), lds, st,
+                         (const uint4 *)buffer, slots, n_el, iters, sink);
+    N2V_HIP_CHECK(hipGetLastError());
+    return N2V_OK;
+  }
   if (mode == 4) {
     const int classes = row_bytes;  // a power of two
     if (classes < 64 || classes > 8192 || (classes & (classes - 1))) return N2V_EINVAL;

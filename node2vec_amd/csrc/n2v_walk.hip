@@ -647,6 +647,81 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void partition_step_kernel(
   }
 }
 
+// ---- one step of the walkers of a batch that stand on LONG rows (n2v_walk_weighted_step: the
+// lane-per-walker kernel of n2v_walk_wlanes.hip takes the rows of up to `min_n` slots, a lane that
+// walked a row of 10^4 slots alone would be the launch's tail).  The walkers come ordered by the length
+// of the row they stand on, descending; waves take them from a counter (status[1], zero at launch) and a
+// wave leaves when it meets a row that is the lanes'.  The draw is exact_draw above: N(s) read from the
+// graph, the classes by membership search -- no per-edge table needed.
+__global__ __launch_bounds__(kWavesPerBlock * 64) void weighted_step_wave_kernel(
+    n2v_graph g, const int32_t *__restrict__ start_ids, int32_t num_walks,
+    const int64_t *__restrict__ order, int64_t n_rows, int32_t min_n, int32_t step, int32_t walk_length,
+    double p, double q, uint64_t seed, int64_t *__restrict__ edge_state, int32_t *__restrict__ walks,
+    uint8_t *__restrict__ valid, uint32_t *__restrict__ status) {
+  __shared__ WaveLds lds_all[kWavesPerBlock];
+  const int lane = threadIdx.x & 63;
+  WaveLds &L = lds_all[threadIdx.x >> 6];
+#ifdef N2V_STATS
+  WaveStats WS;
+  for (int i = 0; i < 40; ++i) WS.v[i] = 0;
+#endif
+  const int L1 = walk_length + 1;
+  StepCtx c;
+  c.p = p;
+  c.q = q;
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&status[1], 1u);
+    const int64_t i = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (i >= n_rows) break;
+    const int64_t r = readfirstlane_i64(order[i]);
+    if (r < 0 || r >= n_rows) break;  // (the lane kernel flags it)
+    int32_t *row = walks + r * (int64_t)L1;
+    const int32_t v = __builtin_amdgcn_readfirstlane(row[step]);
+    if (v < 0 || (int64_t)v >= g.n_vertices || !valid[r]) break;  // vanished walkers come last in the order
+    const int64_t vb = readfirstlane_i64(g.rowptr[v]);
+    const int n = (int)(readfirstlane_i64(g.rowptr[v + 1]) - vb);
+    if (n <= min_n) break;  // this row and every later one: the lane kernel's
+    const int32_t s = step > 0 ? __builtin_amdgcn_readfirstlane(row[step - 1]) : -1;
+    c.vcol = g.col + vb;
+    c.vw = g.w ? g.w + vb : nullptr;
+    c.vw64 = g.w64 ? g.w64 + vb : nullptr;
+    c.n = n;
+    c.nch = (n + 63) >> 6;
+    c.s = s;
+    const bool first = s < 0;  // randomwalk.py:320-321: unbiased table
+    c.need_cls = !first && !(p == 1.0 && q == 1.0);
+    c.need_mem = c.need_cls && q != 1.0;
+    c.scol = g.col;
+    c.m = 1;
+    c.iters = 1;
+    if (c.need_mem) {
+      const int64_t sb = readfirstlane_i64(g.rowptr[s]);
+      const int64_t se = readfirstlane_i64(g.rowptr[s + 1]);
+      c.scol = g.col + sb;
+      c.m = (int)(se - sb);
+      c.iters = 32 - __clz(c.m > 0 ? c.m : 1);
+    }
+    const uint64_t key = (uint64_t)start_ids[r / num_walks] * (uint64_t)num_walks + (uint64_t)(r % num_walks);
+    const uint64_t bits = step_bits(walker_stream(seed, key), (uint32_t)step);
+    const int idx = exact_draw(c, (uint32_t)(bits >> 32), (uint32_t)bits, lane, L N2V_STATS_PASS);
+    if (lane == 0) {
+      if (idx < 0) {  // ZeroDivisionError (:172-173)
+        atomicOr(status, N2V_ST_ZERODIV);
+        valid[r] = 0;
+      } else {
+        const int32_t x = c.vcol[idx];
+        row[step + 1] = x;
+        edge_state[r] = vb + idx;
+        if (step + 1 < walk_length &&
+            (x < 0 || (int64_t)x >= g.n_vertices || g.rowptr[x + 1] == g.rowptr[x]))
+          valid[r] = 0;  // fugue.py:147
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace n2v
 
 extern "C" int n2v_walk_exact_launch(const n2v_graph *g, const int32_t *start_ids,
@@ -700,3 +775,20 @@ extern "C" int n2v_debug_stats(unsigned long long *out_host, int reset) {
   return 0;
 }
 #endif
+
+// the long rows of n2v_walk_weighted_step (n2v_walk_wlanes.hip): status[1] must be zero at launch
+extern "C" int n2v_weighted_step_wave_launch(const n2v_graph *g, const int32_t *start_ids, int32_t num_walks,
+                                             const int64_t *order, int64_t n_rows, int32_t min_n,
+                                             int32_t step, int32_t walk_length, double p, double q,
+                                             uint64_t seed, int64_t *edge_state, int32_t *walks,
+                                             uint8_t *valid, uint32_t *status, void *stream) {
+  int64_t blocks = (n_rows + n2v::kWavesPerBlock - 1) / n2v::kWavesPerBlock;
+  const int64_t cap = n2v::resident_blocks((const void *)n2v::weighted_step_wave_kernel,
+                                           n2v::kWavesPerBlock * 64, 0);
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(n2v::weighted_step_wave_kernel, dim3((unsigned)blocks), dim3(n2v::kWavesPerBlock * 64), 0,
+                     (hipStream_t)stream, *g, start_ids, num_walks, order, n_rows, min_n, step, walk_length, p, q,
+                     seed, edge_state, walks, valid, status);
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}

@@ -233,8 +233,11 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     return walks, valid.bool() if out is None else valid
 
 
-# Below this many walkers a launch per step cannot win over the one-launch wave-per-walker kernel
-WEIGHTED_LANES_MIN_WALKERS = 4096
+# The lane-per-walker step kernel wins over the one-launch wave-per-walker kernel only when a step has
+# enough walkers to fill the chip beside the wave that stands on the longest row: that wave is the tail of
+# every step (cfg 2 weighted: 78 ms per step whatever the batch; 4.7 M walkers: 53 M steps/s against 35 - 40 M,
+# 0.47 M walkers: 6 M against 34 M -- profiles/r7k_time_wlanes.log)
+WEIGHTED_LANES_MIN_WALKERS = 1 << 21
 
 
 def weighted_lanes_tables(graph: DeviceGraph, insist: bool = False) -> bool:
@@ -265,6 +268,17 @@ def _walk_weighted_lanes(graph: DeviceGraph, start_ids: torch.Tensor, num_walks:
         walks, valid = out
     status = torch.zeros(4, dtype=torch.int32, device=dev)
     deg = graph.degrees().to(torch.int32)
+    # walkers are ordered by the RANK of the vertex they stand on (descending degree, ties by id): rows
+    # of one length come together, and so do the walkers on one and the same row -- a walk stands on a
+    # vertex in proportion to its degree, so most waves have all 64 lanes on one or two rows and their
+    # loads of the row coalesce instead of fetching 64 different lines
+    if getattr(graph, "_degree_rank", None) is None:
+        order0 = torch.sort(deg, descending=True, stable=True).indices
+        rk = torch.empty(graph.n_vertices, dtype=torch.int32, device=dev)
+        rk[order0] = torch.arange(graph.n_vertices, dtype=torch.int32, device=dev)
+        graph._degree_rank = rk
+        del order0
+    rank_of = graph._degree_rank
     s64 = start_ids.long()
     in_range = (s64 >= 0) & (s64 < graph.n_vertices)
     alive = in_range & (deg[s64.clamp(0, max(graph.n_vertices - 1, 0))] > 0)  # fugue.py:132
@@ -278,10 +292,10 @@ def _walk_weighted_lanes(graph: DeviceGraph, start_ids: torch.Tensor, num_walks:
         stream = _lib.current_stream_ptr()
         for step in range(Lw):
             cur = walks[:, step]
-            # the lanes of a wave should stand on rows of about the same length: order the walkers of
-            # this step by the degree of their vertex (vanished walkers last; they are skipped)
-            key = torch.where(valid.bool() & (cur >= 0), deg[cur.clamp(min=0).long()], torch.full_like(cur, -1))
-            order = torch.sort(key, descending=True).indices
+            # (vanished walkers last; they are skipped)
+            key = torch.where(valid.bool() & (cur >= 0), rank_of[cur.clamp(min=0).long()],
+                              torch.full_like(cur, 0x7fffffff))
+            order = torch.sort(key).indices
             _lib.check(L.n2v_walk_weighted_step(g, start_ids.data_ptr(), W, order.data_ptr(), total, step, Lw,
                                                 float(p), float(q), seed & (2 ** 64 - 1),
                                                 edge_state.data_ptr(), walks.data_ptr(), valid.data_ptr(),
