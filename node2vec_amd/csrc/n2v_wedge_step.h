@@ -141,7 +141,32 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
                                           uint32_t u1, uint32_t u2, int32_t s, int64_t vb, int n,
                                           int64_t e_prev, uint32_t ec_prev, n2v_hop &h,
                                           uint32_t *stage, int lane, uint32_t *status,
-                                          uint16_t *lds_list = nullptr) {
+                                          uint16_t *lds_list = nullptr);
+
+// the step of a walker standing on a WIDE row of a mixed wedge table, out of line (N2V_WIDE_NOINLINE):
+// it is taken by a few per cent of the steps at most, and inlined into the slots kernel its 32-bit
+// instances of the closed forms cost every step registers (scratch 24 -> 40 B per lane in <0>, 100 -> 144 in <1>)
+template <int kMode, bool kJumpOnly>
+#ifdef N2V_WIDE_NOINLINE
+__device__ __attribute__((noinline)) int
+#else
+__device__ __forceinline__ int
+#endif
+wedge_step_wide(const n2v_graph &g, const UnitConsts &K, const StepFlags &F, uint32_t u1, uint32_t u2, int32_t s,
+                int64_t vb, int n, int64_t e_prev, uint32_t ec_prev, n2v_hop &h, uint32_t *stage, int lane,
+                uint32_t *status) {
+  StepFlags Fw = F;
+  Fw.w_wide = true;
+  return wedge_step<kMode, kJumpOnly, false>(g, K, Fw, u1, u2, s, vb, n, e_prev, ec_prev, h, stage, lane, status,
+                                             nullptr);
+}
+
+template <int kMode, bool kJumpOnly, bool kSlots>
+__device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &K, const StepFlags &F,
+                                          uint32_t u1, uint32_t u2, int32_t s, int64_t vb, int n,
+                                          int64_t e_prev, uint32_t ec_prev, n2v_hop &h,
+                                          uint32_t *stage, int lane, uint32_t *status,
+                                          uint16_t *lds_list) {
   constexpr bool kShared = kMode == 1 || kMode == 2;
   if constexpr (kSlots) {
     // mixed wedge table (g.wedge_wide = T >= 2): the edges into a row of T entries or more have
@@ -153,10 +178,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
       h = load_hop(g.hops + vb + pk);
       return pk;
 #endif
-      StepFlags Fw = F;
-      Fw.w_wide = true;
-      return wedge_step<kMode, kJumpOnly, false>(g, K, Fw, u1, u2, s, vb, n, e_prev, ec_prev, h, stage, lane,
-                                                 status, nullptr);
+      return wedge_step_wide<kMode, kJumpOnly>(g, K, F, u1, u2, s, vb, n, e_prev, ec_prev, h, stage, lane, status);
     }
   }
   const int pick = pick_index(u1, n);
