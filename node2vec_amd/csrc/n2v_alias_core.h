@@ -43,7 +43,59 @@ struct StepCtx {
   int32_t s;
   bool need_cls, need_mem;
   double p, q;
+  // Optional (round 5): the per-edge tables of the edge (s -> v) walked last -- the shared positions
+  // of N(v) (ascending), the return run -- when the caller has them (n2v_edge_classes_build,
+  // n2v_wedge_build: they depend on the ids alone, weighted graphs have them too).  The classes of the
+  // slots then come from them: no filter over N(s), no membership search, no pass over col.  lst == NULL:
+  // classes by search (rows of another kind: first steps, C callers without the tables).
+  const void *lst = nullptr;
+  int lst_n = 0, lst_wide = 0, rpos = 0, n_ret = 0;
 };
+
+// entry k of the shared-position list of the step (a plain branch on the width)
+__device__ __forceinline__ int lst_at(const StepCtx &c, int k) {
+  if (c.lst_wide) return (int)reinterpret_cast<const uint32_t *>(c.lst)[k];
+  return (int)reinterpret_cast<const uint16_t *>(c.lst)[k];
+}
+// is position i one of the shared positions?  one lane, binary search
+__device__ __forceinline__ bool lst_has(const StepCtx &c, int i) {
+  int lo = 0, hi = c.lst_n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (lst_at(c, mid) < i)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo < c.lst_n && lst_at(c, lo) == i;
+}
+// The shared positions inside [64 chunk, 64 chunk + 64) as a ballot, by the whole wave, from a cursor
+// `lm` (wave-uniform: entries below it lie in earlier chunks) that the call advances.  `flags`: 64 bytes
+// of this wave's LDS, zero on entry and on return.
+__device__ __forceinline__ uint64_t lst_chunk_mask(const StepCtx &c, int chunk, int lane, int &lm,
+                                                   uint8_t *flags) {
+  const int c0 = chunk * 64;
+  bool any = false;
+  for (;;) {
+    const int k = lm + lane;
+    const int pos = k < c.lst_n ? lst_at(c, k) : 0x7fffffff;
+    const bool in = pos < c0 + 64;
+    if (in) flags[pos - c0] = 1;
+    const int cnt = __popcll(ballot64(in));
+    lm += cnt;
+    any = any || cnt > 0;
+    if (cnt < 64) break;  // (64 in range: the next 64 entries may hold more)
+  }
+  if (!any) return 0ull;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const bool mine = flags[lane] != 0;
+  __builtin_amdgcn_wave_barrier();
+  flags[lane] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return ballot64(mine);
+}
 
 // weight of neighbour i of the current row, widened to the fp64 the reference computes in
 // (wave-uniform pointers: the selection is a scalar branch)
@@ -181,6 +233,10 @@ __device__ __forceinline__ double chunk_bias(const StepCtx &c, int chunk, int la
     is_ret = (cls[2 * chunk] >> lane) & 1ull;
     is_mem = (cls[2 * chunk + 1] >> lane) & 1ull;
   } else {
+    if (c.lst) {  // the per-edge tables: the return run by position, the shared slots by a search of the list
+      is_ret = valid && i >= c.rpos && i < c.rpos + c.n_ret;
+      is_mem = c.need_mem && valid && !is_ret && lst_has(c, i);
+    } else {
     int32_t x = valid ? c.vcol[i] : -1;
     is_ret = valid && x == c.s;
     is_mem = false;
@@ -189,6 +245,7 @@ __device__ __forceinline__ double chunk_bias(const StepCtx &c, int chunk, int la
 #else
     if (c.need_mem) is_mem = member_sorted(c.scol, c.m, x, c.iters) && valid && !is_ret;
 #endif
+    }
     if (!kFromCache && chunk < kLdsChunks) {
       uint64_t rm = ballot64(is_ret), mm = ballot64(is_mem);
       if (lane == 0) {

@@ -34,6 +34,7 @@ struct WaveLds {
   int32_t bq[kBqCap];            // b * 2^20 at position n-1-i (valid in exact-sum mode)
   uint32_t bits[kBitWordsMax];   // hashed id filter of N(s)
   int32_t mlist[kMaybeCap];      // indices into N(v) that hit the filter
+  uint8_t flags[64];             // lst_chunk_mask scratch (zero between calls)
 };
 
 struct SumState {
@@ -242,7 +243,7 @@ __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_
 #if defined(N2V_ABLATE) && (N2V_ABLATE & 8)  // timing-only: no filter, no search at all
   const bool use_filter = false;
 #else
-  const bool use_filter = c.need_mem && c.m <= 4096 && c.m <= 8 * n + 64;
+  const bool use_filter = c.lst == nullptr && c.need_mem && c.m <= 4096 && c.m <= 8 * n + 64;
 #endif
   int shift = 32;
   if (use_filter) {
@@ -281,6 +282,8 @@ __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_
   st.bmin = __builtin_huge_val();
   st.bmax = -__builtin_huge_val();
   int mcount = 0;
+  int lm_fwd = 0;  // cursor into the shared-position list (table classes)
+  const bool tables = c.lst != nullptr && c.need_cls;
   constexpr int kU = 4;  // chunks per iteration: 2 * kU global loads in flight per lane
   for (int chunk0 = 0; chunk0 < c.nch; chunk0 += kU) {
     double wf[kU];
@@ -290,12 +293,20 @@ __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_
       const int i = (chunk0 + u) * 64 + lane;
       const bool valid = i < n;
       wf[u] = valid ? weight_at(c, i) : 0.0;
-      xs[u] = (valid && c.need_cls) ? c.vcol[i] : -1;
+      xs[u] = (valid && c.need_cls && !tables) ? c.vcol[i] : -1;
     }
     bool memv[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u) memv[u] = false;
-    if (c.need_mem && !use_filter) {
+    uint64_t tmask[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) tmask[u] = 0ull;
+    if (tables && c.need_mem) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (chunk0 + u < c.nch) tmask[u] = lst_chunk_mask(c, chunk0 + u, lane, lm_fwd, L.flags);
+    }
+    if (c.need_mem && !use_filter && !tables) {
 #if !(defined(N2V_ABLATE) && (N2V_ABLATE & 2))
       member_sorted_x4(c.scol, c.m, xs, c.iters, memv);  // 4 interleaved searches
 #endif
@@ -308,7 +319,17 @@ __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_
       const bool valid = i < n;
       const double wt = wf[u];
       bool is_ret = false, is_mem = false, maybe = false;
-      if (c.need_cls) {
+      if (tables) {
+        is_ret = valid && i >= c.rpos && i < c.rpos + c.n_ret;
+        is_mem = valid && !is_ret && ((tmask[u] >> lane) & 1ull);
+        if (chunk < kLdsChunks) {
+          const uint64_t rm = ballot64(is_ret), mm = ballot64(is_mem);
+          if (lane == 0) {
+            L.cls[2 * chunk] = rm;
+            L.cls[2 * chunk + 1] = mm;
+          }
+        }
+      } else if (c.need_cls) {
         const int32_t x = xs[u];
         is_ret = valid && x == c.s;
         if (use_filter) {
@@ -424,6 +445,25 @@ __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_
   return res2;
 }
 
+// the per-edge tables of the edge walked last into the step context (wave-uniform), when the graph has them
+__device__ __forceinline__ void step_tables(StepCtx &c, const n2v_graph &g, int64_t e_prev) {
+  c.lst = nullptr;
+  if (!c.need_cls || !g.edge_classes || !g.wedge_off || !g.wedge_pos || e_prev < 0 || e_prev >= g.n_edges) return;
+  const uint32_t ec = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.edge_classes[e_prev]);
+  const uint32_t fR = ec >> N2V_EC_RETURN_SHIFT, fM = ec & N2V_EC_SHARED_MASK;
+  if (fR == N2V_EC_RETURN_SAT || fM == N2V_EC_SHARED_MASK) return;  // a saturated count: classes by search
+  const uint64_t wraw = readfirstlane_u64(g.wedge_off[e_prev]);
+  const int rpos = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
+  if ((int64_t)fR + (int64_t)fM > c.n || rpos + (int)fR > c.n) return;  // not a table of this row
+  const uint64_t off = wraw & N2V_WEDGE_OFF_MASK;
+  c.lst_wide = wedge_row_wide(g.wedge_wide, c.n) ? 1 : 0;
+  c.lst = c.lst_wide ? (const void *)(reinterpret_cast<const uint32_t *>(g.wedge_pos) + off)
+                     : (const void *)(reinterpret_cast<const uint16_t *>(g.wedge_pos) + off);
+  c.lst_n = (int)fM;
+  c.rpos = rpos;
+  c.n_ret = (int)fR;
+}
+
 __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double p, double q, uint64_t seed, int32_t *__restrict__ walks_out,
@@ -432,6 +472,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   WaveLds &L = lds_all[wave_in_block];
+  if (lane < 16) reinterpret_cast<uint32_t *>(L.flags)[lane] = 0u;
   const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
   const int64_t total = n_start * (int64_t)num_walks;
   const int L1 = walk_length + 1;
@@ -483,6 +524,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
       alive = false;
     }
     int32_t s = -1, v = start;
+    int64_t e_prev = -1;  // the edge walked last (its per-edge tables say which slots are which)
     if (alive) {
       // fugue.py:132: only vertices with an adjacency row start walks
       int64_t vb = readfirstlane_i64(g.rowptr[v]);
@@ -525,6 +567,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
           c.m = (int)(se - sb);
           c.iters = 32 - __clz(c.m);
         }
+        step_tables(c, g, e_prev);
         const uint64_t bits = step_bits(h0, (uint32_t)step);
         const int idx = exact_draw(c, (uint32_t)(bits >> 32), (uint32_t)bits, lane, L N2V_STATS_PASS);
         if (idx < 0) {
@@ -532,6 +575,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
           alive = false;
           break;
         }
+        e_prev = vb + idx;
         const int32_t next = __builtin_amdgcn_readfirstlane(c.vcol[idx]);
         if (buffered) {
           const int t = step + 1;
@@ -581,6 +625,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void partition_step_kernel(
   __shared__ WaveLds lds_all[kWavesPerBlock];
   const int lane = threadIdx.x & 63;
   WaveLds &L = lds_all[threadIdx.x >> 6];
+  if (lane < 16) reinterpret_cast<uint32_t *>(L.flags)[lane] = 0u;
 #ifdef N2V_STATS
   WaveStats WS;
   for (int i = 0; i < 40; ++i) WS.v[i] = 0;
@@ -661,6 +706,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void weighted_step_wave_kernel
   __shared__ WaveLds lds_all[kWavesPerBlock];
   const int lane = threadIdx.x & 63;
   WaveLds &L = lds_all[threadIdx.x >> 6];
+  if (lane < 16) reinterpret_cast<uint32_t *>(L.flags)[lane] = 0u;
 #ifdef N2V_STATS
   WaveStats WS;
   for (int i = 0; i < 40; ++i) WS.v[i] = 0;
@@ -702,6 +748,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void weighted_step_wave_kernel
       c.m = (int)(se - sb);
       c.iters = 32 - __clz(c.m > 0 ? c.m : 1);
     }
+    step_tables(c, g, first ? -1 : readfirstlane_i64(edge_state[r]));
     const uint64_t key = (uint64_t)start_ids[r / num_walks] * (uint64_t)num_walks + (uint64_t)(r % num_walks);
     const uint64_t bits = step_bits(walker_stream(seed, key), (uint32_t)step);
     const int idx = exact_draw(c, (uint32_t)(bits >> 32), (uint32_t)bits, lane, L N2V_STATS_PASS);

@@ -140,6 +140,11 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
             if use_wedges and graph.wedge_off is None and not graph.wedge_tried:
                 graph.wedge_tried = True
                 graph.build_wedges()
+    elif mode == "exact" and biased and use_edge_classes and use_wedges:
+        # weighted graph, biased exact walk: the per-edge class counts and wedge lists (they depend on
+        # the ids alone) tell both weighted kernels which slots of a step's table are return / shared /
+        # other -- no filter over N(s), no membership search, no pass over col
+        weighted_lanes_tables(graph)
     elif mode == "exact" and not biased and graph.slots is None:
         # the reference's default p = q = 1: every per-step table is the first-order table of
         # the current vertex, i.e. the K1 slots (bit-identical); build them once (milliseconds)
