@@ -264,8 +264,15 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void walk_exact_wed
 #ifndef N2V_SLOTS_WAVES
 #define N2V_SLOTS_WAVES 6
 #endif
+// Instances <1> (the return run shares a stack) and <2> (values that are not dyadic) carry the most code per
+// step; at six waves per SIMD (80 VGPRs) they spill 144 / 132 bytes per lane, at five (96 VGPRs) next to
+// nothing.  The kernel is bound by its sectors, not by its waves, so those two run at five.
+#ifndef N2V_SLOTS_WAVES_BIG
+#define N2V_SLOTS_WAVES_BIG 5
+#endif
 template <int kMode>
-__global__ __launch_bounds__(kWedgeThreads, N2V_SLOTS_WAVES) void walk_exact_wedge_slots_kernel(
+__global__ __launch_bounds__(kWedgeThreads, (kMode == 1 || kMode == 2) ? N2V_SLOTS_WAVES_BIG : N2V_SLOTS_WAVES)
+void walk_exact_wedge_slots_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double q, UnitConsts K, uint64_t seed, int32_t *__restrict__ walks_out,
     uint8_t *__restrict__ valid_out, uint32_t *__restrict__ status) {
