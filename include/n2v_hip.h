@@ -326,9 +326,9 @@ int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_ids, int32_t
  * quick exits and closed forms of the pairing loop (randomwalk.py:182-189) only, each followed by
  * a launch that replays the steps whose closed form declined -- same walks, bit for bit, as
  * n2v_walk (csrc/n2v_walk_wedge2.hip; measured SLOWER than the one-launch kernel on every BASELINE
- * graph, DESIGN.md 5: a tested variant, not a default).  The number of main/replay rounds before
- * the finishing launch is 4; the environment variable N2V_WEDGE2_ROUNDS (0 - 9), read at the call,
- * overrides it -- the one environment variable the library reads.  n2v_walk_workspace_bytes says how many bytes the
+ * graph).  That variant is a BUILD OPTION since round 5 (`make WEDGE2=1`): the default
+ * library reports 0 bytes from n2v_walk_workspace_bytes and n2v_walk_ws is n2v_walk whatever it is lent.
+ * (With the option: 4 main/replay rounds before the finishing launch, N2V_WEDGE2_ROUNDS overrides.)  n2v_walk_workspace_bytes says how many bytes the
  * call can use (0: this graph / mode / (p, q) has no use for one); workspace == NULL, or fewer
  * bytes than that, is n2v_walk.  The workspace must be 16-byte aligned; its contents mean nothing
  * before or after the call, and it may be reused by the next call on the same stream. */

@@ -1702,7 +1702,11 @@ extern "C" int64_t n2v_walk_exact_unit_workspace(const n2v_graph *g, int64_t tot
   bool dyadic = false;
   if (!unit_consts(p, q, K, dyadic) || !dyadic) return 0;
   if (total <= 0 || total >= 0xffffff00ll || walk_length >= 0xfffff0) return 0;
+#ifdef N2V_WITH_WEDGE2
   return n2v_walk_wedge2_workspace(total);
+#else
+  return 0;  // the passes over a workspace (n2v_walk_wedge2.hip) are not part of this build: `make WEDGE2=1`
+#endif
 }
 
 extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_ids,
@@ -1735,6 +1739,7 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
   if (!(p == 1.0 && q == 1.0) && !(g->reserved & 1)) {
     // every per-edge table is at hand and the caller lent a workspace: closed forms in the main
     // launches, declined steps replayed out of line (n2v_walk_wedge2.hip)
+#ifdef N2V_WITH_WEDGE2  // (measured slower than the one-launch kernel on every BASELINE graph: a build option)
     if (workspace) {
       int rounds = 4;
       if (const char *e = getenv("N2V_WEDGE2_ROUNDS")) rounds = atoi(e);
@@ -1743,6 +1748,10 @@ extern "C" int n2v_walk_exact_unit_try(const n2v_graph *g, const int32_t *start_
                                          rounds, stream);
       if (r2 != 0) return r2;
     }
+#else
+    (void)workspace;
+    (void)workspace_bytes;
+#endif
     // every per-edge table is at hand: the kernel in which no step needs the wave
     const int rw = n2v_walk_wedge_try(g, start_ids, n_start, num_walks, walk_length, p, q, K, seed,
                                       walks_out, valid_out, status, stream);

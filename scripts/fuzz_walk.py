@@ -106,11 +106,14 @@ while time.time() - t0 < budget:
     # unit weights, dyadic p, q: the lanes kernel (per-edge class counts) by default, the
     # wave-per-walker kernel without them -- both must match
     uec = bool(rng.random() < 0.7)
-    # the passes of n2v_walk_ws (dyadic p, q with all tables): any number of main / resolve rounds
-    # before the finishing launch must give the same walks
+    # the passes of n2v_walk_ws (a `make WEDGE2=1` build; the default library ignores the workspace): any
+    # number of main / resolve rounds before the finishing launch must give the same walks
     os.environ["N2V_WEDGE2_ROUNDS"] = str(int(rng.choice([0, 1, 2, 4, 9])))
+    # weighted graphs: the lane-per-walker step kernel / a wave per walker with table classes / by search
+    wlanes = bool(rng.random() < 0.5)
     got, gv = rw.walk(g, starts, nw, wl, p, q, seed, use_edge_classes=uec,
-                      use_workspace=bool(rng.random() < 0.3), use_wedge_slots=bool(rng.random() < 0.7))
+                      use_workspace=bool(rng.random() < 0.3), use_wedge_slots=bool(rng.random() < 0.7),
+                      use_weighted_lanes=wlanes)
     want, wv = n2v_oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.w.cpu().numpy(),
                                       starts.cpu().numpy(), nw, wl, p, q, seed, n_threads=THREADS)
     ok = np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy(), want)
@@ -143,7 +146,7 @@ while time.time() - t0 < budget:
         bad = np.nonzero((got.cpu().numpy() != want).any(1) | (gv.cpu().numpy() != wv))[0][:5]
         print("MISMATCH", dict(kind=kind, nv=nv, ne=len(src), weights=wk, p=p, q=q, nw=nw, wl=wl, seed=seed,
                                maxdeg=int(deg.max()), unit=g.unit_weights, edge_classes=uec,
-                               wide_from=g.WEDGE_WIDE_FROM, wedge_mode=g.wedge_mode), "rows", bad.tolist(), flush=True)
+                               wide_from=g.WEDGE_WIDE_FROM, wedge_mode=g.wedge_mode, weighted_lanes=wlanes), "rows", bad.tolist(), flush=True)
         for r in bad[:2]:
             print(" got ", got[r].tolist()[:12], "\n want", want[r].tolist()[:12])
         sys.exit(1)
