@@ -41,6 +41,16 @@ struct SumState {
   int64_t isum;
   bool exact;
   double b_pick, bmin, bmax;
+  // (round 5) the row sum when its additions are exact in ANY order: every addend a multiple of
+  // G = 2^e_min (the lowest set bit of any addend) and the whole sum below 2^53 G -- then every partial sum
+  // of the reference's left-to-right loop is representable, nothing is ever rounded, and the sum of the
+  // lanes' partial sums is the reference's sum bit for bit.  fp32 weights with p, q powers of two (24-bit
+  // addends), integer and short decimal weights: the 10^3 - 10^4 serial additions of a step (a third of
+  // this kernel's cycles, profiles/r03g_walk_stats_generic_cfg2.log) become one wave reduction.
+  double psum;
+  int e_min;     // min over the addends > 0 of the exponent of their lowest set bit
+  bool grid_ok;  // no addend negative / infinite / NaN
+  bool track;    // wave-uniform: still worth tracking (the test can only get harder as the row goes by)
 };
 
 __device__ __forceinline__ void account(SumState &st, WaveLds &L, const StepCtx &c, int i,
@@ -49,6 +59,18 @@ __device__ __forceinline__ void account(SumState &st, WaveLds &L, const StepCtx 
   const bool ok = (t >= 0.0) && (t < 2147483648.0) && (t == trunc(t));
   st.exact = st.exact && (ok || !act);
   st.isum += (ok && act) ? (int64_t)t : 0;
+  if (act && st.track) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(b);
+    const int ex = (int)((bits >> 52) & 0x7ffull);
+    if ((bits >> 63) != 0ull || ex == 0x7ff) {
+      st.grid_ok = st.grid_ok && b == 0.0;  // (-0.0 is a harmless addend)
+    } else if (b != 0.0) {
+      const unsigned long long man = (bits & 0xfffffffffffffull) | (ex ? (1ull << 52) : 0ull);
+      const int e_lsb = (ex ? ex : 1) - 1075 + (int)__builtin_ctzll(man);
+      st.e_min = e_lsb < st.e_min ? e_lsb : st.e_min;
+      st.psum += b;
+    }
+  }
   if (act) {
     const int pos = c.n - 1 - i;
     if (pos < kBqCap) L.bq[pos] = ok ? (int32_t)t : 0;
@@ -57,6 +79,23 @@ __device__ __forceinline__ void account(SumState &st, WaveLds &L, const StepCtx 
   }
   const uint64_t pm = ballot64(act && i == pick);
   if (pm) st.b_pick = readlane_f64(b, __ffsll((long long)pm) - 1);
+}
+
+// are the additions of this row's sum exact in any order?  (wave-uniform answer)
+__device__ __forceinline__ bool sum_any_order(const SumState &st, int n) {
+  if (!st.track || ballot64(!st.grid_ok) != 0ull) return false;
+  int e_min = st.e_min;
+  double bmax = st.bmax;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int eo = __shfl_xor(e_min, off, 64);
+    e_min = eo < e_min ? eo : e_min;
+    bmax = fmax(bmax, __shfl_xor(bmax, off, 64));
+  }
+  if (e_min == 0x7fffffff) return true;        // every addend is 0
+  if (e_min < -1000 || !(bmax < 0x1p1000)) return false;
+  // n addends of at most bmax: the sum stays below 2^52 G (one bit to spare)
+  return (double)n * bmax < ldexp(1.0, 52 + e_min);
 }
 
 // exact membership for the filter hits collected in L.mlist[0, count)
@@ -278,6 +317,10 @@ __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_
   SumState st;
   st.isum = 0;
   st.exact = true;
+  st.psum = 0.0;
+  st.e_min = 0x7fffffff;
+  st.grid_ok = true;
+  st.track = true;
   st.b_pick = 0.0;
   st.bmin = __builtin_huge_val();
   st.bmax = -__builtin_huge_val();
@@ -367,6 +410,9 @@ __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_
         mcount += cnt;
       }
     }
+    // full-width addends (w / q with q not a power of two, fp64 weights): hopeless after the first chunks --
+    // e_min only falls and bmax only grows -- so the bookkeeping stops (a uniform branch)
+    if (chunk0 == 0 && st.track && n > 256) st.track = sum_any_order(st, n);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -388,6 +434,11 @@ __device__ __forceinline__ int exact_draw(const StepCtx &c, uint32_t u1, uint32_
     // (a shuffle reduction is lane-varying to the compiler: make the sum a scalar so that
     // avg, the shortcuts and the pairing loops below stay wave-uniform)
     total = (double)readfirstlane_i64(wave_sum_i64(st.isum)) * (1.0 / 1048576.0);
+  } else if (sum_any_order(st, n)) {
+    double ps = st.psum;  // exact additions: any tree gives the reference's bits
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ps += __shfl_xor(ps, off, 64);
+    total = readfirstlane_f64(ps);
   } else {
     total = 0.0;  // left to right, one rounding per add
     for (int chunk = 0; chunk < c.nch; ++chunk) {
@@ -464,7 +515,7 @@ __device__ __forceinline__ void step_tables(StepCtx &c, const n2v_graph &g, int6
   c.n_ret = (int)fR;
 }
 
-__global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
+__global__ __launch_bounds__(kWavesPerBlock * 64, 7) void walk_exact_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
     int32_t walk_length, double p, double q, uint64_t seed, int32_t *__restrict__ walks_out,
     uint8_t *__restrict__ valid_out, uint32_t *__restrict__ status) {
@@ -615,7 +666,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void walk_exact_kernel(
 // table, the same uniforms (keyed by walker and step, not by where the walker is), hence the
 // same vertex as n2v_walk on the whole graph.  One wave per walker, taken from a counter.
 // head: int64 [k, 4] = (output row, RNG key, s << 32 | v, step); s == -1 on the first step.
-__global__ __launch_bounds__(kWavesPerBlock * 64) void partition_step_kernel(
+__global__ __launch_bounds__(kWavesPerBlock * 64, 7) void partition_step_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ w, const double *__restrict__ w64, int64_t lo, int64_t n_local,
     const int64_t *__restrict__ head, int head_cols, const int64_t *__restrict__ src_ptr,
@@ -698,7 +749,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void partition_step_kernel(
 // of the row they stand on, descending; waves take them from a counter (status[1], zero at launch) and a
 // wave leaves when it meets a row that is the lanes'.  The draw is exact_draw above: N(s) read from the
 // graph, the classes by membership search -- no per-edge table needed.
-__global__ __launch_bounds__(kWavesPerBlock * 64) void weighted_step_wave_kernel(
+__global__ __launch_bounds__(kWavesPerBlock * 64, 7) void weighted_step_wave_kernel(
     n2v_graph g, const int32_t *__restrict__ start_ids, int32_t num_walks,
     const int64_t *__restrict__ order, int64_t n_rows, int32_t min_n, int32_t step, int32_t walk_length,
     double p, double q, uint64_t seed, int64_t *__restrict__ edge_state, int32_t *__restrict__ walks,
