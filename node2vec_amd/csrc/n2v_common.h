@@ -151,11 +151,34 @@ __device__ __forceinline__ int wedge_at_t(const void *base, int64_t k) {
   return (int)reinterpret_cast<const P *>(base)[k];
 }
 
-// is `pos` one of the (ascending) positions list[0, cnt)?  one lane
+// Entries of the ascending list a[0, cnt) below `pos` (its lower bound), by one lane.  A plain binary search
+// is a chain of log2(cnt) DEPENDENT probes, and on the lists of a hub row (10^3 - 10^4 entries: graphs trimmed
+// at the reference's own cap of 100 000) nearly every probe is a cache miss: the closed forms of a pairing
+// there make 2 - 4 such searches, 10 - 25 k cycles in all (profiles/r7f_big_stats.log).  So a long range is
+// cut by SEVEN evenly spaced probes at a time -- independent loads, one round trip -- to an eighth, and
+// only the last 64 entries (two or three sectors) are searched by halving.
+#ifndef N2V_LIST_KARY
+#define N2V_LIST_KARY 1
+#endif
 template <typename P>
-__device__ __forceinline__ bool wedge_has_t(const void *base, int64_t off, int cnt, int pos) {
-  const P *a = reinterpret_cast<const P *>(base) + off;
+__device__ __forceinline__ int list_lower_bound(const P *a, int cnt, int pos) {
   int lo = 0, hi = cnt;
+#if N2V_LIST_KARY
+  while (hi - lo > 64) {
+    const int step = (hi - lo) >> 3;
+    int v[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = (int)a[lo + (k + 1) * step];
+    int below = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) below += v[k] < pos ? 1 : 0;
+    // the pivots below `pos` are the first `below` of them (the list ascends)
+    const int nlo = below == 0 ? lo : lo + below * step + 1;
+    const int nhi = below == 7 ? hi : lo + (below + 1) * step;
+    lo = nlo;
+    hi = nhi;
+  }
+#endif
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
     if ((int)a[mid] < pos)
@@ -163,6 +186,14 @@ __device__ __forceinline__ bool wedge_has_t(const void *base, int64_t off, int c
     else
       hi = mid;
   }
+  return lo;
+}
+
+// is `pos` one of the (ascending) positions list[0, cnt)?  one lane
+template <typename P>
+__device__ __forceinline__ bool wedge_has_t(const void *base, int64_t off, int cnt, int pos) {
+  const P *a = reinterpret_cast<const P *>(base) + off;
+  const int lo = list_lower_bound<P>(a, cnt, pos);
   if (lo >= cnt) return false;
   return (int)a[lo] == pos;
 }
@@ -172,14 +203,7 @@ template <typename P>
 __device__ __forceinline__ int wedge_lower_t(const void *base, int64_t off, int cnt, int pos,
                                              bool &found) {
   const P *a = reinterpret_cast<const P *>(base) + off;
-  int lo = 0, hi = cnt;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if ((int)a[mid] < pos)
-      lo = mid + 1;
-    else
-      hi = mid;
-  }
+  const int lo = list_lower_bound<P>(a, cnt, pos);
   found = false;
   if (lo < cnt) found = (int)a[lo] == pos;
   return lo;
@@ -240,13 +264,7 @@ __device__ __forceinline__ int slot_lower(const int4 &sa, const int4 &sb, int nM
   int lo = j == 0 ? 0 : (int)(((int64_t)j * nM) / 9) + 1;
   int hi = j == kSlotPivots ? nM : (int)(((int64_t)(j + 1) * nM) / 9);
   const int top = hi;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if ((int)list[mid] < pick)
-      lo = mid + 1;
-    else
-      hi = mid;
-  }
+  lo += list_lower_bound<uint16_t>(list + lo, hi - lo, pick);
   if (lo < nM) {
     int e = 0;  // list[lo]: the pivot itself when the search ran to the end of its ninth
     if (lo == top && j < kSlotPivots) {

@@ -216,14 +216,7 @@ __device__ __forceinline__ int lane_case_a(int n, int pick, double r2, double vR
   int km = nM - 1, kr = nR - 1;  // next shared / return slot, descending
   int rank = -1;                 // pick is the (rank + 1)-th "other" slot from the top
   if (!pickR && !pickM) {
-    int lo = 0, hi = nM;  // entries of the list above pick
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if ((int)list[mid] <= pick)
-        lo = mid + 1;
-      else
-        hi = mid;
-    }
+    const int lo = list_lower_bound<P>(list, nM, pick + 1);  // entries of the list at or below pick
     int above_r = rpos + nR - 1 - pick;
     above_r = above_r < 0 ? 0 : (above_r > nR ? nR : above_r);
     rank = (n - 1 - pick) - (nM - lo) - above_r;
@@ -346,15 +339,7 @@ __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, cons
   if (nR > 0 && nM > 0) {
     int lo = below;  // entries of the list below the return position: stored with the wedge slot,
     if (lo < 0) {    // else searched (probes of the list are requests the kernel is bound by)
-      lo = 0;
-      int hi = nM;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if ((int)list[mid] < rpos)
-          lo = mid + 1;
-        else
-          hi = mid;
-      }
+      lo = list_lower_bound<P>(list, nM, rpos);
     }
     mA = nM - lo;
   }
@@ -435,15 +420,7 @@ __device__ __forceinline__ int lane_case_b_jump(int n, int pick, double r2, cons
   if (nO <= 0 || !(e > 0.0) || (nM > 0 && !(dM > 0.0)) || (nR > 0 && !(dR > 0.0))) return -1;
   if (dn * isum > 2.0e14 || dn * dn * K.fO > 4.0e15) return -1;
   auto list_lower = [&](int pos) -> int {  // entries of the list below pos
-    int lo = 0, hi = nM;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if ((int)list[mid] < pos)
-        lo = mid + 1;
-      else
-        hi = mid;
-    }
-    return lo;
+    return list_lower_bound<P>(list, nM, pos);
   };
   int mA = nM;  // shared slots above the return run come first in descending order
   if (nR > 0 && nM > 0) mA = nM - (below >= 0 ? below : list_lower(rpos));
@@ -617,15 +594,7 @@ __device__ __forceinline__ int lane_case_b(int n, int pick, double r2, double vR
                                            bool pickR, bool pickM) {
   const int nO = n - nR - nM;
   auto list_lower = [&](int pos) -> int {  // entries of the list below pos
-    int lo = 0, hi = nM;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if ((int)list[mid] < pos)
-        lo = mid + 1;
-      else
-        hi = mid;
-    }
-    return lo;
+    return list_lower_bound<P>(list, nM, pos);
   };
   auto specials_ge = [&](int pos) -> int {
     int r = rpos + nR - pos;
@@ -736,15 +705,7 @@ struct TwoOnStack {
   int n, nR, rpos, nM, nO, rho, nS;  // nS = nO + nR slots on the mixed stack
   const P *list;
   __device__ __forceinline__ int list_lower(int pos) const {  // entries of the list below pos
-    int lo = 0, hi = nM;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if ((int)list[mid] < pos)
-        lo = mid + 1;
-      else
-        hi = mid;
-    }
-    return lo;
+    return list_lower_bound<P>(list, nM, pos);
   }
   // `below`: the number of listed slots below the return position when the caller has it stored
   // (wedge slots), else -1 and the list is searched

@@ -67,15 +67,7 @@ __device__ __forceinline__ int lane_case_a_near(int n, int pick, double r2, cons
   if (nR > 0 && nM > 0) {
     int lo = below;
     if (lo < 0) {
-      lo = 0;
-      int hi = nM;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if ((int)list[mid] < rpos)
-          lo = mid + 1;
-        else
-          hi = mid;
-      }
+      lo = list_lower_bound<P>(list, nM, rpos);
     }
     mA = nM - lo;
   }
@@ -142,15 +134,7 @@ __device__ __forceinline__ int lane_case_b_near(int n, int pick, double r2, cons
   const double e = V.vO - 1.0, dR = 1.0 - V.vR, dM = 1.0 - V.vM;
   if (nO <= 0 || !(e > mg) || (nM > 0 && !(dM > mg)) || (nR > 0 && !(dR > mg))) return -1;
   auto list_lower = [&](int pos) -> int {
-    int lo = 0, hi = nM;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if ((int)list[mid] < pos)
-        lo = mid + 1;
-      else
-        hi = mid;
-    }
-    return lo;
+    return list_lower_bound<P>(list, nM, pos);
   };
   int mA = nM;
   if (nR > 0 && nM > 0) mA = nM - (below >= 0 ? below : list_lower(rpos));

@@ -287,6 +287,9 @@ void walk_exact_wedge_slots_kernel(
 #ifdef N2V_NEAR_COUNT
   n2v_count_words = status;
 #endif
+#if defined(N2V_BIG_STATS) && defined(N2V_BIG_DECLINES)
+  n2v_big_words = status;
+#endif
   const bool base_aligned = (reinterpret_cast<uintptr_t>(walks_out) & 63u) == 0;
 
   int64_t w0 = 0;  // absolute word index of path position 0 of the current walker

@@ -17,6 +17,9 @@ namespace n2v {
 #ifdef N2V_NEAR_COUNT
 __device__ uint32_t *n2v_count_words;  // = status of the launch (set by the kernel's first lines)
 #endif
+#if defined(N2V_BIG_STATS) && defined(N2V_BIG_DECLINES)
+__device__ uint32_t *n2v_big_words;
+#endif
 
 // the pairing loop for slot `pick` by one lane: closed form by arrangement `arr` (see the kernel),
 // else -- fp64 rounding decides the draw: a tie or a thin margin -- the replays.
@@ -55,6 +58,9 @@ __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, 
     atomicAdd(n2v_count_words + 2, 1u);
     if (res < 0) atomicAdd(n2v_count_words + 3, 1u);
   }
+#endif
+#if defined(N2V_BIG_STATS) && defined(N2V_BIG_DECLINES)  // diagnostic: [2] then counts the big-row pairings the closed forms DECLINED
+  if (n >= N2V_BIG_STATS && res < 0) atomicAdd(n2v_big_words + 2, 1u);
 #endif
   if (res >= 0) return res;
   if constexpr (kMode == 2) {
@@ -415,7 +421,9 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
     }
 #ifdef N2V_BIG_STATS
     if (n >= N2V_BIG_STATS && idx >= 0) {
+#ifndef N2V_BIG_DECLINES
       atomicAdd(status + 2, 1u);
+#endif
       atomicAdd(status + 3, (uint32_t)((__builtin_readcyclecounter() - big_t0) >> 8));
     }
 #endif
