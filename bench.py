@@ -81,6 +81,8 @@ def parse(argv=None):
     ap.add_argument("--trim", type=int, default=-1,
                     help="out-degree cap of trim_hotspot_vertices (-1 = the config's, 10000; 100000 = the "
                          "reference's default cap, constants.py:6; 0 = no trim)")
+    ap.add_argument("--no-ref-cap", action="store_true",
+                    help="skip the legs on the graph trimmed at the reference's default cap (100 000)")
     ap.add_argument("--no-audition", action="store_true",
                     help="take the first output buffer the allocator hands out (no placement audition)")
     ap.add_argument("--spawn", action="store_true",
@@ -465,6 +467,14 @@ def main():
     g.wedge_slots = g.rank_hops = g.rank_of = g.rank_vertex = None
     torch.cuda.empty_cache()
 
+    # ---- the same graph trimmed at the REFERENCE's default cap (constants.py:6: 100 000; randomwalk.py:252-253)
+    # instead of the examples' 10 000: rows of 65 536 slots and more (mixed wedge table), hub lists of thousands
+    # of entries.  Two legs: p = q = 1 as fit_streaming launches it, and the exact biased kernel at (0.5, 2).
+    if not args.no_ref_cap and cfg["gen"] == "chung_lu" and setup["trim_cap"] not in (0, 100_000):
+        out_cap = bench_reference_cap(args, cfg, torch, dist, rw, dev, W, L, rank, world, barrier, use_dist, setup)
+        if rank == 0 and out_cap:
+            out["reference_trim_cap"] = out_cap
+
     # ---- SGNS on the config's model ------------------------------------------------------------
     model = None
     if not args.no_sgns:
@@ -483,6 +493,37 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_reference_cap(args, cfg, torch, dist, rw, dev, W, L, rank, world, barrier, use_dist, setup):
+    """the workload's graph trimmed at 100 000 (trim_index(max_out_deg=0), the reference's default): exact
+    p = q = 1 (ranks out) and exact (0.5, 2), K launches each"""
+    sub = {}
+    g2 = build_graph(cfg, torch, dev, sub, trim=100_000)
+    if int(g2.degrees().max()) < 65536:
+        return None
+    start2 = rw.start_vertices(g2)
+    res = {"trim_cap": 100_000, "n_edges": g2.n_edges, "max_out_degree": int(g2.degrees().max()),
+           "share_of_steps_on_rows_of_65536_or_more": float(g2.degrees()[g2.degrees() >= 65536].sum()) / g2.n_edges}
+    g2.build_ranked()
+    for name, (p2, q2), in_ranks in (("exact_pq1_ranks_out", (1.0, 1.0), g2.rank_hops is not None),
+                                     ("exact_biased_0.5_2", BIASED_PQ, False)):
+        if (p2, q2) != (1.0, 1.0):
+            prepare_tables(torch, g2, p2, q2, "exact", sub, "cap")
+        leg = WalkLeg(torch, rw, g2, start2, W, L, p2, q2, "exact", cfg["biased_batch"], rank, world,
+                      rank_ids=in_ranks, audition=not args.no_audition)
+        r = leg.run(args.steps, args.warmup, barrier)
+        e, s_ = reduce_job(torch, dist, use_dist, dev, r["elapsed"], r["steps_done"])
+        res[name] = {"value": s_ / e, "unit": "walk-steps/s", "ms_per_step": 1e3 * e / args.steps,
+                     "kernel": kernel_name(g2, p2, q2)}
+        del leg
+        torch.cuda.empty_cache()
+    res["wedge_table"] = {"mode": int(g2.wedge_mode), "slots": g2.wedge_slots is not None,
+                          "note": "65536 = mixed: only the lists of the edges into rows of >= 65536 slots are 32-bit"}
+    setup["reference_cap_tables_s"] = {k: v for k, v in sub.items() if k.endswith("_s")}
+    del g2
+    torch.cuda.empty_cache()
+    return res
 
 
 def ordered_line(out):
@@ -514,7 +555,9 @@ def ordered_line(out):
             "exact_pq1_ranks_out": out["value"], "exact_pq1_vertex_ids_out": out.get("value_vertex_ids"),
             "exact_biased_0.5_2": (out.get("biased") or {}).get("value"),
             **{"exact_%g_%g" % (r["p"], r["q"]): r["value"] for r in out.get("biased_other_regimes", [])},
-            "fast_0.5_2": (out.get("fast_mode") or {}).get("value")},
+            "fast_0.5_2": (out.get("fast_mode") or {}).get("value"),
+            "trim_cap_100000_exact_pq1_ranks_out": ((out.get("reference_trim_cap") or {}).get("exact_pq1_ranks_out") or {}).get("value"),
+            "trim_cap_100000_exact_biased_0.5_2": ((out.get("reference_trim_cap") or {}).get("exact_biased_0.5_2") or {}).get("value")},
         "walk_roofline_frac": {"exact_pq1_ranks_out": frac(out),
                                "exact_pq1_vertex_ids_out": None if "roofline_vertex_ids" not in out
                                else round(out["roofline_vertex_ids"]["frac"], 4),
@@ -658,14 +701,13 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
          "wedge_table": ":wedges" in kernel_key,
          "kernel_ms": 1e3 * res["kernel_s"],
          "output_buffer_audition": getattr(leg, "audition", None) or None,
-         "achieved_from": "ALGORITHMIC bytes of the kernel (formula below) x walk-steps per launch / "
-                          "HIP-event duration of the launch",
+         "achieved_from": "algorithmic bytes (formula below) x walk-steps per launch / HIP-event duration",
          "frac_algorithmic": ach / HBM_PEAK,
          "algorithmic_bytes_per_launch": alg_launch, "algorithmic_bytes_per_walk_step": alg,
          "algorithmic_formula": formula,
          "traffic_committed_source": None if not traffic else
-         "profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-         "command on an earlier box (a committed measurement, not observed in this run)"}
+         "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command: committed, "
+         "not observed in this run)"}
     if traffic:
         # counter bytes: what crossed the memory side of L2.  The walk kernels' reads are random
         # gathers and each costs one 64-byte sector whatever it uses of it

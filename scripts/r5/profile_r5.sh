@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # (--no-audition: every launch of a walk kernel then has the bench size, so that the kernel-trace
 # average of a kernel is the HIP-event average of the bench line taken in the same run)
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-regimes --no-hub --no-audition $*"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-regimes --no-hub --no-audition --no-ref-cap $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $ARGS > $OUT/pmc_write.log 2>&1
