@@ -160,11 +160,14 @@ __device__ __forceinline__ int wedge_at_t(const void *base, int64_t k) {
 #ifndef N2V_LIST_KARY
 #define N2V_LIST_KARY 1
 #endif
+#ifndef N2V_LIST_KARY_MIN
+#define N2V_LIST_KARY_MIN 64  // ranges above this many entries are cut 8-ary; below, by halving
+#endif
 template <typename P>
 __device__ __forceinline__ int list_lower_bound(const P *a, int cnt, int pos) {
   int lo = 0, hi = cnt;
 #if N2V_LIST_KARY
-  while (hi - lo > 64) {
+  while (hi - lo > N2V_LIST_KARY_MIN) {
     const int step = (hi - lo) >> 3;
     int v[7];
 #pragma unroll
