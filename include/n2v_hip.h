@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define N2V_ABI_VERSION 10
+#define N2V_ABI_VERSION 11
 
 #define N2V_OK 0
 #define N2V_EINVAL (-1)  /* maps to ValueError (randomwalk.py:212-217)      */
@@ -554,6 +554,9 @@ int n2v_corpus_index(const int32_t *walks, const uint8_t *valid, const int32_t *
  *                              neither N(s) nor a pass over N(v) is needed.  With q == 1 the
  *                              lists are empty (only the return run matters), with p == q == 1
  *                              nothing is read beyond the first four header words
+ *   A header whose output row (head[i][0]) is NEGATIVE is an EMPTY SLOT of a capacity-bounded
+ *   mailbox: n2v_partition_step draws nothing for it and n2v_partition_forward neither logs nor
+ *   forwards it, so a mailbox of fixed capacity can be stepped whole, without its count on the host.
  *   next_out  int32 [k]: the vertex drawn (-1 when status reports an error for that walker)
  *   edge_out  int64 [k] or NULL: the index (into the part's col) of the edge drawn
  *   status    uint32 [4] as for n2v_walk; [1] is used as the walker counter.
@@ -628,6 +631,22 @@ int n2v_partition_forward(const int64_t *head_in, int32_t head_cols, const int32
                           int64_t *box_head, int64_t *box_off, int32_t *box_words,
                           unsigned long long *box_count, int64_t cap, int64_t wcap, int64_t *log_out,
                           int32_t *walks_out, uint8_t *valid_out, uint32_t *status, void *stream);
+/* n2v_partition_forward into mailboxes with a capacity PER DESTINATION, laid out back to back (what an
+ * all-to-all with fixed split sizes sends as it lies): box_starts int64 [2 * n_parts + 2] -- mailbox d
+ * is box_head / box_off [box_starts[d], box_starts[d + 1]), its word pool box_words
+ * [box_starts[n_parts + 1 + d], box_starts[n_parts + 2 + d]); box_off holds the list start INSIDE the
+ * pool of its destination.  The path records go to log_out.  With empty slots (see n2v_partition_step)
+ * this is the step of a rank of a multi-GPU walk that reads nothing on the host: capacities fixed
+ * once, overflow reported in the status word (N2V_ST_OVERFLOW) and looked at after the last step.
+ * Replaces the shuffle of fugue.py:146-149. */
+int n2v_partition_forward_boxes(const int64_t *head_in, int32_t head_cols, const int32_t *next,
+                                const int64_t *edge, int64_t k, int32_t walk_length,
+                                const int64_t *bounds, int32_t n_parts, int32_t carry,
+                                const uint32_t *edge_classes, const uint64_t *wedge_off,
+                                const void *wedge_pos, int32_t wide, int64_t *box_head, int64_t *box_off,
+                                int32_t *box_words, unsigned long long *box_count,
+                                const int64_t *box_starts, int64_t *log_out, uint32_t *status,
+                                void *stream);
 int n2v_gather_rows(const int64_t *ptr, const int32_t *ids, const int64_t *rows,
                     const int64_t *out_ptr, int64_t k, int32_t *out, void *stream);
 int n2v_gather_wedges(const uint32_t *edge_classes, const uint64_t *wedge_off, const void *wedge_pos,

@@ -322,7 +322,8 @@ __global__ __launch_bounds__(kFwdThreads) void n2v_partition_forward_kernel(
     int n_parts, int carry, const uint32_t *__restrict__ edge_classes,
     const uint64_t *__restrict__ wedge_off, const void *__restrict__ wedge_pos, int wide,
     int64_t *__restrict__ box_head, int64_t *__restrict__ box_off, int32_t *__restrict__ box_words,
-    unsigned long long *__restrict__ box_count, int64_t cap, int64_t wcap, int64_t *__restrict__ log_out,
+    unsigned long long *__restrict__ box_count, int64_t cap, int64_t wcap,
+    const int64_t *__restrict__ box_starts, int64_t *__restrict__ log_out,
     int32_t *__restrict__ walks_out, uint8_t *__restrict__ valid_out, uint32_t *__restrict__ status) {
   // Same-address atomics serialise in L2 (~0.1 us each): one per wave and destination made this
   // kernel take 0.85 ms for 6 x 10^5 walkers.  So the block counts first -- walkers and words per
@@ -335,7 +336,9 @@ __global__ __launch_bounds__(kFwdThreads) void n2v_partition_forward_kernel(
   const int64_t k_up = (k + kFwdThreads - 1) / kFwdThreads * kFwdThreads;  // whole blocks stay in the loop
   for (int64_t i = (int64_t)blockIdx.x * kFwdThreads + threadIdx.x; i < k_up;
        i += (int64_t)gridDim.x * kFwdThreads) {
-    const bool have = i < k;
+    // (a header whose output row is negative is an empty slot of a capacity-bounded mailbox: nothing is
+    // logged or forwarded for it)
+    const bool have = i < k && head_in[i * head_cols] >= 0;
     int64_t row = 0, key = 0, v = 0, step = 0, src = 0;
     int32_t nx = -1;
     int dest = -1;  // -1: not forwarded
@@ -428,20 +431,31 @@ __global__ __launch_bounds__(kFwdThreads) void n2v_partition_forward_kernel(
       woff = (int64_t)basew[dest] + cntw[wv][dest] + (int64_t)wrank;  // inside the pool of `dest`
     }
     __syncthreads();  // (cnt is cleared at the top of the next pass)
-    bool fits = dest >= 0 && pos < cap && woff + (int64_t)len <= wcap;
+    // where the mailbox and the word pool of `dest` start and how much they hold: equal shares of the
+    // arrays, or (box_starts) ragged ones -- a capacity per destination
+    int64_t hstart = 0, hcap = 0, wstart = 0, wcap_d = 0;
+    if (dest >= 0) {
+      if (box_starts) {
+        hstart = box_starts[dest], hcap = box_starts[dest + 1] - hstart;
+        wstart = box_starts[n_parts + 1 + dest], wcap_d = box_starts[n_parts + 2 + dest] - wstart;
+      } else {
+        hstart = (int64_t)dest * cap, hcap = cap, wstart = (int64_t)dest * wcap, wcap_d = wcap;
+      }
+    }
+    bool fits = dest >= 0 && pos < hcap && woff + (int64_t)len <= wcap_d;
     if (dest >= 0 && !fits) atomicOr(status, N2V_ST_OVERFLOW);
     if (fits) {
-      int64_t *ho = box_head + ((int64_t)dest * cap + pos) * head_cols;
+      int64_t *ho = box_head + (hstart + pos) * head_cols;
       ho[0] = row;
       ho[1] = key;
       ho[2] = (v << 32) | (int64_t)(uint32_t)nx;
       ho[3] = step + 1;
       if (head_cols > 4) ho[4] = (int64_t)extra;
       for (int c = 5; c < head_cols; ++c) ho[c] = 0;
-      box_off[(int64_t)dest * cap + pos] = woff;
+      box_off[hstart + pos] = woff;
     }
     if (!fits) len = 0;
-    const int64_t wabs = (int64_t)(dest < 0 ? 0 : dest) * wcap + woff;  // in box_words
+    const int64_t wabs = wstart + woff;  // in box_words
     // lists: short ones lane by lane, long ones by the whole wave
     uint64_t big = n2v::ballot64(len >= 32u);
     while (big) {
@@ -460,14 +474,14 @@ __global__ __launch_bounds__(kFwdThreads) void n2v_partition_forward_kernel(
   }
 }
 
-extern "C" int n2v_partition_forward(const int64_t *head_in, int32_t head_cols, const int32_t *next,
-                                     const int64_t *edge, int64_t k, int32_t walk_length,
-                                     const int64_t *bounds, int32_t n_parts, int32_t carry,
-                                     const uint32_t *edge_classes, const uint64_t *wedge_off,
-                                     const void *wedge_pos, int32_t wide, int64_t *box_head,
-                                     int64_t *box_off, int32_t *box_words, unsigned long long *box_count,
-                                     int64_t cap, int64_t wcap, int64_t *log_out, int32_t *walks_out,
-                                     uint8_t *valid_out, uint32_t *status, void *stream) {
+static int partition_forward(const int64_t *head_in, int32_t head_cols, const int32_t *next,
+                             const int64_t *edge, int64_t k, int32_t walk_length,
+                             const int64_t *bounds, int32_t n_parts, int32_t carry,
+                             const uint32_t *edge_classes, const uint64_t *wedge_off,
+                             const void *wedge_pos, int32_t wide, int64_t *box_head,
+                             int64_t *box_off, int32_t *box_words, unsigned long long *box_count,
+                             int64_t cap, int64_t wcap, const int64_t *box_starts, int64_t *log_out,
+                             int32_t *walks_out, uint8_t *valid_out, uint32_t *status, void *stream) {
   if (k < 0 || head_cols < 4 || n_parts < 1 || n_parts > kFwdMaxParts || cap < 0 || wcap < 0 ||
       walk_length < 0)
     return N2V_EINVAL;
@@ -484,7 +498,34 @@ extern "C" int n2v_partition_forward(const int64_t *head_in, int32_t head_cols, 
   hipLaunchKernelGGL(n2v_partition_forward_kernel, dim3((unsigned)blocks), dim3(kFwdThreads), 0, (hipStream_t)stream,
                      head_in, (int)head_cols, next, edge, k, (int)walk_length, bounds, (int)n_parts, (int)carry,
                      edge_classes, wedge_off, wedge_pos, (int)wide, box_head, box_off, box_words, box_count, cap,
-                     wcap, log_out, walks_out, valid_out, status);
+                     wcap, box_starts, log_out, walks_out, valid_out, status);
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
+}
+
+extern "C" int n2v_partition_forward(const int64_t *head_in, int32_t head_cols, const int32_t *next,
+                                     const int64_t *edge, int64_t k, int32_t walk_length,
+                                     const int64_t *bounds, int32_t n_parts, int32_t carry,
+                                     const uint32_t *edge_classes, const uint64_t *wedge_off,
+                                     const void *wedge_pos, int32_t wide, int64_t *box_head,
+                                     int64_t *box_off, int32_t *box_words, unsigned long long *box_count,
+                                     int64_t cap, int64_t wcap, int64_t *log_out, int32_t *walks_out,
+                                     uint8_t *valid_out, uint32_t *status, void *stream) {
+  return partition_forward(head_in, head_cols, next, edge, k, walk_length, bounds, n_parts, carry, edge_classes,
+                           wedge_off, wedge_pos, wide, box_head, box_off, box_words, box_count, cap, wcap, nullptr,
+                           log_out, walks_out, valid_out, status, stream);
+}
+
+extern "C" int n2v_partition_forward_boxes(const int64_t *head_in, int32_t head_cols, const int32_t *next,
+                                           const int64_t *edge, int64_t k, int32_t walk_length,
+                                           const int64_t *bounds, int32_t n_parts, int32_t carry,
+                                           const uint32_t *edge_classes, const uint64_t *wedge_off,
+                                           const void *wedge_pos, int32_t wide, int64_t *box_head,
+                                           int64_t *box_off, int32_t *box_words,
+                                           unsigned long long *box_count, const int64_t *box_starts,
+                                           int64_t *log_out, uint32_t *status, void *stream) {
+  if (!box_starts || !log_out) return N2V_EINVAL;
+  return partition_forward(head_in, head_cols, next, edge, k, walk_length, bounds, n_parts, carry, edge_classes,
+                           wedge_off, wedge_pos, wide, box_head, box_off, box_words, box_count, 0, 0, box_starts,
+                           log_out, nullptr, nullptr, status, stream);
 }

@@ -696,7 +696,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 7) void partition_step_kernel(
     const int64_t local = (int64_t)(uint32_t)sv - lo;
     int32_t next = -1;
     int64_t edge = -1;
-    if (local < 0 || local >= n_local) {  // a walker that is not resident here
+    if (readfirstlane_i64(hd[0]) < 0) {
+      // an empty slot of a capacity-bounded mailbox (negative output row): nothing to step
+    } else if (local < 0 || local >= n_local) {  // a walker that is not resident here
       if (lane == 0) atomicOr(status, N2V_ST_RANGE);
     } else {
       const int64_t vb = readfirstlane_i64(rowptr[local]);

@@ -416,8 +416,10 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void partition_step
   const int64_t k_up = (k + 63) & ~(int64_t)63;
   for (int64_t i = (int64_t)blockIdx.x * kWedgeThreads + tid; i < k_up;
        i += (int64_t)gridDim.x * kWedgeThreads) {
+    // (a header whose output row is negative is an EMPTY slot of a capacity-bounded mailbox: skipped)
     const bool have = i < k;
     const int64_t *hd = head + (have ? i : 0) * head_cols;
+    const bool empty = have && hd[0] < 0;
     const uint64_t key = (uint64_t)hd[1];
     const int64_t sv = hd[2];
     const uint32_t step = (uint32_t)hd[3];
@@ -425,8 +427,8 @@ __global__ __launch_bounds__(kWedgeThreads, N2V_WEDGE_WAVES) void partition_step
     const int64_t local = (int64_t)(uint32_t)sv - lo;
     int32_t next = -1;
     int64_t edge = -1;
-    bool ok = have;
-    if (have && (local < 0 || local >= n_local)) {  // a walker that is not resident here
+    bool ok = have && !empty;
+    if (ok && (local < 0 || local >= n_local)) {  // a walker that is not resident here
       atomicOr(status, N2V_ST_RANGE);
       ok = false;
     }

@@ -254,6 +254,73 @@ def hip_step(dst_ptr, dst_ids, dst_w, src_id, src_ptr, src_ids, keys, steps, p, 
     return tables_step(dst_ptr, dst_ids, dst_w, src_id, src_ptr, src_ids, keys, steps, p, q, seed)
 
 
+class Outboxes:
+    """The capacity-bounded mailboxes of one rank.  caps_h[s][d] / caps_w[s][d] = how many walkers /
+    list words rank s can send to rank d in one step (the same matrices on every rank).  To SEND:
+    the boxes of this rank's row back to back (send_head / send_off / send_words; `box_starts` is
+    their layout as n2v_partition_forward_boxes takes it); to RECEIVE: the boxes of its column back
+    to back, which is exactly what an all-to-all with those fixed split sizes delivers.  Slots
+    nobody wrote are EMPTY (output row -1: the kernels skip them).  Allocated once per walk -- with
+    the path records of all its steps and the step's scratch -- and reused by every step; nothing
+    about the exchange is read on the host.  `count` = walkers, then words, per destination of the
+    last step; `need` = their maxima over the steps so far (what a second attempt is sized by when
+    a box overflowed)."""
+
+    def __init__(self, world: int, rank: int, caps_h, caps_w, dev, send=None, recv=None):
+        self.world, self.rank = world, rank
+        self.send_h, self.send_w = [int(c) for c in caps_h[rank]], [int(c) for c in caps_w[rank]]
+        self.recv_h = [int(caps_h[s][rank]) for s in range(world)]
+        self.recv_w = [int(caps_w[s][rank]) for s in range(world)]
+
+        def make(nh, nw):
+            return (torch.empty((nh, HEAD_COLS), dtype=torch.int64, device=dev),
+                    torch.empty(nh, dtype=torch.int64, device=dev),
+                    torch.empty(max(nw, 1), dtype=torch.int32, device=dev))
+
+        self.send_head, self.send_off, self.send_words = \
+            send if send is not None else make(sum(self.send_h), sum(self.send_w))
+        self.recv_head, self.recv_off, self.recv_words = \
+            recv if recv is not None else make(sum(self.recv_h), sum(self.recv_w))
+        if self.send_words.numel() == 0:  # (no lists travel: the kernels still want an address)
+            self.send_words = torch.zeros(1, dtype=torch.int32, device=dev)
+        if self.recv_words.numel() == 0:
+            self.recv_words = torch.zeros(1, dtype=torch.int32, device=dev)
+        starts, run = [], 0
+        for caps in (self.send_h, self.send_w):
+            run = 0
+            for c in caps:
+                starts.append(run)
+                run += c
+            starts.append(run)
+        self.box_starts = torch.tensor(starts, dtype=torch.int64, device=dev)
+        # a list start is written relative to the pool of its destination d; there that pool lies behind
+        # the pools of the ranks before this one
+        base_there = [sum(int(caps_w[s][d]) for s in range(rank)) for d in range(world)]
+        self.off_add = torch.repeat_interleave(torch.tensor(base_there, dtype=torch.int64, device=dev),
+                                               torch.tensor(self.send_h, dtype=torch.int64, device=dev))
+        self.count = torch.zeros(2 * world, dtype=torch.int64, device=dev)
+        self.need = torch.zeros(2 * world, dtype=torch.int64, device=dev)
+        self.inbox_live = False  # False: the next step still reads the exact mail of the calibration
+        self.logs: List[torch.Tensor] = []
+        self.nxt = self.edge = None
+
+    def begin(self, first_k: int, steps: int, wedge: bool):
+        """the path records of the `steps` bounded steps (rows -1 until written: empty slots leave none) and
+        the step's scratch, allocated before the first of them"""
+        dev, k_in = self.count.device, int(self.recv_head.shape[0])
+        self.logs = [torch.full((first_k, 3), -1, dtype=torch.int64, device=dev)]
+        if steps > 1:
+            self.logs += list(torch.full((steps - 1, k_in, 3), -1, dtype=torch.int64, device=dev).unbind(0))
+        k = max(first_k, k_in, 1)
+        self.nxt = torch.empty(k, dtype=torch.int32, device=dev)
+        self.edge = torch.empty(k, dtype=torch.int64, device=dev) if wedge else None
+        self.step_no = 0
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in (self.send_head, self.send_off, self.send_words,
+                                                         self.recv_head, self.recv_off, self.recv_words))
+
+
 class RankState:
     """what one rank holds between steps"""
 
@@ -276,6 +343,9 @@ class RankState:
         # per-lane work, instead of route + group + prefix sum + gather (walkers travel as Walkers)
         self.forward = False
         self.mail = Mail.empty(part.device)
+        self.last_counts: Optional[List[int]] = None  # what _advance_forward sent: walkers, then words, per rank
+        self.flow_counts: Optional[List[int]] = None
+        self.boxes: Optional[Outboxes] = None          # capacity-bounded mailboxes (advance_bounded)
 
     # -- initiate_random_walk (randomwalk.py:279-296) for the start vertices this rank owns ----
     def initiate(self, start_ids_global: torch.Tensor):
@@ -284,6 +354,8 @@ class RankState:
         ordinal o) is i * W + o - 1, as in n2v_walk."""
         part, dev = self.part, self.part.device
         s = start_ids_global.to(device=dev, dtype=torch.int64)
+        if s.numel() > 1 and not bool((s[1:] >= s[:-1]).all()):
+            raise ValueError("walk_partitioned: the start list must be sorted (the rows of a rank are a range of it)")
         idx = torch.nonzero((s >= part.lo) & (s < part.hi)).reshape(-1)
         mine = s[idx]
         deg = (part.rowptr[1:] - part.rowptr[:-1])[mine - part.lo]
@@ -423,6 +495,13 @@ class RankState:
         return [Walkers(head[cuts_h[r]:cuts_h[r + 1]], lens[cuts_h[r]:cuts_h[r + 1]], ids[at[r]:at[r + 1]])
                 for r in range(n_parts)]
 
+    def _note_counts(self, counts: List[int]):
+        """what this step sent (walkers, then words, per rank); `flow_counts` = the larger of this and the
+        previous step's, the figure the capacity-bounded mailboxes are sized by"""
+        prev = self.last_counts
+        self.last_counts = counts
+        self.flow_counts = counts if prev is None else [max(a, b) for a, b in zip(prev, counts)]
+
     def _parts_arange(self, n_parts: int) -> torch.Tensor:
         if self._arange is None or self._arange.numel() != n_parts:
             self._arange = torch.arange(1, n_parts + 1, dtype=torch.int32, device=self.part.device)
@@ -487,15 +566,78 @@ class RankState:
             self.status[0] = word & ~_lib.ST_OVERFLOW
         self.log.append(log)
         self.last_status |= word
+        self._note_counts([int(c) for c in host[:2 * n_parts]])
         if not self.defer_status:
             _lib.check_status_word(word, "n2v_partition_step")
         return [Mail(box_head[d, :host[d]], box_off[d, :host[d]], box_words[d, :host[n_parts + d]])
                 for d in range(n_parts)]
 
+    def advance_bounded(self, n_parts: int):
+        """_advance_forward WITHOUT a host read: the outboxes have a fixed capacity per destination
+        (`self.boxes`, kept across steps) and travel whole, so neither the sizes of the exchange nor
+        the next launch depend on a count.  A walker or list that does not fit sets N2V_ST_OVERFLOW
+        in the status word, which the driver reads once, after the last step, and then repeats the
+        walk with larger boxes.  Input: the resident mail of the calibration steps the first time,
+        from then on the inbox the exchange filled (`boxes.recv_*`).  Allocates nothing (the parts of
+        a one-process run are stepped on separate streams)."""
+        from node2vec_amd import _lib
+
+        L = _lib.load()
+        part, dev, bx = self.part, self.part.device, self.boxes
+        lanes = self._lane_mode()
+        wedge = lanes >= 2
+        carry = lanes if wedge else 0
+        if bx.inbox_live:
+            head_in, off_in, words_in = bx.recv_head, bx.recv_off, bx.recv_words
+        else:
+            ml = self.mail
+            head_in, off_in = ml.head, ml.off
+            words_in = ml.words if ml.words.numel() else bx.recv_words
+        k = int(head_in.shape[0])
+        bx.send_head[:, 0].fill_(-1)  # every slot empty until the forwarding writes it
+        bx.count.zero_()
+        if k:
+            log = bx.logs[bx.step_no]
+            stream = _lib.current_stream_ptr()
+            with torch.cuda.device(dev):
+                _lib.check(L.n2v_partition_step(part.rowptr.data_ptr(), part.col.data_ptr(), 0, 0, part.lo,
+                                                part.hi - part.lo, head_in.data_ptr(), HEAD_COLS, off_in.data_ptr(),
+                                                words_in.data_ptr(), 2,  # N2V_SRC_WEDGES_AT
+                                                k, float(self.p), float(self.q), int(self.seed) & (2 ** 64 - 1),
+                                                bx.nxt.data_ptr(), bx.edge.data_ptr() if wedge else 0,
+                                                self.status.data_ptr(), stream), "n2v_partition_step")
+                _lib.check(L.n2v_partition_forward_boxes(
+                    head_in.data_ptr(), HEAD_COLS, bx.nxt.data_ptr(), bx.edge.data_ptr() if wedge else 0, k, self.L,
+                    part.bounds.data_ptr(), n_parts, carry,
+                    part.edge_classes.data_ptr() if wedge else 0, part.wedge_off.data_ptr() if wedge else 0,
+                    part.wedge_pos.data_ptr() if wedge else 0, int(wedge and part.wedge_pos.dtype == torch.int32),
+                    bx.send_head.data_ptr(), bx.send_off.data_ptr(), bx.send_words.data_ptr(), bx.count.data_ptr(),
+                    bx.box_starts.data_ptr(), log.data_ptr(), self.status.data_ptr(), stream),
+                    "n2v_partition_forward_boxes")
+            if lanes == 2:
+                bx.send_off.add_(bx.off_add)
+            torch.maximum(bx.need, bx.count, out=bx.need)
+        bx.step_no += 1
+        bx.inbox_live = True
+
+    def begin_bounded(self, boxes: Outboxes, steps: int):
+        """before the first bounded step (may allocate; on the stream the walk was started on)"""
+        dev = self.part.device
+        self.boxes = boxes
+        self.mail = Mail(self.mail.head.contiguous(), self.mail.off.contiguous(), self.mail.words)
+        if self.status is None:
+            self.status = torch.zeros(4, dtype=torch.int32, device=dev)
+        boxes.begin(len(self.mail), steps, self._lane_mode() >= 2)
+
+    def end_bounded(self):
+        self.log += [lg for lg in self.boxes.logs[:self.boxes.step_no] if lg.numel()]
+        self.mail = Mail.empty(self.part.device)
+
     def advance(self, n_parts: int) -> List[Walkers]:
         part, dev, wk = self.part, self.part.device, self.walkers
         if self.forwarding():
             if len(self.mail) == 0:
+                self._note_counts([0] * (2 * n_parts))
                 return [Mail.empty(dev) for _ in range(n_parts)]
             return self._advance_forward(n_parts)
         if len(wk) == 0:
@@ -554,34 +696,47 @@ class RankState:
         self.walkers = wk
 
     def log_by_home(self, start_ids_global: torch.Tensor, n_parts: int) -> List[torch.Tensor]:
-        """the path records, split by the rank that emits each row (owner of its start vertex)"""
+        """the path records, split by the rank that emits each row (owner of its start vertex).  The
+        start list is sorted and the parts are vertex ranges, so the rows of a home rank are a RANGE of
+        output rows: the home of a record is a search over n_parts cuts; the records are then grouped by a
+        sort of that one-byte key (empty slots of the bounded inboxes -- row -1 -- last, and dropped)."""
         dev = self.part.device
         rec = torch.cat(self.log) if self.log else torch.zeros((0, 3), dtype=torch.int64, device=dev)
+        if rec.shape[0] == 0:
+            return [rec for _ in range(n_parts)]
         s = start_ids_global.to(device=dev, dtype=torch.int64)
-        home = self.part.owner(s[rec[:, 0] // self.W]) if rec.numel() else rec[:, 0]
-        return [rec[home == r] for r in range(n_parts)]
+        # first output row of every rank's start vertices (bounds = the first vertex of every part)
+        cuts = torch.searchsorted(s, self.part.bounds.to(torch.int64)) * self.W
+        row = rec[:, 0].contiguous()
+        home = torch.searchsorted(cuts, row, right=True) - 1  # (-1 for an empty slot)
+        key = torch.where(row >= 0, home, torch.full_like(home, n_parts)).to(torch.uint8)
+        key, order = torch.sort(key)
+        counts = torch.bincount(key.to(torch.int64), minlength=n_parts + 1).tolist()  # one host read
+        rec = rec[order]
+        return list(torch.split(rec, counts)[:n_parts])
 
     def assemble(self, records: Sequence[torch.Tensor], start_ids_global: torch.Tensor):
         """rows of this rank (start vertices in its range, in start-list order):
         (walks int32 [k * W, L + 1], valid bool [k * W], global row ids int64)"""
         part, dev = self.part, self.part.device
         s = start_ids_global.to(device=dev, dtype=torch.int64)
-        idx = torch.nonzero((s >= part.lo) & (s < part.hi)).reshape(-1)
-        ords = torch.arange(self.W, device=dev, dtype=torch.int64)
-        rows = (idx[:, None] * self.W + ords[None, :]).reshape(-1)
-        pos_of = torch.full((int(s.numel()) * self.W,), -1, dtype=torch.int64, device=dev)
-        pos_of[rows] = torch.arange(rows.numel(), device=dev)
-        walks = torch.full((rows.numel(), self.L + 1), -1, dtype=torch.int32, device=dev)
-        valid = torch.ones(rows.numel(), dtype=torch.bool, device=dev)
+        # (sorted start list, contiguous vertex range: this rank's start vertices are a range of the list)
+        i0, i1 = torch.searchsorted(s, torch.tensor([part.lo, part.hi], dtype=torch.int64, device=dev)).tolist()
+        n_rows, width = (i1 - i0) * self.W, self.L + 1
+        rows = torch.arange(i0 * self.W, i1 * self.W, device=dev, dtype=torch.int64)
+        # one spare cell behind the rows: where the writes of records that carry no vertex go
+        flat = torch.full((n_rows * width + 1,), -1, dtype=torch.int32, device=dev)
+        ok = torch.ones(n_rows + 1, dtype=torch.bool, device=dev)
         rec = torch.cat([r.to(dev) for r in records]) if records else torch.zeros((0, 3), dtype=torch.int64, device=dev)
         if rec.numel():
-            r = pos_of[rec[:, 0]]
-            dropped = rec[:, 1] < 0
-            valid[r[dropped]] = False
-            ok = ~dropped
-            walks[r[ok], rec[ok, 1]] = rec[ok, 2].to(torch.int32)
-            valid[r[ok & (rec[:, 2] < 0)]] = False  # a start vertex without out-edges
-        return walks, valid, rows
+            r = rec[:, 0] - i0 * self.W
+            pos, vertex = rec[:, 1], rec[:, 2]
+            dropped = pos < 0  # vanished on arrival (fugue.py:147)
+            flat[torch.where(dropped, n_rows * width, r * width + pos)] = vertex.to(torch.int32)
+            # (vertex < 0 at position 0: a start vertex without out-edges)
+            ok[torch.where(dropped | (vertex < 0), r, n_rows)] = False
+        ok[n_rows:] = True
+        return flat[:n_rows * width].view(n_rows, width), ok[:n_rows], rows
 
 
 # ---- drivers ----------------------------------------------------------------------------------
@@ -590,6 +745,16 @@ class RankState:
 FORWARD_WORDS_PER_WALKER = 8
 FORWARD_STREAMS = True  # step the parts of a step on separate streams
 FORWARD_MIN_WORDS = 1 << 16
+# walk_partitioned's ranks: after this many steps with exact sizes (one host read each: their counts
+# are what the capacities are set from -- the walkers start spread over the VERTICES and are spread
+# like the EDGES one step later) the mailboxes get a fixed capacity per destination,
+# BOUNDED_SLACK times the largest flow between two ranks seen, and the remaining steps read nothing
+# on the host.  BOUNDED = False: every step with exact sizes, as in round 4.
+BOUNDED = True
+BOUNDED_CALIBRATION_STEPS = 3  # capacities from the larger flow of the last TWO (p < 1 sends walkers back: the
+#                                flows of even and odd steps differ until the walkers have mixed)
+BOUNDED_SLACK = 1.5
+BOUNDED_MIN_SLOTS = 256
 
 
 def _forward_mode(parts: Sequence[GraphPart], p: float, q: float, step_fn: Callable) -> int:
@@ -732,10 +897,56 @@ def _walk_local_forwarding(parts: Sequence[GraphPart], start_ids: torch.Tensor, 
     return walks, valid.bool()
 
 
+def _ST_OVERFLOW() -> int:
+    from node2vec_amd import _lib
+
+    return _lib.ST_OVERFLOW
+
+
+def _check_word(word: int):
+    from node2vec_amd import _lib
+
+    _lib.check_status_word(int(word), "n2v_partition_step")
+
+
+def _bounded_caps(flows_h, flows_w, lanes: int):
+    """capacities per (source, destination) -- header slots, list words -- from the flows [s][d] of the
+    last step with exact sizes"""
+    caps_h = [[max(int(BOUNDED_SLACK * f) + 1, BOUNDED_MIN_SLOTS) for f in row] for row in flows_h]
+    caps_w = [[max(int(BOUNDED_SLACK * f) + 1, 8 * BOUNDED_MIN_SLOTS) if lanes == 2 else 0 for f in row]
+              for row in flows_w]
+    return caps_h, caps_w
+
+
+def _bounded_caps_retry(caps, need_h, need_w, lanes: int):
+    """after an overflow: every box at least what the failed attempt asked of it (a lower bound: a
+    walker that did not fit was not walked further) with the slack on top; a box that overflowed at
+    least doubles"""
+    def grow(c, need):
+        new = max(c, int(BOUNDED_SLACK * need) + 1)
+        return max(new, 2 * c) if need > c else new
+
+    caps_h = [[grow(c, f) for c, f in zip(cr, fr)] for cr, fr in zip(caps[0], need_h)]
+    caps_w = [[grow(c, f) if lanes == 2 else 0 for c, f in zip(cr, fr)] for cr, fr in zip(caps[1], need_w)]
+    return caps_h, caps_w
+
+
+def _transposed_blocks(t: torch.Tensor, caps) -> List[torch.Tensor]:
+    """`t` holds boxes laid out by (source, destination): its blocks in (destination, source) order --
+    their concatenation is what the all-to-all delivers (a one-process run does it as ONE cat)"""
+    n = len(caps)
+    at, run = [[0] * n for _ in range(n)], 0
+    for s_ in range(n):
+        for d in range(n):
+            at[s_][d] = run
+            run += int(caps[s_][d])
+    return [t[at[s_][d]:at[s_][d] + int(caps[s_][d])] for d in range(n) for s_ in range(n)]
+
+
 def walk_partitioned_local(parts: Sequence[GraphPart], start_ids: torch.Tensor, num_walks: int,
                            walk_length: int, p: float, q: float, seed: int,
-                           step_fn: Callable = hip_step,
-                           forwarding: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                           step_fn: Callable = hip_step, forwarding: Optional[bool] = None,
+                           timings: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Every rank of the partition in ONE process (the all-to-all is a list transpose): returns
     (walks, valid) in the row order of n2v_walk over the same start list.  `forwarding`: None =
     the two-launch form (_walk_local_forwarding) wherever it applies, False = always the
@@ -748,7 +959,7 @@ def walk_partitioned_local(parts: Sequence[GraphPart], start_ids: torch.Tensor, 
     if not lanes:
         forwarding = False  # ("ranks": the ranks then route launch by stage, as walk_partitioned's would)
     if lanes and forwarding != "ranks":
-        return _walk_local_forwarding(parts, start_ids, num_walks, walk_length, p, q, seed, lanes)
+        return _walk_local_forwarding(parts, start_ids, num_walks, walk_length, p, q, seed, lanes, timings)
     n = len(parts)
     ranks = [RankState(pt, num_walks, walk_length, p, q, seed, step_fn) for pt in parts]
     # what travels with a walker (wedge lists or rows) must be the same on every part: lists only
@@ -758,18 +969,104 @@ def walk_partitioned_local(parts: Sequence[GraphPart], start_ids: torch.Tensor, 
         r.use_tables = tables
         r.forward = forwarding == "ranks"  # what walk_partitioned's ranks do, the exchange a list transpose
         r.initiate(start_ids)
-    for _ in range(walk_length):
-        out = [r.advance(n) for r in ranks]
-        for d, r in enumerate(ranks):
-            r.receive([out[src][d] for src in range(n)])
-    logs = [r.log_by_home(start_ids, n) for r in ranks]
     dev = parts[0].device
+
+    def mark(name):  # timings["sections"] = {}: wall time per phase (synchronising: a diagnostic)
+        if timings is not None and "sections" in timings:
+            import time
+
+            torch.cuda.synchronize(dev)
+            now = time.perf_counter()
+            timings["sections"][name] = timings["sections"].get(name, 0.0) + now - timings.get("_t", now)
+            timings["_t"] = now
+
+    mark("start")
+    bounded = BOUNDED and forwarding == "ranks" and all(r.forwarding() for r in ranks)
+    exact_steps = min(BOUNDED_CALIBRATION_STEPS, walk_length) if bounded else walk_length
+    caps = None
+    while True:
+        for _ in range(exact_steps):
+            out = [r.advance(n) for r in ranks]
+            for d, r in enumerate(ranks):
+                r.receive([out[src][d] for src in range(n)])
+        mark("exact steps")
+        if exact_steps == walk_length:
+            break
+        # the remaining steps with capacity-bounded mailboxes: here the boxes of all ranks are slices of
+        # one tensor per kind and the all-to-all is one gather per kind
+        lanes = ranks[0]._lane_mode()
+        if caps is None:
+            caps = _bounded_caps([r.flow_counts[:n] for r in ranks], [r.flow_counts[n:] for r in ranks], lanes)
+        caps_h, caps_w = caps
+        if timings is not None:  # (one entry per attempt: an overflow repeats the walk with larger boxes)
+            timings.setdefault("bounded_caps", []).append(caps)
+            timings["exact_steps"] = exact_steps
+        tot_h, tot_w = sum(map(sum, caps_h)), sum(map(sum, caps_w))
+
+        def make():  # (nothing is read that was not written: a slot is empty unless its header says otherwise)
+            return (torch.empty((tot_h, HEAD_COLS), dtype=torch.int64, device=dev),
+                    torch.empty(tot_h, dtype=torch.int64, device=dev),
+                    torch.empty(max(tot_w, 1), dtype=torch.int32, device=dev))
+
+        send, recv = make(), make()
+        blocks = [_transposed_blocks(send[0], caps_h), _transposed_blocks(send[1], caps_h)]
+        if lanes == 2:
+            blocks.append(_transposed_blocks(send[2], caps_w))
+        sh = sw = rh = rw_ = 0
+        for i, r in enumerate(ranks):
+            nsh, nsw = sum(caps_h[i]), sum(caps_w[i])
+            nrh, nrw = sum(caps_h[s_][i] for s_ in range(n)), sum(caps_w[s_][i] for s_ in range(n))
+            r.begin_bounded(Outboxes(n, i, caps_h, caps_w, dev,
+                                     (send[0][sh:sh + nsh], send[1][sh:sh + nsh], send[2][sw:sw + nsw]),
+                                     (recv[0][rh:rh + nrh], recv[1][rh:rh + nrh], recv[2][rw_:rw_ + nrw])),
+                            walk_length - exact_steps)
+            sh, sw, rh, rw_ = sh + nsh, sw + nsw, rh + nrh, rw_ + nrw
+        # (the parts are different GPUs in a real run: each is stepped on its own stream, as in
+        # _walk_local_forwarding)
+        main = torch.cuda.current_stream(dev)
+        streams = [torch.cuda.Stream(device=dev) for _ in ranks] if FORWARD_STREAMS else [main] * n
+        mark("boxes allocated")
+        for step in range(exact_steps, walk_length):
+            if FORWARD_STREAMS:
+                for st_ in streams:
+                    st_.wait_stream(main)
+            for r, st_ in zip(ranks, streams):
+                with torch.cuda.stream(st_):
+                    r.advance_bounded(n)
+            if FORWARD_STREAMS:
+                for st_ in streams:
+                    main.wait_stream(st_)
+            if step + 1 < walk_length:  # (nobody is forwarded by the last step)
+                for kind, blk in enumerate(blocks):
+                    torch.cat(blk, out=recv[kind])
+        host = torch.cat([r.status[:1].to(torch.int64) for r in ranks]
+                         + [r.boxes.need for r in ranks]).tolist()  # the one host read of these steps
+        mark("bounded steps")
+        word = 0
+        for x in host[:n]:
+            word |= int(x) & 0xffffffff
+        if not (word & _ST_OVERFLOW()):
+            _check_word(word)
+            for r in ranks:
+                r.end_bounded()
+            break
+        _check_word(word & ~_ST_OVERFLOW())
+        need = [host[n + 2 * n * i:n + 2 * n * (i + 1)] for i in range(n)]
+        caps = _bounded_caps_retry(caps, [x[:n] for x in need], [x[n:] for x in need], lanes)
+        del send, recv, blocks
+        ranks = [RankState(pt, num_walks, walk_length, p, q, seed, step_fn) for pt in parts]
+        for r in ranks:
+            r.use_tables, r.forward = tables, True
+            r.initiate(start_ids)
+    logs = [r.log_by_home(start_ids, n) for r in ranks]
+    mark("records by home rank")
     total = int(start_ids.numel()) * num_walks
     walks = torch.full((total, walk_length + 1), -1, dtype=torch.int32, device=dev)
     valid = torch.zeros(total, dtype=torch.bool, device=dev)
     for d, r in enumerate(ranks):
         w, v, rows = r.assemble([logs[src][d] for src in range(n)], start_ids)
         walks[rows], valid[rows] = w, v
+    mark("rows assembled")
     return walks, valid
 
 
@@ -855,7 +1152,8 @@ def _exchange_mail(out: List[Mail], group, dist, dev, status: int = 0) -> List[M
 
 
 def walk_partitioned(part: GraphPart, start_ids: torch.Tensor, num_walks: int, walk_length: int,
-                     p: float, q: float, seed: int, group=None, step_fn: Callable = hip_step):
+                     p: float, q: float, seed: int, group=None, step_fn: Callable = hip_step,
+                     timings: Optional[dict] = None):
     """One rank of the partitioned walk under torch.distributed (one process per GPU; backend
     "nccl" = RCCL over xGMI, or gloo on CPU tensors).  Every rank passes the same sorted
     `start_ids` and the same seed.  Returns this rank's rows: (walks, valid, global row ids) --
@@ -870,15 +1168,75 @@ def walk_partitioned(part: GraphPart, start_ids: torch.Tensor, num_walks: int, w
     # EVERY rank holds the per-edge tables of its part
     have = torch.tensor([0 if part.wedge_off is None else 1], dtype=torch.int32, device=part.device)
     all_reduce(have, dist.ReduceOp.MIN, group)
-    st.use_tables = bool(have.item())
-    st.defer_status = True
-    # per-lane steps (unit weights; the tables on every rank, or p == q == 1): route with
-    # n2v_partition_forward, one launch; every rank takes the same branch (use_tables is agreed)
-    st.forward = True
-    st.initiate(start_ids)
-    for _ in range(walk_length):
-        out = st.advance(world)
-        exchange = _exchange_mail if st.forwarding() else _exchange_walkers
-        st.receive(exchange(out, group, dist, part.device, st.last_status))
+    use_tables = bool(have.item())
+    dev = part.device
+    cpu = dist.get_backend(group) == "gloo"  # gloo moves host tensors
+    caps = None
+    while True:
+        st.use_tables = use_tables
+        st.defer_status = True
+        # per-lane steps (unit weights; the tables on every rank, or p == q == 1): route with
+        # n2v_partition_forward, one launch; every rank takes the same branch (use_tables is agreed)
+        st.forward = True
+        st.initiate(start_ids)
+        bounded = BOUNDED and st.forwarding()
+        exact_steps = min(BOUNDED_CALIBRATION_STEPS, walk_length) if bounded else walk_length
+        for _ in range(exact_steps):
+            out = st.advance(world)
+            exchange = _exchange_mail if st.forwarding() else _exchange_walkers
+            st.receive(exchange(out, group, dist, dev, st.last_status))
+        if exact_steps == walk_length:
+            break
+        # the remaining steps: capacity-bounded mailboxes, exchanged whole -- no size, count or status
+        # is read on the host until the last step is done (fugue.py:146-149: one shuffle per step)
+        lanes = st._lane_mode()
+        rank = part.rank
+        if caps is None:
+            m = torch.zeros((world, 2 * world), dtype=torch.int64, device=dev)
+            m[rank] = torch.tensor(st.flow_counts or [0] * (2 * world), dtype=torch.int64, device=dev)
+            all_reduce(m, dist.ReduceOp.SUM, group)
+            m = m.tolist()  # (the last host read of the calibration: the flows between every two ranks)
+            caps = _bounded_caps([row[:world] for row in m], [row[world:] for row in m], lanes)
+        if timings is not None:  # (one entry per attempt: an overflow repeats the walk with larger boxes)
+            timings.setdefault("bounded_caps", []).append(caps)
+            timings["exact_steps"] = exact_steps
+        bx = Outboxes(world, rank, caps[0], caps[1], dev)
+        st.begin_bounded(bx, walk_length - exact_steps)
+        for step in range(exact_steps, walk_length):
+            st.advance_bounded(world)
+            if step + 1 < walk_length:  # (nobody is forwarded by the last step)
+                _exchange_bounded(bx, group, dist, cpu, lanes == 2)
+        fin = torch.zeros((world, 1 + 2 * world), dtype=torch.int64, device=dev)
+        fin[rank, 0] = st.status[0].to(torch.int64) & 0xffffffff
+        fin[rank, 1:] = bx.need
+        all_reduce(fin, dist.ReduceOp.SUM, group)
+        fin = fin.tolist()  # the one host read of these steps
+        word = 0
+        for row in fin:
+            word |= int(row[0])
+        if not (word & _ST_OVERFLOW()):
+            _check_word(word)
+            st.end_bounded()
+            break
+        _check_word(word & ~_ST_OVERFLOW())
+        caps = _bounded_caps_retry(caps, [row[1:1 + world] for row in fin], [row[1 + world:] for row in fin], lanes)
+        del bx
+        st = RankState(part, num_walks, walk_length, p, q, seed, step_fn)
     records = _all_to_all_var(st.log_by_home(start_ids, world), group, dist)
     return st.assemble(records, start_ids)
+
+
+def _exchange_bounded(bx: Outboxes, group, dist, cpu: bool, words: bool):
+    """the migration of one step with capacity-bounded mailboxes: box d of every rank goes to rank d
+    whole -- headers, list starts and, when lists travel, the word pools; the split sizes are the
+    capacities, fixed for the walk"""
+    todo = [(bx.recv_head, bx.send_head, bx.recv_h, bx.send_h), (bx.recv_off, bx.send_off, bx.recv_h, bx.send_h)]
+    if words:
+        todo.append((bx.recv_words, bx.send_words, bx.recv_w, bx.send_w))
+    for recv, send, n_recv, n_send in todo:
+        if cpu:
+            got = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(got, send.cpu(), n_recv, n_send, group=group)
+            recv.copy_(got)
+        else:
+            dist.all_to_all_single(recv, send, n_recv, n_send, group=group)

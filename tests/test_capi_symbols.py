@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert sorted(_lib.SYMBOLS) == _declared()
     lib.n2v_abi_version.restype = ctypes.c_int
-    assert lib.n2v_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.n2v_abi_version() == _lib.ABI_VERSION == 11
     lib.n2v_status_string.restype = ctypes.c_char_p
     assert lib.n2v_status_string(-1) == b"invalid argument"
 
@@ -105,6 +105,13 @@ def test_partition_entry_points_validate_their_arguments():
                                        a["wide"], a["box_head"], a["box_off"], a["box_words"], a["box_count"],
                                        a["cap"], a["wcap"], a["log"], a["walks"], a["valid"], a["status"], None)
 
+    def boxes(**kw):  # n2v_partition_forward_boxes: ragged mailboxes, the path records always to the log
+        a = dict(k=1, starts=p_, log=p_, n_parts=2)
+        a.update(kw)
+        return L.n2v_partition_forward_boxes(p_, 5, p_, p_, a["k"], 10, p_, a["n_parts"], 2, p_, p_, p_, 0, p_, p_,
+                                             p_, p_, a["starts"], a["log"], p_, None)
+
+    assert boxes(k=0) == 0 and boxes(starts=0) == -1 and boxes(log=0) == -1 and boxes(n_parts=0) == -1
     assert forward(k=0) == 0
     assert forward(carry=1) == -1  # rows do not travel this way
     assert forward(carry=2, head_cols=4) == -1 and forward(k=-1) == -1 and forward(n_parts=0) == -1

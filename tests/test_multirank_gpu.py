@@ -110,9 +110,11 @@ def _worker(rank, world, port, ret):
         part = P.partition_graph(g, world)[rank]
         start = rw.start_vertices(g)
         for pq in PART_PQ:
-            pw, pv, prow = P.walk_partitioned(part, start, 2, 15, pq[0], pq[1], 31)
+            tp = {}
+            pw, pv, prow = P.walk_partitioned(part, start, 2, 15, pq[0], pq[1], 31, timings=tp)
             out["partitioned_%g_%g" % pq] = {"walks": pw.cpu().numpy(), "valid": pv.cpu().numpy(),
-                                             "rows": prow.cpu().numpy(), "edges": int(part.col.numel())}
+                                             "rows": prow.cpu().numpy(), "edges": int(part.col.numel()),
+                                             "bounded_attempts": len(tp.get("bounded_caps", []))}
         # one rank WITHOUT the per-edge tables: both must fall back to rows travelling
         import dataclasses
 
@@ -172,6 +174,8 @@ def test_two_ranks_on_one_gpu_fit_and_fit_streaming():
         want, wv = want.cpu().numpy(), wv.cpu().numpy().astype(bool)
         pa, pb = r0[key], r1[key]
         assert 0 < pa["edges"] < g.n_edges and pa["edges"] + pb["edges"] == g.n_edges
+        if key != "partitioned_mixed":  # the steps after the calibration ran with capacity-bounded mailboxes
+            assert pa["bounded_attempts"] == pb["bounded_attempts"] >= 1
         rows = np.concatenate([pa["rows"], pb["rows"]])
         assert np.array_equal(np.sort(rows), np.arange(want.shape[0]))  # every row emitted once
         for part in (pa, pb):

@@ -138,6 +138,50 @@ def test_forwarding_repeats_a_step_whose_word_pool_was_too_small(monkeypatch):
         P.walk_partitioned_local(P.partition_graph(g, 5, wedges=False), start, 2, 20, 0.5, 2.0, 8, forwarding=True)
 
 
+@pytest.mark.parametrize("pq", [(0.5, 2.0), (1.0, 1.0), (3.0, 1.0)])
+def test_ranks_walk_with_capacity_bounded_mailboxes(monkeypatch, pq):
+    """walk_partitioned's ranks after the calibration steps: mailboxes of a fixed capacity per destination,
+    exchanged whole (here: a transpose), empty slots skipped by the kernels, nothing read on the host until
+    the last step -- same walks; boxes that are too small are reported once, at the end, and the walk is
+    repeated with larger ones"""
+    from node2vec_amd import partitioned as P
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+
+    rng = np.random.default_rng(5)
+    nv = 6000
+    src = np.concatenate([rng.integers(0, nv, 50_000), rng.integers(0, 12, 9000)])
+    dst = np.concatenate([rng.integers(0, nv, 50_000), rng.integers(0, nv, 9000)])
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    a, b = np.concatenate([src, dst]), np.concatenate([dst, src])
+    out = a < nv - 40  # the last vertices have in-edges only: walkers vanish there
+    g = DeviceGraph.from_edges(a[out], b[out], None, n_vertices=nv, device="cuda")
+    parts = P.partition_graph(g, 5)
+    start = rw.start_vertices(g)
+    p, q = pq
+    want, wv = rw.walk(g, start, 3, 25, p, q, 19)
+    assert not bool(wv.all())
+    t = {}
+    walks, valid = P.walk_partitioned_local(parts, start, 3, 25, p, q, 19, forwarding="ranks", timings=t)
+    assert t["exact_steps"] == P.BOUNDED_CALIBRATION_STEPS and len(t["bounded_caps"]) == 1
+    assert torch.equal(valid, wv) and torch.equal(walks, want)
+    # boxes far too small: the attempt overflows, says so once, and the walk is repeated
+    monkeypatch.setattr(P, "BOUNDED_SLACK", 0.2)
+    monkeypatch.setattr(P, "BOUNDED_MIN_SLOTS", 1)
+    t = {}
+    walks, valid = P.walk_partitioned_local(parts, start, 3, 25, p, q, 19, forwarding="ranks", timings=t)
+    slots = [sum(map(sum, caps_h)) for caps_h, _ in t["bounded_caps"]]  # one (slots, words) pair of matrices per attempt
+    assert len(slots) >= 2 and slots[-1] > slots[0]
+    assert torch.equal(valid, wv) and torch.equal(walks, want)
+    # and with every step at exact sizes (round 4's form)
+    monkeypatch.setattr(P, "BOUNDED", False)
+    t = {}
+    walks, valid = P.walk_partitioned_local(parts, start, 3, 25, p, q, 19, forwarding="ranks", timings=t)
+    assert "bounded_caps" not in t
+    assert torch.equal(valid, wv) and torch.equal(walks, want)
+
+
 def test_partitioned_cfg2_sample_equals_n2v_walk():
     """BASELINE cfg 2 graph (R-MAT scale 20) cut into 8 parts, L = 80"""
     from node2vec_amd import partitioned as P
