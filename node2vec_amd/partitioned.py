@@ -22,8 +22,10 @@ design point on a GPU node:
   graph, just the WEDGE LIST of the edge it leaves along (the positions, in the row it is going
   to, of the neighbours that row shares with this one: usually a handful of words instead of a
   row, and the receiving rank then needs neither a search over N(s) nor a pass over N(v)): one
-  variable-size all-to-all per step
-  (`torch.distributed.all_to_all_single`, RCCL over xGMI on the GPUs, gloo in the CPU tests);
+  all-to-all per step (`torch.distributed.all_to_all_single`, RCCL over xGMI on the GPUs, gloo in
+  the CPU tests) -- of variable size, read on the host, for the first three steps; from then on of
+  mailboxes with a fixed capacity per (source, destination) set from the flows seen so far, sent
+  whole, empty slots included, so that a step reads nothing on the host (`Outboxes`);
 * every appended vertex is logged as (row, position, vertex) and sent once, at the end, to the
   rank that emits the walk (the owner of its start vertex); walkers that reach a vertex without
   out-edges vanish (inner join, fugue.py:147) and their row is marked invalid -- the step finds

@@ -155,6 +155,32 @@ def _worker(rank, world, port, ret):
         v = build_vocab(shards[rank], min_count=2)
         ok = ok and v.ids.tolist() == [2, 5, 9] and v.counts.tolist() == [5, 4, 4]  # ties: id asc
         ok = ok and v.index_of.tolist() == [-1, -1, 0, -1, -1, 1, -1, -1, -1, 2, -1, -1]
+        # the capacity-bounded mailboxes of the partitioned walk (partitioned.Outboxes): box d of every rank
+        # reaches rank d whole with the capacities as FIXED split sizes, and a list start written relative to
+        # the pool of its destination points behind the pools of the ranks before this one
+        from node2vec_amd import partitioned as P
+
+        caps_h, caps_w = [[2, 3], [4, 1]], [[5, 6], [2, 7]]  # [source][destination]
+        bx = P.Outboxes(world, rank, caps_h, caps_w, torch.device("cpu"))
+        ok = ok and bx.box_starts.tolist() == ([0, 2, 5, 0, 5, 11] if rank == 0 else [0, 4, 5, 0, 2, 9])
+        ok = ok and bx.off_add.tolist() == ([0] * 5 if rank == 0 else [5] * 4 + [6])
+
+        def sent(src, kind):  # what rank `src` puts into its send arrays
+            nh, nw = sum(caps_h[src]), sum(caps_w[src])
+            if kind == "head":
+                return (torch.arange(nh * P.HEAD_COLS, dtype=torch.int64) + 1000 * src).view(nh, P.HEAD_COLS)
+            return torch.arange(nh, dtype=torch.int64) + 100 * src if kind == "off" else \
+                torch.arange(nw, dtype=torch.int32) + 10 * src
+
+        bx.send_head.copy_(sent(rank, "head")), bx.send_off.copy_(sent(rank, "off")), bx.send_words.copy_(sent(rank, "words"))
+        P._exchange_bounded(bx, None, dist, True, True)
+        for kind, got, caps in (("head", bx.recv_head, caps_h), ("off", bx.recv_off, caps_h),
+                                ("words", bx.recv_words, caps_w)):
+            want = []
+            for src in range(world):  # box `rank` of every source, in source order
+                at = sum(caps[src][:rank])
+                want.append(sent(src, kind)[at:at + caps[src][rank]])
+            ok = ok and torch.equal(got, torch.cat(want))
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
