@@ -313,12 +313,26 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
  * and the result is n2v_walk's, bit for bit (same uniform stream, keyed by start vertex, ordinal and
  * step).  For return_param or inout_param != 1 the steps after the first read the classes of the
  * slots from g->edge_classes, g->wedge_off and g->wedge_pos (n2v_edge_classes_build, n2v_wedge_build:
- * they depend on the ids alone and are built for a weighted graph as for a unit one). */
+ * they depend on the ids alone and are built for a weighted graph as for a unit one).
+ *     scratch  int64 [n_rows + 2] or NULL, row_sums fp64 [n_vertices + 2] or NULL: the sum of the stored
+ *            weights of every row, in any order (all weights finite and >= 0), then row_sums[n_vertices] =
+ *            a power of two that divides every stored weight (fp32 weights: 2^(e - 24) of the smallest
+ *            one, w = m 2^e; 0 = none known: then the margins are the general ones) and
+ *            row_sums[n_vertices + 1] = the largest stored weight.  With an order AND both of
+ *            these the walkers on rows of 128 slots or more get a WAVE each that does not replay the
+ *            pairing loop but DECIDES the one slot the draw asks for from sums over the row (the k-th
+ *            overfull slot is demoted where the running sum of the underfull slots' deficits passes that
+ *            of the overfull slots' excess; the row sum itself comes from row_sums and the shared and
+ *            return slots: no pass), every comparison with a margin that covers the roundings of the
+ *            reference's loop (16 n^2 2^-52 and up); a walker whose draw some comparison cannot decide
+ *            by that margin is listed in scratch (scratch[0] = how many after the call, scratch[1 ..] =
+ *            their rows) and stepped by the exact wave-per-walker kernel in the same call.  Same bits as
+ *            without them. */
 int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_ids, int32_t num_walks,
                            const int64_t *order, int64_t n_rows, int32_t step, int32_t walk_length,
                            double return_param, double inout_param, uint64_t seed,
                            int64_t *edge_state, int32_t *walks, uint8_t *valid, uint32_t *status,
-                           void *stream);
+                           int64_t *scratch, const double *row_sums, void *stream);
 
 /* n2v_walk with a workspace lent by the caller (the library never allocates).  Exact biased walks
  * on a unit-weight graph that carries the hop and wedge tables, dyadic return_param / inout_param,

@@ -125,7 +125,8 @@ def load():
     L.n2v_walk_weighted_step.restype = C.c_int
     L.n2v_walk_weighted_step.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
                                          C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint64,
-                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]
     L.n2v_sgns_hogwild_waves.restype = C.c_int64
     L.n2v_sgns_hogwild_waves.argtypes = [C.POINTER(SgnsParams), C.c_int64, C.c_int32]
     L.n2v_sgns_job_alpha.restype = C.c_int

@@ -43,6 +43,7 @@ namespace n2v {
 struct WlConsts {
   double p, q, inv_p, inv_q;
   int p_pow2, q_pow2;  // w / p == w * (1 / p) bit for bit when p is a power of two
+  int coef_bits;       // significant bits of 1 - 1/q and 1/p - 1/q (powers of two p, q; see wm_draw)
 };
 
 // what a lane knows about the row it stands on
@@ -441,6 +442,505 @@ __global__ __launch_bounds__(TH) void walk_weighted_step_kernel(
   }
 }
 
+
+// ---- long rows: one WAVE per walker, the pairing DECIDED, not replayed ------------------------------
+// The pairing of :182-189 is serial, but what a draw needs of it is little: the final (alias, probs) of
+// ONE slot.  Take the slots in the order the stacks are popped (descending position) and write
+// d_i = 1 - probs[i] for the underfull ones, e_i = probs[i] - 1 for the others, D_j / E_k for their
+// running sums from the top.  In exact arithmetic the loop is a merge of the two sums: the k-th
+// overfull slot stays `over` while E_k - D_j >= 0, i.e. it absorbs underfull slots until D_j > E_k, is then
+// demoted with probs = 1 + E_k - D_j and is the next `under` of the (k + 1)-th; so
+//   * an underfull `pick` (the j-th) keeps its probs and gets alias = the first k with E_k >= D_{j-1};
+//   * an overfull `pick` (the k-th) ends with probs = 1 + E_k - D_j at the first j with D_j > E_k and
+//     alias = the next overfull slot below it -- or is never demoted (probs >= 1: the draw returns it).
+// Sums, not a replay: a wave streams the row twice (the row sum; the chunk sums of d and e) and looks at
+// one or two chunks again.  In floating point the reference's loop rounds twice per pairing
+// (probs[over] + probs[under] - 1.0) and this kernel adds in another order and from an average that was
+// summed in another order, so every comparison is made with a MARGIN M = 16 n^2 2^-52 that covers both
+//   (the loop's residual differs from E_k - D_j by at most 2 n 2^-53 (n + 1) whatever path it took: each
+//    pairing rounds twice at magnitude <= probs[over] <= n; the sums here differ from the exact ones by
+//    at most (2 n + 4) 2^-53 of sum(probs) = n for the average, plus log2 n roundings of the tree, plus
+//    2 (2 n + 4) 2^-53 per slot whose side of 1.0 cannot be told: together < 6 n^2 2^-53)
+// and a draw that any comparison cannot decide by that margin -- r2 against probs, a sum against the
+// sum it crosses, `pick` against 1.0 -- is NOT decided here: the walker goes on a list and the exact
+// wave kernel (n2v_weighted_step_wave_launch) steps it.  With real-valued weights that is one step in
+// ~10^6; rows whose sums tie exactly (few distinct weights) are undecided often and walk at the exact
+// kernel's rate.  Same draws either way.
+constexpr int kWmUndecided = -2;
+constexpr int kWmEntries = 256;  // running sums kept per wave (a row of more than 256 x 256 slots: several blocks per entry)
+struct WmLds {
+  double cd[kWmEntries], cx[kWmEntries];  // sum of d / of x = probs - 1 over the slots up to the end of entry i
+  int lm0[kWmEntries];                    // how many shared positions lie below the first slot of entry i
+  uint32_t flags[64];                     // one byte per slot of a block of 256: the slot is a shared position
+};
+
+__device__ __forceinline__ int64_t readlane_i64(int64_t v, int lane) {
+  const int lo = __builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+  const int hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), lane);
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+// one DPP step on a 64-bit value: the value of the lane selected by kCtrl (no LDS round trip)
+template <int kCtrl>
+__device__ __forceinline__ uint64_t wm_dpp_u64(uint64_t x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, kCtrl, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), kCtrl, 0xF, 0xF, true);
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+template <int kCtrl>
+__device__ __forceinline__ double wm_dpp_f64(double x) {
+  return __longlong_as_double((long long)wm_dpp_u64<kCtrl>((uint64_t)__double_as_longlong(x)));
+}
+// Sum over the wave as a balanced tree (the order does not matter to the caller: margins): distances 1, 2,
+// 4, 8 inside a row of 16 lanes are DPP moves, the four row sums are read with v_readlane -- six dependent
+// ds_bpermute round trips per sum made this kernel 10 x slower (profiles/r7y_wm_kernel_stats.csv).  The
+// result is uniform.
+__device__ __forceinline__ double wm_wave_sum(double x) {
+  x = x + wm_dpp_f64<0xB1>(x);   // quad_perm [1,0,3,2]: lane ^ 1
+  x = x + wm_dpp_f64<0x4E>(x);   // quad_perm [2,3,0,1]: lane ^ 2
+  x = x + wm_dpp_f64<0x141>(x);  // row_half_mirror: the other quad
+  x = x + wm_dpp_f64<0x140>(x);  // row_mirror: the other half row
+  return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
+}
+// inclusive sum over the lanes at or ABOVE this one (the order the stacks are popped in), without LDS: a
+// Hillis-Steele scan inside every row of 16 lanes by DPP row shifts, the sums of the rows above added as scalars
+template <int kCtrl>
+__device__ __forceinline__ double wm_dpp_f64_or0(double x) {  // the selected lane's value, 0 where the row ends
+  const uint64_t u = (uint64_t)__double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, kCtrl, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), kCtrl, 0xF, 0xF, true);
+  return __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
+}
+__device__ __forceinline__ double wm_scan_down(double x, int lane) {
+  x = x + wm_dpp_f64_or0<0x101>(x);  // row_shl:1  (lane l reads lane l + 1 of its row)
+  x = x + wm_dpp_f64_or0<0x102>(x);  // row_shl:2
+  x = x + wm_dpp_f64_or0<0x104>(x);  // row_shl:4
+  x = x + wm_dpp_f64_or0<0x108>(x);  // row_shl:8
+  const double t1 = readlane_f64(x, 16), t2 = readlane_f64(x, 32), t3 = readlane_f64(x, 48);
+  const double s2 = t2 + t3, s1 = t1 + s2;
+  const int row = lane >> 4;
+  return x + (row == 0 ? s1 : (row == 1 ? s2 : (row == 2 ? t3 : 0.0)));
+}
+
+// The shared positions of the edge walked last, taken in ASCENDING order by blocks of 256 slots.  The wave
+// holds a window of 64 list entries in registers (lane l: entry base + l) and reloads it only when the blocks
+// have consumed it -- a list load per block would put a memory round trip on the path of every block.
+struct WmWindow {
+  int base;  // first entry of the window (wave-uniform); entries below `lm` are consumed
+  int lm;
+  int pos;   // this lane's entry (0x7fffffff past the end of the list)
+};
+__device__ __forceinline__ void wm_window_load(WmWindow &W, const WlRow &R, int lane) {
+  W.base = W.lm;
+  const int k = W.base + lane;
+  W.pos = k < R.nM ? wl_list_at(R, k) : 0x7fffffff;
+}
+__device__ __forceinline__ void wm_window_init(WmWindow &W, const WlRow &R, int lane, int lm) {
+  W.lm = lm;
+  W.pos = 0x7fffffff;
+  W.base = lm;
+  if (!R.first && R.nM > 0) wm_window_load(W, R, lane);
+}
+// which of the lane's 4 slots [c0 + 4 lane, + 4) of the block starting at slot c0 are shared positions: byte k
+// of the result.  Entries below c0 are passed over.  The lanes that hold an entry of the block set its byte in
+// the wave's LDS, every lane reads the dword of its own slots and clears it.
+__device__ __forceinline__ uint32_t wm_block_flags(WmWindow &W, const WlRow &R, int c0, int lane, WmLds &L) {
+  if (R.first || R.nM == 0) return 0u;
+  bool any = false;
+  for (;;) {
+    const bool in = W.base + lane >= W.lm && W.pos < c0 + 256;
+    const uint64_t bal = ballot64(in);
+    if (bal) {
+      if (in && W.pos >= c0) {
+        reinterpret_cast<uint8_t *>(L.flags)[W.pos - c0] = 1;
+        any = true;
+      }
+      W.lm += __popcll(bal);
+    }
+    if (W.lm < W.base + 64 || W.lm >= R.nM) break;
+    wm_window_load(W, R, lane);  // the window is used up and the list goes on
+  }
+  if (!ballot64(any)) return 0u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t m4 = L.flags[lane];
+  __builtin_amdgcn_wave_barrier();
+  L.flags[lane] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return m4;
+}
+// first list entry at or beyond position `pos` (wave-uniform binary search)
+__device__ __forceinline__ int wm_list_lower(const WlRow &R, int pos) {
+  int lo = 0, hi = R.nM;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (wl_list_at(R, mid) < pos)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// 4 consecutive stored weights of a row, widened (slots at or beyond n: 0)
+template <typename WT>
+__device__ __forceinline__ void wm_load4(const WT *w, int j0, int n, double (&out)[4]) {
+  if (j0 + 4 <= n) {
+    struct __attribute__((packed, aligned(4))) Pack {
+      WT v[4];
+    };
+    const Pack pk = *reinterpret_cast<const Pack *>(w + j0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = (double)pk.v[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = (j0 + k < n) ? (double)w[j0 + k] : 0.0;
+  }
+}
+
+// probs - 1 (x) of the lane's 4 slots of block `blk`, looked at again after the pass over the row (0 for slots
+// beyond the row); the list cursor of the block's entry was recorded by the pass
+template <typename WT, bool kPow2>
+__device__ __forceinline__ void wm_block_again(const WlRow &R, const WT *w, const WlConsts &K, double inv, int blk,
+                                               int g, int lane, WmLds &L, double (&x)[4]) {
+  double raw[4];
+  const int c0 = blk << 8, j0 = c0 + 4 * lane;
+  wm_load4<WT>(w, j0, R.n, raw);
+  WmWindow W;
+  wm_window_init(W, R, lane, (!R.first && R.nM > 0) ? L.lm0[blk / g] : 0);
+  const uint32_t m4 = wm_block_flags(W, R, c0, lane, L);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = j0 + k;
+    int cls = 1;
+    if (!R.first) cls = ((m4 >> (8 * k)) & 1u) ? 1 : ((j >= R.rpos && j < R.rpos + R.nR) ? 2 : 0);
+    x[k] = j < R.n ? wl_bias<kPow2>(raw[k], cls, K) * inv - 1.0 : 0.0;
+  }
+}
+
+// The first crossing of `target` by the running sum, from the top of the row, of the d (kDeficit) or e of
+// the slots: returns its slot (or -1: the sum of the whole row stays below target), `before` / `at` = the
+// running sum without / with that slot; kWmUndecided when the sums per entry and per slot disagree.
+// L.cd / L.cx hold the sums from the BOTTOM of the row up to the end of every entry (g blocks of 256 slots
+// each), so the sum from the top down to the start of entry i is total - c[i - 1].
+template <typename WT, bool kPow2, bool kDeficit>
+__device__ __forceinline__ int wm_crossing(const WlRow &R, const WT *w, const WlConsts &K, double inv, double target,
+                                           int nent, int g, double tot_d, double tot_x, int lane, WmLds &L,
+                                           double &before, double &at) {
+  const double tot = kDeficit ? tot_d : tot_x + tot_d;
+  int ent = -1;
+  double base = 0.0;  // the sum over the entries above `ent`
+  for (int top = nent - 1; top >= 0 && ent < 0; top -= 64) {
+    const int e = top - lane;  // lane 0 holds the topmost entry
+    double below = 0.0, upto = 0.0;  // sums from the bottom to the start / to the end of entry e
+    if (e >= 0) {
+      upto = kDeficit ? L.cd[e] : L.cx[e] + L.cd[e];
+      if (e > 0) below = kDeficit ? L.cd[e - 1] : L.cx[e - 1] + L.cd[e - 1];
+    }
+    const uint64_t hit = ballot64(e >= 0 && tot - below >= target);
+    if (hit) {
+      const int l = __builtin_ctzll(hit);
+      ent = top - l;
+      base = tot - readlane_f64(upto, l);
+    }
+  }
+  if (ent < 0) return -1;
+  // inside the entry: its blocks from the top; in a block the lanes from the top, in a lane its 4 slots
+  const int nblk = (R.n + 255) >> 8;
+  for (int blk = min(nblk, (ent + 1) * g) - 1; blk >= ent * g; --blk) {
+    double x[4], v[4];
+    wm_block_again<WT, kPow2>(R, w, K, inv, blk, g, lane, L, x);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = kDeficit ? fmax(-x[k], 0.0) : fmax(x[k], 0.0);
+    const double mine = (v[0] + v[1]) + (v[2] + v[3]);
+    const double inc = wm_scan_down(mine, lane);
+    const uint64_t hit = ballot64(base + inc >= target);
+    if (hit) {
+      const int l = 63 - __builtin_clzll(hit);
+      double run = readlane_f64(base + inc - mine, l);  // everything above the lane's slots
+#pragma unroll
+      for (int k = 3; k >= 0; --k) {
+        const double vk = readlane_f64(v[k], l);
+        if (run + vk >= target) {
+          before = run;
+          at = run + vk;
+          return (blk << 8) + 4 * l + k;
+        }
+        run += vk;
+      }
+      return kWmUndecided;  // (the lane's sum crossed, its slots one by one did not: rounding)
+    }
+    base = readlane_f64(base + inc, 0);
+  }
+  return kWmUndecided;  // (rounding between the entry sums and the slot sums: nobody crossed inside the entry)
+}
+
+// the first slot below position `top` that is overfull, every slot skipped on the way underfull -- by the
+// margin delta on both sides, else kWmUndecided
+template <typename WT, bool kPow2>
+__device__ __forceinline__ int wm_next_over_below(const WlRow &R, const WT *w, const WlConsts &K, double inv,
+                                                  double delta, int top, int g, int lane, WmLds &L) {
+  for (int blk = (top - 1) >> 8; blk >= 0; --blk) {
+    double x[4];
+    wm_block_again<WT, kPow2>(R, w, K, inv, blk, g, lane, L, x);
+    int best = -1;  // the lane's highest slot below `top` that is not decidedly underfull (bit 2: not decidedly overfull)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = (blk << 8) + 4 * lane + k;
+      const bool below = j < R.n && j < top;
+      const bool over = x[k] > 2.0 * delta, unsure = !over && !(x[k] < -2.0 * delta);
+      if (below && (over || unsure)) best = k | (unsure ? 4 : 0);
+    }
+    const uint64_t any = ballot64(best >= 0);
+    if (any) {
+      const int l = 63 - __builtin_clzll(any);
+      const int code = __builtin_amdgcn_readlane(best, l);
+      if (code & 4) return kWmUndecided;
+      return (blk << 8) + 4 * l + (code & 3);
+    }
+  }
+  return kWmUndecided;  // no overfull slot left: the slot asked for would keep alias 0
+}
+
+// index sampling_from_alias(r1, r2) returns on the table of this row, or kWmUndecided.  row_sum = the sum of
+// the STORED weights of the row (any order; n2v_row_weight_sums).
+template <typename WT, bool kPow2>
+__device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlConsts &K, double row_sum, double w_grid,
+                                       double w_max, int pick, double r2, int lane, WmLds &L) {
+  const int n = R.n;
+  const bool biased = !R.first;
+  // ---- the row sum WITHOUT a pass over the row: every slot is "other" (w / q) but the shared positions and
+  //      the return run, so sum = W / q + (1 - 1 / q) sum(shared w) + (1 / p - 1 / q) sum(return w): O(list) ----
+  const double cq = kPow2 ? K.inv_q : 1.0 / K.q, cp = kPow2 ? K.inv_p : 1.0 / K.p;
+  double total = row_sum, kfac = 1.0;
+  bool pick_shared = false;
+  if (biased) {
+    double acc_s = 0.0, acc_r = 0.0;
+    for (int k = lane; k < R.nM; k += 64) {
+      const int pos = wl_list_at(R, k);
+      pick_shared = pick_shared || pos == pick;
+      acc_s += (double)w[pos < n ? pos : 0];
+    }
+    for (int j = R.rpos + lane; j < R.rpos + R.nR; j += 64) acc_r += (double)w[j];
+    const double ss = R.nM > 0 ? wm_wave_sum(acc_s) : 0.0, sr = R.nR > 0 ? wm_wave_sum(acc_r) : 0.0;
+    total = cq * row_sum + (1.0 - cq) * ss + (cp - cq) * sr;
+    const double cmax = fmax(fmax(cp, cq), 1.0), cmin = fmin(fmin(cp, cq), 1.0);
+    kfac = 1.0 + 2.0 * (cmax / cmin);  // the three terms are up to cmax / cmin times the sum each
+  }
+  if (!(total > 0.0) || !(total < 1.0e300) || !(row_sum > 0.0)) return kWmUndecided;
+  int cls_pick = 1;
+  if (biased) cls_pick = ballot64(pick_shared) ? 1 : ((pick >= R.rpos && pick < R.rpos + R.nR) ? 2 : 0);
+  const double b_pick = wl_bias<kPow2>((double)w[pick], cls_pick, K);
+  const double nn = (double)n;
+  const double inv = nn / total;  // 1 / avg
+  const double eps = 2.220446049250313e-16;
+  // EXACT row sum: when every biased weight is a multiple of one power of two G (fp32 weights: w_grid = the
+  // place of the last mantissa bit of the smallest one; factors powers of two) and n max < 2^52 G, the
+  // reference's left-to-right sum rounds nowhere, and neither do the three products and two additions above
+  // (coef_bits of room): `total` IS the reference's.  Then what separates b * inv from probs[i] is 4 roundings,
+  // and the margin covers the loop (2 roundings per pairing, each of a value <= max(probs) + 1) and the sums
+  // taken here (a lane adds n / 256 blocks, the tree 16 more, each of a value <= 4 D + 4) -- linear in n,
+  // not 16 n^2: on the hubs, where n^2 2^-52 is 10^-6 and a replay costs a millisecond, that is the difference
+  // between four walkers per step left to the exact kernel and none.
+  const double cmax = biased ? fmax(fmax(cp, cq), 1.0) : 1.0, cmin = biased ? fmin(fmin(cp, cq), 1.0) : 1.0;
+  const bool exact_total = (kPow2 || !biased) && w_grid > 0.0 &&
+                           nn * w_max * cmax < w_grid * cmin * ldexp(1.0, 52 - (biased ? K.coef_bits : 0));
+  const double delta = exact_total ? 8.0 * eps
+                                   : kfac * (2.0 * nn + 16.0) * eps;  // relative distance of b * inv from probs[i]
+  double M = kfac * 16.0 * nn * nn * eps;
+  const double p_pick = b_pick * inv;
+  const bool under = p_pick < 1.0 - 2.0 * delta;
+#if defined(N2V_WM_ABLATE) && N2V_WM_ABLATE == 1  // timing only: the walk ends with the row sum
+  return pick;
+#endif
+  if (!under && !(p_pick > 1.0 + 2.0 * delta)) return kWmUndecided;
+  if (under) {
+    if (r2 < p_pick * (1.0 - delta)) return pick;  // an underfull slot keeps its probs: accepted
+    if (!(r2 > p_pick * (1.0 + delta))) return kWmUndecided;
+  }
+  // ---- ONE pass over the row, 4 slots per lane and block of 256: x = probs - 1 and d = max(-x, 0) summed per
+  //      lane; the running sums over the wave are taken at the end of every entry (e = x + d) -------------
+  const int nblk = (n + 255) >> 8;
+  const int g = (nblk + kWmEntries - 1) / kWmEntries;  // blocks per entry
+  const int nent = (nblk + g - 1) / g;
+  const int bp = pick >> 8;
+  double run_d = 0.0, run_x = 0.0;  // per lane, the whole row so far
+  double pre_d = 0.0, pre_x = 0.0;  // per lane: the same over the slots BELOW pick
+  WmWindow W;
+  wm_window_init(W, R, lane, 0);
+  double raw[4], ahead[4];
+  wm_load4<WT>(w, 4 * lane, n, ahead);
+  int in_entry = 0, ent = 0;
+  double tot_d = 0.0, tot_x = 0.0;
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int c0 = blk << 8, j0 = c0 + 4 * lane;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) raw[k] = ahead[k];
+    if (blk + 1 < nblk) wm_load4<WT>(w, j0 + 256, n, ahead);  // (one block ahead)
+    if (in_entry == 0 && lane == 0) L.lm0[ent] = W.lm;  // (looked at again: wm_block_again)
+    const uint32_t m4 = wm_block_flags(W, R, c0, lane, L);  // byte k: slot j0 + k is a shared position
+    if (blk == bp) {
+      pre_d = run_d;
+      pre_x = run_x;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = j0 + k;
+      int cls = 1;
+      if (biased) cls = ((m4 >> (8 * k)) & 1u) ? 1 : ((j >= R.rpos && j < R.rpos + R.nR) ? 2 : 0);
+      const double b = wl_bias<kPow2>(raw[k], cls, K);
+      const double x = j < n ? b * inv - 1.0 : 0.0;
+      const double d = fmax(-x, 0.0);
+      run_x += x;
+      run_d += d;
+      if (blk == bp && j < pick) {
+        pre_x += x;
+        pre_d += d;
+      }
+    }
+    if (++in_entry == g || blk + 1 == nblk) {
+      tot_d = wm_wave_sum(run_d);
+      tot_x = wm_wave_sum(run_x);
+      if (lane == 0) {
+        L.cd[ent] = tot_d;
+        L.cx[ent] = tot_x;
+      }
+      in_entry = 0;
+      ++ent;
+    }
+  }
+  const double below_d = wm_wave_sum(pre_d), below_x = wm_wave_sum(pre_x);  // over the slots below pick
+  if (exact_total)
+    M = 8.0 * eps * (nn * (w_max * cmax * inv + 12.0) + (nn * (1.0 / 256.0) + 16.0) * (4.0 * tot_d + 4.0));
+#if defined(N2V_WM_ABLATE) && N2V_WM_ABLATE == 2  // timing only: the walk ends with the pass over the row
+  return below_d + below_x > 1.0e300 ? 0 : pick;
+#endif
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const double x_pick = p_pick - 1.0;
+  double before = 0.0, at = 0.0;
+  if (under) {
+    // rejected: alias = the overfull slot on top when `pick` is popped -- the first k with E_k >= D_{j-1},
+    // D_{j-1} = the d of the slots ABOVE pick
+    const double d_above = tot_d - below_d - (-x_pick);
+    if (!(d_above > M)) {
+      // (next to) nothing underfull above pick: the topmost overfull slot is still `over` when pick is popped
+      // if its excess outlasts whatever was popped before -- at most d_above + M <= 2 M
+      const int t = wm_next_over_below<WT, kPow2>(R, w, K, inv, delta, n, g, lane, L);
+      if (t < 0) return kWmUndecided;
+      int cls_t = 1;
+      if (biased) {
+        const int lo = wm_list_lower(R, t);
+        const bool shared = lo < R.nM && wl_list_at(R, lo) == t;
+        cls_t = shared ? 1 : ((t >= R.rpos && t < R.rpos + R.nR) ? 2 : 0);
+      }
+      const double p_t = wl_bias<kPow2>((double)w[t], cls_t, K) * inv;
+      return p_t - 1.0 >= 3.0 * M ? t : kWmUndecided;
+    }
+    const int k = wm_crossing<WT, kPow2, false>(R, w, K, inv, d_above, nent, g, tot_d, tot_x, lane, L, before, at);
+    if (k < 0 || !(before <= d_above - M) || !(at >= d_above + M)) return kWmUndecided;
+    return k;
+  }
+  // overfull: demoted by the first underfull slot j with D_j > E_k (E_k = the e of the slots at or above
+  // pick), then probs = 1 + E_k - D_j
+  const double e_from = (tot_x + tot_d) - (below_x + below_d);
+  if (tot_d <= e_from - M) return pick;  // never demoted
+  if (tot_d <= e_from + M)               // demoted, if at all, with probs >= 1 - 2 M
+    return r2 < 1.0 - 3.0 * M ? pick : kWmUndecided;
+  const int j = wm_crossing<WT, kPow2, true>(R, w, K, inv, e_from, nent, g, tot_d, tot_x, lane, L, before, at);
+  if (j < 0 || !(before <= e_from - M) || !(at >= e_from + M)) return kWmUndecided;
+  const double resid = 1.0 + e_from - at;
+  if (r2 < resid - M) return pick;
+  if (!(r2 > resid + M)) return kWmUndecided;
+  return wm_next_over_below<WT, kPow2>(R, w, K, inv, delta, pick, g, lane, L);  // alias = the next `over`
+}
+
+constexpr int kWmWaves = 4;
+
+template <typename WT, bool kPow2>
+__global__ __launch_bounds__(kWmWaves * 64) void walk_weighted_margin_kernel(
+    n2v_graph g, const WT *__restrict__ w, const int32_t *__restrict__ start_ids, int32_t num_walks,
+    const int64_t *__restrict__ order, int64_t n_rows, int32_t min_n, int32_t step, int32_t walk_length,
+    WlConsts K, uint64_t seed, int64_t *__restrict__ edge_state, int32_t *__restrict__ walks,
+    uint8_t *__restrict__ valid, uint32_t *__restrict__ status, int64_t *__restrict__ undecided,
+    const double *__restrict__ row_sums) {
+  __shared__ WmLds lds_all[kWmWaves];
+  const int lane = threadIdx.x & 63;
+  WmLds &L = lds_all[threadIdx.x >> 6];
+  L.flags[lane] = 0u;
+  // (behind the sums of the rows: the grid of the stored weights -- 0: unknown -- and their maximum)
+  const double w_grid = readfirstlane_f64(row_sums[g.n_vertices]);
+  const double w_max = readfirstlane_f64(row_sums[g.n_vertices + 1]);
+  const int L1 = walk_length + 1;
+  const bool biased = !(K.p == 1.0 && K.q == 1.0);
+  // Walkers are dealt to the waves round robin (the order is by row length, descending: every wave gets the
+  // same mix, and stops at the first row that is the lane kernel's).  A shared counter -- one atomic per
+  // walker on ONE address -- took 12 ns per walker, 32 of the 36 ms of a step (profiles/r7z_wm_ablation.log).
+  const int64_t n_waves = (int64_t)gridDim.x * kWmWaves;
+  for (int64_t i = (int64_t)blockIdx.x * kWmWaves + (threadIdx.x >> 6); i < n_rows; i += n_waves) {
+    const int64_t r = readfirstlane_i64(order[i]);
+    if (r < 0 || r >= n_rows) break;  // (the lane kernel flags it)
+    int32_t *row = walks + r * (int64_t)L1;
+    const int32_t v = __builtin_amdgcn_readfirstlane(row[step]);
+    if (v < 0 || (int64_t)v >= g.n_vertices || !valid[r]) break;  // vanished walkers come last in the order
+    const int64_t vb = readfirstlane_i64(g.rowptr[v]);
+    WlRow R;
+    R.n = (int)(readfirstlane_i64(g.rowptr[v + 1]) - vb);
+    if (R.n <= min_n) break;  // this row and every later one: the lane kernel's
+    const int32_t s = step > 0 ? __builtin_amdgcn_readfirstlane(row[step - 1]) : -1;
+    R.first = s < 0 || !biased;
+    R.nR = R.nM = R.rpos = 0;
+    R.list = nullptr;
+    R.wide = false;
+    bool ok = true;
+    if (!R.first) {
+      const int64_t e_prev = readfirstlane_i64(edge_state[r]);
+      if (e_prev < 0 || e_prev >= g.n_edges) {
+        ok = false;
+      } else {
+        const uint32_t ec = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.edge_classes[e_prev]);
+        const uint64_t wraw = readfirstlane_u64(g.wedge_off[e_prev]);
+        const uint32_t fR = ec >> N2V_EC_RETURN_SHIFT, fM = ec & N2V_EC_SHARED_MASK;
+        R.nR = (int)fR;
+        R.nM = (int)fM;
+        R.rpos = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
+        R.wide = wedge_row_wide(g.wedge_wide, R.n);
+        const uint64_t off = wraw & N2V_WEDGE_OFF_MASK;
+        R.list = R.wide ? (const void *)(reinterpret_cast<const uint32_t *>(g.wedge_pos) + off)
+                        : (const void *)(reinterpret_cast<const uint16_t *>(g.wedge_pos) + off);
+        ok = fR != N2V_EC_RETURN_SAT && fM != N2V_EC_SHARED_MASK && (int64_t)fR + (int64_t)fM <= R.n &&
+             R.rpos + (int)fR <= R.n;
+      }
+    }
+    if (!ok) {
+      if (lane == 0) atomicOr(status, N2V_ST_RANGE);
+      continue;
+    }
+    const uint64_t key = (uint64_t)start_ids[r / num_walks] * (uint64_t)num_walks + (uint64_t)(r % num_walks);
+    const uint64_t bits = step_bits(walker_stream(seed, key), (uint32_t)step);
+    const uint32_t u1 = (uint32_t)(bits >> 32), u2 = (uint32_t)bits;
+    const int pick = pick_index(u1, R.n);
+    const double r2 = (double)u2 * (1.0 / 4294967296.0);
+    const double row_sum = readfirstlane_f64(row_sums[v]);
+    const int idx = wm_draw<WT, kPow2>(R, w + vb, K, row_sum, w_grid, w_max, pick, r2, lane, L);
+    if (lane == 0) {
+      if (idx < 0) {  // not decided by the margins: the exact wave kernel steps this walker
+        const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long *>(undecided), 1ull);
+        undecided[1 + at] = r;
+      } else {
+        const int64_t e = vb + idx;
+        const int32_t x = g.col[e];
+        row[step + 1] = x;
+        edge_state[r] = e;
+        if (step + 1 < walk_length &&
+            (x < 0 || (int64_t)x >= g.n_vertices || g.rowptr[x + 1] == g.rowptr[x]))
+          valid[r] = 0;  // fugue.py:147
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace n2v
 
 extern "C" int n2v_weighted_step_wave_launch(const n2v_graph *g, const int32_t *start_ids, int32_t num_walks,
@@ -485,11 +985,42 @@ static int wl_launch(const n2v_graph *g, const WT *w, const int32_t *start_ids, 
 }
 }  // namespace n2v
 
+// rows of at least this many slots: a wave per walker that decides the pairing with margins
+// (walk_weighted_margin_kernel), given an order and a scratch list for the walkers it leaves undecided
+#ifndef N2V_WLANES_MARGIN_FROM
+#define N2V_WLANES_MARGIN_FROM 128
+#endif
+
+namespace n2v {
+template <typename WT>
+static int wm_launch(const n2v_graph *g, const WT *w, const int32_t *start_ids, int32_t num_walks,
+                     const int64_t *order, int64_t n_rows, int min_n, int32_t step, int32_t walk_length,
+                     const WlConsts &K, uint64_t seed, int64_t *edge_state, int32_t *walks, uint8_t *valid,
+                     uint32_t *status, int64_t *undecided, const double *row_sums, hipStream_t st) {
+  const bool pow2 = K.p_pow2 && K.q_pow2;
+  const void *fn = pow2 ? (const void *)walk_weighted_margin_kernel<WT, true>
+                        : (const void *)walk_weighted_margin_kernel<WT, false>;
+  int64_t blocks = (n_rows + kWmWaves - 1) / kWmWaves;
+  const int64_t cap = resident_blocks(fn, kWmWaves * 64, 0);
+  if (blocks > cap) blocks = cap;
+  if (pow2)
+    hipLaunchKernelGGL((walk_weighted_margin_kernel<WT, true>), dim3((unsigned)blocks), dim3(kWmWaves * 64), 0, st, *g,
+                       w, start_ids, num_walks, order, n_rows, min_n, step, walk_length, K, seed, edge_state, walks,
+                       valid, status, undecided, row_sums);
+  else
+    hipLaunchKernelGGL((walk_weighted_margin_kernel<WT, false>), dim3((unsigned)blocks), dim3(kWmWaves * 64), 0, st, *g,
+                       w, start_ids, num_walks, order, n_rows, min_n, step, walk_length, K, seed, edge_state, walks,
+                       valid, status, undecided, row_sums);
+  return hipGetLastError() == hipSuccess ? N2V_OK : N2V_ELAUNCH;
+}
+}  // namespace n2v
+
 extern "C" int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_ids, int32_t num_walks,
                                       const int64_t *order, int64_t n_rows, int32_t step,
                                       int32_t walk_length, double return_param, double inout_param,
                                       uint64_t seed, int64_t *edge_state, int32_t *walks, uint8_t *valid,
-                                      uint32_t *status, void *stream) {
+                                      uint32_t *status, int64_t *scratch, const double *row_sums,
+                                      void *stream) {
   if (!g || !g->rowptr || !g->col || n_rows < 0 || num_walks < 1 || walk_length < 0) return N2V_EINVAL;
   if (step < 0 || step >= walk_length) return N2V_EINVAL;
   if (return_param == 0.0 || inout_param == 0.0) return N2V_EINVAL;  // randomwalk.py:214-217
@@ -507,6 +1038,21 @@ extern "C" int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_i
   int ex = 0;
   K.p_pow2 = frexp(return_param, &ex) == 0.5 && ex > -500 && ex < 500;
   K.q_pow2 = frexp(inout_param, &ex) == 0.5 && ex > -500 && ex < 500;
+  K.coef_bits = 0;
+  if (K.p_pow2 && K.q_pow2) {  // significant bits of the coefficients 1 - 1/q and 1/p - 1/q of wm_draw's row sum
+    const double co[2] = {fabs(1.0 - K.inv_q), fabs(K.inv_p - K.inv_q)};
+    for (double c : co) {
+      if (c == 0.0) continue;
+      double m = frexp(c, &ex);
+      int bits = 0;
+      while (m != 0.0 && bits < 60) {  // mantissa bits until nothing is left
+        m *= 2.0;
+        m -= floor(m);
+        ++bits;
+      }
+      K.coef_bits = bits > K.coef_bits ? bits : K.coef_bits;
+    }
+  }
   hipStream_t st = (hipStream_t)stream;
   // Without an order every row is the 8-slot instance's.  With one (rows sorted by the length of the row
   // stood on, descending): the rows above N2V_WLANES_SHORT slots first, in 32-slot groups; a whole wave per
@@ -514,7 +1060,27 @@ extern "C" int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_i
   const int short_n = order ? N2V_WLANES_SHORT : 0x7fffffff;
   const int wave_from = order ? N2V_WLANES_WAVE_FROM : 0x7fffffff;
   int rc = N2V_OK;
-  if (order && wave_from != 0x7fffffff) {
+  int lanes_max = 0x7fffffff;  // the lane kernel's rows: up to this many slots
+  if (order && scratch && row_sums && N2V_WLANES_MARGIN_FROM > 1) {
+    // long rows first (the order is by row length, descending): a wave per walker, the pairing decided with
+    // margins; scratch[0] = how many walkers it left undecided, scratch[1 ..] = those, -1 behind the last:
+    // the exact wave kernel steps them
+    const int from = N2V_WLANES_MARGIN_FROM;
+    if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), st) != hipSuccess ||
+        hipMemsetAsync(scratch, 0xff, sizeof(int64_t) * (size_t)(n_rows + 2), st) != hipSuccess ||
+        hipMemsetAsync(scratch, 0, sizeof(int64_t), st) != hipSuccess)
+      return N2V_ELAUNCH;
+    rc = g->w64 ? n2v::wm_launch<double>(g, g->w64, start_ids, num_walks, order, n_rows, from - 1, step, walk_length,
+                                         K, seed, edge_state, walks, valid, status, scratch, row_sums, st)
+                : n2v::wm_launch<float>(g, g->w, start_ids, num_walks, order, n_rows, from - 1, step, walk_length, K,
+                                        seed, edge_state, walks, valid, status, scratch, row_sums, st);
+    if (rc != N2V_OK) return rc;
+    if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), st) != hipSuccess) return N2V_ELAUNCH;
+    rc = n2v_weighted_step_wave_launch(g, start_ids, num_walks, scratch + 1, n_rows, 0, step, walk_length,
+                                       return_param, inout_param, seed, edge_state, walks, valid, status, stream);
+    if (rc != N2V_OK) return rc;
+    lanes_max = from - 1;
+  } else if (order && wave_from != 0x7fffffff) {
     if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), st) != hipSuccess) return N2V_ELAUNCH;
     rc = n2v_weighted_step_wave_launch(g, start_ids, num_walks, order, n_rows, wave_from - 1, step, walk_length,
                                        return_param, inout_param, seed, edge_state, walks, valid, status, stream);
@@ -525,14 +1091,16 @@ extern "C" int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_i
       rc = n2v::wl_launch<double, 32, 64>(g, g->w64, start_ids, num_walks, order, n_rows, short_n, wave_from - 1,
                                           step, walk_length, K, seed, edge_state, walks, valid, status, st);
     if (rc == N2V_OK)
-      rc = n2v::wl_launch<double, 8, 256>(g, g->w64, start_ids, num_walks, order, n_rows, 0, short_n, step,
+      rc = n2v::wl_launch<double, 8, 256>(g, g->w64, start_ids, num_walks, order, n_rows, 0,
+                                          short_n < lanes_max ? short_n : lanes_max, step,
                                           walk_length, K, seed, edge_state, walks, valid, status, st);
   } else {
     if (order && short_n != 0x7fffffff)
       rc = n2v::wl_launch<float, 32, 64>(g, g->w, start_ids, num_walks, order, n_rows, short_n, wave_from - 1,
                                          step, walk_length, K, seed, edge_state, walks, valid, status, st);
     if (rc == N2V_OK)
-      rc = n2v::wl_launch<float, 8, 256>(g, g->w, start_ids, num_walks, order, n_rows, 0, short_n, step,
+      rc = n2v::wl_launch<float, 8, 256>(g, g->w, start_ids, num_walks, order, n_rows, 0,
+                                         short_n < lanes_max ? short_n : lanes_max, step,
                                          walk_length, K, seed, edge_state, walks, valid, status, st);
   }
   return rc;

@@ -242,6 +242,7 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
 # enough walkers to fill the chip beside the wave that stands on the longest row: that wave is the tail of
 # every step (cfg 2 weighted: 78 ms per step whatever the batch; 4.7 M walkers: 53 M steps/s against 35 - 40 M,
 # 0.47 M walkers: 6 M against 34 M -- profiles/r7k_time_wlanes.log)
+WEIGHTED_LANES_MARGINS = True  # rows of 128 slots or more: a wave per walker that decides the pairing with margins
 WEIGHTED_LANES_MIN_WALKERS = 1 << 21
 
 
@@ -255,6 +256,33 @@ def weighted_lanes_tables(graph: DeviceGraph, insist: bool = False) -> bool:
         graph.wedge_tried = True
         graph.build_wedges(slots=False)
     return graph.wedge_off is not None
+
+
+def weighted_row_sums(graph: DeviceGraph) -> Optional[torch.Tensor]:
+    """fp64 sum of the stored weights of every row (any order), kept on the graph: what the wave kernel for
+    long rows takes the row sum of a step from (n2v_walk_weighted_step).  None when some weight is negative
+    or not finite -- the margins of that kernel assume neither -- and the lane kernel then walks alone."""
+    got = getattr(graph, "_row_weight_sums", None)
+    if got is None:
+        w = graph.w
+        if not bool((torch.isfinite(w) & (w >= 0)).all()):
+            got = False
+        else:
+            # (per-row sums as differences of one running sum would carry the error of the whole graph;
+            # index_add_ serialises its atomics on the hub rows: 1.6 s on cfg 2)
+            got = torch.empty(graph.n_vertices + 2, dtype=torch.float64, device=graph.device)
+            got[:graph.n_vertices] = torch.segment_reduce(w.double(), "sum", offsets=graph.rowptr)
+            # behind the sums: a power of two that divides every stored weight (fp32: the place of the last
+            # mantissa bit of the smallest one; fp64 weights: none claimed) and the largest weight -- with
+            # them the kernel knows when the reference's own row sum rounds nowhere (include/n2v_hip.h)
+            pos = w[w > 0]
+            grid = 0.0
+            if w.dtype == torch.float32 and pos.numel():
+                grid = 2.0 ** (int(torch.frexp(pos)[1].min()) - 24)
+            got[graph.n_vertices] = grid
+            got[graph.n_vertices + 1] = float(w.max()) if w.numel() else 0.0
+        graph._row_weight_sums = got
+    return None if got is False else got
 
 
 def _walk_weighted_lanes(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_length: int,
@@ -292,6 +320,10 @@ def _walk_weighted_lanes(graph: DeviceGraph, start_ids: torch.Tensor, num_walks:
     walks[:, 0] = torch.where(alive, start_ids, torch.full_like(start_ids, -1)).repeat_interleave(W)
     valid.copy_(alive.repeat_interleave(W).to(torch.uint8))
     edge_state = torch.full((total,), -1, dtype=torch.int64, device=dev)
+    # the list of the walkers whose step the wave kernel for long rows leaves to the exact kernel
+    row_sums = weighted_row_sums(graph) if WEIGHTED_LANES_MARGINS else None
+    scratch = torch.empty(total + 2, dtype=torch.int64, device=dev) if row_sums is not None else None
+    undecided = torch.zeros(1, dtype=torch.int64, device=dev)
     g = graph.c_struct()
     with torch.cuda.device(dev):
         stream = _lib.current_stream_ptr()
@@ -304,12 +336,17 @@ def _walk_weighted_lanes(graph: DeviceGraph, start_ids: torch.Tensor, num_walks:
             _lib.check(L.n2v_walk_weighted_step(g, start_ids.data_ptr(), W, order.data_ptr(), total, step, Lw,
                                                 float(p), float(q), seed & (2 ** 64 - 1),
                                                 edge_state.data_ptr(), walks.data_ptr(), valid.data_ptr(),
-                                                status.data_ptr(), stream), "n2v_walk_weighted_step")
+                                                status.data_ptr(), 0 if scratch is None else scratch.data_ptr(),
+                                                0 if row_sums is None else row_sums.data_ptr(), stream),
+                       "n2v_walk_weighted_step")
+            if scratch is not None and stats is not None:
+                undecided += scratch[:1]
     if check:
         _lib.check_status_word(int(status[0].item()), "n2v_walk")
     if stats is not None:
         stats["trials"] = status[2:4].view(torch.int64)
         stats["status"] = status
+        stats["undecided"] = undecided  # walker-steps the margins did not decide (stepped by the exact kernel)
     return walks, valid.bool() if out is None else valid
 
 

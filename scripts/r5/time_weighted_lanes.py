@@ -21,13 +21,19 @@ for kind in os.environ.get("KINDS", "fp32").split(","):
         p, q = (float(x) for x in pq.split(","))
         for batch in sorted({B, min(start_all.numel(), int(os.environ.get("BIG", start_all.numel())))}):
             start = start_all[:batch].contiguous()
-            best = 1e9
-            for it in range(2):
-                torch.cuda.synchronize(); t = time.time()
-                walks, valid = rw.walk(g, start, 10, 80, p, q, 42, use_weighted_lanes=True)
-                torch.cuda.synchronize(); best = min(best, time.time() - t)
-            steps = int(valid.sum()) * 80
-            print(f"{kind} p={p} q={q} {batch} start vertices: lanes {best * 1e3:8.1f} ms = {steps / best / 1e6:8.1f} M steps/s", flush=True)
+            for margins in ([True, False] if os.environ.get("BOTH") else [rw.WEIGHTED_LANES_MARGINS]):
+                rw.WEIGHTED_LANES_MARGINS = margins
+                best, st = 1e9, {}
+                for it in range(2):
+                    st = {}
+                    torch.cuda.synchronize(); t = time.time()
+                    walks, valid = rw.walk(g, start, 10, 80, p, q, 42, use_weighted_lanes=True, stats=st)
+                    torch.cuda.synchronize(); best = min(best, time.time() - t)
+                steps = int(valid.sum()) * 80
+                print(f"{kind} p={p} q={q} {batch} start vertices: lanes{' + a wave with margins per walker on rows >= 128' if margins else ''} "
+                      f"{best * 1e3:8.1f} ms = {steps / best / 1e6:8.1f} M steps/s"
+                      + (f"; walker-steps left to the exact wave kernel: {int(st['undecided'])} of {steps}" if margins else ""), flush=True)
+            rw.WEIGHTED_LANES_MARGINS = True
             if os.environ.get("OLD", "1") == "1" and batch == B:
                 torch.cuda.synchronize(); t = time.time()
                 w2, v2 = rw.walk(g, start, 10, 80, p, q, 42, use_weighted_lanes=False)

@@ -55,6 +55,19 @@ def test_closed_forms_on_the_exact_average_of_long_rows():
     assert last[0] == "total" and last[-2:] == ["bad", "0"] and int(last[1]) > 5000
 
 
+def test_weighted_rows_decided_with_margins_model():
+    """weighted_margins.py (round 5): the model of walk_weighted_margin_kernel -- the one slot a draw asks of a
+    WEIGHTED row's table decided from sums over the row (the k-th overfull slot is demoted where the running sum
+    of the deficits passes that of the excesses) with margins, the row sum taken from the stored row sum and
+    the shared / return slots -- against the table generate_alias_tables builds: random, heavy-tailed, few-valued
+    and nearly tied rows, uniforms drawn, exactly at the table's threshold and 1e-6 .. 1e-14 beside it.  Every
+    draw is either the table's or left undecided."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "models", "weighted_margins.py"), "700", "3"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert " 0 wrong" in res.stdout and "WRONG" not in res.stdout, res.stdout
+
+
 def test_a_class_exactly_on_the_average_model():
     """lane_case_b2_jump on rows whose "other" slots have excess 0 (scripts/models/flat_b2.py)"""
     env = dict(os.environ, N2V_MODEL_TRIALS="4000")
