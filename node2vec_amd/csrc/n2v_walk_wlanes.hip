@@ -467,7 +467,8 @@ __global__ __launch_bounds__(TH) void walk_weighted_step_kernel(
 // ~10^6; rows whose sums tie exactly (few distinct weights) are undecided often and walk at the exact
 // kernel's rate.  Same draws either way.
 constexpr int kWmUndecided = -2;
-constexpr int kWmEntries = 256;  // running sums kept per wave (a row of more than 256 x 256 slots: several blocks per entry)
+constexpr int kWmEntries = 128;
+constexpr int kWmMinBlocksPerEntry = 4;  // (a sum over the wave per entry: not per block)  // running sums kept per wave (a row of more than 256 x 256 slots: several blocks per entry)
 struct WmLds {
   double cd[kWmEntries], cx[kWmEntries];  // sum of d / of x = probs - 1 over the slots up to the end of entry i
   int lm0[kWmEntries];                    // how many shared positions lie below the first slot of entry i
@@ -584,17 +585,50 @@ __device__ __forceinline__ int wm_list_lower(const WlRow &R, int pos) {
 
 // 4 consecutive stored weights of a row, widened (slots at or beyond n: 0)
 template <typename WT>
-__device__ __forceinline__ void wm_load4(const WT *w, int j0, int n, double (&out)[4]) {
+__device__ __forceinline__ void wm_load4(const WT *w, int j0, int n, WT (&out)[4]) {  // (kept as stored: registers)
   if (j0 + 4 <= n) {
     struct __attribute__((packed, aligned(4))) Pack {
       WT v[4];
     };
     const Pack pk = *reinterpret_cast<const Pack *>(w + j0);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out[k] = (double)pk.v[k];
+    for (int k = 0; k < 4; ++k) out[k] = pk.v[k];
   } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out[k] = (j0 + k < n) ? (double)w[j0 + k] : 0.0;
+    for (int k = 0; k < 4; ++k) out[k] = (j0 + k < n) ? w[j0 + k] : (WT)0;
+  }
+}
+
+// x = probs - 1 of the lane's 4 slots [j0, j0 + 4) from their stored weights and the block's flags (m4: byte k
+// set = slot j0 + k is a shared position).  The value only has to be within a few roundings of b / avg - 1
+// (margins): with p and q powers of two the factor and 1 / avg are one product chosen per slot and x one fma.
+// kWhole: every slot of the block exists (all blocks but the last).
+template <typename WT, bool kPow2, bool kWhole>
+__device__ __forceinline__ void wm_block_x(const WlRow &R, const WlConsts &K, const WT (&raw)[4], uint32_t m4, int j0,
+                                           int c0, double inv, double (&x)[4]) {
+  const bool biased = !R.first;
+  const bool has_ret = biased && R.rpos < c0 + 256 && R.rpos + R.nR > c0;  // (uniform: the block holds return slots)
+  if constexpr (kPow2) {
+    const double f_shared = inv, f_other = biased ? K.inv_q * inv : inv, f_ret = K.inv_p * inv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool shared = (m4 >> (8 * k)) & 1u;
+      double f = shared ? f_shared : f_other;
+      if (has_ret && !shared && j0 + k >= R.rpos && j0 + k < R.rpos + R.nR) f = f_ret;
+      x[k] = __fma_rn((double)raw[k], f, -1.0);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int cls = 1;
+      if (biased)
+        cls = ((m4 >> (8 * k)) & 1u) ? 1 : ((has_ret && j0 + k >= R.rpos && j0 + k < R.rpos + R.nR) ? 2 : 0);
+      x[k] = __fma_rn(wl_bias<false>((double)raw[k], cls, K), inv, -1.0);
+    }
+  }
+  if constexpr (!kWhole) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = j0 + k < R.n ? x[k] : 0.0;
   }
 }
 
@@ -603,19 +637,13 @@ __device__ __forceinline__ void wm_load4(const WT *w, int j0, int n, double (&ou
 template <typename WT, bool kPow2>
 __device__ __forceinline__ void wm_block_again(const WlRow &R, const WT *w, const WlConsts &K, double inv, int blk,
                                                int g, int lane, WmLds &L, double (&x)[4]) {
-  double raw[4];
+  WT raw[4];
   const int c0 = blk << 8, j0 = c0 + 4 * lane;
   wm_load4<WT>(w, j0, R.n, raw);
   WmWindow W;
   wm_window_init(W, R, lane, (!R.first && R.nM > 0) ? L.lm0[blk / g] : 0);
   const uint32_t m4 = wm_block_flags(W, R, c0, lane, L);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int j = j0 + k;
-    int cls = 1;
-    if (!R.first) cls = ((m4 >> (8 * k)) & 1u) ? 1 : ((j >= R.rpos && j < R.rpos + R.nR) ? 2 : 0);
-    x[k] = j < R.n ? wl_bias<kPow2>(raw[k], cls, K) * inv - 1.0 : 0.0;
-  }
+  wm_block_x<WT, kPow2, false>(R, K, raw, m4, j0, c0, inv, x);
 }
 
 // The first crossing of `target` by the running sum, from the top of the row, of the d (kDeficit) or e of
@@ -759,44 +787,46 @@ __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlCons
     if (!(r2 > p_pick * (1.0 + delta))) return kWmUndecided;
   }
   // ---- ONE pass over the row, 4 slots per lane and block of 256: x = probs - 1 and d = max(-x, 0) summed per
-  //      lane; the running sums over the wave are taken at the end of every entry (e = x + d) -------------
+  //      lane; the running sums over the wave are taken at the end of every entry (e = x + d).  The loop body
+  //      is the kernel: whole blocks only (the last, partial block apart), no copy of prefetched weights, the
+  //      factor of a slot one select (the return run looked for only in the block that holds it) ------------
   const int nblk = (n + 255) >> 8;
-  const int g = (nblk + kWmEntries - 1) / kWmEntries;  // blocks per entry
+  const int g = max((nblk + kWmEntries - 1) / kWmEntries, kWmMinBlocksPerEntry);  // blocks per entry
   const int nent = (nblk + g - 1) / g;
   const int bp = pick >> 8;
-  double run_d = 0.0, run_x = 0.0;  // per lane, the whole row so far
-  double pre_d = 0.0, pre_x = 0.0;  // per lane: the same over the slots BELOW pick
+  double run_d = 0.0, run_x = 0.0;    // per lane, the whole row so far
+  double snap_d = 0.0, snap_x = 0.0;  // per lane: the same when the block of pick begins
   WmWindow W;
   wm_window_init(W, R, lane, 0);
-  double raw[4], ahead[4];
-  wm_load4<WT>(w, 4 * lane, n, ahead);
   int in_entry = 0, ent = 0;
   double tot_d = 0.0, tot_x = 0.0;
   for (int blk = 0; blk < nblk; ++blk) {
     const int c0 = blk << 8, j0 = c0 + 4 * lane;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) raw[k] = ahead[k];
-    if (blk + 1 < nblk) wm_load4<WT>(w, j0 + 256, n, ahead);  // (one block ahead)
     if (in_entry == 0 && lane == 0) L.lm0[ent] = W.lm;  // (looked at again: wm_block_again)
-    const uint32_t m4 = wm_block_flags(W, R, c0, lane, L);  // byte k: slot j0 + k is a shared position
     if (blk == bp) {
-      pre_d = run_d;
-      pre_x = run_x;
+      snap_d = run_d;
+      snap_x = run_x;
+    }
+    WT raw[4];
+    double x[4];
+    if (c0 + 256 <= n) {  // (uniform) a whole block: one 16-byte load per lane, no slot beyond the row
+      struct __attribute__((packed, aligned(4))) Pack {
+        WT v[4];
+      };
+      const Pack pk = *reinterpret_cast<const Pack *>(w + j0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) raw[k] = pk.v[k];
+      const uint32_t m4 = wm_block_flags(W, R, c0, lane, L);
+      wm_block_x<WT, kPow2, true>(R, K, raw, m4, j0, c0, inv, x);
+    } else {
+      wm_load4<WT>(w, j0, n, raw);
+      const uint32_t m4 = wm_block_flags(W, R, c0, lane, L);
+      wm_block_x<WT, kPow2, false>(R, K, raw, m4, j0, c0, inv, x);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int j = j0 + k;
-      int cls = 1;
-      if (biased) cls = ((m4 >> (8 * k)) & 1u) ? 1 : ((j >= R.rpos && j < R.rpos + R.nR) ? 2 : 0);
-      const double b = wl_bias<kPow2>(raw[k], cls, K);
-      const double x = j < n ? b * inv - 1.0 : 0.0;
-      const double d = fmax(-x, 0.0);
-      run_x += x;
-      run_d += d;
-      if (blk == bp && j < pick) {
-        pre_x += x;
-        pre_d += d;
-      }
+      run_x += x[k];
+      run_d += fmax(-x[k], 0.0);
     }
     if (++in_entry == g || blk + 1 == nblk) {
       tot_d = wm_wave_sum(run_d);
@@ -808,6 +838,18 @@ __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlCons
       in_entry = 0;
       ++ent;
     }
+  }
+  // the slots of pick's block below pick, once more
+  double pre_d = snap_d, pre_x = snap_x;
+  {
+    double xb[4];
+    wm_block_again<WT, kPow2>(R, w, K, inv, bp, g, lane, L, xb);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if ((bp << 8) + 4 * lane + k < pick) {
+        pre_x += xb[k];
+        pre_d += fmax(-xb[k], 0.0);
+      }
   }
   const double below_d = wm_wave_sum(pre_d), below_x = wm_wave_sum(pre_x);  // over the slots below pick
   if (exact_total)
@@ -856,9 +898,12 @@ __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlCons
 }
 
 constexpr int kWmWaves = 4;
+#ifndef N2V_WM_WAVES_PER_SIMD
+#define N2V_WM_WAVES_PER_SIMD 6
+#endif
 
 template <typename WT, bool kPow2>
-__global__ __launch_bounds__(kWmWaves * 64) void walk_weighted_margin_kernel(
+__global__ __launch_bounds__(kWmWaves * 64, N2V_WM_WAVES_PER_SIMD) void walk_weighted_margin_kernel(
     n2v_graph g, const WT *__restrict__ w, const int32_t *__restrict__ start_ids, int32_t num_walks,
     const int64_t *__restrict__ order, int64_t n_rows, int32_t min_n, int32_t step, int32_t walk_length,
     WlConsts K, uint64_t seed, int64_t *__restrict__ edge_state, int32_t *__restrict__ walks,
