@@ -922,29 +922,51 @@ __global__ __launch_bounds__(kWmWaves * 64, N2V_WM_WAVES_PER_SIMD) void walk_wei
   // same mix, and stops at the first row that is the lane kernel's).  A shared counter -- one atomic per
   // walker on ONE address -- took 12 ns per walker, 32 of the 36 ms of a step (profiles/r7z_wm_ablation.log).
   const int64_t n_waves = (int64_t)gridDim.x * kWmWaves;
-  for (int64_t i = (int64_t)blockIdx.x * kWmWaves + (threadIdx.x >> 6); i < n_rows; i += n_waves) {
-    const int64_t r = readfirstlane_i64(order[i]);
+  // What a wave needs to know of a walker sits behind three dependent round trips (order -> the walker's
+  // state -> the row and the tables of the edge walked last); everything of one level is requested at once,
+  // on indices clamped into range, BEFORE anything of it is looked at -- read one by one between the range
+  // checks it was eight round trips per walker, the larger part of a step (profiles/r7z_wm_ablation.log: "sum").
+  const bool tables = biased && g.edge_classes && g.wedge_off;
+  int64_t i = (int64_t)blockIdx.x * kWmWaves + (threadIdx.x >> 6);
+  int64_t r_raw = i < n_rows ? order[i] : -1;
+  for (; i < n_rows; i += n_waves) {
+    const int64_t r = readfirstlane_i64(r_raw);
+    if (i + n_waves < n_rows) r_raw = order[i + n_waves];  // (the next walker of this wave: one level ahead)
     if (r < 0 || r >= n_rows) break;  // (the lane kernel flags it)
     int32_t *row = walks + r * (int64_t)L1;
-    const int32_t v = __builtin_amdgcn_readfirstlane(row[step]);
-    if (v < 0 || (int64_t)v >= g.n_vertices || !valid[r]) break;  // vanished walkers come last in the order
-    const int64_t vb = readfirstlane_i64(g.rowptr[v]);
+    // level 2: the walker
+    const int32_t v_ld = row[step], s_ld = step > 0 ? row[step - 1] : -1;
+    const uint8_t valid_ld = valid[r];
+    const int64_t e_ld = edge_state[r];
+    const int32_t sid_ld = start_ids[r / num_walks];
+    const int32_t v = __builtin_amdgcn_readfirstlane(v_ld);
+    if (v < 0 || (int64_t)v >= g.n_vertices || !__builtin_amdgcn_readfirstlane((int)valid_ld))
+      break;  // vanished walkers come last in the order
+    const int32_t s = __builtin_amdgcn_readfirstlane(s_ld);
+    const int64_t e_prev = readfirstlane_i64(e_ld);
+    // level 3: the row, and the tables of the edge walked last
+    const bool first = s < 0 || !biased;
+    const int64_t e_at = (!first && tables && e_prev >= 0 && e_prev < g.n_edges) ? e_prev : 0;
+    const int64_t vb_ld = g.rowptr[v], ve_ld = g.rowptr[v + 1];
+    const double rs_ld = row_sums[v];
+    const uint32_t ec_ld = tables ? g.edge_classes[e_at] : 0u;
+    const uint64_t wraw_ld = tables ? g.wedge_off[e_at] : 0ull;
+    const int64_t vb = readfirstlane_i64(vb_ld);
     WlRow R;
-    R.n = (int)(readfirstlane_i64(g.rowptr[v + 1]) - vb);
+    R.n = (int)(readfirstlane_i64(ve_ld) - vb);
     if (R.n <= min_n) break;  // this row and every later one: the lane kernel's
-    const int32_t s = step > 0 ? __builtin_amdgcn_readfirstlane(row[step - 1]) : -1;
-    R.first = s < 0 || !biased;
+    const double row_sum = readfirstlane_f64(rs_ld);
+    R.first = first;
     R.nR = R.nM = R.rpos = 0;
     R.list = nullptr;
     R.wide = false;
     bool ok = true;
     if (!R.first) {
-      const int64_t e_prev = readfirstlane_i64(edge_state[r]);
-      if (e_prev < 0 || e_prev >= g.n_edges) {
+      if (!tables || e_prev < 0 || e_prev >= g.n_edges) {
         ok = false;
       } else {
-        const uint32_t ec = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.edge_classes[e_prev]);
-        const uint64_t wraw = readfirstlane_u64(g.wedge_off[e_prev]);
+        const uint32_t ec = (uint32_t)__builtin_amdgcn_readfirstlane((int)ec_ld);
+        const uint64_t wraw = readfirstlane_u64(wraw_ld);
         const uint32_t fR = ec >> N2V_EC_RETURN_SHIFT, fM = ec & N2V_EC_SHARED_MASK;
         R.nR = (int)fR;
         R.nM = (int)fM;
@@ -961,12 +983,12 @@ __global__ __launch_bounds__(kWmWaves * 64, N2V_WM_WAVES_PER_SIMD) void walk_wei
       if (lane == 0) atomicOr(status, N2V_ST_RANGE);
       continue;
     }
-    const uint64_t key = (uint64_t)start_ids[r / num_walks] * (uint64_t)num_walks + (uint64_t)(r % num_walks);
+    const uint64_t key = (uint64_t)__builtin_amdgcn_readfirstlane(sid_ld) * (uint64_t)num_walks +
+                         (uint64_t)(r % num_walks);
     const uint64_t bits = step_bits(walker_stream(seed, key), (uint32_t)step);
     const uint32_t u1 = (uint32_t)(bits >> 32), u2 = (uint32_t)bits;
     const int pick = pick_index(u1, R.n);
     const double r2 = (double)u2 * (1.0 / 4294967296.0);
-    const double row_sum = readfirstlane_f64(row_sums[v]);
     const int idx = wm_draw<WT, kPow2>(R, w + vb, K, row_sum, w_grid, w_max, pick, r2, lane, L);
     if (lane == 0) {
       if (idx < 0) {  // not decided by the margins: the exact wave kernel steps this walker
