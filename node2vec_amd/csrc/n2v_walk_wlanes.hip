@@ -609,13 +609,24 @@ __device__ __forceinline__ void wm_block_x(const WlRow &R, const WlConsts &K, co
   const bool biased = !R.first;
   const bool has_ret = biased && R.rpos < c0 + 256 && R.rpos + R.nR > c0;  // (uniform: the block holds return slots)
   if constexpr (kPow2) {
+    // (three uniform cases, so that the common block pays no select it does not need: this loop is bound by
+    // the number of vector instructions -- profiles/r7y_wm_pmc.txt)
     const double f_shared = inv, f_other = biased ? K.inv_q * inv : inv, f_ret = K.inv_p * inv;
+    if (!has_ret && !ballot64(m4 != 0u)) {  // every slot of the block is "other" (or the row unbiased)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const bool shared = (m4 >> (8 * k)) & 1u;
-      double f = shared ? f_shared : f_other;
-      if (has_ret && !shared && j0 + k >= R.rpos && j0 + k < R.rpos + R.nR) f = f_ret;
-      x[k] = __fma_rn((double)raw[k], f, -1.0);
+      for (int k = 0; k < 4; ++k) x[k] = __fma_rn((double)raw[k], f_other, -1.0);
+    } else if (!has_ret) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        x[k] = __fma_rn((double)raw[k], (m4 & (1u << (8 * k))) ? f_shared : f_other, -1.0);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool shared = (m4 >> (8 * k)) & 1u;
+        double f = shared ? f_shared : f_other;
+        if (!shared && j0 + k >= R.rpos && j0 + k < R.rpos + R.nR) f = f_ret;
+        x[k] = __fma_rn((double)raw[k], f, -1.0);
+      }
     }
   } else {
 #pragma unroll
