@@ -761,7 +761,8 @@ __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlCons
       acc_s += (double)w[pos < n ? pos : 0];
     }
     for (int j = R.rpos + lane; j < R.rpos + R.nR; j += 64) acc_r += (double)w[j];
-    const double ss = R.nM > 0 ? wm_wave_sum(acc_s) : 0.0, sr = R.nR > 0 ? wm_wave_sum(acc_r) : 0.0;
+    const double ss = R.nM > 0 ? wm_wave_sum(acc_s) : 0.0;
+    const double sr = R.nR > 1 ? wm_wave_sum(acc_r) : (R.nR == 1 ? readlane_f64(acc_r, 0) : 0.0);
     total = cq * row_sum + (1.0 - cq) * ss + (cp - cq) * sr;
     const double cmax = fmax(fmax(cp, cq), 1.0), cmin = fmin(fmin(cp, cq), 1.0);
     kfac = 1.0 + 2.0 * (cmax / cmin);  // the three terms are up to cmax / cmin times the sum each
@@ -806,7 +807,7 @@ __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlCons
   const int nent = (nblk + g - 1) / g;
   const int bp = pick >> 8;
   double run_d = 0.0, run_x = 0.0;    // per lane, the whole row so far
-  double snap_d = 0.0, snap_x = 0.0;  // per lane: the same when the block of pick begins
+  double pre_d = 0.0, pre_x = 0.0;    // per lane: the same over the slots BELOW pick
   WmWindow W;
   wm_window_init(W, R, lane, 0);
   int in_entry = 0, ent = 0;
@@ -815,8 +816,8 @@ __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlCons
     const int c0 = blk << 8, j0 = c0 + 4 * lane;
     if (in_entry == 0 && lane == 0) L.lm0[ent] = W.lm;  // (looked at again: wm_block_again)
     if (blk == bp) {
-      snap_d = run_d;
-      snap_x = run_x;
+      pre_d = run_d;
+      pre_x = run_x;
     }
     WT raw[4];
     double x[4];
@@ -834,6 +835,14 @@ __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlCons
       const uint32_t m4 = wm_block_flags(W, R, c0, lane, L);
       wm_block_x<WT, kPow2, false>(R, K, raw, m4, j0, c0, inv, x);
     }
+    if (blk == bp) {  // (uniform) the slots of pick's block below pick
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (j0 + k < pick) {
+          pre_x += x[k];
+          pre_d += fmax(-x[k], 0.0);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       run_x += x[k];
@@ -849,18 +858,6 @@ __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlCons
       in_entry = 0;
       ++ent;
     }
-  }
-  // the slots of pick's block below pick, once more
-  double pre_d = snap_d, pre_x = snap_x;
-  {
-    double xb[4];
-    wm_block_again<WT, kPow2>(R, w, K, inv, bp, g, lane, L, xb);
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if ((bp << 8) + 4 * lane + k < pick) {
-        pre_x += xb[k];
-        pre_d += fmax(-xb[k], 0.0);
-      }
   }
   const double below_d = wm_wave_sum(pre_d), below_x = wm_wave_sum(pre_x);  // over the slots below pick
   if (exact_total)
@@ -949,7 +946,11 @@ __global__ __launch_bounds__(kWmWaves * 64, N2V_WM_WAVES_PER_SIMD) void walk_wei
     const int32_t v_ld = row[step], s_ld = step > 0 ? row[step - 1] : -1;
     const uint8_t valid_ld = valid[r];
     const int64_t e_ld = edge_state[r];
-    const int32_t sid_ld = start_ids[r / num_walks];
+    // (a 64-bit division is ~150 instructions and this kernel is bound by their number: 32 bits when they do)
+    const bool small = n_rows <= 0x7fffffffll;
+    const int64_t r_start = small ? (int64_t)((uint32_t)r / (uint32_t)num_walks) : r / num_walks;
+    const int64_t r_ord = small ? (int64_t)((uint32_t)r % (uint32_t)num_walks) : r % num_walks;
+    const int32_t sid_ld = start_ids[r_start];
     const int32_t v = __builtin_amdgcn_readfirstlane(v_ld);
     if (v < 0 || (int64_t)v >= g.n_vertices || !__builtin_amdgcn_readfirstlane((int)valid_ld))
       break;  // vanished walkers come last in the order
@@ -994,8 +995,7 @@ __global__ __launch_bounds__(kWmWaves * 64, N2V_WM_WAVES_PER_SIMD) void walk_wei
       if (lane == 0) atomicOr(status, N2V_ST_RANGE);
       continue;
     }
-    const uint64_t key = (uint64_t)__builtin_amdgcn_readfirstlane(sid_ld) * (uint64_t)num_walks +
-                         (uint64_t)(r % num_walks);
+    const uint64_t key = (uint64_t)__builtin_amdgcn_readfirstlane(sid_ld) * (uint64_t)num_walks + (uint64_t)r_ord;
     const uint64_t bits = step_bits(walker_stream(seed, key), (uint32_t)step);
     const uint32_t u1 = (uint32_t)(bits >> 32), u2 = (uint32_t)bits;
     const int pick = pick_index(u1, R.n);
