@@ -238,12 +238,15 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     return walks, valid.bool() if out is None else valid
 
 
-# The lane-per-walker step kernel wins over the one-launch wave-per-walker kernel only when a step has
-# enough walkers to fill the chip beside the wave that stands on the longest row: that wave is the tail of
-# every step (cfg 2 weighted: 78 ms per step whatever the batch; 4.7 M walkers: 53 M steps/s against 35 - 40 M,
-# 0.47 M walkers: 6 M against 34 M -- profiles/r7k_time_wlanes.log)
-WEIGHTED_LANES_MARGINS = True  # rows of 128 slots or more: a wave per walker that decides the pairing with margins
-WEIGHTED_LANES_MIN_WALKERS = 1 << 21
+# The step-synchronous form -- per step one sort and three launches: a wave per walker on the rows of 128 slots
+# or more, which decides the slot a draw asks for from sums over the row with margins (WEIGHTED_LANES_MARGINS;
+# csrc/n2v_walk_wlanes.hip), the exact wave kernel for what the margins leave undecided, a lane per walker on
+# the short rows -- wins over the one-launch wave-per-walker kernel from a few 10^4 walkers on (weighted cfg 2 at
+# (0.5, 2): 47 k walkers 57 M steps/s against 38 M, 471 k: 302 M against 44 M, 4.7 M: 481 M;
+# profiles/r7zf_time_wm_more.log).  Without the margins the lane kernel alone has the wave on the longest
+# row as the tail of every step (78 ms whatever the batch) and only wins from 2 M walkers on.
+WEIGHTED_LANES_MARGINS = True
+WEIGHTED_LANES_MIN_WALKERS = 1 << 15
 
 
 def weighted_lanes_tables(graph: DeviceGraph, insist: bool = False) -> bool:

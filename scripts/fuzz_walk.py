@@ -111,6 +111,8 @@ while time.time() - t0 < budget:
     os.environ["N2V_WEDGE2_ROUNDS"] = str(int(rng.choice([0, 1, 2, 4, 9])))
     # weighted graphs: the lane-per-walker step kernel / a wave per walker with table classes / by search
     wlanes = bool(rng.random() < 0.5)
+    # (with or without the wave kernel that decides long rows by margins)
+    rw.WEIGHTED_LANES_MARGINS = bool(rng.random() < 0.7)
     got, gv = rw.walk(g, starts, nw, wl, p, q, seed, use_edge_classes=uec,
                       use_workspace=bool(rng.random() < 0.3), use_wedge_slots=bool(rng.random() < 0.7),
                       use_weighted_lanes=wlanes)
