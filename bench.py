@@ -83,6 +83,8 @@ def parse(argv=None):
                          "reference's default cap, constants.py:6; 0 = no trim)")
     ap.add_argument("--no-ref-cap", action="store_true",
                     help="skip the legs on the graph trimmed at the reference's default cap (100 000)")
+    ap.add_argument("--no-weighted", action="store_true",
+                    help="skip the leg on the WEIGHTED cfg 2 graph (exact walks at (0.5, 2), every start vertex)")
     ap.add_argument("--no-audition", action="store_true",
                     help="take the first output buffer the allocator hands out (no placement audition)")
     ap.add_argument("--spawn", action="store_true",
@@ -475,6 +477,13 @@ def main():
         if rank == 0 and out_cap:
             out["reference_trim_cap"] = out_cap
 
+    # ---- exact biased walks on a WEIGHTED graph (no closed form: every table of a step is different): the cfg 2
+    # graph with fp32 weights U[0.1, 2], every start vertex x W walks in ONE call, step-synchronous kernels
+    if not args.no_weighted and world == 1:
+        out_w = bench_weighted(args, torch, rw, dev, W, L)
+        if rank == 0 and out_w:
+            out["weighted"] = out_w
+
     # ---- SGNS on the config's model ------------------------------------------------------------
     model = None
     if not args.no_sgns:
@@ -526,6 +535,40 @@ def bench_reference_cap(args, cfg, torch, dist, rw, dev, W, L, rank, world, barr
     return res
 
 
+def bench_weighted(args, torch, rw, dev, W, L):
+    """exact walks at (0.5, 2) on the weighted cfg 2 graph (R-MAT 2^20 vertices, 10^7 edges, fp32 weights
+    U[0.1, 2]): every start vertex x W walks x L steps in one call of randomwalk.walk -- the per-edge tables and
+    row sums built before the clock starts, the clock around the whole call (per step: one sort, a wave with
+    margins per walker on long rows, a lane per walker on short ones; csrc/n2v_walk_wlanes.hip)"""
+    from node2vec_amd import synthetic
+
+    g = synthetic.rmat(20, 5_000_000, device=dev, weights="uniform")
+    start = rw.start_vertices(g)
+    t0 = time.perf_counter()
+    rw.weighted_lanes_tables(g)
+    rw.weighted_row_sums(g)
+    torch.cuda.synchronize()
+    tables_s = time.perf_counter() - t0
+    best, st, valid = None, {}, None
+    for _ in range(2):
+        st = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        walks, valid = rw.walk(g, start, W, L, BIASED_PQ[0], BIASED_PQ[1], 42, stats=st)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    steps = int(valid.sum()) * L
+    res = {"graph": "cfg 2 (R-MAT scale 20, 1e7 directed edges), fp32 weights U[0.1, 2]", "p": BIASED_PQ[0],
+           "q": BIASED_PQ[1], "walkers": int(valid.numel()), "value": steps / best, "unit": "walk-steps/s",
+           "s_per_call": best, "tables_s": tables_s,
+           "walker_steps_left_to_the_exact_kernel": int(st["undecided"]) if "undecided" in st else None,
+           "kernel": "walk_weighted_margin_kernel + walk_weighted_step_kernel (n2v_walk_weighted_step)"}
+    del g, walks, valid
+    torch.cuda.empty_cache()
+    return res
+
+
 def ordered_line(out):
     """The ONE line, ordered for its readers: the contract's keys first; the bulky sub-objects
     (setup, sgns, fast_mode, the regimes) in the middle; at the END -- the part of a long line
@@ -556,6 +599,7 @@ def ordered_line(out):
             "exact_biased_0.5_2": (out.get("biased") or {}).get("value"),
             **{"exact_%g_%g" % (r["p"], r["q"]): r["value"] for r in out.get("biased_other_regimes", [])},
             "fast_0.5_2": (out.get("fast_mode") or {}).get("value"),
+            "weighted_cfg2_exact_0.5_2": (out.get("weighted") or {}).get("value"),
             "trim_cap_100000_exact_pq1_ranks_out": ((out.get("reference_trim_cap") or {}).get("exact_pq1_ranks_out") or {}).get("value"),
             "trim_cap_100000_exact_biased_0.5_2": ((out.get("reference_trim_cap") or {}).get("exact_biased_0.5_2") or {}).get("value")},
         "walk_roofline_frac": {"exact_pq1_ranks_out": frac(out),
