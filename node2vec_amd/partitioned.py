@@ -511,9 +511,10 @@ class RankState:
 
     # -- one step of every resident walker; returns the migrating walkers per destination -----
     def forwarding(self) -> bool:
-        """this rank's walkers travel as Mail (n2v_partition_forward)"""
+        """this rank's walkers travel as Mail (n2v_partition_forward: at most FORWARD_MAX_PARTS destinations --
+        its per-block counters live in LDS; a larger world routes launch by stage)"""
         return (self.forward and self.step_fn is hip_step and self.part.rowptr.is_cuda
-                and self._lane_mode() >= 1)
+                and self._lane_mode() >= 1 and int(self.part.bounds.numel()) <= FORWARD_MAX_PARTS)
 
     def _advance_forward(self, n_parts: int) -> List[Mail]:
         """_advance_fused with the routing in ONE launch: n2v_partition_step on the resident mail,
@@ -747,6 +748,7 @@ class RankState:
 FORWARD_WORDS_PER_WALKER = 8
 FORWARD_STREAMS = True  # step the parts of a step on separate streams
 FORWARD_MIN_WORDS = 1 << 16
+FORWARD_MAX_PARTS = 256  # kFwdMaxParts of csrc/n2v_partition.hip
 # walk_partitioned's ranks: after this many steps with exact sizes (one host read each: their counts
 # are what the capacities are set from -- the walkers start spread over the VERTICES and are spread
 # like the EDGES one step later) the mailboxes get a fixed capacity per destination,
@@ -766,6 +768,8 @@ def _forward_mode(parts: Sequence[GraphPart], p: float, q: float, step_fn: Calla
     if step_fn is not hip_step or not parts or not all(pt.rowptr.is_cuda for pt in parts):
         return 0
     if len({pt.device for pt in parts}) != 1 or any(pt.w is not None for pt in parts):
+        return 0
+    if len(parts) > FORWARD_MAX_PARTS:
         return 0
     tables = all(pt.wedge_off is not None for pt in parts)
     modes = set()
