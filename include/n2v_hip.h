@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define N2V_ABI_VERSION 11
+#define N2V_ABI_VERSION 12
 
 #define N2V_OK 0
 #define N2V_EINVAL (-1)  /* maps to ValueError (randomwalk.py:212-217)      */
@@ -328,6 +328,12 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
  *            by that margin is listed in scratch (scratch[0] = how many after the call, scratch[1 ..] =
  *            their rows) and stepped by the exact wave-per-walker kernel in the same call.  Same bits as
  *            without them. */
+/* The sort keys of n2v_walk_weighted_step's `order`, one pass: keys[r] = rank_of[walks[r][step]] (rank_of: the
+ * place of every vertex in the order of descending out-degree, ties by id) for a walker that walks, 0x7fffffff
+ * for one that has vanished or never started -- sorting them ascending gives the order the step wants. */
+int n2v_walk_weighted_keys(const int32_t *walks, const uint8_t *valid, const int32_t *rank_of,
+                           int64_t n_vertices, int64_t n_rows, int32_t step, int32_t walk_length,
+                           int32_t *keys, void *stream);
 int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_ids, int32_t num_walks,
                            const int64_t *order, int64_t n_rows, int32_t step, int32_t walk_length,
                            double return_param, double inout_param, uint64_t seed,

@@ -859,11 +859,12 @@ __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlCons
       ++ent;
     }
   }
-  const double below_d = wm_wave_sum(pre_d), below_x = wm_wave_sum(pre_x);  // over the slots below pick
+  // over the slots below pick: the d for an underfull pick, the e = x + d for an overfull one (one sum over the wave)
+  const double below = wm_wave_sum(under ? pre_d : pre_x + pre_d);
   if (exact_total)
     M = 8.0 * eps * (nn * (w_max * cmax * inv + 12.0) + (nn * (1.0 / 256.0) + 16.0) * (4.0 * tot_d + 4.0));
 #if defined(N2V_WM_ABLATE) && N2V_WM_ABLATE == 2  // timing only: the walk ends with the pass over the row
-  return below_d + below_x > 1.0e300 ? 0 : pick;
+  return below > 1.0e300 ? 0 : pick;
 #endif
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -872,7 +873,7 @@ __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlCons
   if (under) {
     // rejected: alias = the overfull slot on top when `pick` is popped -- the first k with E_k >= D_{j-1},
     // D_{j-1} = the d of the slots ABOVE pick
-    const double d_above = tot_d - below_d - (-x_pick);
+    const double d_above = tot_d - below - (-x_pick);
     if (!(d_above > M)) {
       // (next to) nothing underfull above pick: the topmost overfull slot is still `over` when pick is popped
       // if its excess outlasts whatever was popped before -- at most d_above + M <= 2 M
@@ -893,7 +894,7 @@ __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlCons
   }
   // overfull: demoted by the first underfull slot j with D_j > E_k (E_k = the e of the slots at or above
   // pick), then probs = 1 + E_k - D_j
-  const double e_from = (tot_x + tot_d) - (below_x + below_d);
+  const double e_from = (tot_x + tot_d) - below;
   if (tot_d <= e_from - M) return pick;  // never demoted
   if (tot_d <= e_from + M)               // demoted, if at all, with probs >= 1 - 2 M
     return r2 < 1.0 - 3.0 * M ? pick : kWmUndecided;
@@ -1092,6 +1093,32 @@ static int wm_launch(const n2v_graph *g, const WT *w, const int32_t *start_ids, 
   return hipGetLastError() == hipSuccess ? N2V_OK : N2V_ELAUNCH;
 }
 }  // namespace n2v
+
+namespace n2v {
+__global__ __launch_bounds__(256) void weighted_keys_kernel(const int32_t *__restrict__ walks,
+                                                            const uint8_t *__restrict__ valid,
+                                                            const int32_t *__restrict__ rank_of, int64_t n_vertices,
+                                                            int64_t n_rows, int32_t step, int32_t L1,
+                                                            int32_t *__restrict__ keys) {
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * 256) {
+    const int32_t v = walks[r * (int64_t)L1 + step];
+    keys[r] = (valid[r] && v >= 0 && (int64_t)v < n_vertices) ? rank_of[v] : 0x7fffffff;
+  }
+}
+}  // namespace n2v
+
+extern "C" int n2v_walk_weighted_keys(const int32_t *walks, const uint8_t *valid, const int32_t *rank_of,
+                                      int64_t n_vertices, int64_t n_rows, int32_t step, int32_t walk_length,
+                                      int32_t *keys, void *stream) {
+  if (n_rows < 0 || step < 0 || step > walk_length || n_vertices < 0) return N2V_EINVAL;
+  if (n_rows == 0) return N2V_OK;
+  if (!walks || !valid || !rank_of || !keys) return N2V_EINVAL;
+  int64_t blocks = (n_rows + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(n2v::weighted_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, walks, valid,
+                     rank_of, n_vertices, n_rows, step, walk_length + 1, keys);
+  return hipGetLastError() == hipSuccess ? N2V_OK : N2V_ELAUNCH;
+}
 
 extern "C" int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_ids, int32_t num_walks,
                                       const int64_t *order, int64_t n_rows, int32_t step,

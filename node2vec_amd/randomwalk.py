@@ -327,14 +327,15 @@ def _walk_weighted_lanes(graph: DeviceGraph, start_ids: torch.Tensor, num_walks:
     row_sums = weighted_row_sums(graph) if WEIGHTED_LANES_MARGINS else None
     scratch = torch.empty(total + 2, dtype=torch.int64, device=dev) if row_sums is not None else None
     undecided = torch.zeros(1, dtype=torch.int64, device=dev)
+    key = torch.empty(total, dtype=torch.int32, device=dev)
     g = graph.c_struct()
     with torch.cuda.device(dev):
         stream = _lib.current_stream_ptr()
         for step in range(Lw):
-            cur = walks[:, step]
             # (vanished walkers last; they are skipped)
-            key = torch.where(valid.bool() & (cur >= 0), rank_of[cur.clamp(min=0).long()],
-                              torch.full_like(cur, 0x7fffffff))
+            _lib.check(L.n2v_walk_weighted_keys(walks.data_ptr(), valid.data_ptr(), rank_of.data_ptr(),
+                                                graph.n_vertices, total, step, Lw, key.data_ptr(), stream),
+                       "n2v_walk_weighted_keys")
             order = torch.sort(key).indices
             _lib.check(L.n2v_walk_weighted_step(g, start_ids.data_ptr(), W, order.data_ptr(), total, step, Lw,
                                                 float(p), float(q), seed & (2 ** 64 - 1),
