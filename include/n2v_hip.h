@@ -314,7 +314,7 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
  * step).  For return_param or inout_param != 1 the steps after the first read the classes of the
  * slots from g->edge_classes, g->wedge_off and g->wedge_pos (n2v_edge_classes_build, n2v_wedge_build:
  * they depend on the ids alone and are built for a weighted graph as for a unit one).
- *     scratch  int64 [n_rows + 2] or NULL, row_sums fp64 [n_vertices + 2] or NULL: the sum of the stored
+ *     scratch  int64 [2 (n_rows + 2)] or NULL, row_sums fp64 [n_vertices + 2] or NULL: the sum of the stored
  *            weights of every row, in any order (all weights finite and >= 0), then row_sums[n_vertices] =
  *            a power of two that divides every stored weight (fp32 weights: 2^(e - 24) of the smallest
  *            one, w = m 2^e; 0 = none known: then the margins are the general ones) and
@@ -325,9 +325,11 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
  *            of the overfull slots' excess; the row sum itself comes from row_sums and the shared and
  *            return slots: no pass), every comparison with a margin that covers the roundings of the
  *            reference's loop (16 n^2 2^-52 and up); a walker whose draw some comparison cannot decide
- *            by that margin is listed in scratch (scratch[0] = how many after the call, scratch[1 ..] =
- *            their rows) and stepped by the exact wave-per-walker kernel in the same call.  Same bits as
- *            without them. */
+ *            by that margin gets a second chance in a launch of its own -- the row sum in the
+ *            reference's order, hence the margins of an exact sum -- and, if still undecided, is stepped by
+ *            the exact wave-per-walker kernel, all in the same call (after it scratch[0] = how many had the
+ *            second chance, scratch[n_rows + 2] = how many the exact kernel stepped; their rows follow each
+ *            count).  Same bits as without them. */
 /* The sort keys of n2v_walk_weighted_step's `order`, one pass: keys[r] = rank_of[walks[r][step]] (rank_of: the
  * place of every vertex in the order of descending out-degree, ties by id) for a walker that walks, 0x7fffffff
  * for one that has vanished or never started -- sorting them ascending gives the order the step wants. */

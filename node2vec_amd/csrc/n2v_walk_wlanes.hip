@@ -743,7 +743,51 @@ __device__ __forceinline__ int wm_next_over_below(const WlRow &R, const WT *w, c
 
 // index sampling_from_alias(r1, r2) returns on the table of this row, or kWmUndecided.  row_sum = the sum of
 // the STORED weights of the row (any order; n2v_row_weight_sums).
+// The biased row sum in the REFERENCE's order (:172: left to right, one rounding per addition), by the wave: the
+// lanes bias a block of 256 slots (4 each) into LDS, lane 0 adds them up in order.  ~50 us on a row of 26 786
+// slots against the 1 - 5 ms of an exact replay: the second chance of a walker the general margins left undecided.
 template <typename WT, bool kPow2>
+__device__ __forceinline__ double wm_sequential_total(const WlRow &R, const WT *w, const WlConsts &K, int lane,
+                                                      WmLds &L) {
+  const int n = R.n, nblk = (n + 255) >> 8;
+  double *buf = L.cd;  // 256 doubles: cd and cx lie back to back (the pass that follows rewrites them)
+  static_assert(kWmEntries == 128, "wm_sequential_total uses cd + cx as one array of 256 doubles");
+  WmWindow W;
+  wm_window_init(W, R, lane, 0);
+  double total = 0.0;
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int c0 = blk << 8, j0 = c0 + 4 * lane;
+    WT raw[4];
+    wm_load4<WT>(w, j0, n, raw);
+    const uint32_t m4 = wm_block_flags(W, R, c0, lane, L);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = j0 + k;
+      int cls = 1;
+      if (!R.first) cls = ((m4 >> (8 * k)) & 1u) ? 1 : ((j >= R.rpos && j < R.rpos + R.nR) ? 2 : 0);
+      buf[4 * lane + k] = wl_bias<kPow2>((double)raw[k], cls, K);  // the reference's own operation (:219-231)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      const int m = min(256, n - c0);
+      for (int t = 0; t < m; ++t) total = total + buf[t];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  return readlane_f64(total, 0);
+}
+
+template <typename WT, bool kPow2>
+__device__ __forceinline__ int wm_decide(const WlRow &R, const WT *w, const WlConsts &K, double total, bool exact_total,
+                                         double kfac, double w_max, double cmax, double b_pick, int pick, double r2,
+                                         int lane, WmLds &L);
+
+// kSeq: the second chance of a walker the general margins left undecided -- the row sum in the reference's own
+// order, hence the exact-sum margins (a launch of its own over the list of those walkers: inside the first one
+// the second attempt cost every walker registers, 485 -> 335 M steps/s)
+template <typename WT, bool kPow2, bool kSeq>
 __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlConsts &K, double row_sum, double w_grid,
                                        double w_max, int pick, double r2, int lane, WmLds &L) {
   const int n = R.n;
@@ -772,6 +816,27 @@ __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlCons
   if (biased) cls_pick = ballot64(pick_shared) ? 1 : ((pick >= R.rpos && pick < R.rpos + R.nR) ? 2 : 0);
   const double b_pick = wl_bias<kPow2>((double)w[pick], cls_pick, K);
   const double nn = (double)n;
+  const double eps = 2.220446049250313e-16;
+  const double cmax = biased ? fmax(fmax(cp, cq), 1.0) : 1.0, cmin = biased ? fmin(fmin(cp, cq), 1.0) : 1.0;
+  bool exact_total = (kPow2 || !biased) && w_grid > 0.0 &&
+                     nn * w_max * cmax < w_grid * cmin * ldexp(1.0, 52 - (biased ? K.coef_bits : 0));
+  if constexpr (kSeq) {
+    if (exact_total) return kWmUndecided;  // (the exact-sum margins have spoken already: a tie, or r2 on a threshold)
+    total = wm_sequential_total<WT, kPow2>(R, w, K, lane, L);
+    if (!(total > 0.0) || !(total < 1.0e300)) return kWmUndecided;
+    exact_total = true;
+  }
+  return wm_decide<WT, kPow2>(R, w, K, total, exact_total, kfac, w_max, cmax, b_pick, pick, r2, lane, L);
+}
+
+// what follows the row sum: `total` within (n + 2) 2^-53 kfac of the reference's, or (exact_total) the reference's
+template <typename WT, bool kPow2>
+__device__ __forceinline__ int wm_decide(const WlRow &R, const WT *w, const WlConsts &K, double total, bool exact_total,
+                                         double kfac, double w_max, double cmax, double b_pick, int pick, double r2,
+                                         int lane, WmLds &L) {
+  const int n = R.n;
+  const bool biased = !R.first;
+  const double nn = (double)n;
   const double inv = nn / total;  // 1 / avg
   const double eps = 2.220446049250313e-16;
   // EXACT row sum: when every biased weight is a multiple of one power of two G (fp32 weights: w_grid = the
@@ -782,9 +847,6 @@ __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlCons
   // taken here (a lane adds n / 256 blocks, the tree 16 more, each of a value <= 4 D + 4) -- linear in n,
   // not 16 n^2: on the hubs, where n^2 2^-52 is 10^-6 and a replay costs a millisecond, that is the difference
   // between four walkers per step left to the exact kernel and none.
-  const double cmax = biased ? fmax(fmax(cp, cq), 1.0) : 1.0, cmin = biased ? fmin(fmin(cp, cq), 1.0) : 1.0;
-  const bool exact_total = (kPow2 || !biased) && w_grid > 0.0 &&
-                           nn * w_max * cmax < w_grid * cmin * ldexp(1.0, 52 - (biased ? K.coef_bits : 0));
   const double delta = exact_total ? 8.0 * eps
                                    : kfac * (2.0 * nn + 16.0) * eps;  // relative distance of b * inv from probs[i]
   double M = kfac * 16.0 * nn * nn * eps;
@@ -911,7 +973,7 @@ constexpr int kWmWaves = 4;
 #define N2V_WM_WAVES_PER_SIMD 6
 #endif
 
-template <typename WT, bool kPow2>
+template <typename WT, bool kPow2, bool kSeq>
 __global__ __launch_bounds__(kWmWaves * 64, N2V_WM_WAVES_PER_SIMD) void walk_weighted_margin_kernel(
     n2v_graph g, const WT *__restrict__ w, const int32_t *__restrict__ start_ids, int32_t num_walks,
     const int64_t *__restrict__ order, int64_t n_rows, int32_t min_n, int32_t step, int32_t walk_length,
@@ -967,7 +1029,7 @@ __global__ __launch_bounds__(kWmWaves * 64, N2V_WM_WAVES_PER_SIMD) void walk_wei
     const int64_t vb = readfirstlane_i64(vb_ld);
     WlRow R;
     R.n = (int)(readfirstlane_i64(ve_ld) - vb);
-    if (R.n <= min_n) break;  // this row and every later one: the lane kernel's
+    if (!kSeq && R.n <= min_n) break;  // this row and every later one: the lane kernel's
     const double row_sum = readfirstlane_f64(rs_ld);
     R.first = first;
     R.nR = R.nM = R.rpos = 0;
@@ -1001,7 +1063,7 @@ __global__ __launch_bounds__(kWmWaves * 64, N2V_WM_WAVES_PER_SIMD) void walk_wei
     const uint32_t u1 = (uint32_t)(bits >> 32), u2 = (uint32_t)bits;
     const int pick = pick_index(u1, R.n);
     const double r2 = (double)u2 * (1.0 / 4294967296.0);
-    const int idx = wm_draw<WT, kPow2>(R, w + vb, K, row_sum, w_grid, w_max, pick, r2, lane, L);
+    const int idx = wm_draw<WT, kPow2, kSeq>(R, w + vb, K, row_sum, w_grid, w_max, pick, r2, lane, L);
     if (lane == 0) {
       if (idx < 0) {  // not decided by the margins: the exact wave kernel steps this walker
         const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long *>(undecided), 1ull);
@@ -1071,25 +1133,26 @@ static int wl_launch(const n2v_graph *g, const WT *w, const int32_t *start_ids, 
 #endif
 
 namespace n2v {
-template <typename WT>
+template <typename WT, bool kSeq>
 static int wm_launch(const n2v_graph *g, const WT *w, const int32_t *start_ids, int32_t num_walks,
                      const int64_t *order, int64_t n_rows, int min_n, int32_t step, int32_t walk_length,
                      const WlConsts &K, uint64_t seed, int64_t *edge_state, int32_t *walks, uint8_t *valid,
                      uint32_t *status, int64_t *undecided, const double *row_sums, hipStream_t st) {
   const bool pow2 = K.p_pow2 && K.q_pow2;
-  const void *fn = pow2 ? (const void *)walk_weighted_margin_kernel<WT, true>
-                        : (const void *)walk_weighted_margin_kernel<WT, false>;
+  const void *fn = pow2 ? (const void *)walk_weighted_margin_kernel<WT, true, kSeq>
+                        : (const void *)walk_weighted_margin_kernel<WT, false, kSeq>;
   int64_t blocks = (n_rows + kWmWaves - 1) / kWmWaves;
-  const int64_t cap = resident_blocks(fn, kWmWaves * 64, 0);
+  int64_t cap = resident_blocks(fn, kWmWaves * 64, 0);
+  if (kSeq && cap > 1024) cap = 1024;  // (a list of a few walkers as a rule)
   if (blocks > cap) blocks = cap;
   if (pow2)
-    hipLaunchKernelGGL((walk_weighted_margin_kernel<WT, true>), dim3((unsigned)blocks), dim3(kWmWaves * 64), 0, st, *g,
-                       w, start_ids, num_walks, order, n_rows, min_n, step, walk_length, K, seed, edge_state, walks,
-                       valid, status, undecided, row_sums);
+    hipLaunchKernelGGL((walk_weighted_margin_kernel<WT, true, kSeq>), dim3((unsigned)blocks), dim3(kWmWaves * 64), 0,
+                       st, *g, w, start_ids, num_walks, order, n_rows, min_n, step, walk_length, K, seed, edge_state,
+                       walks, valid, status, undecided, row_sums);
   else
-    hipLaunchKernelGGL((walk_weighted_margin_kernel<WT, false>), dim3((unsigned)blocks), dim3(kWmWaves * 64), 0, st, *g,
-                       w, start_ids, num_walks, order, n_rows, min_n, step, walk_length, K, seed, edge_state, walks,
-                       valid, status, undecided, row_sums);
+    hipLaunchKernelGGL((walk_weighted_margin_kernel<WT, false, kSeq>), dim3((unsigned)blocks), dim3(kWmWaves * 64), 0,
+                       st, *g, w, start_ids, num_walks, order, n_rows, min_n, step, walk_length, K, seed, edge_state,
+                       walks, valid, status, undecided, row_sums);
   return hipGetLastError() == hipSuccess ? N2V_OK : N2V_ELAUNCH;
 }
 }  // namespace n2v
@@ -1171,17 +1234,30 @@ extern "C" int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_i
     // margins; scratch[0] = how many walkers it left undecided, scratch[1 ..] = those, -1 behind the last:
     // the exact wave kernel steps them
     const int from = N2V_WLANES_MARGIN_FROM;
-    if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), st) != hipSuccess ||
-        hipMemsetAsync(scratch, 0xff, sizeof(int64_t) * (size_t)(n_rows + 2), st) != hipSuccess ||
-        hipMemsetAsync(scratch, 0, sizeof(int64_t), st) != hipSuccess)
+    // scratch: two lists of n_rows + 2 words each -- [0] how many, [1 ..] the rows, -1 behind the last: what the
+    // first launch (row sum in any order: general margins unless the sum is exact anyway) leaves undecided, and
+    // what the second (row sum in the reference's order: exact-sum margins) still does; the exact wave kernel
+    // steps those
+    int64_t *second = scratch, *last = scratch + (n_rows + 2);
+    if (hipMemsetAsync(scratch, 0xff, sizeof(int64_t) * (size_t)(2 * (n_rows + 2)), st) != hipSuccess ||
+        hipMemsetAsync(second, 0, sizeof(int64_t), st) != hipSuccess ||
+        hipMemsetAsync(last, 0, sizeof(int64_t), st) != hipSuccess)
       return N2V_ELAUNCH;
-    rc = g->w64 ? n2v::wm_launch<double>(g, g->w64, start_ids, num_walks, order, n_rows, from - 1, step, walk_length,
-                                         K, seed, edge_state, walks, valid, status, scratch, row_sums, st)
-                : n2v::wm_launch<float>(g, g->w, start_ids, num_walks, order, n_rows, from - 1, step, walk_length, K,
-                                        seed, edge_state, walks, valid, status, scratch, row_sums, st);
+    rc = g->w64 ? n2v::wm_launch<double, false>(g, g->w64, start_ids, num_walks, order, n_rows, from - 1, step,
+                                                walk_length, K, seed, edge_state, walks, valid, status, second,
+                                                row_sums, st)
+                : n2v::wm_launch<float, false>(g, g->w, start_ids, num_walks, order, n_rows, from - 1, step,
+                                               walk_length, K, seed, edge_state, walks, valid, status, second, row_sums,
+                                               st);
+    if (rc != N2V_OK) return rc;
+    rc = g->w64 ? n2v::wm_launch<double, true>(g, g->w64, start_ids, num_walks, second + 1, n_rows, 0, step,
+                                               walk_length, K, seed, edge_state, walks, valid, status, last, row_sums,
+                                               st)
+                : n2v::wm_launch<float, true>(g, g->w, start_ids, num_walks, second + 1, n_rows, 0, step, walk_length,
+                                              K, seed, edge_state, walks, valid, status, last, row_sums, st);
     if (rc != N2V_OK) return rc;
     if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), st) != hipSuccess) return N2V_ELAUNCH;
-    rc = n2v_weighted_step_wave_launch(g, start_ids, num_walks, scratch + 1, n_rows, 0, step, walk_length,
+    rc = n2v_weighted_step_wave_launch(g, start_ids, num_walks, last + 1, n_rows, 0, step, walk_length,
                                        return_param, inout_param, seed, edge_state, walks, valid, status, stream);
     if (rc != N2V_OK) return rc;
     lanes_max = from - 1;

@@ -325,8 +325,8 @@ def _walk_weighted_lanes(graph: DeviceGraph, start_ids: torch.Tensor, num_walks:
     edge_state = torch.full((total,), -1, dtype=torch.int64, device=dev)
     # the list of the walkers whose step the wave kernel for long rows leaves to the exact kernel
     row_sums = weighted_row_sums(graph) if WEIGHTED_LANES_MARGINS else None
-    scratch = torch.empty(total + 2, dtype=torch.int64, device=dev) if row_sums is not None else None
-    undecided = torch.zeros(1, dtype=torch.int64, device=dev)
+    scratch = torch.empty(2 * (total + 2), dtype=torch.int64, device=dev) if row_sums is not None else None
+    undecided = torch.zeros(2, dtype=torch.int64, device=dev)  # second chances; left to the exact kernel
     key = torch.empty(total, dtype=torch.int32, device=dev)
     g = graph.c_struct()
     with torch.cuda.device(dev):
@@ -344,13 +344,16 @@ def _walk_weighted_lanes(graph: DeviceGraph, start_ids: torch.Tensor, num_walks:
                                                 0 if row_sums is None else row_sums.data_ptr(), stream),
                        "n2v_walk_weighted_step")
             if scratch is not None and stats is not None:
-                undecided += scratch[:1]
+                undecided += scratch[0::total + 2]
     if check:
         _lib.check_status_word(int(status[0].item()), "n2v_walk")
     if stats is not None:
         stats["trials"] = status[2:4].view(torch.int64)
         stats["status"] = status
-        stats["undecided"] = undecided  # walker-steps the margins did not decide (stepped by the exact kernel)
+        # walker-steps the margins did not decide (stepped by the exact kernel); those that needed the
+        # reference-order row sum before they were decided
+        stats["undecided"] = undecided[1]
+        stats["second_chance"] = undecided[0]
     return walks, valid.bool() if out is None else valid
 
 

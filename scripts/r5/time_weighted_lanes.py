@@ -32,7 +32,8 @@ for kind in os.environ.get("KINDS", "fp32").split(","):
                 steps = int(valid.sum()) * 80
                 print(f"{kind} p={p} q={q} {batch} start vertices: lanes{' + a wave with margins per walker on rows >= 128' if margins else ''} "
                       f"{best * 1e3:8.1f} ms = {steps / best / 1e6:8.1f} M steps/s"
-                      + (f"; walker-steps left to the exact wave kernel: {int(st['undecided'])} of {steps}" if margins else ""), flush=True)
+                      + (f"; walker-steps left to the exact wave kernel: {int(st['undecided'])} of {steps} ({int(st['second_chance'])} "
+                         f"decided on the reference-order row sum)" if margins else ""), flush=True)
             rw.WEIGHTED_LANES_MARGINS = True
             if os.environ.get("OLD", "1") == "1" and batch == B:
                 torch.cuda.synchronize(); t = time.time()
