@@ -1,7 +1,8 @@
 """Model of walk_weighted_margin_kernel (csrc/n2v_walk_wlanes.hip): the draw of ONE slot of the table
 generate_alias_tables builds (randomwalk.py:157-190) decided from sums over the row with margins, against
 the table itself (oracle/n2v_oracle: the reference's loop, fp64).  Every DECIDED draw must be the table's;
-the share left undecided is printed.
+the share left undecided is printed.  As in the kernel a draw the general margins leave undecided gets a second
+chance with the row added up in the reference's own order (the margins of an exact sum).
   python scripts/models/weighted_margins.py [rows] [seed]      (also run by tests/test_closed_form_models.py)"""
 import os
 import sys
@@ -26,7 +27,7 @@ def crossing(vals, target):
     return len(vals) - 1 - t, float(run[t] - vals[len(vals) - 1 - t]), float(run[t]), float(run[-1])
 
 
-def margin_draw(b, pick, r2, rng=None, w=None, cls=None, factors=None, exact_total=False):
+def margin_draw(b, pick, r2, rng=None, w=None, cls=None, factors=None, exact_total=False, sequential=False):
     """b: biased weights (fp64, >= 0); returns the slot sampling_from_alias returns, or UNDECIDED.  With the
     stored weights w, the classes and the three factors the row sum is taken as the kernel takes it: from the
     sum of the stored weights and the sums over the shared and the return slots"""
@@ -35,7 +36,10 @@ def margin_draw(b, pick, r2, rng=None, w=None, cls=None, factors=None, exact_tot
     if not np.all(b >= 0.0):
         return UNDECIDED
     kfac = 1.0
-    if w is None:
+    if sequential:  # the second chance: the row added up in the reference's own order -- its sum, bit for bit
+        total = float(np.cumsum(b)[-1])
+        exact_total = True
+    elif w is None:
         total = float(np.sum(b[order]))
     else:
         cq, c1, cp = factors  # other, shared, return
@@ -147,7 +151,7 @@ def rows(rng, count):
 
 def main(count=3000, seed=1):
     rng = np.random.default_rng(seed)
-    draws = undecided = 0
+    draws = undecided = second = 0
     per_kind = {}
     for i, (b, w, cls, factors, exact) in enumerate(rows(rng, count)):
         n = len(b)
@@ -163,6 +167,9 @@ def main(count=3000, seed=1):
                     continue
                 want = int(pick) if r2 < probs[pick] else int(alias[pick])
                 got = margin_draw(b, int(pick), r2, rng, w, cls, factors, exact)
+                if got == UNDECIDED and not exact:  # the second chance of the kernel
+                    got = margin_draw(b, int(pick), r2, rng, w, cls, factors, sequential=True)
+                    second += 1
                 draws += 1
                 k = per_kind.setdefault(i % 7, [0, 0, 0, 0])  # random r2: draws, undecided; at the threshold: same
                 k[0 if which == 0 else 2] += 1
@@ -172,7 +179,8 @@ def main(count=3000, seed=1):
                 elif got != want:
                     print(f"WRONG: row {i} (n = {n}), pick {pick}, r2 {r2!r}: decided {got}, the table says {want}")
                     return 1
-    print(f"{count} rows, {draws} draws: 0 wrong, {undecided} undecided ({undecided / max(draws, 1):.4f}); "
+    print(f"{count} rows, {draws} draws: 0 wrong, {second} had the second chance (the row sum in the reference's order), "
+          f"{undecided} undecided ({undecided / max(draws, 1):.4f}); "
           f"by kind of row (uniform r2: draws, undecided; r2 at the table's threshold: draws, undecided): {per_kind}")
     return 0
 
