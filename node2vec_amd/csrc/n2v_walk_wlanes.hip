@@ -122,6 +122,20 @@ struct WlList {
       cur = wl_list_at(*R, idx);  // the tail of the list / a wide row: one by one
     }
   }
+  // a stream that starts at entry `at` (descending: the entries above it are not looked at)
+  __device__ __forceinline__ void init_at(const WlRow &row, int at) {
+    R = &row;
+    win = nxt = 0ull;
+    have_nxt = 0;
+    const int n = row.first ? 0 : row.nM;
+    idx = at;
+    if (n == 0 || at < 0 || at >= n) {
+      cur = kFwd ? 0x7fffffff : -1;
+      idx = kFwd ? n : -1;
+      return;
+    }
+    open();
+  }
   __device__ __forceinline__ void advance() {
     const int n = R->nM;
     idx += kFwd ? 1 : -1;
@@ -816,7 +830,6 @@ __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlCons
   if (biased) cls_pick = ballot64(pick_shared) ? 1 : ((pick >= R.rpos && pick < R.rpos + R.nR) ? 2 : 0);
   const double b_pick = wl_bias<kPow2>((double)w[pick], cls_pick, K);
   const double nn = (double)n;
-  const double eps = 2.220446049250313e-16;
   const double cmax = biased ? fmax(fmax(cp, cq), 1.0) : 1.0, cmin = biased ? fmin(fmin(cp, cq), 1.0) : 1.0;
   bool exact_total = (kPow2 || !biased) && w_grid > 0.0 &&
                      nn * w_max * cmax < w_grid * cmin * ldexp(1.0, 52 - (biased ? K.coef_bits : 0));
@@ -966,6 +979,268 @@ __device__ __forceinline__ int wm_decide(const WlRow &R, const WT *w, const WlCo
   if (r2 < resid - M) return pick;
   if (!(r2 > resid + M)) return kWmUndecided;
   return wm_next_over_below<WT, kPow2>(R, w, K, inv, delta, pick, g, lane, L);  // alias = the next `over`
+}
+
+
+// ---- rows below the wave kernel's: the SAME decision, one LANE per walker -------------------------------------
+// The decision of wm_draw is three plain loops over the row -- the sums of x = probs - 1 and of d = max(-x, 0), the
+// descending scan to the crossing, the look for the next overfull slot -- with no state machine: 64 walkers of a
+// wave run them side by side and diverge in nothing but the trip counts (the walkers are sorted by row length).  A
+// wave per walker pays ~700 vector instructions per walker before the first slot; a lane pays the row: ~0.6 n.
+// (scripts/models/weighted_margins.py is this function, line by line.)
+template <typename WT, bool kPow2>
+__device__ __forceinline__ void lm_group_x(const WlRow &R, const WlConsts &K, const WT *w, int c0, uint32_t mm,
+                                           double inv, double (&x)[4]) {
+  const WlRaw<WT, 4> raw = wl_load_raw<WT, 4>(w, c0, R.n);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = c0 + k;
+    int cls = 1;
+    if (!R.first) cls = ((mm >> k) & 1u) ? 1 : ((j >= R.rpos && j < R.rpos + R.nR) ? 2 : 0);
+    const double b = wl_bias<kPow2>((double)raw.v[k], cls, K);
+    x[k] = j < R.n ? __fma_rn(b, inv, -1.0) : 0.0;
+  }
+}
+
+// the first slot below position `top` that is overfull, every slot skipped on the way underfull (by delta)
+template <typename WT, bool kPow2>
+__device__ __forceinline__ int lm_next_over_below(const WlRow &R, const WlConsts &K, const WT *w, double inv,
+                                                  double delta, int top, double &x_found) {
+  if (top <= 0) return kWmUndecided;
+  WlList<false> bwd;
+  int at = R.nM - 1;
+  if (!R.first && R.nM > 0 && top < R.n) {  // the last entry below `top`
+    int lo = 0, hi = R.nM;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (wl_list_at(R, mid) < top)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    at = lo - 1;
+  }
+  bwd.init_at(R, at);
+  for (int c0 = (top - 1) & ~3; c0 >= 0; c0 -= 4) {
+    uint32_t mm = 0u;
+    while (bwd.cur >= c0) {
+      mm |= 1u << (bwd.cur - c0);
+      bwd.advance();
+    }
+    double x[4];
+    lm_group_x<WT, kPow2>(R, K, w, c0, mm & 0xfu, inv, x);
+#pragma unroll
+    for (int k = 3; k >= 0; --k) {
+      const int j = c0 + k;
+      if (j >= top || j >= R.n) continue;
+      if (x[k] > 2.0 * delta) {
+        x_found = x[k];
+        return j;
+      }
+      if (!(x[k] < -2.0 * delta)) return kWmUndecided;
+    }
+  }
+  return kWmUndecided;  // no overfull slot left: the slot asked for would keep alias 0
+}
+
+template <typename WT, bool kPow2>
+__device__ __forceinline__ int lm_draw(const WlRow &R, const WT *w, const WlConsts &K, double row_sum, double w_grid,
+                                       double w_max, int pick, double r2) {
+  const int n = R.n;
+  const bool biased = !R.first;
+  // a row of one slot: probs = [w / w] = [1.0], nothing is paired, r2 < 1.0 returns the slot (a weight of 0 or a
+  // NaN is the exact kernels' business)
+  if (n == 1) return (double)w[0] > 0.0 && (double)w[0] < 1.0e300 ? 0 : kWmUndecided;
+  const double cq = kPow2 ? K.inv_q : 1.0 / K.q, cp = kPow2 ? K.inv_p : 1.0 / K.p;
+  double total = row_sum, kfac = 1.0;
+  bool pick_shared = false;
+  if (biased) {
+    double ss = 0.0, sr = 0.0;
+    for (int k = 0; k < R.nM; ++k) {
+      const int pos = wl_list_at(R, k);
+      pick_shared = pick_shared || pos == pick;
+      ss += (double)w[pos < n ? pos : 0];
+    }
+    for (int j = R.rpos; j < R.rpos + R.nR; ++j) sr += (double)w[j];
+    total = cq * row_sum + (1.0 - cq) * ss + (cp - cq) * sr;
+    const double cmax0 = fmax(fmax(cp, cq), 1.0), cmin0 = fmin(fmin(cp, cq), 1.0);
+    kfac = 1.0 + 2.0 * (cmax0 / cmin0);
+  }
+  if (!(total > 0.0) || !(total < 1.0e300) || !(row_sum > 0.0)) return kWmUndecided;
+  int cls_pick = 1;
+  if (biased) cls_pick = pick_shared ? 1 : ((pick >= R.rpos && pick < R.rpos + R.nR) ? 2 : 0);
+  const double b_pick = wl_bias<kPow2>((double)w[pick], cls_pick, K);
+  const double nn = (double)n, inv = nn / total, eps = 2.220446049250313e-16;
+  const double cmax = biased ? fmax(fmax(cp, cq), 1.0) : 1.0, cmin = biased ? fmin(fmin(cp, cq), 1.0) : 1.0;
+  const bool exact_total = (kPow2 || !biased) && w_grid > 0.0 &&
+                           nn * w_max * cmax < w_grid * cmin * ldexp(1.0, 52 - (biased ? K.coef_bits : 0));
+  const double delta = exact_total ? 8.0 * eps : kfac * (2.0 * nn + 16.0) * eps;
+  double M = kfac * 16.0 * nn * nn * eps;
+  const double p_pick = b_pick * inv;
+  const bool under = p_pick < 1.0 - 2.0 * delta;
+  if (!under && !(p_pick > 1.0 + 2.0 * delta)) return kWmUndecided;
+  if (under) {
+    if (r2 < p_pick * (1.0 - delta)) return pick;
+    if (!(r2 > p_pick * (1.0 + delta))) return kWmUndecided;
+  }
+  // the sums over the row, and over the slots below pick
+  double tot_d = 0.0, tot_x = 0.0, pre_d = 0.0, pre_x = 0.0;
+  {
+    WlList<true> fwd;
+    fwd.init(R);
+    for (int c0 = 0; c0 < n; c0 += 4) {
+      uint32_t mm = 0u;
+      while (fwd.cur < c0 + 4) {
+        mm |= 1u << (fwd.cur - c0);
+        fwd.advance();
+      }
+      double x[4];
+      lm_group_x<WT, kPow2>(R, K, w, c0, mm, inv, x);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double d = fmax(-x[k], 0.0);
+        tot_x += x[k];
+        tot_d += d;
+        const bool below = c0 + k < pick;
+        pre_x += below ? x[k] : 0.0;
+        pre_d += below ? d : 0.0;
+      }
+    }
+  }
+  if (exact_total)  // (a lane adds the n slots one by one: n roundings of a value <= 4 D + 4, not n / 256 + 16)
+    M = 8.0 * eps * (nn * (w_max * cmax * inv + 12.0) + (nn + 16.0) * (4.0 * tot_d + 4.0));
+  const double x_pick = p_pick - 1.0;
+  double target;
+  if (under) {
+    target = tot_d - pre_d - (-x_pick);  // the d of the slots above pick
+    if (!(target > M)) {
+      double x_t = 0.0;
+      const int t = lm_next_over_below<WT, kPow2>(R, K, w, inv, delta, n, x_t);
+      if (t < 0) return kWmUndecided;
+      return x_t >= 3.0 * M ? t : kWmUndecided;
+    }
+  } else {
+    target = (tot_x + tot_d) - (pre_x + pre_d);  // the e of the slots at or above pick
+    if (tot_d <= target - M) return pick;  // never demoted
+    if (tot_d <= target + M) return r2 < 1.0 - 3.0 * M ? pick : kWmUndecided;
+  }
+  // the crossing: from the top, the running sum of e (underfull pick) / of d (overfull pick) up to `target`
+  double run = 0.0, before = 0.0, at = 0.0;
+  int found = -1;
+  {
+    WlList<false> bwd;
+    bwd.init(R);
+    for (int c0 = (n - 1) & ~3; c0 >= 0 && found < 0; c0 -= 4) {
+      uint32_t mm = 0u;
+      while (bwd.cur >= c0) {
+        mm |= 1u << (bwd.cur - c0);
+        bwd.advance();
+      }
+      double x[4];
+      lm_group_x<WT, kPow2>(R, K, w, c0, mm & 0xfu, inv, x);
+#pragma unroll
+      for (int k = 3; k >= 0; --k) {
+        const double v = under ? fmax(x[k], 0.0) : fmax(-x[k], 0.0);
+        if (found < 0 && c0 + k < n) {
+          if (run + v >= target) {
+            before = run;
+            at = run + v;
+            found = c0 + k;
+          } else {
+            run += v;
+          }
+        }
+      }
+    }
+  }
+  if (found < 0 || !(before <= target - M) || !(at >= target + M)) return kWmUndecided;
+  if (under) return found;
+  const double resid = 1.0 + target - at;
+  if (r2 < resid - M) return pick;
+  if (!(r2 > resid + M)) return kWmUndecided;
+  double x_t = 0.0;
+  return lm_next_over_below<WT, kPow2>(R, K, w, inv, delta, pick, x_t);
+}
+
+template <typename WT, bool kPow2>
+__global__ __launch_bounds__(256) void walk_weighted_lane_margin_kernel(
+    n2v_graph g, const WT *__restrict__ w, const int32_t *__restrict__ start_ids, int32_t num_walks,
+    const int64_t *__restrict__ order, int64_t n_rows, int32_t max_n, int32_t step, int32_t walk_length,
+    WlConsts K, uint64_t seed, int64_t *__restrict__ edge_state, int32_t *__restrict__ walks,
+    uint8_t *__restrict__ valid, uint32_t *__restrict__ status, int64_t *__restrict__ undecided,
+    const double *__restrict__ row_sums) {
+  const int L1 = walk_length + 1;
+  const bool biased = !(K.p == 1.0 && K.q == 1.0);
+  const bool tables = biased && g.edge_classes && g.wedge_off;
+  const double w_grid = row_sums[g.n_vertices], w_max = row_sums[g.n_vertices + 1];
+  const bool small = n_rows <= 0x7fffffffll;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = order[i];
+    if (r < 0 || r >= n_rows) {
+      atomicOr(status, N2V_ST_RANGE);
+      continue;
+    }
+    int32_t *row = walks + r * (int64_t)L1;
+    const int32_t v = row[step];
+    if (v < 0 || !valid[r]) continue;  // a walker that has vanished (or never started)
+    if ((int64_t)v >= g.n_vertices) {
+      atomicOr(status, N2V_ST_RANGE);
+      continue;
+    }
+    const int32_t s = step > 0 ? row[step - 1] : -1;
+    const int64_t vb = g.rowptr[v];
+    WlRow R;
+    R.n = (int)(g.rowptr[v + 1] - vb);
+    if (R.n > max_n || R.n <= 0) continue;  // (the wave kernel's rows)
+    R.first = s < 0 || !biased;
+    R.nR = R.nM = R.rpos = 0;
+    R.list = nullptr;
+    R.wide = false;
+    bool ok = true;
+    if (!R.first) {
+      const int64_t e_prev = edge_state[r];
+      if (!tables || e_prev < 0 || e_prev >= g.n_edges) {
+        ok = false;
+      } else {
+        const uint32_t ec = g.edge_classes[e_prev];
+        const uint64_t wraw = g.wedge_off[e_prev];
+        const uint32_t fR = ec >> N2V_EC_RETURN_SHIFT, fM = ec & N2V_EC_SHARED_MASK;
+        R.nR = (int)fR;
+        R.nM = (int)fM;
+        R.rpos = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
+        R.wide = wedge_row_wide(g.wedge_wide, R.n);
+        const uint64_t off = wraw & N2V_WEDGE_OFF_MASK;
+        R.list = R.wide ? (const void *)(reinterpret_cast<const uint32_t *>(g.wedge_pos) + off)
+                        : (const void *)(reinterpret_cast<const uint16_t *>(g.wedge_pos) + off);
+        ok = fR != N2V_EC_RETURN_SAT && fM != N2V_EC_SHARED_MASK && (int64_t)fR + (int64_t)fM <= R.n &&
+             R.rpos + (int)fR <= R.n;
+      }
+    }
+    if (!ok) {
+      atomicOr(status, N2V_ST_RANGE);
+      continue;
+    }
+    const int64_t r_start = small ? (int64_t)((uint32_t)r / (uint32_t)num_walks) : r / num_walks;
+    const int64_t r_ord = small ? (int64_t)((uint32_t)r % (uint32_t)num_walks) : r % num_walks;
+    const uint64_t key = (uint64_t)start_ids[r_start] * (uint64_t)num_walks + (uint64_t)r_ord;
+    const uint64_t bits = step_bits(walker_stream(seed, key), (uint32_t)step);
+    const uint32_t u1 = (uint32_t)(bits >> 32), u2 = (uint32_t)bits;
+    const int pick = pick_index(u1, R.n);
+    const double r2 = (double)u2 * (1.0 / 4294967296.0);
+    const int idx = lm_draw<WT, kPow2>(R, w + vb, K, row_sums[v], w_grid, w_max, pick, r2);
+    if (idx < 0) {  // not decided by the margins: the second chance, then the exact wave kernel
+      const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long *>(undecided), 1ull);
+      undecided[1 + at] = r;
+      continue;
+    }
+    const int64_t e = vb + idx;
+    const int32_t x = g.col[e];
+    row[step + 1] = x;
+    edge_state[r] = e;
+    if (step + 1 < walk_length &&
+        (x < 0 || (int64_t)x >= g.n_vertices || g.rowptr[x + 1] == g.rowptr[x]))
+      valid[r] = 0;  // fugue.py:147
+  }
 }
 
 constexpr int kWmWaves = 4;
@@ -1129,7 +1404,12 @@ static int wl_launch(const n2v_graph *g, const WT *w, const int32_t *start_ids, 
 // rows of at least this many slots: a wave per walker that decides the pairing with margins
 // (walk_weighted_margin_kernel), given an order and a scratch list for the walkers it leaves undecided
 #ifndef N2V_WLANES_MARGIN_FROM
-#define N2V_WLANES_MARGIN_FROM 128
+#define N2V_WLANES_MARGIN_FROM 2048
+#endif
+// the rows below that: 1 = the same decision with a lane per walker (walk_weighted_lane_margin_kernel), 0 = the
+// exact lane kernel (the pairing replayed: round 5's first form)
+#ifndef N2V_WLANES_LANE_MARGINS
+#define N2V_WLANES_LANE_MARGINS 1
 #endif
 
 namespace n2v {
@@ -1153,6 +1433,27 @@ static int wm_launch(const n2v_graph *g, const WT *w, const int32_t *start_ids, 
     hipLaunchKernelGGL((walk_weighted_margin_kernel<WT, false, kSeq>), dim3((unsigned)blocks), dim3(kWmWaves * 64), 0,
                        st, *g, w, start_ids, num_walks, order, n_rows, min_n, step, walk_length, K, seed, edge_state,
                        walks, valid, status, undecided, row_sums);
+  return hipGetLastError() == hipSuccess ? N2V_OK : N2V_ELAUNCH;
+}
+template <typename WT>
+static int lm_launch(const n2v_graph *g, const WT *w, const int32_t *start_ids, int32_t num_walks,
+                     const int64_t *order, int64_t n_rows, int max_n, int32_t step, int32_t walk_length,
+                     const WlConsts &K, uint64_t seed, int64_t *edge_state, int32_t *walks, uint8_t *valid,
+                     uint32_t *status, int64_t *undecided, const double *row_sums, hipStream_t st) {
+  const bool pow2 = K.p_pow2 && K.q_pow2;
+  const void *fn = pow2 ? (const void *)walk_weighted_lane_margin_kernel<WT, true>
+                        : (const void *)walk_weighted_lane_margin_kernel<WT, false>;
+  int64_t blocks = (n_rows + 255) / 256;
+  const int64_t cap = resident_blocks(fn, 256, 0);
+  if (blocks > cap) blocks = cap;
+  if (pow2)
+    hipLaunchKernelGGL((walk_weighted_lane_margin_kernel<WT, true>), dim3((unsigned)blocks), dim3(256), 0, st, *g, w,
+                       start_ids, num_walks, order, n_rows, max_n, step, walk_length, K, seed, edge_state, walks, valid,
+                       status, undecided, row_sums);
+  else
+    hipLaunchKernelGGL((walk_weighted_lane_margin_kernel<WT, false>), dim3((unsigned)blocks), dim3(256), 0, st, *g, w,
+                       start_ids, num_walks, order, n_rows, max_n, step, walk_length, K, seed, edge_state, walks, valid,
+                       status, undecided, row_sums);
   return hipGetLastError() == hipSuccess ? N2V_OK : N2V_ELAUNCH;
 }
 }  // namespace n2v
@@ -1250,6 +1551,14 @@ extern "C" int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_i
                                                walk_length, K, seed, edge_state, walks, valid, status, second, row_sums,
                                                st);
     if (rc != N2V_OK) return rc;
+#if N2V_WLANES_LANE_MARGINS
+    // the rows below the cut: the same decision, a lane per walker (its undecided walkers join the list)
+    rc = g->w64 ? n2v::lm_launch<double>(g, g->w64, start_ids, num_walks, order, n_rows, from - 1, step, walk_length, K,
+                                         seed, edge_state, walks, valid, status, second, row_sums, st)
+                : n2v::lm_launch<float>(g, g->w, start_ids, num_walks, order, n_rows, from - 1, step, walk_length, K,
+                                        seed, edge_state, walks, valid, status, second, row_sums, st);
+    if (rc != N2V_OK) return rc;
+#endif
     rc = g->w64 ? n2v::wm_launch<double, true>(g, g->w64, start_ids, num_walks, second + 1, n_rows, 0, step,
                                                walk_length, K, seed, edge_state, walks, valid, status, last, row_sums,
                                                st)
@@ -1260,6 +1569,9 @@ extern "C" int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_i
     rc = n2v_weighted_step_wave_launch(g, start_ids, num_walks, last + 1, n_rows, 0, step, walk_length,
                                        return_param, inout_param, seed, edge_state, walks, valid, status, stream);
     if (rc != N2V_OK) return rc;
+#if N2V_WLANES_LANE_MARGINS
+    return N2V_OK;  // (every row was one of the two margin kernels')
+#endif
     lanes_max = from - 1;
   } else if (order && wave_from != 0x7fffffff) {
     if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), st) != hipSuccess) return N2V_ELAUNCH;
