@@ -1404,7 +1404,7 @@ static int wl_launch(const n2v_graph *g, const WT *w, const int32_t *start_ids, 
 // rows of at least this many slots: a wave per walker that decides the pairing with margins
 // (walk_weighted_margin_kernel), given an order and a scratch list for the walkers it leaves undecided
 #ifndef N2V_WLANES_MARGIN_FROM
-#define N2V_WLANES_MARGIN_FROM 2048
+#define N2V_WLANES_MARGIN_FROM 768
 #endif
 // the rows below that: 1 = the same decision with a lane per walker (walk_weighted_lane_margin_kernel), 0 = the
 // exact lane kernel (the pairing replayed: round 5's first form)

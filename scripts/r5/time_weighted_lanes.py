@@ -30,7 +30,7 @@ for kind in os.environ.get("KINDS", "fp32").split(","):
                     walks, valid = rw.walk(g, start, 10, 80, p, q, 42, use_weighted_lanes=True, stats=st)
                     torch.cuda.synchronize(); best = min(best, time.time() - t)
                 steps = int(valid.sum()) * 80
-                print(f"{kind} p={p} q={q} {batch} start vertices: lanes{' + a wave with margins per walker on rows >= 128' if margins else ''} "
+                print(f"{kind} p={p} q={q} {batch} start vertices: {'margin kernels (a lane per walker, a wave per walker on the long rows)' if margins else 'exact lane kernel'} "
                       f"{best * 1e3:8.1f} ms = {steps / best / 1e6:8.1f} M steps/s"
                       + (f"; walker-steps left to the exact wave kernel: {int(st['undecided'])} of {steps} ({int(st['second_chance'])} "
                          f"decided on the reference-order row sum)" if margins else ""), flush=True)
