@@ -563,7 +563,7 @@ def bench_weighted(args, torch, rw, dev, W, L):
            "q": BIASED_PQ[1], "walkers": int(valid.numel()), "value": steps / best, "unit": "walk-steps/s",
            "s_per_call": best, "tables_s": tables_s,
            "walker_steps_left_to_the_exact_kernel": int(st["undecided"]) if "undecided" in st else None,
-           "kernel": "walk_weighted_margin_kernel + walk_weighted_step_kernel (n2v_walk_weighted_step)"}
+           "kernel": "walk_weighted_lane_margin_kernel + walk_weighted_margin_kernel (n2v_walk_weighted_step)"}
     del g, walks, valid
     torch.cuda.empty_cache()
     return res

@@ -319,8 +319,9 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
  *            a power of two that divides every stored weight (fp32 weights: 2^(e - 24) of the smallest
  *            one, w = m 2^e; 0 = none known: then the margins are the general ones) and
  *            row_sums[n_vertices + 1] = the largest stored weight.  With an order AND both of
- *            these the walkers on rows of 128 slots or more get a WAVE each that does not replay the
- *            pairing loop but DECIDES the one slot the draw asks for from sums over the row (the k-th
+ *            these no walker's pairing loop is replayed: the one slot the draw asks for is DECIDED from
+ *            sums over the row -- by a lane per walker on rows below 768 slots, by a wave per walker on the
+ *            rows above -- (the k-th
  *            overfull slot is demoted where the running sum of the underfull slots' deficits passes that
  *            of the overfull slots' excess; the row sum itself comes from row_sums and the shared and
  *            return slots: no pass), every comparison with a margin that covers the roundings of the
