@@ -1,5 +1,17 @@
 // n2v_walk_wlanes.hip -- K2 exact mode on WEIGHTED graphs with p or q != 1: ONE STEP of every
-// walker of a batch, one LANE per walker (n2v_walk_weighted_step, include/n2v_hip.h).
+// walker of a batch (n2v_walk_weighted_step, include/n2v_hip.h), the walkers ordered by the length
+// of the row they stand on.  Three kernels, in the order they were written:
+//   1. walk_weighted_step_kernel        a LANE per walker, the pairing loop REPLAYED with O(1) state (below);
+//                                       what runs when the caller lends no scratch / row sums
+//   2. walk_weighted_margin_kernel      a WAVE per walker on the long rows (768 slots and more): the pairing is
+//                                       not replayed but DECIDED -- the one slot the draw asks for, from sums over
+//                                       the row, every comparison with a margin that covers the roundings of the
+//                                       reference's loop; what the margins cannot decide gets a second chance on
+//                                       the reference-order row sum (the kSeq instance), then the exact wave
+//                                       kernel of n2v_walk.hip
+//   3. walk_weighted_lane_margin_kernel the same decision with a LANE per walker on the rows below 768 slots
+// With 2 and 3 weighted cfg 2 walks at 0.64 G steps/s at (0.5, 2) where 1 alone reached 0.06 G and the
+// wave-per-walker kernel of n2v_walk.hip 0.04 G (DESIGN.md 5, K2 exact, weighted graphs).
 //
 // The reference rebuilds the whole table of the row a walker stands on at every step
 // (generate_edge_alias_tables + generate_alias_tables, randomwalk.py:157-232): bias every weight by
