@@ -559,10 +559,24 @@ def bench_weighted(args, torch, rw, dev, W, L):
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     steps = int(valid.sum()) * L
+    # the rows the steps stood on: what the reference's table of a step is built from (every weight of the row once)
+    deg = g.degrees()
+    stood = walks[:, :L][valid.bool()] if valid.dtype != torch.bool else walks[:, :L][valid]
+    stood = stood[stood >= 0].long()
+    mean_row = float(deg[stood].double().mean()) if stood.numel() else 0.0
+    del stood
     res = {"graph": "cfg 2 (R-MAT scale 20, 1e7 directed edges), fp32 weights U[0.1, 2]", "p": BIASED_PQ[0],
            "q": BIASED_PQ[1], "walkers": int(valid.numel()), "value": steps / best, "unit": "walk-steps/s",
            "s_per_call": best, "tables_s": tables_s,
            "walker_steps_left_to_the_exact_kernel": int(st["undecided"]) if "undecided" in st else None,
+           "mean_row_slots_per_step": mean_row,
+           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0,
+                        "achieved": steps / best * (4.0 * mean_row + 4.0) / 1e9,
+                        "frac": steps / best * (4.0 * mean_row + 4.0) / 8e12, "traffic": None,
+                        "algorithmic_formula": "4 B x the slots of the row stood on (every weight of the step's table "
+                                               "once) + 4 (path write) per step; the rows of a step are hot in L2 "
+                                               "(40 MB of weights in all): the kernels are bound by vector "
+                                               "instructions, not by these bytes"},
            "kernel": "walk_weighted_lane_margin_kernel + walk_weighted_margin_kernel (n2v_walk_weighted_step)"}
     del g, walks, valid
     torch.cuda.empty_cache()
