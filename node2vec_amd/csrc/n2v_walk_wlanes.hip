@@ -1068,10 +1068,20 @@ __device__ __forceinline__ int lm_draw(const WlRow &R, const WT *w, const WlCons
   bool pick_shared = false;
   if (biased) {
     double ss = 0.0, sr = 0.0;
-    for (int k = 0; k < R.nM; ++k) {
-      const int pos = wl_list_at(R, k);
-      pick_shared = pick_shared || pos == pick;
-      ss += (double)w[pos < n ? pos : 0];
+    // (four entries at a time: the four positions, then the four weights behind them, are independent loads --
+    // one by one every entry was two dependent round trips of a lane that has nothing else to do)
+    for (int k = 0; k < R.nM; k += 4) {
+      int pos[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) pos[t] = k + t < R.nM ? wl_list_at(R, k + t) : -1;
+      double wt[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) wt[t] = (pos[t] >= 0 && pos[t] < n) ? (double)w[pos[t]] : 0.0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        pick_shared = pick_shared || pos[t] == pick;
+        ss += wt[t];
+      }
     }
     for (int j = R.rpos; j < R.rpos + R.nR; ++j) sr += (double)w[j];
     total = cq * row_sum + (1.0 - cq) * ss + (cp - cq) * sr;
