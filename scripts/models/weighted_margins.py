@@ -162,6 +162,9 @@ def main(count=3000, seed=1):
             cand = [float(rng.integers(0, 2 ** 32)) / 2 ** 32, float(probs[pick]),
                     float(np.nextafter(probs[pick], 0.0)), float(np.nextafter(probs[pick], 2.0))]
             cand += [float(probs[pick]) + sgn * 10.0 ** -int(rng.integers(6, 15)) for sgn in (-1.0, 1.0)]
+            # the kernels' uniforms are u / 2^32: the grid points around the table's threshold
+            base = np.floor(float(probs[pick]) * 4294967296.0)
+            cand += [float(base + k) / 4294967296.0 for k in (-1, 0, 1, 2)]
             for which, r2 in enumerate(cand):
                 if not (0.0 <= r2 < 1.0):
                     continue
