@@ -8,7 +8,8 @@ from node2vec_amd import synthetic, randomwalk as rw
 from node2vec_amd.graph import DeviceGraph
 base = synthetic.rmat(20, 5_000_000, device="cuda")
 gen = torch.Generator(device="cuda").manual_seed(1)
-kinds = {"fp32": (torch.rand(base.n_edges, generator=gen, device="cuda") * 1.9 + 0.1),
+kinds = {"int": torch.randint(1, 5, (base.n_edges,), generator=gen, device="cuda").float(),  # few values: sums tie
+         "fp32": (torch.rand(base.n_edges, generator=gen, device="cuda") * 1.9 + 0.1),
          "fp64": (torch.rand(base.n_edges, generator=gen, device="cuda", dtype=torch.float64) * 1.9 + 0.1)}
 B = int(os.environ.get("BATCH", 47104))
 for kind in os.environ.get("KINDS", "fp32").split(","):
