@@ -460,3 +460,30 @@ def test_bench_gpus_n_spawns_n_ranks(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "WORLD_SIZE=1" in str(e.value.code)
+
+
+def test_weighted_row_sums_and_the_grid_of_the_weights():
+    """randomwalk.weighted_row_sums: what the margin kernels of weighted exact walks take the row sum of a step
+    from -- per-row fp64 sums, then a power of two that divides every stored weight (fp32 storage only) and the
+    largest weight; None when a weight is negative or not finite (the margins assume neither)"""
+    import numpy as np
+    import torch
+
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+
+    src = np.array([0, 0, 0, 1, 3, 3])
+    dst = np.array([1, 2, 3, 0, 0, 2])
+    w = np.array([0.5, 0.75, 3.0, 1.25, 0.1875, 2.0], dtype=np.float32)
+    g = DeviceGraph.from_edges(src, dst, w, n_vertices=5)
+    got = rw.weighted_row_sums(g)
+    assert got.dtype == torch.float64 and got.numel() == 5 + 2
+    assert got[:5].tolist() == [4.25, 1.25, 0.0, 2.1875, 0.0]
+    # the smallest weight is 0.1875 = 0.75 * 2^-2: frexp exponent -2, 24 mantissa bits -> 2^-26 divides them all
+    assert float(got[5]) == 2.0 ** -26 and float(got[6]) == 3.0
+    assert all(float(x) % float(got[5]) == 0.0 for x in w)
+    assert rw.weighted_row_sums(g) is got  # kept on the graph
+    g64 = DeviceGraph.from_edges(src, dst, np.array([0.1, 0.3, 0.7, 1.1, 2.9, 0.2]), n_vertices=5)  # not fp32 values
+    assert g64.w.dtype == torch.float64 and float(rw.weighted_row_sums(g64)[5]) == 0.0  # no grid claimed
+    bad = DeviceGraph.from_edges(src, dst, np.array([0.5, -0.75, 3.0, 1.25, 0.1875, 2.0], dtype=np.float32), n_vertices=5)
+    assert rw.weighted_row_sums(bad) is None
