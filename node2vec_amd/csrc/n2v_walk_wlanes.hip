@@ -493,8 +493,14 @@ __global__ __launch_bounds__(TH) void walk_weighted_step_kernel(
 // ~10^6; rows whose sums tie exactly (few distinct weights) are undecided often and walk at the exact
 // kernel's rate.  Same draws either way.
 constexpr int kWmUndecided = -2;
+// running sums kept per wave: one entry per 4 blocks of 256 slots (a sum over the wave per entry, not per block;
+// 2 and 8 blocks measured the same, profiles/r8y_wm_variants.log), more blocks per entry on rows of more than
+// 128 x 1 024 slots
 constexpr int kWmEntries = 128;
-constexpr int kWmMinBlocksPerEntry = 4;  // (a sum over the wave per entry: not per block)  // running sums kept per wave (a row of more than 256 x 256 slots: several blocks per entry)
+#ifndef N2V_WM_MIN_BLOCKS_PER_ENTRY
+#define N2V_WM_MIN_BLOCKS_PER_ENTRY 4
+#endif
+constexpr int kWmMinBlocksPerEntry = N2V_WM_MIN_BLOCKS_PER_ENTRY;
 struct WmLds {
   double cd[kWmEntries], cx[kWmEntries];  // sum of d / of x = probs - 1 over the slots up to the end of entry i
   int lm0[kWmEntries];                    // how many shared positions lie below the first slot of entry i
