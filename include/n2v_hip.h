@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define N2V_ABI_VERSION 12
+#define N2V_ABI_VERSION 13
 
 #define N2V_OK 0
 #define N2V_EINVAL (-1)  /* maps to ValueError (randomwalk.py:212-217)      */
@@ -330,7 +330,25 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
  *            reference's order, hence the margins of an exact sum -- and, if still undecided, is stepped by
  *            the exact wave-per-walker kernel, all in the same call (after it scratch[0] = how many had the
  *            second chance, scratch[n_rows + 2] = how many the exact kernel stepped; their rows follow each
- *            count).  Same bits as without them. */
+ *            count).  Same bits as without them.
+ *     hubs   NULL or the summaries of the long rows (n2v_weighted_hubs, above): the wave kernel then takes
+ *            the sums of a step over such a row from them instead of a pass over the row.  Same bits. */
+/* Summaries of the HUB rows of a weighted graph for n2v_walk_weighted_step (optional): for every row of at least
+ * min_slots slots, cut into blocks of 256 slots in row order, the weights of each block SORTED ascending (the last
+ * block padded with +inf) and their prefix sums -- with them the sums of a step over such a row (the deficits and
+ * excesses of its slots at the walker's own threshold) are one binary search per block instead of a pass over the
+ * row; the slots that are not "other" (shared positions, return run) are corrected from the wedge list.
+ *   block0  int32 [n_vertices]: the first block of the row in sorted / prefix, -1 = the row has no summary
+ *   sorted  [n_blocks][256] weights as stored (fp32 beside n2v_graph.w, fp64 beside w64)
+ *   prefix  fp64 [n_blocks][257]: prefix[b][k] = the sum of the k smallest weights of block b */
+typedef struct n2v_weighted_hubs {
+  const int32_t *block0;
+  const void *sorted;
+  const double *prefix;
+  int32_t min_slots;
+  int32_t reserved;
+} n2v_weighted_hubs;
+
 /* The sort keys of n2v_walk_weighted_step's `order`, one pass: keys[r] = rank_of[walks[r][step]] (rank_of: the
  * place of every vertex in the order of descending out-degree, ties by id) for a walker that walks, 0x7fffffff
  * for one that has vanished or never started -- sorting them ascending gives the order the step wants. */
@@ -341,7 +359,8 @@ int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_ids, int32_t
                            const int64_t *order, int64_t n_rows, int32_t step, int32_t walk_length,
                            double return_param, double inout_param, uint64_t seed,
                            int64_t *edge_state, int32_t *walks, uint8_t *valid, uint32_t *status,
-                           int64_t *scratch, const double *row_sums, void *stream);
+                           int64_t *scratch, const double *row_sums, const n2v_weighted_hubs *hubs,
+                           void *stream);
 
 /* n2v_walk with a workspace lent by the caller (the library never allocates).  Exact biased walks
  * on a unit-weight graph that carries the hop and wedge tables, dyadic return_param / inout_param,

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libn2v_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 OK, EINVAL, ELAUNCH, ENOGPU = 0, -1, -2, -3
 ST_ZERODIV, ST_RANGE, ST_OVERFLOW = 1, 2, 4
@@ -27,6 +27,12 @@ SYMBOLS = ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alia
            "n2v_partition_route", "n2v_partition_group", "n2v_walk_ws", "n2v_walk_workspace_bytes",
            "n2v_delta_reduce", "n2v_wedge_slots_build", "n2v_sgns_job_alpha", "n2v_rank_hops_build", "n2v_partition_forward",
            "n2v_sgns_hogwild_waves", "n2v_walk_weighted_step", "n2v_partition_forward_boxes", "n2v_walk_weighted_keys")
+
+
+class WeightedHubs(C.Structure):
+    """struct n2v_weighted_hubs"""
+    _fields_ = [("block0", C.c_void_p), ("sorted", C.c_void_p), ("prefix", C.c_void_p),
+                ("min_slots", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Graph(C.Structure):
@@ -126,7 +132,7 @@ def load():
     L.n2v_walk_weighted_step.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
                                          C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint64,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                         C.c_void_p]
+                                         C.POINTER(WeightedHubs), C.c_void_p]
     L.n2v_walk_weighted_keys.restype = C.c_int
     L.n2v_walk_weighted_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                          C.c_int32, C.c_void_p, C.c_void_p]

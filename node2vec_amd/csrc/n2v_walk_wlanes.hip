@@ -811,17 +811,137 @@ __device__ __forceinline__ double wm_sequential_total(const WlRow &R, const WT *
   return readlane_f64(total, 0);
 }
 
+// The sums of a HUB row without the pass (n2v_weighted_hubs): two thirds of the slots a step stands on belong to a
+// few hundred rows on which thousands of walkers make nearly the same pass -- the same weights, the one factor of
+// the "other" slots times a 1 / avg that differs from walker to walker.  For every block of 256 slots of such a row
+// the graph keeps the weights SORTED and their prefix sums: the block's sum of d and of x at the walker's own
+// threshold is one binary search (a lane per block: 64 blocks per round), as if every slot were "other"; the shared
+// positions and the return run are then CORRECTED from the list (O(list), LDS atomics per entry).  Fills what the
+// pass fills -- the running sums per entry, the list cursor of every entry, the sums below pick.
+template <typename WT, bool kPow2>
+__device__ __forceinline__ void wm_hub_sums(const WlRow &R, const WT *w, const WlConsts &K, double inv, const WT *hs,
+                                            const double *hp, int pick, bool under, int nblk, int nent, int lane,
+                                            WmLds &L, double &tot_d, double &tot_x, double &below) {
+  const int n = R.n;
+  const bool biased = !R.first;
+  const double cq = kPow2 ? K.inv_q : 1.0 / K.q, cp = kPow2 ? K.inv_p : 1.0 / K.p;
+  const double f_other = biased ? cq * inv : inv, f_shared = inv, f_ret = cp * inv;
+  for (int e = lane; e < nent; e += 64) {
+    L.cd[e] = 0.0;
+    L.cx[e] = 0.0;
+    L.lm0[e] = 0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  double lo_d = 0.0, lo_x = 0.0;  // per lane: over the slots below pick
+  if (biased) {
+    for (int k = lane; k < R.nM; k += 64) {
+      const int pos = wl_list_at(R, k);
+      const double wv = (double)w[pos < n ? pos : 0];
+      const double xo = __fma_rn(wv, f_other, -1.0), xs = __fma_rn(wv, f_shared, -1.0);
+      const double dx = xs - xo, dd = fmax(-xs, 0.0) - fmax(-xo, 0.0);
+      const int e = pos >> 10;
+      atomicAdd(&L.cx[e], dx);
+      atomicAdd(&L.cd[e], dd);
+      atomicAdd(&L.lm0[e], 1);
+      if (pos < pick) {
+        lo_x += dx;
+        lo_d += dd;
+      }
+    }
+    for (int j = R.rpos + lane; j < R.rpos + R.nR; j += 64) {
+      const double wv = (double)w[j];
+      const double xo = __fma_rn(wv, f_other, -1.0), xr = __fma_rn(wv, f_ret, -1.0);
+      const double dx = xr - xo, dd = fmax(-xr, 0.0) - fmax(-xo, 0.0);
+      atomicAdd(&L.cx[j >> 10], dx);
+      atomicAdd(&L.cd[j >> 10], dd);
+      if (j < pick) {
+        lo_x += dx;
+        lo_d += dd;
+      }
+    }
+  }
+  const int bp = pick >> 8;
+  for (int c = 0; c < nblk; c += 64) {
+    const int blk = c + lane;
+    if (blk < nblk) {
+      const int cnt = min(256, n - (blk << 8));
+      const WT *srt = hs + (int64_t)blk * 256;
+      const double *pre = hp + (int64_t)blk * 257;
+      int lo = 0, hi = cnt;  // the weights below the walker's threshold: x < 0 as "other"
+#pragma unroll 1
+      for (int it = 0; it < 9; ++it) {
+        const int mid = (lo + hi) >> 1;
+        const bool go = lo < hi;
+        const double v = (double)srt[go ? mid : 0];
+        const bool neg = __fma_rn(v, f_other, -1.0) < 0.0;
+        lo = (go && neg) ? mid + 1 : lo;
+        hi = (go && !neg) ? mid : hi;
+      }
+      const double s_below = pre[lo], s_all = pre[cnt];
+      const double d_blk = (double)lo - f_other * s_below;  // sum of 1 - w f over the slots below the threshold
+      const double x_blk = f_other * s_all - (double)cnt;
+      atomicAdd(&L.cd[blk >> 2], d_blk);
+      atomicAdd(&L.cx[blk >> 2], x_blk);
+      if (blk < bp) {
+        lo_d += d_blk;
+        lo_x += x_blk;
+      }
+    }
+  }
+  {  // the slots of pick's block below pick, one by one (as "other": the corrections above did the rest)
+    WT raw[4];
+    const int j0 = (bp << 8) + 4 * lane;
+    wm_load4<WT>(w, j0, n, raw);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (j0 + k < pick && j0 + k < n) {
+        const double xo = __fma_rn((double)raw[k], f_other, -1.0);
+        lo_x += xo;
+        lo_d += fmax(-xo, 0.0);
+      }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    double run = 0.0;
+    for (int e = 0; e < nent; ++e) {
+      run += L.cd[e];
+      L.cd[e] = run;
+    }
+  } else if (lane == 1) {
+    double run = 0.0;
+    for (int e = 0; e < nent; ++e) {
+      run += L.cx[e];
+      L.cx[e] = run;
+    }
+  } else if (lane == 2) {
+    int run = 0;
+    for (int e = 0; e < nent; ++e) {
+      const int t = L.lm0[e];
+      L.lm0[e] = run;
+      run += t;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  tot_d = readfirstlane_f64(L.cd[nent - 1]);
+  tot_x = readfirstlane_f64(L.cx[nent - 1]);
+  below = wm_wave_sum(under ? lo_d : lo_x + lo_d);
+}
+
 template <typename WT, bool kPow2>
 __device__ __forceinline__ int wm_decide(const WlRow &R, const WT *w, const WlConsts &K, double total, bool exact_total,
                                          double kfac, double w_max, double cmax, double b_pick, int pick, double r2,
-                                         int lane, WmLds &L);
+                                         int lane, WmLds &L, const WT *hub_sorted, const double *hub_prefix);
 
 // kSeq: the second chance of a walker the general margins left undecided -- the row sum in the reference's own
 // order, hence the exact-sum margins (a launch of its own over the list of those walkers: inside the first one
 // the second attempt cost every walker registers, 485 -> 335 M steps/s)
 template <typename WT, bool kPow2, bool kSeq>
 __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlConsts &K, double row_sum, double w_grid,
-                                       double w_max, int pick, double r2, int lane, WmLds &L) {
+                                       double w_max, int pick, double r2, int lane, WmLds &L, const WT *hub_sorted,
+                                       const double *hub_prefix) {
   const int n = R.n;
   const bool biased = !R.first;
   // ---- the row sum WITHOUT a pass over the row: every slot is "other" (w / q) but the shared positions and
@@ -857,14 +977,15 @@ __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlCons
     if (!(total > 0.0) || !(total < 1.0e300)) return kWmUndecided;
     exact_total = true;
   }
-  return wm_decide<WT, kPow2>(R, w, K, total, exact_total, kfac, w_max, cmax, b_pick, pick, r2, lane, L);
+  return wm_decide<WT, kPow2>(R, w, K, total, exact_total, kfac, w_max, cmax, b_pick, pick, r2, lane, L, hub_sorted,
+                              hub_prefix);
 }
 
 // what follows the row sum: `total` within (n + 2) 2^-53 kfac of the reference's, or (exact_total) the reference's
 template <typename WT, bool kPow2>
 __device__ __forceinline__ int wm_decide(const WlRow &R, const WT *w, const WlConsts &K, double total, bool exact_total,
                                          double kfac, double w_max, double cmax, double b_pick, int pick, double r2,
-                                         int lane, WmLds &L) {
+                                         int lane, WmLds &L, const WT *hub_sorted, const double *hub_prefix) {
   const int n = R.n;
   const bool biased = !R.first;
   const double nn = (double)n;
@@ -904,8 +1025,11 @@ __device__ __forceinline__ int wm_decide(const WlRow &R, const WT *w, const WlCo
   WmWindow W;
   wm_window_init(W, R, lane, 0);
   int in_entry = 0, ent = 0;
-  double tot_d = 0.0, tot_x = 0.0;
-  for (int blk = 0; blk < nblk; ++blk) {
+  double tot_d = 0.0, tot_x = 0.0, below = 0.0;
+  const bool summaries = hub_sorted != nullptr && g == 4;  // (a hub row: no pass)
+  if (summaries)
+    wm_hub_sums<WT, kPow2>(R, w, K, inv, hub_sorted, hub_prefix, pick, under, nblk, nent, lane, L, tot_d, tot_x, below);
+  for (int blk = summaries ? nblk : 0; blk < nblk; ++blk) {
     const int c0 = blk << 8, j0 = c0 + 4 * lane;
     if (in_entry == 0 && lane == 0) L.lm0[ent] = W.lm;  // (looked at again: wm_block_again)
     if (blk == bp) {
@@ -953,9 +1077,9 @@ __device__ __forceinline__ int wm_decide(const WlRow &R, const WT *w, const WlCo
     }
   }
   // over the slots below pick: the d for an underfull pick, the e = x + d for an overfull one (one sum over the wave)
-  const double below = wm_wave_sum(under ? pre_d : pre_x + pre_d);
-  if (exact_total)
-    M = 8.0 * eps * (nn * (w_max * cmax * inv + 12.0) + (nn * (1.0 / 256.0) + 16.0) * (4.0 * tot_d + 4.0));
+  if (!summaries) below = wm_wave_sum(under ? pre_d : pre_x + pre_d);
+  if (exact_total)  // (+ 64: a block summary is the difference of two sums of up to 256 weights)
+    M = 8.0 * eps * (nn * (w_max * cmax * inv + 12.0 + 64.0) + (nn * (1.0 / 256.0) + 16.0) * (4.0 * tot_d + 4.0));
 #if defined(N2V_WM_ABLATE) && N2V_WM_ABLATE == 2  // timing only: the walk ends with the pass over the row
   return below > 1.0e300 ? 0 : pick;
 #endif
@@ -1282,7 +1406,7 @@ __global__ __launch_bounds__(kWmWaves * 64, N2V_WM_WAVES_PER_SIMD) void walk_wei
     const int64_t *__restrict__ order, int64_t n_rows, int32_t min_n, int32_t step, int32_t walk_length,
     WlConsts K, uint64_t seed, int64_t *__restrict__ edge_state, int32_t *__restrict__ walks,
     uint8_t *__restrict__ valid, uint32_t *__restrict__ status, int64_t *__restrict__ undecided,
-    const double *__restrict__ row_sums) {
+    const double *__restrict__ row_sums, n2v_weighted_hubs hubs) {
   __shared__ WmLds lds_all[kWmWaves];
   const int lane = threadIdx.x & 63;
   WmLds &L = lds_all[threadIdx.x >> 6];
@@ -1327,6 +1451,7 @@ __global__ __launch_bounds__(kWmWaves * 64, N2V_WM_WAVES_PER_SIMD) void walk_wei
     const int64_t e_at = (!first && tables && e_prev >= 0 && e_prev < g.n_edges) ? e_prev : 0;
     const int64_t vb_ld = g.rowptr[v], ve_ld = g.rowptr[v + 1];
     const double rs_ld = row_sums[v];
+    const int32_t hub_ld = hubs.block0 ? hubs.block0[v] : -1;
     const uint32_t ec_ld = tables ? g.edge_classes[e_at] : 0u;
     const uint64_t wraw_ld = tables ? g.wedge_off[e_at] : 0ull;
     const int64_t vb = readfirstlane_i64(vb_ld);
@@ -1366,7 +1491,11 @@ __global__ __launch_bounds__(kWmWaves * 64, N2V_WM_WAVES_PER_SIMD) void walk_wei
     const uint32_t u1 = (uint32_t)(bits >> 32), u2 = (uint32_t)bits;
     const int pick = pick_index(u1, R.n);
     const double r2 = (double)u2 * (1.0 / 4294967296.0);
-    const int idx = wm_draw<WT, kPow2, kSeq>(R, w + vb, K, row_sum, w_grid, w_max, pick, r2, lane, L);
+    const int64_t hub_b0 = (int64_t)__builtin_amdgcn_readfirstlane(hub_ld);
+    const WT *hub_sorted = hub_b0 >= 0 ? reinterpret_cast<const WT *>(hubs.sorted) + hub_b0 * 256 : nullptr;
+    const double *hub_prefix = hub_b0 >= 0 ? hubs.prefix + hub_b0 * 257 : nullptr;
+    const int idx = wm_draw<WT, kPow2, kSeq>(R, w + vb, K, row_sum, w_grid, w_max, pick, r2, lane, L, hub_sorted,
+                                             hub_prefix);
     if (lane == 0) {
       if (idx < 0) {  // not decided by the margins: the exact wave kernel steps this walker
         const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long *>(undecided), 1ull);
@@ -1445,7 +1574,8 @@ template <typename WT, bool kSeq>
 static int wm_launch(const n2v_graph *g, const WT *w, const int32_t *start_ids, int32_t num_walks,
                      const int64_t *order, int64_t n_rows, int min_n, int32_t step, int32_t walk_length,
                      const WlConsts &K, uint64_t seed, int64_t *edge_state, int32_t *walks, uint8_t *valid,
-                     uint32_t *status, int64_t *undecided, const double *row_sums, hipStream_t st) {
+                     uint32_t *status, int64_t *undecided, const double *row_sums, const n2v_weighted_hubs &hubs,
+                     hipStream_t st) {
   const bool pow2 = K.p_pow2 && K.q_pow2;
   const void *fn = pow2 ? (const void *)walk_weighted_margin_kernel<WT, true, kSeq>
                         : (const void *)walk_weighted_margin_kernel<WT, false, kSeq>;
@@ -1456,11 +1586,11 @@ static int wm_launch(const n2v_graph *g, const WT *w, const int32_t *start_ids, 
   if (pow2)
     hipLaunchKernelGGL((walk_weighted_margin_kernel<WT, true, kSeq>), dim3((unsigned)blocks), dim3(kWmWaves * 64), 0,
                        st, *g, w, start_ids, num_walks, order, n_rows, min_n, step, walk_length, K, seed, edge_state,
-                       walks, valid, status, undecided, row_sums);
+                       walks, valid, status, undecided, row_sums, hubs);
   else
     hipLaunchKernelGGL((walk_weighted_margin_kernel<WT, false, kSeq>), dim3((unsigned)blocks), dim3(kWmWaves * 64), 0,
                        st, *g, w, start_ids, num_walks, order, n_rows, min_n, step, walk_length, K, seed, edge_state,
-                       walks, valid, status, undecided, row_sums);
+                       walks, valid, status, undecided, row_sums, hubs);
   return hipGetLastError() == hipSuccess ? N2V_OK : N2V_ELAUNCH;
 }
 template <typename WT>
@@ -1517,7 +1647,7 @@ extern "C" int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_i
                                       int32_t walk_length, double return_param, double inout_param,
                                       uint64_t seed, int64_t *edge_state, int32_t *walks, uint8_t *valid,
                                       uint32_t *status, int64_t *scratch, const double *row_sums,
-                                      void *stream) {
+                                      const n2v_weighted_hubs *hubs, void *stream) {
   if (!g || !g->rowptr || !g->col || n_rows < 0 || num_walks < 1 || walk_length < 0) return N2V_EINVAL;
   if (step < 0 || step >= walk_length) return N2V_EINVAL;
   if (return_param == 0.0 || inout_param == 0.0) return N2V_EINVAL;  // randomwalk.py:214-217
@@ -1568,16 +1698,23 @@ extern "C" int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_i
     // what the second (row sum in the reference's order: exact-sum margins) still does; the exact wave kernel
     // steps those
     int64_t *second = scratch, *last = scratch + (n_rows + 2);
+    n2v_weighted_hubs hb;  // (no summaries: every row of the wave kernel makes its pass)
+    hb.block0 = nullptr;
+    hb.sorted = nullptr;
+    hb.prefix = nullptr;
+    hb.min_slots = hb.reserved = 0;
+    // (the sorted weights are stored as the graph's: fp32 beside g->w, fp64 beside g->w64)
+    if (hubs && hubs->block0 && hubs->sorted && hubs->prefix) hb = *hubs;
     if (hipMemsetAsync(scratch, 0xff, sizeof(int64_t) * (size_t)(2 * (n_rows + 2)), st) != hipSuccess ||
         hipMemsetAsync(second, 0, sizeof(int64_t), st) != hipSuccess ||
         hipMemsetAsync(last, 0, sizeof(int64_t), st) != hipSuccess)
       return N2V_ELAUNCH;
     rc = g->w64 ? n2v::wm_launch<double, false>(g, g->w64, start_ids, num_walks, order, n_rows, from - 1, step,
                                                 walk_length, K, seed, edge_state, walks, valid, status, second,
-                                                row_sums, st)
+                                                row_sums, hb, st)
                 : n2v::wm_launch<float, false>(g, g->w, start_ids, num_walks, order, n_rows, from - 1, step,
                                                walk_length, K, seed, edge_state, walks, valid, status, second, row_sums,
-                                               st);
+                                               hb, st);
     if (rc != N2V_OK) return rc;
 #if N2V_WLANES_LANE_MARGINS
     // the rows below the cut: the same decision, a lane per walker (its undecided walkers join the list)
@@ -1589,9 +1726,9 @@ extern "C" int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_i
 #endif
     rc = g->w64 ? n2v::wm_launch<double, true>(g, g->w64, start_ids, num_walks, second + 1, n_rows, 0, step,
                                                walk_length, K, seed, edge_state, walks, valid, status, last, row_sums,
-                                               st)
+                                               hb, st)
                 : n2v::wm_launch<float, true>(g, g->w, start_ids, num_walks, second + 1, n_rows, 0, step, walk_length,
-                                              K, seed, edge_state, walks, valid, status, last, row_sums, st);
+                                              K, seed, edge_state, walks, valid, status, last, row_sums, hb, st);
     if (rc != N2V_OK) return rc;
     if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), st) != hipSuccess) return N2V_ELAUNCH;
     rc = n2v_weighted_step_wave_launch(g, start_ids, num_walks, last + 1, n_rows, 0, step, walk_length,
