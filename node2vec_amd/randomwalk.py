@@ -289,7 +289,7 @@ def weighted_row_sums(graph: DeviceGraph) -> Optional[torch.Tensor]:
     return None if got is False else got
 
 
-WEIGHTED_HUB_SLOTS = 2048  # rows of at least this many slots get block summaries (weighted_hub_summaries)
+WEIGHTED_HUB_SLOTS = 768  # rows of at least this many slots get block summaries (weighted_hub_summaries)
 
 
 def weighted_hub_summaries(graph: DeviceGraph):

@@ -12,6 +12,8 @@ kinds = {"int": torch.randint(1, 5, (base.n_edges,), generator=gen, device="cuda
          "fp32": (torch.rand(base.n_edges, generator=gen, device="cuda") * 1.9 + 0.1),
          "fp64": (torch.rand(base.n_edges, generator=gen, device="cuda", dtype=torch.float64) * 1.9 + 0.1)}
 B = int(os.environ.get("BATCH", 47104))
+if os.environ.get("HUB_SLOTS"):
+    rw.WEIGHTED_HUB_SLOTS = int(os.environ["HUB_SLOTS"])  # rows with block summaries (0: none)
 for kind in os.environ.get("KINDS", "fp32").split(","):
     g = DeviceGraph(base.rowptr, base.col, kinds[kind])
     start_all = rw.start_vertices(g)
