@@ -74,9 +74,33 @@ def margin_draw(b, pick, r2, rng=None, w=None, cls=None, factors=None, exact_tot
     pr = b * inv
     # running sums from the bottom, as the kernel keeps them (per lane, then over the wave)
     tot_d, tot_x = float(np.sum(d[order])), float(np.sum(x[order]))
-    if exact_total:
-        M = 8.0 * EPS * (nn * (float(np.max(b)) * inv + 12.0) + (nn / 256.0 + 16.0) * (4.0 * tot_d + 4.0))
     below_d, below_x = float(np.sum(d[:pick])), float(np.sum(x[:pick]))
+    if w is not None and n >= 300:
+        # a long row: the sums as wm_hub_sums takes them -- per block of 256 slots the sorted weights and their
+        # prefix sums give the block's d and x AS IF every slot were "other" (a count below the threshold and a
+        # prefix sum), the shared and return slots are corrected one by one
+        cq, c1, cp = factors
+        f_other = cq * inv
+        fac = np.where(cls == 2, cp, np.where(cls == 1, c1, cq)) * inv
+        blk_d, blk_x = [], []
+        for c0 in range(0, n, 256):
+            srt = np.sort(w[c0:c0 + 256])
+            pre = np.concatenate([[0.0], np.cumsum(srt)])
+            k = int(np.sum(srt * f_other - 1.0 < 0.0))
+            blk_d.append(k - f_other * pre[k])
+            blk_x.append(f_other * pre[len(srt)] - len(srt))
+        xo = w * f_other - 1.0
+        xs = w * fac - 1.0
+        corr_x = np.where(cls != 0, xs - xo, 0.0)
+        corr_d = np.where(cls != 0, np.maximum(-xs, 0.0) - np.maximum(-xo, 0.0), 0.0)
+        tot_d = float(np.sum(blk_d) + np.sum(corr_d))
+        tot_x = float(np.sum(blk_x) + np.sum(corr_x))
+        bp = pick // 256
+        part = slice(bp * 256, pick)
+        below_d = float(np.sum(blk_d[:bp]) + np.sum(np.maximum(-xo[part], 0.0)) + np.sum(corr_d[:pick]))
+        below_x = float(np.sum(blk_x[:bp]) + np.sum(xo[part]) + np.sum(corr_x[:pick]))
+    if exact_total:  # (+ 64: a block summary is the difference of two sums of up to 256 weights)
+        M = 8.0 * EPS * (nn * (float(np.max(b)) * inv + 12.0 + 64.0) + (nn / 256.0 + 16.0) * (4.0 * tot_d + 4.0))
 
     def next_over_below(top):  # the first slot below `top` that is overfull, every slot skipped underfull
         for t in range(top - 1, -1, -1):
