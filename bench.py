@@ -537,8 +537,8 @@ def bench_reference_cap(args, cfg, torch, dist, rw, dev, W, L, rank, world, barr
 
 def bench_weighted(args, torch, rw, dev, W, L):
     """exact walks at (0.5, 2) on the weighted cfg 2 graph (R-MAT 2^20 vertices, 10^7 edges, fp32 weights
-    U[0.1, 2]): every start vertex x W walks x L steps in one call of randomwalk.walk -- the per-edge tables and
-    row sums built before the clock starts, the clock around the whole call (per step: one sort, a wave with
+    U[0.1, 2]): every start vertex x W walks x L steps in one call of randomwalk.walk -- the per-edge tables, row
+    sums and the block summaries of the long rows built before the clock starts, the clock around the whole call (per step: one sort, a wave with
     margins per walker on long rows, a lane per walker on short ones; csrc/n2v_walk_wlanes.hip)"""
     from node2vec_amd import synthetic
 
@@ -547,6 +547,7 @@ def bench_weighted(args, torch, rw, dev, W, L):
     t0 = time.perf_counter()
     rw.weighted_lanes_tables(g)
     rw.weighted_row_sums(g)
+    rw.weighted_hub_summaries(g)
     torch.cuda.synchronize()
     tables_s = time.perf_counter() - t0
     best, st, valid = None, {}, None

@@ -62,7 +62,7 @@ def test_weighted_rows_decided_with_margins_model():
     the shared / return slots -- against the table generate_alias_tables builds: random, heavy-tailed, few-valued
     and nearly tied rows, uniforms drawn, exactly at the table's threshold and 1e-6 .. 1e-14 beside it.  Every
     draw is either the table's or left undecided."""
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "models", "weighted_margins.py"), "700", "3"],
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "models", "weighted_margins.py"), "400", "3"],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert " 0 wrong" in res.stdout and "WRONG" not in res.stdout, res.stdout
