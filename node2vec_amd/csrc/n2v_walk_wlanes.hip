@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(256) void walk_weighted_lane_margin_kernel(
 
 constexpr int kWmWaves = 4;
 #ifndef N2V_WM_WAVES_PER_SIMD
-#define N2V_WM_WAVES_PER_SIMD 6
+#define N2V_WM_WAVES_PER_SIMD 5
 #endif
 
 template <typename WT, bool kPow2, bool kSeq>
