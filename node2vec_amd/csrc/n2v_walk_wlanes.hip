@@ -1314,8 +1314,11 @@ __device__ __forceinline__ int lm_draw(const WlRow &R, const WT *w, const WlCons
   return lm_next_over_below<WT, kPow2>(R, K, w, inv, delta, pick, x_t);
 }
 
+#ifndef N2V_LM_WAVES_PER_SIMD
+#define N2V_LM_WAVES_PER_SIMD 6
+#endif
 template <typename WT, bool kPow2>
-__global__ __launch_bounds__(256) void walk_weighted_lane_margin_kernel(
+__global__ __launch_bounds__(256, N2V_LM_WAVES_PER_SIMD) void walk_weighted_lane_margin_kernel(
     n2v_graph g, const WT *__restrict__ w, const int32_t *__restrict__ start_ids, int32_t num_walks,
     const int64_t *__restrict__ order, int64_t n_rows, int32_t max_n, int32_t step, int32_t walk_length,
     WlConsts K, uint64_t seed, int64_t *__restrict__ edge_state, int32_t *__restrict__ walks,
