@@ -10,7 +10,7 @@
 //                                       the reference-order row sum (the kSeq instance), then the exact wave
 //                                       kernel of n2v_walk.hip
 //   3. walk_weighted_lane_margin_kernel the same decision with a LANE per walker on the rows below 768 slots
-// With 2 and 3 weighted cfg 2 walks at 0.64 G steps/s at (0.5, 2) where 1 alone reached 0.06 G and the
+// With 2 and 3 weighted cfg 2 walks at 0.79 G steps/s at (0.5, 2) where 1 alone reached 0.06 G and the
 // wave-per-walker kernel of n2v_walk.hip 0.04 G (DESIGN.md 5, K2 exact, weighted graphs).
 //
 // The reference rebuilds the whole table of the row a walker stands on at every step

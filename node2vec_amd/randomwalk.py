@@ -243,7 +243,7 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
 # the rows of 768 slots or more and by a lane per walker on the rows below, a second chance on the reference-order
 # row sum and the exact wave kernel for what the margins leave undecided -- wins over the one-launch
 # wave-per-walker kernel from a few 10^4 walkers on (weighted cfg 2 at (0.5, 2): 47 k walkers 83 M steps/s against
-# 38 M, 471 k: 420 M against 44 M, 4.7 M: 730 M; profiles/r9l_time_wm_more.log).  Without the margins the exact
+# 38 M, 471 k: 430 M against 44 M, 4.7 M: 793 M; profiles/r9u_time_wm_more.log).  Without the margins the exact
 # lane kernel (the pairing replayed) has the wave on the longest row as the tail of every step (78 ms whatever
 # the batch) and only wins from 2 M walkers on.
 WEIGHTED_LANES_MARGINS = True
