@@ -3,7 +3,8 @@ generate_alias_tables builds (randomwalk.py:157-190) decided from sums over the 
 the table itself (oracle/n2v_oracle: the reference's loop, fp64).  Every DECIDED draw must be the table's;
 the share left undecided is printed.  As in the kernel a draw the general margins leave undecided gets a second
 chance with the row added up in the reference's own order (the margins of an exact sum).
-  python scripts/models/weighted_margins.py [rows] [seed]      (also run by tests/test_closed_form_models.py)"""
+  python scripts/models/weighted_margins.py [rows] [seed]      (also run by tests/test_closed_form_models.py)
+TEST INFRASTRUCTURE (like oracle/, which it checks against): nothing in node2vec_amd/ imports it."""
 import os
 import sys
 
