@@ -821,7 +821,8 @@ __device__ __forceinline__ double wm_sequential_total(const WlRow &R, const WT *
 template <typename WT, bool kPow2>
 __device__ __forceinline__ void wm_hub_sums(const WlRow &R, const WT *w, const WlConsts &K, double inv, const WT *hs,
                                             const double *hp, int pick, bool under, int nblk, int nent, int lane,
-                                            WmLds &L, double &tot_d, double &tot_x, double &below) {
+                                            WmLds &L, double &tot_d, double &tot_x, double &below, int pos0,
+                                            double w0) {
   const int n = R.n;
   const bool biased = !R.first;
   const double cq = kPow2 ? K.inv_q : 1.0 / K.q, cp = kPow2 ? K.inv_p : 1.0 / K.p;
@@ -836,8 +837,9 @@ __device__ __forceinline__ void wm_hub_sums(const WlRow &R, const WT *w, const W
   double lo_d = 0.0, lo_x = 0.0;  // per lane: over the slots below pick
   if (biased) {
     for (int k = lane; k < R.nM; k += 64) {
-      const int pos = wl_list_at(R, k);
-      const double wv = (double)w[pos < n ? pos : 0];
+      // (the first 64 entries and their weights were read for the row sum and kept: wm_draw)
+      const int pos = k < 64 ? pos0 : wl_list_at(R, k);
+      const double wv = k < 64 ? w0 : (double)w[pos < n ? pos : 0];
       const double xo = __fma_rn(wv, f_other, -1.0), xs = __fma_rn(wv, f_shared, -1.0);
       const double dx = xs - xo, dd = fmax(-xs, 0.0) - fmax(-xo, 0.0);
       const int e = pos >> 10;
@@ -933,7 +935,7 @@ __device__ __forceinline__ void wm_hub_sums(const WlRow &R, const WT *w, const W
 template <typename WT, bool kPow2>
 __device__ __forceinline__ int wm_decide(const WlRow &R, const WT *w, const WlConsts &K, double total, bool exact_total,
                                          double kfac, double w_max, double cmax, double b_pick, int pick, double r2,
-                                         int lane, WmLds &L, const WT *hub_sorted, const double *hub_prefix);
+                                         int lane, WmLds &L, const WT *hub_sorted, const double *hub_prefix, int pos0, double w0);
 
 // kSeq: the second chance of a walker the general margins left undecided -- the row sum in the reference's own
 // order, hence the exact-sum margins (a launch of its own over the list of those walkers: inside the first one
@@ -949,12 +951,19 @@ __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlCons
   const double cq = kPow2 ? K.inv_q : 1.0 / K.q, cp = kPow2 ? K.inv_p : 1.0 / K.p;
   double total = row_sum, kfac = 1.0;
   bool pick_shared = false;
+  int pos0 = -1;     // this lane's entry of the first 64 of the list and its weight: the corrections of a row
+  double w0 = 0.0;   // with block summaries read them again (wm_hub_sums) -- from here, not from memory
   if (biased) {
     double acc_s = 0.0, acc_r = 0.0;
     for (int k = lane; k < R.nM; k += 64) {
       const int pos = wl_list_at(R, k);
       pick_shared = pick_shared || pos == pick;
-      acc_s += (double)w[pos < n ? pos : 0];
+      const double wv = (double)w[pos < n ? pos : 0];
+      acc_s += wv;
+      if (k < 64) {
+        pos0 = pos;
+        w0 = wv;
+      }
     }
     for (int j = R.rpos + lane; j < R.rpos + R.nR; j += 64) acc_r += (double)w[j];
     const double ss = R.nM > 0 ? wm_wave_sum(acc_s) : 0.0;
@@ -978,14 +987,15 @@ __device__ __forceinline__ int wm_draw(const WlRow &R, const WT *w, const WlCons
     exact_total = true;
   }
   return wm_decide<WT, kPow2>(R, w, K, total, exact_total, kfac, w_max, cmax, b_pick, pick, r2, lane, L, hub_sorted,
-                              hub_prefix);
+                              hub_prefix, pos0, w0);
 }
 
 // what follows the row sum: `total` within (n + 2) 2^-53 kfac of the reference's, or (exact_total) the reference's
 template <typename WT, bool kPow2>
 __device__ __forceinline__ int wm_decide(const WlRow &R, const WT *w, const WlConsts &K, double total, bool exact_total,
                                          double kfac, double w_max, double cmax, double b_pick, int pick, double r2,
-                                         int lane, WmLds &L, const WT *hub_sorted, const double *hub_prefix) {
+                                         int lane, WmLds &L, const WT *hub_sorted, const double *hub_prefix, int pos0,
+                                         double w0) {
   const int n = R.n;
   const bool biased = !R.first;
   const double nn = (double)n;
@@ -1028,7 +1038,8 @@ __device__ __forceinline__ int wm_decide(const WlRow &R, const WT *w, const WlCo
   double tot_d = 0.0, tot_x = 0.0, below = 0.0;
   const bool summaries = hub_sorted != nullptr && g == 4;  // (a hub row: no pass)
   if (summaries)
-    wm_hub_sums<WT, kPow2>(R, w, K, inv, hub_sorted, hub_prefix, pick, under, nblk, nent, lane, L, tot_d, tot_x, below);
+    wm_hub_sums<WT, kPow2>(R, w, K, inv, hub_sorted, hub_prefix, pick, under, nblk, nent, lane, L, tot_d, tot_x, below,
+                           pos0, w0);
   for (int blk = summaries ? nblk : 0; blk < nblk; ++blk) {
     const int c0 = blk << 8, j0 = c0 + 4 * lane;
     if (in_entry == 0 && lane == 0) L.lm0[ent] = W.lm;  // (looked at again: wm_block_again)
