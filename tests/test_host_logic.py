@@ -487,3 +487,45 @@ def test_weighted_row_sums_and_the_grid_of_the_weights():
     assert g64.w.dtype == torch.float64 and float(rw.weighted_row_sums(g64)[5]) == 0.0  # no grid claimed
     bad = DeviceGraph.from_edges(src, dst, np.array([0.5, -0.75, 3.0, 1.25, 0.1875, 2.0], dtype=np.float32), n_vertices=5)
     assert rw.weighted_row_sums(bad) is None
+
+
+def test_weighted_hub_summaries_blocks_are_sorted_with_prefix_sums(monkeypatch):
+    """randomwalk.weighted_hub_summaries (struct n2v_weighted_hubs): for every row of WEIGHTED_HUB_SLOTS slots or
+    more, per block of 256 slots in row order, the weights sorted ascending (+inf behind the last weight of the
+    row) and their fp64 prefix sums; -1 for the other rows"""
+    import numpy as np
+    import torch
+
+    from node2vec_amd import randomwalk as rw
+    from node2vec_amd.graph import DeviceGraph
+
+    monkeypatch.setattr(rw, "WEIGHTED_HUB_SLOTS", 300)
+    rng = np.random.default_rng(1)
+    src = np.concatenate([rng.integers(0, 50, 400), np.repeat([3, 7], [700, 300])])
+    dst = np.concatenate([rng.integers(0, 50, 400), rng.integers(0, 1000, 1000)])
+    w = (rng.random(src.size) + 0.1).astype(np.float32)
+    g = DeviceGraph.from_edges(src, dst, w, n_vertices=1000)
+    st = rw.weighted_hub_summaries(g)
+    assert st is not None and st.min_slots == 300 and rw.weighted_hub_summaries(g) is st  # kept on the graph
+    _, block0, srt, prefix = g._weighted_hubs
+    deg = g.degrees()
+    hubs = torch.nonzero(deg >= 300).reshape(-1).tolist()
+    assert hubs == [3, 7] and int((block0 >= 0).sum()) == 2
+    assert srt.shape[1] == 256 and prefix.shape == (srt.shape[0], 257) and prefix.dtype == torch.float64
+    nb = 0
+    for v in hubs:
+        assert int(block0[v]) == nb
+        row = g.w[int(g.rowptr[v]):int(g.rowptr[v + 1])]
+        for b in range((row.numel() + 255) // 256):
+            seg = row[256 * b:256 * (b + 1)]
+            got = srt[nb + b]
+            assert torch.equal(got[:seg.numel()], torch.sort(seg).values) and bool(torch.isinf(got[seg.numel():]).all())
+            want = torch.cumsum(torch.sort(seg).values.double(), 0)
+            assert float(prefix[nb + b][0]) == 0.0 and torch.allclose(prefix[nb + b][1:seg.numel() + 1], want, rtol=1e-15)
+            assert bool((prefix[nb + b][seg.numel():] == prefix[nb + b][seg.numel()]).all())  # (+inf adds nothing)
+        nb += (row.numel() + 255) // 256
+    assert nb == srt.shape[0]
+    unit = DeviceGraph.from_edges(src, dst, None, n_vertices=1000)
+    monkeypatch.setattr(rw, "WEIGHTED_HUB_SLOTS", 10 ** 9)
+    g2 = DeviceGraph.from_edges(src, dst, w, n_vertices=1000)
+    assert rw.weighted_hub_summaries(g2) is None and unit.unit_weights
