@@ -883,8 +883,10 @@ extern "C" int n2v_weighted_step_wave_launch(const n2v_graph *g, const int32_t *
                                              uint64_t seed, int64_t *edge_state, int32_t *walks,
                                              uint8_t *valid, uint32_t *status, void *stream) {
   int64_t blocks = (n_rows + n2v::kWavesPerBlock - 1) / n2v::kWavesPerBlock;
-  const int64_t cap = n2v::resident_blocks((const void *)n2v::weighted_step_wave_kernel,
-                                           n2v::kWavesPerBlock * 64, 0);
+  int64_t cap = n2v::resident_blocks((const void *)n2v::weighted_step_wave_kernel, n2v::kWavesPerBlock * 64, 0);
+  // (min_n == 0: `order` is the short list of the walkers the margin kernels left undecided, -1 behind the last --
+  // a full grid of waves that each take one look at it cost 0.08 ms per step)
+  if (min_n == 0 && cap > 1024) cap = 1024;
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(n2v::weighted_step_wave_kernel, dim3((unsigned)blocks), dim3(n2v::kWavesPerBlock * 64), 0,
                      (hipStream_t)stream, *g, start_ids, num_walks, order, n_rows, min_n, step, walk_length, p, q,
