@@ -308,7 +308,13 @@ int n2v_walk(const n2v_graph *g, const int32_t *start_ids, int64_t n_start,
  *            (N2V_ST_ZERODIV)
  *     edge_state [n_rows] the edge (index into col) every walker walked last; the step writes it
  *     order  [n_rows] the rows in the order lanes take them -- sorted by the out-degree of
- *            walks[r][step], descending -- or NULL (row order)
+ *            walks[r][step], descending, vanished walkers last (the ascending sort of
+ *            n2v_walk_weighted_keys' keys) -- or NULL (row order).  PRECONDITION when scratch and
+ *            row_sums are given: the order IS sorted that way.  The wave-per-walker kernels stop at the
+ *            first row at or below the cut between the two kernels and at the first vanished walker
+ *            (everything behind it is the lane kernel's, or nobody's), so a long row BEHIND a short one
+ *            in an unsorted order would not be stepped and no status bit would say so.  The library
+ *            cannot check a device-side permutation without a pass and a host read; it does not.
  *   for step = 0 .. walk_length - 1:  n2v_walk_weighted_step(..., step, ...)
  * and the result is n2v_walk's, bit for bit (same uniform stream, keyed by start vertex, ordinal and
  * step).  For return_param or inout_param != 1 the steps after the first read the classes of the

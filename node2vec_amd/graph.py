@@ -97,6 +97,12 @@ class DeviceGraph:
         self.rank_class_first: Optional[torch.Tensor] = None  # int32 [P] (uint32)
         self.rank_class_off: Optional[torch.Tensor] = None  # int32 [P] (uint32)
         self.rank_tried = False
+        # caches of the weighted step kernels (randomwalk.weighted_row_sums, weighted_hub_summaries,
+        # _walk_weighted_lanes): functions of rowptr / the stored weights alone.  `w` has no setter and
+        # the arrays of a DeviceGraph are never replaced in place, so they cannot go stale.
+        self._row_weight_sums = None  # fp64 [V + 2] | False (a weight negative or not finite)
+        self._weighted_hubs = None    # (struct n2v_weighted_hubs, its tensors) | False (none / did not fit)
+        self._degree_rank = None      # int32 [V]: place of every vertex by descending out-degree, ties by id
 
     @property
     def w(self) -> torch.Tensor:

@@ -702,7 +702,8 @@ class RankState:
         """the path records, split by the rank that emits each row (owner of its start vertex).  The
         start list is sorted and the parts are vertex ranges, so the rows of a home rank are a RANGE of
         output rows: the home of a record is a search over n_parts cuts; the records are then grouped by a
-        sort of that one-byte key (empty slots of the bounded inboxes -- row -1 -- last, and dropped)."""
+        sort of that key -- one byte while the sentinel `n_parts` fits in it, int16 / int32 for larger worlds
+        (empty slots of the bounded inboxes -- row -1 -- last, and dropped)."""
         dev = self.part.device
         rec = torch.cat(self.log) if self.log else torch.zeros((0, 3), dtype=torch.int64, device=dev)
         if rec.shape[0] == 0:
@@ -712,7 +713,8 @@ class RankState:
         cuts = torch.searchsorted(s, self.part.bounds.to(torch.int64)) * self.W
         row = rec[:, 0].contiguous()
         home = torch.searchsorted(cuts, row, right=True) - 1  # (-1 for an empty slot)
-        key = torch.where(row >= 0, home, torch.full_like(home, n_parts)).to(torch.uint8)
+        key_dtype = torch.uint8 if n_parts < 256 else (torch.int16 if n_parts < 32768 else torch.int32)
+        key = torch.where(row >= 0, home, torch.full_like(home, n_parts)).to(key_dtype)
         key, order = torch.sort(key)
         counts = torch.bincount(key.to(torch.int64), minlength=n_parts + 1).tolist()  # one host read
         rec = rec[order]
@@ -758,6 +760,7 @@ BOUNDED = True
 BOUNDED_CALIBRATION_STEPS = 3  # capacities from the larger flow of the last TWO (p < 1 sends walkers back: the
 #                                flows of even and odd steps differ until the walkers have mixed)
 BOUNDED_SLACK = 1.5
+BOUNDED_MAX_RETRIES = 2  # walk_partitioned: overflowing attempts with enlarged boxes before exact sizes take over
 BOUNDED_MIN_SLOTS = 256
 
 
@@ -1178,6 +1181,7 @@ def walk_partitioned(part: GraphPart, start_ids: torch.Tensor, num_walks: int, w
     dev = part.device
     cpu = dist.get_backend(group) == "gloo"  # gloo moves host tensors
     caps = None
+    overflows = 0  # attempts that ended in N2V_ST_OVERFLOW (the status word is all-reduced: the same on every rank)
     while True:
         st.use_tables = use_tables
         st.defer_status = True
@@ -1185,7 +1189,9 @@ def walk_partitioned(part: GraphPart, start_ids: torch.Tensor, num_walks: int, w
         # n2v_partition_forward, one launch; every rank takes the same branch (use_tables is agreed)
         st.forward = True
         st.initiate(start_ids)
-        bounded = BOUNDED and st.forwarding()
+        # a flow that keeps outgrowing its boxes (BOUNDED_MAX_RETRIES enlargements did not hold it): the
+        # walk is then stepped with exact sizes throughout, a host read per step -- it always terminates
+        bounded = BOUNDED and st.forwarding() and overflows <= BOUNDED_MAX_RETRIES
         exact_steps = min(BOUNDED_CALIBRATION_STEPS, walk_length) if bounded else walk_length
         for _ in range(exact_steps):
             out = st.advance(world)
@@ -1225,6 +1231,9 @@ def walk_partitioned(part: GraphPart, start_ids: torch.Tensor, num_walks: int, w
             st.end_bounded()
             break
         _check_word(word & ~_ST_OVERFLOW())
+        overflows += 1
+        if timings is not None:
+            timings["bounded_overflows"] = overflows
         caps = _bounded_caps_retry(caps, [row[1:1 + world] for row in fin], [row[1 + world:] for row in fin], lanes)
         del bx
         st = RankState(part, num_walks, walk_length, p, q, seed, step_fn)

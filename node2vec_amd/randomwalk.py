@@ -188,6 +188,7 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     total = n_start * num_walks
     if (mode == "exact" and biased and not graph.unit_weights and use_weighted_lanes is not False
             and total > 0 and walk_length > 0
+            and use_edge_classes and use_wedges  # (the flags that force the table-free wave kernel)
             and (use_weighted_lanes or total >= WEIGHTED_LANES_MIN_WALKERS)
             and weighted_lanes_tables(graph, bool(use_weighted_lanes))):
         return _walk_weighted_lanes(graph, start_ids, num_walks, walk_length, return_param, inout_param,
@@ -266,7 +267,7 @@ def weighted_row_sums(graph: DeviceGraph) -> Optional[torch.Tensor]:
     """fp64 sum of the stored weights of every row (any order), kept on the graph: what the wave kernel for
     long rows takes the row sum of a step from (n2v_walk_weighted_step).  None when some weight is negative
     or not finite -- the margins of that kernel assume neither -- and the lane kernel then walks alone."""
-    got = getattr(graph, "_row_weight_sums", None)
+    got = graph._row_weight_sums
     if got is None:
         w = graph.w
         if not bool((torch.isfinite(w) & (w >= 0)).all()):
@@ -297,34 +298,47 @@ def weighted_hub_summaries(graph: DeviceGraph):
     more, cut into blocks of 256 slots in row order, the weights of each block sorted ascending (the last block
     padded with +inf) and their fp64 prefix sums -- what lets the wave kernel of n2v_walk_weighted_step take the
     sums of a step over a hub row from one binary search per block instead of a pass over the row (two thirds of
-    the slots the steps of a walk on cfg 2 stand on belong to 211 such rows)."""
-    got = getattr(graph, "_weighted_hubs", None)
+    the slots the steps of a walk on cfg 2 stand on belong to 211 such rows).  None also when the summaries (12
+    bytes per hub slot that stay, ~60 of temporaries while they are built) do not fit in half of the free
+    memory: the wave kernel then makes its pass over the row -- same bits, slower."""
+    got = graph._weighted_hubs
     if got is None:
         got = False
         deg = graph.degrees()
         rows = torch.nonzero(deg >= WEIGHTED_HUB_SLOTS).reshape(-1)
         if rows.numel() and WEIGHTED_HUB_SLOTS > 0:
-            dev, w = graph.device, graph.w
             nblk = (deg[rows] + 255) // 256
-            first = torch.cumsum(nblk, 0) - nblk  # first block of every hub row
-            n_blocks = int(nblk.sum())
-            block0 = torch.full((graph.n_vertices,), -1, dtype=torch.int32, device=dev)
-            block0[rows] = first.to(torch.int32)
-            # slot s of block b of hub row r = weight rowptr[r] + 256 (b - first[r]) + s, +inf beyond the row
-            blk_row = torch.repeat_interleave(torch.arange(rows.numel(), device=dev), nblk)
-            blk_in_row = torch.arange(n_blocks, device=dev) - first[blk_row]
-            slot = blk_in_row[:, None] * 256 + torch.arange(256, device=dev)[None, :]
-            inside = slot < deg[rows][blk_row][:, None]
-            src = (graph.rowptr[rows][blk_row][:, None] + slot).clamp_(max=max(graph.n_edges - 1, 0))
-            vals = torch.where(inside, w[src], torch.full((), float("inf"), dtype=w.dtype, device=dev))
-            srt = torch.sort(vals, dim=1).values.contiguous()
-            prefix = torch.zeros((n_blocks, 257), dtype=torch.float64, device=dev)
-            torch.cumsum(torch.where(torch.isfinite(srt), srt, torch.zeros((), dtype=w.dtype, device=dev)).double(), 1,
-                         out=prefix[:, 1:])
-            st = _lib.WeightedHubs(block0.data_ptr(), srt.data_ptr(), prefix.data_ptr(), WEIGHTED_HUB_SLOTS, 0)
-            got = (st, block0, srt, prefix)  # (the tensors are kept alive beside the struct that points at them)
+            fits = True
+            if graph.device.type == "cuda":
+                fits = int(nblk.sum()) * 256 * 72 <= torch.cuda.mem_get_info(graph.device)[0] // 2
+            if fits:
+                try:
+                    got = _hub_summaries(graph, deg, rows, nblk)
+                except torch.cuda.OutOfMemoryError:
+                    got = False
         graph._weighted_hubs = got
     return None if got is False else got[0]
+
+
+def _hub_summaries(graph: DeviceGraph, deg, rows, nblk):
+    dev, w = graph.device, graph.w
+    first = torch.cumsum(nblk, 0) - nblk  # first block of every hub row
+    n_blocks = int(nblk.sum())
+    block0 = torch.full((graph.n_vertices,), -1, dtype=torch.int32, device=dev)
+    block0[rows] = first.to(torch.int32)
+    # slot s of block b of hub row r = weight rowptr[r] + 256 (b - first[r]) + s, +inf beyond the row
+    blk_row = torch.repeat_interleave(torch.arange(rows.numel(), device=dev), nblk)
+    blk_in_row = torch.arange(n_blocks, device=dev) - first[blk_row]
+    slot = blk_in_row[:, None] * 256 + torch.arange(256, device=dev)[None, :]
+    inside = slot < deg[rows][blk_row][:, None]
+    src = (graph.rowptr[rows][blk_row][:, None] + slot).clamp_(max=max(graph.n_edges - 1, 0))
+    vals = torch.where(inside, w[src], torch.full((), float("inf"), dtype=w.dtype, device=dev))
+    srt = torch.sort(vals, dim=1).values.contiguous()
+    prefix = torch.zeros((n_blocks, 257), dtype=torch.float64, device=dev)
+    torch.cumsum(torch.where(torch.isfinite(srt), srt, torch.zeros((), dtype=w.dtype, device=dev)).double(), 1,
+                 out=prefix[:, 1:])
+    st = _lib.WeightedHubs(block0.data_ptr(), srt.data_ptr(), prefix.data_ptr(), WEIGHTED_HUB_SLOTS, 0)
+    return (st, block0, srt, prefix)  # (the tensors are kept alive beside the struct that points at them)
 
 
 def _walk_weighted_lanes(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_length: int,
@@ -347,7 +361,7 @@ def _walk_weighted_lanes(graph: DeviceGraph, start_ids: torch.Tensor, num_walks:
     # of one length come together, and so do the walkers on one and the same row -- a walk stands on a
     # vertex in proportion to its degree, so most waves have all 64 lanes on one or two rows and their
     # loads of the row coalesce instead of fetching 64 different lines
-    if getattr(graph, "_degree_rank", None) is None:
+    if graph._degree_rank is None:
         order0 = torch.sort(deg, descending=True, stable=True).indices
         rk = torch.empty(graph.n_vertices, dtype=torch.int32, device=dev)
         rk[order0] = torch.arange(graph.n_vertices, dtype=torch.int32, device=dev)

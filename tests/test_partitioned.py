@@ -122,3 +122,37 @@ def test_partitioned_walk_two_gloo_ranks(oracle):
     ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+@pytest.mark.parametrize("n_parts", [255, 256, 300, 40000])
+def test_log_by_home_with_more_parts_than_a_byte_holds(n_parts):
+    """path records grouped by the rank that emits their row: the sort key must hold every rank AND
+    the sentinel of the empty slots (round-5 advisor finding: a one-byte key wrapped rank 300 to 44 and,
+    at 256 parts, the sentinel to rank 0); then the rows every rank assembles"""
+    from node2vec_amd.partitioned import GraphPart, RankState
+
+    nv, W, L = 2 * n_parts, 2, 3
+    bounds = torch.arange(n_parts, dtype=torch.int64) * 2           # part r = vertices [2 r, 2 r + 2)
+    rowptr = torch.tensor([0, 1, 2], dtype=torch.int64)
+    part = GraphPart(7, 14, 16, rowptr, torch.zeros(2, dtype=torch.int32), None, bounds)
+    st = RankState(part, W, L, 1.0, 1.0, 0, step_fn=None)
+    start = torch.arange(nv, dtype=torch.int64)                      # every vertex starts W walks
+    gen = torch.Generator().manual_seed(n_parts)
+    rows = torch.randint(0, nv * W, (5000,), generator=gen)
+    rows[::7] = -1                                                   # empty slots of a bounded inbox
+    rec = torch.stack([rows, torch.randint(0, L + 1, (5000,), generator=gen),
+                       torch.randint(0, nv, (5000,), generator=gen)], 1)
+    st.log = [rec[:1234], rec[1234:]]
+    by_home = st.log_by_home(start, n_parts)
+    assert len(by_home) == n_parts
+    real = rec[rows >= 0]
+    assert sum(r.shape[0] for r in by_home) == real.shape[0]
+    for r in (0, 1, 43, 44, n_parts // 2, n_parts - 2, n_parts - 1):
+        lo, hi = 2 * r * W, 2 * (r + 1) * W                         # the output rows of rank r
+        want = real[(real[:, 0] >= lo) & (real[:, 0] < hi)]
+        got = by_home[r]
+        assert bool(((got[:, 0] >= lo) & (got[:, 0] < hi)).all()), r
+        assert sorted(map(tuple, got.tolist())) == sorted(map(tuple, want.tolist())), r
+    # rank 7 assembles its rows from what it was handed: every record lands inside its own range
+    walks, ok, out_rows = st.assemble([by_home[7]], start)
+    assert walks.shape == (2 * W, L + 1) and out_rows.tolist() == list(range(14 * W, 16 * W))

@@ -1,0 +1,222 @@
+"""K3 at the MODEL sizes of BASELINE cfgs 3, 4 and 5: 10^7 x 128,
+10^8 x 128 (row offsets past 2^33 bytes, an 8.67 x 10^7-word vocabulary is cfg 4's own; the test
+takes the full 10^8) and 5 x 10^7 x 256, against the CPU oracle bit for bit.
+
+The reference's call site is embedding.py:125-126 (gensim Word2Vec on the walk corpus) with the
+parameters of constants.py:50-68.  The oracle cannot hold a 102 GB model on the host, and does
+not have to: SGNS touches only the rows of the tokens of a block and of the negatives drawn for
+them.  Take U = every row the GPU changed + every token + the last row, ascending.  The oracle is
+given the COMPACT model  syn0[U], syn1neg[U], cum_table[U]  and the tokens renumbered by their
+place in U.  `bisect_left(cum_table[U], x)` is the place in U of `bisect_left(cum_table, x)`
+whenever that row is in U (U is ascending, cum_table non-decreasing, cum_table[U][-1] is the
+domain); if the GPU ever drew, skipped or failed to update another row than the oracle, the oracle
+trains a row of U the GPU left at its initial value, or leaves one the GPU changed: a mismatch
+either way.  So "compact oracle == GPU on U, nothing outside U changed" is the same statement as
+"oracle on the whole model == GPU", at a cost the host can pay.
+
+Two corpora per size: `spread` -- a count-ordered power-law vocabulary (what fit_streaming builds),
+tokens from the whole range, negatives by the 0.75-power table through the cum index; `top` -- the
+tokens AND the whole negative mass in the last 10^6 rows (cum_table flat below the slice), so that
+every row the kernel touches lies past element offset (n - 10^6) x dim.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+WINDOW, NEG = 5, 5  # constants.py:60; gensim's default `negative`
+CHUNK = 1 << 22
+
+
+def _bits(t):
+    return t.view(torch.int32)
+
+
+def _changed_rows(cur, init):
+    """rows of `cur` whose BITS differ from `init` (None = all zeros), ascending; chunked so that the
+    temporaries stay small beside a 51 GB matrix"""
+    out = []
+    for lo in range(0, cur.shape[0], CHUNK):
+        x = _bits(cur[lo:lo + CHUNK])
+        d = (x != 0) if init is None else (x != _bits(init[lo:lo + CHUNK]))
+        out.append(torch.nonzero(d.any(1)).flatten() + lo)
+    return torch.cat(out)
+
+
+def _all_finite(t, rows):
+    return bool(torch.isfinite(t[rows]).all())
+
+
+def _power_law_counts(n, device):
+    """descending token counts, the shape pipeline.corpus_vocabulary finds on a power-law graph:
+    count ~ rank^-0.9, floor 10 (every vertex starts 10 walks, constants.py:16)"""
+    r = torch.arange(1, n + 1, dtype=torch.float64, device=device)
+    c = (3.0e9 * r.pow_(-0.9)).floor_().clamp_(min=10.0)
+    return c.to(torch.int64)
+
+
+def _corpus(kind, n, rows, length, gen):
+    """int32 [rows, length] vocabulary indices on the host"""
+    if kind == "top":
+        lo = n - 1_000_000
+        idx = torch.randint(lo, n, (rows, length), generator=gen, dtype=torch.int64)
+    else:
+        # half of the tokens uniform over the whole vocabulary (a walk visits rare vertices too),
+        # half log-uniform (the hubs a walk keeps returning to)
+        u = torch.rand((rows, length), generator=gen, dtype=torch.float64)
+        zipf = torch.exp(u * float(np.log(n))).long().clamp_(max=n) - 1
+        flat = torch.randint(0, n, (rows, length), generator=gen, dtype=torch.int64)
+        pick = torch.rand((rows, length), generator=gen) < 0.5
+        idx = torch.where(pick, flat, zipf)
+        idx[0, 0], idx[0, 1] = n - 1, 0  # both ends of the matrices
+    idx = idx.to(torch.int32)
+    idx[1, 3] = -1  # out of vocabulary: dropped before windowing (gensim)
+    return idx
+
+
+def _model(n, dim, kind, seed, sample):
+    from node2vec_amd import _lib, sgns
+
+    dev = torch.device("cuda")
+    counts = _power_law_counts(n, dev)
+    ids = torch.arange(n, dtype=torch.int64, device=dev)
+    vocab = sgns.Vocab(ids, counts, ids.to(torch.int32))
+    m = sgns.SgnsModel(vocab, dim, WINDOW, NEG, seed=seed, sample=sample)
+    assert m.cum_index is not None and m.cum_index_bits >= 20
+    if kind == "top":
+        # the whole negative mass in the last 10^6 rows: cum_table is 0 below the slice
+        lo = n - 1_000_000
+        tab = torch.zeros(n, dtype=torch.int64, device=dev)
+        tab[lo:] = torch.round(torch.arange(1, n - lo + 1, dtype=torch.float64, device=dev)
+                               / (n - lo) * sgns.CUM_DOMAIN).to(torch.int64)
+        tab[-1] = sgns.CUM_DOMAIN
+        m.cum_table = tab.to(torch.int32)
+        _lib.check(_lib.load().n2v_cum_index_build(m.cum_table.data_ptr(), n, m.cum_index_bits,
+                                                   m.cum_index.data_ptr(), _lib.current_stream_ptr()),
+                   "n2v_cum_index_build")
+    del counts
+    return m
+
+
+def _model_size_case(oracle, n, dim, kind, rows, sample=0.0, batched=False):
+    """(the matrices are released by shrinking their STORAGE: a failed assertion keeps this frame -- and every
+    tensor it names -- alive inside pytest's traceback, and 150 GB held by one failure would fail the
+    cases after it for want of memory)"""
+    big = []
+    try:
+        _run_case(oracle, big, n, dim, kind, rows, sample, batched)
+    finally:
+        torch.cuda.synchronize()
+        for t in big:
+            t.untyped_storage().resize_(0)
+        torch.cuda.empty_cache()
+
+
+def _run_case(oracle, big, n, dim, kind, rows, sample, batched):
+    from node2vec_amd import sgns
+
+    torch.cuda.empty_cache()
+    seed, length, base = 20 + dim, 81, 123_456_789
+    gen = torch.Generator().manual_seed(n % 1000 + dim + len(kind))
+    m = _model(n, dim, kind, seed, sample)
+    m.batched = batched
+    big += [m.syn0, m.syn1neg, m.vocab.ids, m.vocab.counts, m.cum_table]
+    assert m.syn0.numel() == n * dim and (n < 10 ** 8 or m.syn0.numel() > 2 ** 33)
+    idx_host = _corpus(kind, n, rows, length, gen)
+    idx = idx_host.cuda()
+    init0 = sgns.init_syn0(n, dim, m.seed, m.syn0.device)
+    big.append(init0)
+    assert torch.equal(_bits(init0[-3:]), _bits(m.syn0[-3:]))  # the initial state can be regenerated
+
+    # -- alpha = 0, the default (hogwild) path: nothing moves, the pair count is the corpus's ------
+    m.train_block(idx, 0.0, base)
+    torch.cuda.synchronize()
+    whole = int(m.pairs.item())
+    assert whole > rows * (length - 2)
+    assert _changed_rows(m.syn0, init0).numel() == 0 and _changed_rows(m.syn1neg, None).numel() == 0
+    m.pairs.zero_()
+    cuts = [0, 1, rows // 3, rows]
+    for a, b in zip(cuts, cuts[1:]):
+        m.train_block(idx[a:b].contiguous(), 0.0, base + a)  # sentence ids continue at a
+    torch.cuda.synchronize()
+    assert int(m.pairs.item()) == whole
+
+    # -- deterministic mode against the oracle on the compact model ------------------------------
+    m.pairs.zero_()
+    m.train_block(idx, 0.025, base, deterministic=True)
+    torch.cuda.synchronize()
+    assert int(m.pairs.item()) == whole
+    tok = idx.reshape(-1)
+    tok = tok[tok >= 0].long()
+    ch0, ch1 = _changed_rows(m.syn0, init0), _changed_rows(m.syn1neg, None)
+    last = torch.tensor([n - 1], device="cuda")
+    U = torch.unique(torch.cat([tok, ch0, ch1, last]))
+    # every context word of a pair moves, every centre word is a target; negatives are drawn beyond
+    assert bool(torch.isin(ch0, torch.unique(tok)).all())
+    big = n * dim > 2 ** 32  # cfgs 4 and 5: rows past 32-bit ELEMENT offsets (cfg 3: 1.28 x 10^9 elements)
+    if kind == "top":
+        assert int(U.min()) >= n - 1_000_000 and (not big or int(U.min()) * dim > 2 ** 32)
+    else:
+        assert ch1.numel() > tok.unique().numel() and (not big or int(ch1.max()) * dim > 2 ** 32)
+    o0 = init0[U].cpu().numpy()
+    o1 = np.zeros_like(o0)
+    place = torch.searchsorted(U, idx.long().clamp(min=0)).to(torch.int32)
+    place = torch.where(idx >= 0, place, idx).cpu().numpy()
+    si = None if m.sample_int is None else m.sample_int[U].cpu().numpy()
+    got_pairs = oracle.sgns_train(place, o0, o1, m.cum_table[U].cpu().numpy(), si, sgns.exp_table(),
+                                  int(U.numel()), base, m.seed, dim, WINDOW, NEG, 0.025, batched=batched)
+    assert got_pairs == whole
+    assert np.array_equal(o0.view(np.int32), _bits(m.syn0[U]).cpu().numpy())
+    assert np.array_equal(o1.view(np.int32), _bits(m.syn1neg[U]).cpu().numpy())
+    det1 = m.syn1neg[ch1].clone()
+    del o0, o1
+
+    # -- back to the initial state, then the default path at alpha > 0 ----------------------------
+    m.syn0[ch0] = init0[ch0]
+    m.syn1neg[ch1] = 0.0
+    assert _changed_rows(m.syn0, init0).numel() == 0 and _changed_rows(m.syn1neg, None).numel() == 0
+    m.pairs.zero_()
+    m.train_block(idx, 0.025, base)
+    torch.cuda.synchronize()
+    assert int(m.pairs.item()) == whole
+    h0, h1 = _changed_rows(m.syn0, init0), _changed_rows(m.syn1neg, None)
+    # the draws depend on (seed, sentence, position) alone: the same rows whatever the schedule
+    # (a context word whose targets are all still zero does not move: WHICH words move depends on the
+    # order of the waves, which targets are trained does not)
+    assert bool(torch.isin(h0, torch.unique(tok)).all()) and torch.equal(h1, ch1)
+    assert _all_finite(m.syn0, U) and _all_finite(m.syn1neg, U)
+    # to first order a target row moves by g x syn0[context] with g = (label - 1/2) alpha whatever the order
+    # of the waves (every f starts at 0), so the typical row ends where the ordered run leaves it.  Not every
+    # row: a row trained by waves on two XCDs keeps the updates of one of them (plain stores, L2s that are not
+    # coherent with each other: 5 - 35 % of the rows of a block differ by a whole update, DESIGN.md 5 "K3",
+    # profiles/r6b_diag_hogwild_rows.log) -- the hogwild regime, bounded by the quality tests, not here
+    rel = (m.syn1neg[ch1] - det1).norm(dim=1) / det1.norm(dim=1)
+    assert float(rel.median()) < 0.02, float(rel.median())
+
+
+@pytest.mark.parametrize("kind", ["spread", "top"])
+def test_cfg3_model_size_10m_x_128(oracle, kind):
+    _model_size_case(oracle, 10_000_000, 128, kind, rows=768)
+
+
+def test_cfg3_model_size_subsampling(oracle):
+    """gensim's default `sample` = 1e-3: a 10^7-word threshold table, the frequent words dropped
+    before windowing"""
+    _model_size_case(oracle, 10_000_000, 128, "spread", rows=768, sample=1e-3)
+
+
+@pytest.mark.parametrize("kind", ["spread", "top"])
+def test_cfg4_model_size_100m_x_128(oracle, kind):
+    _model_size_case(oracle, 100_000_000, 128, kind, rows=768)
+
+
+@pytest.mark.parametrize("kind", ["spread", "top"])
+def test_cfg5_model_size_50m_x_256(oracle, kind):
+    _model_size_case(oracle, 50_000_000, 256, kind, rows=512)
+
+
+def test_cfg4_model_size_batched_trainer(oracle):
+    """the opt-in batched trainer (negatives shared by the pairs of a centre position) at 10^8 x 128
+    against ITS oracle"""
+    _model_size_case(oracle, 100_000_000, 128, "spread", rows=256, batched=True)
