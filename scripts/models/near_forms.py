@@ -369,73 +369,74 @@ def compositions(n):
             yield cls
 
 
-random.seed(int(os.environ.get("N2V_MODEL_SEED", 7)))
-mode = sys.argv[1] if len(sys.argv) > 1 else "short"
-big = mode == "big"
-VALS = [0.7, 1.3, 3.0, 0.3, 1.5, 6.0, 0.75, 1.0 / 3.0, 2.0 / 3.0, 5.0, 0.2, 0.6, 1.2, 2.5, 7.0, 1.0 / 7.0, 10.0, 0.1, 37.5, 1.0]
-stats = [0, 0, 0]  # draws, left to the replay, wrong
-rows = 0
-if mode == "adversarial":
-    #  every (return run, shared subset) composition of the rows of n <= NMAX slots x
-    # twelve (p, q) that are not dyadic, then random rows of up to 120 slots, every slot, adversarial r2
-    PQ = [(0.7, 3.0), (3.0, 0.7), (1.3, 1.3), (0.3, 0.7), (3.0, 1.0), (1.0 / 3.0, 2.0 / 3.0), (1.5, 6.0), (6.0, 1.5),
-          (0.75, 1.2), (5.0, 0.2), (7.0, 1.0 / 7.0), (37.5, 0.6)]
-    nmax = int(os.environ.get("N2V_MODEL_NMAX", 6))
-    for n in range(1, nmax + 1):
-        for cls0 in compositions(n):
-            for p, q in PQ:
-                cls = list(cls0)
-                if q == 1.0: cls = [c if c != 'M' else 'O' for c in cls]
-                check_row(n, cls, {'R': 1.0 / p, 'M': 1.0, 'O': 1.0 / q}, range(n), True, stats)
-                rows += 1
-    trials = int(os.environ.get("N2V_MODEL_TRIALS", 600))
-    k = 0
-    while k < trials:
-        n = random.randint(1, 120)
-        p, q = random.choice(VALS), random.choice(VALS)
-        if dyadic_pq(p, q): continue
-        check_row(n, random_row(n, p, q), {'R': 1.0 / p, 'M': 1.0, 'O': 1.0 / q}, range(n), True, stats)
-        k += 1; rows += 1
-elif mode == "exactavg":
-    # the second stage (round 5): rows of 256 .. N2V_MODEL_NMAX slots (default 20 000), the forms on the
-    # reference's own values with the LINEAR margin, r2 random and adversarial, 48 slots per row + every
-    # return / shared slot of the row's first 200
-    STEP[0] = near_step_exact
-    trials = int(os.environ.get("N2V_MODEL_TRIALS", 60))
-    nmax = int(os.environ.get("N2V_MODEL_NMAX", 20000))
-    k = 0
-    while k < trials:
-        n = int(math.exp(random.uniform(math.log(256), math.log(nmax))))
-        p, q = random.choice(VALS), random.choice(VALS)
-        if dyadic_pq(p, q): continue
-        cls = random_row(n, p, q)
-        if random.random() < 0.5:  # a sparse list, as the rows of a hub have
-            cls = [c if c != 'M' or random.random() < 0.05 else 'O' for c in cls]
-        special = [i for i in range(n) if cls[i] != 'O'][:200]
-        picks = sorted(set(random.sample(range(n), 48) + special))
-        bb = {'R': 1.0 / p, 'M': 1.0, 'O': 1.0 / q}
-        check_row(n, cls, bb, picks, True, stats)
-        rnd = [0, 0, 0]
-        check_row(n, cls, bb, picks, False, rnd)
-        STEP[0] = near_step  # the first stage on the same draws, for comparison
-        first = [0, 0, 0]
-        check_row(n, cls, bb, picks, False, first)
+if __name__ == "__main__":  # (importable: scripts/models/margin_adversary.py uses the forms above)
+    random.seed(int(os.environ.get("N2V_MODEL_SEED", 7)))
+    mode = sys.argv[1] if len(sys.argv) > 1 else "short"
+    big = mode == "big"
+    VALS = [0.7, 1.3, 3.0, 0.3, 1.5, 6.0, 0.75, 1.0 / 3.0, 2.0 / 3.0, 5.0, 0.2, 0.6, 1.2, 2.5, 7.0, 1.0 / 7.0, 10.0, 0.1, 37.5, 1.0]
+    stats = [0, 0, 0]  # draws, left to the replay, wrong
+    rows = 0
+    if mode == "adversarial":
+        #  every (return run, shared subset) composition of the rows of n <= NMAX slots x
+        # twelve (p, q) that are not dyadic, then random rows of up to 120 slots, every slot, adversarial r2
+        PQ = [(0.7, 3.0), (3.0, 0.7), (1.3, 1.3), (0.3, 0.7), (3.0, 1.0), (1.0 / 3.0, 2.0 / 3.0), (1.5, 6.0), (6.0, 1.5),
+              (0.75, 1.2), (5.0, 0.2), (7.0, 1.0 / 7.0), (37.5, 0.6)]
+        nmax = int(os.environ.get("N2V_MODEL_NMAX", 6))
+        for n in range(1, nmax + 1):
+            for cls0 in compositions(n):
+                for p, q in PQ:
+                    cls = list(cls0)
+                    if q == 1.0: cls = [c if c != 'M' else 'O' for c in cls]
+                    check_row(n, cls, {'R': 1.0 / p, 'M': 1.0, 'O': 1.0 / q}, range(n), True, stats)
+                    rows += 1
+        trials = int(os.environ.get("N2V_MODEL_TRIALS", 600))
+        k = 0
+        while k < trials:
+            n = random.randint(1, 120)
+            p, q = random.choice(VALS), random.choice(VALS)
+            if dyadic_pq(p, q): continue
+            check_row(n, random_row(n, p, q), {'R': 1.0 / p, 'M': 1.0, 'O': 1.0 / q}, range(n), True, stats)
+            k += 1; rows += 1
+    elif mode == "exactavg":
+        # the second stage (round 5): rows of 256 .. N2V_MODEL_NMAX slots (default 20 000), the forms on the
+        # reference's own values with the LINEAR margin, r2 random and adversarial, 48 slots per row + every
+        # return / shared slot of the row's first 200
         STEP[0] = near_step_exact
-        for i in range(3): stats[i] += rnd[i]
-        random_draws = [a + b for a, b in zip(globals().get("random_draws", [0, 0, 0, 0]), rnd + [first[1]])]
-        k += 1; rows += 1
-    print("random r2 only: draws", random_draws[0], "left to the replay by the second stage", random_draws[1],
-          "(by the first stage, counts + n^2 margin:", random_draws[3], ") bad", random_draws[2])
-else:
-    trials = int(os.environ.get("N2V_MODEL_TRIALS", 3000 if not big else 150))
-    while rows < trials:
-        n = random.randint(200, 2500) if big else random.randint(1, 70)
-        p, q = random.choice(VALS), random.choice(VALS)
-        if dyadic_pq(p, q): continue  # (dyadic: the other forms)
-        cls = random_row(n, p, q)
-        check_row(n, cls, {'R': 1.0 / p, 'M': 1.0, 'O': 1.0 / q},
-                  range(n) if not big else random.sample(range(n), 60), False, stats)
-        rows += 1
-print("rows", rows)
-print("total", stats[0], "ambiguous", stats[1], "bad", stats[2])
-sys.exit(1 if stats[2] else 0)
+        trials = int(os.environ.get("N2V_MODEL_TRIALS", 60))
+        nmax = int(os.environ.get("N2V_MODEL_NMAX", 20000))
+        k = 0
+        while k < trials:
+            n = int(math.exp(random.uniform(math.log(256), math.log(nmax))))
+            p, q = random.choice(VALS), random.choice(VALS)
+            if dyadic_pq(p, q): continue
+            cls = random_row(n, p, q)
+            if random.random() < 0.5:  # a sparse list, as the rows of a hub have
+                cls = [c if c != 'M' or random.random() < 0.05 else 'O' for c in cls]
+            special = [i for i in range(n) if cls[i] != 'O'][:200]
+            picks = sorted(set(random.sample(range(n), 48) + special))
+            bb = {'R': 1.0 / p, 'M': 1.0, 'O': 1.0 / q}
+            check_row(n, cls, bb, picks, True, stats)
+            rnd = [0, 0, 0]
+            check_row(n, cls, bb, picks, False, rnd)
+            STEP[0] = near_step  # the first stage on the same draws, for comparison
+            first = [0, 0, 0]
+            check_row(n, cls, bb, picks, False, first)
+            STEP[0] = near_step_exact
+            for i in range(3): stats[i] += rnd[i]
+            random_draws = [a + b for a, b in zip(globals().get("random_draws", [0, 0, 0, 0]), rnd + [first[1]])]
+            k += 1; rows += 1
+        print("random r2 only: draws", random_draws[0], "left to the replay by the second stage", random_draws[1],
+              "(by the first stage, counts + n^2 margin:", random_draws[3], ") bad", random_draws[2])
+    else:
+        trials = int(os.environ.get("N2V_MODEL_TRIALS", 3000 if not big else 150))
+        while rows < trials:
+            n = random.randint(200, 2500) if big else random.randint(1, 70)
+            p, q = random.choice(VALS), random.choice(VALS)
+            if dyadic_pq(p, q): continue  # (dyadic: the other forms)
+            cls = random_row(n, p, q)
+            check_row(n, cls, {'R': 1.0 / p, 'M': 1.0, 'O': 1.0 / q},
+                      range(n) if not big else random.sample(range(n), 60), False, stats)
+            rows += 1
+    print("rows", rows)
+    print("total", stats[0], "ambiguous", stats[1], "bad", stats[2])
+    sys.exit(1 if stats[2] else 0)

@@ -18,6 +18,28 @@ EPS = 2.220446049250313e-16
 UNDECIDED = -2
 
 
+EXACT_DELTA = 8.0 * EPS
+
+
+def general_margins(n, kfac=1.0):
+    """(delta, M) for any weights and any p, q: probs are known to delta (relative), sums of up to n of them to M"""
+    nn = float(n)
+    return kfac * (2.0 * nn + 16.0) * EPS, kfac * 16.0 * nn * nn * EPS
+
+
+def class_factor_spread(factors):
+    """kfac of general_margins when the row sum is taken from three terms (stored row sum, shared, return)"""
+    cq, c1, cp = factors
+    return 1.0 + 2.0 * max(cq, cp, 1.0) / min(cq, cp, 1.0)
+
+
+def exact_sum_margin(n, max_prob, tot_d):
+    """M when the row sum is the reference's bit for bit (+ 64: a block summary is the difference of two sums of
+    up to 256 weights)"""
+    nn = float(n)
+    return 8.0 * EPS * (nn * (max_prob + 12.0 + 64.0) + (nn / 256.0 + 16.0) * (4.0 * tot_d + 4.0))
+
+
 def crossing(vals, target):
     """first slot from the TOP whose running sum (descending position) reaches target: (slot, before, at, whole)"""
     run = np.cumsum(vals[::-1])  # run[t] = sum of vals[n - 1 - t ..]
@@ -48,18 +70,17 @@ def margin_draw(b, pick, r2, rng=None, w=None, cls=None, factors=None, exact_tot
         ss = float(np.sum(w[cls == 1]))
         sr = float(np.sum(w[cls == 2]))
         total = cq * row_sum + (1.0 - cq) * ss + (cp - cq) * sr
-        kfac = 1.0 + 2.0 * max(cq, cp, 1.0) / min(cq, cp, 1.0)
+        kfac = class_factor_spread(factors)
     if not (total > 0.0):
         return UNDECIDED
     nn = float(n)
     inv = nn / total
-    delta = kfac * (2.0 * nn + 16.0) * EPS
-    M = kfac * 16.0 * nn * nn * EPS
+    delta, M = general_margins(n, kfac)
     if exact_total:
         # every addend a multiple of one power of two and the sum below 2^52 of them: the reference's
         # left-to-right sum rounds nowhere and is THIS sum; what is left are the roundings of the loop
         # (2 per pairing, at most max(probs) + 1 in size) and of the sums taken here
-        delta = 8.0 * EPS
+        delta = EXACT_DELTA
     p_pick = b[pick] * inv
     under = p_pick < 1.0 - 2.0 * delta
     if not under and not (p_pick > 1.0 + 2.0 * delta):
@@ -100,8 +121,8 @@ def margin_draw(b, pick, r2, rng=None, w=None, cls=None, factors=None, exact_tot
         part = slice(bp * 256, pick)
         below_d = float(np.sum(blk_d[:bp]) + np.sum(np.maximum(-xo[part], 0.0)) + np.sum(corr_d[:pick]))
         below_x = float(np.sum(blk_x[:bp]) + np.sum(xo[part]) + np.sum(corr_x[:pick]))
-    if exact_total:  # (+ 64: a block summary is the difference of two sums of up to 256 weights)
-        M = 8.0 * EPS * (nn * (float(np.max(b)) * inv + 12.0 + 64.0) + (nn / 256.0 + 16.0) * (4.0 * tot_d + 4.0))
+    if exact_total:
+        M = exact_sum_margin(n, float(np.max(b)) * inv, tot_d)
 
     def next_over_below(top):  # the first slot below `top` that is overfull, every slot skipped underfull
         for t in range(top - 1, -1, -1):

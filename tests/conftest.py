@@ -21,7 +21,7 @@ def pytest_configure(config):
 # reference's golden vectors and the oracle come first, then the API / edge-case / multi-rank
 # tests, then the full-size property tests, and the statistical tests (chi-square, hogwild
 # quality) last -- a statistical tolerance must never hide a deterministic parity test.
-_ORDER = ["test_walk_gpu", "test_transformers_gpu", "test_wedge_gpu", "test_weighted_lanes_gpu", "test_alias_trim_fast_gpu",
+_ORDER = ["test_walk_gpu", "test_transformers_gpu", "test_wedge_gpu", "test_weighted_lanes_gpu", "test_margin_adversary_gpu", "test_alias_trim_fast_gpu",
           "test_sgns_gpu", "test_sgns_window_gpu", "test_edge_cases_gpu", "test_api_gpu",
           "test_indexer_gpu", "test_partitioned_gpu", "test_delta_sync_gpu", "test_multirank_gpu",
           "test_scale_props_gpu", "test_scale_cfg345_gpu", "test_sgns_model_size_gpu", "test_fast_unit_gpu",

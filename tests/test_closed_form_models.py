@@ -88,3 +88,41 @@ def test_layered_sampler_model_gives_every_slot_its_weight():
     last = res.stdout.strip().splitlines()[-1]
     assert last.startswith("total") and last.endswith(" 0 bad") and int(last.split()[1]) == 3000
 
+
+def _adversary(what, n_max, per, seed):
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "models", "margin_adversary.py"), what,
+                          str(n_max), str(per), str(seed)], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "WRONG" not in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
+    last = res.stdout.strip().splitlines()[-1].split()
+    assert last[0] == "total" and last[-2:] == ["bad", "0"], res.stdout[-500:]
+    return res.stdout, int(last[1]), int(last[3])
+
+
+def test_closed_forms_with_margins_on_rows_placed_at_the_margin_by_exact_arithmetic():
+    """margin_adversary.py near (round 6): the reference's loop run in exact rational arithmetic
+    on a row, q moved until the iteration nearest to a tie -- X_i - k D of DESIGN.md 5 -- sits at +-{0.01, 0.05, 0.25,
+    0.5, 0.9, 1.1, 2, 10} x the margin of the counts stage (5e-15 n (n + 8) vmax) or of the exact-sum stage
+    (2e-14 n (vmax + 1)), rows of 8 ... 10^4 slots in all five class arrangements.  Both stages as the kernel chains
+    them: a decided draw is the reference's fp64 loop's (generate_alias_tables, randomwalk.py:172-189); and outside the
+    smaller margin the placed slots ARE decided (the procedure is not vacuous).  Rows of 10^5 slots:
+    profiles/r6c_margin_adversary_near.log."""
+    out, draws, rows = _adversary("near", 10_000, 1, 11)
+    assert draws > 40_000 and rows > 400
+    inside = [float(l.split("declined")[1].split()[0]) for l in out.splitlines() if "margin ~n  " in l and
+              any(f"x {t:5.2f}:" in l for t in (0.25, 0.5, 0.9))]
+    outside = [float(l.split("declined")[1].split()[0]) for l in out.splitlines() if "margin ~n  " in l and
+               any(f"x {t:5.2f}:" in l for t in (1.1, 2.0, 10.0))]
+    assert len(inside) == 3 and len(outside) == 3 and min(inside) > 0.3 and max(outside) < 0.2, (inside, outside)
+
+
+def test_weighted_decision_on_rows_placed_at_the_margin_by_exact_arithmetic():
+    """margin_adversary.py weighted: the stored weight of one slot moved (on the fp32 grid where the row is to keep an
+    exact row sum) until the crossing E_k - D_j, or probs[pick] - 1, sits at the same multiples of the general margins
+    (kfac 16 n^2 2^-52; 2 delta) or of the margins of an exact sum (linear in n); fp32, fp64, 24-decade rows, and
+    integer rows whose sums tie exactly.  Long rows go through the model of the block summaries."""
+    out, draws, rows = _adversary("weighted", 10_000, 1, 12)
+    assert draws > 25_000 and rows > 200
+    sharp = [l for l in out.splitlines() if "crossing exact-sum" in l]
+    inside = [float(l.split("declined")[1].split()[0]) for l in sharp if any(f"x {t:5.2f}:" in l for t in (0.25, 0.5, 0.9))]
+    outside = [float(l.split("declined")[1].split()[0]) for l in sharp if any(f"x {t:5.2f}:" in l for t in (1.1, 2.0, 10.0))]
+    assert len(inside) == 3 and len(outside) == 3 and min(inside) > 0.2 and max(outside) < 0.1, (inside, outside)
