@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- node2vec hot path on MI355X: walk-steps/s + embedding-updates/s.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg4|cfg3|cfg2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg4|cfg3|cfg2|cfg5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Default workload = the configuration BASELINE.json's metric is quoted on ("100M-node
@@ -51,6 +51,12 @@ CONFIGS = {
                  batch=1 << 20, biased_batch=1 << 20, sgns_vertices=1 << 16, dim=128,
                  label="cfg3 Chung-Lu power-law gamma=2.1, 10M vertices / 1e8 undirected draws "
                        "symmetrised, out-degree trimmed at 10000"),
+    # BASELINE.json configs[4]: 5 000 hubs x 10 000 distinct leaves + one hub
+    # per leaf (hub degree ~20 000 before the trim), p = 4, q = 0.25, dim 256 (model 2 x 51.2 GB)
+    "cfg5": dict(gen="hub_bipartite", n=50_000_000, hubs=5_000, hub_degree=10_000, trim=10_000, p=4.0, q=0.25,
+                 batch=1 << 20, biased_batch=1 << 20, sgns_vertices=1 << 16, dim=256,
+                 label="cfg5 skewed bipartite, 50M vertices, 5000 hubs x 10000 leaves + one hub per leaf, "
+                       "out-degree trimmed at 10000"),
     "cfg2": dict(gen="rmat", scale=20, draws=5_000_000, trim=0, p=0.5, q=2.0,
                  batch=47_104, biased_batch=47_104, sgns_vertices=47_104, dim=128,
                  label="cfg2 R-MAT scale 20, 5e6 draws symmetrised"),
@@ -85,6 +91,8 @@ def parse(argv=None):
                     help="skip the legs on the graph trimmed at the reference's default cap (100 000)")
     ap.add_argument("--no-weighted", action="store_true",
                     help="skip the leg on the WEIGHTED cfg 2 graph (exact walks at (0.5, 2), every start vertex)")
+    ap.add_argument("--no-api", action="store_true",
+                    help="skip the API leg (random_walk() -> DataFrame -> Node2VecGensim.fit() -> embedding() on cfg 2)")
     ap.add_argument("--no-audition", action="store_true",
                     help="take the first output buffer the allocator hands out (no placement audition)")
     ap.add_argument("--spawn", action="store_true",
@@ -140,6 +148,8 @@ def build_graph(cfg, torch, dev, setup, trim=-1):
     t0 = time.perf_counter()
     if cfg["gen"] == "rmat":
         g = synthetic.rmat(cfg["scale"], cfg["draws"], seed=42, device=dev)
+    elif cfg["gen"] == "hub_bipartite":
+        g = synthetic.hub_bipartite(cfg["n"], cfg["hubs"], cfg["hub_degree"], seed=42, device=dev)
     else:
         g = synthetic.chung_lu(cfg["n"], cfg["draws"], seed=42, device=dev)
     torch.cuda.synchronize()
@@ -384,16 +394,26 @@ def main():
                    "seed": 42, "num_walks": W,
                    "walk_length": L, "start_vertices_per_step_per_gpu": leg.batch,
                    "walk_mode": "exact", "n_vertices": g.n_vertices,
-                   "walk_ids": ("degree ranks (fit_streaming's launch); vertex ids out: value_vertex_ids"
-                                if in_ranks else "vertex ids"),
+                   "walk_ids": ("vertex ids (what random_walk() returns); the launch fit_streaming makes, degree "
+                                "ranks out: value_pipeline" if in_ranks else "vertex ids"),
                    "n_edges": g.n_edges, "start_vertices": int(start_all.numel()),
                    "trim_cap": setup["trim_cap"], "max_out_degree": setup["max_out_degree"],
                    "parallelism": f"graph replicated, start vertices range-sharded x{world}"},
     }
     if rank == 0:
         out["roofline"] = roofline(head_kernel, res, leg, args.config, p, q, "exact", ref_bytes)
-        if vertex_leg is not None:
-            out["vertex_id_output"] = vertex_leg
+    if in_ranks:
+        # `value` is what the reference's contract returns -- walks as VERTEX IDS (fugue.py:153-155,
+        # randomwalk.py:343-349): the hop-table launch timed first.  The launch fit_streaming makes (walks out in
+        # degree ranks, consumed by n2v_corpus_index, which folds rank -> vertex id into its vocabulary lookup) is
+        # carried beside it as value_pipeline / ms_per_step_pipeline / roofline_pipeline.
+        out["value_pipeline"], out["ms_per_step_pipeline"] = out["value"], out["ms_per_step"]
+        out["pipeline_consumer"] = ("pipeline.fit_streaming: walks in degree ranks -> n2v_corpus_count / "
+                                    "n2v_corpus_index (rank -> vocabulary index in one lookup) -> n2v_sgns_train")
+        out["value"], out["ms_per_step"] = sv / ev, 1e3 * ev / args.steps
+        if rank == 0:
+            out["roofline_pipeline"] = out["roofline"]
+            out["roofline"] = vertex_leg["roofline"]
     del leg
     torch.cuda.empty_cache()
 
@@ -483,6 +503,10 @@ def main():
         out_w = bench_weighted(args, torch, rw, dev, W, L)
         if rank == 0 and out_w:
             out["weighted"] = out_w
+
+    # ---- the API surface, end to end: random_walk() -> DataFrame -> Node2VecGensim.fit() -> embedding() on cfg 2
+    if not args.no_api and world == 1 and rank == 0:
+        out["api"] = bench_api(args, torch, rw, dev)
 
     # ---- SGNS on the config's model ------------------------------------------------------------
     model = None
@@ -584,24 +608,77 @@ def bench_weighted(args, torch, rw, dev, W, L):
     return res
 
 
+def bench_api(args, torch, rw, dev):
+    """What a user of the reference's API gets (reference fugue.py:81-155, embedding.py:120-143), on BASELINE cfg 2
+    (R-MAT scale 20, p = 0.5, q = 2, 10 walks x 80 steps from every vertex, dim 128, one epoch), wall clock of each call
+    with the device part beside it:
+        df = random_walk("hip", graph, params, random_seed=42)      kernel + D2H + the DataFrame of walks
+        model = Node2VecGensim(df, w2v_params, random_seed=7).fit() vocabulary + training (the walks come from the
+                                                                    device corpus behind the frame, not from its rows)
+        vectors = n2v.embedding()                                   D2H + the DataFrame of vectors
+    The per-edge tables of the graph are built before the clock starts (one-off, reported)."""
+    from node2vec_amd import fugue, synthetic
+    from node2vec_amd.embedding import Node2VecGensim
+
+    W, L, p, q = 10, 80, 0.5, 2.0
+    g = synthetic.rmat(20, 5_000_000, seed=42, device=dev)
+    params = {"num_walks": W, "walk_length": L, "return_param": p, "inout_param": q}
+    t0 = time.perf_counter()
+    rw.walk(g, rw.start_vertices(g)[:4096].contiguous(), W, L, p, q, 1)  # builds the tables
+    torch.cuda.synchronize()
+    tables_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    walks, valid = fugue.random_walk_tensors(g, dict(params), None, 42)
+    torch.cuda.synchronize()
+    walk_device_s = time.perf_counter() - t0
+    n_rows = int(valid.sum())
+    del walks, valid
+    res = {"workload": f"cfg2 R-MAT scale 20, {g.n_vertices} vertices / {g.n_edges} edges, p={p:g} q={q:g}, "
+                       f"{W} walks x {L} steps from every vertex, dim 128, 1 epoch",
+           "rows": n_rows, "tables_s": tables_s, "random_walk_device_s": walk_device_s}
+    kinds = {}
+    for kind in ("auto", "arrow"):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        df = fugue.random_walk("hip", g, dict(params, walk_column=kind), random_seed=42)
+        t1 = time.perf_counter()
+        w2v = {"size": 128, "iter": 1, "min_count": 0, "sample": 0.0, "negative": 5, "window": 5}
+        n2v = Node2VecGensim(df, w2v, random_seed=7)
+        model = n2v.fit()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        emb = n2v.embedding()
+        t3 = time.perf_counter()
+        kinds[kind] = {"random_walk_s": t1 - t0, "fit_s": t2 - t1, "embedding_s": t3 - t2, "total_s": t3 - t0,
+                       "walk_column": str(df["walk"].dtype), "vector_rows": len(emb), "pairs": int(model.pairs_trained)}
+        steps, pairs = n_rows * L, int(model.pairs_trained)
+        del df, n2v, model, emb
+    a = kinds["auto"]
+    res.update({"random_walk_s": a["random_walk_s"], "host_conversion_s": a["random_walk_s"] - walk_device_s,
+                "fit_s": a["fit_s"], "embedding_s": a["embedding_s"], "total_s": a["total_s"],
+                "walk_steps_per_s": steps / a["random_walk_s"], "pairs_per_s": pairs / a["fit_s"],
+                "walk_column_default": "one read-only ndarray view per row beyond 2^22 vertices (corpus.list_column); "
+                                       "Python lists of Python ints as in the reference: n2v_params['walk_column'] = "
+                                       "'list' (3.8e8 int objects here: ~14 GB, not timed)",
+                "with_arrow_backed_columns": kinds["arrow"],
+                "note": "the walk kernel is %.0f %% of random_walk(): the rest is the D2H copy and the Python objects "
+                        "of the DataFrame the reference's API returns" % (100.0 * walk_device_s / a["random_walk_s"])})
+    del g
+    torch.cuda.empty_cache()
+    return res
+
+
 def ordered_line(out):
     """The ONE line, ordered for its readers: the contract's keys first; the bulky sub-objects
     (setup, sgns, fast_mode, the regimes) in the middle; at the END -- the part of a long line
-    that a record keeping only a tail of stdout retains -- the exact biased leg, the two rooflines
-    of the headline (ranks out = what fit_streaming launches; vertex ids out = what random_walk()
-    returns, reference fugue.py:153-155), the CPU baseline and a compact summary of every leg."""
+    that a record keeping only a tail of stdout retains -- the API leg, the exact biased leg, the rooflines
+    of the headline (`roofline`: vertex ids out, what random_walk() returns, reference fugue.py:153-155;
+    `roofline_pipeline`: ranks out, what fit_streaming launches), the CPU baseline and a compact summary of
+    every leg."""
     head = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
             "scaling", "vs_baseline", "dtype", "data", "config"]
-    tail = ["biased", "cpu_baseline", "roofline", "value_vertex_ids", "ms_per_step_vertex_ids",
-            "roofline_vertex_ids", "summary"]
-    vleg = out.pop("vertex_id_output", None)
-    if vleg is not None:
-        out["value_vertex_ids"] = vleg["value"]
-        out["ms_per_step_vertex_ids"] = vleg["ms_per_step"]
-        out["roofline_vertex_ids"] = vleg["roofline"]
-    elif "roofline" in out:  # the headline launch itself writes vertex ids
-        out["value_vertex_ids"] = out["value"]
-        out["ms_per_step_vertex_ids"] = out["ms_per_step"]
+    tail = ["api", "biased", "cpu_baseline", "roofline_pipeline", "value_pipeline", "ms_per_step_pipeline",
+            "pipeline_consumer", "roofline", "summary"]
 
     def frac(o):
         return None if not o or "roofline" not in o else round(o["roofline"]["frac"], 4)
@@ -610,16 +687,16 @@ def ordered_line(out):
     cpu = out.get("cpu_baseline") or {}
     out["summary"] = {
         "walk_steps_per_s": {
-            "exact_pq1_ranks_out": out["value"], "exact_pq1_vertex_ids_out": out.get("value_vertex_ids"),
+            "headline_vertex_ids_out": out["value"], "pq1_ranks_out_pipeline": out.get("value_pipeline"),
             "exact_biased_0.5_2": (out.get("biased") or {}).get("value"),
             **{"exact_%g_%g" % (r["p"], r["q"]): r["value"] for r in out.get("biased_other_regimes", [])},
             "fast_0.5_2": (out.get("fast_mode") or {}).get("value"),
             "weighted_cfg2_exact_0.5_2": (out.get("weighted") or {}).get("value"),
             "trim_cap_100000_exact_pq1_ranks_out": ((out.get("reference_trim_cap") or {}).get("exact_pq1_ranks_out") or {}).get("value"),
             "trim_cap_100000_exact_biased_0.5_2": ((out.get("reference_trim_cap") or {}).get("exact_biased_0.5_2") or {}).get("value")},
-        "walk_roofline_frac": {"exact_pq1_ranks_out": frac(out),
-                               "exact_pq1_vertex_ids_out": None if "roofline_vertex_ids" not in out
-                               else round(out["roofline_vertex_ids"]["frac"], 4),
+        "walk_roofline_frac": {"headline_vertex_ids_out": frac(out),
+                               "pq1_ranks_out_pipeline": None if "roofline_pipeline" not in out
+                               else round(out["roofline_pipeline"]["frac"], 4),
                                "exact_biased_0.5_2": frac(out.get("biased")), "fast_0.5_2": frac(out.get("fast_mode"))},
         "sgns_pairs_per_s": {"per_pair_default": sg.get("value"),
                              "per_pair_plain_stores": (sg.get("plain_stores") or {}).get("value"),
@@ -628,6 +705,8 @@ def ordered_line(out):
         "sgns_exchange_world": (sg.get("exchange") or {}).get("world"),
         "cpu_port": {"walk_steps_per_s": cpu.get("value"), "sgns_pairs_per_s": (cpu.get("sgns") or {}).get("value"),
                      "cores": cpu.get("cores")},
+        "api_cfg2": None if "api" not in out else {k: out["api"].get(k) for k in (
+            "random_walk_s", "random_walk_device_s", "fit_s", "embedding_s", "total_s", "walk_steps_per_s", "pairs_per_s")},
         "hbm_peak_allocated_GB": (out.get("setup") or {}).get("hbm_peak_allocated_GB")}
     keys = head + [k for k in out if k not in head and k not in tail] + [k for k in tail if k in out]
     return {k: out[k] for k in keys if k in out}

@@ -21,7 +21,81 @@ import weakref
 from typing import Optional
 
 import numpy as np
+import pandas as pd
+import pyarrow as pa
 import torch
+
+# Large results.  A Python list per row of Python ints per vertex is what the reference's frame holds, and at BASELINE
+# cfg 2 (4.7 M walks of 81 vertices) that is 3.8 x 10^8 int objects: 14 GB and ~20 s of `ndarray.tolist()` behind a
+# 40 ms kernel.  Beyond LIST_COLUMN_MAX_VALUES values the column therefore holds one READ-ONLY ndarray VIEW per row into
+# the one host buffer of the D2H copy ("rows": 2 s, 0.5 GB at cfg 2) -- what pandas.read_parquet gives for a list
+# column anyway.  `np.array(col.tolist())` (the reference's consumer, embedding.py:125), iteration, len(), indexing and
+# to_parquet (schema randomwalk.py:342) work as on lists; an edit inside a row raises (read-only), a replaced row is
+# another object: the device corpus behind the frame stays valid exactly while every row is the original object.
+# "arrow": an Arrow-backed list<int32> column over the same buffer, O(1) to build and immutable; opt-in, because
+# pandas < 3 cannot read back the parquet file it writes from such a column (its own dtype string in the metadata).
+LIST_COLUMN_MAX_VALUES = 1 << 22  # rows x length up to which random_walk() / embedding() build Python lists
+LIST_COLUMN_KINDS = ("auto", "list", "rows", "arrow")
+
+
+def list_column(values: np.ndarray, kind: str = "auto"):
+    """[n, k] numpy -> the column of n rows.  kind "list": Python lists (ndarray.tolist(), one C call); "rows": an
+    object array of read-only ndarray views; "arrow": pandas ArrowExtensionArray over the flat buffer; "auto": lists
+    up to LIST_COLUMN_MAX_VALUES values, rows beyond."""
+    if kind not in LIST_COLUMN_KINDS:
+        raise ValueError(f"list column kind {kind!r}: " + " | ".join(LIST_COLUMN_KINDS))
+    n, k = values.shape
+    if kind == "auto":
+        kind = "list" if n * k <= LIST_COLUMN_MAX_VALUES else "rows"
+    if kind == "list":
+        return values.tolist()
+    values = np.ascontiguousarray(values)
+    if kind == "rows":
+        values.setflags(write=False)  # (the views inherit it)
+        rows = np.empty(n, dtype=object)
+        rows[:] = list(values)
+        return rows
+    flat = pa.array(values.reshape(-1))
+    if (n + 1) * k < 2 ** 31:
+        arr = pa.ListArray.from_arrays(pa.array(np.arange(0, (n + 1) * k, k, dtype=np.int32)), flat)
+    else:
+        arr = pa.LargeListArray.from_arrays(pa.array(np.arange(0, (n + 1) * k, k, dtype=np.int64)), flat)
+    return pd.arrays.ArrowExtensionArray(arr)
+
+
+def arrow_rows(col) -> Optional[np.ndarray]:
+    """an Arrow-backed list column of equal-length rows as a [n, k] numpy array without touching Python objects;
+    None when the column is not Arrow-backed or ragged"""
+    if not isinstance(getattr(col, "dtype", None), pd.ArrowDtype):
+        return None
+    arr = pa.chunked_array(col.array.__arrow_array__()).combine_chunks()
+    if not (pa.types.is_list(arr.type) or pa.types.is_large_list(arr.type) or pa.types.is_fixed_size_list(arr.type)):
+        return None
+    n = len(arr)
+    if arr.null_count or n == 0:
+        return None
+    flat = arr.flatten().to_numpy(zero_copy_only=False)
+    if flat.shape[0] % n:
+        return None
+    k = flat.shape[0] // n
+    if not pa.types.is_fixed_size_list(arr.type):
+        off = arr.offsets.to_numpy()
+        if not np.array_equal(off - off[0], np.arange(n + 1, dtype=off.dtype) * k):
+            return None
+    return flat.reshape(n, k)
+
+
+def _arrow_identity(col):
+    """(address, offset, length) of the value buffer of every chunk of an Arrow-backed column, or None"""
+    if not isinstance(getattr(col, "dtype", None), pd.ArrowDtype):
+        return None
+    chunks = pa.chunked_array(col.array.__arrow_array__()).chunks
+    out = []
+    for c in chunks:
+        if not (pa.types.is_list(c.type) or pa.types.is_large_list(c.type)):
+            return None
+        out.append((c.values.buffers()[1].address, c.offset, len(c), c.offsets.buffers()[1].address))
+    return tuple(out)
 
 ATTR = "n2v_device_walks"
 _tokens = itertools.count(1)
@@ -35,6 +109,14 @@ def _row_ids(col) -> np.ndarray:
 
 def attach(frame, walks: torch.Tensor) -> None:
     token = next(_tokens)
+    ident = _arrow_identity(frame["walk"])
+    if ident is not None:
+        # Arrow-backed column: immutable, so "the same buffers at the same offsets" IS "unchanged"; the registry keeps
+        # the array alive, so the addresses cannot be reused while the entry lives
+        _registry[token] = (weakref.ref(frame), walks, ident, frame["walk"].array)
+        weakref.finalize(frame, _registry.pop, token, None)
+        frame.attrs[ATTR] = token
+        return
     rows = frame["walk"].to_numpy()
     # (the row objects themselves are kept: CPython reuses the address of a freed list, so bare ids
     # could match a row that was dropped and replaced)
@@ -55,6 +137,10 @@ def lookup(frame) -> Optional[torch.Tensor]:
     if n != len(frame) or n == 0 or "walk" not in frame.columns:
         return None
     col = frame["walk"]
+    if isinstance(entry[2], tuple):  # Arrow-backed: the column must still be the very buffers random_walk() made
+        return walks if _arrow_identity(col) == entry[2] else None
+    if isinstance(col.dtype, pd.ArrowDtype):
+        return None
     if not np.array_equal(_row_ids(col), entry[2]):  # some row is no longer the original object
         return None
     if STRICT:

@@ -23,7 +23,7 @@ import numpy as np
 import pandas as pd
 import torch
 
-from node2vec_amd import sgns
+from node2vec_amd import corpus, sgns
 from node2vec_amd.constants import GENSIM_PARAMS, HIP_SGNS_PARAMS
 
 
@@ -258,6 +258,9 @@ class Node2VecHIP(Node2VecBase):
         dev_walks = corpus.lookup(self.walks)  # the frame random_walk() returned, unchanged
         if dev_walks is not None:
             return dev_walks.to(device=device, dtype=torch.int32)
+        arr = corpus.arrow_rows(self.walks["walk"])  # an Arrow-backed column: no Python object per vertex
+        if arr is not None:
+            return torch.from_numpy(np.array(arr, dtype=np.int32)).to(device)  # (a copy: the Arrow buffer is read-only)
         # embedding.py:125 requires equal-length walks (np.array(walks.tolist()))
         arr = np.array(self.walks["walk"].tolist())
         if arr.ndim != 2:
@@ -328,9 +331,13 @@ class Node2VecHIP(Node2VecBase):
         return self.model
 
     # -- results ------------------------------------------------------------------
-    def iter_embedding(self, chunk_rows: int = 1 << 18):
+    def iter_embedding(self, chunk_rows: int = 1 << 18, vector_column: str = "auto"):
         """embedding() in chunks of `chunk_rows` rows: DataFrames ["id" | "name", "vector"] of the
-        reference's shape, made without ever holding the whole model as Python objects"""
+        reference's shape, made without ever holding the whole model as Python objects.  `vector_column`:
+        "list" = Python lists of floats, "rows" = one read-only ndarray view per row, "arrow" = an Arrow-backed
+        list<float> column, "auto" = lists up to corpus.LIST_COLUMN_MAX_VALUES values per chunk, rows beyond
+        (corpus.list_column)"""
+        from node2vec_amd import corpus
         if self.model is None:
             raise ValueError("Model is not available. Please run fit()")
         wv = self.model.wv
@@ -345,7 +352,7 @@ class Node2VecHIP(Node2VecBase):
                 ids = wv.ids[lo:hi]
             else:
                 ids = np.array([int(t) for t in wv.index2word[lo:hi]], dtype=np.int64)
-            vectors = wv.rows(lo, hi).tolist()
+            vectors = corpus.list_column(wv.rows(lo, hi), vector_column)
             if names is not None:
                 missing = ~pd.Index(ids).isin(names.index)
                 if missing.any():
@@ -363,7 +370,8 @@ class Node2VecHIP(Node2VecBase):
         if len(wv) * max(wv.vector_size, 1) >= 2 ** 31:
             raise MemoryError(f"embedding(): {len(wv)} x {wv.vector_size} values as Python lists do "
                               "not fit a DataFrame; use iter_embedding(chunk_rows) or model.wv.rows()")
-        parts = list(self.iter_embedding())
+        big = len(wv) * max(wv.vector_size, 1) > corpus.LIST_COLUMN_MAX_VALUES
+        parts = list(self.iter_embedding(len(wv) if big else 1 << 18, str(self.w2v_params.get("vector_column", "auto"))))
         if not parts:
             return pd.DataFrame({("name" if self.name_id is not None else "id"): [], "vector": []})
         return parts[0] if len(parts) == 1 else pd.concat(parts, ignore_index=True)

@@ -154,10 +154,13 @@ def random_walk(
     kept = walks[valid]
     w = kept.cpu().numpy()
     logging.info("random_walk(): random walking done ...")
-    # to_path, randomwalk.py:343-349: {"src": path[0], "walk": path}.  ndarray.tolist() builds
-    # the list-of-lists column in one C call (a Python loop over rows is 10x slower).
+    # to_path, randomwalk.py:343-349: {"src": path[0], "walk": path}.  Up to corpus.LIST_COLUMN_MAX_VALUES
+    # vertices the column holds Python lists (ndarray.tolist(): one C call); beyond, one read-only ndarray view
+    # per row into the D2H buffer (no Python object per vertex -- 14 GB and ~20 s at BASELINE cfg 2; what
+    # pandas.read_parquet yields for a list column).  n2v_params["walk_column"] = "list" | "rows" | "arrow"
+    # forces a form (corpus.list_column).
     df = pd.DataFrame({"src": w[:, 0].astype(np.int64) if len(w) else np.zeros(0, np.int64),
-                       "walk": w.tolist()})
+                       "walk": corpus.list_column(w, str(n2v_params.get("walk_column", "auto")))})
     # the same walks as an on-device corpus: Node2VecHIP.fit() trains from it when THIS frame
     # reaches it unchanged, instead of converting the list column back (embedding.py:125).  The
     # frame carries a plain integer token only (pandas copies / compares / serialises attrs).

@@ -529,3 +529,75 @@ def test_weighted_hub_summaries_blocks_are_sorted_with_prefix_sums(monkeypatch):
     monkeypatch.setattr(rw, "WEIGHTED_HUB_SLOTS", 10 ** 9)
     g2 = DeviceGraph.from_edges(src, dst, w, n_vertices=1000)
     assert rw.weighted_hub_summaries(g2) is None and unit.unit_weights
+
+
+def test_arrow_backed_walk_column_is_the_reference_frame_to_its_consumers(tmp_path):
+    """random_walk() beyond corpus.LIST_COLUMN_MAX_VALUES vertices: the "walk" column is list<int32> over one flat
+    buffer instead of a Python list per row.  What the reference's consumers do with the frame still works --
+    np.array(df["walk"].tolist()) (embedding.py:125), iteration, .iloc, to_parquet with the schema of
+    randomwalk.py:342 -- the device corpus is found through the (immutable) buffers, any derived or edited frame is
+    not, and Node2VecHIP reads an Arrow column without building Python objects."""
+    import numpy as np
+    import pandas as pd
+    import pyarrow.parquet as pq
+    import torch
+
+    from node2vec_amd import corpus
+    from node2vec_amd.embedding import Node2VecHIP
+
+    w = torch.randint(0, 50, (300, 7), generator=torch.Generator().manual_seed(8), dtype=torch.int32)
+    assert isinstance(corpus.list_column(w.numpy(), "auto"), list)  # small: Python lists, as before
+    with pytest.raises(ValueError):
+        corpus.list_column(w.numpy(), "tuples")
+    # "rows" (the default beyond LIST_COLUMN_MAX_VALUES values): one read-only ndarray view per row
+    big = np.arange(3 * (corpus.LIST_COLUMN_MAX_VALUES // 2), dtype=np.int32).reshape(-1, 3)
+    auto = corpus.list_column(big, "auto")
+    assert isinstance(auto, np.ndarray) and auto.dtype == object and auto[7].base is not None and not auto[7].flags.writeable
+    del big, auto
+    rdf = pd.DataFrame({"src": w[:, 0].numpy().astype("int64"), "walk": corpus.list_column(w.numpy().copy(), "rows")})
+    corpus.attach(rdf, w)
+    assert corpus.lookup(rdf) is w
+    assert np.array_equal(np.array(rdf["walk"].tolist()), w.numpy()) and len(rdf["walk"].iloc[0]) == 7
+    assert all(r[0] == s for s, r in zip(rdf["src"], rdf["walk"]))
+    with pytest.raises(ValueError):
+        rdf.at[5, "walk"][2] += 1  # an edit INSIDE a row is refused: the views are read-only
+    rdf.to_parquet(tmp_path / "rows.parquet")
+    rback = pd.read_parquet(tmp_path / "rows.parquet")  # (round trip through pandas: ndarray rows again)
+    assert np.array_equal(np.stack(rback["walk"].to_numpy()), w.numpy()) and corpus.lookup(rback) is None
+    col = rdf["walk"].to_numpy().copy()
+    col[9] = np.array(col[9])  # same contents, another object
+    rdf["walk"] = col
+    assert corpus.lookup(rdf) is None
+    col = corpus.list_column(w.numpy(), "arrow")
+    df = pd.DataFrame({"src": w[:, 0].numpy().astype("int64"), "walk": col})
+    corpus.attach(df, w)
+    assert corpus.lookup(df) is w
+    assert df["walk"].iloc[3] == w[3].tolist() and isinstance(df["walk"].iloc[3], list)
+    assert np.array_equal(np.array(df["walk"].tolist()), w.numpy())  # embedding.py:125
+    assert [list(r) for r in df["walk"]][:2] == w[:2].tolist()
+    assert np.array_equal(corpus.arrow_rows(df["walk"]), w.numpy())
+    df.to_parquet(tmp_path / "walks.parquet")
+    assert str(pq.read_schema(tmp_path / "walks.parquet").field("walk").type) in ("list<element: int32>", "list<item: int32>")
+    # (pandas < 3 cannot read this file back itself -- it wrote its own dtype string into the metadata; pyarrow can:
+    # why "arrow" is opt-in and "rows" the default for large results)
+    back = pq.read_table(tmp_path / "walks.parquet").to_pandas(ignore_metadata=True)
+    assert corpus.lookup(back) is None and np.array_equal(np.stack(back["walk"].to_numpy()), w.numpy())
+    assert corpus.lookup(df.head(10)) is None and corpus.lookup(df[df["src"] > 10]) is None
+    assert corpus.lookup(df.copy()) is None or corpus.lookup(df.copy()) is w  # (a copy is another frame: token checked)
+    edited = df.copy()
+    edited.attrs = dict(df.attrs)
+    edited["walk"] = corpus.list_column(np.zeros((300, 7), np.int32), "arrow")
+    assert corpus.lookup(edited) is None
+    e2, w2 = pd.DataFrame({"src": w[:, 0].numpy().astype("int64"), "walk": corpus.list_column(w.numpy(), "arrow")}), w.clone()
+    corpus.attach(e2, w2)
+    e2["walk"] = e2["walk"].array.take(list(range(299, -1, -1)))  # any derived array: no longer the registered buffers
+    assert corpus.lookup(e2) is None
+    # a frame that was never attached: the trainer converts the Arrow column without Python objects
+    plain = pd.DataFrame({"src": w[:, 0].numpy().astype("int64"), "walk": corpus.list_column(w.numpy(), "arrow")})
+    t = Node2VecHIP(plain, {"size": 32, "iter": 1}, random_seed=3)._walk_tensor("cpu")
+    assert t.dtype == torch.int32 and torch.equal(t, w)
+    # ragged Arrow rows are refused by the fast path (and by the reference's np.array too)
+    import pyarrow as pa
+
+    ragged = pd.Series(pd.arrays.ArrowExtensionArray(pa.array([[1, 2], [3]], type=pa.list_(pa.int32()))))
+    assert corpus.arrow_rows(ragged) is None

@@ -231,6 +231,9 @@ def test_bench_under_torchrun_rehearses_the_rccl_exchange():
     assert len(lines) == 1, run.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["value"] > 0
+    api = out["api"]  # random_walk() -> DataFrame -> Node2VecGensim.fit() -> embedding(), wall clock per call
+    assert api["rows"] > 4_000_000 and api["random_walk_s"] > api["random_walk_device_s"] > 0
+    assert api["fit_s"] > 0 and api["embedding_s"] > 0 and api["with_arrow_backed_columns"]["pairs"] == api["with_arrow_backed_columns"]["pairs"]
     ex = out["sgns"]["exchange"]
     assert ex["world"] == 1 and ex["backend"] == "nccl (RCCL)" and ex["wire_dtype"] == "bf16"
     assert ex["tensors_on_device"] is True and ex["blocks_exchanged"] >= 2  # syn0 and syn1neg
@@ -248,7 +251,7 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
 
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--config", "cfg2",
            "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-fast", "--no-regimes", "--no-biased",
-           "--no-batched", "--no-hub"]
+           "--no-batched", "--no-hub", "--no-api"]
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -262,7 +265,7 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert ex["world"] == 1 and ex["backend"] == "nccl (RCCL)"
     assert ex["hbm_peak_allocated_GB_with_exchange_live"] > 0
     assert out["summary"]["sgns_exchange_world"] == 1
-    assert list(out)[-1] == "summary" and "value_vertex_ids" in out
+    assert list(out)[-1] == "summary" and "roofline" in out and "api" not in out
     # a rank count that contradicts --gpus is refused before anything touches the GPU
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT,
                          env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), capture_output=True,
