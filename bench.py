@@ -703,6 +703,9 @@ def ordered_line(out):
                              "batched_opt_in": (sg.get("batched") or {}).get("value")},
         "sgns_roofline_frac": {"per_pair_default": frac(sg), "batched_opt_in": frac(sg.get("batched"))},
         "sgns_exchange_world": (sg.get("exchange") or {}).get("world"),
+        "sgns_exchange_plan_world8": None if "exchange_plan_world8" not in sg else {
+            k: sg["exchange_plan_world8"][k] for k in ("hbm_bytes_per_rank", "fits", "bytes_per_link_per_direction_per_sync",
+                                                       "link_seconds_per_sync_at_peak")},
         "cpu_port": {"walk_steps_per_s": cpu.get("value"), "sgns_pairs_per_s": (cpu.get("sgns") or {}).get("value"),
                      "cores": cpu.get("cores")},
         "api_cfg2": None if "api" not in out else {k: out["api"].get(k) for k in (
@@ -1074,6 +1077,13 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist,
     if not args.no_batched and dim in (64, 128, 256):
         res["batched"] = bench_sgns_batched(args, torch, dist, model, next_block, rows, rank, barrier,
                                             use_dist, dev, dim)
+    # what ONE rank of an 8-GPU job holds and moves per exchange, from the size rules the exchange allocates by
+    # (sgns.exchange_plan; a two-rank gloo test compares them with live buffers) -- no 8-GPU box is needed to know it
+    resident = sum(t.numel() * t.element_size() for t in (g.rowptr, g.col) if t is not None)
+    res["exchange_plan_world8"] = sgns.exchange_plan([tuple(model.syn0.shape), tuple(model.syn1neg.shape)], 8, "bf16",
+                                                     resident_bytes=resident + int(30e9))
+    res["exchange_plan_world8"]["resident_note"] = ("CSR of this graph + 30 GB for the walk tables and one corpus batch "
+                                                    "(cfg 4: hop table 12.1 GB, ranked form 3.8 GB, batch + index 6.8 GB)")
     if use_dist:  # the exchange step of the multi-GPU path, timed once (blocking, bf16 deltas)
         # (at N = 1 under torch.distributed.run the same calls run on a group of one rank: the
         # RCCL path is rehearsed, the mean is of one replica)

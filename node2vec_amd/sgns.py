@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from node2vec_amd import _lib
-from node2vec_amd.shard import all_reduce, ordered_sum
+from node2vec_amd.shard import all_reduce, ordered_sum, ordered_sum_shard
 
 EXP_TABLE_SIZE = 1000
 MAX_EXP = 6
@@ -465,9 +465,14 @@ class DeltaSync:
             ref.copy_(t)
         return ref
 
+    @staticmethod
+    def block_elems(shapes, block_rows: int) -> int:
+        """elements of the largest block that goes through the exchange at once"""
+        return min(int(block_rows), max(int(sh[0]) for sh in shapes)) * max(
+            int(sh[1]) if len(sh) > 1 else 1 for sh in shapes)
+
     def _buffers(self, like):
-        n = min(self.block_rows, max(t.shape[0] for t in self.tensors)) * max(
-            t.shape[1] if t.dim() > 1 else 1 for t in self.tensors)
+        n = self.block_elems([tuple(t.shape) for t in self.tensors], self.block_rows)
         if self._before is None or self._before.numel() < n or self._before.device != like.device:
             self._before = torch.empty(n, dtype=torch.float32, device=like.device)
             self._wire = torch.empty(n, dtype=torch.float32 if self.wire == "fp32" else torch.bfloat16,
@@ -604,3 +609,49 @@ class DeltaSync:
 
 
 DeltaAllReduce = DeltaSync
+
+HBM_BYTES = 288e9          # MI355X (MI355X_MICROARCH.md)
+XGMI_LINK_GBPS = 153.0     # per link, 7 links per GPU, full mesh of 8 (the guide's figure; per direction: half)
+
+
+def exchange_plan(shapes, world: int, wire: str = "bf16", block_rows: int = 1 << 20, resident_bytes: int = 0,
+                  hbm_bytes: float = HBM_BYTES, link_GBps: float = XGMI_LINK_GBPS) -> dict:
+    """What one rank of `world` holds and moves when DeltaSync averages matrices of `shapes` (fp32): from the very
+    size rules the exchange allocates by (DeltaSync.block_elems, shard.ordered_sum_shard; a two-rank gloo test
+    compares them with the live buffers), so it can be evaluated for a world nobody can run here -- BASELINE cfg 4
+    on 8 GPUs (bench.py prints it in sgns.exchange_plan_world8).
+
+    HBM: the replicas, the bf16 reference of the wire format, the snapshot / wire block, ordered_sum's send / recv /
+    shard buffers, + `resident_bytes` (graph, walk tables, corpus batch).  Links: the all-to-all hands every peer one
+    shard of every block and the all-gather returns one: per sync, 2 x wire_bytes / world in EACH direction of EVERY
+    link of the full mesh, all links busy at once (shard.ordered_sum)."""
+    if wire not in ("fp32", "bf16"):
+        raise ValueError(f"unknown wire format {wire!r}")
+    world = int(world)
+    wb = 4 if wire == "fp32" else 2
+    elems = sum(int(np.prod(sh)) for sh in shapes)
+    model = 4 * elems
+    refs = 2 * elems if wire == "bf16" and world > 1 else 0
+    n = DeltaSync.block_elems(shapes, block_rows)
+    m = ordered_sum_shard(n, world)
+    buffers = 4 * n + wb * n
+    scratch = wb * (2 * world * m + m)
+    link = 0
+    blocks = 0
+    for sh in shapes:
+        rows, cols = int(sh[0]), (int(sh[1]) if len(sh) > 1 else 1)
+        for lo in range(0, rows, int(block_rows)):
+            nb = (min(rows, lo + int(block_rows)) - lo) * cols
+            link += 2 * wb * ordered_sum_shard(nb, world)
+            blocks += 1
+    total = model + refs + buffers + scratch + int(resident_bytes)
+    per_dir = link_GBps * 1e9 / 2.0
+    return {"world": world, "wire": wire, "block_rows": int(block_rows), "blocks_per_sync": blocks,
+            "model_bytes": model, "bf16_reference_bytes": refs, "block_buffers_bytes": buffers,
+            "ordered_sum_buffers_bytes": scratch, "resident_bytes": int(resident_bytes),
+            "hbm_bytes_per_rank": total, "hbm_share": total / hbm_bytes, "fits": total <= hbm_bytes,
+            "wire_bytes_per_rank_per_sync": wb * elems,
+            "bytes_per_link_per_direction_per_sync": 0 if world == 1 else link,
+            "links_used": max(world - 1, 0),
+            "link_seconds_per_sync_at_peak": 0.0 if world == 1 else link / per_dir,
+            "link_GBps_assumed": {"per_link": link_GBps, "per_direction": link_GBps / 2.0}}

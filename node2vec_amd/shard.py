@@ -76,6 +76,12 @@ def _rank_ordered_reduce(parts, world: int, m: int, out):
     return out
 
 
+def ordered_sum_shard(n: int, world: int) -> int:
+    """elements of the shard every rank sums in ordered_sum of an n-element tensor (the tensor is padded to
+    world shards): what crosses EVERY link, in each direction, once in the all-to-all and once in the all-gather"""
+    return -(-int(n) // max(int(world), 1))
+
+
 def ordered_sum(t, group=None, dist=None, scratch=None, force=False):
     """Sum of the 1-D tensor `t` (fp32 or bf16) over the ranks, in place, with numerics that do NOT
     depend on the collective library: the ranks exchange BYTES only -- an all-to-all hands rank r
@@ -99,7 +105,7 @@ def ordered_sum(t, group=None, dist=None, scratch=None, force=False):
     if t.dtype not in (torch.float32, torch.bfloat16) or t.dim() != 1 or not t.is_contiguous():
         raise TypeError("ordered_sum wants a contiguous 1-D float32 / bfloat16 tensor")
     n = t.numel()
-    m = -(-n // world)
+    m = ordered_sum_shard(n, world)
     bits = torch.uint8  # moved as plain bytes (every backend carries them; gloo has no 16-bit type)
     key = (t.device, t.dtype, world * m)
     buf = None if scratch is None else scratch.get(key)

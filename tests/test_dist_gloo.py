@@ -47,6 +47,23 @@ def _worker(rank, world, port, ret):
             ok = ok and torch.allclose(syn0, want0 + 2.0, atol=2 * tol)
             sync.finish()
             ok = ok and sync.syncs == 3
+            # sgns.exchange_plan (what bench.py prints for a world of 8) against the buffers an exchange really holds
+            # (rows a multiple of the block: ordered_sum keeps the buffers of the LAST block size only)
+            from node2vec_amd.sgns import exchange_plan
+
+            ok = ok and exchange_plan([(37, 8), (37, 8)], world, wire, block_rows=16)["blocks_per_sync"] * 3 == sync.exchanged_blocks
+            t2 = torch.zeros(32, 8) + rank
+            s2 = DeltaSync([t2], block_rows=16, sync_every=1, wire=wire)
+            s2.step()
+            plan = exchange_plan([(32, 8)], world, wire, block_rows=16)
+            wb = 4 if wire == "fp32" else 2
+            held = s2._before.numel() * 4 + s2._wire.numel() * wb
+            sc = sum(b.numel() * b.element_size() for bufs in s2._scratch.values() for b in bufs)
+            refs = 0 if s2.refs is None else sum(r.numel() * 2 for r in s2.refs)
+            ok = ok and plan["block_buffers_bytes"] == held and plan["ordered_sum_buffers_bytes"] == sc
+            ok = ok and plan["bf16_reference_bytes"] == refs and plan["wire_bytes_per_rank_per_sync"] == s2.wire_bytes
+            ok = ok and plan["blocks_per_sync"] == s2.exchanged_blocks == 2
+            ok = ok and plan["bytes_per_link_per_direction_per_sync"] == 2 * 2 * wb * (16 * 8 // world)
         # the sum itself (shard.ordered_sum): bytes through the backend, additions in fp32 in rank
         # order -- bit-equal to that sum spelled out locally, for both wire types, with a length
         # that does not divide by the world size; identical on every rank

@@ -601,3 +601,30 @@ def test_arrow_backed_walk_column_is_the_reference_frame_to_its_consumers(tmp_pa
 
     ragged = pd.Series(pd.arrays.ArrowExtensionArray(pa.array([[1, 2], [3]], type=pa.list_(pa.int32()))))
     assert corpus.arrow_rows(ragged) is None
+
+
+def test_exchange_plan_cfg4_on_eight_gpus_fits_and_names_its_link_bytes():
+    """Multi-GPU readiness without a multi-GPU box: BASELINE cfg 4 at world 8 -- the model of the
+    workload's own vocabulary (8.67 x 10^7 words x 128, two matrices), bf16 deltas -- from the size rules DeltaSync and
+    shard.ordered_sum allocate by (tests/test_dist_gloo.py compares the plan with the live buffers of a two-rank
+    exchange).  Per rank: replicas + bf16 reference + block buffers + the graph, its tables and a corpus batch
+    <= 288 GB; per sync every link carries 2 x wire / world in each direction."""
+    from node2vec_amd.sgns import exchange_plan
+
+    n_vocab, dim = 86_700_000, 128
+    # resident beside the model at cfg 4 (DESIGN.md 4): CSR 3.8 GB + hop table 12.1 + ranked form 3.8 + a batch of
+    # 2^20 x 10 walks of 81 tokens and its index (2 x 3.4 GB)
+    resident = int((3.8 + 12.1 + 3.8 + 6.8) * 1e9)
+    plan = exchange_plan([(n_vocab, dim), (n_vocab, dim)], 8, "bf16", resident_bytes=resident)
+    assert plan["model_bytes"] == 2 * n_vocab * dim * 4 and plan["bf16_reference_bytes"] == 2 * n_vocab * dim * 2
+    assert plan["fits"] and plan["hbm_bytes_per_rank"] < 170e9
+    wire = 2 * n_vocab * dim * 2
+    assert plan["wire_bytes_per_rank_per_sync"] == wire and plan["links_used"] == 7
+    assert abs(plan["bytes_per_link_per_direction_per_sync"] - 2 * wire / 8) < 1e-3 * wire
+    assert 0.05 < plan["link_seconds_per_sync_at_peak"] < 0.2  # ~0.15 s per exchange at the links' peak
+    fp32 = exchange_plan([(n_vocab, dim), (n_vocab, dim)], 8, "fp32", resident_bytes=resident)
+    assert fp32["bf16_reference_bytes"] == 0 and fp32["bytes_per_link_per_direction_per_sync"] == 2 * plan["bytes_per_link_per_direction_per_sync"]
+    one = exchange_plan([(n_vocab, dim)], 1)
+    assert one["bytes_per_link_per_direction_per_sync"] == 0 and one["links_used"] == 0
+    # cfg 5: 5 x 10^7 x 256
+    assert exchange_plan([(50_000_000, 256)] * 2, 8, "bf16", resident_bytes=int(20e9))["fits"]
