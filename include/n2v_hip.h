@@ -352,7 +352,9 @@ typedef struct n2v_weighted_hubs {
   const void *sorted;
   const double *prefix;
   int32_t min_slots;
-  int32_t reserved;
+  int32_t lane_cut;   /* 0 = chosen by the library from the number of walkers; > 0: rows of at least this many slots
+                       * are decided by a wave per walker, shorter ones by a lane per walker (tuning, tests).  A struct
+                       * with block0 == NULL carries this field alone. */
 } n2v_weighted_hubs;
 
 /* The sort keys of n2v_walk_weighted_step's `order`, one pass: keys[r] = rank_of[walks[r][step]] (rank_of: the

@@ -32,7 +32,7 @@ SYMBOLS = ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alia
 class WeightedHubs(C.Structure):
     """struct n2v_weighted_hubs"""
     _fields_ = [("block0", C.c_void_p), ("sorted", C.c_void_p), ("prefix", C.c_void_p),
-                ("min_slots", C.c_int32), ("reserved", C.c_int32)]
+                ("min_slots", C.c_int32), ("lane_cut", C.c_int32)]
 
 
 class Graph(C.Structure):

@@ -768,6 +768,16 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 7) void weighted_step_wave_ker
   StepCtx c;
   c.p = p;
   c.q = q;
+  // min_n < 0: `order` is a LIST with its length in front of it (order[-1]; n2v_walk_weighted_step: what the margin
+  // kernels left undecided -- nothing, as a rule).  A wave with no entry of its own leaves before it touches the shared
+  // counter: 4 096 waves taking one look each were 4 096 same-address atomics, 48 us of every step whatever the batch
+  // (profiles/r6h_kernel_stats_47k_walkers.csv).
+  if (min_n < 0) {
+    const int64_t listed = readfirstlane_i64(order[-1]);
+    const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (wave >= listed) return;
+    min_n = 0;
+  }
   for (;;) {
     uint32_t t = 0;
     if (lane == 0) t = atomicAdd(&status[1], 1u);
@@ -886,7 +896,7 @@ extern "C" int n2v_weighted_step_wave_launch(const n2v_graph *g, const int32_t *
   int64_t cap = n2v::resident_blocks((const void *)n2v::weighted_step_wave_kernel, n2v::kWavesPerBlock * 64, 0);
   // (min_n == 0: `order` is the short list of the walkers the margin kernels left undecided, -1 behind the last --
   // a full grid of waves that each take one look at it cost 0.08 ms per step)
-  if (min_n == 0 && cap > 1024) cap = 1024;
+  if (min_n <= 0 && cap > 1024) cap = 1024;
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(n2v::weighted_step_wave_kernel, dim3((unsigned)blocks), dim3(n2v::kWavesPerBlock * 64), 0,
                      (hipStream_t)stream, *g, start_ids, num_walks, order, n_rows, min_n, step, walk_length, p, q,

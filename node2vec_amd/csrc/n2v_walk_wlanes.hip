@@ -1577,6 +1577,13 @@ static int wl_launch(const n2v_graph *g, const WT *w, const int32_t *start_ids, 
 #ifndef N2V_WLANES_MARGIN_FROM
 #define N2V_WLANES_MARGIN_FROM 768
 #endif
+// small batches: the cut is n_rows / this, at least N2V_WLANES_MARGIN_FROM_MIN
+#ifndef N2V_WLANES_WALKERS_PER_CUT_SLOT
+#define N2V_WLANES_WALKERS_PER_CUT_SLOT 2048
+#endif
+#ifndef N2V_WLANES_MARGIN_FROM_MIN
+#define N2V_WLANES_MARGIN_FROM_MIN 48
+#endif
 // the rows below that: 1 = the same decision with a lane per walker (walk_weighted_lane_margin_kernel), 0 = the
 // exact lane kernel (the pairing replayed: round 5's first form)
 #ifndef N2V_WLANES_LANE_MARGINS
@@ -1706,7 +1713,17 @@ extern "C" int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_i
     // long rows first (the order is by row length, descending): a wave per walker, the pairing decided with
     // margins; scratch[0] = how many walkers it left undecided, scratch[1 ..] = those, -1 behind the last:
     // the exact wave kernel steps them
-    const int from = N2V_WLANES_MARGIN_FROM;
+    // The cut between the two: a lane pays the row (~0.45 us per slot of its longest row, serial: 340 us of every step
+    // at 768 slots whatever the batch), a wave ~700 vector instructions per walker.  A full batch (millions of walkers)
+    // is throughput-bound and best at 768 (profiles/r8k_wm_cut.log); a small one is bound by that critical path, so the
+    // cut comes down with the number of walkers (profiles/r6i_wm_cut_by_batch.log).  hubs->lane_cut > 0 overrides.
+    int from = N2V_WLANES_MARGIN_FROM;
+    if (hubs && hubs->lane_cut > 0) {
+      from = hubs->lane_cut;
+    } else {
+      const int64_t by_batch = n_rows / N2V_WLANES_WALKERS_PER_CUT_SLOT;
+      if (by_batch < from) from = by_batch < N2V_WLANES_MARGIN_FROM_MIN ? N2V_WLANES_MARGIN_FROM_MIN : (int)by_batch;
+    }
     // scratch: two lists of n_rows + 2 words each -- [0] how many, [1 ..] the rows, -1 behind the last: what the
     // first launch (row sum in any order: general margins unless the sum is exact anyway) leaves undecided, and
     // what the second (row sum in the reference's order: exact-sum margins) still does; the exact wave kernel
@@ -1716,7 +1733,7 @@ extern "C" int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_i
     hb.block0 = nullptr;
     hb.sorted = nullptr;
     hb.prefix = nullptr;
-    hb.min_slots = hb.reserved = 0;
+    hb.min_slots = hb.lane_cut = 0;
     // (the sorted weights are stored as the graph's: fp32 beside g->w, fp64 beside g->w64)
     if (hubs && hubs->block0 && hubs->sorted && hubs->prefix) hb = *hubs;
     if (hipMemsetAsync(scratch, 0xff, sizeof(int64_t) * (size_t)(2 * (n_rows + 2)), st) != hipSuccess ||
@@ -1745,7 +1762,7 @@ extern "C" int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_i
                                               K, seed, edge_state, walks, valid, status, last, row_sums, hb, st);
     if (rc != N2V_OK) return rc;
     if (hipMemsetAsync(status + 1, 0, sizeof(uint32_t), st) != hipSuccess) return N2V_ELAUNCH;
-    rc = n2v_weighted_step_wave_launch(g, start_ids, num_walks, last + 1, n_rows, 0, step, walk_length,
+    rc = n2v_weighted_step_wave_launch(g, start_ids, num_walks, last + 1, n_rows, -1, step, walk_length,
                                        return_param, inout_param, seed, edge_state, walks, valid, status, stream);
     if (rc != N2V_OK) return rc;
 #if N2V_WLANES_LANE_MARGINS

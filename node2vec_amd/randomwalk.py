@@ -241,14 +241,21 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
 
 # The step-synchronous form -- per step the sort keys, one sort and five launches: the slot a draw asks for decided
 # from sums over the row with margins (WEIGHTED_LANES_MARGINS; csrc/n2v_walk_wlanes.hip) by a wave per walker on
-# the rows of 768 slots or more and by a lane per walker on the rows below, a second chance on the reference-order
-# row sum and the exact wave kernel for what the margins leave undecided -- wins over the one-launch
-# wave-per-walker kernel from a few 10^4 walkers on (weighted cfg 2 at (0.5, 2): 47 k walkers 83 M steps/s against
-# 38 M, 471 k: 430 M against 44 M, 4.7 M: 793 M; profiles/r9u_time_wm_more.log).  Without the margins the exact
-# lane kernel (the pairing replayed) has the wave on the longest row as the tail of every step (78 ms whatever
-# the batch) and only wins from 2 M walkers on.
+# the long rows and by a lane per walker on the rows below the cut (768 slots for a full batch, down to 48 for a small
+# one: the library chooses it from the number of walkers), a second chance on the reference-order row sum and the
+# exact wave kernel for what the margins leave undecided -- wins over the one-launch wave-per-walker kernel from a
+# thousand walkers on (weighted cfg 2 at (0.5, 2), round 6: 1 000 walkers 9.6 M steps/s against 4.2 M, 10 k: 69.5 M
+# against 25.6 M, 47 k: 202 M against 38 M, 471 k: 490 M against 44 M, 4.7 M: 826 M; profiles/r6j_wm_small_batches.log).
+# Without the margins the exact lane kernel (the pairing replayed) has the wave on the longest row as the tail of
+# every step (78 ms whatever the batch) and only wins from 2 M walkers on.
 WEIGHTED_LANES_MARGINS = True
-WEIGHTED_LANES_MIN_WALKERS = 1 << 15
+WEIGHTED_LANES_MIN_WALKERS = 1 << 9
+# capture steps 1 .. L - 1 of a call into one hipGraph (below).  OFF: measured in round 6 and slower at every batch
+# size (profiles/r6g_time_weighted_graph.log: 10 k walkers 37.8 -> 41.2 ms, 471 k 83.0 -> 89.3 ms, same walks) -- the
+# ~0.47 ms a step takes whatever the batch is spent ON THE GPU, in a dozen dependent stream operations (the sort's
+# passes, three memsets, four persistent launches), not in issuing them; capture + instantiation add 4 - 6 ms.
+WEIGHTED_LANES_GRAPH = False
+WEIGHTED_LANES_GRAPH_MAX_WALKERS = 1 << 22
 
 
 def weighted_lanes_tables(graph: DeviceGraph, insist: bool = False) -> bool:
@@ -291,6 +298,7 @@ def weighted_row_sums(graph: DeviceGraph) -> Optional[torch.Tensor]:
 
 
 WEIGHTED_HUB_SLOTS = 768  # rows of at least this many slots get block summaries (weighted_hub_summaries)
+WEIGHTED_LANE_CUT = 0     # > 0: n2v_weighted_hubs.lane_cut (rows from this many slots on: a wave per walker)
 
 
 def weighted_hub_summaries(graph: DeviceGraph):
@@ -382,13 +390,16 @@ def _walk_weighted_lanes(graph: DeviceGraph, start_ids: torch.Tensor, num_walks:
     hubs = weighted_hub_summaries(graph) if row_sums is not None and WEIGHTED_HUB_SLOTS > 0 else None
     import ctypes as C
 
+    if WEIGHTED_LANE_CUT > 0:  # (tuning / tests: the library chooses the cut from the batch otherwise)
+        hubs = (_lib.WeightedHubs(0, 0, 0, 0, int(WEIGHTED_LANE_CUT)) if hubs is None else
+                _lib.WeightedHubs(hubs.block0, hubs.sorted, hubs.prefix, hubs.min_slots, int(WEIGHTED_LANE_CUT)))
     hubs_ref = C.byref(hubs) if hubs is not None else None
     undecided = torch.zeros(2, dtype=torch.int64, device=dev)  # second chances; left to the exact kernel
     key = torch.empty(total, dtype=torch.int32, device=dev)
     g = graph.c_struct()
-    with torch.cuda.device(dev):
+    def steps(first: int, last: int):
         stream = _lib.current_stream_ptr()
-        for step in range(Lw):
+        for step in range(first, last):
             # (vanished walkers last; they are skipped)
             _lib.check(L.n2v_walk_weighted_keys(walks.data_ptr(), valid.data_ptr(), rank_of.data_ptr(),
                                                 graph.n_vertices, total, step, Lw, key.data_ptr(), stream),
@@ -401,7 +412,31 @@ def _walk_weighted_lanes(graph: DeviceGraph, start_ids: torch.Tensor, num_walks:
                                                 0 if row_sums is None else row_sums.data_ptr(), hubs_ref, stream),
                        "n2v_walk_weighted_step")
             if scratch is not None and stats is not None:
-                undecided += scratch[0::total + 2]
+                undecided.add_(scratch[0::total + 2])
+
+    with torch.cuda.device(dev):
+        # A step is ~12 stream operations (keys, the sort, three memsets, four kernels, the counters); nothing in it
+        # reads anything on the host, so steps 1 .. L - 1 CAN be captured into one hipGraph and replayed
+        # (WEIGHTED_LANES_GRAPH; same walks, tested) -- it does not pay: see the flag.
+        graphed = False
+        if WEIGHTED_LANES_GRAPH and Lw > 2 and total <= WEIGHTED_LANES_GRAPH_MAX_WALKERS:
+            steps(0, 1)  # eager: also the warm-up of everything a capture may not do for the first time
+            try:
+                cg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(cg):
+                    steps(1, Lw)
+                cg.replay()
+                graphed = True
+            except RuntimeError:  # (a capture that fails has executed nothing: the steps run eagerly below)
+                graphed = False
+            if not graphed:
+                steps(1, Lw)
+            else:
+                del cg
+        else:
+            steps(0, Lw)
+        if stats is not None:
+            stats["graph"] = graphed
     if check:
         _lib.check_status_word(int(status[0].item()), "n2v_walk")
     if stats is not None:
