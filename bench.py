@@ -584,6 +584,17 @@ def bench_weighted(args, torch, rw, dev, W, L):
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     steps = int(valid.sum()) * L
+    # small batches (a partition of a Fugue job, a serving call): the same call on 4 710 and 47 104 start vertices
+    small = {}
+    for nb in (4_710, 47_104):
+        bt = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, v2 = rw.walk(g, start[:nb].contiguous(), W, L, BIASED_PQ[0], BIASED_PQ[1], 42)
+            torch.cuda.synchronize()
+            bt = time.perf_counter() - t0 if bt is None else min(bt, time.perf_counter() - t0)
+        small[f"{nb * W}_walkers"] = {"value": int(v2.sum()) * L / bt, "unit": "walk-steps/s", "s_per_call": bt}
     # the rows the steps stood on: what the reference's table of a step is built from (every weight of the row once)
     deg = g.degrees()
     stood = walks[:, :L][valid.bool()] if valid.dtype != torch.bool else walks[:, :L][valid]
@@ -593,6 +604,7 @@ def bench_weighted(args, torch, rw, dev, W, L):
     res = {"graph": "cfg 2 (R-MAT scale 20, 1e7 directed edges), fp32 weights U[0.1, 2]", "p": BIASED_PQ[0],
            "q": BIASED_PQ[1], "walkers": int(valid.numel()), "value": steps / best, "unit": "walk-steps/s",
            "s_per_call": best, "tables_s": tables_s,
+           "small_batches": small,
            "walker_steps_left_to_the_exact_kernel": int(st["undecided"]) if "undecided" in st else None,
            "mean_row_slots_per_step": mean_row,
            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0,
@@ -692,6 +704,8 @@ def ordered_line(out):
             **{"exact_%g_%g" % (r["p"], r["q"]): r["value"] for r in out.get("biased_other_regimes", [])},
             "fast_0.5_2": (out.get("fast_mode") or {}).get("value"),
             "weighted_cfg2_exact_0.5_2": (out.get("weighted") or {}).get("value"),
+            "weighted_cfg2_exact_0.5_2_47k_walkers": (((out.get("weighted") or {}).get("small_batches") or {})
+                                                      .get("47100_walkers") or {}).get("value"),
             "trim_cap_100000_exact_pq1_ranks_out": ((out.get("reference_trim_cap") or {}).get("exact_pq1_ranks_out") or {}).get("value"),
             "trim_cap_100000_exact_biased_0.5_2": ((out.get("reference_trim_cap") or {}).get("exact_biased_0.5_2") or {}).get("value")},
         "walk_roofline_frac": {"headline_vertex_ids_out": frac(out),
