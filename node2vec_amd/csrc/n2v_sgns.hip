@@ -35,17 +35,57 @@ struct Row {
   float v[VEC];
 };
 
+// Rows are read and written with AGENT-SCOPE (`sc1`) accesses (N2V_SGNS_COHERENT, default 1; 0 = plain accesses, the
+// form of rounds 1 - 5).  The XCDs' L2s are not coherent with each other and a CU's L1 is never refreshed by another
+// CU's stores: with plain accesses a row trained by waves on two XCDs keeps the updates of ONE of them for as long
+// as a line stays cached -- a window of micro- to milliseconds where gensim's threads on a coherent CPU race over
+// nanoseconds.  Measured (round 6, profiles/r6m_sgns_coherent.log): of the rows a block of 768 sentences trains on a
+// 10^7 x 128 model, 4.5 % end a whole update away from the ordered run with plain accesses, 0.95 % with these; cfg 2
+// link AUC 0.8983 -> 0.9016 (hub_rows = 0) and 0.9085 -> 0.9107 (default), the rate on a 10^8 x 128 model unchanged
+// (813.6 / 813.7 M pairs/s: a random 512-byte row misses every cache anyway).  Values are the same bits: the
+// deterministic mode is untouched.  Rows of up to 128 floats only (4- and 8-byte accesses per lane: dim <= 128, the
+// dims of BASELINE cfgs 2 - 4): the 16-byte form (buffer loads / stores with aux = sc1 through a descriptor per row)
+// was built and measured too and costs 3.4 % at dim 256 and 31 % at dim 512 (profiles/r6n_sgns_coherent_rates.log),
+// so wider rows keep plain accesses.
+#ifndef N2V_SGNS_COHERENT
+#define N2V_SGNS_COHERENT 1
+#endif
+
+__device__ __forceinline__ float row_ld1(const float *p) {
+#if N2V_SGNS_COHERENT
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int *>(p), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT));
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void row_st1(float *p, float x) {
+#if N2V_SGNS_COHERENT
+  __hip_atomic_store(reinterpret_cast<unsigned int *>(p), __float_as_uint(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *p = x;
+#endif
+}
+
 template <int VEC>
 __device__ __forceinline__ void load_row(const float *base, int dim, int lane, bool full,
                                          Row<VEC> &r) {
   if (full) {
     if constexpr (VEC == 1) {
-      r.v[0] = base[lane];
+      r.v[0] = row_ld1(base + lane);
     } else if constexpr (VEC == 2) {
+#if N2V_SGNS_COHERENT
+      const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(base + lane * 2),
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      r.v[0] = __uint_as_float((unsigned int)u);
+      r.v[1] = __uint_as_float((unsigned int)(u >> 32));
+#else
       float2 t = *reinterpret_cast<const float2 *>(base + lane * 2);
       r.v[0] = t.x;
       r.v[1] = t.y;
+#endif
     } else {
+      // (16-byte accesses stay plain: see N2V_SGNS_COHERENT)
 #pragma unroll
       for (int q = 0; q < VEC / 4; ++q) {
         float4 t = *reinterpret_cast<const float4 *>(base + lane * VEC + q * 4);
@@ -59,7 +99,7 @@ __device__ __forceinline__ void load_row(const float *base, int dim, int lane, b
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       int e = lane * VEC + v;
-      r.v[v] = e < dim ? base[e] : 0.0f;
+      r.v[v] = e < dim ? row_ld1(base + e) : 0.0f;
     }
   }
 }
@@ -69,9 +109,16 @@ __device__ __forceinline__ void store_row(float *base, int dim, int lane, bool f
                                           const Row<VEC> &r) {
   if (full) {
     if constexpr (VEC == 1) {
-      base[lane] = r.v[0];
+      row_st1(base + lane, r.v[0]);
     } else if constexpr (VEC == 2) {
+#if N2V_SGNS_COHERENT
+      const unsigned long long u = (unsigned long long)__float_as_uint(r.v[0]) |
+                                   ((unsigned long long)__float_as_uint(r.v[1]) << 32);
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(base + lane * 2), u, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+#else
       *reinterpret_cast<float2 *>(base + lane * 2) = make_float2(r.v[0], r.v[1]);
+#endif
     } else {
 #pragma unroll
       for (int q = 0; q < VEC / 4; ++q)
@@ -82,7 +129,7 @@ __device__ __forceinline__ void store_row(float *base, int dim, int lane, bool f
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       int e = lane * VEC + v;
-      if (e < dim) base[e] = r.v[v];
+      if (e < dim) row_st1(base + e, r.v[v]);
     }
   }
 }
