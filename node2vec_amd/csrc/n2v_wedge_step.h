@@ -8,6 +8,9 @@
 #include "n2v_unit_core.h"
 #include "n2v_unit_near.h"
 
+#ifndef N2V_DEFER_HOP
+#define N2V_DEFER_HOP 1  // 0: every step gathers the hop entry of `pick` first (rounds 4 - 5; A/B builds)
+#endif
 #ifndef N2V_NEAR_FORMS
 #define N2V_NEAR_FORMS 1  // 0: values that are not dyadic replay every pairing (rounds 2 - 3; A/B builds)
 #endif
@@ -218,15 +221,21 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
     }
     w_loaded = true;
   }
-  h = load_hop(g.hops + vb + pick);
+  // An edge whose class word carries its return position (`inl`: no shared neighbours) has everything the decision
+  // needs in registers already -- the return run is the slots [rpos, rpos + nR), every other slot is "other" -- so the
+  // hop entry of `pick` is not a gather the step has to wait for, and when the draw returns another slot it was a
+  // gather for nothing (a fifth of the steps at (0.5, 2), most of them where "other" is overfull).  Such a step
+  // decides first and gathers the entry of its RESULT: one gather, always.  (N2V_DEFER_HOP 0: rounds 4 - 5.)
+  const bool defer = N2V_DEFER_HOP && inl;
+  if (!defer) h = load_hop(g.hops + vb + pick);
   if (!counts_ok) {
     atomicOr(status, N2V_ST_RANGE);
     return idx;
   }
-  const int32_t x = h.col;
   const int nR = F.merge_r ? 0 : (int)fR, nM = F.need_mem ? (int)fM : 0, nO = n - nR - nM;
   int64_t w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
-  const bool isR = !F.merge_r && x == s;
+  // (rows are sorted by neighbour: the slots that lead back to s are one run)
+  const bool isR = defer ? (nR > 0 && pick >= sa.x && pick < sa.x + nR) : (!F.merge_r && h.col == s);
   bool isM = false;
   int lo_pick = 0;  // entries of the edge's list below `pick`
   if (F.need_mem && !isR && nM > 0) {  // :226
@@ -269,7 +278,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
           const int res = near_step<uint16_t>(n, pick, r2, K, nR, (int)((uint32_t)sa.x & 0xffffu), nM, nlist, isR,
                                               isM, lo_pick, (int)((uint32_t)sa.x >> 16));
           if (res >= 0) {
-            if (res != pick) h = load_hop(g.hops + vb + res);
+            if (defer || res != pick) h = load_hop(g.hops + vb + res);
             return res;
           }
 #ifdef N2V_NEAR_COUNT  // diagnostic build: steps past the quick accept ([2]) / declined by the closed forms ([3])
@@ -326,7 +335,10 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
     avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;
   }
   const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) / avg;  // :173
-  if (p_pick < 1.0 && r2 < p_pick) return idx;  // an accepted underfull slot is final
+  if (p_pick < 1.0 && r2 < p_pick) {  // an accepted underfull slot is final
+    if (defer) h = load_hop(g.hops + vb + idx);
+    return idx;
+  }
 #if defined(N2V_ABLATE_WIDE) && N2V_ABLATE_WIDE == 2  // timing only: a wide step never pairs
   if (!kSlots) return idx;
 #endif
@@ -372,7 +384,10 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
       if constexpr (kJumpOnly) {
         idx = jump_listed<uint16_t, kMode>(arr, n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick,
                                            w_below);
-        if (idx < 0) return -1;
+        if (idx < 0) {
+          if (defer) h = load_hop(g.hops + vb + pick);
+          return -1;
+        }
       } else {
         bool done = false;
         if (kMode != 2 && lds_list != nullptr && nM <= kSlotShort) {
@@ -428,7 +443,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
     }
 #endif
   }
-  if (idx != pick) h = load_hop(g.hops + vb + idx);
+  if (defer || idx != pick) h = load_hop(g.hops + vb + idx);
   return idx;
 }
 
