@@ -9,7 +9,8 @@
 #include "n2v_unit_near.h"
 
 #ifndef N2V_DEFER_HOP
-#define N2V_DEFER_HOP 1  // 0: every step gathers the hop entry of `pick` first (rounds 4 - 5; A/B builds)
+#define N2V_DEFER_HOP 2  // 0: every step gathers the hop entry of `pick` first (rounds 4 - 5); 1: deferred on edges
+                         // with an inline return position only (A/B builds: profiles/r6o_time_defer_hop_ab.log)
 #endif
 #ifndef N2V_NEAR_FORMS
 #define N2V_NEAR_FORMS 1  // 0: values that are not dyadic replay every pairing (rounds 2 - 3; A/B builds)
@@ -226,7 +227,10 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
   // hop entry of `pick` is not a gather the step has to wait for, and when the draw returns another slot it was a
   // gather for nothing (a fifth of the steps at (0.5, 2), most of them where "other" is overfull).  Such a step
   // decides first and gathers the entry of its RESULT: one gather, always.  (N2V_DEFER_HOP 0: rounds 4 - 5.)
-  const bool defer = N2V_DEFER_HOP && inl;
+  // N2V_DEFER_HOP 2 (the default): also the steps that have asked for their slot -- the hop entry then waits for the
+  // slot, two dependent gathers where there were two parallel ones, and that costs nothing: the kernel is bound by
+  // the NUMBER of random sectors, not by their latency (+2 - 3.5 % over 1 on every (p, q), two runs).
+  const bool defer = N2V_DEFER_HOP && (inl || (N2V_DEFER_HOP == 2 && kSlots && w_loaded));
   if (!defer) h = load_hop(g.hops + vb + pick);
   if (!counts_ok) {
     atomicOr(status, N2V_ST_RANGE);
@@ -235,7 +239,8 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
   const int nR = F.merge_r ? 0 : (int)fR, nM = F.need_mem ? (int)fM : 0, nO = n - nR - nM;
   int64_t w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
   // (rows are sorted by neighbour: the slots that lead back to s are one run)
-  const bool isR = defer ? (nR > 0 && pick >= sa.x && pick < sa.x + nR) : (!F.merge_r && h.col == s);
+  const int rp0 = (int)((uint32_t)sa.x & 0xffffu);
+  const bool isR = defer ? (nR > 0 && pick >= rp0 && pick < rp0 + nR) : (!F.merge_r && h.col == s);
   bool isM = false;
   int lo_pick = 0;  // entries of the edge's list below `pick`
   if (F.need_mem && !isR && nM > 0) {  // :226
