@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define N2V_ABI_VERSION 13
+#define N2V_ABI_VERSION 14
 
 #define N2V_OK 0
 #define N2V_EINVAL (-1)  /* maps to ValueError (randomwalk.py:212-217)      */

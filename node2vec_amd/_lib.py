@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libn2v_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 OK, EINVAL, ELAUNCH, ENOGPU = 0, -1, -2, -3
 ST_ZERODIV, ST_RANGE, ST_OVERFLOW = 1, 2, 4

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert sorted(_lib.SYMBOLS) == _declared()
     lib.n2v_abi_version.restype = ctypes.c_int
-    assert lib.n2v_abi_version() == _lib.ABI_VERSION == 13
+    assert lib.n2v_abi_version() == _lib.ABI_VERSION == 14
     lib.n2v_status_string.restype = ctypes.c_char_p
     assert lib.n2v_status_string(-1) == b"invalid argument"
 
