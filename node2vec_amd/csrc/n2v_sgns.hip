@@ -39,13 +39,13 @@ struct Row {
 // form of rounds 1 - 5).  The XCDs' L2s are not coherent with each other and a CU's L1 is never refreshed by another
 // CU's stores: with plain accesses a row trained by waves on two XCDs keeps the updates of ONE of them for as long
 // as a line stays cached -- a window of micro- to milliseconds where gensim's threads on a coherent CPU race over
-// nanoseconds.  Measured (round 6, profiles/r6m_sgns_coherent.log): of the rows a block of 768 sentences trains on a
+// nanoseconds.  Measured (round 6, profiles/r10m_sgns_coherent.log): of the rows a block of 768 sentences trains on a
 // 10^7 x 128 model, 4.5 % end a whole update away from the ordered run with plain accesses, 0.95 % with these; cfg 2
 // link AUC 0.8983 -> 0.9016 (hub_rows = 0) and 0.9085 -> 0.9107 (default), the rate on a 10^8 x 128 model unchanged
 // (813.6 / 813.7 M pairs/s: a random 512-byte row misses every cache anyway).  Values are the same bits: the
 // deterministic mode is untouched.  Rows of up to 128 floats only (4- and 8-byte accesses per lane: dim <= 128, the
 // dims of BASELINE cfgs 2 - 4): the 16-byte form (buffer loads / stores with aux = sc1 through a descriptor per row)
-// was built and measured too and costs 3.4 % at dim 256 and 31 % at dim 512 (profiles/r6n_sgns_coherent_rates.log),
+// was built and measured too and costs 3.4 % at dim 256 and 31 % at dim 512 (profiles/r10n_sgns_coherent_rates.log),
 // so wider rows keep plain accesses.
 #ifndef N2V_SGNS_COHERENT
 #define N2V_SGNS_COHERENT 1

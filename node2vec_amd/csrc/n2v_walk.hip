@@ -771,7 +771,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 7) void weighted_step_wave_ker
   // min_n < 0: `order` is a LIST with its length in front of it (order[-1]; n2v_walk_weighted_step: what the margin
   // kernels left undecided -- nothing, as a rule).  A wave with no entry of its own leaves before it touches the shared
   // counter: 4 096 waves taking one look each were 4 096 same-address atomics, 48 us of every step whatever the batch
-  // (profiles/r6h_kernel_stats_47k_walkers.csv).
+  // (profiles/r10h_kernel_stats_47k_walkers.csv).
   if (min_n < 0) {
     const int64_t listed = readfirstlane_i64(order[-1]);
     const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);

@@ -1716,7 +1716,7 @@ extern "C" int n2v_walk_weighted_step(const n2v_graph *g, const int32_t *start_i
     // The cut between the two: a lane pays the row (~0.45 us per slot of its longest row, serial: 340 us of every step
     // at 768 slots whatever the batch), a wave ~700 vector instructions per walker.  A full batch (millions of walkers)
     // is throughput-bound and best at 768 (profiles/r8k_wm_cut.log); a small one is bound by that critical path, so the
-    // cut comes down with the number of walkers (profiles/r6i_wm_cut_by_batch.log).  hubs->lane_cut > 0 overrides.
+    // cut comes down with the number of walkers (profiles/r10i_wm_cut_by_batch.log).  hubs->lane_cut > 0 overrides.
     int from = N2V_WLANES_MARGIN_FROM;
     if (hubs && hubs->lane_cut > 0) {
       from = hubs->lane_cut;

@@ -10,7 +10,7 @@
 
 #ifndef N2V_DEFER_HOP
 #define N2V_DEFER_HOP 2  // 0: every step gathers the hop entry of `pick` first (rounds 4 - 5); 1: deferred on edges
-                         // with an inline return position only (A/B builds: profiles/r6o_time_defer_hop_ab.log)
+                         // with an inline return position only (A/B builds: profiles/r10o_time_defer_hop_ab.log)
 #endif
 #ifndef N2V_NEAR_FORMS
 #define N2V_NEAR_FORMS 1  // 0: values that are not dyadic replay every pairing (rounds 2 - 3; A/B builds)

@@ -245,13 +245,13 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
 # one: the library chooses it from the number of walkers), a second chance on the reference-order row sum and the
 # exact wave kernel for what the margins leave undecided -- wins over the one-launch wave-per-walker kernel from a
 # thousand walkers on (weighted cfg 2 at (0.5, 2), round 6: 1 000 walkers 9.6 M steps/s against 4.2 M, 10 k: 69.5 M
-# against 25.6 M, 47 k: 202 M against 38 M, 471 k: 490 M against 44 M, 4.7 M: 826 M; profiles/r6j_wm_small_batches.log).
+# against 25.6 M, 47 k: 202 M against 38 M, 471 k: 490 M against 44 M, 4.7 M: 826 M; profiles/r10j_wm_small_batches.log).
 # Without the margins the exact lane kernel (the pairing replayed) has the wave on the longest row as the tail of
 # every step (78 ms whatever the batch) and only wins from 2 M walkers on.
 WEIGHTED_LANES_MARGINS = True
 WEIGHTED_LANES_MIN_WALKERS = 1 << 9
 # capture steps 1 .. L - 1 of a call into one hipGraph (below).  OFF: measured in round 6 and slower at every batch
-# size (profiles/r6g_time_weighted_graph.log: 10 k walkers 37.8 -> 41.2 ms, 471 k 83.0 -> 89.3 ms, same walks) -- the
+# size (profiles/r10g_time_weighted_graph.log: 10 k walkers 37.8 -> 41.2 ms, 471 k 83.0 -> 89.3 ms, same walks) -- the
 # ~0.47 ms a step takes whatever the batch is spent ON THE GPU, in a dozen dependent stream operations (the sort's
 # passes, three memsets, four persistent launches), not in issuing them; capture + instantiation add 4 - 6 ms.
 WEIGHTED_LANES_GRAPH = False

@@ -2,7 +2,7 @@
 # ordered run, link AUC on cfg 2 by hub_rows, rate on a 10^8 x 128 model.  Run on the GPU box.
 R=$GRAFT_REPO_ROOT
 V=$R/build_variants/libn2v_sgns_coherent.so
-O=$R/gpurun_out/r6m_sgns_coherent.log
+O=$R/gpurun_out/r10m_sgns_coherent.log
 : > $O
 for lib in "" $V; do
   export N2V_HIP_LIB=$lib N2V_VARIANT_LIB=$lib

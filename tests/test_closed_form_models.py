@@ -105,7 +105,7 @@ def test_closed_forms_with_margins_on_rows_placed_at_the_margin_by_exact_arithme
     (2e-14 n (vmax + 1)), rows of 8 ... 10^4 slots in all five class arrangements.  Both stages as the kernel chains
     them: a decided draw is the reference's fp64 loop's (generate_alias_tables, randomwalk.py:172-189); and outside the
     smaller margin the placed slots ARE decided (the procedure is not vacuous).  Rows of 10^5 slots:
-    profiles/r6c_margin_adversary_near.log."""
+    profiles/r10c_margin_adversary_near.log."""
     out, draws, rows = _adversary("near", 10_000, 1, 11)
     assert draws > 40_000 and rows > 400
     inside = [float(l.split("declined")[1].split()[0]) for l in out.splitlines() if "margin ~n  " in l and

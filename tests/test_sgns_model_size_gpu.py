@@ -190,7 +190,7 @@ def _run_case(oracle, big, n, dim, kind, rows, sample, batched):
     # of the waves (every f starts at 0), so the typical row ends where the ordered run leaves it.  Not every
     # row: a row trained by waves on two XCDs keeps the updates of one of them (plain stores, L2s that are not
     # coherent with each other: 5 - 35 % of the rows of a block differ by a whole update, DESIGN.md 5 "K3",
-    # profiles/r6b_diag_hogwild_rows.log) -- the hogwild regime, bounded by the quality tests, not here
+    # profiles/r10b_diag_hogwild_rows.log) -- the hogwild regime, bounded by the quality tests, not here
     rel = (m.syn1neg[ch1] - det1).norm(dim=1) / det1.norm(dim=1)
     assert float(rel.median()) < 0.02, float(rel.median())
 
