@@ -1058,8 +1058,11 @@ def bench_sgns(args, cfg, torch, dist, g, walks, rank, world, barrier, use_dist,
     # threads) at 8192 waves.  The same launches with plain stores everywhere (hub_rows = 0, gensim's
     # code as written; cfg 2 link AUC 0.897 instead of 0.909) for comparison:
     res["hub_rows_auto"] = {"rows": int(model.hub_rows or 0), "n_vocab": len(model.vocab),
-                            "waves_in_flight": model.hub_waves,
-                            "rule": "rows with waves x (token share + k x negative-draw share) >= 1.5"}
+                            "waves_in_flight": model.hub_waves, "rows_the_lambda_rule_selects": model.hub_candidates,
+                            "their_share_of_all_row_holds": model.hub_share,
+                            "rule": "rows with waves x (token share + k x negative-draw share) >= 1.5, when together "
+                                    "they carry >= 10 % of all row-holds (cfg 2: 18 %, + 0.009 link AUC; cfg 3: 5 %, "
+                                    "no difference in AUC for 12 % of the rate: profiles/r10r_auc_cfg3.log)"}
     if not args.no_hub:
         auto_rows = model.hub_rows
         model.hub_rows = 0

@@ -175,12 +175,15 @@ class SgnsModel:
         self.hub_rows: Optional[int] = None
         self.hub_rows_auto = False  # True once auto_hub_rows chose hub_rows (with hub_waves waves in flight)
         self.hub_waves: Optional[int] = None
+        self.hub_share: Optional[float] = None      # share of all row-holds on the rows the lambda rule selects
+        self.hub_candidates: Optional[int] = None   # how many rows it selects (hub_rows = that, or 0 below HUB_MIN_SHARE)
         self.ns_exponent = float(ns_exponent)
         self._counters = torch.zeros(2, dtype=torch.int64, device=device)
         self.pairs = self._counters[:1]
         self.sentences_seen = 0
 
-    HUB_LAMBDA = 1.5      # rows held by at least this many waves on average are updated atomically
+    HUB_LAMBDA = 1.5      # rows held by at least this many waves on average are updated atomically ...
+    HUB_MIN_SHARE = 0.10  # ... when together they carry at least this share of all row-holds (auto_hub_rows)
 
     def hogwild_waves(self, rows: int, length: int) -> int:
         """the waves n2v_sgns_train keeps in flight for a launch of `rows` sentences of `length`
@@ -212,15 +215,25 @@ class SgnsModel:
         (profiles/r4n_hogwild_auc_hub_rows_knee.log, r4l_*: H = 512 / 1024 / 2048 / 4096 / 6196 ->
         AUC 0.9015 / 0.9041 / 0.9093 / 0.9094 / 0.9119 at +9 / +12 / +17 / +30 / +56 % of the epoch
         time): the level of the <= 64-wave runs is reached around 2 000 - 3 000 rows, more rows only
-        cost.  Opt-in kernels (batched) keep 0."""
+        cost.  Round 6: only when those rows carry >= HUB_MIN_SHARE of all row-holds (below).  Opt-in kernels
+        (batched) keep 0."""
         if self.batched:
             return 0
         waves = self.hogwild_waves(rows, length)  # (of the launch the rule is applied to: the first)
         self.hub_waves = waves
         c = self.vocab.counts.to(torch.float64)
         pw = c.pow(self.ns_exponent)
-        lam = waves * (c / c.sum() + self.negative * pw / pw.sum())
-        return int((lam >= self.HUB_LAMBDA).sum().item())
+        held = c / c.sum() + self.negative * pw / pw.sum()
+        h = int((waves * held >= self.HUB_LAMBDA).sum().item())
+        # ... and only where those rows carry a real share of the training (round 6).  On cfg 2 they take 18 % of all
+        # row-holds (31 % of the tokens) and the atomics are worth + 0.009 link AUC for + 17 % of the epoch; on cfg 3
+        # (5 % of the row-holds, 561 rows) one epoch ends at the same AUC with or without them -- 0.9148 / 0.9150, on the
+        # edges of the 1 000 biggest hubs 0.863 / 0.866 -- and they cost 12 % (profiles/r10r_auc_cfg3.log,
+        # r10s_hub_share.log); cfg 4: 2.6 %, 284 rows, 5 % of the rate.  Below HUB_MIN_SHARE the trainer keeps gensim's
+        # plain stores.
+        self.hub_share = float(held[:h].sum().item()) / (1.0 + self.negative) if h else 0.0
+        self.hub_candidates = h
+        return h if self.hub_share >= self.HUB_MIN_SHARE else 0
 
     def _hub_rows(self, rows: int, length: int) -> int:
         if self.hub_rows is None:
