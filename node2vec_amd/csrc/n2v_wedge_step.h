@@ -230,7 +230,10 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
   // N2V_DEFER_HOP 2 (the default): also the steps that have asked for their slot -- the hop entry then waits for the
   // slot, two dependent gathers where there were two parallel ones, and that costs nothing: the kernel is bound by
   // the NUMBER of random sectors, not by their latency (+2 - 3.5 % over 1 on every (p, q), two runs).
-  const bool defer = N2V_DEFER_HOP && (inl || (N2V_DEFER_HOP == 2 && kSlots && w_loaded));
+  // (A list that is not inside the slot is searched in memory, a chain of dependent probes: there the entry of `pick`
+  // is requested at once, as before, and arrives behind them -- waiting with it cost the graph trimmed at the
+  // reference's cap, whose hub steps are such searches, 10 %: 14.0 -> 12.6 G.)
+  const bool defer = N2V_DEFER_HOP && (inl || (N2V_DEFER_HOP == 2 && kSlots && w_loaded && fM <= (uint32_t)kSlotShort));
   if (!defer) h = load_hop(g.hops + vb + pick);
   if (!counts_ok) {
     atomicOr(status, N2V_ST_RANGE);
