@@ -33,6 +33,22 @@ __device__ __forceinline__ T pick3(bool first, bool second, T a, T b, T c) {
   return first ? a : (second ? b : c);
 }
 
+// diagnostic build (-DN2V_DECLINE_STATS): why lane_case_a_jump (codes 1 ..) / lane_case_b_jump (11 ..) return -1 on rows of
+// more than 64 slots (words 8 + code of the launch's status) and of 4096 and more (words 40 + code); scripts/r6/decline_stats.py
+// lends the launch 128 words.  Round 6, cfg 4 trimmed at 100 000 (profiles/r11d_decline_stats.log): every decline on such a
+// row is a TIE of the exact process (codes 3, 5, 15, 20) -- the reference's rounding decides it and only a replay knows.
+#ifdef N2V_DECLINE_STATS
+static __device__ uint32_t *n2v_decline_words;
+#define N2V_DECLINE(code)                                            \
+  do {                                                               \
+    if (n > 64) atomicAdd(n2v_decline_words + (code), 1u);           \
+    if (n >= 4096) atomicAdd(n2v_decline_words + 32 + (code), 1u);   \
+    return -1;                                                       \
+  } while (0)
+#else
+#define N2V_DECLINE(code) return -1
+#endif
+
 struct UnitConsts {
   double bR, bM, bO;     // 1/p, 1, 1/q
   int64_t TR, TM, TO;    // the same times 2^20 (exact integers; dyadic kernel only)
@@ -332,9 +348,9 @@ __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, cons
   // zero-excess rows (scripts/models/flat_a.py: 4.7 M draws, 0 mismatches).  Built and measured in
   // round 4: same walks, no gain -- such rows are short and their replay is the bit-mask loop --
   // so this instance, whose registers are the flagship configuration's, was left as it was.)
-  if (!(D > 0.0) || (nM > 0 && !(EM > 0.0)) || (nR > 0 && !(ER > 0.0))) return -1;
+  if (!(D > 0.0) || (nM > 0 && !(EM > 0.0)) || (nR > 0 && !(ER > 0.0))) N2V_DECLINE(1);
   // exactness of the arithmetic (products < 2^52) and of the decisions (4 n 1e-15 < 1 / isum)
-  if (dn * isum > 2.0e14 || dn * dn * fmax(K.fR, K.fM) > 4.0e15) return -1;
+  if (dn * isum > 2.0e14 || dn * dn * fmax(K.fR, K.fM) > 4.0e15) N2V_DECLINE(2);
   int mA = nM;  // shared slots above the return run come first in descending order
   if (nR > 0 && nM > 0) {
     int lo = below;  // entries of the list below the return position: stored with the wedge slot,
@@ -372,7 +388,7 @@ __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, cons
       else
         i = dmA + dnR + floor_div(T - X1 - dnR * ER + EM - 1.0, EM);
     }
-    if (!(i >= 1.0) || i > (double)N || X_of(i) == T) return -1;  // a tie: fp64 rounding decides
+    if (!(i >= 1.0) || i > (double)N || X_of(i) == T) N2V_DECLINE(3);  // a tie: fp64 rounding decides
     return pos_of((int)i);  // r2 >= probs[pick] here: the caller's quick exit took the other case
   }
   int i0;
@@ -382,7 +398,7 @@ __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, cons
     const int d = nM - lo_pick;  // pick is the d-th shared slot from the top
     i0 = d <= mA ? d : d + nR;
   }
-  if (i0 < 1 || i0 > N) return -1;
+  if (i0 < 1 || i0 > N) N2V_DECLINE(4);
   // the last overfull slot ends at exactly 1.0 in exact arithmetic (mass balance), i.e. within the
   // accumulated rounding of it in fp64 -- or is never reached and keeps its value >= 1; either way
   // probs[pick] > 1 - 1e-9 > r2 (r2 <= 1 - 2^-32): sampling_from_alias returns pick
@@ -390,9 +406,9 @@ __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, cons
   const double X = X_of((double)i0);
   const double xq = floor_div(X, D);
   const double rem0 = fma(-xq, D, X);  // X mod D, exact
-  if (rem0 == 0.0) return -1;
+  if (rem0 == 0.0) N2V_DECLINE(5);
   const double prob = 1.0 + (rem0 - D) / isum;  // demoted at 1 + (X - (xq + 1) D) / isum
-  if (fabs(prob - r2) < 1e-9) return -1;
+  if (fabs(prob - r2) < 1e-9) N2V_DECLINE(6);
   return (r2 < prob) ? pick : pos_of(i0 + 1);
 }
 
@@ -417,8 +433,8 @@ __device__ __forceinline__ int lane_case_b_jump(int n, int pick, double r2, cons
   const double dn = (double)n;
   const double isum = (double)nR * K.fR + (double)nM * K.fM + (double)nO * K.fO;
   const double e = K.fO * dn - isum, dR = isum - K.fR * dn, dM = isum - K.fM * dn;
-  if (nO <= 0 || !(e > 0.0) || (nM > 0 && !(dM > 0.0)) || (nR > 0 && !(dR > 0.0))) return -1;
-  if (dn * isum > 2.0e14 || dn * dn * K.fO > 4.0e15) return -1;
+  if (nO <= 0 || !(e > 0.0) || (nM > 0 && !(dM > 0.0)) || (nR > 0 && !(dR > 0.0))) N2V_DECLINE(11);
+  if (dn * isum > 2.0e14 || dn * dn * K.fO > 4.0e15) N2V_DECLINE(12);
   auto list_lower = [&](int pos) -> int {  // entries of the list below pos
     return list_lower_bound<P>(list, nM, pos);
   };
@@ -443,7 +459,7 @@ __device__ __forceinline__ int lane_case_b_jump(int n, int pick, double r2, cons
       if (c2 == c) return n - t - c;
       c = c2;
     }
-    return -1;
+    N2V_DECLINE(13);
   };
   if (pickR || pickM) {  // underfull: r2 >= its value here (the caller's quick exit took the rest)
     int j;
@@ -453,20 +469,20 @@ __device__ __forceinline__ int lane_case_b_jump(int n, int pick, double r2, cons
       const int d = nM - lo_pick;
       j = d <= mA ? d : d + nR;
     }
-    if (j < 1 || j > S) return -1;
+    if (j < 1 || j > S) N2V_DECLINE(14);
     double t = 1.0;
     if (j > 1) {
       const double Yp = Y_of((double)(j - 1));
       t = floor_div(Yp + e - 1.0, e);
-      if (t * e == Yp) return -1;  // that slot holds exactly 1.0: fp64 decides whether it was demoted
+      if (t * e == Yp) N2V_DECLINE(15);  // that slot holds exactly 1.0: fp64 decides whether it was demoted
     }
-    if (!(t >= 1.0) || t > (double)nO) return -1;
+    if (!(t >= 1.0) || t > (double)nO) N2V_DECLINE(16);
     return other_pos((int)t);
   }
   int ar = rpos + nR - 1 - pick;  // return slots above pick
   ar = ar < 0 ? 0 : (ar > nR ? nR : ar);
   const int t = (n - pick) - (nM - lo_pick) - ar;  // rank of pick among "other", from 1
-  if (t < 1 || t > nO) return -1;
+  if (t < 1 || t > nO) N2V_DECLINE(17);
   // the last "other" slot ends at exactly 1.0 in exact arithmetic (mass balance: Y_S = nO e), i.e.
   // within the accumulated rounding of it in fp64 -- or is never reached and keeps its value
   // >= 1; either way probs[pick] > 1 - 1e-9 > r2 (r2 <= 1 - 2^-32): the draw returns pick
@@ -482,12 +498,12 @@ __device__ __forceinline__ int lane_case_b_jump(int n, int pick, double r2, cons
     else if (dM > 0.0)
       j = dmA + dnR + floor_div(T - Y1 - dnR * dR, dM) + 1.0;
     else
-      return -1;
+      N2V_DECLINE(18);
   }
-  if (!(j >= 1.0) || j > (double)S) return -1;
-  if (j > 1.0 && Y_of(j - 1.0) == T) return -1;  // exactly 1.0 after the previous listed slot
+  if (!(j >= 1.0) || j > (double)S) N2V_DECLINE(19);
+  if (j > 1.0 && Y_of(j - 1.0) == T) N2V_DECLINE(20);  // exactly 1.0 after the previous listed slot
   const double prob = 1.0 + (T - Y_of(j)) / isum;
-  if (fabs(prob - r2) < 1e-9) return -1;
+  if (fabs(prob - r2) < 1e-9) N2V_DECLINE(21);
   if (r2 < prob) return pick;
   // the "other" slot of rank t + 1 is the next one below pick: usually pick - 1, found from the
   // rank of pick in the list (no search); other_pos() if the row runs out (it cannot: t < nO)

@@ -290,6 +290,9 @@ void walk_exact_wedge_slots_kernel(
 #if defined(N2V_BIG_STATS) && defined(N2V_BIG_DECLINES)
   n2v_big_words = status;
 #endif
+#ifdef N2V_DECLINE_STATS
+  n2v_decline_words = status + 8;
+#endif
   const bool base_aligned = (reinterpret_cast<uintptr_t>(walks_out) & 63u) == 0;
 
   int64_t w0 = 0;  // absolute word index of path position 0 of the current walker

@@ -66,7 +66,16 @@ __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, 
 #if defined(N2V_BIG_STATS) && defined(N2V_BIG_DECLINES)  // diagnostic: [2] then counts the big-row pairings the closed forms DECLINED
   if (n >= N2V_BIG_STATS && res < 0) atomicAdd(n2v_big_words + 2, 1u);
 #endif
+#ifdef N2V_DECLINE_STATS  // diagnostic: declined pairings on rows of more than 64 / of 4096 slots and more, by arrangement
+  if (res < 0 && n > 64) atomicAdd(n2v_decline_words + 24 + arr, 1u);
+  if (res < 0 && n >= 4096) atomicAdd(n2v_decline_words + 56 + arr, 1u);
+  if (n > 64) atomicAdd(n2v_decline_words + 30, 1u);  // pairings on such rows
+  if (n >= 4096) atomicAdd(n2v_decline_words + 62, 1u);
+#endif
   if (res >= 0) return res;
+#ifdef N2V_ABLATE_STEP  // timing only: 4 = a pairing the closed forms decline keeps `pick` (no replay); 5 = on rows > 64
+  if (N2V_ABLATE_STEP == 4 || (N2V_ABLATE_STEP == 5 && n > 64)) return pick;
+#endif
   if constexpr (kMode == 2) {
     // a long row whose values are not dyadic: the closed forms on the reference's own values (the exact
     // row sum has been taken), with a margin that grows with n instead of n^2
@@ -246,6 +255,10 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
   const bool isR = defer ? (nR > 0 && pick >= rp0 && pick < rp0 + nR) : (!F.merge_r && h.col == s);
   bool isM = false;
   int lo_pick = 0;  // entries of the edge's list below `pick`
+#ifdef N2V_ABLATE_STEP  // timing only: 1 = no search of a list that is not inside its slot
+  if (N2V_ABLATE_STEP == 1 && nM > kSlotShort) {
+  } else
+#endif
   if (F.need_mem && !isR && nM > 0) {  // :226
     if constexpr (kSlots)
       lo_pick = slot_lower(sa, sb, nM, pick, reinterpret_cast<const uint16_t *>(g.wedge_pos), isM);
@@ -291,6 +304,12 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
           }
 #ifdef N2V_NEAR_COUNT  // diagnostic build: steps past the quick accept ([2]) / declined by the closed forms ([3])
           atomicAdd(status + 3, 1u);
+#endif
+#ifdef N2V_ABLATE_STEP  // timing only: 6 = a step the closed forms with margins decline keeps `pick` (no row sum, no replay)
+          if (N2V_ABLATE_STEP == 6 || (N2V_ABLATE_STEP == 7 && n >= 4096)) {
+            h = load_hop(g.hops + vb + pick);
+            return pick;
+          }
 #endif
         }
         const uint16_t *sum_list = slot + 2;
@@ -349,6 +368,12 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
   }
 #if defined(N2V_ABLATE_WIDE) && N2V_ABLATE_WIDE == 2  // timing only: a wide step never pairs
   if (!kSlots) return idx;
+#endif
+#ifdef N2V_ABLATE_STEP  // timing only: 2 = no pairing at all, 3 = none on rows of 4096 slots and more
+  if (N2V_ABLATE_STEP == 2 || (N2V_ABLATE_STEP == 3 && n >= 4096)) {
+    if (defer) h = load_hop(g.hops + vb + idx);
+    return idx;
+  }
 #endif
   // underfull / overfull by class without dividing: fl(b / avg) < 1.0 <=> b < avg
   const bool uR = K.bR < avg, uM = K.bM < avg, uO = K.bO < avg;

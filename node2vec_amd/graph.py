@@ -340,7 +340,8 @@ class DeviceGraph:
             wide_e = (deg >= t_from)[self.col.long()]  # edges into a wide row
             total_wide = int(counts[wide_e].sum())
         need = 8 * self.n_edges + (total * 4 if mode == 1 else (total - total_wide) * 2 + total_wide * 4 + 4)
-        if max_bytes is None:
+        own_budget = max_bytes is None
+        if own_budget:
             max_bytes = torch.cuda.mem_get_info(self.device)[0] // 2
         if need > max_bytes or total >= (1 << 40):
             return self
@@ -367,8 +368,19 @@ class DeviceGraph:
         if int(status[0].item()) & _lib.ST_RANGE:
             raise RuntimeError("n2v_wedge_build: list lengths disagree with edge_classes")
         self.wedge_off, self.wedge_pos, self.wedge_mode = off, pos, mode
-        if slots and mode != 1 and need + 32 * self.n_edges <= max_bytes:
-            self.build_wedge_slots()
+        if slots and mode != 1:
+            if own_budget:
+                # (the lists are in place: the slots may take half of what is free NOW, counting the blocks torch
+                # holds cached -- the 100 GB of lists of cfg 4 trimmed at the reference's cap of 100 000 left the
+                # old rule, lists + slots within half of what was free before, 1 % short of the slots, and the walk
+                # without them is 30 % slower: 12.8 against 16.7 G steps/s at (0.5, 2), profiles/r11b_*)
+                free = (torch.cuda.mem_get_info(self.device)[0] + torch.cuda.memory_reserved(self.device)
+                        - torch.cuda.memory_allocated(self.device))
+                fits = 32 * self.n_edges <= free // 2
+            else:
+                fits = need + 32 * self.n_edges <= max_bytes
+            if fits:
+                self.build_wedge_slots()
         return self
 
     def build_wedge_slots(self) -> "DeviceGraph":

@@ -198,7 +198,9 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
         valid = torch.empty(total, dtype=torch.uint8, device=graph.device)
     else:
         walks, valid = out
-    status = torch.zeros(4, dtype=torch.int32, device=graph.device)  # include/n2v_hip.h
+    # include/n2v_hip.h: four words (diagnostic builds of the library count in more: N2V_DIAG_STATUS_WORDS)
+    status = torch.zeros(max(4, int(os.environ.get("N2V_DIAG_STATUS_WORDS", 4))), dtype=torch.int32,
+                         device=graph.device)
     g = graph.c_struct()
     if not use_edge_classes:  # the wave-per-walker kernel (what a C caller without the counts gets)
         g.edge_classes = 0

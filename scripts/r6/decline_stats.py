@@ -1,0 +1,24 @@
+"""diagnostic (build_variants/libn2v_wedge_declines.so, -DN2V_DECLINE_STATS=1): why the closed forms of the pairing
+loop decline on rows of more than 64 slots (codes: n2v_unit_core.h, N2V_DECLINE), cfg 4 trimmed at TRIM"""
+import os, sys, time, torch
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, ROOT)
+os.environ["N2V_DIAG_STATUS_WORDS"] = "128"
+from node2vec_amd import _lib
+_lib.LIB_PATH = os.path.join(ROOT, "build_variants", "libn2v_wedge_declines.so")
+from node2vec_amd import synthetic, randomwalk as rw
+TRIM = int(os.environ.get("TRIM", 100_000))
+g = synthetic.chung_lu(100_000_000, 500_000_000, device="cuda").trimmed(TRIM, 42)
+start = rw.start_vertices(g)[:1 << 18].contiguous()
+for pq in os.environ.get("PQ", "0.5,2;4,0.25").split(";"):
+    p, q = (float(x) for x in pq.split(","))
+    st = {}
+    walks, valid = rw.walk(g, start, 10, 80, p, q, 42, stats=st)
+    torch.cuda.synchronize()
+    steps = int(valid.sum()) * 80
+    s = st["status"].cpu().numpy().astype("uint32")[8:]
+    for name, o in (("rows > 64", 0), ("rows >= 4096", 32)):
+        codes = {c: int(s[o + c]) for c in range(1, 24) if s[o + c]}
+        arrs = {a: int(s[o + 24 + a]) for a in range(6) if s[o + 24 + a]}
+        print(f"trim {TRIM} p={p} q={q} {name}: steps {steps}, pairings {int(s[o + 30])}, declined by arrangement {arrs}, "
+              f"by reason {codes}", flush=True)
