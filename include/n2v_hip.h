@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define N2V_ABI_VERSION 14
+#define N2V_ABI_VERSION 15
 
 #define N2V_OK 0
 #define N2V_EINVAL (-1)  /* maps to ValueError (randomwalk.py:212-217)      */
@@ -117,7 +117,8 @@ typedef struct n2v_graph {
                                    padded (hop8_align_shift > 0), else NULL (= rowptr) */
   int32_t hop8_align_shift;     /* rows of the hops8 table start at multiples of 2^shift entries */
   int32_t reserved2;            /* bit 0 (N2V_HOPS_INLINE_RPOS): the class words of `hops` carry inline
-                                   return positions, see n2v_hops_build; else 0 */
+                                   return positions, see n2v_hops_build; bit 1 (N2V_SLOTS_FOLDED): see
+                                   n2v_wedge_slots_fold; else 0 */
   const uint16_t *wedge_slots;  /* [n_edges][16] or NULL: see n2v_wedge_slots_build */
   /* The degree-ranked form of a unit-weight graph (p == q == 1 walks; n2v_rank_hops_build), or all
    * NULL / 0.  Vertices are numbered again by descending degree (`rank`), rows are laid out in rank
@@ -158,6 +159,9 @@ typedef struct n2v_graph {
  * does not fetch the edge's wedge slot for it (half of the edges of cfg 4, all of cfg 5). */
 #define N2V_EC_INLINE 0x80000000u
 #define N2V_HOPS_INLINE_RPOS 1
+/* bit 1 of reserved2 (ABI 15): the wedge slots of the edges into rows of wedge_wide .. wedge_wide + 65536 entries are
+ * FOLDED slots (n2v_wedge_slots_fold) -- the exact slots kernel then steps those rows like every other */
+#define N2V_SLOTS_FOLDED 2
 
 int n2v_abi_version(void);
 const char *n2v_status_string(int code);
@@ -260,6 +264,29 @@ int n2v_wedge_build(const n2v_graph *g, const uint64_t *list_off, uint64_t *wedg
  * set.  At cfg 4 half of the steps need a list and four fifths of those lists are short.
  * slots_out: [n_edges * 16] uint16. */
 int n2v_wedge_slots_build(const n2v_graph *g, uint16_t *slots_out, void *stream);
+
+/* Folded lists and slots for the edges into WIDE rows of a mixed wedge table (ABI 15).  The reference trims rows at
+ * 100 000 (constants.py:6), so the rows of its hubs hold positions that need 17 bits.  The mixed table keeps the lists
+ * of the edges into such rows as uint32 without a slot, and a walker standing there took its step through a second,
+ * 32-bit instance of the step (wedge_off, then the list): a wave pays for every code path ONE of its lanes takes, and
+ * on cfg 4 trimmed at 100 000 nearly every wave-step has such a lane.  A FOLDED list stores a position below
+ * T = wedge_wide as it is and one from T on minus T, in the same order -- both parts ascend, entry k is
+ * list[k] + (k >= nlow ? T : 0) with nlow the number of entries below T, and a lower bound is one search in one part --
+ * so it is a uint16 list like every other (rows of up to T + 65536 entries), gets a slot like every other, and the
+ * exact slots kernel steps such a row with the same instructions as the rest:
+ *   n_shared <= 14:  [0] return position (folded)  [1] below | nlow << 4 | upper << 8 (upper: the return position is
+ *                    >= T)  [2 .. 2 + n_shared) the folded list
+ *   n_shared  > 14:  [0] return position (folded)  [1] below, [2] nlow (low 16 bits)  [3] upper | (below >> 16) << 4 |
+ *                    (nlow >> 16) << 8  [4 .. 8) offset of the folded copy in wedge_pos (2-byte units)  [8 .. 16) eight
+ *                    pivots of the folded copy, as in n2v_wedge_slots_build
+ * g: a graph with a mixed table (wedge_wide = T >= 2), edge_classes, wedge_off, wedge_pos set; fold_off [n_edges]:
+ * where the folded copy of edge e's list goes (2-byte units from wedge_pos; read for the edges into rows of T ..
+ * T + 65536 entries with more than 14 shared neighbours only); wedge_pos_rw == g->wedge_pos (the caller's buffer, with
+ * room behind the uint32 lists); slots [n_edges * 16] as n2v_wedge_slots_build left them (the slots of those edges
+ * are rewritten).  The uint32 lists stay: every other kernel reads them.  Set N2V_SLOTS_FOLDED in reserved2 to have
+ * the slots kernel use the result; without the bit the same walks come out of the 32-bit instance. */
+int n2v_wedge_slots_fold(const n2v_graph *g, const uint64_t *fold_off, void *wedge_pos_rw, uint16_t *slots,
+                         void *stream);
 
 /* Search index for N2V_WALK_FAST: the last id of every aligned block of 32 entries of
  * `col` (one 128-byte line).  Inside a sorted row the block ends ascend, so a

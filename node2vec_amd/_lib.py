@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libn2v_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 OK, EINVAL, ELAUNCH, ENOGPU = 0, -1, -2, -3
 ST_ZERODIV, ST_RANGE, ST_OVERFLOW = 1, 2, 4
@@ -26,7 +26,8 @@ SYMBOLS = ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alia
            "n2v_partition_step", "n2v_gather_rows", "n2v_gather_wedges",
            "n2v_partition_route", "n2v_partition_group", "n2v_walk_ws", "n2v_walk_workspace_bytes",
            "n2v_delta_reduce", "n2v_wedge_slots_build", "n2v_sgns_job_alpha", "n2v_rank_hops_build", "n2v_partition_forward",
-           "n2v_sgns_hogwild_waves", "n2v_walk_weighted_step", "n2v_partition_forward_boxes", "n2v_walk_weighted_keys")
+           "n2v_sgns_hogwild_waves", "n2v_walk_weighted_step", "n2v_partition_forward_boxes", "n2v_walk_weighted_keys",
+           "n2v_wedge_slots_fold")
 
 
 class WeightedHubs(C.Structure):
@@ -96,6 +97,8 @@ def load():
                                   C.c_void_p, C.c_void_p]
     L.n2v_wedge_slots_build.restype = C.c_int
     L.n2v_wedge_slots_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p]
+    L.n2v_wedge_slots_fold.restype = C.c_int
+    L.n2v_wedge_slots_fold.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.n2v_hops_build.restype = C.c_int
     L.n2v_hops_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p]
     L.n2v_hops8_build.restype = C.c_int

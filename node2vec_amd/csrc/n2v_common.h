@@ -192,6 +192,43 @@ __device__ __forceinline__ int list_lower_bound(const P *a, int cnt, int pos) {
   return lo;
 }
 
+// A shared-position list as the routines of the pairing loop read it.  Plain: the ascending positions themselves.
+// FOLDED (round 6; the lists of the edges into rows of T = n2v_graph.wedge_wide .. T + 65536 slots, whose positions do
+// not fit 16 bits -- the reference's own trim cap is 100 000, constants.py:6): a position below T is stored as it is,
+// one from T on minus T, in the same order, and `nlow` says how many entries lie below T -- so entry k is
+// p[k] + (k >= nlow ? T : 0), both parts ascend, and a lower bound is ONE search in one of the two parts.  Such a list
+// is 16-bit like every other, has a wedge slot like every other, and its steps run through the SAME instructions as
+// everybody else's (a wave pays for every code path ONE of its lanes takes: the separate 32-bit instance of the step
+// cost cfg 4 trimmed at 100 000 a sixth of its time at (0.5, 2) and three fifths at (3, 0.7), profiles/r11c_*).
+// A raw pointer converts to the plain form, so callers that hold plain lists pass them as before.
+template <typename P>
+struct ListRef {
+  const P *p;
+  int nlow;  // entries [nlow, ..) carry + fold; 0x7fffffff: a plain list
+  int fold;
+  __host__ __device__ __forceinline__ ListRef(const P *q) : p(q), nlow(0x7fffffff), fold(0) {}
+  __host__ __device__ __forceinline__ ListRef(const P *q, int nl, int f) : p(q), nlow(nl), fold(f) {}
+  __device__ __forceinline__ int fix(int k, int raw) const { return k >= nlow ? raw + fold : raw; }
+  __device__ __forceinline__ int operator[](int k) const { return fix(k, (int)p[k]); }
+};
+
+template <typename P>
+__device__ __forceinline__ int list_lower_bound(const ListRef<P> &L, int cnt, int pos) {
+  const P *a = L.p;
+  int c = cnt, t = pos, add = 0;
+  if (L.nlow < cnt) {  // a folded list with entries in both parts: `pos` says which part holds its lower bound
+    if (pos < L.fold) {
+      c = L.nlow;
+    } else {
+      a += L.nlow;
+      c = cnt - L.nlow;
+      t = pos - L.fold;
+      add = L.nlow;
+    }
+  }
+  return add + list_lower_bound<P>(a, c, t);
+}
+
 // is `pos` one of the (ascending) positions list[0, cnt)?  one lane
 template <typename P>
 __device__ __forceinline__ bool wedge_has_t(const void *base, int64_t off, int cnt, int pos) {
@@ -243,15 +280,18 @@ __device__ __forceinline__ int slot_half(const int4 &a, const int4 &b, int k) { 
   return (int)((k & 1) ? (d >> 16) : (d & 0xffffu));
 }
 
-// lower bound of `pick` in the list of a slot (entries below it; found = it is in the list)
+// lower bound of `pick` in the list of a slot (entries below it; found = it is in the list).  A folded list (ListRef):
+// entries from `nlow` on stand for their value + fold; nlow >= nM is a plain list.
 __device__ __forceinline__ int slot_lower(const int4 &sa, const int4 &sb, int nM, int pick,
-                                          const uint16_t *wedge_pos, bool &found) {
+                                          const uint16_t *wedge_pos, bool &found, int nlow = 0x7fffffff,
+                                          int fold = 0) {
   found = false;
   if (nM <= kSlotShort) {
     int lo = 0;
 #pragma unroll
     for (int k = 0; k < kSlotShort; ++k) {
-      const int e = slot_half(sa, sb, k + 2);
+      const int raw = slot_half(sa, sb, k + 2);
+      const int e = k >= nlow ? raw + fold : raw;
       const bool in = k < nM;
       lo += (in && e < pick) ? 1 : 0;
       found = found || (in && e == pick);
@@ -262,12 +302,27 @@ __device__ __forceinline__ int slot_lower(const int4 &sa, const int4 &sb, int nM
   const uint16_t *list = wedge_pos + off;
   int j = 0;  // pivots below pick
 #pragma unroll
-  for (int k = 0; k < kSlotPivots; ++k) j += (slot_half(sa, sb, 8 + k) < pick) ? 1 : 0;
+  for (int k = 0; k < kSlotPivots; ++k) {
+    const int raw = slot_half(sa, sb, 8 + k);
+    const int at = (int)(((int64_t)(k + 1) * nM) / 9);
+    j += ((at >= nlow ? raw + fold : raw) < pick) ? 1 : 0;
+  }
   // list[idx(j - 1)] < pick <= list[idx(j)], idx(k) = ((k + 1) nM) / 9, idx(-1) = -1, idx(8) = nM
   int lo = j == 0 ? 0 : (int)(((int64_t)j * nM) / 9) + 1;
   int hi = j == kSlotPivots ? nM : (int)(((int64_t)(j + 1) * nM) / 9);
   const int top = hi;
-  lo += list_lower_bound<uint16_t>(list + lo, hi - lo, pick);
+  int target = pick;
+  if (nlow < nM) {  // folded: the part of the ninth that can hold the lower bound
+    if (pick < fold) {
+      hi = hi < nlow ? hi : nlow;
+      lo = lo < hi ? lo : hi;
+    } else {
+      lo = lo > nlow ? lo : nlow;
+      hi = hi > lo ? hi : lo;
+      target = pick - fold;
+    }
+  }
+  lo += list_lower_bound<uint16_t>(list + lo, hi - lo, target);
   if (lo < nM) {
     int e = 0;  // list[lo]: the pivot itself when the search ran to the end of its ninth
     if (lo == top && j < kSlotPivots) {
@@ -277,6 +332,7 @@ __device__ __forceinline__ int slot_lower(const int4 &sa, const int4 &sb, int nM
     } else {
       e = (int)list[lo];
     }
+    if (lo >= nlow) e += fold;
     found = e == pick;
   }
   return lo;

@@ -150,7 +150,7 @@ __device__ __forceinline__ double rep_add_lane(double s, double c, int k) {
 // listed (shared) positions and the return run
 template <typename P>
 __device__ __forceinline__ double lane_row_sum(int n, const UnitConsts &K, int nR, int rpos, int nM,
-                                               const P *list) {
+                                               ListRef<P> list) {
   double sum = 0.0;
   int pos = 0;
   bool run_done = nR == 0;
@@ -197,6 +197,21 @@ __device__ __forceinline__ uint64_t wedge_mask_t(const void *base, int64_t off, 
   return mk;
 }
 
+// the same for a list as the pairing routines hold it (plain or folded)
+template <typename P>
+__device__ __forceinline__ uint64_t wedge_mask_l(const ListRef<P> &L, int cnt) {
+  uint64_t mk = 0ull;
+  for (int k = 0; k < cnt; k += 8) {  // eight independent loads per round trip
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (k + u < cnt) ? L[k + u] : 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k + u < cnt) mk |= 1ull << (v[u] & 63);
+  }
+  return mk;
+}
+
 // ---- the pairing loop for ONE slot of a row of any length, by one lane, when "other" is the
 // ONLY underfull class (return and shared slots overfull or absent: what p <= q, q > 1 gives on
 // every row that is not nearly a clique).  Every slot the loop absorbs from `underfull` then has
@@ -213,7 +228,7 @@ __device__ __forceinline__ uint64_t wedge_mask_t(const void *base, int64_t off, 
 // wave, idle outside the wave fallback): kStage independent loads per round trip.
 template <typename P>
 __device__ __forceinline__ int lane_case_a(int n, int pick, double r2, double vR, double vM,
-                                           double vO, int nR, int rpos, int nM, const P *list,
+                                           double vO, int nR, int rpos, int nM, ListRef<P> list,
                                            bool pickR, bool pickM, P *stage, int lane) {
   constexpr int kStage = sizeof(P) == 2 ? 16 : 8;
   int st_hi = -1;  // stage slot u holds list[st_hi - u]; nothing staged yet
@@ -222,11 +237,11 @@ __device__ __forceinline__ int lane_case_a(int n, int pick, double r2, double vR
       st_hi = k;
       P v[kStage];
 #pragma unroll
-      for (int u = 0; u < kStage; ++u) v[u] = (k - u >= 0) ? list[k - u] : (P)0;
+      for (int u = 0; u < kStage; ++u) v[u] = (k - u >= 0) ? list.p[k - u] : (P)0;  // raw: a folded entry is fixed on the way out
 #pragma unroll
       for (int u = 0; u < kStage; ++u) stage[u * 64 + lane] = v[u];
     }
-    return (int)stage[(st_hi - k) * 64 + lane];
+    return list.fix(k, (int)stage[(st_hi - k) * 64 + lane]);
   };
   const int nO = n - nR - nM;
   int km = nM - 1, kr = nR - 1;  // next shared / return slot, descending
@@ -337,7 +352,7 @@ __device__ __forceinline__ double floor_div(double a, double b) {  // 0 <= a, 0 
 // reference loop in Python (0 mismatches in 85 k short and 1 k long rows, 5-20 % returned -1).
 template <typename P>
 __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, const UnitConsts &K,
-                                                int nR, int rpos, int nM, const P *list,
+                                                int nR, int rpos, int nM, ListRef<P> list,
                                                 bool pickR, bool pickM, int lo_pick, int below = -1) {
   const int nO = n - nR - nM;
   const double dn = (double)n;
@@ -427,7 +442,7 @@ __device__ __forceinline__ int lane_case_a_jump(int n, int pick, double r2, cons
 // reference loop in Python (0 mismatches in 180 k short and 5.7 k long rows, 2-10 % return -1).
 template <typename P, bool kNextSlot>
 __device__ __forceinline__ int lane_case_b_jump(int n, int pick, double r2, const UnitConsts &K,
-                                                int nR, int rpos, int nM, const P *list,
+                                                int nR, int rpos, int nM, ListRef<P> list,
                                                 bool pickR, bool pickM, int lo_pick, int below = -1) {
   const int nO = n - nR - nM;
   const double dn = (double)n;
@@ -606,7 +621,7 @@ __device__ __forceinline__ int lane_pairing(int n, uint64_t Rm, uint64_t Mm, int
 // `list` = the shared positions, ascending.
 template <typename P>
 __device__ __forceinline__ int lane_case_b(int n, int pick, double r2, double vR, double vM,
-                                           double vO, int nR, int rpos, int nM, const P *list,
+                                           double vO, int nR, int rpos, int nM, ListRef<P> list,
                                            bool pickR, bool pickM) {
   const int nO = n - nR - nM;
   auto list_lower = [&](int pos) -> int {  // entries of the list below pos
@@ -719,13 +734,13 @@ __device__ __forceinline__ int lane_case_b(int n, int pick, double r2, double vR
 template <typename P>
 struct TwoOnStack {
   int n, nR, rpos, nM, nO, rho, nS;  // nS = nO + nR slots on the mixed stack
-  const P *list;
+  ListRef<P> list;
   __device__ __forceinline__ int list_lower(int pos) const {  // entries of the list below pos
     return list_lower_bound<P>(list, nM, pos);
   }
   // `below`: the number of listed slots below the return position when the caller has it stored
   // (wedge slots), else -1 and the list is searched
-  __device__ __forceinline__ TwoOnStack(int n_, int nR_, int rpos_, int nM_, const P *list_, int below = -1)
+  __device__ __forceinline__ TwoOnStack(int n_, int nR_, int rpos_, int nM_, ListRef<P> list_, int below = -1)
       : n(n_), nR(nR_), rpos(rpos_), nM(nM_), nO(n_ - nR_ - nM_), list(list_) {
     const int mA = nM - (below >= 0 ? below : list_lower(rpos));  // shared slots above the return run
     rho = (n - rpos - nR) - mA;            // "other" slots above the return run
@@ -765,7 +780,7 @@ struct TwoOnStack {
 // Checked against the reference loop in Python (0 mismatches in 70 k short and 1.9 k long rows).
 template <typename P>
 __device__ __forceinline__ int lane_case_a2_jump(int n, int pick, double r2, const UnitConsts &K,
-                                                 int nR, int rpos, int nM, const P *list,
+                                                 int nR, int rpos, int nM, ListRef<P> list,
                                                  bool pickR, bool pickM, int lo_pick, int below = -1) {
   const int nO = n - nR - nM;
   const double dn = (double)n;
@@ -818,7 +833,7 @@ __device__ __forceinline__ int lane_case_a2_jump(int n, int pick, double r2, con
 // split at the return run (three segments: vO, vR, vO).
 template <typename P>
 __device__ __forceinline__ int lane_case_a2(int n, int pick, double r2, double vR, double vM,
-                                            double vO, int nR, int rpos, int nM, const P *list,
+                                            double vO, int nR, int rpos, int nM, ListRef<P> list,
                                             bool pickR, bool pickM, P *stage, int lane) {
   constexpr int kStage = sizeof(P) == 2 ? 16 : 8;
   int st_hi = -1;
@@ -827,11 +842,11 @@ __device__ __forceinline__ int lane_case_a2(int n, int pick, double r2, double v
       st_hi = k;
       P v[kStage];
 #pragma unroll
-      for (int u = 0; u < kStage; ++u) v[u] = (k - u >= 0) ? list[k - u] : (P)0;
+      for (int u = 0; u < kStage; ++u) v[u] = (k - u >= 0) ? list.p[k - u] : (P)0;  // raw: a folded entry is fixed on the way out
 #pragma unroll
       for (int u = 0; u < kStage; ++u) stage[u * 64 + lane] = v[u];
     }
-    return (int)stage[(st_hi - k) * 64 + lane];
+    return list.fix(k, (int)stage[(st_hi - k) * 64 + lane]);
   };
   const TwoOnStack<P> G(n, nR, rpos, nM, list);
   const int nU = G.nS, rho = G.rho;
@@ -907,7 +922,7 @@ __device__ __forceinline__ int lane_case_a2(int n, int pick, double r2, double v
 // Checked against the reference loop in Python (0 mismatches in 76 k short and 3.7 k long rows).
 template <typename P>
 __device__ __forceinline__ int lane_case_b2_jump(int n, int pick, double r2, const UnitConsts &K,
-                                                 int nR, int rpos, int nM, const P *list,
+                                                 int nR, int rpos, int nM, ListRef<P> list,
                                                  bool pickR, bool pickM, int lo_pick, int below = -1) {
   const int nO = n - nR - nM;
   const double dn = (double)n;
@@ -983,7 +998,7 @@ __device__ __forceinline__ int lane_case_b2_jump(int n, int pick, double r2, con
 // not vO: they take the two real operations each).
 template <typename P>
 __device__ __forceinline__ int lane_case_b2(int n, int pick, double r2, double vR, double vM,
-                                            double vO, int nR, int rpos, int nM, const P *list,
+                                            double vO, int nR, int rpos, int nM, ListRef<P> list,
                                             bool pickR, bool pickM) {
   const TwoOnStack<P> G(n, nR, rpos, nM, list);
   const int nV = G.nS, rho = G.rho;
@@ -1093,7 +1108,7 @@ __device__ __forceinline__ int lane_case_a3_jump(int n, int pick, double r2, con
 // alone and the underfull values = runs of vO split by the listed slots (vM).
 template <typename P>
 __device__ __forceinline__ int lane_case_a3(int n, int pick, double r2, double vR, double vM,
-                                            double vO, int nR, int rpos, int nM, const P *list,
+                                            double vO, int nR, int rpos, int nM, ListRef<P> list,
                                             bool pickR, bool pickM) {
   const int nU = n - nR;
   auto urank = [&](int pos) -> int {  // underfull slots above position pos
@@ -1177,7 +1192,7 @@ __device__ __forceinline__ int lane_case_a3(int n, int pick, double r2, double v
 template <typename P>
 __device__ __forceinline__ int lane_pairing_list(int n, int pick, double r2, double vR, double vM,
                                                  double vO, int nR, int rpos, int nM,
-                                                 const P *list) {
+                                                 ListRef<P> list) {
   const bool uR = vR < 1.0, uM = vM < 1.0, uO = vO < 1.0;
   // class of position i (0 return, 1 shared, 2 other); k walks down the list with i
   auto cls_at = [&](int i, int &k) -> int {

@@ -58,7 +58,7 @@ __device__ __forceinline__ double near_floor_div(double T, double step) {
 // "other" is the only underfull class (lane_case_a_jump)
 template <typename P>
 __device__ __forceinline__ int lane_case_a_near(int n, int pick, double r2, const NearVals &V, int nR,
-                                                int rpos, int nM, const P *list, bool pickR, bool pickM,
+                                                int rpos, int nM, ListRef<P> list, bool pickR, bool pickM,
                                                 int lo_pick, int below) {
   const double mg = V.mg;
   const double EM = V.vM - 1.0, ER = V.vR - 1.0, D = 1.0 - V.vO;
@@ -127,7 +127,7 @@ __device__ __forceinline__ int lane_case_a_near(int n, int pick, double r2, cons
 // "other" is the only overfull class (lane_case_b_jump)
 template <typename P>
 __device__ __forceinline__ int lane_case_b_near(int n, int pick, double r2, const NearVals &V, int nR,
-                                                int rpos, int nM, const P *list, bool pickR, bool pickM,
+                                                int rpos, int nM, ListRef<P> list, bool pickR, bool pickM,
                                                 int lo_pick, int below) {
   const int nO = n - nR - nM;
   const double mg = V.mg;
@@ -224,7 +224,7 @@ __device__ __forceinline__ int lane_case_b_near(int n, int pick, double r2, cons
 // return + "other" underfull, the listed slots overfull (lane_case_a2_jump)
 template <typename P>
 __device__ __forceinline__ int lane_case_a2_near(int n, int pick, double r2, const NearVals &V, int nR,
-                                                 int rpos, int nM, const P *list, bool pickR, bool pickM,
+                                                 int rpos, int nM, ListRef<P> list, bool pickR, bool pickM,
                                                  int lo_pick, int below) {
   const double mg = V.mg;
   const double EM = V.vM - 1.0, D = 1.0 - V.vO, DR = 1.0 - V.vR;
@@ -276,7 +276,7 @@ __device__ __forceinline__ int lane_case_a2_near(int n, int pick, double r2, con
 // return + "other" overfull, the listed slots underfull (lane_case_b2_jump)
 template <typename P>
 __device__ __forceinline__ int lane_case_b2_near(int n, int pick, double r2, const NearVals &V, int nR,
-                                                 int rpos, int nM, const P *list, bool pickR, bool pickM,
+                                                 int rpos, int nM, ListRef<P> list, bool pickR, bool pickM,
                                                  int lo_pick, int below) {
   const int nO = n - nR - nM;
   const double mg = V.mg;
@@ -362,7 +362,7 @@ __device__ __forceinline__ int lane_case_a3_near(int n, int pick, double r2, con
 // -1 (the caller adds the row up in the reference's order and replays)
 template <typename P>
 __device__ __forceinline__ int near_listed(int arr, int n, int pick, double r2, const NearVals &V, int nR,
-                                           int rpos, int nM, const P *list, bool isR, bool isM,
+                                           int rpos, int nM, ListRef<P> list, bool isR, bool isM,
                                            int lo_pick, int below) {
   if (arr == 1) return lane_case_a_near<P>(n, pick, r2, V, nR, rpos, nM, list, isR, isM, lo_pick, below);
   if (arr == 2) return lane_case_b_near<P>(n, pick, r2, V, nR, rpos, nM, list, isR, isM, lo_pick, below);
@@ -385,7 +385,7 @@ __device__ __forceinline__ int near_listed(int arr, int n, int pick, double r2, 
 // so a margin of 2e-14 n (vmax + 1) -- LINEAR in n, twelve times the sum -- decides.  -1: replay.
 template <typename P>
 __device__ __forceinline__ int near_listed_exact(int arr, int n, int pick, double r2, const UnitConsts &K,
-                                                 double avg, int nR, int rpos, int nM, const P *list, bool isR,
+                                                 double avg, int nR, int rpos, int nM, ListRef<P> list, bool isR,
                                                  bool isM, int lo_pick, int below) {
   const int nO = n - nR - nM;
   NearVals V;
@@ -405,7 +405,7 @@ constexpr int kNearExactMin = 256;  // rows from this length on try the forms ag
 // replays decide.  `below`: listed slots below the return position, or -1 (searched).
 template <typename P>
 __device__ __forceinline__ int near_step(int n, int pick, double r2, const UnitConsts &K, int nR, int rpos,
-                                         int nM, const P *list, bool isR, bool isM, int lo_pick, int below) {
+                                         int nM, ListRef<P> list, bool isR, bool isM, int lo_pick, int below) {
   const int nO = n - nR - nM;
   // one class only (a leaf's single return edge; a row without shared neighbours when p == q): every
   // value is b / avg = 1 within n 2^-53, and sampling_from_alias returns `pick` on either side of 1.0

@@ -536,7 +536,9 @@ int n2v_walk_wedge_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_s
   // the return run shares a stack with "other" on ordinary rows: q > 1 with p > q, q < 1 with p < q
   const bool alone_under = K.bO <= 1.0 && K.bR >= K.bO, alone_over = K.bO >= 1.0 && K.bR <= K.bO;
   if (g->wedge_wide < 0 || g->wedge_wide > 65536) return N2V_EINVAL;
-  if (g->wedge_slots && g->wedge_wide != 1 && !(g->reserved & 2)) {
+  // (a mixed table -- rows of wedge_wide slots and more -- goes to the slots kernel with FOLDED slots only)
+  if (g->wedge_slots && g->wedge_wide != 1 && !(g->reserved & 2) &&
+      (g->wedge_wide == 0 || (g->reserved2 & N2V_SLOTS_FOLDED))) {
     // the wedge slots are at hand: the list of a step arrives with its hop entry
     auto sk = !K.dyadic    ? n2v::walk_exact_wedge_slots_kernel<2>
               : alone_under ? n2v::walk_exact_wedge_slots_kernel<0>

@@ -347,3 +347,132 @@ extern "C" int n2v_wedge_slots_build(const n2v_graph *g, uint16_t *slots_out, vo
   N2V_HIP_CHECK(hipGetLastError());
   return N2V_OK;
 }
+
+// ---- folded lists and slots for the edges into wide rows (include/n2v_hip.h, n2v_wedge_slots_fold) ----
+namespace n2v {
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void wedge_slots_fold_kernel(n2v_graph g, const uint64_t *__restrict__ fold_off,
+                                                               uint16_t *__restrict__ pos16,
+                                                               uint16_t *__restrict__ slots) {
+  const int T = g.wedge_wide;
+  const int lane = threadIdx.x & 63;
+  const uint32_t *pos32 = reinterpret_cast<const uint32_t *>(g.wedge_pos);
+  const int64_t n_chunks = (g.n_edges + 63) / 64;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  auto fold = [&](int v) -> uint32_t { return (uint32_t)(v < T ? v : v - T) & 0xffffu; };
+  for (int64_t c = wave; c < n_chunks; c += n_waves) {
+    const int64_t e = c * 64 + lane;
+    bool wide = false;
+    int nM = 0, rpos = 0;
+    int64_t off32 = 0;
+    if (e < g.n_edges) {
+      const int64_t x = g.col[e];
+      const int64_t d = g.rowptr[x + 1] - g.rowptr[x];
+      wide = d >= (int64_t)T && d - (int64_t)T <= 65536;
+    }
+    if (wide) {
+      const uint32_t ec = g.edge_classes[e];
+      const uint64_t wraw = g.wedge_off[e];
+      off32 = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
+      rpos = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
+      nM = (int)(ec & N2V_EC_SHARED_MASK);
+      if ((uint32_t)nM == N2V_EC_SHARED_MASK) nM = 0;  // saturated: the walk kernels flag it
+    }
+    const uint32_t upper = rpos >= T ? 1u : 0u;
+    if (wide && nM <= 14) {  // the list lives in the slot: one lane
+      const uint32_t *list = pos32 + off32;
+      uint32_t hw[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) hw[k] = 0;
+      int below = 0, nlow = 0;
+      for (int k = 0; k < nM; ++k) {
+        const int v = (int)list[k];
+        below += v < rpos ? 1 : 0;
+        nlow += v < T ? 1 : 0;
+#pragma unroll
+        for (int u = 0; u < 14; ++u)
+          if (u == k) hw[2 + u] = fold(v);
+      }
+      hw[0] = fold(rpos);
+      hw[1] = (uint32_t)below | ((uint32_t)nlow << 4) | (upper << 8);
+      int4 a, b;
+      a.x = (int)(hw[0] | (hw[1] << 16));
+      a.y = (int)(hw[2] | (hw[3] << 16));
+      a.z = (int)(hw[4] | (hw[5] << 16));
+      a.w = (int)(hw[6] | (hw[7] << 16));
+      b.x = (int)(hw[8] | (hw[9] << 16));
+      b.y = (int)(hw[10] | (hw[11] << 16));
+      b.z = (int)(hw[12] | (hw[13] << 16));
+      b.w = (int)(hw[14] | (hw[15] << 16));
+      reinterpret_cast<int4 *>(slots + e * 16)[0] = a;
+      reinterpret_cast<int4 *>(slots + e * 16)[1] = b;
+    }
+    // a longer list: the whole wave folds it into its place among the 16-bit lists
+    uint64_t todo = __ballot(wide && nM > 14);
+    while (todo != 0ull) {
+      const int src = __ffsll((unsigned long long)todo) - 1;
+      todo &= todo - 1ull;
+      const int64_t e1 = c * 64 + src;
+      const int n1 = __builtin_amdgcn_readlane(nM, src);
+      const int r1 = __builtin_amdgcn_readlane(rpos, src);
+      const int64_t o32 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)off32 >> 32), src) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)off32, src));
+      const uint64_t o16 = fold_off[e1];
+      const uint32_t *list = pos32 + o32;
+      uint16_t *out = pos16 + o16;
+      int below = 0, nlow = 0;
+      for (int k = lane; k < n1; k += 64) {
+        const int v = (int)list[k];
+        below += v < r1 ? 1 : 0;
+        nlow += v < T ? 1 : 0;
+        out[k] = (uint16_t)fold(v);
+      }
+      below = wave_sum_i32(below);
+      nlow = wave_sum_i32(nlow);
+      uint32_t piv = 0;
+      if (lane < 8) piv = fold((int)list[((int64_t)(lane + 1) * n1) / 9]);
+      uint32_t pv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pv[k] = (uint32_t)__builtin_amdgcn_readlane((int)piv, k);
+      if (lane == 0) {
+        const uint32_t up1 = r1 >= T ? 1u : 0u;
+        int4 a, b;
+        a.x = (int)(fold(r1) | (((uint32_t)below & 0xffffu) << 16));
+        a.y = (int)(((uint32_t)nlow & 0xffffu) |
+                    ((up1 | ((((uint32_t)below >> 16) & 0xfu) << 4) | ((((uint32_t)nlow >> 16) & 0xfu) << 8)) << 16));
+        a.z = (int)(uint32_t)(o16 & 0xffffffffull);
+        a.w = (int)(uint32_t)(o16 >> 32);
+        b.x = (int)(pv[0] | (pv[1] << 16));
+        b.y = (int)(pv[2] | (pv[3] << 16));
+        b.z = (int)(pv[4] | (pv[5] << 16));
+        b.w = (int)(pv[6] | (pv[7] << 16));
+        reinterpret_cast<int4 *>(slots + e1 * 16)[0] = a;
+        reinterpret_cast<int4 *>(slots + e1 * 16)[1] = b;
+      }
+    }
+  }
+}
+}  // namespace n2v
+
+extern "C" int n2v_wedge_slots_fold(const n2v_graph *g, const uint64_t *fold_off, void *wedge_pos_rw, uint16_t *slots,
+                                    void *stream) {
+  if (!g || g->n_edges < 0) return N2V_EINVAL;
+  if (g->n_edges == 0) return N2V_OK;
+  if (!g->rowptr || !g->col || !g->edge_classes || !g->wedge_off || !g->wedge_pos || !fold_off || !slots ||
+      g->wedge_wide < 2 || g->wedge_wide > 65536 || wedge_pos_rw != g->wedge_pos)
+    return N2V_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(slots) & 31u) != 0) return N2V_EINVAL;
+  int64_t blocks = ((g->n_edges + 63) / 64 + 3) / 4;
+  const int64_t cap = 8 * n2v::resident_blocks((const void *)n2v::wedge_slots_fold_kernel, 256, 0);
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(n2v::wedge_slots_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *g,
+                     fold_off, reinterpret_cast<uint16_t *>(wedge_pos_rw), slots);
+  N2V_HIP_CHECK(hipGetLastError());
+  return N2V_OK;
+}

@@ -35,7 +35,7 @@ __device__ uint32_t *n2v_big_words;
 // closed form: every pairing is replayed run by run in fp64.
 template <typename P, int kMode>
 __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, const UnitConsts &K,
-                                           double avg, int nR, int rpos, int nM, const P *list,
+                                           double avg, int nR, int rpos, int nM, ListRef<P> list,
                                            bool isR, bool isM, int lo_pick, P *stage, int lane,
                                            int below = -1) {
   constexpr bool kShared = kMode == 1 || kMode == 2;
@@ -88,7 +88,7 @@ __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, 
   if (n <= 64) {  // a short row: the two stacks as bit masks
     uint64_t Rm = 0ull;
     if (nR) Rm = ((nR >= 64) ? ~0ull : ((1ull << nR) - 1ull)) << rpos;
-    const uint64_t Mm = wedge_mask_t<P>(list, 0, nM);
+    const uint64_t Mm = wedge_mask_l<P>(list, nM);
     return lane_pairing(n, Rm, Mm, pick, r2, vR, vM, vO);
   }
   if (arr == 1) return lane_case_a<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM, stage, lane);
@@ -107,7 +107,7 @@ __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, 
 // the step replayed (pair_listed) somewhere else.  kMode 0, 1, 3 (dyadic p, q).
 template <typename P, int kMode>
 __device__ __forceinline__ int jump_listed(int arr, int n, int pick, double r2, const UnitConsts &K,
-                                           int nR, int rpos, int nM, const P *list, bool isR,
+                                           int nR, int rpos, int nM, ListRef<P> list, bool isR,
                                            bool isM, int lo_pick, int below = -1) {
   static_assert(kMode != 2, "values that are not dyadic have no closed form");
   if (arr == 1) return lane_case_a_jump<P>(n, pick, r2, K, nR, rpos, nM, list, isR, isM, lo_pick, below);
@@ -135,7 +135,7 @@ __device__ __forceinline__ int jump_listed(int arr, int n, int pick, double r2, 
 
 // what a kernel needs of (p, q) beyond UnitConsts, computed once
 struct StepFlags {
-  bool need_mem, always_pair, merge_r, w_wide, inline_rpos;
+  bool need_mem, always_pair, merge_r, w_wide, inline_rpos, folded;
 };
 __device__ __forceinline__ StepFlags step_flags(const n2v_graph &g, const UnitConsts &K, double q) {
   StepFlags f;
@@ -144,6 +144,7 @@ __device__ __forceinline__ StepFlags step_flags(const n2v_graph &g, const UnitCo
   f.merge_r = K.bR == K.bO;    // p == q: the return slot IS an "other" slot (:223-230)
   f.w_wide = g.wedge_wide == 1;  // (a mixed table, wedge_wide >= 2: by the row, in wedge_step)
   f.inline_rpos = (g.reserved2 & N2V_HOPS_INLINE_RPOS) != 0;  // (the slots kernel's hop table only)
+  f.folded = (g.reserved2 & N2V_SLOTS_FOLDED) != 0;  // the edges into wide rows have folded lists and slots
   return f;
 }
 
@@ -187,6 +188,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
                                           uint32_t *stage, int lane, uint32_t *status,
                                           uint16_t *lds_list) {
   constexpr bool kShared = kMode == 1 || kMode == 2;
+  bool folded = false;  // this lane stands on a wide row and reads a folded slot / list
   if constexpr (kSlots) {
     // mixed wedge table (g.wedge_wide = T >= 2): the edges into a row of T entries or more have
     // uint32 lists and no slot -- the step of a walker standing on such a row goes through wedge_off
@@ -197,7 +199,17 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
       h = load_hop(g.hops + vb + pk);
       return pk;
 #endif
-      return wedge_step_wide<kMode, kJumpOnly>(g, K, F, u1, u2, s, vb, n, e_prev, ec_prev, h, stage, lane, status);
+      // (round 6) a wide row: its edges have FOLDED lists and slots (ListRef, n2v_wedge_slots_fold) and it takes the
+      // step below like every other row.  (The launcher gives a mixed table without folded slots to the kernel that
+      // reads wedge_off; rounds 4 - 5 stepped such a row here through a second, 32-bit instance of this function,
+      // wedge_step_wide: every wave with one lane on a wide row executed both.)
+      if (!(F.folded && n - g.wedge_wide <= 65536)) {  // slots that do not belong to this graph
+        atomicOr(status, N2V_ST_RANGE);
+        const int pk = pick_index(u1, n);
+        h = load_hop(g.hops + vb + pk);
+        return pk;
+      }
+      folded = true;
     }
   }
   const int pick = pick_index(u1, n);
@@ -217,6 +229,27 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
   if (inl) sa.x = (int)(ec_prev & 0xffffu);  // halfword 0: the return position (16-bit positions), 1: below = 0
   const uint16_t *slot = nullptr;
   if constexpr (kSlots) slot = reinterpret_cast<const uint16_t *>(g.wedge_slots) + e_prev * 16;
+  // what the slot says once its first 16 bytes are in `sa`.  A FOLDED slot (n2v_wedge_slots_fold: the edge leads into
+  // a wide row) packs three more numbers: whether the return position lies in the upper part, the entries of the list
+  // in the lower part (ListRef::nlow), and the high bits of counts that a list of up to 2^20 entries needs --
+  // a list that lives in the slot (<= 14 entries): halfword [1] = below | nlow << 4 | upper << 8; a longer one:
+  // [1] = below, [2] = nlow (low 16 bits each), [3] = upper | (below >> 16) << 4 | (nlow >> 16) << 8
+  const bool fshort = fM <= (uint32_t)kSlotShort;
+  auto slot_rpos = [&]() -> int {
+    int r = (int)((uint32_t)sa.x & 0xffffu);
+    if (folded && (((fshort ? (uint32_t)sa.x >> 24 : (uint32_t)sa.y >> 16) & 1u) != 0u)) r += g.wedge_wide;
+    return r;
+  };
+  auto slot_below = [&]() -> int {
+    uint32_t b = (uint32_t)sa.x >> 16;
+    if (folded) b = fshort ? (b & 0xfu) : (b | ((((uint32_t)sa.y >> 20) & 0xfu) << 16));
+    return (int)b;
+  };
+  auto slot_nlow = [&]() -> int {
+    if (!folded) return 0x7fffffff;
+    return fshort ? (int)(((uint32_t)sa.x >> 20) & 0xfu)
+                  : (int)(((uint32_t)sa.y & 0xffffu) | ((((uint32_t)sa.y >> 24) & 0xfu) << 16));
+  };
   // (not dyadic: the steps past the quick accept need the return position and the list -- for the
   // closed forms with margins, else for the row sum --: fetched there if not here)
   if (!inl && counts_ok &&
@@ -251,7 +284,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
   const int nR = F.merge_r ? 0 : (int)fR, nM = F.need_mem ? (int)fM : 0, nO = n - nR - nM;
   int64_t w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
   // (rows are sorted by neighbour: the slots that lead back to s are one run)
-  const int rp0 = (int)((uint32_t)sa.x & 0xffffu);
+  const int rp0 = slot_rpos();
   const bool isR = defer ? (nR > 0 && pick >= rp0 && pick < rp0 + nR) : (!F.merge_r && h.col == s);
   bool isM = false;
   int lo_pick = 0;  // entries of the edge's list below `pick`
@@ -261,7 +294,8 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
 #endif
   if (F.need_mem && !isR && nM > 0) {  // :226
     if constexpr (kSlots)
-      lo_pick = slot_lower(sa, sb, nM, pick, reinterpret_cast<const uint16_t *>(g.wedge_pos), isM);
+      lo_pick = slot_lower(sa, sb, nM, pick, reinterpret_cast<const uint16_t *>(g.wedge_pos), isM, slot_nlow(),
+                           g.wedge_wide);
     else
       lo_pick = wedge_lower(g.wedge_pos, w_off, nM, pick, w_wide, isM);
   }
@@ -296,8 +330,9 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
           if (nM > kSlotShort)
             nlist = reinterpret_cast<const uint16_t *>(g.wedge_pos) +
                     ((uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32));
-          const int res = near_step<uint16_t>(n, pick, r2, K, nR, (int)((uint32_t)sa.x & 0xffffu), nM, nlist, isR,
-                                              isM, lo_pick, (int)((uint32_t)sa.x >> 16));
+          const int res = near_step<uint16_t>(n, pick, r2, K, nR, slot_rpos(), nM,
+                                              ListRef<uint16_t>(nlist, slot_nlow(), g.wedge_wide), isR, isM, lo_pick,
+                                              slot_below());
           if (res >= 0) {
             if (defer || res != pick) h = load_hop(g.hops + vb + res);
             return res;
@@ -327,7 +362,8 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
           row[6] = (uint32_t)sb.w;
           sum_list = lds_list;
         }
-        avg = lane_row_sum<uint16_t>(n, K, nR, (int)((uint32_t)sa.x & 0xffffu), nM, sum_list) / (double)n;
+        avg = lane_row_sum<uint16_t>(n, K, nR, slot_rpos(), nM, ListRef<uint16_t>(sum_list, slot_nlow(), g.wedge_wide)) /
+              (double)n;
       } else {
         // through wedge_off (the wide rows of a mixed table): the same two stages on the list in memory
         if (!w_loaded) {
@@ -395,7 +431,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
     }
     int w_rpos;
     if constexpr (kSlots)
-      w_rpos = (int)((uint32_t)sa.x & 0xffffu);
+      w_rpos = slot_rpos();
     else
       w_rpos = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
     // the stacks: 1 = "other" alone underfull, 2 = "other" alone overfull, 3 = return + "other"
@@ -408,12 +444,13 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
     else if (kShared && uO && nR && !uR && nM && uM) arr = 5;
     if constexpr (kSlots) {
       // entries of the list below the return position (stored: saves the routines a search)
-      const int w_below = (int)((uint32_t)sa.x >> 16);
+      const int w_below = slot_below();
       // the list as the pairing routines read it: inside the slot, or in wedge_pos
-      const uint16_t *list = slot + 2;
+      const uint16_t *list_p = slot + 2;
       if (nM > kSlotShort)
-        list = reinterpret_cast<const uint16_t *>(g.wedge_pos) +
-               ((uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32));
+        list_p = reinterpret_cast<const uint16_t *>(g.wedge_pos) +
+                 ((uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32));
+      const ListRef<uint16_t> list(list_p, slot_nlow(), g.wedge_wide);
       if constexpr (kJumpOnly) {
         idx = jump_listed<uint16_t, kMode>(arr, n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick,
                                            w_below);
@@ -438,7 +475,8 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
           row[5] = (uint32_t)sb.z;
           row[6] = (uint32_t)sb.w;
           if constexpr (kMode != 2)
-            idx = jump_listed<uint16_t, kMode>(arr, n, pick, r2, K, nR, w_rpos, nM, lds_list, isR, isM,
+            idx = jump_listed<uint16_t, kMode>(arr, n, pick, r2, K, nR, w_rpos, nM,
+                                               ListRef<uint16_t>(lds_list, slot_nlow(), g.wedge_wide), isR, isM,
                                                lo_pick, w_below);
           done = idx >= 0;
         }

@@ -87,6 +87,7 @@ class DeviceGraph:
         self.wedge_mode = 0  # n2v_graph.wedge_wide: 0 16-bit lists, 1 32-bit, T >= 2 mixed (build_wedges)
         self.wedge_tried = False  # randomwalk.walk tries to build the table once
         self.wedge_slots: Optional[torch.Tensor] = None  # int16 [E, 16]: n2v_wedge_slots_build
+        self.slots_folded = False  # the slots of the edges into wide rows are folded slots (n2v_wedge_slots_fold)
         self.hops_inline_rpos = False  # the hop table's class words carry return positions (slots kernel)
         self._inline_ok = None  # (edge_classes tensor, every return count < 128): can_inline_rpos()
         # the degree-ranked form (build_ranked): 4-byte entries for p = q = 1 walks
@@ -203,6 +204,7 @@ class DeviceGraph:
         g.hops8_tried, g.wedge_tried, g.rank_tried = self.hops8_tried, self.wedge_tried, self.rank_tried
         g.hops_inline_rpos = self.hops_inline_rpos
         g.wedge_mode = self.wedge_mode
+        g.slots_folded = self.slots_folded
         return g
 
     def c_struct(self) -> _lib.Graph:
@@ -221,7 +223,9 @@ class DeviceGraph:
                           0 if self.hops8 is None else self.hops8.data_ptr(),
                           self.hops8_bits[0], self.hops8_bits[1],
                           0 if self.hops8_rowptr is None else self.hops8_rowptr.data_ptr(),
-                          self.hops8_shift, int(self.hops_inline_rpos and self.hops is not None),
+                          self.hops8_shift,
+                          int(self.hops_inline_rpos and self.hops is not None)
+                          | (2 if self.slots_folded and self.wedge_slots is not None else 0),  # N2V_SLOTS_FOLDED
                           0 if self.wedge_slots is None else self.wedge_slots.data_ptr(),
                           *self._rank_fields())
 
@@ -301,7 +305,7 @@ class DeviceGraph:
     WEDGE_WIDE_FROM = 65536  # rows of this many entries or more need 32-bit positions
 
     def build_wedges(self, max_bytes: Optional[int] = None, wide: Optional[bool] = None,
-                     slots: bool = True, wide_from: Optional[int] = None) -> "DeviceGraph":
+                     slots: bool = True, wide_from: Optional[int] = None, fold: bool = True) -> "DeviceGraph":
         """Shared-position lists (n2v_wedge_build): for every edge (s -> v) the positions in
         N(v) of the neighbours v shares with s -- what generate_edge_alias_tables recomputes by a
         set intersection at every step (randomwalk.py:226), stored once.  8 bytes per edge + 2
@@ -323,6 +327,7 @@ class DeviceGraph:
             self.build_edge_classes()
         self.wedge_off = self.wedge_pos = self.wedge_slots = None
         self.wedge_mode = 0
+        self.slots_folded = False
         if self.n_edges == 0 or int(self.degrees().max()) >= self.HOP_MAX_DEGREE:
             return self
         counts = (self.edge_classes & 0xffffff).to(torch.int64)
@@ -345,6 +350,18 @@ class DeviceGraph:
             max_bytes = torch.cuda.mem_get_info(self.device)[0] // 2
         if need > max_bytes or total >= (1 << 40):
             return self
+        # folded copies (n2v_wedge_slots_fold) of the lists of more than 14 entries of the edges into rows of
+        # t_from .. t_from + 65536 entries: 2 bytes per entry behind the 32-bit lists, when they fit as well
+        fold_e, fold_total = None, 0
+        # (ALL wide rows must fold -- a row of more than t_from + 65536 entries leaves the table as it is, and the
+        # walk to the kernel that reads wedge_off: the slots kernel has no 32-bit instance of the step any more)
+        if mode >= 2 and slots and fold and int(deg.max()) - t_from <= 65536:
+            fold_e = wide_e & (counts > 14)
+            fold_total = int(counts[fold_e].sum())
+            if need + 2 * fold_total > max_bytes:
+                fold_e, fold_total = None, 0
+            need += 2 * fold_total
+        fold_off = None
         if mode >= 2:
             # the 16-bit lists first (offsets in 2-byte units), then the 32-bit lists of the edges into
             # wide rows (offsets in 4-byte units from the same base)
@@ -355,11 +372,15 @@ class DeviceGraph:
             off32 = torch.cumsum(c32, 0) - c32 + base32
             off = torch.where(wide_e, off32, off)
             del c16, c32, off32
-            pos = torch.empty(2 * (base32 + max(total_wide, 1)), dtype=torch.int16, device=self.device)
+            pos = torch.empty(2 * (base32 + max(total_wide, 1)) + fold_total, dtype=torch.int16, device=self.device)
+            if fold_e is not None:
+                fc = torch.where(fold_e, counts, torch.zeros_like(counts))
+                fold_off = torch.cumsum(fc, 0) - fc + 2 * (base32 + max(total_wide, 1))
+                del fc
         else:
             off = torch.cumsum(counts, 0) - counts  # exclusive prefix sum; becomes wedge_off in place
             pos = torch.empty(max(total, 1), dtype=torch.int32 if mode == 1 else torch.int16, device=self.device)
-        del counts, wide_e
+        del counts, wide_e, fold_e
         status = torch.zeros(4, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             rc = L.n2v_wedge_build(self.c_struct(), off.data_ptr(), off.data_ptr(), pos.data_ptr(),
@@ -381,6 +402,14 @@ class DeviceGraph:
                 fits = need + 32 * self.n_edges <= max_bytes
             if fits:
                 self.build_wedge_slots()
+            if self.wedge_slots is not None and mode >= 2 and fold_off is not None:
+                # the edges into wide rows: folded lists and slots, so that the slots kernel steps those rows with
+                # the instructions of every other row (the 32-bit lists stay for the other kernels)
+                with torch.cuda.device(self.device):
+                    rc = L.n2v_wedge_slots_fold(self.c_struct(), fold_off.data_ptr(), pos.data_ptr(),
+                                                self.wedge_slots.data_ptr(), _lib.current_stream_ptr())
+                _lib.check(rc, "n2v_wedge_slots_fold")
+                self.slots_folded = True
         return self
 
     def build_wedge_slots(self) -> "DeviceGraph":
@@ -409,6 +438,8 @@ class DeviceGraph:
             return False
         if self.wedge_pos is None or self.wedge_mode == 1:
             return False
+        if self.wedge_mode >= 2 and not self.slots_folded:
+            return False  # a mixed table without folded slots walks through wedge_off: the plain hop table
         if self._inline_ok is None or self._inline_ok[0] is not self.edge_classes:
             # one pass over the class words and a host sync: once per table, not per walk() call
             ok = self.n_edges == 0 or int((self.edge_classes >> 24 & 0xff).max()) < 128

@@ -113,9 +113,16 @@ while time.time() - t0 < budget:
     wlanes = bool(rng.random() < 0.5)
     # (with or without the wave kernel that decides long rows by margins)
     rw.WEIGHTED_LANES_MARGINS = bool(rng.random() < 0.7)
-    got, gv = rw.walk(g, starts, nw, wl, p, q, seed, use_edge_classes=uec,
-                      use_workspace=bool(rng.random() < 0.3), use_wedge_slots=bool(rng.random() < 0.7),
-                      use_weighted_lanes=wlanes)
+    try:
+        got, gv = rw.walk(g, starts, nw, wl, p, q, seed, use_edge_classes=uec,
+                          use_workspace=bool(rng.random() < 0.3), use_wedge_slots=bool(rng.random() < 0.7),
+                          use_weighted_lanes=wlanes)
+    except Exception:
+        print("RAISED", dict(kind=kind, nv=nv, ne=len(src), weights=wk, p=p, q=q, nw=nw, wl=wl, seed=seed,
+                             maxdeg=int(deg.max()), unit=g.unit_weights, edge_classes=uec, wide_from=g.WEDGE_WIDE_FROM,
+                             wedge_mode=g.wedge_mode, slots=g.wedge_slots is not None, folded=g.slots_folded,
+                             inline=g.hops_inline_rpos, weighted_lanes=wlanes), flush=True)
+        raise
     want, wv = n2v_oracle.random_walk(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.w.cpu().numpy(),
                                       starts.cpu().numpy(), nw, wl, p, q, seed, n_threads=THREADS)
     ok = np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy(), want)

@@ -22,7 +22,8 @@ def test_header_declares_the_expected_entry_points():
                  "n2v_mem_probe", "n2v_corpus_count", "n2v_corpus_index", "n2v_hops8_build",
                  "n2v_partition_step", "n2v_gather_rows", "n2v_gather_wedges",
                  "n2v_partition_route", "n2v_partition_group", "n2v_walk_ws",
-                 "n2v_walk_workspace_bytes", "n2v_delta_reduce", "n2v_wedge_slots_build", "n2v_sgns_job_alpha", "n2v_rank_hops_build", "n2v_partition_forward"):
+                 "n2v_walk_workspace_bytes", "n2v_delta_reduce", "n2v_wedge_slots_build", "n2v_sgns_job_alpha", "n2v_rank_hops_build", "n2v_partition_forward",
+                 "n2v_wedge_slots_fold"):
         assert want in names
 
 
@@ -37,7 +38,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert sorted(_lib.SYMBOLS) == _declared()
     lib.n2v_abi_version.restype = ctypes.c_int
-    assert lib.n2v_abi_version() == _lib.ABI_VERSION == 14
+    assert lib.n2v_abi_version() == _lib.ABI_VERSION == 15
     lib.n2v_status_string.restype = ctypes.c_char_p
     assert lib.n2v_status_string(-1) == b"invalid argument"
 

@@ -118,7 +118,34 @@ def test_mixed_wedge_table_widens_only_the_lists_into_wide_rows():
         if n_ret:
             assert rp == want_rpos[e], e
     slots = g.wedge_slots.cpu().numpy().astype(np.uint16).astype(np.int64)
-    assert not slots[wide_e].any()  # no slot for an edge into a wide row
+    # the edges into wide rows have FOLDED slots (n2v_wedge_slots_fold, round 6): a position below T as it is, one
+    # from T on minus T; `nlow` entries lie below T; lists of more than 14 entries have a folded 16-bit copy behind
+    # the 32-bit lists, and its offset and pivots in the slot
+    assert g.slots_folded and (g.c_struct().reserved2 & 2)
+    fold = lambda v: v if v < T else v - T
+    n_long_folded = 0
+    for e in np.nonzero(wide_e)[0]:
+        lst, n_ret = want_pos[e], int(ec[e] >> 24)
+        rp = want_rpos[e] if n_ret else int(off[e] >> np.uint64(40))
+        below, nlow, upper = sum(1 for x in lst if x < rp), sum(1 for x in lst if x < T), int(rp >= T)
+        assert slots[e, 0] == fold(rp), e
+        if len(lst) <= 14:
+            assert slots[e, 1] == below | nlow << 4 | upper << 8, e
+            assert slots[e, 2:2 + len(lst)].tolist() == [fold(x) for x in lst], e
+        else:
+            assert slots[e, 1] == below & 0xffff and slots[e, 2] == nlow & 0xffff, e
+            assert slots[e, 3] == upper | (below >> 16) << 4 | (nlow >> 16) << 8, e
+            o = int(slots[e, 4] | (slots[e, 5] << 16) | (slots[e, 6] << 32) | (slots[e, 7] << 48))
+            assert o >= 2 * lo32 and pos16[o:o + len(lst)].tolist() == [fold(x) for x in lst], e
+            assert slots[e, 8:16].tolist() == [fold(lst[((k + 1) * len(lst)) // 9]) for k in range(8)], e
+            n_long_folded += 1
+    assert n_long_folded > 100
+    # fold=False: the mixed table as rounds 4 - 5 built it -- no slot for an edge into a wide row, and the walks go
+    # through the kernel that reads wedge_off
+    g2 = DeviceGraph.from_edges(src, dst, None, n_vertices=nv, device="cuda")
+    g2.build_wedges(wide_from=T, fold=False)
+    assert not g2.slots_folded and not (g2.c_struct().reserved2 & 2)
+    assert not g2.wedge_slots.cpu().numpy()[wide_e].any()
     for e in np.nonzero(~wide_e)[0][::7]:
         lst, n_ret = want_pos[e], int(ec[e] >> 24)
         rp = want_rpos[e] if n_ret else int(off[e] >> np.uint64(40))
@@ -162,15 +189,25 @@ def test_walks_over_a_mixed_wedge_table_equal_the_oracle(wide_from):
     g.build_wedges(wide_from=wide_from)
     g.wedge_tried = True
     assert g.wedge_mode == wide_from and g.wedge_slots is not None
+    # the same table without folded slots (what a graph gets whose folded copies do not fit): the kernel that reads
+    # wedge_off walks it
+    g_plain = DeviceGraph.from_edges(np.concatenate([src, dst]), np.concatenate([dst, src]), None, n_vertices=nv,
+                                     device="cuda")
+    g_plain.build_wedges(wide_from=wide_from, fold=False)
+    g_plain.wedge_tried = True
+    assert not g_plain.slots_folded and g_plain.wedge_slots is not None
     start = rw.start_vertices(g)
     rowptr, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
     for p, q in PQ_MIXED:
         want, wv = n2v_oracle.random_walk(rowptr, col, None, start.cpu().numpy(), 2, 25, p, q, 77, n_threads=8)
+        assert g.slots_folded  # the slots kernel steps the wide rows through folded lists
         for kw in ({}, {"use_wedge_slots": False}, {"use_wedge_kernel": False}, {"use_workspace": True}):
             got, gv = rw.walk(g, start, 2, 25, p, q, 77, **kw)
             assert g.wedge_mode == wide_from  # (the table was not rebuilt)
             assert np.array_equal(gv.cpu().numpy(), wv), (p, q, kw)
             assert np.array_equal(got.cpu().numpy(), want), (p, q, kw)
+        got, gv = rw.walk(g_plain, start, 2, 25, p, q, 77)
+        assert np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(got.cpu().numpy(), want), (p, q, "no fold")
 
 
 def test_a_row_of_more_than_65535_entries_keeps_the_slots_kernel():
