@@ -144,6 +144,14 @@ typedef struct n2v_graph {
                                        composes rank_vertex into its own per-token lookup, as
                                        n2v_corpus_index's index_of) */
   int32_t reserved3;                /* 0 */
+  /* Row sums of the tables of the steps into LONG rows, for ONE (p, q) whose 1/p or 1/q is not dyadic
+   * (n2v_edge_row_sums_build; ABI 15), or NULL / 0.  The walk kernels ignore the table unless row_sums_p / _q are
+   * the p, q of the walk. */
+  const double *row_sums;           /* [n_edges]; valid for the edges into rows of >= row_sums_from entries */
+  double row_sums_p;
+  double row_sums_q;
+  int32_t row_sums_from;
+  int32_t reserved4;                /* 0 */
 } n2v_graph;
 
 /* edge_classes[e] for e = (s -> v): bits 0..23 = number of entries x of N(v) with
@@ -287,6 +295,20 @@ int n2v_wedge_slots_build(const n2v_graph *g, uint16_t *slots_out, void *stream)
  * the slots kernel use the result; without the bit the same walks come out of the 32-bit instance. */
 int n2v_wedge_slots_fold(const n2v_graph *g, const uint64_t *fold_off, void *wedge_pos_rw, uint16_t *slots,
                          void *stream);
+
+/* Row sums for values that are not dyadic (ABI 15).  generate_alias_tables divides every weight of the step's table
+ * by sum(node_weights) / n (randomwalk.py:172-173), a sum rounded at every addition in slot order.  With dyadic 1/p,
+ * 1/q it is an integer combination of the edge's class counts; otherwise a step whose decision is closer to its
+ * threshold than the rounding of that sum (1 % of the steps on long rows) has to add the row up in the reference's
+ * order, run by run between the shared positions: O(list) dependent operations by ONE lane while its wave waits
+ * (cfg 4 trimmed at 100 000, (3, 0.7): 102 of 149 ms per launch, profiles/r12c_*).  The sum depends on the EDGE walked
+ * and on (p, q) only: this pass computes it once for every edge into a row of >= min_row entries -- the same routine,
+ * hence the same bits -- and a walk at that (p, q) reads it with one gather.
+ *   edges [k]: the edges to compute (the caller lists those into rows of >= min_row entries, longest lists first so
+ *   that the lanes of a wave finish together); sums_out [n_edges] (entries of other edges are not written).
+ * g: unit weights, edge_classes, wedge_off, wedge_pos set.  Put sums_out, p, q, min_row into n2v_graph.row_sums*. */
+int n2v_edge_row_sums_build(const n2v_graph *g, double p, double q, const int64_t *edges, int64_t k,
+                            double *sums_out, void *stream);
 
 /* Search index for N2V_WALK_FAST: the last id of every aligned block of 32 entries of
  * `col` (one 128-byte line).  Inside a sorted row the block ends ascend, so a

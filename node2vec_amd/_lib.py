@@ -27,7 +27,7 @@ SYMBOLS = ("n2v_abi_version", "n2v_status_string", "n2v_device_count", "n2v_alia
            "n2v_partition_route", "n2v_partition_group", "n2v_walk_ws", "n2v_walk_workspace_bytes",
            "n2v_delta_reduce", "n2v_wedge_slots_build", "n2v_sgns_job_alpha", "n2v_rank_hops_build", "n2v_partition_forward",
            "n2v_sgns_hogwild_waves", "n2v_walk_weighted_step", "n2v_partition_forward_boxes", "n2v_walk_weighted_keys",
-           "n2v_wedge_slots_fold")
+           "n2v_wedge_slots_fold", "n2v_edge_row_sums_build")
 
 
 class WeightedHubs(C.Structure):
@@ -49,7 +49,9 @@ class Graph(C.Structure):
                 ("wedge_slots", C.c_void_p), ("rank_hops", C.c_void_p), ("rank_of", C.c_void_p),
                 ("rank_vertex", C.c_void_p), ("rank_head", C.c_void_p), ("rank_class_first", C.c_void_p),
                 ("rank_class_off", C.c_void_p), ("rank_head_n", C.c_int32), ("rank_classes", C.c_int32),
-                ("rank_emit", C.c_int32), ("reserved3", C.c_int32)]
+                ("rank_emit", C.c_int32), ("reserved3", C.c_int32),
+                ("row_sums", C.c_void_p), ("row_sums_p", C.c_double), ("row_sums_q", C.c_double),
+                ("row_sums_from", C.c_int32), ("reserved4", C.c_int32)]
 
 
 class SgnsParams(C.Structure):
@@ -99,6 +101,9 @@ def load():
     L.n2v_wedge_slots_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p]
     L.n2v_wedge_slots_fold.restype = C.c_int
     L.n2v_wedge_slots_fold.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.n2v_edge_row_sums_build.restype = C.c_int
+    L.n2v_edge_row_sums_build.argtypes = [C.POINTER(Graph), C.c_double, C.c_double, C.c_void_p, C.c_int64, C.c_void_p,
+                                          C.c_void_p]
     L.n2v_hops_build.restype = C.c_int
     L.n2v_hops_build.argtypes = [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p]
     L.n2v_hops8_build.restype = C.c_int

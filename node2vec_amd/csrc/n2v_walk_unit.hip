@@ -1693,6 +1693,22 @@ static bool unit_consts(double p, double q, n2v::UnitConsts &K, bool &dyadic) {
   return dyadic || ordinary;
 }
 
+int n2v_edge_row_sums_launch(const n2v_graph *g, const n2v::UnitConsts &K, double q, const int64_t *edges, int64_t k,
+                             double *sums_out, void *stream);
+
+extern "C" int n2v_edge_row_sums_build(const n2v_graph *g, double p, double q, const int64_t *edges, int64_t k,
+                                       double *sums_out, void *stream) {
+  if (!g || k < 0 || p == 0.0 || q == 0.0) return N2V_EINVAL;
+  if (k == 0) return N2V_OK;
+  if (g->w || g->w64 || !g->rowptr || !g->col || !g->edge_classes || !g->wedge_off || !g->wedge_pos || !edges ||
+      !sums_out || g->wedge_wide < 0 || g->wedge_wide > 65536)
+    return N2V_EINVAL;
+  n2v::UnitConsts K;
+  bool dyadic = false;
+  if (!unit_consts(p, q, K, dyadic)) return N2V_EINVAL;
+  return n2v_edge_row_sums_launch(g, K, q, edges, k, sums_out, stream);
+}
+
 // returns 1 when the unit-weight kernel applies (and was launched), 0 when the caller
 // must use the generic kernel, < 0 on error
 // workspace n2v_walk_ws can use for (g, p, q): the record lists of n2v_walk_wedge2.hip, 0 = none

@@ -539,6 +539,10 @@ int n2v_walk_wedge_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_s
   // (a mixed table -- rows of wedge_wide slots and more -- goes to the slots kernel with FOLDED slots only)
   if (g->wedge_slots && g->wedge_wide != 1 && !(g->reserved & 2) &&
       (g->wedge_wide == 0 || (g->reserved2 & N2V_SLOTS_FOLDED))) {
+    n2v_graph gs = *g;  // the table of row sums counts for the (p, q) it was built for only
+    if (K.dyadic || gs.row_sums == nullptr || !(gs.row_sums_p == p && gs.row_sums_q == q) || gs.row_sums_from < 1)
+      gs.row_sums = nullptr;
+    g = &gs;
     // the wedge slots are at hand: the list of a step arrives with its hop entry
     auto sk = !K.dyadic    ? n2v::walk_exact_wedge_slots_kernel<2>
               : alone_under ? n2v::walk_exact_wedge_slots_kernel<0>
@@ -554,6 +558,9 @@ int n2v_walk_wedge_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_s
     return 1;
   }
   if (g->reserved2 & N2V_HOPS_INLINE_RPOS) return N2V_EINVAL;  // that hop table is the slots kernel's
+  n2v_graph gp = *g;
+  gp.row_sums = nullptr;  // (this kernel adds every row up itself)
+  g = &gp;
   auto kernel = !K.dyadic    ? n2v::walk_exact_wedge_kernel<2>
                 : alone_under ? n2v::walk_exact_wedge_kernel<0>
                 : alone_over  ? n2v::walk_exact_wedge_kernel<3>
@@ -590,4 +597,48 @@ int n2v_partition_step_wedge_launch(const int64_t *rowptr, const int32_t *col, i
                      seed, next_out, edge_out, status);
   if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
   return 1;
+}
+
+// ---- row sums of the tables of the steps into long rows, for one (p, q) that is not dyadic (include/n2v_hip.h,
+// n2v_edge_row_sums_build): lane_row_sum -- the routine a step of walk_exact_wedge_slots_kernel<2> would run -- once
+// per edge, one lane per edge of the caller's list
+namespace n2v {
+__global__ __launch_bounds__(256) void edge_row_sums_kernel(n2v_graph g, UnitConsts K, bool merge_r, bool need_mem,
+                                                            const int64_t *__restrict__ edges, int64_t k,
+                                                            double *__restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < k; i += (int64_t)gridDim.x * 256) {
+    const int64_t e = edges[i];
+    if (e < 0 || e >= g.n_edges) continue;
+    const int64_t x = g.col[e];
+    const int64_t nn = g.rowptr[x + 1] - g.rowptr[x];
+    const uint32_t ec = g.edge_classes[e];
+    const uint32_t fR = ec >> N2V_EC_RETURN_SHIFT, fM = ec & N2V_EC_SHARED_MASK;
+    if (fR == N2V_EC_RETURN_SAT || fM == N2V_EC_SHARED_MASK || nn <= 0 || nn >= (1 << 24)) {
+      out[e] = 0.0;  // (the walk kernels flag such an edge before they would read this)
+      continue;
+    }
+    const int n = (int)nn;
+    const int nR = merge_r ? 0 : (int)fR, nM = need_mem ? (int)fM : 0;
+    const uint64_t wraw = g.wedge_off[e];
+    const int64_t off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
+    const int rp = (int)(wraw >> N2V_WEDGE_RPOS_SHIFT);
+    double sum;
+    if (wedge_row_wide(g.wedge_wide, n))
+      sum = lane_row_sum<uint32_t>(n, K, nR, rp, nM, reinterpret_cast<const uint32_t *>(g.wedge_pos) + off);
+    else
+      sum = lane_row_sum<uint16_t>(n, K, nR, rp, nM, reinterpret_cast<const uint16_t *>(g.wedge_pos) + off);
+    out[e] = sum;
+  }
+}
+}  // namespace n2v
+
+int n2v_edge_row_sums_launch(const n2v_graph *g, const n2v::UnitConsts &K, double q, const int64_t *edges, int64_t k,
+                             double *sums_out, void *stream) {
+  int64_t blocks = (k + 255) / 256;
+  const int64_t cap = 4 * n2v::resident_blocks((const void *)n2v::edge_row_sums_kernel, 256, 0);
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(n2v::edge_row_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *g, K,
+                     K.bR == K.bO, q != 1.0, edges, k, sums_out);
+  if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
+  return N2V_OK;
 }

@@ -347,6 +347,10 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
           }
 #endif
         }
+        if (g.row_sums != nullptr && n >= g.row_sums_from) {
+          // a long row: the sum of this edge's table was added up once (n2v_edge_row_sums_build: this routine, these bits)
+          avg = g.row_sums[e_prev] / (double)n;
+        } else {
         const uint16_t *sum_list = slot + 2;
         if (nM > kSlotShort) {
           sum_list = reinterpret_cast<const uint16_t *>(g.wedge_pos) +
@@ -364,6 +368,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
         }
         avg = lane_row_sum<uint16_t>(n, K, nR, slot_rpos(), nM, ListRef<uint16_t>(sum_list, slot_nlow(), g.wedge_wide)) /
               (double)n;
+        }
       } else {
         // through wedge_off (the wide rows of a mixed table): the same two stages on the list in memory
         if (!w_loaded) {
@@ -386,7 +391,9 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
           }
         }
         double sum;
-        if (w_wide)
+        if (g.row_sums != nullptr && n >= g.row_sums_from)
+          sum = g.row_sums[e_prev];
+        else if (w_wide)
           sum = lane_row_sum<uint32_t>(n, K, nR, rp, nM, reinterpret_cast<const uint32_t *>(g.wedge_pos) + w_off);
         else
           sum = lane_row_sum<uint16_t>(n, K, nR, rp, nM, reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off);

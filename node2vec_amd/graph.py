@@ -88,6 +88,9 @@ class DeviceGraph:
         self.wedge_tried = False  # randomwalk.walk tries to build the table once
         self.wedge_slots: Optional[torch.Tensor] = None  # int16 [E, 16]: n2v_wedge_slots_build
         self.slots_folded = False  # the slots of the edges into wide rows are folded slots (n2v_wedge_slots_fold)
+        # row sums of the steps into long rows for ONE (p, q) that is not dyadic (build_row_sums):
+        # (fp64 [E] tensor, p, q, the wedge_off tensor they were computed from) | None
+        self.row_sums = None
         self.hops_inline_rpos = False  # the hop table's class words carry return positions (slots kernel)
         self._inline_ok = None  # (edge_classes tensor, every return count < 128): can_inline_rpos()
         # the degree-ranked form (build_ranked): 4-byte entries for p = q = 1 walks
@@ -227,7 +230,49 @@ class DeviceGraph:
                           int(self.hops_inline_rpos and self.hops is not None)
                           | (2 if self.slots_folded and self.wedge_slots is not None else 0),  # N2V_SLOTS_FOLDED
                           0 if self.wedge_slots is None else self.wedge_slots.data_ptr(),
-                          *self._rank_fields())
+                          *self._rank_fields(), *self._row_sum_fields())
+
+    ROW_SUMS_FROM = 1024  # rows of this many entries and more have the sums of their steps' tables stored
+
+    def _row_sum_fields(self):
+        rs = self.row_sums
+        if rs is None or self.wedge_off is None or rs[3] is not self.wedge_off:
+            return (0, 0.0, 0.0, 0, 0)
+        return (rs[0].data_ptr(), rs[1], rs[2], self.ROW_SUMS_FROM, 0)
+
+    def build_row_sums(self, p: float, q: float, max_bytes: Optional[int] = None) -> "DeviceGraph":
+        """sum(node_weights) (randomwalk.py:172) of the table of every step into a row of ROW_SUMS_FROM entries or
+        more, for one (p, q) whose 1/p or 1/q is not dyadic (n2v_edge_row_sums_build): 8 bytes per edge, kept for
+        the last (p, q) asked.  A step that has to know the reference's rounded sum -- 1 % of the steps on long
+        rows -- then reads it instead of adding the row up by one lane.  Same bits either way."""
+        L = _lib.load()
+        if self.row_sums is not None and self.row_sums[1:3] == (float(p), float(q)) and \
+                self.row_sums[3] is self.wedge_off:
+            return self
+        self.row_sums = None
+        if (not self.unit_weights or self.edge_classes is None or self.wedge_off is None or self.wedge_pos is None
+                or self.n_edges == 0):
+            return self
+        deg = self.degrees()
+        if int(deg.max()) < self.ROW_SUMS_FROM:
+            return self
+        if max_bytes is None:
+            max_bytes = torch.cuda.mem_get_info(self.device)[0] // 4
+        if 8 * self.n_edges > max_bytes:
+            return self
+        long_row = deg >= self.ROW_SUMS_FROM
+        edges = torch.nonzero(long_row[self.col.long()]).reshape(-1)
+        # longest lists first: the lanes of a wave then have lists of one length
+        order = torch.argsort((self.edge_classes[edges] & 0xffffff), descending=True)
+        edges = edges[order].contiguous()
+        del order, long_row
+        sums = torch.empty(self.n_edges, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = L.n2v_edge_row_sums_build(self.c_struct(), float(p), float(q), edges.data_ptr(), edges.numel(),
+                                           sums.data_ptr(), _lib.current_stream_ptr())
+        _lib.check(rc, "n2v_edge_row_sums_build")
+        self.row_sums = (sums, float(p), float(q), self.wedge_off)
+        return self
 
     def _rank_fields(self):
         if self.rank_hops is None:

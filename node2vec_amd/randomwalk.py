@@ -71,7 +71,7 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
          stats: Optional[dict] = None, use_edge_classes: bool = True, use_hops: bool = True,
          use_wedges: bool = True, use_wedge_kernel: bool = True, use_hops8: bool = True,
          use_workspace: bool = False, use_wedge_slots: bool = True, use_ranked: Optional[bool] = None,
-         rank_ids: bool = False, use_weighted_lanes: Optional[bool] = None):
+         rank_ids: bool = False, use_weighted_lanes: Optional[bool] = None, use_row_sums: bool = True):
     """Launch K2.  Returns (walks int32 [n_start*num_walks, walk_length+1], valid bool).
 
     mode "fast", and on weighted graphs mode "exact" with return_param == inout_param == 1
@@ -100,7 +100,10 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     Exact biased walks on a WEIGHTED graph run step-synchronously, one lane per walker, the walkers
     of every step ordered by the degree of the vertex they stand on (n2v_walk_weighted_step; the
     per-edge class counts and wedge lists are built on first use -- they depend on the ids alone):
-    the same walks as the wave-per-walker kernel of n2v_walk, which use_weighted_lanes=False keeps."""
+    the same walks as the wave-per-walker kernel of n2v_walk, which use_weighted_lanes=False keeps.
+    Values of p, q that are not dyadic: the row sums of the steps into rows of 1024 entries and more are computed
+    once per (p, q) (graph.build_row_sums(): 8 bytes per edge, skipped when they do not fit) and read by the steps
+    that need them; use_row_sums=False has those steps add the row up themselves: same bits."""
     L = _lib.load()
     _lib.require_gpu()
     if mode not in MODES:
@@ -140,6 +143,10 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
             if use_wedges and graph.wedge_off is None and not graph.wedge_tried:
                 graph.wedge_tried = True
                 graph.build_wedges()
+            # values that are not dyadic: the reference's rounded row sums of the steps into long rows, once
+            if (use_wedges and use_row_sums and graph.wedge_slots is not None
+                    and not (_dyadic(return_param) and _dyadic(inout_param))):
+                graph.build_row_sums(return_param, inout_param)
     elif mode == "exact" and biased and use_edge_classes and use_wedges:
         # weighted graph, biased exact walk: the per-edge class counts and wedge lists (they depend on
         # the ids alone) tell both weighted kernels which slots of a step's table are return / shared /
@@ -219,6 +226,8 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
         g.reserved = 1
     if not use_wedge_slots:  # the all-tables kernel through wedge_off (tests: same bits)
         g.wedge_slots = 0
+    if not use_row_sums:  # every row added up by the lane that needs its sum (tests: same bits)
+        g.row_sums = 0
     with torch.cuda.device(graph.device):
         ws_bytes = 0
         if use_workspace and n_start > 0:

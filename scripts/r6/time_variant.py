@@ -21,7 +21,8 @@ for pq in os.environ.get("PQ", "0.5,2.0;3,0.7;4,0.25").split(";"):
     P_, Q_ = (float(x) for x in pq.split(","))
 
     def run(k):
-        rw.walk(g, start[(k % nb) * b:(k % nb + 1) * b], 10, 80, P_, Q_, 42, out=(walks, valid), check=False)
+        rw.walk(g, start[(k % nb) * b:(k % nb + 1) * b], 10, 80, P_, Q_, 42, out=(walks, valid), check=False,
+                use_workspace=bool(os.environ.get("USE_WS")))  # (USE_WS=1 + a `make WEDGE2=1` library: the passes of n2v_walk_ws)
 
     run(0); torch.cuda.synchronize()
     t0 = time.perf_counter()

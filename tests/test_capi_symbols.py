@@ -23,7 +23,7 @@ def test_header_declares_the_expected_entry_points():
                  "n2v_partition_step", "n2v_gather_rows", "n2v_gather_wedges",
                  "n2v_partition_route", "n2v_partition_group", "n2v_walk_ws",
                  "n2v_walk_workspace_bytes", "n2v_delta_reduce", "n2v_wedge_slots_build", "n2v_sgns_job_alpha", "n2v_rank_hops_build", "n2v_partition_forward",
-                 "n2v_wedge_slots_fold"):
+                 "n2v_wedge_slots_fold", "n2v_edge_row_sums_build"):
         assert want in names
 
 
@@ -47,14 +47,15 @@ def test_ctypes_structs_match_header_layout():
     """sizeof / field order of the two structs passed by pointer"""
     from node2vec_amd import _lib
 
-    assert ctypes.sizeof(_lib.Graph) == 18 * 8 + 6 * 8 + 4 * 4
+    assert ctypes.sizeof(_lib.Graph) == 18 * 8 + 6 * 8 + 4 * 4 + 4 * 8
     assert [f[0] for f in _lib.Graph._fields_] == ["n_vertices", "n_edges", "rowptr", "col", "w", "w64",
                                                     "slots", "pivots", "edge_classes", "hops", "wedge_off", "wedge_pos",
                                                     "wedge_wide", "reserved", "hops8", "hop8_col_bits", "hop8_row_bits",
                                                     "hop8_rowptr", "hop8_align_shift", "reserved2", "wedge_slots",
                                                     "rank_hops", "rank_of", "rank_vertex", "rank_head",
                                                     "rank_class_first", "rank_class_off", "rank_head_n",
-                                                    "rank_classes", "rank_emit", "reserved3"]
+                                                    "rank_classes", "rank_emit", "reserved3", "row_sums", "row_sums_p",
+                                                    "row_sums_q", "row_sums_from", "reserved4"]
     # the header's field order, read from the header itself
     text = open(os.path.join(ROOT, "include", "n2v_hip.h")).read()
     body = text[text.index("typedef struct n2v_graph {"):text.index("} n2v_graph;")]

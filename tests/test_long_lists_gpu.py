@@ -68,6 +68,28 @@ def test_walks_over_hub_to_hub_lists_equal_the_oracle(wide_from, n_common):
         a, av = rw.walk(g, start, 2, 16, p, q, 9)
         b, bv = rw.walk(g, start, 2, 16, p, q, 9, use_wedge_slots=False)
         assert torch.equal(av, bv) and torch.equal(a, b), (p, q)
+        if (p, q) in ((3.0, 0.7), (0.7, 3.0)):
+            # values that are not dyadic: the row sums of the steps into the hubs' rows were computed once
+            # (n2v_edge_row_sums_build) -- the same walks with every such row added up by the lane that needs it,
+            # and the stored sums equal Python's left-to-right float sum of the step's table (randomwalk.py:172)
+            assert g.row_sums is not None and g.row_sums[1:3] == (p, q) and g.c_struct().row_sums
+            c, cv = rw.walk(g, start, 2, 16, p, q, 9, use_row_sums=False)
+            assert torch.equal(av, cv) and torch.equal(a, c), (p, q)
+            sums = g.row_sums[0].cpu().numpy()
+            checked = 0
+            sources = [0, 1] + [int(x) for x in col[rowptr[0]:rowptr[0] + 400:100]]  # two hubs, some of their neighbours
+            for s_ in sources:
+                mine = col[rowptr[s_]:rowptr[s_ + 1]]
+                nbr = set(mine.tolist())
+                for k, v in enumerate(mine.tolist()):
+                    if v >= n_hubs:  # (the rows of the hubs are the long ones)
+                        continue
+                    e = int(rowptr[s_]) + k
+                    assert rowptr[v + 1] - rowptr[v] >= g.ROW_SUMS_FROM
+                    row = col[rowptr[v]:rowptr[v + 1]].tolist()
+                    assert sums[e] == sum((1.0 / p if x == s_ else (1.0 if x in nbr else 1.0 / q)) for x in row), (s_, v)
+                    checked += 1
+            assert checked >= 5
         # walkers that start on a hub and stay among the hubs' rows: most steps search a long list
         a, _ = rw.walk(g, sample_t[:n_hubs], 40, 30, p, q, 13)
         b, _ = rw.walk(g, sample_t[:n_hubs], 40, 30, p, q, 13, use_wedge_slots=False)
