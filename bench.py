@@ -486,7 +486,7 @@ def main():
         torch.cuda.empty_cache()
     # the walk tables are not needed any more (the CPU baseline reads rowptr / col only)
     g.slots = g.pivots = g.hops = g.hops8 = g.edge_classes = g.wedge_off = g.wedge_pos = None
-    g.wedge_slots = g.rank_hops = g.rank_of = g.rank_vertex = None
+    g.wedge_slots = g.rank_hops = g.rank_of = g.rank_vertex = g.row_sums = None
     torch.cuda.empty_cache()
 
     # ---- the same graph trimmed at the REFERENCE's default cap (constants.py:6: 100 000; randomwalk.py:252-253)
@@ -539,8 +539,10 @@ def bench_reference_cap(args, cfg, torch, dist, rw, dev, W, L, rank, world, barr
     res = {"trim_cap": 100_000, "n_edges": g2.n_edges, "max_out_degree": int(g2.degrees().max()),
            "share_of_steps_on_rows_of_65536_or_more": float(g2.degrees()[g2.degrees() >= 65536].sum()) / g2.n_edges}
     g2.build_ranked()
-    for name, (p2, q2), in_ranks in (("exact_pq1_ranks_out", (1.0, 1.0), g2.rank_hops is not None),
-                                     ("exact_biased_0.5_2", BIASED_PQ, False)):
+    legs = [("exact_pq1_ranks_out", (1.0, 1.0), g2.rank_hops is not None), ("exact_biased_0.5_2", BIASED_PQ, False)]
+    if not args.no_regimes:
+        legs += [("exact_biased_4_0.25", (4.0, 0.25), False), ("exact_biased_3_0.7", (3.0, 0.7), False)]
+    for name, (p2, q2), in_ranks in legs:
         if (p2, q2) != (1.0, 1.0):
             prepare_tables(torch, g2, p2, q2, "exact", sub, "cap")
         leg = WalkLeg(torch, rw, g2, start2, W, L, p2, q2, "exact", cfg["biased_batch"], rank, world,
@@ -549,10 +551,20 @@ def bench_reference_cap(args, cfg, torch, dist, rw, dev, W, L, rank, world, barr
         e, s_ = reduce_job(torch, dist, use_dist, dev, r["elapsed"], r["steps_done"])
         res[name] = {"value": s_ / e, "unit": "walk-steps/s", "ms_per_step": 1e3 * e / args.steps,
                      "kernel": kernel_name(g2, p2, q2)}
+        if rank == 0 and name == "exact_biased_0.5_2":
+            res[name]["roofline"] = roofline(kernel_name(g2, p2, q2), r, leg, args.config, p2, q2, "exact", None)
         del leg
         torch.cuda.empty_cache()
     res["wedge_table"] = {"mode": int(g2.wedge_mode), "slots": g2.wedge_slots is not None,
-                          "note": "65536 = mixed: only the lists of the edges into rows of >= 65536 slots are 32-bit"}
+                          "folded_slots": bool(g2.slots_folded),
+                          "row_sums_for": None if g2.row_sums is None else list(g2.row_sums[1:3]),
+                          "GB": {"lists": 0.0 if g2.wedge_pos is None else g2.wedge_pos.numel() * 2 / 1e9,
+                                 "slots": 0.0 if g2.wedge_slots is None else g2.wedge_slots.numel() * 2 / 1e9,
+                                 "row_sums": 0.0 if g2.row_sums is None else g2.row_sums[0].numel() * 8 / 1e9},
+                          "note": "65536 = mixed: the lists of the edges into rows of >= 65536 slots are 32-bit for "
+                                  "every kernel but the exact slots kernel, which reads FOLDED 16-bit copies and slots "
+                                  "(n2v_wedge_slots_fold); (3, 0.7): the row sums of the steps into rows of >= 1024 "
+                                  "slots stored once (n2v_edge_row_sums_build)"}
     setup["reference_cap_tables_s"] = {k: v for k, v in sub.items() if k.endswith("_s")}
     del g2
     torch.cuda.empty_cache()
@@ -707,7 +719,9 @@ def ordered_line(out):
             "weighted_cfg2_exact_0.5_2_47k_walkers": (((out.get("weighted") or {}).get("small_batches") or {})
                                                       .get("47100_walkers") or {}).get("value"),
             "trim_cap_100000_exact_pq1_ranks_out": ((out.get("reference_trim_cap") or {}).get("exact_pq1_ranks_out") or {}).get("value"),
-            "trim_cap_100000_exact_biased_0.5_2": ((out.get("reference_trim_cap") or {}).get("exact_biased_0.5_2") or {}).get("value")},
+            "trim_cap_100000_exact_biased_0.5_2": ((out.get("reference_trim_cap") or {}).get("exact_biased_0.5_2") or {}).get("value"),
+            "trim_cap_100000_exact_biased_4_0.25": ((out.get("reference_trim_cap") or {}).get("exact_biased_4_0.25") or {}).get("value"),
+            "trim_cap_100000_exact_biased_3_0.7": ((out.get("reference_trim_cap") or {}).get("exact_biased_3_0.7") or {}).get("value")},
         "walk_roofline_frac": {"headline_vertex_ids_out": frac(out),
                                "pq1_ranks_out_pipeline": None if "roofline_pipeline" not in out
                                else round(out["roofline_pipeline"]["frac"], 4),
@@ -731,7 +745,7 @@ def ordered_line(out):
 
 def prepare_tables(torch, g, p, q, mode, setup, tag):
     """the one-off tables randomwalk.walk builds on first use for (p, q, mode), timed"""
-    from node2vec_amd.randomwalk import tables_regime
+    from node2vec_amd.randomwalk import _dyadic, tables_regime
 
     biased = not (p == 1.0 and q == 1.0)
 
@@ -754,6 +768,9 @@ def prepare_tables(torch, g, p, q, mode, setup, tag):
                 g.wedge_off.numel() * 8 + g.wedge_pos.numel() * g.wedge_pos.element_size()) / 1e9
             setup[f"{tag}_wedge_slots_GB"] = 0.0 if g.wedge_slots is None else g.wedge_slots.numel() * 2 / 1e9
 
+        if (biased and mode == "exact" and tables_regime(p, q) and g.wedge_slots is not None
+                and not (_dyadic(p) and _dyadic(q))):
+            timed("row_sums_build", lambda: g.build_row_sums(p, q))  # (walk() would build them on first use)
         if not biased and mode == "exact" and g.hops8 is None and not g.hops8_tried:
             timed("hop8_table_build", g.build_hops8)  # 8 bytes per edge; p = q = 1 only
         if (biased or mode != "exact" or g.hops8 is None) and (
@@ -772,7 +789,7 @@ def kernel_name(g, p, q):
         if p == 1.0 and q == 1.0:
             return "walk_uniform_kernel"
         if tables_regime(p, q) and g.hops is not None and g.wedge_off is not None:
-            if g.wedge_slots is not None:  # (all four instances: dyadic p, q or not)
+            if g.wedge_slots is not None and (g.wedge_mode == 0 or g.slots_folded):  # (all four instances)
                 return "walk_exact_wedge_slots_kernel"
             return "walk_exact_wedge_kernel"
         if lanes_regime(p, q) and g.edge_classes is not None:
