@@ -544,7 +544,12 @@ def bench_reference_cap(args, cfg, torch, dist, rw, dev, W, L, rank, world, barr
         legs += [("exact_biased_4_0.25", (4.0, 0.25), False), ("exact_biased_3_0.7", (3.0, 0.7), False)]
     for name, (p2, q2), in_ranks in legs:
         if (p2, q2) != (1.0, 1.0):
-            prepare_tables(torch, g2, p2, q2, "exact", sub, "cap")
+            # this leg owns the card (its tables go when it ends): lists (101 GB at cfg 4) + folded copies (17 GB) +
+            # slots (26 GB) may take what is free less 24 GB for the walks and the other tables
+            torch.cuda.empty_cache()
+            free = torch.cuda.mem_get_info(dev)[0]
+            res.setdefault("hbm_free_GB_before_tables", free / 1e9)
+            prepare_tables(torch, g2, p2, q2, "exact", sub, "cap", wedge_bytes=max(free - (24 << 30), free // 2))
         leg = WalkLeg(torch, rw, g2, start2, W, L, p2, q2, "exact", cfg["biased_batch"], rank, world,
                       rank_ids=in_ranks, audition=not args.no_audition)
         r = leg.run(args.steps, args.warmup, barrier)
@@ -743,7 +748,7 @@ def ordered_line(out):
     return {k: out[k] for k in keys if k in out}
 
 
-def prepare_tables(torch, g, p, q, mode, setup, tag):
+def prepare_tables(torch, g, p, q, mode, setup, tag, wedge_bytes=None):
     """the one-off tables randomwalk.walk builds on first use for (p, q, mode), timed"""
     from node2vec_amd.randomwalk import _dyadic, tables_regime
 
@@ -763,13 +768,14 @@ def prepare_tables(torch, g, p, q, mode, setup, tag):
             timed("edge_classes_build", g.build_edge_classes)
         if biased and (mode == "fast" or tables_regime(p, q)) and g.wedge_off is None and not g.wedge_tried:
             g.wedge_tried = True
-            timed("wedge_table_build", g.build_wedges)
+            # (wedge_bytes: the budget of a leg that owns the card; None = the library's own rule, half of what is free)
+            timed("wedge_table_build", lambda: g.build_wedges(max_bytes=wedge_bytes))
             setup[f"{tag}_wedge_table_GB"] = 0.0 if g.wedge_off is None else (
                 g.wedge_off.numel() * 8 + g.wedge_pos.numel() * g.wedge_pos.element_size()) / 1e9
             setup[f"{tag}_wedge_slots_GB"] = 0.0 if g.wedge_slots is None else g.wedge_slots.numel() * 2 / 1e9
 
         if (biased and mode == "exact" and tables_regime(p, q) and g.wedge_slots is not None
-                and not (_dyadic(p) and _dyadic(q))):
+                and (g.wedge_mode == 0 or g.slots_folded) and not (_dyadic(p) and _dyadic(q))):
             timed("row_sums_build", lambda: g.build_row_sums(p, q))  # (walk() would build them on first use)
         if not biased and mode == "exact" and g.hops8 is None and not g.hops8_tried:
             timed("hop8_table_build", g.build_hops8)  # 8 bytes per edge; p = q = 1 only

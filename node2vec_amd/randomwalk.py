@@ -144,7 +144,9 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
                 graph.wedge_tried = True
                 graph.build_wedges()
             # values that are not dyadic: the reference's rounded row sums of the steps into long rows, once
+            # (the slots kernel reads them: a mixed table without folded slots walks through the other kernel)
             if (use_wedges and use_row_sums and graph.wedge_slots is not None
+                    and (graph.wedge_mode == 0 or graph.slots_folded)
                     and not (_dyadic(return_param) and _dyadic(inout_param))):
                 graph.build_row_sums(return_param, inout_param)
     elif mode == "exact" and biased and use_edge_classes and use_wedges:
