@@ -622,7 +622,7 @@ __device__ __forceinline__ int lane_pairing(int n, uint64_t Rm, uint64_t Mm, int
 template <typename P>
 __device__ __forceinline__ int lane_case_b(int n, int pick, double r2, double vR, double vM,
                                            double vO, int nR, int rpos, int nM, ListRef<P> list,
-                                           bool pickR, bool pickM) {
+                                           bool pickR, bool pickM, int lo_pick = -1, int below = -1) {
   const int nO = n - nR - nM;
   auto list_lower = [&](int pos) -> int {  // entries of the list below pos
     return list_lower_bound<P>(list, nM, pos);
@@ -654,28 +654,32 @@ __device__ __forceinline__ int lane_case_b(int n, int pick, double r2, double vR
   if (!pickR && !pickM) pick_rank = (n - pick) - specials_ge(pick + 1);
   const double d = vO - 1.0;  // exact (vO in [1, 2))
   const double inv = d > 0.0 ? 1.0 / d : 0.0;
-  int km = nM - 1, kr = nR - 1;  // next shared / return slot, descending
+  // The underfull stack is popped from the highest position: the mA listed slots above the return run, the run,
+  // the listed slots below it -- so the i-th slot popped is a listed one unless mA < i <= mA + nR, and which i is
+  // `pick` follows from its rank in the list (lo_pick).  The loop therefore reads NO list entry (round 6: it read
+  // list[km] at every iteration, one more dependent load in a chain that one lane runs while its wave waits; on
+  // cfg 4 trimmed at 100 000 these replays are a third of the (4, 0.25) kernel, profiles/r12c_*).
+  const int lo_p = (pickM && lo_pick < 0) ? list_lower(pick) : lo_pick;
+  const int mA = nM - ((nR > 0 && nM > 0) ? (below >= 0 ? below : list_lower(rpos)) : 0);
+  int i_pick = 0;  // the place of `pick` on the underfull stack, from 1; 0: an "other" slot
+  if (pickR) {
+    i_pick = mA + (nR - (pick - rpos));
+  } else if (pickM) {
+    const int dd = nM - lo_p;
+    i_pick = dd <= mA ? dd : dd + nR;
+  }
+  const int S = nM + nR;
+  int i_next = 1;                // next slot of the underfull stack
   int t_used = 0;                // "other" slots of rank <= t_used have been demoted
   bool have_cur = false;         // rank t_used + 1 is the current overfull slot, at cur_val >= 1
   double cur_val = 0.0;
   for (;;) {
-    const int pm = km >= 0 ? (int)list[km] : -1;
-    const int pr = kr >= 0 ? rpos + kr : -1;
-    if (pm < 0 && pr < 0) break;  // underfull is empty (:182)
+    if (i_next > S) break;  // underfull is empty (:182)
     if (!have_cur && t_used >= nO) break;  // overfull is empty (:182)
-    int ui;
-    double uv;
-    if (pm > pr) {
-      ui = pm;
-      uv = vM;
-      --km;
-    } else {
-      ui = pr;
-      uv = vR;
-      --kr;
-    }
+    const int i_cur = i_next++;
+    const double uv = (i_cur > mA && i_cur <= mA + nR) ? vR : vM;
     const int over_rank = t_used + 1;
-    if (ui == pick) return other_pos(over_rank);  // alias[pick]; r2 >= probs[pick] here
+    if (i_cur == i_pick) return other_pos(over_rank);  // alias[pick]; r2 >= probs[pick] here
     double a = (have_cur ? cur_val : vO) + uv - 1.0;  // :185
     if (!(a < 1.0)) {
       cur_val = a;

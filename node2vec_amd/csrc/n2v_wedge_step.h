@@ -72,6 +72,9 @@ __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, 
   if (n > 64) atomicAdd(n2v_decline_words + 30, 1u);  // pairings on such rows
   if (n >= 4096) atomicAdd(n2v_decline_words + 62, 1u);
 #endif
+#ifdef N2V_FORCE_REPLAY  // test build: every pairing on a row of more than 64 slots is REPLAYED (the closed forms unused)
+  res = -1;
+#endif
   if (res >= 0) return res;
 #ifdef N2V_ABLATE_STEP  // timing only: 4 = a pairing the closed forms decline keeps `pick` (no replay); 5 = on rows > 64
   if (N2V_ABLATE_STEP == 4 || (N2V_ABLATE_STEP == 5 && n > 64)) return pick;
@@ -79,10 +82,12 @@ __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, 
   if constexpr (kMode == 2) {
     // a long row whose values are not dyadic: the closed forms on the reference's own values (the exact
     // row sum has been taken), with a margin that grows with n instead of n^2
+#ifndef N2V_FORCE_REPLAY
     if (N2V_NEAR_FORMS && n >= kNearExactMin && arr >= 1) {
       res = near_listed_exact<P>(arr, n, pick, r2, K, avg, nR, rpos, nM, list, isR, isM, lo_pick, below);
       if (res >= 0) return res;
     }
+#endif
   }
   const double vR = K.bR / avg, vM = K.bM / avg, vO = K.bO / avg;
   if (n <= 64) {  // a short row: the two stacks as bit masks
@@ -92,7 +97,7 @@ __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, 
     return lane_pairing(n, Rm, Mm, pick, r2, vR, vM, vO);
   }
   if (arr == 1) return lane_case_a<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM, stage, lane);
-  if (arr == 2) return lane_case_b<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM);
+  if (arr == 2) return lane_case_b<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM, lo_pick, below);
   if constexpr (kShared) {
     if (arr == 3) return lane_case_a2<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM, stage, lane);
     if (arr == 4) return lane_case_b2<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM);
