@@ -320,6 +320,51 @@ __device__ __forceinline__ int lane_case_a(int n, int pick, double r2, double vR
   return (r2 < p_pick) ? pick : alias_pick;
 }
 
+// Position of the T-th slot from the top of a row of n slots (position n - 1 first) that is NOT in the ascending list
+// list[0, nM): the largest pos with (n - pos) - (listed entries >= pos) >= T, 1 <= T <= n - nM.  h(k) = list[k] - k
+// never decreases (the list ascends strictly), and with i = the number of k with h(k) <= c, c = n - T - nM, the slot
+// lies between list[i - 1] and list[i], at c + i: ONE search of the list.  (Rounds 2 - 5 iterated pos = n - T - cnt,
+// cnt = listed entries >= pos, to its fixed point -- a full search of the list per iteration, 64 at most, then a
+// count slot by slot.  Where the listed slots are dense -- the low positions of a hub's row are the other hubs -- that
+// takes dozens of iterations: on cfg 4 trimmed at 100 000 it was 27 of the 72 ms of the (4, 0.25) kernel in the
+// replays alone, profiles/r13e_time.log.)
+template <typename P>
+__device__ __forceinline__ int unlisted_from_top(int n, int nM, const ListRef<P> &list, int T) {
+  const int c = n - T - nM;
+  int lo = 0, hi = nM;  // the number of k with list[k] - k <= c
+  while (hi - lo > N2V_LIST_KARY_MIN) {  // seven independent probes per round trip (as list_lower_bound)
+    const int step = (hi - lo) >> 3;
+    int v[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = list[lo + (k + 1) * step] - (lo + (k + 1) * step);
+    int le = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) le += v[k] <= c ? 1 : 0;
+    const int nlo = le == 0 ? lo : lo + le * step + 1;
+    const int nhi = le == 7 ? hi : lo + (le + 1) * step;
+    lo = nlo;
+    hi = nhi;
+  }
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (list[mid] - mid <= c)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return c + lo;
+}
+
+// the same with a run of nR more slots [rpos, rpos + nR) taken out (the return run: never listed): position of the
+// t-th "other" slot from the top, 1 <= t <= n - nM - nR.  Either it lies above the run -- then the run does not count --
+// or below it -- then all of the run does.
+template <typename P>
+__device__ __forceinline__ int other_from_top(int n, int nR, int rpos, int nM, const ListRef<P> &list, int t) {
+  int pos = unlisted_from_top<P>(n, nM, list, t);
+  if (nR > 0 && pos < rpos + nR) pos = unlisted_from_top<P>(n, nM, list, t + nR);
+  return pos;
+}
+
 // The closed forms below do exact INTEGER arithmetic in fp64: every quantity is an integer below
 // 2^53 (guarded), for which +, -, * and fma are exact, and a quotient is one fp64 division plus an
 // exact correction.  (As int64 the same code cost ~5x the instructions -- 64-bit multiply, divide
@@ -462,19 +507,8 @@ __device__ __forceinline__ int lane_case_b_jump(int n, int pick, double r2, cons
     if (j <= dmA + dnR) return dmA * dM + (j - dmA) * dR;
     return dmA * dM + dnR * dR + (j - dmA - dnR) * dM;
   };
-  auto specials_ge = [&](int pos) -> int {  // listed + return slots at positions >= pos
-    int r = rpos + nR - pos;
-    r = r < 0 ? 0 : (r > nR ? nR : r);
-    return (nM - list_lower(pos)) + r;
-  };
   auto other_pos = [&](int t) -> int {  // position of the t-th "other" slot from the top
-    int c = 0;
-    for (int it = 0; it < 64; ++it) {
-      const int c2 = specials_ge(n - t - c);
-      if (c2 == c) return n - t - c;
-      c = c2;
-    }
-    N2V_DECLINE(13);
+    return other_from_top<P>(n, nR, rpos, nM, list, t);
   };
   if (pickR || pickM) {  // underfull: r2 >= its value here (the caller's quick exit took the rest)
     int j;
@@ -624,6 +658,9 @@ __device__ __forceinline__ int lane_case_b(int n, int pick, double r2, double vR
                                            double vO, int nR, int rpos, int nM, ListRef<P> list,
                                            bool pickR, bool pickM, int lo_pick = -1, int below = -1) {
   const int nO = n - nR - nM;
+#if defined(N2V_ABLATE_B) && N2V_ABLATE_B == 1  // timing only: the replay does nothing
+  return pick;
+#endif
   auto list_lower = [&](int pos) -> int {  // entries of the list below pos
     return list_lower_bound<P>(list, nM, pos);
   };
@@ -633,21 +670,11 @@ __device__ __forceinline__ int lane_case_b(int n, int pick, double r2, double vR
     return (nM - list_lower(pos)) + r;
   };
   auto other_pos = [&](int t) -> int {  // position of the t-th "other" slot from the top; 0 if none
+#if defined(N2V_ABLATE_B) && N2V_ABLATE_B == 2  // timing only: no search for the slot of a rank
+    return pick;
+#endif
     if (t < 1 || t > nO) return 0;
-    int c = 0;
-    for (int it = 0; it < 64; ++it) {
-      const int c2 = specials_ge(n - t - c);
-      if (c2 == c) return n - t - c;
-      c = c2;
-    }
-    // more than 64 corrections: count the "other" slots from the top one by one (never observed)
-    int seen = 0, km = nM - 1;
-    for (int i = n - 1; i >= 0; --i) {
-      while (km >= 0 && (int)list[km] > i) --km;
-      const bool special = (i >= rpos && i < rpos + nR) || (km >= 0 && (int)list[km] == i);
-      if (!special && ++seen == t) return i;
-    }
-    return 0;
+    return other_from_top<P>(n, nR, rpos, nM, list, t);
   };
   // rank of pick among the "other" slots (1 = highest position), 0 if pick is listed
   int pick_rank = 0;
@@ -677,6 +704,9 @@ __device__ __forceinline__ int lane_case_b(int n, int pick, double r2, double vR
     if (i_next > S) break;  // underfull is empty (:182)
     if (!have_cur && t_used >= nO) break;  // overfull is empty (:182)
     const int i_cur = i_next++;
+#ifdef N2V_DECLINE_STATS
+    atomicAdd(n2v_decline_words + 81, 1u);  // iterations of this loop
+#endif
     const double uv = (i_cur > mA && i_cur <= mA + nR) ? vR : vM;
     const int over_rank = t_used + 1;
     if (i_cur == i_pick) return other_pos(over_rank);  // alias[pick]; r2 >= probs[pick] here
@@ -709,6 +739,15 @@ __device__ __forceinline__ int lane_case_b(int n, int pick, double r2, double vR
     }
     // j = the first i >= 1 with a1 + i d >= 1: slots 1 .. j are demoted, slot j + 1 settles
     double j = fmin(fmax(ceil(need * inv), 1.0), m1);
+#ifdef N2V_DECLINE_STATS
+    {
+      double jj = j;
+      unsigned fix = 0;
+      while (jj * d < need) { jj += 1.0; ++fix; }
+      while (jj >= 2.0 && (jj - 1.0) * d >= need) { jj -= 1.0; ++fix; }
+      atomicAdd(n2v_decline_words + 82, fix);  // corrections of the cascade length
+    }
+#endif
     while (j * d < need) j += 1.0;
     while (j >= 2.0 && (j - 1.0) * d >= need) j -= 1.0;
     const int jd = (int)j;
@@ -755,18 +794,7 @@ struct TwoOnStack {
   // position of its t-th slot (0 if none)
   __device__ __forceinline__ int stack_pos(int t) const {
     if (t < 1 || t > nS) return 0;
-    int c = 0;
-    for (int it = 0; it < 64; ++it) {
-      const int c2 = nM - list_lower(n - t - c);  // listed slots at or above the candidate
-      if (c2 == c) return n - t - c;
-      c = c2;
-    }
-    int seen = 0, km = nM - 1;  // more than 64 corrections: count one by one (never observed)
-    for (int i = n - 1; i >= 0; --i) {
-      while (km >= 0 && (int)list[km] > i) --km;
-      if (!(km >= 0 && (int)list[km] == i) && ++seen == t) return i;
-    }
-    return 0;
+    return unlisted_from_top<P>(n, nM, list, t);
   }
   // 1-based rank on the mixed stack of a return slot / of an "other" slot with lo_pick listed
   // slots below it

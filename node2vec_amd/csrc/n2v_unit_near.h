@@ -145,19 +145,8 @@ __device__ __forceinline__ int lane_case_b_near(int n, int pick, double r2, cons
     if (j <= dmA + dnR) return dmA * dM + (j - dmA) * dR;
     return dmA * dM + dnR * dR + (j - dmA - dnR) * dM;
   };
-  auto specials_ge = [&](int pos) -> int {
-    int r = rpos + nR - pos;
-    r = r < 0 ? 0 : (r > nR ? nR : r);
-    return (nM - list_lower(pos)) + r;
-  };
   auto other_pos = [&](int t) -> int {
-    int c = 0;
-    for (int it = 0; it < 64; ++it) {
-      const int c2 = specials_ge(n - t - c);
-      if (c2 == c) return n - t - c;
-      c = c2;
-    }
-    return -1;
+    return other_from_top<P>(n, nR, rpos, nM, list, t);
   };
   if (pickR || pickM) {
     int j;

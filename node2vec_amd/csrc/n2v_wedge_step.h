@@ -37,7 +37,7 @@ template <typename P, int kMode>
 __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, const UnitConsts &K,
                                            double avg, int nR, int rpos, int nM, ListRef<P> list,
                                            bool isR, bool isM, int lo_pick, P *stage, int lane,
-                                           int below = -1) {
+                                           int below = -1, bool park = false) {
   constexpr bool kShared = kMode == 1 || kMode == 2;
   int res = -1;
   if constexpr (kMode != 2) {
@@ -89,6 +89,9 @@ __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, 
     }
 #endif
   }
+  // `park`: the caller steps the replays of long rows in groups (walk_exact_wedge_replay_kernel): -2 = "this step needs
+  // one" -- nothing has been decided, the same call with park == false replays it
+  if (park && n > 64) return -2;
   const double vR = K.bR / avg, vM = K.bM / avg, vO = K.bO / avg;
   if (n <= 64) {  // a short row: the two stacks as bit masks
     uint64_t Rm = 0ull;
@@ -96,8 +99,20 @@ __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, 
     const uint64_t Mm = wedge_mask_l<P>(list, nM);
     return lane_pairing(n, Rm, Mm, pick, r2, vR, vM, vO);
   }
-  if (arr == 1) return lane_case_a<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM, stage, lane);
-  if (arr == 2) return lane_case_b<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM, lo_pick, below);
+#ifdef N2V_DECLINE_STATS  // diagnostic: the cycles / 256 of the replays of long rows, and their number, by the length of the
+  // list (words 64 + 2 b, 65 + 2 b of the decline words; b = 0: <= 64 entries, 1: <= 256, 2: <= 1024, 3: <= 4096, 4: more)
+  const unsigned long long rep_t0 = __builtin_readcyclecounter();
+  auto timed = [&](int result) -> int {
+    const int b = nM <= 64 ? 0 : nM <= 256 ? 1 : nM <= 1024 ? 2 : nM <= 4096 ? 3 : 4;
+    atomicAdd(n2v_decline_words + 64 + 2 * b, (uint32_t)((__builtin_readcyclecounter() - rep_t0) >> 8));
+    atomicAdd(n2v_decline_words + 65 + 2 * b, 1u);
+    return result;
+  };
+#else
+  auto timed = [&](int result) -> int { return result; };
+#endif
+  if (arr == 1) return timed(lane_case_a<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM, stage, lane));
+  if (arr == 2) return timed(lane_case_b<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM, lo_pick, below));
   if constexpr (kShared) {
     if (arr == 3) return lane_case_a2<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM, stage, lane);
     if (arr == 4) return lane_case_b2<P>(n, pick, r2, vR, vM, vO, nR, rpos, nM, list, isR, isM);
@@ -141,6 +156,7 @@ __device__ __forceinline__ int jump_listed(int arr, int n, int pick, double r2, 
 // what a kernel needs of (p, q) beyond UnitConsts, computed once
 struct StepFlags {
   bool need_mem, always_pair, merge_r, w_wide, inline_rpos, folded;
+  bool park_replays;  // a pairing on a row of more than 64 slots that the closed forms decline returns -2 (not replayed)
 };
 __device__ __forceinline__ StepFlags step_flags(const n2v_graph &g, const UnitConsts &K, double q) {
   StepFlags f;
@@ -150,6 +166,7 @@ __device__ __forceinline__ StepFlags step_flags(const n2v_graph &g, const UnitCo
   f.w_wide = g.wedge_wide == 1;  // (a mixed table, wedge_wide >= 2: by the row, in wedge_step)
   f.inline_rpos = (g.reserved2 & N2V_HOPS_INLINE_RPOS) != 0;  // (the slots kernel's hop table only)
   f.folded = (g.reserved2 & N2V_SLOTS_FOLDED) != 0;  // the edges into wide rows have folded lists and slots
+  f.park_replays = false;
   return f;
 }
 
@@ -494,7 +511,8 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
         }
         if (!done)  // long lists; a tie or a thin margin: the replays read the list in memory
           idx = pair_listed<uint16_t, kMode>(arr, n, pick, r2, K, avg, nR, w_rpos, nM, list, isR, isM,
-                                             lo_pick, reinterpret_cast<uint16_t *>(stage), lane, w_below);
+                                             lo_pick, reinterpret_cast<uint16_t *>(stage), lane, w_below,
+                                             F.park_replays);
       }
     } else if constexpr (kJumpOnly) {
       // a plain branch on the (uniform) list width: never a select between two loads
@@ -526,6 +544,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
     }
 #endif
   }
+  if (idx < 0) return idx;  // (F.park_replays: the step waits for its replay)
   if (defer || idx != pick) h = load_hop(g.hops + vb + idx);
   return idx;
 }

@@ -17,6 +17,14 @@ for pq in os.environ.get("PQ", "0.5,2;4,0.25").split(";"):
     torch.cuda.synchronize()
     steps = int(valid.sum()) * 80
     s = st["status"].cpu().numpy().astype("uint32")[8:]
+    rep = st["status"].cpu().numpy().astype("uint32")[8 + 64:8 + 74]
+    print(f"trim {TRIM} p={p} q={q} replays on rows > 64 by list length (<= 64, <= 256, <= 1024, <= 4096, more): "
+          + ", ".join(f"{int(rep[2 * b + 1])} x {256.0 * rep[2 * b] / max(int(rep[2 * b + 1]), 1) / 1e3:.0f} k cycles"
+                      for b in range(5))
+          + f"; in all {256.0 * float(rep[0::2].sum()) / 2.4e9 * 1e3:.0f} ms of lane time at 2.4 GHz", flush=True)
+    ex = st["status"].cpu().numpy().astype("uint32")[8 + 80:8 + 83]
+    print(f"   lane_case_b: one-by-one counts of other_pos {int(ex[0])}, loop iterations {int(ex[1])}, corrections of the "
+          f"cascade length {int(ex[2])}", flush=True)
     for name, o in (("rows > 64", 0), ("rows >= 4096", 32)):
         codes = {c: int(s[o + c]) for c in range(1, 24) if s[o + c]}
         arrs = {a: int(s[o + 24 + a]) for a in range(6) if s[o + 24 + a]}
