@@ -387,174 +387,6 @@ void walk_exact_wedge_slots_kernel(
   }
 }
 
-// ---- the slots kernel with the REPLAYS of long rows stepped in groups (round 6).  A pairing that the closed forms
-// decline on a row of more than 64 slots -- an exact tie, which only the reference's rounding decides -- is replayed
-// by ONE lane, O(listed slots) dependent fp64 operations, ~0.4 ms on a hub row, while the other 63 wait: on cfg 4
-// trimmed at the reference's cap of 100 000 a sixth ((0.5, 2)) to two fifths ((4, 0.25)) of the kernel
-// (profiles/r12i_time.log).  Here every lane walks at its own step; a lane whose step needs such a replay stands
-// still (its step is not taken: wedge_step returns -2) while the others go on, and once kReplayLanes lanes of the
-// wave wait -- or nobody else has work -- their replays run side by side: the wave pays the longest of them instead of
-// their sum.  A lane whose walk is complete takes the next walker of the wave's chunk of 64.  Same step function,
-// same walks (a walker's draws depend on its key alone).  [Setting aside every lane whose next step is merely SLOW
-// -- a hub row, a list searched in memory -- was measured with this loop and lost 11 - 24 %: those are one lane in
-// ten, and an idle lane costs what a waiting one does.  Replays are one step in a thousand.]
-#ifndef N2V_REPLAY_LANES
-#define N2V_REPLAY_LANES 8
-#endif
-template <int kMode>
-__global__ __launch_bounds__(kWedgeThreads, (kMode == 1 || kMode == 2) ? N2V_SLOTS_WAVES_BIG : N2V_SLOTS_WAVES)
-void walk_exact_wedge_replay_kernel(
-    n2v_graph g, const int32_t *__restrict__ start_ids, int64_t n_start, int32_t num_walks,
-    int32_t walk_length, double q, UnitConsts K, uint64_t seed, int32_t *__restrict__ walks_out,
-    uint8_t *__restrict__ valid_out, uint32_t *__restrict__ status) {
-  __shared__ int32_t path_tile[16][kWedgeThreads];             // word k of thread t at [k][t]
-  __shared__ uint32_t stage_all[kWedgeThreads / 64][16 * 32];  // 2 KB per wave (lane_case_a)
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  uint32_t *stage = stage_all[tid >> 6];
-  const int64_t total = n_start * (int64_t)num_walks;
-  const int L1 = walk_length + 1;
-  StepFlags F = step_flags(g, K, q);
-#ifdef N2V_NEAR_COUNT
-  n2v_count_words = status;
-#endif
-#ifdef N2V_DECLINE_STATS
-  n2v_decline_words = status + 8;
-#endif
-  const bool base_aligned = (reinterpret_cast<uintptr_t>(walks_out) & 63u) == 0;
-
-  int64_t w0 = 0;  // absolute word index of path position 0 of this lane's walker
-  int lo = 0;      // first word of the current sector that belongs to this row
-  auto flush = [&](int64_t a) {  // words [sector(a) + lo, a] are complete: store them
-    const int k = (int)(a & 15);
-    int32_t *sec = walks_out + (a & ~(int64_t)15);
-    if (lo == 0 && k == 15 && base_aligned) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        reinterpret_cast<int4 *>(sec)[u] =
-            make_int4(path_tile[4 * u][tid], path_tile[4 * u + 1][tid], path_tile[4 * u + 2][tid],
-                      path_tile[4 * u + 3][tid]);
-    } else {
-      for (int kk = lo; kk <= k; ++kk) sec[kk] = path_tile[kk][tid];
-    }
-    lo = 0;
-  };
-  auto emit = [&](int pos, int32_t x) {  // path position pos of this lane's walker
-    const int64_t a = w0 + pos;
-    path_tile[(int)(a & 15)][tid] = x;
-    if ((a & 15) == 15 || pos == walk_length) flush(a);
-  };
-
-  // the wave's chunk of walker indices [pool_next, pool_end): wave-uniform
-  int64_t pool_next = 0, pool_end = 0;
-  bool exhausted = false;
-  // this lane's walker
-  bool walking = false, pending = false;
-  int64_t r = 0, vb = 0, e_prev = 0;
-  uint64_t h0 = 0;
-  uint32_t ec_prev = 0;
-  int32_t s = -1, v = -1;
-  int n = 0, step = 0;
-  for (;;) {
-    // ---- lanes without a walker take the next ones of the chunk
-    const uint64_t want = ballot64(!walking);
-    if (want != 0ull && !(exhausted && pool_next == pool_end)) {
-      if (pool_next == pool_end) {
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(&status[1], 64u);
-        const int64_t base = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        pool_next = base < total ? base : total;
-        pool_end = base + 64 < total ? base + 64 : total;
-        if (pool_end < pool_next) pool_end = pool_next;
-        if (base + 64 >= total) exhausted = true;
-      }
-      const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
-      const int64_t mine = pool_next + rank;
-      const bool take = !walking && mine < pool_end;
-      const int64_t asked = (int64_t)__builtin_popcountll(want);
-      pool_next = pool_next + asked < pool_end ? pool_next + asked : pool_end;
-      if (take) {
-        r = mine;
-        const int32_t start = start_ids[r / num_walks];
-        const int32_t ordinal = (int32_t)(r % num_walks) + 1;
-        h0 = walker_stream(seed, (uint64_t)start * (uint64_t)num_walks + (uint64_t)(ordinal - 1));
-        bool alive = true;
-        if (start < 0 || (int64_t)start >= g.n_vertices) {
-          atomicOr(status, N2V_ST_RANGE);
-          alive = false;
-        }
-        n = 0;
-        if (alive) {
-          vb = g.rowptr[start];
-          n = (int)(g.rowptr[start + 1] - vb);
-          alive = n > 0 && walk_length > 0;  // fugue.py:132
-        }
-        w0 = r * (int64_t)L1;
-        lo = (int)(w0 & 15);
-        const bool has_row = n > 0;
-        emit(0, has_row ? start : -1);
-        if (!has_row) {  // no such vertex / no out-edges: the row is all -1, like the other kernels
-          for (int tt = 1; tt < L1; ++tt) emit(tt, -1);
-          valid_out[r] = 0;
-        } else if (!alive) {  // walk_length == 0
-          valid_out[r] = 1;
-        }
-        s = -1;
-        v = start;
-        step = 0;
-        pending = false;
-        walking = alive;
-      }
-    }
-    const uint64_t busy = ballot64(walking);
-    if (busy == 0ull) {
-      if (exhausted && pool_next == pool_end) break;
-      continue;
-    }
-    // ---- the lanes that wait for a replay go when there are enough of them, or when nobody else has work
-    const uint64_t pend_m = ballot64(walking && pending);
-    const bool run_replays = __builtin_popcountll(pend_m) >= N2V_REPLAY_LANES || (busy & ~pend_m) == 0ull;
-    F.park_replays = !run_replays;
-    if (walking && pending == run_replays) {  // (no `continue` here: the ballots above need the whole wave back)
-      const uint64_t bits = step_bits(h0, (uint32_t)step);
-      const uint32_t u1 = (uint32_t)(bits >> 32), u2 = (uint32_t)bits;
-      n2v_hop h;
-      int idx;
-      if (s >= 0) {
-        idx = wedge_step<kMode, false, true>(g, K, F, u1, u2, s, vb, n, e_prev, ec_prev, h, stage, lane,
-                                             status);
-      } else {  // first step: generate_alias_tables of unit weights is the uniform draw (:320-321)
-        idx = pick_index(u1, n);
-        h = load_hop(g.hops + vb + idx);
-      }
-      if (idx < 0) {  // the step needs a replay on a long row: it is taken with the group
-        pending = true;
-      } else {
-        pending = false;
-        const int32_t x = h.col;
-        emit(step + 1, x);
-        e_prev = vb + idx;
-        ec_prev = h.classes;
-        s = v;
-        v = x;
-        ++step;
-        if (step < walk_length) {
-          vb = hop_row(h);
-          n = hop_deg(h);
-          if (n == 0) {  // fugue.py:147: the walker vanishes at a sink, the rest of its row is -1
-            for (int tt = step + 1; tt < L1; ++tt) emit(tt, -1);
-            valid_out[r] = 0;
-            walking = false;
-          }
-        } else {
-          valid_out[r] = 1;
-          walking = false;
-        }
-      }
-    }
-  }
-}
-
 // ---- one step of the walkers resident on one part of a partitioned graph, wedge lists travelling
 // (n2v_partition_step with N2V_SRC_WEDGES, n2v_walk.hip).  A walker that leaves along edge e brings
 // the class counts of e, the return position and the wedge list of e -- exactly what the kernel
@@ -716,12 +548,6 @@ int n2v_walk_wedge_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_s
               : alone_under ? n2v::walk_exact_wedge_slots_kernel<0>
               : alone_over  ? n2v::walk_exact_wedge_slots_kernel<3>
                             : n2v::walk_exact_wedge_slots_kernel<1>;
-    if (g->reserved & 8) {  // (bit 3 of `reserved`: the replays of long rows stepped in groups)
-      sk = !K.dyadic    ? n2v::walk_exact_wedge_replay_kernel<2>
-           : alone_under ? n2v::walk_exact_wedge_replay_kernel<0>
-           : alone_over  ? n2v::walk_exact_wedge_replay_kernel<3>
-                         : n2v::walk_exact_wedge_replay_kernel<1>;
-    }
     int64_t sblocks = (total + n2v::kWedgeThreads - 1) / n2v::kWedgeThreads;
     const int64_t scap = n2v::resident_blocks((const void *)sk, n2v::kWedgeThreads, 0);
     if (sblocks > scap) sblocks = scap;

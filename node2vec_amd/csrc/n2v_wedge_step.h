@@ -37,7 +37,7 @@ template <typename P, int kMode>
 __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, const UnitConsts &K,
                                            double avg, int nR, int rpos, int nM, ListRef<P> list,
                                            bool isR, bool isM, int lo_pick, P *stage, int lane,
-                                           int below = -1, bool park = false) {
+                                           int below = -1) {
   constexpr bool kShared = kMode == 1 || kMode == 2;
   int res = -1;
   if constexpr (kMode != 2) {
@@ -89,9 +89,6 @@ __device__ __forceinline__ int pair_listed(int arr, int n, int pick, double r2, 
     }
 #endif
   }
-  // `park`: the caller steps the replays of long rows in groups (walk_exact_wedge_replay_kernel): -2 = "this step needs
-  // one" -- nothing has been decided, the same call with park == false replays it
-  if (park && n > 64) return -2;
   const double vR = K.bR / avg, vM = K.bM / avg, vO = K.bO / avg;
   if (n <= 64) {  // a short row: the two stacks as bit masks
     uint64_t Rm = 0ull;
@@ -156,7 +153,6 @@ __device__ __forceinline__ int jump_listed(int arr, int n, int pick, double r2, 
 // what a kernel needs of (p, q) beyond UnitConsts, computed once
 struct StepFlags {
   bool need_mem, always_pair, merge_r, w_wide, inline_rpos, folded;
-  bool park_replays;  // a pairing on a row of more than 64 slots that the closed forms decline returns -2 (not replayed)
 };
 __device__ __forceinline__ StepFlags step_flags(const n2v_graph &g, const UnitConsts &K, double q) {
   StepFlags f;
@@ -166,7 +162,6 @@ __device__ __forceinline__ StepFlags step_flags(const n2v_graph &g, const UnitCo
   f.w_wide = g.wedge_wide == 1;  // (a mixed table, wedge_wide >= 2: by the row, in wedge_step)
   f.inline_rpos = (g.reserved2 & N2V_HOPS_INLINE_RPOS) != 0;  // (the slots kernel's hop table only)
   f.folded = (g.reserved2 & N2V_SLOTS_FOLDED) != 0;  // the edges into wide rows have folded lists and slots
-  f.park_replays = false;
   return f;
 }
 
@@ -511,8 +506,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
         }
         if (!done)  // long lists; a tie or a thin margin: the replays read the list in memory
           idx = pair_listed<uint16_t, kMode>(arr, n, pick, r2, K, avg, nR, w_rpos, nM, list, isR, isM,
-                                             lo_pick, reinterpret_cast<uint16_t *>(stage), lane, w_below,
-                                             F.park_replays);
+                                             lo_pick, reinterpret_cast<uint16_t *>(stage), lane, w_below);
       }
     } else if constexpr (kJumpOnly) {
       // a plain branch on the (uniform) list width: never a select between two loads
@@ -544,7 +538,6 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
     }
 #endif
   }
-  if (idx < 0) return idx;  // (F.park_replays: the step waits for its replay)
   if (defer || idx != pick) h = load_hop(g.hops + vb + idx);
   return idx;
 }

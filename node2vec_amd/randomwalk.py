@@ -46,15 +46,6 @@ def tables_regime(p: float, q: float) -> bool:
     return all(2.0 ** -20 <= 1.0 / x <= 2.0 ** 20 for x in (p, q))
 
 
-def replay_groups_default(graph: DeviceGraph) -> bool:
-    """whether the exact slots kernel steps the replays of long rows in groups (walk_exact_wedge_replay_kernel):
-    N2V_REPLAY_GROUPS=0|1 overrides"""
-    env = os.environ.get("N2V_REPLAY_GROUPS")
-    if env is not None:
-        return env == "1"
-    return False
-
-
 def fresh_seed() -> int:
     """random_seed=None in the reference means an unseeded `random` (randomwalk.py:314)."""
     return int.from_bytes(os.urandom(8), "little")
@@ -80,8 +71,7 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
          stats: Optional[dict] = None, use_edge_classes: bool = True, use_hops: bool = True,
          use_wedges: bool = True, use_wedge_kernel: bool = True, use_hops8: bool = True,
          use_workspace: bool = False, use_wedge_slots: bool = True, use_ranked: Optional[bool] = None,
-         rank_ids: bool = False, use_weighted_lanes: Optional[bool] = None, use_row_sums: bool = True,
-         use_replay_groups: Optional[bool] = None):
+         rank_ids: bool = False, use_weighted_lanes: Optional[bool] = None, use_row_sums: bool = True):
     """Launch K2.  Returns (walks int32 [n_start*num_walks, walk_length+1], valid bool).
 
     mode "fast", and on weighted graphs mode "exact" with return_param == inout_param == 1
@@ -240,8 +230,6 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
         g.wedge_slots = 0
     if not use_row_sums:  # every row added up by the lane that needs its sum (tests: same bits)
         g.row_sums = 0
-    if use_replay_groups if use_replay_groups is not None else replay_groups_default(graph):
-        g.reserved |= 8  # the slots kernel steps the replays of long rows in groups (same bits)
     with torch.cuda.device(graph.device):
         ws_bytes = 0
         if use_workspace and n_start > 0:

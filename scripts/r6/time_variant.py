@@ -22,7 +22,6 @@ for pq in os.environ.get("PQ", "0.5,2.0;3,0.7;4,0.25").split(";"):
 
     def run(k):
         rw.walk(g, start[(k % nb) * b:(k % nb + 1) * b], 10, 80, P_, Q_, 42, out=(walks, valid), check=False,
-                use_replay_groups={"0": False, "1": True}.get(os.environ.get("GROUPS", ""), None),
                 use_workspace=bool(os.environ.get("USE_WS")))  # (USE_WS=1 + a `make WEDGE2=1` library: the passes of n2v_walk_ws)
 
     run(0); torch.cuda.synchronize()
@@ -30,13 +29,5 @@ for pq in os.environ.get("PQ", "0.5,2.0;3,0.7;4,0.25").split(";"):
     for k in range(1, 1 + reps): run(k)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    same = ""
-    if os.environ.get("CHECK"):  # the same batch through the lock-step slots kernel
-        ref = torch.empty_like(walks)
-        rw.walk(g, start[(reps % nb) * b:(reps % nb + 1) * b], 10, 80, P_, Q_, 42, out=(ref, valid), check=False,
-                use_replay_groups=False)
-        torch.cuda.synchronize()
-        same = f" identical={bool(torch.equal(ref, walks))}"
-        del ref
-    print(f"{label}: trim {TRIM} p={P_} q={Q_}: {b * 800 / dt / 1e9:.2f} G steps/s ({dt * 1e3:.2f} ms) slots {g.wedge_slots is not None}{same}",
+    print(f"{label}: trim {TRIM} p={P_} q={Q_}: {b * 800 / dt / 1e9:.2f} G steps/s ({dt * 1e3:.2f} ms) slots {g.wedge_slots is not None}",
           flush=True)
