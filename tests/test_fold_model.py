@@ -84,3 +84,54 @@ def test_a_short_folded_list_packs_its_counts_into_one_halfword():
         assert (hw1 & 0xf, (hw1 >> 4) & 0xf, (hw1 >> 8) & 1) == (below, nlow, upper)
         r_f = rpos if rpos < T else rpos - T
         assert r_f < 1 << 16 and r_f + upper * T == rpos
+
+
+def unlisted_from_top(n, listed, T):
+    """csrc/n2v_unit_core.h unlisted_from_top: the T-th slot from the top (position n - 1 first) that is not listed:
+    h(k) = listed[k] - k never decreases; with i = #{k : h(k) <= c}, c = n - T - len(listed), the slot is c + i"""
+    c = n - T - len(listed)
+    h = np.asarray(listed, dtype=np.int64) - np.arange(len(listed))
+    assert (np.diff(h) >= 0).all()
+    return c + int(np.searchsorted(h, c, side="right"))
+
+
+def other_from_top(n, n_ret, rpos, listed, t):
+    pos = unlisted_from_top(n, listed, t)
+    if n_ret > 0 and pos < rpos + n_ret:
+        pos = unlisted_from_top(n, listed, t + n_ret)
+    return pos
+
+
+def test_the_slot_of_a_rank_is_one_search_of_the_list():
+    """The alias of a pairing with "other" overfull is "the t-th `other` slot from the top" (the stack of :179-181 is
+    popped from the highest position).  The kernels found it by iterating pos = n - t - (listed and return slots
+    >= pos) to its fixed point (rounds 2 - 5) and now by one search (unlisted_from_top / other_from_top): both against
+    a plain count over the row, on rows whose listed slots crowd the low positions as a hub's do."""
+    rng = np.random.default_rng(11)
+    for _ in range(300):
+        n = int(rng.integers(3, 400))
+        n_ret = int(rng.integers(0, 3))
+        rpos = int(rng.integers(0, n - n_ret + 1)) if n_ret else 0
+        free = np.array([x for x in range(n) if not (rpos <= x < rpos + n_ret)])
+        m = int(rng.integers(0, max(1, len(free) - 1)))
+        if rng.random() < 0.5 and m:  # crowded at the low positions
+            k = min(len(free), max(m + m // 3, 1))
+            listed = np.sort(free[:k][rng.permutation(k)[:m]])
+        else:
+            listed = np.sort(rng.choice(free, m, replace=False)) if m else np.array([], dtype=np.int64)
+        special = set(listed.tolist()) | set(range(rpos, rpos + n_ret))
+        others = [x for x in range(n - 1, -1, -1) if x not in special]
+        unlisted = [x for x in range(n - 1, -1, -1) if x not in set(listed.tolist())]
+        for t in range(1, len(unlisted) + 1):
+            assert unlisted_from_top(n, listed, t) == unlisted[t - 1], (n, listed, t)
+        for t in range(1, len(others) + 1):
+            assert other_from_top(n, n_ret, rpos, listed, t) == others[t - 1], (n, n_ret, rpos, listed, t)
+            # the fixed-point iteration of rounds 2 - 5 lands on the same slot (when it converges at all)
+            c = 0
+            for _it in range(len(special) + 2):
+                pos = n - t - c
+                c2 = sum(1 for x in special if x >= pos)
+                if c2 == c:
+                    break
+                c = c2
+            assert n - t - c == others[t - 1]
