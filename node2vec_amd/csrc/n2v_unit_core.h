@@ -41,8 +41,9 @@ __device__ __forceinline__ T pick3(bool first, bool second, T a, T b, T c) {
 static __device__ uint32_t *n2v_decline_words;
 #define N2V_DECLINE(code)                                            \
   do {                                                               \
-    if (n > 64) atomicAdd(n2v_decline_words + (code), 1u);           \
-    if (n >= 4096) atomicAdd(n2v_decline_words + 32 + (code), 1u);   \
+    atomicAdd(n2v_decline_words + 256 + (code), 1u); /* rows of any length */                       \
+    if (n > 64) atomicAdd(n2v_decline_words + ((code) < 32 ? (code) : 96 + (code)), 1u);           \
+    if (n >= 4096 && (code) < 32) atomicAdd(n2v_decline_words + 32 + (code), 1u);   \
     return -1;                                                       \
   } while (0)
 #else
@@ -818,8 +819,8 @@ __device__ __forceinline__ int lane_case_a2_jump(int n, int pick, double r2, con
   const double dn = (double)n;
   const double isum = (double)nR * K.fR + (double)nM * K.fM + (double)nO * K.fO;
   const double EM = K.fM * dn - isum, D = isum - K.fO * dn, DR = isum - K.fR * dn;
-  if (nR <= 0 || nM <= 0 || !(D > 0.0) || !(DR > 0.0) || !(EM > 0.0)) return -1;
-  if (dn * isum > 2.0e14 || dn * dn * K.fM > 4.0e15) return -1;
+  if (nR <= 0 || nM <= 0 || !(D > 0.0) || !(DR > 0.0) || !(EM > 0.0)) N2V_DECLINE(41);
+  if (dn * isum > 2.0e14 || dn * dn * K.fM > 4.0e15) N2V_DECLINE(42);
   const TwoOnStack<P> G(n, nR, rpos, nM, list, below);
   const double drho = (double)G.rho, dnR = (double)nR;
   auto Def = [&](double k) -> double {
@@ -829,18 +830,18 @@ __device__ __forceinline__ int lane_case_a2_jump(int n, int pick, double r2, con
   };
   if (!pickM) {  // underfull: r2 >= its value here (the caller's quick exit took the rest)
     const int k = G.stack_rank(pick, pickR, lo_pick) - 1;  // slots of the stack above pick
-    if (k < 0 || k >= G.nS) return -1;
+    if (k < 0 || k >= G.nS) N2V_DECLINE(43);
     const double T = Def((double)k);
     double i = 1.0;
     if (T > 0.0) {
       i = floor_div(T + EM - 1.0, EM);
-      if (i * EM == T) return -1;  // that listed slot holds exactly 1.0: fp64 decides
+      if (i * EM == T) N2V_DECLINE(44);  // that listed slot holds exactly 1.0: fp64 decides
     }
-    if (!(i >= 1.0) || i > (double)nM) return -1;
+    if (!(i >= 1.0) || i > (double)nM) N2V_DECLINE(45);
     return (int)list[nM - (int)i];
   }
   const int i0 = nM - lo_pick;  // pick is the i0-th listed slot from the top
-  if (i0 < 1 || i0 > nM) return -1;
+  if (i0 < 1 || i0 > nM) N2V_DECLINE(46);
   if (i0 == nM) return pick;  // the last overfull slot: 1.0 within rounding, or never reached
   const double X = (double)i0 * EM;
   double k;  // smallest k with Def(k) > X
@@ -853,10 +854,10 @@ __device__ __forceinline__ int lane_case_a2_jump(int n, int pick, double r2, con
     else
       k = drho + dnR + floor_div(X - Y1 - dnR * DR, D) + 1.0;
   }
-  if (!(k >= 1.0) || k > (double)G.nS) return -1;
-  if (Def(k - 1.0) == X) return -1;
+  if (!(k >= 1.0) || k > (double)G.nS) N2V_DECLINE(47);
+  if (Def(k - 1.0) == X) N2V_DECLINE(48);
   const double prob = 1.0 + (X - Def(k)) / isum;
-  if (fabs(prob - r2) < 1e-9) return -1;
+  if (fabs(prob - r2) < 1e-9) N2V_DECLINE(49);
   return (r2 < prob) ? pick : (int)list[nM - (i0 + 1)];
 }
 
@@ -968,8 +969,8 @@ __device__ __forceinline__ int lane_case_b2_jump(int n, int pick, double r2, con
   // below it are never reached.  The formulas below hold with the ties taken that way (checked
   // against the reference loop in Python: 4.7 M draws, 0 mismatches).
   const bool flat = e == 0.0;
-  if (nR <= 0 || nM <= 0 || nO <= 0 || !(e > 0.0 || flat) || !(eR > 0.0) || !(dM > 0.0)) return -1;
-  if (dn * isum > 2.0e14 || dn * dn * fmax(K.fR, K.fO) > 4.0e15) return -1;
+  if (nR <= 0 || nM <= 0 || nO <= 0 || !(e > 0.0 || flat) || !(eR > 0.0) || !(dM > 0.0)) N2V_DECLINE(61);
+  if (dn * isum > 2.0e14 || dn * dn * fmax(K.fR, K.fO) > 4.0e15) N2V_DECLINE(62);
   const TwoOnStack<P> G(n, nR, rpos, nM, list, below);
   const double drho = (double)G.rho, dnR = (double)nR;
   auto Xo = [&](double t) -> double {
@@ -979,7 +980,7 @@ __device__ __forceinline__ int lane_case_b2_jump(int n, int pick, double r2, con
   };
   if (pickM) {  // underfull: r2 >= its value here
     const int j = nM - lo_pick;
-    if (j < 1 || j > nM) return -1;
+    if (j < 1 || j > nM) N2V_DECLINE(63);
     double t = 1.0;
     if (j > 1) {
       const double Yp = (double)(j - 1) * dM;  // smallest t with Xo(t) >= Yp
@@ -992,23 +993,23 @@ __device__ __forceinline__ int lane_case_b2_jump(int n, int pick, double r2, con
         else if (!flat)
           t = drho + dnR + floor_div(Yp - X1 - dnR * eR + e - 1.0, e);
         else
-          return -1;  // (mass balance: the return run covers every listed slot)
+          N2V_DECLINE(64);  // (mass balance: the return run covers every listed slot)
       }
-      if (!flat && Xo(t) == Yp) return -1;  // that slot holds exactly 1.0: fp64 decides
+      if (!flat && Xo(t) == Yp) N2V_DECLINE(65);  // that slot holds exactly 1.0: fp64 decides
     }
-    if (!(t >= 1.0) || t > (double)G.nS) return -1;
+    if (!(t >= 1.0) || t > (double)G.nS) N2V_DECLINE(66);
     return G.stack_pos((int)t);
   }
   const int t = G.stack_rank(pick, pickR, lo_pick);
-  if (t < 1 || t > G.nS) return -1;
+  if (t < 1 || t > G.nS) N2V_DECLINE(67);
   if (t == G.nS) return pick;  // the last overfull slot: 1.0 within rounding, or never reached
   const double T = Xo((double)t);
   const double j = floor_div(T, dM) + 1.0;
   if (flat && j > (double)nM) return pick;  // never demoted: the end of the return run, "other" below it
-  if (!(j >= 1.0) || j > (double)nM) return -1;
-  if (!flat && j > 1.0 && (j - 1.0) * dM == T) return -1;
+  if (!(j >= 1.0) || j > (double)nM) N2V_DECLINE(68);
+  if (!flat && j > 1.0 && (j - 1.0) * dM == T) N2V_DECLINE(69);
   const double prob = 1.0 + (T - j * dM) / isum;
-  if (fabs(prob - r2) < 1e-9) return -1;
+  if (fabs(prob - r2) < 1e-9) N2V_DECLINE(70);
   if (r2 < prob) return pick;
   if (!pickR) {  // the next slot of the stack is the next position below pick that is not listed
     int cpos = pick - 1, k = lo_pick - 1;
@@ -1122,8 +1123,8 @@ __device__ __forceinline__ int lane_case_a3_jump(int n, int pick, double r2, con
   const double dn = (double)n;
   const double isum = (double)nR * K.fR + (double)nM * K.fM + (double)nO * K.fO;
   const double ER = K.fR * dn - isum, D = isum - K.fO * dn, DM = isum - K.fM * dn;
-  if (nR <= 0 || nM <= 0 || !(ER > 0.0) || !(D > 0.0) || !(DM > 0.0)) return -1;
-  if (dn * isum > 2.0e14 || dn * dn * K.fR > 4.0e15) return -1;
+  if (nR <= 0 || nM <= 0 || !(ER > 0.0) || !(D > 0.0) || !(DM > 0.0)) N2V_DECLINE(81);
+  if (dn * isum > 2.0e14 || dn * dn * K.fR > 4.0e15) N2V_DECLINE(82);
   if (pickR) return (rpos + nR - pick == nR) ? pick : -1;
   const int m_above = nM - lo_pick - (pickM ? 1 : 0);
   int ar = rpos + nR - 1 - pick;  // return slots above pick
@@ -1131,7 +1132,7 @@ __device__ __forceinline__ int lane_case_a3_jump(int n, int pick, double r2, con
   const int o_above = (n - 1 - pick) - ar - m_above;
   const double T = (double)o_above * D + (double)m_above * DM;
   const double iq = floor_div(T, ER);
-  if (T > 0.0 && fma(-iq, ER, T) == 0.0) return -1;  // that return slot holds exactly 1.0
+  if (T > 0.0 && fma(-iq, ER, T) == 0.0) N2V_DECLINE(83);  // that return slot holds exactly 1.0
   if (iq >= (double)nR) return 0;  // never paired: alias stays 0 (:170)
   return rpos + nR - 1 - (int)iq;
 }

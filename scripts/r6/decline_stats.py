@@ -3,11 +3,11 @@ loop decline on rows of more than 64 slots (codes: n2v_unit_core.h, N2V_DECLINE)
 import os, sys, time, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
-os.environ["N2V_DIAG_STATUS_WORDS"] = "128"
+os.environ["N2V_DIAG_STATUS_WORDS"] = "512"
 from node2vec_amd import _lib
 _lib.LIB_PATH = os.path.join(ROOT, "build_variants", "libn2v_wedge_declines.so")
 from node2vec_amd import synthetic, randomwalk as rw
-TRIM = int(os.environ.get("TRIM", 100_000))
+TRIM = int(os.environ.get("TRIM", 100_000))  # (cycle counts of this build are NOT usable: its counters are contended atomics)
 g = synthetic.chung_lu(100_000_000, 500_000_000, device="cuda").trimmed(TRIM, 42)
 start = rw.start_vertices(g)[:1 << 18].contiguous()
 for pq in os.environ.get("PQ", "0.5,2;4,0.25").split(";"):
@@ -25,6 +25,9 @@ for pq in os.environ.get("PQ", "0.5,2;4,0.25").split(";"):
     ex = st["status"].cpu().numpy().astype("uint32")[8 + 80:8 + 83]
     print(f"   lane_case_b: one-by-one counts of other_pos {int(ex[0])}, loop iterations {int(ex[1])}, corrections of the "
           f"cascade length {int(ex[2])}", flush=True)
+    allw = st["status"].cpu().numpy().astype("uint32")[8:]
+    print("   declines by reason, rows of any length: " + str({c: int(allw[256 + c]) for c in range(1, 100) if allw[256 + c]})
+          + "; rows > 64, codes 40+: " + str({c: int(allw[96 + c]) for c in range(32, 100) if allw[96 + c]}), flush=True)
     for name, o in (("rows > 64", 0), ("rows >= 4096", 32)):
         codes = {c: int(s[o + c]) for c in range(1, 24) if s[o + c]}
         arrs = {a: int(s[o + 24 + a]) for a in range(6) if s[o + 24 + a]}
