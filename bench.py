@@ -557,7 +557,9 @@ def bench_reference_cap(args, cfg, torch, dist, rw, dev, W, L, rank, world, barr
         res[name] = {"value": s_ / e, "unit": "walk-steps/s", "ms_per_step": 1e3 * e / args.steps,
                      "kernel": kernel_name(g2, p2, q2)}
         if rank == 0 and name == "exact_biased_0.5_2":
-            res[name]["roofline"] = roofline(kernel_name(g2, p2, q2), r, leg, args.config, p2, q2, "exact", None)
+            # (its own key in profiles/pmc_traffic.json: another graph than the config's)
+            res[name]["roofline"] = roofline(kernel_name(g2, p2, q2), r, leg, args.config + "@cap100000", p2, q2,
+                                             "exact", None)
         del leg
         torch.cuda.empty_cache()
     res["wedge_table"] = {"mode": int(g2.wedge_mode), "slots": g2.wedge_slots is not None,
