@@ -141,3 +141,42 @@ def test_product_package_never_touches_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "n2v_oracle" not in text.replace("oracle/n2v_oracle", ""), f
                 assert "import n2v_oracle" not in text, f
+
+
+def test_round6_table_builders_validate_their_arguments():
+    """n2v_wedge_slots_fold / n2v_edge_row_sums_build (ABI 15): argument errors come back as N2V_EINVAL (-1) before
+    anything is launched (no GPU needed); nothing to do is N2V_OK"""
+    from node2vec_amd import _lib
+
+    L = _lib.load()
+    buf = (ctypes.c_int64 * 64)()
+    p_ = ctypes.addressof(buf) & ~31  # (32-byte aligned, inside the buffer's page: never dereferenced)
+
+    def graph(**kw):
+        g = _lib.Graph()
+        g.n_vertices, g.n_edges = 4, 8
+        g.rowptr = g.col = g.edge_classes = g.wedge_off = g.wedge_pos = p_
+        g.wedge_wide = 65536
+        for k, v in kw.items():
+            setattr(g, k, v)
+        return g
+
+    def fold(g, off=p_, pos=p_, slots=p_):
+        return L.n2v_wedge_slots_fold(g, off, pos, slots, None)
+
+    assert fold(graph(n_edges=0)) == 0 and fold(graph(n_edges=-1)) == -1
+    assert fold(graph(wedge_wide=0)) == -1 and fold(graph(wedge_wide=1)) == -1 and fold(graph(wedge_wide=70000)) == -1
+    assert fold(graph(edge_classes=0)) == -1 and fold(graph(wedge_off=0)) == -1 and fold(graph(rowptr=0)) == -1
+    assert fold(graph(), off=0) == -1 and fold(graph(), slots=0) == -1
+    assert fold(graph(), pos=p_ + 64) == -1  # the folded copies go into the graph's own wedge_pos
+    assert fold(graph(), slots=p_ + 8) == -1  # 32-byte slots
+
+    def sums(g, p=3.0, q=0.7, edges=p_, k=1, out=p_):
+        return L.n2v_edge_row_sums_build(g, p, q, edges, k, out, None)
+
+    assert sums(graph(), k=0) == 0 and sums(graph(), k=-1) == -1
+    assert sums(graph(), p=0.0) == -1 and sums(graph(), q=0.0) == -1  # randomwalk.py:214-217
+    assert sums(graph(w=p_)) == -1 and sums(graph(w64=p_)) == -1  # unit weights only
+    assert sums(graph(edge_classes=0)) == -1 and sums(graph(wedge_pos=0)) == -1
+    assert sums(graph(), edges=0) == -1 and sums(graph(), out=0) == -1
+    assert sums(graph(), p=1e-30) == -1  # 1/p outside 2^-20 .. 2^20 and not dyadic: no unit-weight kernel walks it
