@@ -22,6 +22,7 @@ for pq in os.environ.get("PQ", "0.5,2.0;3,0.7;4,0.25").split(";"):
 
     def run(k):
         rw.walk(g, start[(k % nb) * b:(k % nb + 1) * b], 10, 80, P_, Q_, 42, out=(walks, valid), check=False,
+                mode=os.environ.get("MODE", "exact"),
                 use_workspace=bool(os.environ.get("USE_WS")))  # (USE_WS=1 + a `make WEDGE2=1` library: the passes of n2v_walk_ws)
 
     run(0); torch.cuda.synchronize()
