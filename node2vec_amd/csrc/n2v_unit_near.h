@@ -194,7 +194,9 @@ __device__ __forceinline__ int lane_case_b_near(int n, int pick, double r2, cons
   // the "other" slot of rank t + 1 is the next one below pick: usually pick - 1, found from the
   // rank of pick in the list (no search); other_pos() if the row runs out (it cannot: t < nO)
   int cpos = pick - 1, k = lo_pick - 1;
-  while (cpos >= 0) {
+  // (at most four steps down: where the listed slots crowd -- the low positions of a hub's row -- the walk down a run of
+  // them is a chain of dependent loads as long as the run; the search below finds the slot whatever lies between)
+  for (int tries = 0; cpos >= 0 && tries < 4; ++tries) {
     if (nR > 0 && cpos >= rpos && cpos < rpos + nR) {
       cpos = rpos - 1;
       continue;
@@ -313,7 +315,7 @@ __device__ __forceinline__ int lane_case_b2_near(int n, int pick, double r2, con
   if (r2 < prob) return pick;
   if (!pickR) {  // the next slot of the stack is the next position below pick that is not listed
     int cpos = pick - 1, k = lo_pick - 1;
-    while (cpos >= 0) {
+    for (int tries = 0; cpos >= 0 && tries < 4; ++tries) {  // (at most four steps down, then the search)
       while (k >= 0 && (int)list[k] > cpos) --k;
       if (k >= 0 && (int)list[k] == cpos) {
         --cpos;
