@@ -634,6 +634,21 @@ def bench_weighted(args, torch, rw, dev, W, L):
                                                "(40 MB of weights in all): the kernels are bound by vector "
                                                "instructions, not by these bytes"},
            "kernel": "walk_weighted_lane_margin_kernel + walk_weighted_margin_kernel (n2v_walk_weighted_step)"}
+    # What bounds this leg is vector-instruction issue, not bytes: the committed counter passes
+    # of exactly this call (profiles/r9w_wm_pmc.txt: SQ_INSTS_VALU per dispatch, one dispatch of each kernel per
+    # step) against what the chip's 1024 SIMDs issue -- one wave-instruction per 4 cycles each -- in the step
+    # time measured HERE.  (The kernels have not changed since those passes; `frac` of the HBM object above counts
+    # bytes that are hot in L2.)
+    valu_per_step = 1.016e9 + 7.264e8 + 1.532e6 + 5.202e5 + 4.803e5  # margin (wave) + lane margin + keys + second chance + exact
+    step_s = best / L
+    res["valu_issue"] = {"wave_instructions_per_step_committed": valu_per_step,
+                         "source": "profiles/r9w_wm_pmc.txt (rocprofv3 --pmc SQ_INSTS_VALU of this call, 160 steps)",
+                         "issue_ms_per_step": 1e3 * valu_per_step * 4.0 / (1024 * 2.4e9),
+                         "step_ms": 1e3 * step_s,
+                         "frac": valu_per_step * 4.0 / (1024 * 2.4e9) / step_s,
+                         "note": "256 CUs x 4 SIMDs, a 64-lane vector instruction every 4 cycles per SIMD at 2.4 GHz; "
+                                 "the wave kernel of the long rows also waits on three dependent levels of loads "
+                                 "(DESIGN.md 5)"}
     del g, walks, valid
     torch.cuda.empty_cache()
     return res
