@@ -420,8 +420,15 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
   } else {
     const int64_t isum = (int64_t)nR * K.TR + (int64_t)nM * K.TM + (int64_t)nO * K.TO;
     avg = ((double)isum * (1.0 / 1048576.0)) / (double)n;
+#if defined(N2V_ABLATE_STEP) && N2V_ABLATE_STEP == 8  // timing only: neither division of the quick path (with 2: no pairing either)
+    avg = ((double)isum * (1.0 / 1048576.0)) * 1e-3;
+#endif
   }
+#if defined(N2V_ABLATE_STEP) && N2V_ABLATE_STEP == 8
+  const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) * 0.9 + avg * 1e-30;
+#else
   const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) / avg;  // :173
+#endif
   if (p_pick < 1.0 && r2 < p_pick) {  // an accepted underfull slot is final
     if (defer) h = load_hop(g.hops + vb + idx);
     return idx;
@@ -430,7 +437,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
   if (!kSlots) return idx;
 #endif
 #ifdef N2V_ABLATE_STEP  // timing only: 2 = no pairing at all, 3 = none on rows of 4096 slots and more
-  if (N2V_ABLATE_STEP == 2 || (N2V_ABLATE_STEP == 3 && n >= 4096)) {
+  if (N2V_ABLATE_STEP == 2 || N2V_ABLATE_STEP == 8 || (N2V_ABLATE_STEP == 3 && n >= 4096)) {
     if (defer) h = load_hop(g.hops + vb + idx);
     return idx;
   }
