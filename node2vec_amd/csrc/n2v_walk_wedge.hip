@@ -368,7 +368,7 @@ void walk_exact_wedge_slots_kernel(
         idx = pick_index(u1, n);
         const int4 *q = reinterpret_cast<const int4 *>(g.hops) + ((vb + idx) << F.hop_shift);
         h = load_hop(reinterpret_cast<const n2v_hop *>(q));
-        if (F.hop_shift) ext = q[1];
+        if (F.hop_shift && (!F.inline_rpos || (h.classes & N2V_EC_INLINE) == 0u || h.classes == 0xffffffffu)) ext = q[1];
       }
       const int32_t x = h.col;
       emit(step + 1, x);

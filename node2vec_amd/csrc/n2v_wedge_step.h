@@ -220,7 +220,10 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
     h.col = v.x;
     h.classes = (uint32_t)v.y;
     h.row = (uint64_t)(uint32_t)v.z | ((uint64_t)(uint32_t)v.w << 32);
-    if (hop32) *ext = q[1];
+    // (the half slot only where the next step reads it: an edge whose class word carries its return position has no
+    // list -- on cfg 5, where no edge has one, the wider read cost 10 % for nothing; the second load is of the sector
+    // the first has just brought)
+    if (hop32 && (F.inline_rpos == false || ((uint32_t)v.y & N2V_EC_INLINE) == 0u || (uint32_t)v.y == 0xffffffffu)) *ext = q[1];
   };
   if constexpr (kSlots) {
     // mixed wedge table (g.wedge_wide = T >= 2): the edges into a row of T entries or more have

@@ -94,6 +94,7 @@ class DeviceGraph:
         self.row_sums = None
         self.hops_inline_rpos = False  # the hop table's class words carry return positions (slots kernel)
         self._inline_ok = None  # (edge_classes tensor, every return count < 128): can_inline_rpos()
+        self._listed_share = None  # (edge_classes tensor, share of edges with shared neighbours): listed_share()
         # the degree-ranked form (build_ranked): 4-byte entries for p = q = 1 walks
         self.rank_hops: Optional[torch.Tensor] = None  # int32 [E] (uint32 ranks)
         self.rank_of: Optional[torch.Tensor] = None  # int32 [V] vertex id -> rank
@@ -526,6 +527,15 @@ class DeviceGraph:
         self.hops_inline_rpos = inline_rpos
         self.hops_have_classes = self.edge_classes is not None
         return self
+
+    def listed_share(self) -> float:
+        """share of the edges that have shared neighbours (a list the walker's next step reads); cached"""
+        if self.edge_classes is None or self.n_edges == 0:
+            return 0.0
+        if self._listed_share is None or self._listed_share[0] is not self.edge_classes:
+            self._listed_share = (self.edge_classes,
+                                  float(((self.edge_classes & 0xffffff) != 0).float().mean()))
+        return self._listed_share[1]
 
     def build_hops32(self, max_bytes: Optional[int] = None) -> "DeviceGraph":
         """32-byte hop entries for the exact slots kernel (N2V_HOPS_WITH_SLOT): the hop entry of every edge followed

@@ -198,11 +198,13 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
                 or (biased and mode == "exact" and graph.hops_inline_rpos != want_inline)):
             graph.build_hops(inline_rpos=want_inline)
         # 32-byte hop entries for the exact slots kernel (the hop entry + the first half of the edge's slot)
-        # (default: graphs without rows of 65 536 slots and more -- there it is worth 5 - 9 % at (0.5, 2) and
-        # (0.25, 0.5) for 32 more bytes per edge; with such rows 1 %: profiles/r14a_time.log.  N2V_HOPS32=0|1 overrides.)
+        # (default: graphs without rows of 65 536 slots and more on which a quarter of the edges or more have a list --
+        # cfg 4: half of them, + 3 - 9 % by (p, q) for 32 more bytes per edge; with wide rows + 1 %; cfg 5, where no
+        # edge has a list, - 0 - 4 %: profiles/r14a_time.log, r14f_time.log.  N2V_HOPS32=0|1 overrides.)
         if use_hops32 is None:
             env = os.environ.get("N2V_HOPS32")
-            use_hops32 = (env == "1") if env is not None else graph.wedge_mode == 0
+            use_hops32 = (env == "1") if env is not None else (
+                bool(want_inline) and graph.wedge_mode == 0 and graph.listed_share() >= 0.25)
         hops32 = bool(use_hops32 and want_inline and mode == "exact" and graph.hops_inline_rpos
                       and (graph.wedge_mode == 0 or graph.slots_folded))
         if hops32 and graph.hops32 is None:
