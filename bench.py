@@ -485,7 +485,7 @@ def main():
         del leg
         torch.cuda.empty_cache()
     # the walk tables are not needed any more (the CPU baseline reads rowptr / col only)
-    g.slots = g.pivots = g.hops = g.hops32 = g.hops8 = g.edge_classes = g.wedge_off = g.wedge_pos = None
+    g.slots = g.pivots = g.hops = g.hops8 = g.edge_classes = g.wedge_off = g.wedge_pos = None
     g.wedge_slots = g.rank_hops = g.rank_of = g.rank_vertex = g.row_sums = None
     torch.cuda.empty_cache()
 
@@ -871,19 +871,10 @@ def roofline(kernel, res, leg, config, p, q, mode, ref_bytes):
             # and read the slot for the return position alone are not counted)
             share = float(((leg.g.edge_classes & 0xffffff) != 0).float().mean())
             alg = 16 + 4 + 32 * share
-            if getattr(leg.g, "hops32", None) is not None and leg.g.wedge_mode == 0:
-                # 32-byte hop entries (hop entry + first half of the edge's slot): the slot's own sector only for
-                # lists of more than six entries
-                share6 = float(((leg.g.edge_classes & 0xffffff) > 6).float().mean())
-                alg = 32 + 4 + 32 * share6
         formula = (("16 (hop entry) + 4 (path write)" if hops else
                     "16 (rowptr pair) + 4 (edge class word) + 4 (col[pick]) + 4 (path write)") +
                    " per step" +
-                   (", read as ONE 32-byte entry with the first half of the edge's slot (return position, counts, six "
-                    "list entries: what the next step needs); + 32 (the slot's own sector) x the share of edges with "
-                    "more than six shared neighbours" if slots and getattr(leg.g, "hops32", None) is not None
-                    and leg.g.wedge_mode == 0 else
-                    ", + 32 (the edge's wedge slot: return position + the list itself up to 14 entries, "
+                   (", + 32 (the edge's wedge slot: return position + the list itself up to 14 entries, "
                     "else its offset and eight pivots) x the share of edges with shared neighbours (counted "
                     "in the figure above; probes of longer lists and slots read for the return position "
                     "alone are not)" if slots else

@@ -170,12 +170,6 @@ typedef struct n2v_graph {
 /* bit 1 of reserved2 (ABI 15): the wedge slots of the edges into rows of wedge_wide .. wedge_wide + 65536 entries are
  * FOLDED slots (n2v_wedge_slots_fold) -- the exact slots kernel then steps those rows like every other */
 #define N2V_SLOTS_FOLDED 2
-/* bit 2 of reserved2 (ABI 15): `hops` holds 32-BYTE entries for the exact slots kernel -- the 16-byte hop entry of edge
- * e followed by the first 16 bytes of wedge_slots[e] (return position, counts, the first six entries of the list).  The
- * list a walker needs at its next step is the list of the edge it picks now: it arrives in the sector the hop gather
- * fetches anyway, and the slot's own sector is read only for lists of more than six entries.  The caller interleaves
- * the two tables (node2vec_amd/graph.py: build_hops32); only the exact slots kernel takes such a table. */
-#define N2V_HOPS_WITH_SLOT 4
 
 int n2v_abi_version(void);
 const char *n2v_status_string(int code);

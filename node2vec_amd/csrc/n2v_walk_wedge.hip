@@ -353,7 +353,6 @@ void walk_exact_wedge_slots_kernel(
     }
     int32_t s = -1, v = start;
     bool walking = alive;
-    int4 ext = make_int4(0, 0, 0, 0);  // (32-byte hop entries: the slot half that came with the entry of the edge walked last)
     for (int step = 0; step < walk_length; ++step) {
       if (ballot64(walking) == 0ull) break;
       if (!walking) continue;
@@ -363,12 +362,10 @@ void walk_exact_wedge_slots_kernel(
       int idx;
       if (s >= 0) {
         idx = wedge_step<kMode, false, true>(g, K, F, u1, u2, s, vb, n, e_prev, ec_prev, h, stage, lane,
-                                             status, nullptr, &ext);
+                                             status);
       } else {  // first step: generate_alias_tables of unit weights is the uniform draw (:320-321)
         idx = pick_index(u1, n);
-        const int4 *q = reinterpret_cast<const int4 *>(g.hops) + ((vb + idx) << F.hop_shift);
-        h = load_hop(reinterpret_cast<const n2v_hop *>(q));
-        if (F.hop_shift && (!F.inline_rpos || (h.classes & N2V_EC_INLINE) == 0u || h.classes == 0xffffffffu)) ext = q[1];
+        h = load_hop(g.hops + vb + idx);
       }
       const int32_t x = h.col;
       emit(step + 1, x);
@@ -560,7 +557,7 @@ int n2v_walk_wedge_try(const n2v_graph *g, const int32_t *start_ids, int64_t n_s
     if (hipGetLastError() != hipSuccess) return N2V_ELAUNCH;
     return 1;
   }
-  if (g->reserved2 & (N2V_HOPS_INLINE_RPOS | N2V_HOPS_WITH_SLOT)) return N2V_EINVAL;  // that hop table is the slots kernel's
+  if (g->reserved2 & N2V_HOPS_INLINE_RPOS) return N2V_EINVAL;  // that hop table is the slots kernel's
   n2v_graph gp = *g;
   gp.row_sums = nullptr;  // (this kernel adds every row up itself)
   g = &gp;

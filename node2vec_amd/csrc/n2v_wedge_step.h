@@ -153,7 +153,6 @@ __device__ __forceinline__ int jump_listed(int arr, int n, int pick, double r2, 
 // what a kernel needs of (p, q) beyond UnitConsts, computed once
 struct StepFlags {
   bool need_mem, always_pair, merge_r, w_wide, inline_rpos, folded;
-  int hop_shift;  // 1: `hops` holds 32-byte entries, the hop entry of an edge followed by the first half of its wedge slot
 };
 __device__ __forceinline__ StepFlags step_flags(const n2v_graph &g, const UnitConsts &K, double q) {
   StepFlags f;
@@ -163,7 +162,6 @@ __device__ __forceinline__ StepFlags step_flags(const n2v_graph &g, const UnitCo
   f.w_wide = g.wedge_wide == 1;  // (a mixed table, wedge_wide >= 2: by the row, in wedge_step)
   f.inline_rpos = (g.reserved2 & N2V_HOPS_INLINE_RPOS) != 0;  // (the slots kernel's hop table only)
   f.folded = (g.reserved2 & N2V_SLOTS_FOLDED) != 0;  // the edges into wide rows have folded lists and slots
-  f.hop_shift = (g.reserved2 & N2V_HOPS_WITH_SLOT) != 0 ? 1 : 0;
   return f;
 }
 
@@ -180,7 +178,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
                                           uint32_t u1, uint32_t u2, int32_t s, int64_t vb, int n,
                                           int64_t e_prev, uint32_t ec_prev, n2v_hop &h,
                                           uint32_t *stage, int lane, uint32_t *status,
-                                          uint16_t *lds_list = nullptr, int4 *ext = nullptr);
+                                          uint16_t *lds_list = nullptr);
 
 // the step of a walker standing on a WIDE row of a mixed wedge table, out of line (N2V_WIDE_NOINLINE):
 // it is taken by a few per cent of the steps at most, and inlined into the slots kernel its 32-bit
@@ -205,26 +203,9 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
                                           uint32_t u1, uint32_t u2, int32_t s, int64_t vb, int n,
                                           int64_t e_prev, uint32_t ec_prev, n2v_hop &h,
                                           uint32_t *stage, int lane, uint32_t *status,
-                                          uint16_t *lds_list, int4 *ext) {
+                                          uint16_t *lds_list) {
   constexpr bool kShared = kMode == 1 || kMode == 2;
   bool folded = false;  // this lane stands on a wide row and reads a folded slot / list
-  // 32-byte hop entries (N2V_HOPS_WITH_SLOT; *ext: in = the slot half that came with the entry of the edge walked last,
-  // out = the one that comes with the entry of this step's result): the list a walker needs at its NEXT step is the list
-  // of the edge it picks now, so the first half of that edge's slot -- return position, counts, six entries -- rides
-  // in the sector the hop gather fetches anyway
-  const bool hop32 = kSlots && F.hop_shift != 0 && ext != nullptr;
-  const int4 ext_in = hop32 ? *ext : make_int4(0, 0, 0, 0);
-  auto fetch = [&](int64_t at) {
-    const int4 *q = reinterpret_cast<const int4 *>(g.hops) + (at << F.hop_shift);
-    const int4 v = q[0];
-    h.col = v.x;
-    h.classes = (uint32_t)v.y;
-    h.row = (uint64_t)(uint32_t)v.z | ((uint64_t)(uint32_t)v.w << 32);
-    // (the half slot only where the next step reads it: an edge whose class word carries its return position has no
-    // list -- on cfg 5, where no edge has one, the wider read cost 10 % for nothing; the second load is of the sector
-    // the first has just brought)
-    if (hop32 && (F.inline_rpos == false || ((uint32_t)v.y & N2V_EC_INLINE) == 0u || (uint32_t)v.y == 0xffffffffu)) *ext = q[1];
-  };
   if constexpr (kSlots) {
     // mixed wedge table (g.wedge_wide = T >= 2): the edges into a row of T entries or more have
     // uint32 lists and no slot -- the step of a walker standing on such a row goes through wedge_off
@@ -232,7 +213,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
     if (g.wedge_wide >= 2 && n >= g.wedge_wide) {
 #if defined(N2V_ABLATE_WIDE) && N2V_ABLATE_WIDE == 1  // timing only: a wide step is a plain uniform draw
       const int pk = pick_index(u1, n);
-      fetch(vb + pk);
+      h = load_hop(g.hops + vb + pk);
       return pk;
 #endif
       // (round 6) a wide row: its edges have FOLDED lists and slots (ListRef, n2v_wedge_slots_fold) and it takes the
@@ -242,7 +223,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
       if (!(F.folded && n - g.wedge_wide <= 65536)) {  // slots that do not belong to this graph
         atomicOr(status, N2V_ST_RANGE);
         const int pk = pick_index(u1, n);
-        fetch(vb + pk);
+        h = load_hop(g.hops + vb + pk);
         return pk;
       }
       folded = true;
@@ -263,14 +244,8 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
   int4 sa = make_int4(0, 0, 0, 0), sb = make_int4(0, 0, 0, 0);
   bool w_loaded = inl;
   if (inl) sa.x = (int)(ec_prev & 0xffffu);  // halfword 0: the return position (16-bit positions), 1: below = 0
-  if (hop32 && !inl) sa = ext_in;
   const uint16_t *slot = nullptr;
   if constexpr (kSlots) slot = reinterpret_cast<const uint16_t *>(g.wedge_slots) + e_prev * 16;
-  // (32-byte hop entries: a list of up to six entries is read where it was fetched -- behind the hop entry of e_prev --
-  // and the slot's own sector is never touched)
-  const uint16_t *slot_list = slot + 2;
-  if (hop32 && fM <= 6u)
-    slot_list = reinterpret_cast<const uint16_t *>(reinterpret_cast<const int4 *>(g.hops) + (e_prev << 1) + 1) + 2;
   // what the slot says once its first 16 bytes are in `sa`.  A FOLDED slot (n2v_wedge_slots_fold: the edge leads into
   // a wide row) packs three more numbers: whether the return position lies in the upper part, the entries of the list
   // in the lower part (ListRef::nlow), and the high bits of counts that a list of up to 2^20 entries needs --
@@ -299,12 +274,8 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
     if constexpr (kSlots) {
       // (asking for the second half only when the list has more than six entries was measured
       // and changes nothing: -3 .. +4 % by (p, q), profiles/r4i_time_slots_on_demand.log)
-      if (hop32) {  // the first half came with the hop entry of the step before; the second holds entries 6 .. 13 / the pivots
-        if (fM > 6u) sb = reinterpret_cast<const int4 *>(slot)[1];
-      } else {
-        sa = reinterpret_cast<const int4 *>(slot)[0];
-        sb = reinterpret_cast<const int4 *>(slot)[1];
-      }
+      sa = reinterpret_cast<const int4 *>(slot)[0];
+      sb = reinterpret_cast<const int4 *>(slot)[1];
     } else {
       wraw = g.wedge_off[e_prev];
     }
@@ -322,7 +293,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
   // is requested at once, as before, and arrives behind them -- waiting with it cost the graph trimmed at the
   // reference's cap, whose hub steps are such searches, 10 %: 14.0 -> 12.6 G.)
   const bool defer = N2V_DEFER_HOP && (inl || (N2V_DEFER_HOP == 2 && kSlots && w_loaded && fM <= (uint32_t)kSlotShort));
-  if (!defer) fetch(vb + pick);
+  if (!defer) h = load_hop(g.hops + vb + pick);
   if (!counts_ok) {
     atomicOr(status, N2V_ST_RANGE);
     return idx;
@@ -367,14 +338,12 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
 #endif
       if constexpr (kSlots) {
         if (!w_loaded) {  // an edge without shared neighbours whose step got here: its return position
-          if (!hop32) {
-            sa = reinterpret_cast<const int4 *>(slot)[0];
-            sb = reinterpret_cast<const int4 *>(slot)[1];
-          }
+          sa = reinterpret_cast<const int4 *>(slot)[0];
+          sb = reinterpret_cast<const int4 *>(slot)[1];
           w_loaded = true;
         }
         if (N2V_NEAR_FORMS) {
-          const uint16_t *nlist = slot_list;
+          const uint16_t *nlist = slot + 2;
           if (nM > kSlotShort)
             nlist = reinterpret_cast<const uint16_t *>(g.wedge_pos) +
                     ((uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32));
@@ -382,7 +351,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
                                               ListRef<uint16_t>(nlist, slot_nlow(), g.wedge_wide), isR, isM, lo_pick,
                                               slot_below());
           if (res >= 0) {
-            if (defer || res != pick) fetch(vb + res);
+            if (defer || res != pick) h = load_hop(g.hops + vb + res);
             return res;
           }
 #ifdef N2V_NEAR_COUNT  // diagnostic build: steps past the quick accept ([2]) / declined by the closed forms ([3])
@@ -390,7 +359,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
 #endif
 #ifdef N2V_ABLATE_STEP  // timing only: 6 = a step the closed forms with margins decline keeps `pick` (no row sum, no replay)
           if (N2V_ABLATE_STEP == 6 || (N2V_ABLATE_STEP == 7 && n >= 4096)) {
-            fetch(vb + pick);
+            h = load_hop(g.hops + vb + pick);
             return pick;
           }
 #endif
@@ -399,7 +368,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
           // a long row: the sum of this edge's table was added up once (n2v_edge_row_sums_build: this routine, these bits)
           avg = g.row_sums[e_prev] / (double)n;
         } else {
-        const uint16_t *sum_list = slot_list;
+        const uint16_t *sum_list = slot + 2;
         if (nM > kSlotShort) {
           sum_list = reinterpret_cast<const uint16_t *>(g.wedge_pos) +
                      ((uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32));
@@ -434,7 +403,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
             res = near_step<uint16_t>(n, pick, r2, K, nR, rp, nM,
                                       reinterpret_cast<const uint16_t *>(g.wedge_pos) + w_off, isR, isM, lo_pick, -1);
           if (res >= 0) {
-            if (res != pick) fetch(vb + res);
+            if (res != pick) h = load_hop(g.hops + vb + res);
             return res;
           }
         }
@@ -461,7 +430,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
   const double p_pick = pick3(isR, isM, K.bR, K.bM, K.bO) / avg;  // :173
 #endif
   if (p_pick < 1.0 && r2 < p_pick) {  // an accepted underfull slot is final
-    if (defer) fetch(vb + idx);
+    if (defer) h = load_hop(g.hops + vb + idx);
     return idx;
   }
 #if defined(N2V_ABLATE_WIDE) && N2V_ABLATE_WIDE == 2  // timing only: a wide step never pairs
@@ -469,7 +438,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
 #endif
 #ifdef N2V_ABLATE_STEP  // timing only: 2 = no pairing at all, 3 = none on rows of 4096 slots and more
   if (N2V_ABLATE_STEP == 2 || N2V_ABLATE_STEP == 8 || (N2V_ABLATE_STEP == 3 && n >= 4096)) {
-    if (defer) fetch(vb + idx);
+    if (defer) h = load_hop(g.hops + vb + idx);
     return idx;
   }
 #endif
@@ -485,7 +454,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
 #endif
     if (!w_loaded) {  // the return position (and an empty list)
       if constexpr (kSlots) {
-        if (!hop32) sa = reinterpret_cast<const int4 *>(slot)[0];
+        sa = reinterpret_cast<const int4 *>(slot)[0];
       } else {
         wraw = g.wedge_off[e_prev];
         w_off = (int64_t)(wraw & N2V_WEDGE_OFF_MASK);
@@ -508,7 +477,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
       // entries of the list below the return position (stored: saves the routines a search)
       const int w_below = slot_below();
       // the list as the pairing routines read it: inside the slot, or in wedge_pos
-      const uint16_t *list_p = slot_list;
+      const uint16_t *list_p = slot + 2;
       if (nM > kSlotShort)
         list_p = reinterpret_cast<const uint16_t *>(g.wedge_pos) +
                  ((uint64_t)(uint32_t)sa.z | ((uint64_t)(uint32_t)sa.w << 32));
@@ -517,7 +486,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
         idx = jump_listed<uint16_t, kMode>(arr, n, pick, r2, K, nR, w_rpos, nM, list, isR, isM, lo_pick,
                                            w_below);
         if (idx < 0) {
-          if (defer) fetch(vb + pick);
+          if (defer) h = load_hop(g.hops + vb + pick);
           return -1;
         }
       } else {
@@ -576,7 +545,7 @@ __device__ __forceinline__ int wedge_step(const n2v_graph &g, const UnitConsts &
     }
 #endif
   }
-  if (defer || idx != pick) fetch(vb + idx);
+  if (defer || idx != pick) h = load_hop(g.hops + vb + idx);
   return idx;
 }
 

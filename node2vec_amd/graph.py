@@ -77,7 +77,6 @@ class DeviceGraph:
         self.edge_classes: Optional[torch.Tensor] = None  # uint32-in-int32 [E] (exact mode, unit weights)
         self.hops: Optional[torch.Tensor] = None  # int32 [E, 4] view of n2v_hop[E] (unit weights)
         self.hops_have_classes = False
-        self.hops32: Optional[torch.Tensor] = None  # int32 [E, 8]: hop entry + first half of the wedge slot (build_hops32)
         self.hops8: Optional[torch.Tensor] = None  # int64 [E]: 8-byte hop entries (p = q = 1 walks)
         self.hops8_bits = (0, 0)  # (col_bits, row_bits) of a hops8 entry
         self.hops8_rowptr: Optional[torch.Tensor] = None  # int64 [V + 1]: padded rows of the hops8 table
@@ -94,7 +93,6 @@ class DeviceGraph:
         self.row_sums = None
         self.hops_inline_rpos = False  # the hop table's class words carry return positions (slots kernel)
         self._inline_ok = None  # (edge_classes tensor, every return count < 128): can_inline_rpos()
-        self._listed_share = None  # (edge_classes tensor, share of edges with shared neighbours): listed_share()
         # the degree-ranked form (build_ranked): 4-byte entries for p = q = 1 walks
         self.rank_hops: Optional[torch.Tensor] = None  # int32 [E] (uint32 ranks)
         self.rank_of: Optional[torch.Tensor] = None  # int32 [V] vertex id -> rank
@@ -372,7 +370,7 @@ class DeviceGraph:
         _lib.require_gpu()
         if self.edge_classes is None:
             self.build_edge_classes()
-        self.wedge_off = self.wedge_pos = self.wedge_slots = self.hops32 = None
+        self.wedge_off = self.wedge_pos = self.wedge_slots = None
         self.wedge_mode = 0
         self.slots_folded = False
         if self.n_edges == 0 or int(self.degrees().max()) >= self.HOP_MAX_DEGREE:
@@ -466,7 +464,7 @@ class DeviceGraph:
         kernel then fetches hop entry and list in two independent gathers instead of hop, offset
         and list (DESIGN.md "K2 exact, biased").  Needs the wedge table with 16-bit positions."""
         L = _lib.load()
-        self.wedge_slots = self.hops32 = None
+        self.wedge_slots = None
         if self.wedge_off is None or self.wedge_pos is None or self.wedge_mode == 1:
             return self
         slots = torch.empty((self.n_edges, 16), dtype=torch.int16, device=self.device)
@@ -511,7 +509,6 @@ class DeviceGraph:
             self.hops = None
             return self
         self.hops = None  # the kernel must not read a half-written table through c_struct()
-        self.hops32 = None
         inline_rpos = bool(inline_rpos) and self.can_inline_rpos()
         hops = torch.empty((self.n_edges, 4), dtype=torch.int32, device=self.device)
         status = torch.zeros(4, dtype=torch.int32, device=self.device)
@@ -526,31 +523,6 @@ class DeviceGraph:
         self.hops = hops
         self.hops_inline_rpos = inline_rpos
         self.hops_have_classes = self.edge_classes is not None
-        return self
-
-    def listed_share(self) -> float:
-        """share of the edges that have shared neighbours (a list the walker's next step reads); cached"""
-        if self.edge_classes is None or self.n_edges == 0:
-            return 0.0
-        if self._listed_share is None or self._listed_share[0] is not self.edge_classes:
-            self._listed_share = (self.edge_classes,
-                                  float(((self.edge_classes & 0xffffff) != 0).float().mean()))
-        return self._listed_share[1]
-
-    def build_hops32(self, max_bytes: Optional[int] = None) -> "DeviceGraph":
-        """32-byte hop entries for the exact slots kernel (N2V_HOPS_WITH_SLOT): the hop entry of every edge followed
-        by the first 16 bytes of its wedge slot -- the list a walker needs at its next step is the list of the edge
-        it picks now, so it arrives with the hop gather.  Needs the slots kernel's hop table (inline return
-        positions) and the wedge slots; 32 bytes per edge."""
-        self.hops32 = None
-        if self.hops is None or self.wedge_slots is None or not self.hops_inline_rpos:
-            return self
-        if max_bytes is None:
-            max_bytes = torch.cuda.mem_get_info(self.device)[0] // 2
-        if 64 * self.n_edges > max_bytes:  # (the table and the temporary of the interleave)
-            return self
-        half = self.wedge_slots.view(torch.int32).view(self.n_edges, 8)[:, :4]
-        self.hops32 = torch.cat([self.hops, half], dim=1).contiguous()
         return self
 
     # Measured (profiles/r3x_time_hop8_*.log): with 0 - 11 % of the steps taking the escape the 8-byte

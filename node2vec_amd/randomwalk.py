@@ -71,8 +71,7 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
          stats: Optional[dict] = None, use_edge_classes: bool = True, use_hops: bool = True,
          use_wedges: bool = True, use_wedge_kernel: bool = True, use_hops8: bool = True,
          use_workspace: bool = False, use_wedge_slots: bool = True, use_ranked: Optional[bool] = None,
-         rank_ids: bool = False, use_weighted_lanes: Optional[bool] = None, use_row_sums: bool = True,
-         use_hops32: Optional[bool] = None):
+         rank_ids: bool = False, use_weighted_lanes: Optional[bool] = None, use_row_sums: bool = True):
     """Launch K2.  Returns (walks int32 [n_start*num_walks, walk_length+1], valid bool).
 
     mode "fast", and on weighted graphs mode "exact" with return_param == inout_param == 1
@@ -104,11 +103,7 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
     the same walks as the wave-per-walker kernel of n2v_walk, which use_weighted_lanes=False keeps.
     Values of p, q that are not dyadic: the row sums of the steps into rows of 1024 entries and more are computed
     once per (p, q) (graph.build_row_sums(): 8 bytes per edge, skipped when they do not fit) and read by the steps
-    that need them; use_row_sums=False has those steps add the row up themselves: same bits.
-    The exact slots kernel reads 32-byte hop entries -- the hop entry of an edge followed by the first half of its
-    wedge slot: the list of the NEXT step arrives with this step's hop gather (graph.build_hops32(), built on first
-    use where it fits; default on graphs without rows of 65 536 slots and more); use_hops32=False keeps the
-    16-byte entries and the slot gather: same bits."""
+    that need them; use_row_sums=False has those steps add the row up themselves: same bits."""
     L = _lib.load()
     _lib.require_gpu()
     if mode not in MODES:
@@ -197,19 +192,6 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
         if (graph.hops is None or (want_classes and not graph.hops_have_classes)
                 or (biased and mode == "exact" and graph.hops_inline_rpos != want_inline)):
             graph.build_hops(inline_rpos=want_inline)
-        # 32-byte hop entries for the exact slots kernel (the hop entry + the first half of the edge's slot)
-        # (default: graphs without rows of 65 536 slots and more on which a quarter of the edges or more have a list --
-        # cfg 4: half of them, + 3 - 9 % by (p, q) for 32 more bytes per edge; with wide rows + 1 %; cfg 5, where no
-        # edge has a list, - 0 - 4 %: profiles/r14a_time.log, r14f_time.log.  N2V_HOPS32=0|1 overrides.)
-        if use_hops32 is None:
-            env = os.environ.get("N2V_HOPS32")
-            use_hops32 = (env == "1") if env is not None else (
-                bool(want_inline) and graph.wedge_mode == 0 and graph.listed_share() >= 0.25)
-        hops32 = bool(use_hops32 and want_inline and mode == "exact" and graph.hops_inline_rpos
-                      and (graph.wedge_mode == 0 or graph.slots_folded))
-        if hops32 and graph.hops32 is None:
-            graph.build_hops32()
-        hops32 = hops32 and graph.hops32 is not None
     start_ids = start_ids.to(device=graph.device, dtype=torch.int32).contiguous()
     n_start = start_ids.numel()
     total = n_start * num_walks
@@ -248,10 +230,6 @@ def walk(graph: DeviceGraph, start_ids: torch.Tensor, num_walks: int, walk_lengt
         g.wedge_slots = 0
     if not use_row_sums:  # every row added up by the lane that needs its sum (tests: same bits)
         g.row_sums = 0
-    if (graph.unit_weights and use_hops and not uniform8 and not ranked and hops32 and g.hops and g.wedge_slots
-            and not (g.reserved & 3)):
-        g.hops = graph.hops32.data_ptr()
-        g.reserved2 |= 4  # N2V_HOPS_WITH_SLOT
     with torch.cuda.device(graph.device):
         ws_bytes = 0
         if use_workspace and n_start > 0:

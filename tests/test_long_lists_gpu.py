@@ -68,11 +68,6 @@ def test_walks_over_hub_to_hub_lists_equal_the_oracle(wide_from, n_common):
         a, av = rw.walk(g, start, 2, 16, p, q, 9)
         b, bv = rw.walk(g, start, 2, 16, p, q, 9, use_wedge_slots=False)
         assert torch.equal(av, bv) and torch.equal(a, b), (p, q)
-        # 32-byte hop entries (the first half of the edge's slot rides with its hop entry) and 16-byte ones
-        for h32 in (True, False):
-            c, cv = rw.walk(g, start, 2, 16, p, q, 9, use_hops32=h32)
-            assert torch.equal(av, cv) and torch.equal(a, c), (p, q, h32)
-        assert g.hops32 is not None and g.hops32.shape == (g.n_edges, 8)
         if (p, q) in ((3.0, 0.7), (0.7, 3.0)):
             # values that are not dyadic: the row sums of the steps into the hubs' rows were computed once
             # (n2v_edge_row_sums_build) -- the same walks with every such row added up by the lane that needs it,
